@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X phase-rotation hot path.
+
+Metric (BASELINE.json): mono-sample frames/s through the 4096-pt OLA
+phase-rotate, % of the HBM roofline at 1 GPU.
+
+Workload (BASELINE.json configs[1], "LV2 mono run(), 4096-pt OLA, 48 kHz"):
+the LV2 48 kHz filter (3072-tap windowed Hilbert FIR, latency 1792) re-blocked
+onto one 4096-point overlap-add FFT per 1024-frame hop, over a device-resident
+mono stream of 2^27 frames per GPU (512 MiB in + 512 MiB out, beyond the
+256 MiB Infinity Cache).  One "step" = one pass of the hot path over that
+stream = one kernel launch.  Inputs are resident in HBM before the timed
+region; outputs stay in HBM.
+
+  python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by torch.distributed.run, one rank per GPU: every rank runs an
+independent stream (the apply path has no exchange step: weak scaling, no
+collective); the 360-angle sweep sub-benchmark shards frame-blocks across ranks
+and MAX-all-reduces the peak table over RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames-log2", type=int, default=27, help="frames per GPU per step (2^k)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--sweep-seconds", type=float, default=3600.0, help="sweep: audio seconds (stereo 96 kHz)")
+    return ap.parse_args()
+
+
+def cpu_baseline(n_target_s=12.0):
+    """The oracle (CPU restatement of src/phaserotate.c run()) timed on this host:
+    LV2 mono 48 kHz, 1024-frame buffers, 1 thread.  A reported baseline only."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import orc  # checker / baseline leg only
+    rng = np.random.default_rng(1)
+    e = orc.Lv2Engine(48000, 1)
+    probe = (rng.random(1 << 16, dtype=np.float32) - 0.5)[None, :]
+    t0 = time.perf_counter()
+    e.run_stream(probe, 90.0, 1024)
+    dt = time.perf_counter() - t0
+    rate = probe.shape[1] / dt
+    n = int(min(max(rate * n_target_s, 1 << 17), 1 << 26)) // 1024 * 1024
+    x = (rng.random(n, dtype=np.float32) - 0.5)[None, :]
+    e = orc.Lv2Engine(48000, 1)
+    t0 = time.perf_counter()
+    e.run_stream(x, 90.0, 1024)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "oracle/prot_oracle.c orc_lv2_run (restated src/phaserotate.c run(), own radix-2 "
+                      "FFT in place of FFTW), LV2 mono 48 kHz, %d frames in 1024-frame buffers, %.1f s" % (n, dt),
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    from __graft_entry__ import load_package
+    pkg = load_package()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # launches go to a non-default torch stream so that torch events bracket them
+    ts = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(ts)
+    st = ts.cuda_stream
+
+    n = 1 << args.frames_log2
+    gen = torch.Generator(device=dev).manual_seed(0x9E3779B9 ^ rank)
+    x = torch.rand(n, generator=gen, device=dev, dtype=torch.float32) - 0.5  # uniform [-0.5, 0.5)
+    y = torch.empty_like(x)
+    th = -2.0 * np.pi * 90.0 / 360.0
+    rot = np.array([np.cos(th), np.sin(th)], np.float32)
+
+    def timed(engine, steps, warmup, n_frames):
+        def step():
+            engine.apply_dev(x.data_ptr(), n_frames, n_frames, y.data_ptr(), n_frames, n_frames, rot,
+                             pkg.F_STATELESS, st)
+        for _ in range(warmup):
+            step()
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        ev0.record(ts)
+        for _ in range(steps):
+            step()
+        ev1.record(ts)
+        barrier()
+        wall = time.perf_counter() - t0
+        kern_ms = ev0.elapsed_time(ev1) / steps  # one kernel per step on this stream
+        if world > 1:
+            t = torch.tensor([wall], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        return wall, kern_ms
+
+    eng = pkg.Engine(pkg.KIND_LV2, 48000, 1, device=local_rank)
+    wall, kern_ms = timed(eng, args.steps, args.warmup, n)
+    value = world * n * args.steps / wall
+    bytes_per_launch = 8.0 * n  # 4 B read + 4 B written per frame
+    achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "mono-sample frames/s through 4096-pt OLA phase-rotate",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "LV2 mono 48 kHz: 3072-tap Hilbert FIR, 4096-pt OLA, hop 1024, angle 90 deg, "
+                               "device-resident stream of 2^%d frames per GPU per step" % args.frames_log2,
+                   "fftlen": int(eng.info.fftlen), "hop": int(eng.info.hop), "firlen": int(eng.info.firlen),
+                   "latency": int(eng.info.latency), "frames_per_gpu": n, "streams_per_gpu": 1,
+                   "parallelism": "independent streams x%d" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "prot::ola4096_kernel<4,1>", "kernel_ms": kern_ms,
+                     "algorithmic_bytes_per_launch": bytes_per_launch},
+    }
+    eng.close()
+
+    if not args.no_extra:
+        # the CLI engine A (blksiz 2048: 2048-tap FIR, 4096-pt OLA, hop 2048) on the same stream
+        engA = pkg.Engine(pkg.KIND_CLI, 2048, 1, device=local_rank)
+        wallA, kmsA = timed(engA, args.steps, args.warmup, n)
+        out["also"] = {"workload": "CLI engine blksiz 2048: 2048-tap FIR, 4096-pt OLA, hop 2048",
+                       "value": world * n * args.steps / wallA, "unit": "frames/s",
+                       "roofline_frac": 8.0 * n / (kmsA * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": kmsA}
+        engA.close()
+
+    if not args.no_sweep:
+        out["sweep"] = bench_sweep(args, pkg, torch, dist, dev, st, world, rank, local_rank, barrier)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_sweep(args, pkg, torch, dist, dev, st, world, rank, local_rank, barrier):
+    """BASELINE config 4: 360-angle (-s 1) min-peak sweep of stereo 96 kHz audio,
+    blksiz 2048 (-f 2048, 4096-pt), frame-blocks sharded across the ranks with a
+    history halo, one RCCL MAX all-reduce of the [2][360] peak table.  Strong
+    scaling: the total amount of audio is fixed."""
+    from phaserotate_lv2_amd import sweep_dist
+    P, n_chn = 2048, 2
+    total = int(args.sweep_seconds * 96000) // P * P
+    plan = sweep_dist.plan_shards(total, P, world)
+    b0, b1 = plan[rank]
+    n = (b1 - b0) * P
+    eng = pkg.Engine(pkg.KIND_CLI, P, n_chn, device=local_rank)
+    H = int(eng.info.history)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = (torch.rand((n_chn, n), generator=gen, device=dev) - 0.5) * 0.9
+    if rank > 0:  # halo: the tail of the previous rank's shard (same seed -> same data)
+        pb0, pb1 = plan[rank - 1]
+        pg = torch.Generator(device=dev).manual_seed(1234 + rank - 1)
+        prev = (torch.rand((n_chn, (pb1 - pb0) * P), generator=pg, device=dev) - 0.5) * 0.9
+        halo = prev[:, -H:].contiguous()
+        del prev
+    peaks = torch.zeros((n_chn, 360), device=dev)
+    flags = (pkg.F_STREAM_START if rank == 0 else 0) | (pkg.F_STREAM_END if rank == world - 1 else 0)
+
+    def one_pass():
+        eng.reset()
+        peaks.zero_()
+        if rank > 0:
+            sweep_dist.prime_history(eng, halo, st)
+        eng.sweep_dev(x.data_ptr(), n, n, 0, 360, 1, -1, peaks.data_ptr(), flags, st)
+        if world > 1:
+            dist.all_reduce(peaks, op=dist.ReduceOp.MAX)
+
+    one_pass()
+    barrier()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one_pass()
+    barrier()
+    wall = (time.perf_counter() - t0) / reps
+    if world > 1:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    pk = peaks.cpu().numpy()
+    eng.close()
+    return {"metric": "channel-frames/s through the 360-angle min-peak sweep (cli -s 1 -f 2048)",
+            "value": total * n_chn / wall, "unit": "channel-frames/s", "seconds_of_audio": total / 96000.0,
+            "channels": n_chn, "rate": 96000, "ms": wall * 1e3, "scaling": "strong", "n_gpus": world,
+            "min_angle_index": [int(pk[c].argmin()) for c in range(n_chn)],
+            "collective": "all_reduce(MAX) float[2][360] over RCCL" if world > 1 else None}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,181 @@
+/*
+ * prot_hip.h -- C ABI of libprot_hip.so: the MI355X (gfx950) implementation
+ * of phaserotate.lv2's FFT/Hilbert phase-rotation hot path.
+ *
+ * Plain C: opaque handle, plain pointers and sizes, int status returns.  No
+ * HIP, C++ or torch types cross this boundary (a HIP stream is passed as
+ * void*; NULL = the engine's own stream).  Every entry point names the
+ * reference interface it replaces (file:line into x42/phaserotate.lv2).
+ *
+ * There is NO CPU fallback behind this ABI: if no gfx950 device/HIP runtime
+ * is usable, prot_engine_create fails with PROT_ENODEV and nothing else works.
+ */
+#ifndef PROT_HIP_H
+#define PROT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PROT_ABI_VERSION 1
+#define PROT_SUBSAMPLE 2                      /* cli/phase-rotate.cc:38 */
+#define PROT_MAXSAMPLE (180 * PROT_SUBSAMPLE) /* cli/phase-rotate.cc:39 */
+
+enum prot_status {
+	PROT_OK           = 0,
+	PROT_EINVAL       = 1, /* bad argument */
+	PROT_ENODEV       = 2, /* no usable gfx950 device / HIP runtime */
+	PROT_ENOMEM       = 3, /* host or device allocation failed */
+	PROT_EHIP         = 4, /* a HIP call failed (see prot_last_error) */
+	PROT_EUNSUPPORTED = 5  /* valid in the reference, not yet built here */
+};
+
+enum prot_kind {
+	/* PhaseRotateProc(blksiz): FIR = blksiz taps, fftlen = 2*blksiz,
+	 * hop = blksiz, dry delay blksiz/2 (cli/phase-rotate.cc:128-165, :214-225) */
+	PROT_KIND_CLI = 0,
+	/* instantiate(rate): FIR 3072/4096/8192 taps by rate, latency
+	 * parsiz + firlen/2 (src/phaserotate.c:278-297, :374-401).  The device
+	 * engine re-blocks the same LTI filter onto one 4096/8192-point OLA FFT
+	 * per hop instead of n_segm 512..2048-point partitions. */
+	PROT_KIND_LV2 = 1
+};
+
+typedef struct {
+	int32_t  kind;    /* enum prot_kind */
+	double   param;   /* CLI: blksiz (power of two 1024..32768); LV2: sample rate */
+	uint32_t n_chn;   /* channel-streams (LV2: 1..2 via the plugin; engine itself: 1..65535) */
+	int32_t  device;  /* HIP device ordinal */
+	uint32_t fftlen;  /* 0 = smallest supported (4096 or 8192) */
+	uint32_t flags;   /* reserved, 0 */
+} prot_config;
+
+typedef struct {
+	int32_t  kind;
+	uint32_t n_chn;
+	uint32_t fftlen;      /* device OLA FFT length */
+	uint32_t hop;         /* new frames per FFT block */
+	uint32_t firlen;      /* Hilbert FIR taps */
+	uint32_t latency;     /* LV2: latency port value; CLI: blksiz/2 (cli/phase-rotate.cc:963) */
+	uint32_t dry_delay;   /* frames the dry path is delayed by */
+	uint32_t conv_delay;  /* extra delay in front of the FIR */
+	uint32_t history;     /* input frames of state kept per channel */
+	uint32_t blksiz;      /* CLI: parsiz; LV2: reference parsiz (ramp granularity) */
+} prot_info;
+
+typedef struct prot_engine prot_engine;
+
+/* ---- lifetime ----------------------------------------------------------- */
+/* replaces PhaseRotateProc::PhaseRotateProc + PhaseRotate::PhaseRotate
+ * (cli/phase-rotate.cc:128-165, :314-335) and instantiate()'s DSP part
+ * (src/phaserotate.c:278-401).  Returns NULL on failure (as instantiate does,
+ * src/phaserotate.c:315-372); *status (optional) receives the reason. */
+prot_engine* prot_engine_create (const prot_config* cfg, int* status);
+/* ~PhaseRotateProc / ~PhaseRotate / cleanup() (src/phaserotate.c:179-223) */
+void prot_engine_destroy (prot_engine* e);
+/* PhaseRotate::reset (cli/phase-rotate.cc:355-366) / activate -> channel_reset
+ * (src/phaserotate.c:169-177, :511-520): clears input history, OLA state,
+ * peak table and block position.  The LV2 angle state is NOT reset (Q10). */
+int prot_engine_reset (prot_engine* e);
+int prot_engine_info (const prot_engine* e, prot_info* out);
+/* the time-domain FIR the engine convolves with (firlen floats); reference
+ * values: src/phaserotate.c:374-391, cli/phase-rotate.cc:144-161 */
+int prot_engine_fir (const prot_engine* e, float* fir_out);
+const char* prot_strerror (int status);
+/* thread-local text of the last failing HIP call, "" if none */
+const char* prot_last_error (void);
+int prot_abi_version (void);
+
+/* ---- device-resident streaming path (the roofline path) ----------------- */
+#define PROT_F_STATELESS 1u /* history = silence, engine state untouched */
+#define PROT_F_HILBERT   2u /* write the Hilbert branch u[t] only (rot ignored) */
+
+/* y[c][t] = ca_c * x[c][t - dry_delay] + sa_c * (fir * x[c])[t - conv_delay]
+ * for t in [0, n_out), x = [engine history | d_in[0..n_in) | silence].
+ * d_in/d_out are DEVICE pointers, planar, channel c at + c*stride (floats).
+ * rot is a HOST array [n_chn][2] = {ca, sa}.  Replaces the block body of
+ * process_channel (src/phaserotate.c:629-720, steady branch :710-717) and
+ * PhaseRotateProc::process (cli/phase-rotate.cc:181-232) for a whole run of
+ * blocks per launch.  Unless PROT_F_STATELESS, the last `history` input
+ * frames are kept for the next call.  Asynchronous on `stream`. */
+int prot_apply_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_in,
+                    float* d_out, int64_t out_stride, uint64_t n_out,
+                    const float* rot, uint32_t flags, void* stream);
+
+/* same with a per-sample rotation (angle ramp, src/phaserotate.c:673-709):
+ * d_rot is a DEVICE array [n_chn][n_out][2] = {ca, sa} per output frame. */
+int prot_apply_dev_ramp (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_in,
+                         float* d_out, int64_t out_stride, uint64_t n_out,
+                         const float* d_rot, uint32_t flags, void* stream);
+
+#define PROT_F_STREAM_START 4u /* first chunk of a file: block 0 gets the Q1 treatment */
+#define PROT_F_STREAM_END   8u /* last chunk: zero-pad the partial block and add the flush block */
+
+/* Rotated abs-max sweep of a device-resident planar stream (CLI engines only):
+ * for angle = ang_start; ; angle += ang_stride (loop bounds exactly as
+ * cli/phase-rotate.cc:409-428) d_peaks[c][a] = max(d_peaks[c][a], ...) over
+ * all blocks of this chunk, with the first-block (cli/phase-rotate.cc:418-419),
+ * angle-0 (:413-414), zero-pad and flush-block (:577-586) rules.  chn = -1:
+ * all channels (cli/phase-rotate.cc:434-435).  d_peaks is a DEVICE array
+ * [n_chn][PROT_MAXSAMPLE], max-accumulated (so it can be all-reduced with MAX
+ * across GPUs); NULL = the engine's own table (see prot_cli_peaks).
+ * Replaces PhaseRotate::analyze/thr_process + calc_rotated_peak +
+ * dsp_compute_peak (cli/phase-rotate.cc:98-121, :388-444, cli/dsp_peak_calc.h)
+ * and analyze_file's block loop (:565-587).  n_frames must be a multiple of
+ * blksiz unless PROT_F_STREAM_END is set. */
+int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_frames,
+                    int ang_start, int ang_end, int ang_stride, int chn,
+                    float* d_peaks, uint32_t flags, void* stream);
+
+/* block until everything queued on the engine's stream has finished */
+int prot_engine_sync (prot_engine* e);
+
+/* ---- host-buffer drop-ins (mirror the reference call for call) ---------- */
+/* run()'s DSP for n_samples frames of every channel: in/out are HOST planar
+ * port buffers (in == out allowed, src/phaserotate.c:779-785), angle_deg the
+ * control-port values.  Handles any n_samples, the block-rate angle ramp
+ * (:673-709) and the latency of `latency` frames.  Replaces
+ * run()/process_channel (src/phaserotate.c:538-725, :840-843).
+ * lvl (optional, [n_chn][2]) receives max|delayed in| is NOT computed here:
+ * meters stay in host C (see host/lv2_plugin.c). */
+int prot_lv2_run (prot_engine* e, const float* const* in, float* const* out,
+                  uint32_t n_samples, const float* angle_deg);
+
+/* PhaseRotate::apply (cli/phase-rotate.cc:467-485): one interleaved block of
+ * blksiz frames, processed in place; angles are half-degree indices, reduced
+ * (a + 360) % 360 exactly as :463 (Q9). */
+int prot_cli_apply (prot_engine* e, float* buf, const int* angles);
+
+/* PhaseRotate::analyze (cli/phase-rotate.cc:431-444): one interleaved block. */
+int prot_cli_analyze (prot_engine* e, const float* buf, int ang_start, int ang_end,
+                      int ang_stride, int chn, int start);
+
+/* analyze_file (cli/phase-rotate.cc:565-587) on an in-memory interleaved
+ * float file: whole-file device pass (upload, de-interleave, sweep). */
+int prot_cli_analyze_file (prot_engine* e, const float* data, uint64_t n_frames,
+                           int ang_start, int ang_end, int ang_stride, int chn);
+
+/* the apply loop of main() (cli/phase-rotate.cc:950-1003) on an in-memory
+ * interleaved float file: out receives n_frames frames with the blksiz/2
+ * latency removed and the tail flushed (done right for any length -- the
+ * reference's own tail handling is broken for partial blocks). */
+int prot_cli_apply_file (prot_engine* e, const float* data, uint64_t n_frames,
+                         const int* angles, float* out);
+
+/* PhaseRotate::peak / peak_all (cli/phase-rotate.cc:275-299) */
+float prot_cli_peak (prot_engine* e, int c, int a);
+float prot_cli_peak_all (prot_engine* e, int a);
+/* whole table, HOST array [n_chn][PROT_MAXSAMPLE] */
+int prot_cli_peaks (prot_engine* e, float* out);
+/* DEVICE pointer of the engine's own table (for an external MAX all-reduce) */
+float* prot_cli_peaks_dev (prot_engine* e);
+
+/* SinCosLut::sincos (cli/phase-rotate.cc:41-74) -- the table the device uses */
+void prot_sincos_lut (int a, float* s, float* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,289 @@
+"""phaserotate.lv2_amd -- host-side mirror of the reference's interfaces over the
+C ABI of libprot_hip.so (include/prot_hip.h).
+
+This package is plumbing for tests and bench.py: ctypes bindings that look like
+the reference's own classes (PhaseRotate of cli/phase-rotate.cc:251-485, the
+LV2 instance of src/phaserotate.c).  All arithmetic happens in the gfx950
+kernels behind the C ABI.  There is NO fallback: if the shared library is
+missing, or no HIP device is usable, importing / constructing fails loudly.
+
+The directory name contains a dot, so import it through
+``__graft_entry__.load_package()`` (module name ``phaserotate_lv2_amd``).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libprot_hip.so")
+
+MAXSAMPLE = 360          # cli/phase-rotate.cc:39
+SUBSAMPLE = 2            # cli/phase-rotate.cc:38
+KIND_CLI, KIND_LV2 = 0, 1
+F_STATELESS, F_HILBERT, F_STREAM_START, F_STREAM_END = 1, 2, 4, 8
+
+# every symbol include/prot_hip.h declares (tests check the .so exports them all)
+ABI_SYMBOLS = (
+    "prot_abi_version", "prot_strerror", "prot_last_error", "prot_sincos_lut",
+    "prot_engine_create", "prot_engine_destroy", "prot_engine_reset", "prot_engine_info",
+    "prot_engine_fir", "prot_engine_sync",
+    "prot_apply_dev", "prot_apply_dev_ramp", "prot_sweep_dev",
+    "prot_lv2_run", "prot_cli_apply", "prot_cli_analyze", "prot_cli_analyze_file",
+    "prot_cli_apply_file", "prot_cli_peak", "prot_cli_peak_all", "prot_cli_peaks",
+    "prot_cli_peaks_dev",
+)
+
+
+class ProtError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("param", C.c_double), ("n_chn", C.c_uint32),
+                ("device", C.c_int32), ("fftlen", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class Info(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n_chn", C.c_uint32), ("fftlen", C.c_uint32),
+                ("hop", C.c_uint32), ("firlen", C.c_uint32), ("latency", C.c_uint32),
+                ("dry_delay", C.c_uint32), ("conv_delay", C.c_uint32), ("history", C.c_uint32),
+                ("blksiz", C.c_uint32)]
+
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_lib = None
+
+
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64/libhsa-runtime64.  Two HIP
+    runtimes in one process cannot both own the GPU, and a torch stream or
+    tensor is only meaningful to the runtime that made it.  So when torch is
+    importable, load ITS libamdhip64 with RTLD_GLOBAL before libprot_hip.so:
+    the library's HIP calls then bind to that one runtime (global scope is
+    searched before a library's own DT_NEEDED), and torch allocations /
+    streams / RCCL and the engine share it.  Pure C hosts (the CLI, the LV2
+    plugin) never load torch and use /opt/rocm's runtime."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        return
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
+def load_library():
+    """dlopen libprot_hip.so; raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ProtError(
+            "HIP extension missing: %s not built (run __graft_entry__.build()); "
+            "there is no CPU fallback" % LIB_PATH)
+    _share_hip_runtime_with_torch()
+    lib = C.CDLL(LIB_PATH)
+    lib.prot_abi_version.restype = C.c_int
+    lib.prot_strerror.restype = C.c_char_p
+    lib.prot_strerror.argtypes = [C.c_int]
+    lib.prot_last_error.restype = C.c_char_p
+    lib.prot_sincos_lut.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.prot_engine_create.restype = C.c_void_p
+    lib.prot_engine_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_int)]
+    lib.prot_engine_destroy.argtypes = [C.c_void_p]
+    lib.prot_engine_reset.argtypes = [C.c_void_p]
+    lib.prot_engine_info.argtypes = [C.c_void_p, C.POINTER(Info)]
+    lib.prot_engine_fir.argtypes = [C.c_void_p, _f32p]
+    lib.prot_engine_sync.argtypes = [C.c_void_p]
+    lib.prot_apply_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p,
+                                   C.c_int64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.prot_apply_dev_ramp.argtypes = lib.prot_apply_dev.argtypes
+    lib.prot_sweep_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.prot_lv2_run.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                 C.c_uint32, _f32p]
+    lib.prot_cli_apply.argtypes = [C.c_void_p, _f32p, _i32p]
+    lib.prot_cli_analyze.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.prot_cli_analyze_file.argtypes = [C.c_void_p, _f32p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.prot_cli_apply_file.argtypes = [C.c_void_p, _f32p, C.c_uint64, _i32p, _f32p]
+    lib.prot_cli_peak.restype = C.c_float
+    lib.prot_cli_peak.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.prot_cli_peak_all.restype = C.c_float
+    lib.prot_cli_peak_all.argtypes = [C.c_void_p, C.c_int]
+    lib.prot_cli_peaks.argtypes = [C.c_void_p, _f32p]
+    lib.prot_cli_peaks_dev.restype = C.c_void_p
+    lib.prot_cli_peaks_dev.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        lib = load_library()
+        raise ProtError("%s failed: %s (%s)" % (
+            what, lib.prot_strerror(rc).decode(), lib.prot_last_error().decode()))
+
+
+def sincos_lut(a):
+    """SinCosLut::sincos (cli/phase-rotate.cc:57-67) as the device uses it."""
+    lib = load_library()
+    s, c = C.c_float(), C.c_float()
+    lib.prot_sincos_lut(a, C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+class Engine:
+    """Opaque prot_engine handle + the device-resident streaming API."""
+
+    def __init__(self, kind, param, n_chn=1, device=0, fftlen=0):
+        self._lib = load_library()
+        cfg = Config(kind, float(param), n_chn, device, fftlen, 0)
+        st = C.c_int(0)
+        self._h = self._lib.prot_engine_create(C.byref(cfg), C.byref(st))
+        if not self._h:
+            raise ProtError("prot_engine_create failed: %s (%s)" % (
+                self._lib.prot_strerror(st.value).decode(), self._lib.prot_last_error().decode()))
+        inf = Info()
+        _check(self._lib.prot_engine_info(self._h, C.byref(inf)), "prot_engine_info")
+        self.info = inf
+        self.n_chn = n_chn
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.prot_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        _check(self._lib.prot_engine_reset(self._h), "prot_engine_reset")
+
+    def sync(self):
+        _check(self._lib.prot_engine_sync(self._h), "prot_engine_sync")
+
+    def fir(self):
+        f = np.empty(self.info.firlen, np.float32)
+        _check(self._lib.prot_engine_fir(self._h, f), "prot_engine_fir")
+        return f
+
+    # -- device-resident path: arguments are raw device addresses (ints) ------
+    def apply_dev(self, d_in, in_stride, n_in, d_out, out_stride, n_out, rot, flags=0, stream=0):
+        rot = np.ascontiguousarray(rot, np.float32).reshape(-1)
+        assert rot.size == 2 * self.n_chn
+        _check(self._lib.prot_apply_dev(self._h, d_in, in_stride, n_in, d_out, out_stride, n_out,
+                                        rot.ctypes.data, flags, stream), "prot_apply_dev")
+
+    def hilbert_dev(self, d_in, in_stride, n_in, d_out, out_stride, n_out, flags=0, stream=0):
+        _check(self._lib.prot_apply_dev(self._h, d_in, in_stride, n_in, d_out, out_stride, n_out,
+                                        None, flags | F_HILBERT, stream), "prot_apply_dev")
+
+    def apply_dev_ramp(self, d_in, in_stride, n_in, d_out, out_stride, n_out, d_rot, flags=0, stream=0):
+        _check(self._lib.prot_apply_dev_ramp(self._h, d_in, in_stride, n_in, d_out, out_stride,
+                                             n_out, d_rot, flags, stream), "prot_apply_dev_ramp")
+
+    def sweep_dev(self, d_in, in_stride, n_frames, ang_start, ang_end, ang_stride, chn=-1,
+                  d_peaks=0, flags=0, stream=0):
+        _check(self._lib.prot_sweep_dev(self._h, d_in, in_stride, n_frames, ang_start, ang_end,
+                                        ang_stride, chn, d_peaks or None, flags, stream),
+               "prot_sweep_dev")
+
+    def peaks(self):
+        out = np.empty((self.n_chn, MAXSAMPLE), np.float32)
+        _check(self._lib.prot_cli_peaks(self._h, out.reshape(-1)), "prot_cli_peaks")
+        return out
+
+    def peaks_dev(self):
+        return self._lib.prot_cli_peaks_dev(self._h)
+
+
+class PhaseRotate(Engine):
+    """Mirror of class PhaseRotate (cli/phase-rotate.cc:251-485): same method
+    names, argument meaning and defaults; one PhaseRotateProc per channel is
+    implied by the engine (cli/phase-rotate.cc:768-777)."""
+
+    def __init__(self, blksiz, n_chn, device=0):
+        super().__init__(KIND_CLI, blksiz, n_chn, device)
+        self._blksiz = blksiz
+
+    def n_channels(self):
+        return self.n_chn
+
+    def blksiz(self):
+        return self._blksiz
+
+    def analyze(self, buf, ang_start=0, ang_end=180, ang_stride=1, chn=-1, start=False):
+        buf = np.ascontiguousarray(buf, np.float32).reshape(-1)
+        if buf.size != self._blksiz * self.n_chn:
+            raise ValueError("analyze wants one interleaved block of blksiz frames")
+        _check(self._lib.prot_cli_analyze(self._h, buf, ang_start, ang_end, ang_stride, chn, int(start)),
+               "prot_cli_analyze")
+
+    def apply(self, buf, angles):
+        buf = np.ascontiguousarray(buf, np.float32).reshape(-1).copy()
+        if buf.size != self._blksiz * self.n_chn:
+            raise ValueError("apply wants one interleaved block of blksiz frames")
+        ang = np.ascontiguousarray(angles, np.int32)
+        if ang.size != self.n_chn:
+            raise ValueError("one angle per channel")
+        _check(self._lib.prot_cli_apply(self._h, buf, ang), "prot_cli_apply")
+        return buf
+
+    def peak(self, c, a):
+        return self._lib.prot_cli_peak(self._h, c, a)
+
+    def peak_all(self, a):
+        return self._lib.prot_cli_peak_all(self._h, a)
+
+    # analyze_file / the apply loop of main(), on in-memory interleaved files
+    def analyze_file(self, data, ang_start, ang_end, ang_stride, chn=-1):
+        data = np.ascontiguousarray(data, np.float32).reshape(-1)
+        _check(self._lib.prot_cli_analyze_file(self._h, data, data.size // self.n_chn, ang_start,
+                                               ang_end, ang_stride, chn), "prot_cli_analyze_file")
+
+    def apply_file(self, data, angles):
+        data = np.ascontiguousarray(data, np.float32).reshape(-1)
+        out = np.zeros_like(data)
+        _check(self._lib.prot_cli_apply_file(self._h, data, data.size // self.n_chn,
+                                             np.ascontiguousarray(angles, np.int32), out),
+               "prot_cli_apply_file")
+        return out
+
+
+class Lv2Instance(Engine):
+    """Mirror of the LV2 instance (src/phaserotate.c): instantiate(rate) ->
+    activate() -> run(n_samples) with planar port buffers and the angle
+    control ports in degrees."""
+
+    def __init__(self, rate, n_chn=1, device=0):
+        super().__init__(KIND_LV2, rate, n_chn, device)
+
+    @property
+    def latency(self):
+        return self.info.latency
+
+    def activate(self):
+        self.reset()
+
+    def run(self, x, angle_deg):
+        x = np.ascontiguousarray(np.atleast_2d(x), np.float32)
+        assert x.shape[0] == self.n_chn
+        y = np.empty_like(x)
+        n = x.shape[1]
+        pin = (C.c_void_p * self.n_chn)(*[x[c].ctypes.data for c in range(self.n_chn)])
+        pout = (C.c_void_p * self.n_chn)(*[y[c].ctypes.data for c in range(self.n_chn)])
+        ang = np.ascontiguousarray(np.broadcast_to(np.asarray(angle_deg, np.float32), (self.n_chn,)))
+        _check(self._lib.prot_lv2_run(self._h, pin, pout, n, ang), "prot_lv2_run")
+        return y
+
+    def run_stream(self, x, angle_deg, bufsize):
+        x = np.ascontiguousarray(np.atleast_2d(x), np.float32)
+        out = np.empty_like(x)
+        for s in range(0, x.shape[1], bufsize):
+            out[:, s:s + bufsize] = self.run(x[:, s:s + bufsize], angle_deg)
+        return out

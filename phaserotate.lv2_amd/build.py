@@ -1,0 +1,103 @@
+"""Build recipes for the gfx950 shared library and the host-side C front ends.
+
+Everything is built IN-TREE (phaserotate.lv2_amd/lib/) so the artefacts travel
+with the repo snapshot to the GPU box.  hipcc cross-compiles for gfx950
+without a GPU present.
+"""
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+HOST = os.path.join(PKG, "host")
+LIBDIR = os.path.join(PKG, "lib")
+OBJDIR = os.path.join(PKG, "build")
+LIB = os.path.join(LIBDIR, "libprot_hip.so")
+ARCH = "gfx950"
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the gfx950 library cannot be built")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return r.stdout
+
+
+def build_lib(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> phaserotate.lv2_amd/lib/libprot_hip.so"""
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc = _hipcc()
+    hdrs = [os.path.join(CSRC, h) for h in ("prot_fft.h", "prot_kernels.h")] + \
+           [os.path.join(ROOT, "include", "prot_hip.h")]
+    common = [hipcc, "--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall",
+              "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")]
+    units = [
+        # device code: fast-math lets the compiler prune the zero-padded radix-16 inputs
+        ("prot_kernels.hip", ["-ffast-math"]),
+        # host logic mirrors the reference's float arithmetic: no fast-math
+        ("prot_capi.hip", []),
+    ]
+    objs = []
+    for src, extra in units:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        if force or _newer(o, [s] + hdrs):
+            out = _run(common + extra + ["-c", s, "-o", o])
+            if verbose and out:
+                print(out)
+        objs.append(o)
+    if force or _newer(LIB, objs):
+        _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"])
+    return LIB
+
+
+def build_host(force=False):
+    """gcc/g++ -> the LV2 plugin .so and the phase-rotate CLI (host C/C++ over the C ABI)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    built = []
+    inc = "-I" + os.path.join(ROOT, "include")
+    plug_src = os.path.join(HOST, "lv2_plugin.c")
+    if os.path.exists(plug_src):
+        plug = os.path.join(LIBDIR, "phaserotate.so")
+        if force or _newer(plug, [plug_src, LIB]):
+            _run(["gcc", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-std=gnu99", "-Wall", inc,
+                  "-I" + HOST, plug_src, "-o", plug, "-L" + LIBDIR, "-lprot_hip",
+                  "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"])
+        built.append(plug)
+    cli_src = os.path.join(HOST, "phase_rotate_cli.cc")
+    if os.path.exists(cli_src):
+        cli = os.path.join(LIBDIR, "phase-rotate")
+        deps = [cli_src, LIB] + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")]
+        if force or _newer(cli, deps):
+            _run(["g++", "-O2", "-std=c++11", "-Wall", inc, "-I" + HOST, cli_src, "-o", cli,
+                  "-L" + LIBDIR, "-lprot_hip", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"])
+        built.append(cli)
+    return built
+
+
+def build_all(force=False):
+    lib = build_lib(force)
+    return [lib] + build_host(force)
+
+
+if __name__ == "__main__":
+    import sys
+    for p in build_all(force="--force" in sys.argv):
+        print("built", p)

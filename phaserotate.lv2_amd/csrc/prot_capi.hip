@@ -1,0 +1,1062 @@
+// prot_capi.hip -- the C ABI of libprot_hip.so (include/prot_hip.h): engine
+// lifetime, FIR design, state keeping and launch logic around the gfx950
+// kernels.  Host-side only; compiled by hipcc together with the kernels.
+//
+// No CPU fallback lives here: without a usable HIP device every entry point
+// fails (PROT_ENODEV / NULL), loudly.
+#include "../../include/prot_hip.h"
+#include "prot_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int hip_fail (hipError_t e, const char* what)
+{
+	snprintf (g_err, sizeof (g_err), "%s: %s", what, hipGetErrorString (e));
+	return e == hipErrorOutOfMemory ? PROT_ENOMEM : PROT_EHIP;
+}
+
+#define HIP_TRY(expr)                                  \
+	do {                                               \
+		hipError_t _e = (expr);                        \
+		if (_e != hipSuccess) {                        \
+			return hip_fail (_e, #expr);               \
+		}                                              \
+	} while (0)
+
+// ---- SinCosLut (cli/phase-rotate.cc:41-74) --------------------------------
+float          g_lut[PROT_MAXSAMPLE * 2]; // {sin, cos}
+std::once_flag g_lut_once;
+
+void lut_init ()
+{
+	float mp = 2.f * M_PI / PROT_SUBSAMPLE / -360.0; // :46
+	for (int i = 0; i < PROT_MAXSAMPLE; ++i) {
+		sincosf (mp * i, &g_lut[2 * i], &g_lut[2 * i + 1]); // :52
+	}
+}
+
+// ---- FIR design -------------------------------------------------------------
+// Closed form of "spectrum j(-1)^k -> c2r_N -> x (0.5/N)(1 - cos 2 pi n/N)"
+// (src/phaserotate.c:374-391, cli/phase-rotate.cc:144-161), in double, rounded
+// to float once (the reference stores the FIR as float too).
+void fir_design (int n, std::vector<float>& fir)
+{
+	fir.assign (n, 0.f);
+	for (int i = 0; i < n; ++i) {
+		const int m = i - n / 2;
+		if (m & 1) {
+			const double a = M_PI * (double)m / (double)n;
+			fir[i] = (float)(-(2.0 / n) * (std::cos (a) / std::sin (a)) * 0.5 *
+			                 (1.0 - std::cos (2.0 * M_PI * (double)i / (double)n)));
+		}
+	}
+}
+
+// in-place complex FFT, double, radix-2 (host, init-time only)
+void fft_f64 (std::vector<double>& re, std::vector<double>& im)
+{
+	const size_t n = re.size ();
+	for (size_t i = 1, j = 0; i < n; ++i) {
+		size_t bit = n >> 1;
+		for (; j & bit; bit >>= 1) {
+			j ^= bit;
+		}
+		j ^= bit;
+		if (i < j) {
+			std::swap (re[i], re[j]);
+			std::swap (im[i], im[j]);
+		}
+	}
+	for (size_t len = 2; len <= n; len <<= 1) {
+		const size_t half = len / 2;
+		for (size_t k = 0; k < half; ++k) {
+			const double a = -2.0 * M_PI * (double)k / (double)len;
+			const double wr = std::cos (a), wi = std::sin (a);
+			for (size_t i = k; i < n; i += len) {
+				const size_t j  = i + half;
+				const double tr = re[j] * wr - im[j] * wi;
+				const double ti = re[j] * wi + im[j] * wr;
+				re[j] = re[i] - tr;
+				im[j] = im[i] - ti;
+				re[i] += tr;
+				im[i] += ti;
+			}
+		}
+	}
+}
+
+template <typename T>
+struct DevBuf {
+	T*     p   = nullptr;
+	size_t cap = 0; // elements
+	int    ensure (size_t n)
+	{
+		if (n <= cap) {
+			return PROT_OK;
+		}
+		if (p) {
+			(void)hipFree (p);
+			p   = nullptr;
+			cap = 0;
+		}
+		hipError_t e = hipMalloc ((void**)&p, n * sizeof (T));
+		if (e != hipSuccess) {
+			return hip_fail (e, "hipMalloc");
+		}
+		cap = n;
+		return PROT_OK;
+	}
+	void release ()
+	{
+		if (p) {
+			(void)hipFree (p);
+		}
+		p   = nullptr;
+		cap = 0;
+	}
+};
+
+template <typename T>
+struct PinBuf {
+	T*     p   = nullptr;
+	size_t cap = 0;
+	int    ensure (size_t n)
+	{
+		if (n <= cap) {
+			return PROT_OK;
+		}
+		if (p) {
+			(void)hipHostFree (p);
+			p   = nullptr;
+			cap = 0;
+		}
+		hipError_t e = hipHostMalloc ((void**)&p, n * sizeof (T), hipHostMallocDefault);
+		if (e != hipSuccess) {
+			return hip_fail (e, "hipHostMalloc");
+		}
+		cap = n;
+		return PROT_OK;
+	}
+	void release ()
+	{
+		if (p) {
+			(void)hipHostFree (p);
+		}
+		p   = nullptr;
+		cap = 0;
+	}
+};
+
+struct Lv2Chn {            // Channel angle state, src/phaserotate.c:52-55, :61
+	float               angle = 0.f, sa = 0.f, ca = 1.f;
+	uint32_t            offset = 0;
+	std::vector<float>  rotq;  // [parsiz][2] {ca, sa} of the block being delivered
+};
+
+} // namespace
+
+struct prot_engine {
+	prot_info   info {};
+	int         device  = 0;
+	int         hopseg  = 0;
+	hipStream_t stream  = nullptr;
+	std::vector<float> fir;
+
+	DevBuf<float2> d_H, d_tw;
+	DevBuf<float>  d_lut, d_rot, d_hist[2], d_peaks, d_in, d_out, d_u, d_inter, d_rot_s;
+	DevBuf<int>    d_angles;
+	PinBuf<float>  h_io;
+	int            hist_cur = 0;
+	uint64_t       pos      = 0; // frames consumed since reset (CLI stream position)
+	int            pairs_per_run_override = 0;
+
+	// LV2 block-rate angle state (src/phaserotate.c:563-571, :673-717)
+	float   interp_th = 0.f, interp_nm = 0.f;
+	std::vector<Lv2Chn> lv2;
+
+	std::vector<float> h_peaks; // host mirror for prot_cli_peak
+	bool               h_peaks_valid = false;
+};
+
+namespace {
+
+int zero_state (prot_engine* e)
+{
+	const size_t hn = (size_t)e->info.history * e->info.n_chn;
+	HIP_TRY (hipMemsetAsync (e->d_hist[0].p, 0, hn * sizeof (float), e->stream));
+	HIP_TRY (hipMemsetAsync (e->d_hist[1].p, 0, hn * sizeof (float), e->stream));
+	HIP_TRY (hipMemsetAsync (e->d_peaks.p, 0, (size_t)PROT_MAXSAMPLE * e->info.n_chn * sizeof (float), e->stream));
+	e->hist_cur      = 0;
+	e->pos           = 0;
+	e->h_peaks_valid = false;
+	return PROT_OK;
+}
+
+int pick_run_frames (const prot_engine* e, uint64_t n_out, int n_chn)
+{
+	const int     pair   = 2 * (int)e->info.hop;
+	const int64_t pairs  = (int64_t)((n_out + pair - 1) / pair);
+	int64_t       target = std::max<int64_t> (1, 2048 / std::max (1, n_chn));
+	int64_t       ppr    = (pairs + target - 1) / target;
+	if (e->pairs_per_run_override > 0) {
+		ppr = e->pairs_per_run_override;
+	}
+	ppr = std::min<int64_t> (std::max<int64_t> (ppr, 1), 4096);
+	return (int)(ppr * pair);
+}
+
+// core of prot_apply_dev / the Hilbert pass of the sweep
+int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_in, float* d_out,
+                int64_t out_stride, uint64_t n_out, const float* d_rot, const float* d_rot_s,
+                bool hilbert_only, bool stateless, int chn0, int n_chn, hipStream_t s)
+{
+	prot::OlaParams p {};
+	p.in           = d_in + (int64_t)chn0 * in_stride;
+	p.in_stride    = in_stride;
+	p.n_in         = (int64_t)n_in;
+	p.hist         = stateless ? nullptr : e->d_hist[e->hist_cur].p + (size_t)chn0 * e->info.history;
+	p.hist_len     = (int)e->info.history;
+	p.out          = d_out + (int64_t)chn0 * out_stride;
+	p.out_stride   = out_stride;
+	p.n_out        = (int64_t)n_out;
+	p.H            = e->d_H.p;
+	p.tw           = e->d_tw.p;
+	p.rot          = d_rot ? d_rot + 2 * chn0 : nullptr;
+	p.rot_s        = d_rot_s ? d_rot_s + 2 * (int64_t)chn0 * (int64_t)n_out : nullptr;
+	p.run_frames   = pick_run_frames (e, n_out, n_chn);
+	p.conv_delay   = (int)e->info.conv_delay;
+	p.dry_delay    = (int)e->info.dry_delay;
+	p.hilbert_only = hilbert_only ? 1 : 0;
+	hipError_t err = e->info.fftlen == 4096 ? prot::launch_ola4096 (p, e->hopseg, n_chn, s)
+	                                        : prot::launch_ola8192 (p, e->hopseg, n_chn, s);
+	if (err != hipSuccess) {
+		return hip_fail (err, "ola kernel launch");
+	}
+	return PROT_OK;
+}
+
+// advance the per-channel input history by one chunk (channels [chn0, chn0+n_chn))
+int hist_advance (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_in, int chn0,
+                  int n_chn, hipStream_t s)
+{
+	const int    H   = (int)e->info.history;
+	const int    cur = e->hist_cur;
+	const float* hin = e->d_hist[cur].p;
+	float*       hout = e->d_hist[1 - cur].p;
+	if (n_chn != (int)e->info.n_chn) {
+		// untouched channels keep their history: carry it over to the other buffer
+		HIP_TRY (hipMemcpyAsync (hout, hin, (size_t)H * e->info.n_chn * sizeof (float),
+		                         hipMemcpyDeviceToDevice, s));
+	}
+	hipError_t err = prot::launch_hist_update (d_in + (int64_t)chn0 * in_stride, in_stride, (int64_t)n_in,
+	                                           hin + (size_t)chn0 * H, hout + (size_t)chn0 * H, H, n_chn, s);
+	if (err != hipSuccess) {
+		return hip_fail (err, "hist update launch");
+	}
+	e->hist_cur = 1 - cur;
+	return PROT_OK;
+}
+
+hipStream_t pick_stream (prot_engine* e, void* stream)
+{
+	return stream ? (hipStream_t)stream : e->stream;
+}
+
+} // namespace
+
+extern "C" {
+
+int prot_abi_version (void)
+{
+	return PROT_ABI_VERSION;
+}
+
+const char* prot_strerror (int status)
+{
+	switch (status) {
+		case PROT_OK: return "ok";
+		case PROT_EINVAL: return "invalid argument";
+		case PROT_ENODEV: return "no usable gfx950 device / HIP runtime";
+		case PROT_ENOMEM: return "out of memory";
+		case PROT_EHIP: return "HIP call failed";
+		case PROT_EUNSUPPORTED: return "configuration not supported by this build";
+		default: return "unknown status";
+	}
+}
+
+const char* prot_last_error (void)
+{
+	return g_err;
+}
+
+void prot_sincos_lut (int a, float* s, float* c)
+{
+	std::call_once (g_lut_once, lut_init);
+	a  = ((a % PROT_MAXSAMPLE) + PROT_MAXSAMPLE) % PROT_MAXSAMPLE;
+	*s = g_lut[2 * a];
+	*c = g_lut[2 * a + 1];
+}
+
+prot_engine* prot_engine_create (const prot_config* cfg, int* status)
+{
+	int  st_dummy;
+	int& st = status ? *status : st_dummy;
+	st      = PROT_OK;
+	g_err[0] = 0;
+	if (!cfg || cfg->n_chn < 1 || cfg->n_chn > 65535) {
+		st = PROT_EINVAL;
+		return nullptr;
+	}
+	std::call_once (g_lut_once, lut_init);
+
+	prot_info inf {};
+	inf.kind  = cfg->kind;
+	inf.n_chn = cfg->n_chn;
+	if (cfg->kind == PROT_KIND_CLI) {
+		const uint32_t P = (uint32_t)cfg->param;
+		if (P < 1024 || P > 32768 || (P & (P - 1)) || (double)P != cfg->param) { // cli/phase-rotate.cc:673, :753-755
+			st = PROT_EINVAL;
+			return nullptr;
+		}
+		inf.blksiz     = P;
+		inf.firlen     = P;      // cli/phase-rotate.cc:154 (c2r of _parsiz points)
+		inf.dry_delay  = P / 2;  // :220  fin = &in[_firlen]
+		inf.conv_delay = 0;
+		inf.latency    = P / 2;  // :963
+	} else if (cfg->kind == PROT_KIND_LV2) {
+		const double rate = cfg->param;
+		if (!(rate > 0)) {
+			st = PROT_EINVAL;
+			return nullptr;
+		}
+		uint32_t fftlen, firlen; // src/phaserotate.c:278-289
+		if (rate < 64000) {
+			fftlen = 512;
+			firlen = 3072;
+		} else if (rate < 128000) {
+			fftlen = 1024;
+			firlen = 4096;
+		} else {
+			fftlen = 2048;
+			firlen = 8192;
+		}
+		inf.blksiz     = fftlen / 2;                // parsiz :292
+		inf.firlen     = firlen;
+		inf.conv_delay = inf.blksiz;                // block buffering latency
+		inf.latency    = inf.blksiz + firlen / 2;   // :297
+		inf.dry_delay  = inf.latency;
+	} else {
+		st = PROT_EINVAL;
+		return nullptr;
+	}
+	// device OLA geometry: smallest supported power-of-two FFT that holds
+	// firlen + hop - 1 with hop a multiple of fftlen/16
+	uint32_t F = cfg->fftlen ? cfg->fftlen : (inf.firlen <= 3072 ? 4096u : 8192u);
+	if (F != 4096) { // the 8192-point workgroup kernel is not built yet
+		st = PROT_EUNSUPPORTED;
+		snprintf (g_err, sizeof (g_err), "fftlen %u (firlen %u) not supported yet; only 4096", F, inf.firlen);
+		return nullptr;
+	}
+	if (inf.firlen > F - F / 4) {
+		st = PROT_EUNSUPPORTED;
+		return nullptr;
+	}
+	const uint32_t seg = F / 16;
+	int hopseg = (inf.firlen - 1 <= F / 2) ? 8 : 4;  // hop = F/2 or F/4
+	inf.fftlen  = F;
+	inf.hop     = hopseg * seg;
+	// history: conv delay + the halo the OLA run start reaches back, and the dry delay
+	uint32_t H = inf.conv_delay + (F / inf.hop) * inf.hop;
+	H          = std::max (H, inf.dry_delay);
+	inf.history = (H + 255) & ~255u;
+
+	int ndev = 0;
+	hipError_t he = hipGetDeviceCount (&ndev);
+	if (he != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+		st = PROT_ENODEV;
+		snprintf (g_err, sizeof (g_err), "hipGetDeviceCount: %s (count %d, wanted device %d)",
+		          hipGetErrorString (he), ndev, cfg->device);
+		return nullptr;
+	}
+	if (hipSetDevice (cfg->device) != hipSuccess) {
+		st = PROT_ENODEV;
+		return nullptr;
+	}
+
+	prot_engine* e = new (std::nothrow) prot_engine ();
+	if (!e) {
+		st = PROT_ENOMEM;
+		return nullptr;
+	}
+	e->info   = inf;
+	e->device = cfg->device;
+	e->hopseg = hopseg;
+	if (const char* o = getenv ("PROT_PAIRS_PER_RUN")) {
+		e->pairs_per_run_override = atoi (o);
+	}
+
+	auto fail = [&] (int code) -> prot_engine* {
+		st = code;
+		prot_engine_destroy (e);
+		return nullptr;
+	};
+
+	if (hipStreamCreateWithFlags (&e->stream, hipStreamNonBlocking) != hipSuccess) {
+		return fail (PROT_EHIP);
+	}
+
+	// FIR -> spectrum / F (the 1/fftlen of the OLA c2r, cli/phase-rotate.cc:142,
+	// src/phaserotate.c:393, folded into the table)
+	fir_design ((int)inf.firlen, e->fir);
+	std::vector<double> re (F, 0.0), im (F, 0.0);
+	for (uint32_t i = 0; i < inf.firlen; ++i) {
+		re[i] = e->fir[i];
+	}
+	fft_f64 (re, im);
+	std::vector<float2> H_h (F), tw_h (F);
+	for (uint32_t k = 0; k < F; ++k) {
+		H_h[k] = make_float2 ((float)(re[k] / F), (float)(im[k] / F));
+		const double a = -2.0 * M_PI * (double)k / (double)F;
+		tw_h[k] = make_float2 ((float)std::cos (a), (float)std::sin (a));
+	}
+	const size_t hn = (size_t)inf.history * inf.n_chn;
+	int rc;
+	if ((rc = e->d_H.ensure (F)) || (rc = e->d_tw.ensure (F)) || (rc = e->d_lut.ensure (PROT_MAXSAMPLE * 2)) ||
+	    (rc = e->d_rot.ensure (2 * (size_t)inf.n_chn)) || (rc = e->d_hist[0].ensure (hn)) ||
+	    (rc = e->d_hist[1].ensure (hn)) || (rc = e->d_peaks.ensure ((size_t)PROT_MAXSAMPLE * inf.n_chn)) ||
+	    (rc = e->d_angles.ensure (PROT_MAXSAMPLE + 8))) {
+		return fail (rc);
+	}
+	if (hipMemcpy (e->d_H.p, H_h.data (), F * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemcpy (e->d_tw.p, tw_h.data (), F * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemcpy (e->d_lut.p, g_lut, sizeof (g_lut), hipMemcpyHostToDevice) != hipSuccess) {
+		return fail (PROT_EHIP);
+	}
+	if (zero_state (e) != PROT_OK || hipStreamSynchronize (e->stream) != hipSuccess) {
+		return fail (PROT_EHIP);
+	}
+
+	if (inf.kind == PROT_KIND_LV2) {
+		e->interp_th = inf.blksiz * 1e-6f; // src/phaserotate.c:295
+		e->interp_nm = 1.f / inf.blksiz;   // :296
+		e->lv2.resize (inf.n_chn);
+		for (auto& c : e->lv2) {
+			c.rotq.assign ((size_t)inf.blksiz * 2, 0.f);
+			for (uint32_t i = 0; i < inf.blksiz; ++i) {
+				c.rotq[2 * i] = 1.f; // cos 0
+			}
+		}
+	}
+	e->h_peaks.assign ((size_t)PROT_MAXSAMPLE * inf.n_chn, 0.f);
+	return e;
+}
+
+void prot_engine_destroy (prot_engine* e)
+{
+	if (!e) {
+		return;
+	}
+	(void)hipSetDevice (e->device);
+	if (e->stream) {
+		(void)hipStreamSynchronize (e->stream);
+	}
+	e->d_H.release ();
+	e->d_tw.release ();
+	e->d_lut.release ();
+	e->d_rot.release ();
+	e->d_hist[0].release ();
+	e->d_hist[1].release ();
+	e->d_peaks.release ();
+	e->d_in.release ();
+	e->d_out.release ();
+	e->d_u.release ();
+	e->d_inter.release ();
+	e->d_rot_s.release ();
+	e->d_angles.release ();
+	e->h_io.release ();
+	if (e->stream) {
+		(void)hipStreamDestroy (e->stream);
+	}
+	delete e;
+}
+
+int prot_engine_reset (prot_engine* e)
+{
+	if (!e) {
+		return PROT_EINVAL;
+	}
+	HIP_TRY (hipSetDevice (e->device));
+	int rc = zero_state (e);
+	if (rc) {
+		return rc;
+	}
+	for (auto& c : e->lv2) { // channel_reset: offset = 0, buf_out = 0 (angle state kept, Q10)
+		c.offset = 0;
+	}
+	HIP_TRY (hipStreamSynchronize (e->stream));
+	return PROT_OK;
+}
+
+int prot_engine_info (const prot_engine* e, prot_info* out)
+{
+	if (!e || !out) {
+		return PROT_EINVAL;
+	}
+	*out = e->info;
+	return PROT_OK;
+}
+
+int prot_engine_fir (const prot_engine* e, float* fir_out)
+{
+	if (!e || !fir_out) {
+		return PROT_EINVAL;
+	}
+	memcpy (fir_out, e->fir.data (), e->fir.size () * sizeof (float));
+	return PROT_OK;
+}
+
+int prot_engine_sync (prot_engine* e)
+{
+	if (!e) {
+		return PROT_EINVAL;
+	}
+	HIP_TRY (hipSetDevice (e->device));
+	HIP_TRY (hipStreamSynchronize (e->stream));
+	return PROT_OK;
+}
+
+// ---------------------------------------------------------------- device API
+int prot_apply_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_in, float* d_out,
+                    int64_t out_stride, uint64_t n_out, const float* rot, uint32_t flags, void* stream)
+{
+	if (!e || !d_in || !d_out || (!rot && !(flags & PROT_F_HILBERT))) {
+		return PROT_EINVAL;
+	}
+	HIP_TRY (hipSetDevice (e->device));
+	hipStream_t s = pick_stream (e, stream);
+	const int   nc = (int)e->info.n_chn;
+	if (rot) {
+		HIP_TRY (hipMemcpyAsync (e->d_rot.p, rot, 2 * (size_t)nc * sizeof (float), hipMemcpyHostToDevice, s));
+	}
+	const bool stateless = flags & PROT_F_STATELESS;
+	int rc = ola_launch (e, d_in, in_stride, n_in, d_out, out_stride, n_out, e->d_rot.p, nullptr,
+	                     flags & PROT_F_HILBERT, stateless, 0, nc, s);
+	if (rc) {
+		return rc;
+	}
+	if (!stateless) {
+		rc = hist_advance (e, d_in, in_stride, n_in, 0, nc, s);
+		e->pos += n_in;
+	}
+	return rc;
+}
+
+int prot_apply_dev_ramp (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_in, float* d_out,
+                         int64_t out_stride, uint64_t n_out, const float* d_rot, uint32_t flags, void* stream)
+{
+	if (!e || !d_in || !d_out || !d_rot) {
+		return PROT_EINVAL;
+	}
+	HIP_TRY (hipSetDevice (e->device));
+	hipStream_t s         = pick_stream (e, stream);
+	const int   nc        = (int)e->info.n_chn;
+	const bool  stateless = flags & PROT_F_STATELESS;
+	int rc = ola_launch (e, d_in, in_stride, n_in, d_out, out_stride, n_out, nullptr, d_rot, false, stateless, 0, nc, s);
+	if (rc) {
+		return rc;
+	}
+	if (!stateless) {
+		rc = hist_advance (e, d_in, in_stride, n_in, 0, nc, s);
+		e->pos += n_in;
+	}
+	return rc;
+}
+
+int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_frames, int ang_start,
+                    int ang_end, int ang_stride, int chn, float* d_peaks, uint32_t flags, void* stream)
+{
+	if (!e || !d_in || e->info.kind != PROT_KIND_CLI || ang_stride < 1 || chn >= (int)e->info.n_chn) {
+		return PROT_EINVAL;
+	}
+	const uint32_t P   = e->info.blksiz;
+	const bool     end = flags & PROT_F_STREAM_END;
+	const bool     beg = flags & PROT_F_STREAM_START;
+	if (!end && (n_frames % P) != 0) {
+		return PROT_EINVAL;
+	}
+	HIP_TRY (hipSetDevice (e->device));
+	hipStream_t s   = pick_stream (e, stream);
+	const int   c0  = chn < 0 ? 0 : chn;                       // cli/phase-rotate.cc:434-435
+	const int   nc  = chn < 0 ? (int)e->info.n_chn : 1;
+	float*      pk  = d_peaks ? d_peaks : e->d_peaks.p;
+	if (!d_peaks) {
+		e->h_peaks_valid = false;
+	}
+
+	// blocks of this chunk: data blocks (last one zero-padded, :577-580) + flush block (:585-586)
+	const uint64_t nb    = (n_frames + P - 1) / P + (end ? 1 : 0);
+	const uint64_t n_out = nb * P;
+	if (n_out == 0) {
+		return PROT_OK;
+	}
+
+	// angle list with the loop bounds of cli/phase-rotate.cc:409-428
+	int  lut_idx[PROT_MAXSAMPLE + 8];
+	int  n_ang = 0;
+	bool raw0  = false;
+	for (int angle = ang_start; angle <= ang_end;) {
+		const int a = ((angle % PROT_MAXSAMPLE) + PROT_MAXSAMPLE) % PROT_MAXSAMPLE; // (angle + MAXSAMPLE) % MAXSAMPLE for angle > -360
+		if (angle == 0) {
+			raw0 = true; // :413-414 peak of the un-delayed block
+		} else if (n_ang < PROT_MAXSAMPLE) {
+			lut_idx[n_ang++] = a;
+		}
+		angle += ang_stride;
+		if (angle >= ang_end) {
+			break;
+		}
+	}
+
+	// 1. Hilbert branch u[t], t in [0, n_out)
+	const size_t ustride = (size_t)((n_out + 255) & ~(uint64_t)255);
+	int rc = e->d_u.ensure (ustride * e->info.n_chn);
+	if (rc) {
+		return rc;
+	}
+	const float* hist_old = e->d_hist[e->hist_cur].p; // stays intact: history is double-buffered
+	rc = ola_launch (e, d_in, in_stride, n_frames, e->d_u.p, (int64_t)ustride, n_out, nullptr, nullptr, true,
+	                 false, c0, nc, s);
+	if (rc) {
+		return rc;
+	}
+	// 2. rotated peaks
+	if (n_ang > 0) {
+		HIP_TRY (hipMemcpyAsync (e->d_angles.p, lut_idx, n_ang * sizeof (int), hipMemcpyHostToDevice, s));
+		prot::SweepParams sp {};
+		sp.x        = d_in;
+		sp.x_stride = in_stride;
+		sp.n_x      = (int64_t)n_frames;
+		sp.hist     = hist_old;
+		sp.hist_len = (int)e->info.history;
+		sp.u        = e->d_u.p;
+		sp.u_stride = (int64_t)ustride;
+		sp.t_begin  = beg ? P / 2 : 0;               // :418-419: first block looks at hil[firlen..parsiz) only
+		sp.t_end    = (int64_t)n_out;
+		sp.t_abs0   = (int64_t)e->pos;
+		sp.dry_from = beg ? (int64_t)e->pos + P : 0; // ... paired with the (silent) previous block
+		sp.delay    = (int)P / 2;
+		sp.angles   = e->d_angles.p;
+		sp.n_angles = n_ang;
+		sp.lut      = e->d_lut.p;
+		sp.peaks    = pk;
+		sp.chn0     = c0;
+		hipError_t err = prot::launch_sweep (sp, nc, s);
+		if (err != hipSuccess) {
+			return hip_fail (err, "sweep kernel launch");
+		}
+	}
+	// 3. angle 0: raw peak of the (un-delayed) blocks
+	if (raw0) {
+		hipError_t err = prot::launch_absmax (d_in, in_stride, (int64_t)n_frames, pk, 0, c0, nc, s);
+		if (err != hipSuccess) {
+			return hip_fail (err, "absmax kernel launch");
+		}
+	}
+	// 4. state: the reference has consumed nb blocks (zero padding included)
+	rc = hist_advance (e, d_in, in_stride, n_frames, c0, nc, s);
+	if (rc) {
+		return rc;
+	}
+	if (n_out > n_frames) {
+		// padding/flush frames are silence that also entered the history
+		const uint64_t extra = n_out - n_frames;
+		// shift history by `extra` frames of silence
+		const int    H    = (int)e->info.history;
+		const int    cur  = e->hist_cur;
+		const float* hin  = e->d_hist[cur].p;
+		float*       hout = e->d_hist[1 - cur].p;
+		if (nc != (int)e->info.n_chn) {
+			HIP_TRY (hipMemcpyAsync (hout, hin, (size_t)H * e->info.n_chn * sizeof (float), hipMemcpyDeviceToDevice, s));
+		}
+		for (int c = c0; c < c0 + nc; ++c) {
+			const uint64_t keep = extra >= (uint64_t)H ? 0 : (uint64_t)H - extra;
+			if (keep) {
+				HIP_TRY (hipMemcpyAsync (hout + (size_t)c * H, hin + (size_t)c * H + (H - keep), keep * sizeof (float),
+				                         hipMemcpyDeviceToDevice, s));
+			}
+			HIP_TRY (hipMemsetAsync (hout + (size_t)c * H + keep, 0, ((size_t)H - keep) * sizeof (float), s));
+		}
+		e->hist_cur = 1 - cur;
+	}
+	e->pos += n_out;
+	return PROT_OK;
+}
+
+float* prot_cli_peaks_dev (prot_engine* e)
+{
+	return e ? e->d_peaks.p : nullptr;
+}
+
+int prot_cli_peaks (prot_engine* e, float* out)
+{
+	if (!e || !out) {
+		return PROT_EINVAL;
+	}
+	HIP_TRY (hipSetDevice (e->device));
+	HIP_TRY (hipStreamSynchronize (e->stream));
+	HIP_TRY (hipMemcpy (out, e->d_peaks.p, (size_t)PROT_MAXSAMPLE * e->info.n_chn * sizeof (float), hipMemcpyDeviceToHost));
+	return PROT_OK;
+}
+
+static int refresh_peaks (prot_engine* e)
+{
+	if (e->h_peaks_valid) {
+		return PROT_OK;
+	}
+	int rc = prot_cli_peaks (e, e->h_peaks.data ());
+	if (rc == PROT_OK) {
+		e->h_peaks_valid = true;
+	}
+	return rc;
+}
+
+float prot_cli_peak_all (prot_engine* e, int a)
+{
+	if (!e || refresh_peaks (e)) {
+		return NAN;
+	}
+	float p = 0; // cli/phase-rotate.cc:287-299
+	if (a < 0) {
+		a += PROT_MAXSAMPLE;
+	}
+	a = a % PROT_MAXSAMPLE;
+	for (uint32_t c = 0; c < e->info.n_chn; ++c) {
+		p = std::max (p, e->h_peaks[(size_t)c * PROT_MAXSAMPLE + a]);
+	}
+	return p;
+}
+
+float prot_cli_peak (prot_engine* e, int c, int a)
+{
+	if (!e) {
+		return NAN;
+	}
+	if (c < 0 || (uint32_t)c >= e->info.n_chn) { // cli/phase-rotate.cc:278 (its '>' would read out of bounds at c == n_chn)
+		return prot_cli_peak_all (e, a);
+	}
+	if (refresh_peaks (e)) {
+		return NAN;
+	}
+	if (a < 0) {
+		a += PROT_MAXSAMPLE;
+	}
+	return e->h_peaks[(size_t)c * PROT_MAXSAMPLE + (a % PROT_MAXSAMPLE)];
+}
+
+// ------------------------------------------------------------ host drop-ins
+int prot_lv2_run (prot_engine* e, const float* const* in, float* const* out, uint32_t n_samples,
+                  const float* angle_deg)
+{
+	if (!e || !in || !out || !angle_deg || e->info.kind != PROT_KIND_LV2) {
+		return PROT_EINVAL;
+	}
+	if (n_samples == 0) {
+		return PROT_OK;
+	}
+	HIP_TRY (hipSetDevice (e->device));
+	const uint32_t nc = e->info.n_chn;
+	const uint32_t P  = e->info.blksiz;
+	const size_t   n  = n_samples;
+	hipStream_t    s  = e->stream;
+
+	int rc;
+	if ((rc = e->h_io.ensure (n * nc * 4)) || (rc = e->d_in.ensure (n * nc)) || (rc = e->d_out.ensure (n * nc)) ||
+	    (rc = e->d_rot_s.ensure (2 * n * nc))) {
+		return rc;
+	}
+	float* h_in  = e->h_io.p;
+	float* h_out = e->h_io.p + n * nc;
+	float* h_rot = e->h_io.p + 2 * n * nc; // [nc][n][2]
+
+	// block-rate angle state machine, exactly process_channel's
+	// (src/phaserotate.c:563-571 target, :673-709 ramp, :710-717 steady)
+	bool steady = true;
+	for (uint32_t c = 0; c < nc; ++c) {
+		memcpy (h_in + c * n, in[c], n * sizeof (float));
+		Lv2Chn& ch = e->lv2[c];
+		float target_angle = angle_deg[c] / -360.f;
+		if (target_angle < -.5f) {
+			target_angle = -.5f;
+		}
+		if (target_angle > 0.5f) {
+			target_angle = 0.5f;
+		}
+		float*   r      = h_rot + 2 * n * c;
+		uint32_t remain = n_samples, done = 0;
+		while (remain > 0) {
+			uint32_t ns = std::min (P - ch.offset, remain);
+			memcpy (r + 2 * done, &ch.rotq[2 * ch.offset], 2 * ns * sizeof (float));
+			done += ns;
+			remain -= ns;
+			ch.offset += ns;
+			if (ch.offset == P) {
+				ch.offset   = 0;
+				float angle = ch.angle;
+				if (target_angle != angle) {
+					float da = (target_angle - angle);
+					if (fabs (da) > 0.5) {
+						if (da < 0) {
+							da += 1.f;
+						} else {
+							da -= 1.f;
+						}
+					}
+					da *= e->interp_nm;
+					int         final_ = 0;
+					const float thresh = e->interp_th;
+					if (da > thresh) {
+						da = thresh;
+					} else if (da < -thresh) {
+						da = -thresh;
+					} else {
+						final_ = 1;
+					}
+					static const float twopi = 2 * M_PI; // sin_cos, src/phaserotate.c:122-133
+					for (uint32_t i = 0; i < P; ++i) {
+						float ca, sa;
+						sincosf (angle * twopi, &sa, &ca);
+						ch.rotq[2 * i]     = ca;
+						ch.rotq[2 * i + 1] = sa;
+						angle += da;
+					}
+					if (final_) {
+						angle = target_angle;
+					}
+					if (angle == target_angle) {
+						sincosf (angle * twopi, &ch.sa, &ch.ca);
+					}
+				} else {
+					for (uint32_t i = 0; i < P; ++i) {
+						ch.rotq[2 * i]     = ch.ca;
+						ch.rotq[2 * i + 1] = ch.sa;
+					}
+				}
+				ch.angle = angle;
+			}
+		}
+		for (uint32_t i = 1; i < n_samples && steady; ++i) {
+			steady = (r[2 * i] == r[0]) && (r[2 * i + 1] == r[1]);
+		}
+	}
+
+	HIP_TRY (hipMemcpyAsync (e->d_in.p, h_in, n * nc * sizeof (float), hipMemcpyHostToDevice, s));
+	if (steady) {
+		float rot[2 * 64];
+		std::vector<float> rot_big;
+		float* rp = rot;
+		if (nc > 64) {
+			rot_big.resize (2 * (size_t)nc);
+			rp = rot_big.data ();
+		}
+		for (uint32_t c = 0; c < nc; ++c) {
+			rp[2 * c]     = h_rot[2 * n * c];
+			rp[2 * c + 1] = h_rot[2 * n * c + 1];
+		}
+		rc = prot_apply_dev (e, e->d_in.p, (int64_t)n, n, e->d_out.p, (int64_t)n, n, rp, 0, s);
+	} else {
+		HIP_TRY (hipMemcpyAsync (e->d_rot_s.p, h_rot, 2 * n * nc * sizeof (float), hipMemcpyHostToDevice, s));
+		rc = prot_apply_dev_ramp (e, e->d_in.p, (int64_t)n, n, e->d_out.p, (int64_t)n, n, e->d_rot_s.p, 0, s);
+	}
+	if (rc) {
+		return rc;
+	}
+	HIP_TRY (hipMemcpyAsync (h_out, e->d_out.p, n * nc * sizeof (float), hipMemcpyDeviceToHost, s));
+	HIP_TRY (hipStreamSynchronize (s));
+	for (uint32_t c = 0; c < nc; ++c) {
+		memcpy (out[c], h_out + c * n, n * sizeof (float));
+	}
+	return PROT_OK;
+}
+
+int prot_cli_apply (prot_engine* e, float* buf, const int* angles)
+{
+	if (!e || !buf || !angles || e->info.kind != PROT_KIND_CLI) {
+		return PROT_EINVAL;
+	}
+	HIP_TRY (hipSetDevice (e->device));
+	const uint32_t nc = e->info.n_chn;
+	const size_t   P  = e->info.blksiz;
+	hipStream_t    s  = e->stream;
+	int rc;
+	if ((rc = e->d_inter.ensure (P * nc)) || (rc = e->d_in.ensure (P * nc)) || (rc = e->d_out.ensure (P * nc))) {
+		return rc;
+	}
+	std::vector<float> rot (2 * (size_t)nc);
+	for (uint32_t c = 0; c < nc; ++c) {
+		const int a = ((angles[c] % PROT_MAXSAMPLE) + PROT_MAXSAMPLE) % PROT_MAXSAMPLE; // :463
+		rot[2 * c]     = g_lut[2 * a + 1]; // ca
+		rot[2 * c + 1] = g_lut[2 * a];     // sa
+	}
+	HIP_TRY (hipMemcpyAsync (e->d_inter.p, buf, P * nc * sizeof (float), hipMemcpyHostToDevice, s));
+	hipError_t err = prot::launch_deinterleave (e->d_inter.p, e->d_in.p, (int64_t)P, (int64_t)P, (int)nc, s);
+	if (err != hipSuccess) {
+		return hip_fail (err, "deinterleave launch");
+	}
+	rc = prot_apply_dev (e, e->d_in.p, (int64_t)P, P, e->d_out.p, (int64_t)P, P, rot.data (), 0, s);
+	if (rc) {
+		return rc;
+	}
+	err = prot::launch_interleave (e->d_out.p, (int64_t)P, e->d_inter.p, (int64_t)P, (int)nc, s);
+	if (err != hipSuccess) {
+		return hip_fail (err, "interleave launch");
+	}
+	HIP_TRY (hipMemcpyAsync (buf, e->d_inter.p, P * nc * sizeof (float), hipMemcpyDeviceToHost, s));
+	HIP_TRY (hipStreamSynchronize (s));
+	return PROT_OK;
+}
+
+int prot_cli_analyze (prot_engine* e, const float* buf, int ang_start, int ang_end, int ang_stride, int chn,
+                      int start)
+{
+	if (!e || !buf || e->info.kind != PROT_KIND_CLI) {
+		return PROT_EINVAL;
+	}
+	HIP_TRY (hipSetDevice (e->device));
+	const uint32_t nc = e->info.n_chn;
+	const size_t   P  = e->info.blksiz;
+	hipStream_t    s  = e->stream;
+	int rc;
+	if ((rc = e->d_inter.ensure (P * nc)) || (rc = e->d_in.ensure (P * nc))) {
+		return rc;
+	}
+	HIP_TRY (hipMemcpyAsync (e->d_inter.p, buf, P * nc * sizeof (float), hipMemcpyHostToDevice, s));
+	hipError_t err = prot::launch_deinterleave (e->d_inter.p, e->d_in.p, (int64_t)P, (int64_t)P, (int)nc, s);
+	if (err != hipSuccess) {
+		return hip_fail (err, "deinterleave launch");
+	}
+	rc = prot_sweep_dev (e, e->d_in.p, (int64_t)P, P, ang_start, ang_end, ang_stride, chn, nullptr,
+	                     start ? PROT_F_STREAM_START : 0, s);
+	if (rc) {
+		return rc;
+	}
+	HIP_TRY (hipStreamSynchronize (s));
+	return PROT_OK;
+}
+
+int prot_cli_analyze_file (prot_engine* e, const float* data, uint64_t n_frames, int ang_start, int ang_end,
+                           int ang_stride, int chn)
+{
+	if (!e || (!data && n_frames) || e->info.kind != PROT_KIND_CLI) {
+		return PROT_EINVAL;
+	}
+	HIP_TRY (hipSetDevice (e->device));
+	const uint32_t nc = e->info.n_chn;
+	const uint64_t P  = e->info.blksiz;
+	hipStream_t    s  = e->stream;
+	// chunk: whole blocks, <= 2^22 frames per channel (<= 16 MiB per channel per buffer)
+	const uint64_t chunk = std::max<uint64_t> (P, ((uint64_t)1 << 22) / P * P);
+	int rc;
+	const uint64_t cap = std::min<uint64_t> (chunk, std::max<uint64_t> (n_frames, 1));
+	if ((rc = e->d_inter.ensure (cap * nc)) || (rc = e->d_in.ensure (cap * nc))) {
+		return rc;
+	}
+	uint64_t pos   = 0;
+	bool     first = true;
+	do {
+		const uint64_t n    = std::min (chunk, n_frames - pos);
+		const bool     last = pos + n >= n_frames;
+		if (n) {
+			HIP_TRY (hipMemcpyAsync (e->d_inter.p, data + pos * nc, n * nc * sizeof (float), hipMemcpyHostToDevice, s));
+			hipError_t err = prot::launch_deinterleave (e->d_inter.p, e->d_in.p, (int64_t)cap, (int64_t)n, (int)nc, s);
+			if (err != hipSuccess) {
+				return hip_fail (err, "deinterleave launch");
+			}
+		}
+		// an empty file never sets `start` (cli/phase-rotate.cc:573-576)
+		uint32_t fl = (first && n ? PROT_F_STREAM_START : 0) | (last ? PROT_F_STREAM_END : 0);
+		rc = prot_sweep_dev (e, e->d_in.p, (int64_t)cap, n, ang_start, ang_end, ang_stride, chn, nullptr, fl, s);
+		if (rc) {
+			return rc;
+		}
+		HIP_TRY (hipStreamSynchronize (s)); // d_inter / d_in are reused by the next chunk
+		pos += n;
+		first = false;
+	} while (pos < n_frames);
+	return PROT_OK;
+}
+
+int prot_cli_apply_file (prot_engine* e, const float* data, uint64_t n_frames, const int* angles, float* out)
+{
+	if (!e || !data || !angles || !out || e->info.kind != PROT_KIND_CLI) {
+		return PROT_EINVAL;
+	}
+	if (n_frames == 0) {
+		return PROT_OK;
+	}
+	HIP_TRY (hipSetDevice (e->device));
+	const uint32_t nc  = e->info.n_chn;
+	const uint64_t P   = e->info.blksiz;
+	const uint64_t lat = P / 2; // cli/phase-rotate.cc:963
+	hipStream_t    s   = e->stream;
+	const uint64_t chunk = std::max<uint64_t> (P, ((uint64_t)1 << 22) / P * P);
+	const uint64_t cap   = std::min<uint64_t> (chunk, n_frames) + lat;
+	int rc;
+	if ((rc = e->d_inter.ensure (cap * nc)) || (rc = e->d_in.ensure (cap * nc)) || (rc = e->d_out.ensure (cap * nc))) {
+		return rc;
+	}
+	std::vector<float> rot (2 * (size_t)nc);
+	for (uint32_t c = 0; c < nc; ++c) {
+		const int a = ((angles[c] % PROT_MAXSAMPLE) + PROT_MAXSAMPLE) % PROT_MAXSAMPLE;
+		rot[2 * c]     = g_lut[2 * a + 1];
+		rot[2 * c + 1] = g_lut[2 * a];
+	}
+	uint64_t pos = 0;
+	while (pos < n_frames) {
+		const uint64_t n     = std::min (chunk, n_frames - pos);
+		const bool     last  = pos + n >= n_frames;
+		const uint64_t n_out = n + (last ? lat : 0); // flush: latency frames of silence in (:993-1001)
+		HIP_TRY (hipMemcpyAsync (e->d_inter.p, data + pos * nc, n * nc * sizeof (float), hipMemcpyHostToDevice, s));
+		hipError_t err = prot::launch_deinterleave (e->d_inter.p, e->d_in.p, (int64_t)cap, (int64_t)n, (int)nc, s);
+		if (err != hipSuccess) {
+			return hip_fail (err, "deinterleave launch");
+		}
+		rc = prot_apply_dev (e, e->d_in.p, (int64_t)cap, n, e->d_out.p, (int64_t)cap, n_out, rot.data (), 0, s);
+		if (rc) {
+			return rc;
+		}
+		err = prot::launch_interleave (e->d_out.p, (int64_t)cap, e->d_inter.p, (int64_t)n_out, (int)nc, s);
+		if (err != hipSuccess) {
+			return hip_fail (err, "interleave launch");
+		}
+		// y[t] for t in [pos, pos + n_out) -> file frame t - lat
+		const uint64_t skip = pos < lat ? std::min (lat - pos, n_out) : 0; // :963-966 off = latency on the first block(s)
+		if (n_out > skip) {
+			const uint64_t dst = pos + skip - lat;
+			const uint64_t cnt = std::min (n_out - skip, n_frames - dst);
+			HIP_TRY (hipMemcpyAsync (out + dst * nc, e->d_inter.p + skip * nc, cnt * nc * sizeof (float),
+			                         hipMemcpyDeviceToHost, s));
+		}
+		HIP_TRY (hipStreamSynchronize (s));
+		pos += n;
+	}
+	return PROT_OK;
+}
+
+} // extern "C"

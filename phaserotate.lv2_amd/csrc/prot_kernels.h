@@ -1,0 +1,75 @@
+// prot_kernels.h -- launch interface between the C-ABI host code
+// (prot_capi.hip) and the gfx950 kernels (prot_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace prot {
+
+constexpr int kMaxSample = 360; // cli/phase-rotate.cc:39
+
+// One launch of the overlap-add kernel: every workgroup owns a run of
+// consecutive hops of one channel-stream.
+struct OlaParams {
+	const float*  in;         // device, planar; channel c at in + c*in_stride
+	int64_t       in_stride;
+	int64_t       n_in;       // valid input frames; reads at >= n_in are silence
+	const float*  hist;       // device, [n_chn][hist_len]: frames before in[0]; NULL = silence
+	int32_t       hist_len;
+	float*        out;        // device, planar
+	int64_t       out_stride;
+	int64_t       n_out;      // emit t in [0, n_out)
+	const float2* H;          // device, [fftlen] FIR spectrum / fftlen, natural bin order
+	const float2* tw;         // device, [fftlen] e^{-2 pi i m / fftlen}
+	const float*  rot;        // device, [n_chn][2] {ca, sa}              (steady)
+	const float*  rot_s;      // device, [n_chn][n_out][2] per-frame      (ramp) or NULL
+	int32_t       run_frames; // outputs per workgroup, multiple of 2*hop
+	int32_t       conv_delay; // Dc
+	int32_t       dry_delay;  // Dd
+	int32_t       hilbert_only;
+};
+
+// fftlen 4096; hop = 256 * hopseg, hopseg in {4, 8}
+hipError_t launch_ola4096 (const OlaParams& p, int hopseg, int n_chn, hipStream_t s);
+// fftlen 8192; hop = 512 * hopseg, hopseg in {4, 8}   (512-thread workgroups)
+hipError_t launch_ola8192 (const OlaParams& p, int hopseg, int n_chn, hipStream_t s);
+
+// Rotated abs-max sweep over t in [t_begin, t_end) of one chunk:
+//   v = ca[a] * (t_abs >= dry_from ? x[t - delay] : 0) + sa[a] * u[t]
+//   peaks[c][a] = max(peaks[c][a], |v|)
+struct SweepParams {
+	const float* x;           // device planar input (dry), channel stride x_stride
+	int64_t      x_stride;
+	int64_t      n_x;         // valid frames of x (beyond: silence)
+	const float* hist;        // [n_chn][hist_len] frames before x[0], or NULL
+	int32_t      hist_len;
+	const float* u;           // device planar Hilbert branch, u[t] for t in [0, n_u)
+	int64_t      u_stride;
+	int64_t      t_begin, t_end;
+	int64_t      t_abs0;      // absolute stream position of local t = 0
+	int64_t      dry_from;    // dry term forced to 0 while t_abs < dry_from (Q1)
+	int32_t      delay;       // blksiz / 2
+	const int*   angles;      // device, [n_angles] LUT indices 0..359 (never the raw-peak angle 0 entry)
+	int32_t      n_angles;
+	const float* lut;         // device, [360][2] = {sin, cos}  (SinCosLut)
+	float*       peaks;       // device, [n_chn][360], max-accumulated
+	int32_t      chn0;        // first channel handled by blockIdx.y = 0
+};
+hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s);
+
+// peaks[c][slot] = max(peaks[c][slot], max_{t in [0,n)} |x[c][t]|)   (angle 0, Q4)
+hipError_t launch_absmax (const float* x, int64_t x_stride, int64_t n, float* peaks, int slot,
+                          int chn0, int n_chn, hipStream_t s);
+
+// hist_out[c][i] = virtual(n_in - hist_len + i), virtual = [hist_in | in | silence]
+hipError_t launch_hist_update (const float* in, int64_t in_stride, int64_t n_in,
+                               const float* hist_in, float* hist_out, int hist_len,
+                               int n_chn, hipStream_t s);
+
+// interleaved [n][n_chn] <-> planar [n_chn][stride]
+hipError_t launch_deinterleave (const float* inter, float* planar, int64_t stride, int64_t n,
+                                int n_chn, hipStream_t s);
+hipError_t launch_interleave (const float* planar, int64_t stride, float* inter, int64_t n,
+                              int n_chn, hipStream_t s);
+
+} // namespace prot

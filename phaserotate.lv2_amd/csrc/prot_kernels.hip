@@ -1,0 +1,538 @@
+// prot_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the phase-rotation
+// hot path.  wave64 throughout; no hipFFT/rocFFT, no MFMA (the path is a
+// butterfly network, not a contraction).
+//
+// ola4096_kernel -- overlap-add Hilbert convolution + rotation, one
+//   workgroup (256 threads = 4 waves) per run of consecutive hops of one
+//   channel-stream.  Replaces the block body of process_channel
+//   (src/phaserotate.c:629-720) and PhaseRotateProc::hilbert/rotate
+//   (cli/phase-rotate.cc:181-225).
+//     * two consecutive hops A, B ride in one complex transform (re = A,
+//       im = B): forward FFT-4096 -> x H (real FIR => acts on re and im
+//       independently) -> inverse FFT-4096 gives both convolutions, no
+//       real/complex split pass;
+//     * FFT-4096 = 16 x 16 x 16: three radix-16 passes in registers (16
+//       complex per thread), two digit transpositions through LDS
+//       (34 KiB, strides 272/257/258 chosen conflict-free for ds_write_b64 /
+//       ds_read_b64);  the inverse runs the mirror image so the spectrum
+//       stays in registers across "x H";
+//     * thread t owns frames t + 256k of every block, so HBM loads/stores are
+//       coalesced dwords of contiguous frames and the overlap-add tail
+//       (fftlen - hop frames) lives in registers across the run -- LDS holds
+//       nothing but the FFT exchange;
+//     * a run starts (fftlen/hop) halo blocks early to rebuild the tail from
+//       input history, so workgroups never exchange data.
+// sweep_kernel  -- K7: per-angle max |ca*d + sa*h| (cli/phase-rotate.cc:98-121,
+//   :409-428, cli/dsp_peak_calc.h): lanes own frames, the angle loop is
+//   scalar (sin/cos in SGPRs), one DPP wave-reduction per angle per tile,
+//   running maxima in 6 VGPRs per wave, unsigned atomicMax at the end.
+#include "prot_fft.h"
+#include "prot_kernels.h"
+
+namespace prot {
+
+// ------------------------------------------------------------------ helpers
+// virtual stream [hist | in | silence] at index i (i may be negative)
+PROT_DEV float ldv (const float* __restrict__ in, int64_t n_in, const float* __restrict__ hist,
+                    int hist_len, int64_t i)
+{
+	if (i >= 0) {
+		return i < n_in ? in[i] : 0.f;
+	}
+	const int64_t h = i + hist_len;
+	return (hist != nullptr && h >= 0) ? hist[h] : 0.f;
+}
+
+// ------------------------------------------------------------ OLA, FFT-4096
+constexpr int kL1 = 272; // exchange between pass 1 and 2 (and inverse mirror)
+constexpr int kL2 = 257; // forward exchange 2
+constexpr int kL3 = 258; // inverse exchange A
+constexpr int kLdsRegion = 16 * kL1;
+
+template <int HOPSEG, int NREG>
+__global__ __launch_bounds__ (256) void ola4096_kernel (const OlaParams p)
+{
+	constexpr int HOP  = HOPSEG * 256;
+	constexpr int NS   = 16 / HOPSEG;        // hop-sized segments per FFT
+	constexpr int NH   = NS - 1;             // halo blocks that reach into a run
+	constexpr int NACC = (NS - 1) * HOPSEG;  // OLA tail registers
+
+	__shared__ float2 lds[NREG][kLdsRegion];
+	__shared__ float2 twm[256];              // twm[k1*16 + n0] = W256^{n0 k1}
+
+	const int     t  = threadIdx.x;
+	const int     c  = blockIdx.y;
+	const int64_t r0 = (int64_t)blockIdx.x * p.run_frames;
+	if (r0 >= p.n_out) {
+		return;
+	}
+	const int64_t r1 = (r0 + p.run_frames < p.n_out) ? r0 + p.run_frames : p.n_out;
+
+	const float* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
+	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
+	float* __restrict__ out        = p.out + (int64_t)c * p.out_stride;
+	const int64_t n_in             = p.n_in;
+	const int     Dc = p.conv_delay, Dd = p.dry_delay;
+
+	// pass-1 twiddles W4096^{t k0}, k0 = 1..15, live in registers for the run
+	float2 tw1[16];
+#pragma unroll
+	for (int k = 1; k < 16; ++k) {
+		tw1[k] = p.tw[(t * k) & 4095];
+	}
+	twm[t] = p.tw[16 * (((t & 15) * (t >> 4)) & 255)];
+
+	float ca = 0.f, sa = 1.f;
+	if (!p.hilbert_only && p.rot_s == nullptr) {
+		ca = p.rot[2 * c];
+		sa = p.rot[2 * c + 1];
+	}
+
+	float acc[NACC];
+#pragma unroll
+	for (int i = 0; i < NACC; ++i) {
+		acc[i] = 0.f;
+	}
+	__syncthreads ();
+
+	const int tl = t & 15, th = t >> 4;
+	const int n_pairs = (NH + 1) / 2 + (int)((r1 - r0 + 2 * HOP - 1) / (2 * HOP));
+	int64_t   sA      = r0 - (int64_t)(NH + 1) * HOP;
+
+	for (int it = 0; it < n_pairs; ++it, sA += 2 * HOP) {
+		const int64_t sB = sA + HOP;
+		float2        v[16];
+
+		// ---- load two hops of contiguous frames (coalesced dwords) ----------
+		{
+			const int64_t iA   = sA - Dc; // first input frame of block A
+			const bool    fast = (iA >= 0) && (iA + 2 * HOP <= n_in);
+			if (fast) {
+				const float* __restrict__ q = in + iA + t;
+#pragma unroll
+				for (int k = 0; k < HOPSEG; ++k) {
+					v[k].x = q[256 * k];
+					v[k].y = q[HOP + 256 * k];
+				}
+			} else {
+#pragma unroll
+				for (int k = 0; k < HOPSEG; ++k) {
+					v[k].x = ldv (in, n_in, hist, p.hist_len, iA + t + 256 * k);
+					v[k].y = ldv (in, n_in, hist, p.hist_len, iA + HOP + t + 256 * k);
+				}
+			}
+			if (it == 0) { // alignment block in front of the halo: contributes nothing
+#pragma unroll
+				for (int k = 0; k < HOPSEG; ++k) {
+					v[k].x = 0.f;
+				}
+			}
+#pragma unroll
+			for (int k = HOPSEG; k < 16; ++k) {
+				v[k] = make_float2 (0.f, 0.f); // zero padding (pruned by the compiler)
+			}
+		}
+
+		// ---- forward pass 1 (over n2), twiddle W^{t k0} ---------------------
+		fft16<1> (v);
+#pragma unroll
+		for (int k = 1; k < 16; ++k) {
+			v[k] = cmulw<1> (v[k], tw1[k]);
+		}
+		if (NREG == 1) {
+			__syncthreads ();
+		}
+		{
+			float2* w = &lds[0][t];
+#pragma unroll
+			for (int k = 0; k < 16; ++k) {
+				w[k * kL1] = v[k];
+			}
+			__syncthreads ();
+			const float2* r = &lds[0][th * kL1 + tl];
+#pragma unroll
+			for (int k = 0; k < 16; ++k) {
+				v[k] = r[16 * k];
+			}
+		}
+		// ---- forward pass 2 (over n1), twiddle W256^{n0 k1} -----------------
+		fft16<1> (v);
+#pragma unroll
+		for (int k = 1; k < 16; ++k) {
+			v[k] = cmulw<1> (v[k], twm[k * 16 + tl]);
+		}
+		if (NREG == 1) {
+			__syncthreads ();
+		}
+		{
+			float2* w = &lds[NREG - 1][tl * kL2 + th];
+#pragma unroll
+			for (int k = 0; k < 16; ++k) {
+				w[16 * k] = v[k];
+			}
+			__syncthreads ();
+			const float2* r = &lds[NREG - 1][t];
+#pragma unroll
+			for (int k = 0; k < 16; ++k) {
+				v[k] = r[k * kL2];
+			}
+		}
+		// ---- forward pass 3 (over n0): v[k2] = X[t + 256 k2] ----------------
+		fft16<1> (v);
+
+		// ---- x H: Hilbert FIR spectrum, 1/fftlen folded in -------------------
+		{
+			const float2* __restrict__ hp = p.H + t;
+#pragma unroll
+			for (int k = 0; k < 16; ++k) {
+				v[k] = cmulw<1> (v[k], hp[256 * k]);
+			}
+		}
+
+		// ---- inverse pass 1 (over k2), twiddle conj W256^{n0 k1} ------------
+		fft16<-1> (v);
+#pragma unroll
+		for (int k = 1; k < 16; ++k) {
+			v[k] = cmulw<-1> (v[k], twm[th * 16 + k]);
+		}
+		if (NREG == 1) {
+			__syncthreads ();
+		}
+		{
+			float2* w = &lds[0][t];
+#pragma unroll
+			for (int k = 0; k < 16; ++k) {
+				w[k * kL3] = v[k];
+			}
+			__syncthreads ();
+			const float2* r = &lds[0][tl * kL3 + th];
+#pragma unroll
+			for (int k = 0; k < 16; ++k) {
+				v[k] = r[16 * k];
+			}
+		}
+		// ---- inverse pass 2 (over k1) ----------------------------------------
+		fft16<-1> (v);
+		if (NREG == 1) {
+			__syncthreads ();
+		}
+		{
+			float2* w = &lds[NREG - 1][th * kL1 + tl];
+#pragma unroll
+			for (int k = 0; k < 16; ++k) {
+				w[16 * k] = v[k];
+			}
+			__syncthreads ();
+			const float2* r = &lds[NREG - 1][t];
+#pragma unroll
+			for (int k = 0; k < 16; ++k) {
+				v[k] = r[k * kL1];
+			}
+		}
+		// ---- twiddle conj W^{t k0}, inverse pass 3 (over k0) -----------------
+#pragma unroll
+		for (int k = 1; k < 16; ++k) {
+			v[k] = cmulw<-1> (v[k], tw1[k]);
+		}
+		fft16<-1> (v);
+		// v[k].x = (fir * A)[t + 256k], v[k].y = (fir * B)[t + 256k]
+
+		// ---- overlap-add in registers ----------------------------------------
+		float uA[HOPSEG], uB[HOPSEG];
+#pragma unroll
+		for (int j = 0; j < HOPSEG; ++j) {
+			uA[j] = acc[j] + v[j].x;
+			uB[j] = v[HOPSEG + j].x + v[j].y;
+			if (NS > 2) {
+				uB[j] += acc[HOPSEG + j];
+			}
+		}
+#pragma unroll
+		for (int q = 0; q < NS - 1; ++q) {
+#pragma unroll
+			for (int j = 0; j < HOPSEG; ++j) {
+				float a = v[(q + 1) * HOPSEG + j].y;
+				if (q + 2 < NS) {
+					a += v[(q + 2) * HOPSEG + j].x;
+				}
+				if (q + 2 <= NS - 2) {
+					a += acc[(q + 2) * HOPSEG + j];
+				}
+				acc[q * HOPSEG + j] = a;
+			}
+		}
+
+		// ---- rotate and store --------------------------------------------------
+		if (sA >= r0) { // uniform: halo blocks emit nothing
+			const bool fast = (!p.hilbert_only) && (sA - Dd >= 0) && (sA + 2 * HOP <= n_in + Dd) && (sA + 2 * HOP <= r1);
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+#pragma unroll
+				for (int j = 0; j < HOPSEG; ++j) {
+					const int64_t pos = sA + h * HOP + t + 256 * j;
+					const float   u   = h ? uB[j] : uA[j];
+					if (p.hilbert_only) {
+						if (pos < r1) {
+							out[pos] = u;
+						}
+					} else if (fast && p.rot_s == nullptr) {
+						out[pos] = ca * in[pos - Dd] + sa * u;
+					} else if (pos < r1) {
+						const float dry = ldv (in, n_in, hist, p.hist_len, pos - Dd);
+						float       cc = ca, ss = sa;
+						if (p.rot_s != nullptr) {
+							const float2 cs = reinterpret_cast<const float2*> (p.rot_s)[(int64_t)c * p.n_out + pos];
+							cc              = cs.x;
+							ss              = cs.y;
+						}
+						out[pos] = cc * dry + ss * u;
+					}
+				}
+			}
+		}
+	}
+}
+
+hipError_t launch_ola4096 (const OlaParams& p, int hopseg, int n_chn, hipStream_t s)
+{
+	if (p.n_out <= 0) {
+		return hipSuccess;
+	}
+	const int64_t runs = (p.n_out + p.run_frames - 1) / p.run_frames;
+	dim3          grid ((unsigned)runs, (unsigned)n_chn), block (256);
+	if (hopseg == 4) {
+		hipLaunchKernelGGL ((ola4096_kernel<4, 1>), grid, block, 0, s, p);
+	} else if (hopseg == 8) {
+		hipLaunchKernelGGL ((ola4096_kernel<8, 1>), grid, block, 0, s, p);
+	} else {
+		return hipErrorInvalidValue;
+	}
+	return hipGetLastError ();
+}
+
+hipError_t launch_ola8192 (const OlaParams&, int, int, hipStream_t)
+{
+	return hipErrorNotSupported;
+}
+
+// ------------------------------------------------------------------- sweep
+// max over the 64 lanes of a non-negative value, result valid in lane 63
+PROT_DEV float wave_max_nonneg (float v)
+{
+#define PROT_DPP_MAX(ctrl, rmask)                                                               \
+	v = fmaxf (v, __int_as_float (__builtin_amdgcn_update_dpp (0, __float_as_int (v), ctrl,     \
+	                                                           rmask, 0xf, true)))
+	PROT_DPP_MAX (0x111, 0xf); // row_shr:1   (out-of-row source reads 0 = identity for |.|)
+	PROT_DPP_MAX (0x112, 0xf); // row_shr:2
+	PROT_DPP_MAX (0x114, 0xf); // row_shr:4
+	PROT_DPP_MAX (0x118, 0xf); // row_shr:8   lane 15 of each row = row max
+	PROT_DPP_MAX (0x142, 0xa); // row_bcast:15 into rows 1 and 3
+	PROT_DPP_MAX (0x143, 0xc); // row_bcast:31 into rows 2 and 3
+#undef PROT_DPP_MAX
+	return v;
+}
+
+constexpr int kSweepE    = 32;                // frames per thread per tile
+constexpr int kSweepTile = 256 * kSweepE;     // frames per workgroup iteration
+
+__global__ __launch_bounds__ (256) void sweep_kernel (const SweepParams p)
+{
+	const int tid  = threadIdx.x;
+	const int lane = tid & 63;
+	const int c    = p.chn0 + blockIdx.y;
+
+	const float* __restrict__ x    = p.x + (int64_t)c * p.x_stride;
+	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
+	const float* __restrict__ u    = p.u + (int64_t)c * p.u_stride;
+
+	float pk[6];
+#pragma unroll
+	for (int r = 0; r < 6; ++r) {
+		pk[r] = 0.f;
+	}
+
+	for (int64_t base = p.t_begin + (int64_t)blockIdx.x * kSweepTile; base < p.t_end;
+	     base += (int64_t)gridDim.x * kSweepTile) {
+		float d[kSweepE], h[kSweepE];
+		const bool fast = (base + kSweepTile <= p.t_end) && (base - p.delay >= 0) &&
+		                  (base + kSweepTile - p.delay <= p.n_x) && (base + p.t_abs0 >= p.dry_from);
+		if (fast) {
+#pragma unroll
+			for (int e = 0; e < kSweepE; ++e) {
+				const int64_t tt = base + e * 256 + tid;
+				d[e]             = x[tt - p.delay];
+				h[e]             = u[tt];
+			}
+		} else {
+#pragma unroll
+			for (int e = 0; e < kSweepE; ++e) {
+				const int64_t tt = base + e * 256 + tid;
+				float         dd = 0.f, hh = 0.f;
+				if (tt < p.t_end) {
+					hh = u[tt];
+					if (tt + p.t_abs0 >= p.dry_from) {
+						dd = ldv (x, p.n_x, hist, p.hist_len, tt - p.delay);
+					}
+				}
+				d[e] = dd;
+				h[e] = hh;
+			}
+		}
+#pragma unroll
+		for (int r = 0; r < 6; ++r) {
+			for (int j = 0; j < 64; ++j) {
+				const int i = r * 64 + j;
+				if (i >= p.n_angles) {
+					break;
+				}
+				const int   a  = p.angles[i];       // wave-uniform -> scalar loads
+				const float sa = p.lut[2 * a];
+				const float ca = p.lut[2 * a + 1];
+				float       m0 = 0.f, m1 = 0.f;
+#pragma unroll
+				for (int e = 0; e < kSweepE; e += 2) {
+					const float v0 = ca * d[e] + sa * h[e];
+					const float v1 = ca * d[e + 1] + sa * h[e + 1];
+					m0             = fmaxf (m0, fabsf (v0));
+					m1             = fmaxf (m1, fabsf (v1));
+				}
+				float m = wave_max_nonneg (fmaxf (m0, m1));
+				m       = __int_as_float (__builtin_amdgcn_readlane (__float_as_int (m), 63));
+				pk[r]   = (lane == j) ? fmaxf (pk[r], m) : pk[r];
+			}
+		}
+	}
+
+	unsigned* gp = reinterpret_cast<unsigned*> (p.peaks + (int64_t)c * kMaxSample);
+#pragma unroll
+	for (int r = 0; r < 6; ++r) {
+		const int i = r * 64 + lane;
+		if (i < p.n_angles) {
+			// non-negative floats order like their bit patterns
+			atomicMax (&gp[p.angles[i]], __float_as_uint (pk[r]));
+		}
+	}
+}
+
+hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s)
+{
+	if (p.t_end <= p.t_begin || p.n_angles <= 0 || n_chn <= 0) {
+		return hipSuccess;
+	}
+	const int64_t tiles = (p.t_end - p.t_begin + kSweepTile - 1) / kSweepTile;
+	int64_t       gx    = tiles;
+	const int64_t cap   = (2048 + n_chn - 1) / n_chn; // ~8 workgroups per CU in flight
+	if (gx > cap) {
+		gx = cap;
+	}
+	dim3 grid ((unsigned)gx, (unsigned)n_chn), block (256);
+	hipLaunchKernelGGL (sweep_kernel, grid, block, 0, s, p);
+	return hipGetLastError ();
+}
+
+// ------------------------------------------------------------------ absmax
+__global__ __launch_bounds__ (256) void absmax_kernel (const float* __restrict__ x, int64_t x_stride,
+                                                       int64_t n, float* peaks, int slot, int chn0)
+{
+	const int c                   = chn0 + blockIdx.y;
+	const float* __restrict__ xc = x + (int64_t)c * x_stride;
+	float m = 0.f;
+	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+		m = fmaxf (m, fabsf (xc[i]));
+	}
+	m = wave_max_nonneg (m);
+	if ((threadIdx.x & 63) == 63) {
+		atomicMax (reinterpret_cast<unsigned*> (peaks + (int64_t)c * kMaxSample + slot), __float_as_uint (m));
+	}
+}
+
+hipError_t launch_absmax (const float* x, int64_t x_stride, int64_t n, float* peaks, int slot,
+                          int chn0, int n_chn, hipStream_t s)
+{
+	if (n <= 0 || n_chn <= 0) {
+		return hipSuccess;
+	}
+	int64_t gx = (n + 256 * 16 - 1) / (256 * 16);
+	if (gx > 1024) {
+		gx = 1024;
+	}
+	dim3 grid ((unsigned)gx, (unsigned)n_chn), block (256);
+	hipLaunchKernelGGL (absmax_kernel, grid, block, 0, s, x, x_stride, n, peaks, slot, chn0);
+	return hipGetLastError ();
+}
+
+// ------------------------------------------------------------ small movers
+__global__ void hist_update_kernel (const float* __restrict__ in, int64_t in_stride, int64_t n_in,
+                                    const float* __restrict__ hist_in, float* __restrict__ hist_out,
+                                    int hist_len)
+{
+	const int c = blockIdx.y;
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < hist_len) {
+		hist_out[(int64_t)c * hist_len + i] =
+		    ldv (in + (int64_t)c * in_stride, n_in, hist_in + (int64_t)c * hist_len, hist_len,
+		         n_in - hist_len + i);
+	}
+}
+
+hipError_t launch_hist_update (const float* in, int64_t in_stride, int64_t n_in, const float* hist_in,
+                               float* hist_out, int hist_len, int n_chn, hipStream_t s)
+{
+	dim3 grid ((unsigned)((hist_len + 255) / 256), (unsigned)n_chn), block (256);
+	hipLaunchKernelGGL (hist_update_kernel, grid, block, 0, s, in, in_stride, n_in, hist_in, hist_out, hist_len);
+	return hipGetLastError ();
+}
+
+__global__ void deinterleave_kernel (const float* __restrict__ inter, float* __restrict__ planar,
+                                     int64_t stride, int64_t n, int n_chn)
+{
+	const int64_t total = n * n_chn;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+	     i += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t f = i / n_chn;
+		const int     c = (int)(i - f * n_chn);
+		planar[(int64_t)c * stride + f] = inter[i];
+	}
+}
+
+__global__ void interleave_kernel (const float* __restrict__ planar, int64_t stride,
+                                   float* __restrict__ inter, int64_t n, int n_chn)
+{
+	const int64_t total = n * n_chn;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+	     i += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t f = i / n_chn;
+		const int     c = (int)(i - f * n_chn);
+		inter[i]        = planar[(int64_t)c * stride + f];
+	}
+}
+
+static unsigned mover_grid (int64_t total)
+{
+	int64_t g = (total + 255) / 256;
+	return (unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+hipError_t launch_deinterleave (const float* inter, float* planar, int64_t stride, int64_t n,
+                                int n_chn, hipStream_t s)
+{
+	if (n <= 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL (deinterleave_kernel, dim3 (mover_grid (n * n_chn)), dim3 (256), 0, s, inter,
+	                    planar, stride, n, n_chn);
+	return hipGetLastError ();
+}
+
+hipError_t launch_interleave (const float* planar, int64_t stride, float* inter, int64_t n, int n_chn,
+                              hipStream_t s)
+{
+	if (n <= 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL (interleave_kernel, dim3 (mover_grid (n * n_chn)), dim3 (256), 0, s, planar,
+	                    stride, inter, n, n_chn);
+	return hipGetLastError ();
+}
+
+} // namespace prot

@@ -1,0 +1,120 @@
+"""Multi-GPU plumbing of the CLI min-peak sweep: one process per GPU
+(torch.distributed, backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
+CPU tests).
+
+The reference has no distributed code; its only "reduction" is peak_all()'s max
+over channel rows (cli/phase-rotate.cc:287-299) after the per-channel threads
+join (:441-443).  Here the independent (angle x channel x frame-block) work
+items are sharded by frame-block range: rank r sweeps blocks [b0, b1) of the
+file for all requested angles, seeded with `history` frames of input in front
+of b0 (the previous block for the dry delay + what the OLA tail needs), and the
+per-angle maxima are merged with ONE all-reduce(MAX) of float[n_chn][360]
+(2 880 B for stereo: latency-bound, the xGMI link bandwidth is irrelevant).
+max is associative, commutative and exact in fp32, so sharding cannot change
+the table or the argmin.  The first-block rule (Q1) stays with rank 0 and the
+zero-pad + flush block (Q2) with the last rank.
+"""
+import numpy as np
+
+MAXSAMPLE = 360
+SUBSAMPLE = 2
+
+
+def plan_shards(n_frames, blksiz, world):
+    """Split ceil(n_frames / blksiz) data blocks into `world` contiguous ranges
+    [(b0, b1), ...]; earlier ranks get the remainder.  Empty ranges are allowed
+    (more ranks than blocks)."""
+    nb = (n_frames + blksiz - 1) // blksiz
+    base, rem = divmod(nb, world)
+    out, b = [], 0
+    for r in range(world):
+        k = base + (1 if r < rem else 0)
+        out.append((b, b + k))
+        b += k
+    return out
+
+
+def shard_frames(n_frames, blksiz, plan, rank):
+    """(first_frame, n_valid_frames) of rank's shard; only the file's last block may be partial."""
+    b0, b1 = plan[rank]
+    f0 = b0 * blksiz
+    f1 = min(b1 * blksiz, n_frames)
+    return f0, max(0, f1 - f0)
+
+
+def prime_history(engine, halo, stream=0):
+    """Feed `halo` ([n_chn, H] device tensor: the H frames in front of this
+    rank's shard) through the engine so that its input history equals what a
+    single-GPU pass would hold at this point.  The Hilbert output is discarded."""
+    import torch
+    n_chn, h = halo.shape
+    scratch = torch.empty_like(halo)
+    engine.hilbert_dev(halo.data_ptr(), h, h, scratch.data_ptr(), h, h, 0, stream)
+    return scratch  # keep alive until the stream has consumed it
+
+
+def allreduce_peaks(peaks):
+    """In-place MAX all-reduce of a [n_chn, 360] peak table (torch tensor)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(peaks, op=dist.ReduceOp.MAX)
+    return peaks
+
+
+def angle_list(ang_start, ang_end, ang_stride):
+    """The angles one analyze() call visits (loop bounds of cli/phase-rotate.cc:409-428)."""
+    out, angle = [], ang_start
+    while angle <= ang_end:
+        out.append(angle)
+        angle += ang_stride
+        if angle >= ang_end:
+            break
+    return out
+
+
+def coarse_candidates(peaks, stride, link_chn=False):
+    """Candidate minima after the coarse pass (cli/phase-rotate.cc:815-857).
+    peaks: [n_chn, 360] float32.  Returns (mins: {angle: [channels]}, p_min, r_zro)."""
+    peaks = np.asarray(peaks, np.float32)
+    n_chn = peaks.shape[0]
+    allp = peaks.max(axis=0)
+    mins = {}
+    p_min = np.full(n_chn, np.inf, np.float32)
+    r_zro = peaks[:, 0].copy()
+    for c in range(n_chn):
+        row = allp if link_chn else peaks[c]
+        sel = row[0:MAXSAMPLE:stride]
+        c_min, c_max = np.float32(sel.min()), np.float32(sel.max())
+        rng = np.float32(c_max - c_min)
+        if rng == 0:
+            mins.setdefault(0, []).append(c)
+            continue
+        if stride > 1:
+            rng = np.float32(rng * np.float32(.07))
+        else:
+            rng = np.float32(0)
+            p_min[c] = c_min
+        for a in range(0, MAXSAMPLE, stride):
+            if row[a] <= np.float32(c_min + rng):
+                mins.setdefault(a, []).append(c)
+    return dict(sorted(mins.items())), p_min, r_zro
+
+
+def finish_selection(min_angle, p_min):
+    """Phase-distance unwrapping of the per-channel minima (cli/phase-rotate.cc:905-929)."""
+    min_angle = [int(a) for a in min_angle]
+    found = [bool(p != np.inf) for p in p_min]
+    cnt = sum(found)
+    avg_rotate = np.float32(sum(a for a, f in zip(min_angle, found) if f)) / np.float32(cnt) if cnt else np.float32(np.nan)
+    avg_dist = np.float32(MAXSAMPLE) / np.float32(cnt) if cnt else np.float32(np.inf)
+    out = []
+    for a, f in zip(min_angle, found):
+        if not f:
+            out.append(0)
+            continue
+        if a > 90 * SUBSAMPLE and abs(np.float32(a) - avg_rotate) > avg_dist:
+            a -= MAXSAMPLE
+        elif avg_rotate > 90 * SUBSAMPLE:
+            a -= MAXSAMPLE
+        out.append(a)
+    return out, found

@@ -1,0 +1,86 @@
+"""CPU: the C-ABI shared library loads, exports every symbol include/prot_hip.h
+declares, and fails loudly (no CPU fallback) when there is no GPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = os.path.join(ROOT, "include", "prot_hip.h")
+
+
+def declared_symbols():
+    src = open(HDR).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(prot_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_python_binding_agree(pkg):
+    assert set(declared_symbols()) == set(pkg.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.load_library()
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+    exported = set(re.findall(r" T (prot_[a-z0-9_]+)", out))
+    assert set(declared_symbols()) <= exported
+    assert lib.prot_abi_version() == 1
+
+
+def test_header_is_plain_c():
+    """No torch/HIP/C++ types in the signatures: the header compiles as C99 on its own."""
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", HDR],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    code = re.sub(r"/\*.*?\*/", "", open(HDR).read(), flags=re.S)
+    assert "#include <stdint.h>" in code and code.count("#include") == 1
+    assert "hip" not in code.replace("PROT_HIP_H", "").replace("PROT_EHIP", "").lower() and "torch" not in code.lower()
+
+
+def test_strerror_and_lut(pkg):
+    lib = pkg.load_library()
+    assert lib.prot_strerror(0) == b"ok"
+    assert b"device" in lib.prot_strerror(2)
+    s, c = pkg.sincos_lut(0)
+    assert (abs(s), c) == (0.0, 1.0)
+    import orc
+    for a in (1, 90, 180, 359):
+        assert pkg.sincos_lut(a) == orc.sincos_lut(a)  # same SinCosLut construction
+    assert pkg.sincos_lut(-1) == pkg.sincos_lut(359)   # (a + 360) % 360
+
+
+def test_no_cpu_fallback_without_gpu(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.ProtError) as ei:
+        pkg.PhaseRotate(2048, 1)
+    assert "no usable gfx950 device" in str(ei.value)
+    with pytest.raises(pkg.ProtError):
+        pkg.Lv2Instance(48000, 1)
+
+
+def test_invalid_configs_rejected_before_touching_the_gpu(pkg):
+    lib = pkg.load_library()
+    st = ctypes.c_int(0)
+    for kind, param, n_chn in ((0, 1000, 1), (0, 65536, 1), (0, 2048, 0), (7, 2048, 1), (1, -1.0, 1)):
+        cfg = pkg.Config(kind, float(param), n_chn, 0, 0, 0)
+        assert not lib.prot_engine_create(ctypes.byref(cfg), ctypes.byref(st))
+        assert st.value == 1  # PROT_EINVAL (cli/phase-rotate.cc:673 bounds)
+    assert lib.prot_engine_reset(None) == 1
+
+
+def test_product_never_imports_the_oracle():
+    """The package, the C sources and the host front ends must not reference oracle/."""
+    pkgdir = os.path.join(ROOT, "phaserotate.lv2_amd")
+    for dp, dn, fn in os.walk(pkgdir):
+        if os.path.basename(dp) in ("build", "lib", "__pycache__"):
+            continue
+        for f in fn:
+            if f.endswith((".py", ".hip", ".h", ".c", ".cc", ".cpp")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "prot_oracle" not in txt and "liborc" not in txt and "import orc" not in txt, f

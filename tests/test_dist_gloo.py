@@ -1,0 +1,74 @@
+"""CPU, world_size 2, gloo: frame-block sharding + MAX all-reduce of the peak
+table reproduces the single-process table bit for bit (max is exact), and the
+selection logic on the reduced table matches the oracle's restatement of main()."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import orc
+from conftest import harmonic_stack, xorshift_uniform
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_plan_shards(pkg):
+    from phaserotate_lv2_amd import sweep_dist as sd
+    assert sd.plan_shards(10 * 2048, 2048, 2) == [(0, 5), (5, 10)]
+    assert sd.plan_shards(10 * 2048 + 1, 2048, 4) == [(0, 3), (3, 6), (6, 9), (9, 11)]
+    assert sd.plan_shards(2048, 2048, 8) == [(0, 1)] + [(1, 1)] * 7
+    assert sd.plan_shards(0, 2048, 2) == [(0, 0), (0, 0)]
+    plan = sd.plan_shards(5 * 2048 + 100, 2048, 2)
+    assert sd.shard_frames(5 * 2048 + 100, 2048, plan, 1) == (3 * 2048, 2 * 2048 + 100)
+
+
+@pytest.mark.parametrize("n_chn,n_frames", [(2, 2048 * 9 + 517), (1, 2048 * 4)])
+def test_sharded_sweep_world2_gloo(tmp_path, n_chn, n_frames):
+    blksiz, world = 2048, 2
+    port = free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world),
+                               str(port), str(blksiz), str(n_chn), str(n_frames), str(tmp_path)])
+             for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    data = np.stack([0.8 * harmonic_stack(n_frames, f0=110.0 * (1 + 0.37 * c)) +
+                     0.1 * xorshift_uniform(n_frames, seed=40 + c) for c in range(n_chn)], axis=1)
+    ref = orc.CliEngine(blksiz, n_chn)
+    ref.analyze_file(data.astype(np.float32), 0, 360, 1)
+    want = ref.peaks()
+    for r in range(world):
+        got = np.load(os.path.join(tmp_path, "peaks_%d.npy" % r))
+        assert np.array_equal(got, want)  # bit-exact: sharding cannot change a max
+
+
+def test_selection_logic_matches_oracle_main(pkg):
+    from phaserotate_lv2_amd import sweep_dist as sd
+    P, n = 2048, 40000
+    chans = [0.8 * harmonic_stack(n, f0=97.0 * (1 + 0.41 * c)) + 0.02 * xorshift_uniform(n, seed=c)
+             for c in range(2)]
+    data = np.stack(chans, axis=1).astype(np.float32)
+    for link in (False, True):
+        ma, fo, rz, rm, tbl = orc.cli_find_min(P, 2, data, stride=1, link=link)
+        mins, p_min, r_zro = sd.coarse_candidates(tbl, 1, link)
+        min_angle = [0, 0]
+        for a, chs in mins.items():  # stride 1: last candidate wins (cli/phase-rotate.cc:859-865)
+            for c in chs:
+                min_angle[c] = a
+        out, found = sd.finish_selection(min_angle, p_min)
+        assert out == ma.tolist() and [int(f) for f in found] == fo.tolist()
+        assert np.array_equal(r_zro, rz)
+    # coarse candidates of the default stride are the ones the oracle refines
+    ma24, fo24, _, _, tbl24 = orc.cli_find_min(P, 2, data, stride=24)
+    mins, _, _ = sd.coarse_candidates(tbl24, 24, False)
+    assert all(a % 24 == 0 for a in mins) and set(c for v in mins.values() for c in v) == {0, 1}

@@ -1,0 +1,285 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the
+same seeded inputs.  Tolerances: samples 2e-6 abs at
+|y| <= 1, ramp regions 1e-5, peak table 1e-3 dB, min-peak angle index exact.
+"""
+import numpy as np
+import pytest
+
+import orc
+from conftest import harmonic_stack, xorshift_uniform
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-6
+TOL_RAMP = 1e-5
+TOL_DB = 1e-3
+
+
+def db(x):
+    return 20.0 * np.log10(np.maximum(np.asarray(x, np.float64), 1e-30))
+
+
+# ------------------------------------------------------------------ FIR ---
+@pytest.mark.parametrize("kind,param,n", [(0, 2048, 2048), (0, 1024, 1024), (1, 48000, 3072)])
+def test_engine_fir_matches_reference_design(pkg, kind, param, n):
+    e = pkg.Engine(kind, param, 1)
+    f = e.fir()
+    assert f.shape == (n,)
+    ref = orc.fir_design(n)  # spectrum -> c2r -> window, as the reference does
+    assert np.abs(f - ref).max() < 2e-7
+    cf = orc.fir_closed_form(n)
+    assert np.abs(f - cf).max() < 6e-8  # the engine uses the closed form, rounded once
+    assert f[n // 2 - 1] == pytest.approx((2 / n) / np.tan(np.pi / n) * 0.5 * (1 + np.cos(2 * np.pi / n)), abs=1e-7)
+    assert f[n // 2 + 1] == -f[n // 2 - 1]
+    assert np.all(f[(np.arange(n) - n // 2) % 2 == 0] == 0)
+    e.close()
+
+
+# ------------------------------------------------------------ CLI apply ---
+@pytest.mark.parametrize("blksiz,n_chn,angles,nblk", [
+    (2048, 1, [90], 20),       # "4096-pt OLA", 45 deg
+    (2048, 1, [-61], 20),      # -30.5 deg (Q9: negative wraps by +360)
+    (2048, 2, [20, 40], 8),    # -a 10,20
+    (1024, 1, [340], 12),      # 170 deg
+    (2048, 1, [360], 4),       # +-180 deg is a no-op rotation index 0 (Q9)
+])
+def test_cli_apply_blocks(pkg, blksiz, n_chn, angles, nblk):
+    x = xorshift_uniform(blksiz * n_chn * nblk, seed=blksiz + n_chn)
+    g = pkg.PhaseRotate(blksiz, n_chn)
+    o = orc.CliEngine(blksiz, n_chn)
+    worst = 0.0
+    for b in range(nblk):
+        blk = x[b * blksiz * n_chn:(b + 1) * blksiz * n_chn]
+        yg = g.apply(blk, angles)
+        yo = o.apply(blk, angles)
+        worst = max(worst, float(np.abs(yg - yo).max()))
+    assert worst < TOL, worst
+    g.close()
+
+
+def test_cli_apply_file_matches_float64_model(pkg):
+    """y[t] = cos th x[t] + sin th (fir*x)[t + blksiz/2], th = -a pi/360."""
+    P, a = 2048, 90
+    n = P * 16
+    x = xorshift_uniform(n, seed=5)
+    g = pkg.PhaseRotate(P, 1)
+    y = g.apply_file(x, [a])
+    fir = orc.fir_closed_form(P)
+    u = np.convolve(x.astype(np.float64), fir)
+    th = -a * np.pi / 360
+    ym = np.cos(th) * x + np.sin(th) * u[P // 2:P // 2 + n]
+    assert np.abs(y - ym).max() < TOL
+    # and against the oracle's restatement of main()'s apply loop
+    yo = orc.cli_apply_file_mono(P, x, a)
+    assert np.abs(y - yo).max() < TOL
+    g.close()
+
+
+def test_cli_apply_file_ragged_length(pkg):
+    """Partial last block: the reference is broken here (Q3); we do the right thing."""
+    P, a = 2048, 180
+    n = P * 5 + 777
+    x = xorshift_uniform(n, seed=6)
+    g = pkg.PhaseRotate(P, 1)
+    y = g.apply_file(x, [a])
+    fir = orc.fir_closed_form(P)
+    u = np.convolve(x.astype(np.float64), fir)
+    th = -a * np.pi / 360
+    ym = np.cos(th) * x + np.sin(th) * u[P // 2:P // 2 + n]
+    assert np.abs(y - ym).max() < TOL
+    g.close()
+
+
+# -------------------------------------------------------------- LV2 run ---
+@pytest.mark.parametrize("rate,bufsize,angle,n_chn", [
+    (48000, 1024, 90.0, 1),    # BASELINE config 2
+    (48000, 64, -120.0, 1),
+    (48000, 4096, 180.0, 1),
+    (44100, 333, -77.0, 1),
+    (48000, 1024, (30.0, -45.0), 2),
+])
+def test_lv2_run_stream(pkg, rate, bufsize, angle, n_chn):
+    n = 20000
+    x = xorshift_uniform(n * n_chn, seed=int(rate) + bufsize).reshape(n_chn, n)
+    g = pkg.Lv2Instance(rate, n_chn)
+    g.activate()
+    o = orc.Lv2Engine(rate, n_chn)
+    assert g.latency == o.latency == 1792
+    yg = g.run_stream(x, angle, bufsize)
+    yo = o.run_stream(x, angle, bufsize)
+    d = np.abs(yg - yo)
+    ramp_end = 1792 + 2304  # Q10: first blocks ramp from 0 deg
+    assert d[:, ramp_end:].max() < TOL, d[:, ramp_end:].max()
+    assert d[:, :ramp_end].max() < TOL_RAMP, d[:, :ramp_end].max()
+    g.close()
+
+
+def test_lv2_angle_change_mid_stream(pkg):
+    n, bs = 24000, 512
+    x = xorshift_uniform(n, seed=99).reshape(1, n)
+    g = pkg.Lv2Instance(48000, 1)
+    g.activate()
+    o = orc.Lv2Engine(48000, 1)
+    yg, yo = np.empty_like(x), np.empty_like(x)
+    for s in range(0, n, bs):
+        ang = 45.0 if s < 10240 else -135.0  # 180 deg step: longest ramp, wraps
+        yg[:, s:s + bs] = g.run(x[:, s:s + bs], ang)
+        yo[:, s:s + bs] = o.run(x[:, s:s + bs], ang)
+    assert np.abs(yg - yo).max() < TOL_RAMP
+    assert np.abs(yg[:, 16000:] - yo[:, 16000:]).max() < TOL
+    g.close()
+
+
+def test_lv2_reactivate_clears_history(pkg):
+    x = xorshift_uniform(4096, seed=3).reshape(1, -1)
+    g = pkg.Lv2Instance(48000, 1)
+    g.activate()
+    g.run_stream(x, 90.0, 1024)
+    g.activate()
+    y = g.run(np.zeros((1, 1024), np.float32), 90.0)
+    assert np.abs(y).max() == 0.0
+    g.close()
+
+
+# ---------------------------------------------------------------- sweep ---
+def _signal(n, n_chn, seed):
+    chans = []
+    for c in range(n_chn):
+        h = harmonic_stack(n, f0=110.0 * (1 + 0.31 * c))
+        chans.append(0.85 * h + 0.1 * xorshift_uniform(n, seed=seed + c))
+    return np.stack(chans, axis=1).astype(np.float32).reshape(-1)  # interleaved
+
+
+@pytest.mark.parametrize("blksiz,n_chn,nblk_frac", [(2048, 1, 10.0), (2048, 2, 7.37), (1024, 1, 9.5)])
+def test_sweep_full_table(pkg, blksiz, n_chn, nblk_frac):
+    n = int(blksiz * nblk_frac)
+    data = _signal(n, n_chn, seed=11)
+    g = pkg.PhaseRotate(blksiz, n_chn)
+    g.analyze_file(data, 0, 360, 1)
+    o = orc.CliEngine(blksiz, n_chn)
+    o.analyze_file(data, 0, 360, 1)
+    pg, po = g.peaks(), o.peaks()
+    assert np.abs(db(pg) - db(po)).max() < TOL_DB
+    assert pg[:, 0].tolist() == po[:, 0].tolist()  # angle 0 is an exact abs-max (Q4)
+    for c in range(n_chn):
+        assert int(np.argmin(pg[c])) == int(np.argmin(po[c]))
+    g.close()
+
+
+def test_sweep_block_by_block_matches_oracle(pkg):
+    """PhaseRotate::analyze call for call, incl. start=True on the first block (Q1),
+    stride 24 (Q5) and a single-channel fine pass with negative angles."""
+    P, n_chn, nblk = 2048, 2, 6
+    data = _signal(P * nblk, n_chn, seed=21).reshape(nblk, P * n_chn)
+    g = pkg.PhaseRotate(P, n_chn)
+    o = orc.CliEngine(P, n_chn)
+    for b in range(nblk):
+        g.analyze(data[b], 0, 360, 24, -1, b == 0)
+        o.analyze(data[b], 0, 360, 24, -1, b == 0)
+    assert np.abs(db(g.peaks()) - db(o.peaks())).max() < TOL_DB
+    for a in range(0, 360, 24):
+        assert g.peak(-1, a) == pytest.approx(o.peaks()[:, a].max(), rel=1e-6)
+    g.reset()
+    o.reset()
+    for b in range(nblk):
+        g.analyze(data[b], -12, 13, 1, 1, b == 0)
+        o.analyze(data[b], -12, 13, 1, 1, b == 0)
+    pg, po = g.peaks(), o.peaks()
+    assert np.abs(db(pg) - db(po)).max() < TOL_DB
+    assert np.all(pg[0] == 0)  # channel 0 untouched by a chn=1 pass
+    g.close()
+
+
+def test_sweep_first_block_quirk_q1(pkg):
+    """An early impulse: dry contributions of t < blksiz/2 never enter a rotated peak."""
+    P = 2048
+    x = np.zeros(P * 3, np.float32)
+    x[5] = 0.9
+    g = pkg.PhaseRotate(P, 1)
+    g.analyze_file(x, 0, 360, 1)
+    pg = g.peaks()[0]
+    o = orc.CliEngine(P, 1)
+    o.analyze_file(x, 0, 360, 1)
+    po = o.peaks()[0]
+    assert pg[0] == np.float32(0.9)
+    assert db(pg[2]) < -35.0  # ~ -40 dB at 1 deg
+    assert np.abs(db(pg[1:]) - db(po[1:])).max() < 0.01
+    g.close()
+
+
+def test_sweep_empty_and_tiny_files(pkg):
+    P = 2048
+    g = pkg.PhaseRotate(P, 1)
+    g.analyze_file(np.zeros(0, np.float32), 0, 360, 24)
+    assert np.all(g.peaks() == 0)
+    g.reset()
+    x = xorshift_uniform(100, seed=2)
+    g.analyze_file(x, 0, 360, 1)
+    o = orc.CliEngine(P, 1)
+    o.analyze_file(x, 0, 360, 1)
+    assert np.abs(g.peaks() - o.peaks()).max() < 1e-6
+    g.close()
+
+
+# ------------------------------------------------- device-resident stream ---
+def test_apply_dev_large_stream_properties(pkg):
+    """BASELINE-size style checks through size-independent properties:
+    linearity, time-invariance across run boundaries and a 90+90 = polarity flip."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 1 << 22
+    e = pkg.Engine(pkg.KIND_LV2, 48000, 1)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = (torch.rand(n, generator=g) - 0.5).to(dev)
+    y1 = torch.empty_like(x)
+    y2 = torch.empty_like(x)
+    s, c = np.sin(-np.pi / 2), np.cos(-np.pi / 2)
+    rot = np.array([c, s], np.float32)
+    e.apply_dev(x.data_ptr(), n, n, y1.data_ptr(), n, n, rot, pkg.F_STATELESS)
+    e.apply_dev(y1.data_ptr(), n, n, y2.data_ptr(), n, n, rot, pkg.F_STATELESS)
+    e.sync()
+    # two 90-degree rotations = -x delayed by 2 * latency (band-limited error of the FIR aside)
+    L = e.info.latency
+    ref = -x[: n - 2 * L]
+    got = y2[2 * L:]
+    # the Hilbert FIR is not flat below ~50 Hz: compare energy, not samples
+    err = torch.sqrt(torch.mean((got - ref) ** 2)) / torch.sqrt(torch.mean(ref ** 2))
+    assert err.item() < 0.05
+    # linearity: A(2x) == 2 A(x) bit-exactly (power-of-two scaling)
+    x2 = 2 * x
+    y3 = torch.empty_like(x)
+    e.apply_dev(x2.data_ptr(), n, n, y3.data_ptr(), n, n, rot, pkg.F_STATELESS)
+    e.sync()
+    assert torch.equal(y3, 2 * y1)
+    # shift-invariance across workgroup-run boundaries: shifting the input by one hop
+    hop = e.info.hop
+    xs = torch.zeros_like(x)
+    xs[hop:] = x[:-hop]
+    y4 = torch.empty_like(x)
+    e.apply_dev(xs.data_ptr(), n, n, y4.data_ptr(), n, n, rot, pkg.F_STATELESS)
+    e.sync()
+    assert (y4[hop:] - y1[:-hop]).abs().max().item() < TOL
+    e.close()
+
+
+def test_apply_dev_stateful_chunks_equal_one_shot(pkg):
+    import torch
+    dev = torch.device("cuda:0")
+    n = 50000
+    e = pkg.Engine(pkg.KIND_CLI, 2048, 2)
+    x = torch.from_numpy(xorshift_uniform(2 * n, seed=8).reshape(2, n)).to(dev)
+    rot = np.array([0.6, 0.8, -0.8, 0.6], np.float32)
+    y_one = torch.empty_like(x)
+    e.apply_dev(x.data_ptr(), n, n, y_one.data_ptr(), n, n, rot, pkg.F_STATELESS)
+    y_chunks = torch.zeros_like(x)
+    pos = 0
+    for sz in (1, 1023, 2048, 4097, 10000, 32831):
+        xin = x[:, pos:pos + sz].contiguous()
+        yo = torch.empty_like(xin)
+        e.apply_dev(xin.data_ptr(), sz, sz, yo.data_ptr(), sz, sz, rot, 0)
+        e.sync()
+        y_chunks[:, pos:pos + sz] = yo
+        pos += sz
+    assert pos == n
+    assert (y_chunks - y_one).abs().max().item() < TOL
+    e.close()
