@@ -1,5 +1,5 @@
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from __graft_entry__ import load_package
 pkg = load_package()
