@@ -49,8 +49,10 @@ def build_lib(force=False, verbose=False):
     common = [hipcc, "--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall",
               "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")]
     units = [
-        # device code: fast-math lets the compiler prune the zero-padded radix-16 inputs
-        ("prot_kernels.hip", ["-ffast-math"]),
+        # device code: fast-math lets the compiler prune the zero-padded radix-16 inputs;
+        # no SLP: hipcc otherwise packs the butterflies into v_pk_*_f32 with ~500 v_mov per
+        # iteration to marshal register pairs (measured: 1500 -> 1240 VALU, 255 -> 165 VGPRs)
+        ("prot_kernels.hip", ["-ffast-math", "-fno-slp-vectorize"]),
         # host logic mirrors the reference's float arithmetic: no fast-math
         ("prot_capi.hip", []),
     ]

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -186,6 +187,7 @@ struct prot_engine {
 	int            hist_cur = 0;
 	uint64_t       pos      = 0; // frames consumed since reset (CLI stream position)
 	int            pairs_per_run_override = 0;
+	int            wg_slots = 768; // resident OLA workgroups on the device (CUs x 3)
 
 	// LV2 block-rate angle state (src/phaserotate.c:563-571, :673-717)
 	float   interp_th = 0.f, interp_nm = 0.f;
@@ -211,15 +213,26 @@ int zero_state (prot_engine* e)
 
 int pick_run_frames (const prot_engine* e, uint64_t n_out, int n_chn)
 {
-	const int     pair   = 2 * (int)e->info.hop;
-	const int64_t pairs  = (int64_t)((n_out + pair - 1) / pair);
-	int64_t       target = std::max<int64_t> (1, 2048 / std::max (1, n_chn));
-	int64_t       ppr    = (pairs + target - 1) / target;
+	// One workgroup per run.  Long streams: fill every resident-workgroup slot of the
+	// chip (CUs x 3, LDS-limited) a whole number of times so no partial last round is
+	// left, with runs long enough (<= 96 pairs) that the halo re-computation stays ~2 %.
+	const int     pair  = 2 * (int)e->info.hop;
+	const int64_t pairs = (int64_t)((n_out + pair - 1) / pair);
+	int64_t       ppr   = 1;
 	if (e->pairs_per_run_override > 0) {
 		ppr = e->pairs_per_run_override;
+	} else {
+		const int64_t slots = std::max (1, e->wg_slots);
+		for (int k = 1; k <= 64; ++k) {
+			const int64_t runs = std::max<int64_t> (1, slots * k / std::max (1, n_chn));
+			ppr                = (pairs + runs - 1) / runs;
+			if (ppr <= 96) {
+				break;
+			}
+		}
 	}
-	ppr = std::min<int64_t> (std::max<int64_t> (ppr, 1), 4096);
-	return (int)(ppr * pair);
+	ppr = std::min<int64_t> (std::max<int64_t> (ppr, 1), 1 << 20);
+	return (int)std::min<int64_t> (ppr * pair, INT_MAX / 2);
 }
 
 // core of prot_apply_dev / the Hilbert pass of the sweep
@@ -408,6 +421,12 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	e->info   = inf;
 	e->device = cfg->device;
 	e->hopseg = hopseg;
+	{
+		int cus = 0;
+		if (hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) {
+			e->wg_slots = cus * 3; // 53 KiB of LDS per workgroup -> 3 per 160 KiB CU
+		}
+	}
 	if (const char* o = getenv ("PROT_PAIRS_PER_RUN")) {
 		e->pairs_per_run_override = atoi (o);
 	}

@@ -29,6 +29,12 @@
 #include "prot_fft.h"
 #include "prot_kernels.h"
 
+#include <cstdlib>
+
+// ABL (ablation, timing experiments only -- results are wrong): 1 no LDS exchange, 2 no barriers,
+// 4 no H loads, 8 no stream loads
+#define PROT_SYNC() do { if (!(ABL & 2)) __syncthreads (); } while (0)
+
 namespace prot {
 
 // ------------------------------------------------------------------ helpers
@@ -45,12 +51,37 @@ PROT_DEV float ldv (const float* __restrict__ in, int64_t n_in, const float* __r
 
 // ------------------------------------------------------------ OLA, FFT-4096
 constexpr int kL1 = 272; // exchange between pass 1 and 2 (and inverse mirror)
-constexpr int kL2 = 257; // forward exchange 2
-constexpr int kL3 = 258; // inverse exchange A
+constexpr int kL2 = 258; // forward exchange 2 and inverse exchange A share slots (n0*kL2 + t):
+                         // conflict-free b64 reads on the inverse side, 2-way on the forward
+                         // side stores (8 vs 6 cycles) -- cheaper than the barrier it removes
+constexpr int kL3 = kL2;
 constexpr int kLdsRegion = 16 * kL1;
 
-template <int HOPSEG, int NREG>
-__global__ __launch_bounds__ (256) void ola4096_kernel (const OlaParams p)
+enum { MODE_ROT = 0, MODE_RAMP = 1, MODE_HILBERT = 2 };
+
+// the 2*HOPSEG frames thread t contributes to the hop pair whose block A reads in[iA ...]
+template <int HOPSEG>
+PROT_DEV void load_pair (float (&nx)[2 * HOPSEG], const float* __restrict__ in, int64_t n_in,
+                         const float* __restrict__ hist, int hist_len, int64_t iA, int t)
+{
+	constexpr int HOP  = HOPSEG * 256;
+	const bool    fast = (iA >= 0) && (iA + 2 * HOP <= n_in);
+	if (fast) {
+		const float* __restrict__ q = in + iA + t;
+#pragma unroll
+		for (int k = 0; k < 2 * HOPSEG; ++k) {
+			nx[k] = q[256 * k];
+		}
+	} else {
+#pragma unroll
+		for (int k = 0; k < 2 * HOPSEG; ++k) {
+			nx[k] = ldv (in, n_in, hist, hist_len, iA + t + 256 * k);
+		}
+	}
+}
+
+template <int HOPSEG, int NREG, int WAVES, int MODE, int ABL = 0>
+__global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p)
 {
 	constexpr int HOP  = HOPSEG * 256;
 	constexpr int NS   = 16 / HOPSEG;        // hop-sized segments per FFT
@@ -59,6 +90,10 @@ __global__ __launch_bounds__ (256) void ola4096_kernel (const OlaParams p)
 
 	__shared__ float2 lds[NREG][kLdsRegion];
 	__shared__ float2 twm[256];              // twm[k1*16 + n0] = W256^{n0 k1}
+	// FIR spectrum, bins 0..2048 (the FIR is real: H[4096-k] = conj H[k]).  Kept in LDS
+	// (16 KiB; 3 workgroups still fit a CU) because 32 KiB of L2 reads per hop pair from
+	// every workgroup was the largest single stall source (ablation: -28 % time at hop 2048)
+	__shared__ float2 Hs[2049];
 
 	const int     t  = threadIdx.x;
 	const int     c  = blockIdx.y;
@@ -81,9 +116,12 @@ __global__ __launch_bounds__ (256) void ola4096_kernel (const OlaParams p)
 		tw1[k] = p.tw[(t * k) & 4095];
 	}
 	twm[t] = p.tw[16 * (((t & 15) * (t >> 4)) & 255)];
+	for (int i = t; i <= 2048; i += 256) {
+		Hs[i] = p.H[i];
+	}
 
 	float ca = 0.f, sa = 1.f;
-	if (!p.hilbert_only && p.rot_s == nullptr) {
+	if (MODE == MODE_ROT) {
 		ca = p.rot[2 * c];
 		sa = p.rot[2 * c + 1];
 	}
@@ -93,44 +131,26 @@ __global__ __launch_bounds__ (256) void ola4096_kernel (const OlaParams p)
 	for (int i = 0; i < NACC; ++i) {
 		acc[i] = 0.f;
 	}
-	__syncthreads ();
 
 	const int tl = t & 15, th = t >> 4;
 	const int n_pairs = (NH + 1) / 2 + (int)((r1 - r0 + 2 * HOP - 1) / (2 * HOP));
 	int64_t   sA      = r0 - (int64_t)(NH + 1) * HOP;
 
-	for (int it = 0; it < n_pairs; ++it, sA += 2 * HOP) {
-		const int64_t sB = sA + HOP;
-		float2        v[16];
+	// software pipeline: the frames of pair it+1 are requested while pair it is
+	// in its inverse transform, so HBM latency hides behind a whole half-iteration
+	float nx[2 * HOPSEG];
+	load_pair<HOPSEG> (nx, in, n_in, hist, p.hist_len, sA - Dc, t);
+	PROT_SYNC ();
 
-		// ---- load two hops of contiguous frames (coalesced dwords) ----------
-		{
-			const int64_t iA   = sA - Dc; // first input frame of block A
-			const bool    fast = (iA >= 0) && (iA + 2 * HOP <= n_in);
-			if (fast) {
-				const float* __restrict__ q = in + iA + t;
+	for (int it = 0; it < n_pairs; ++it, sA += 2 * HOP) {
+		float2 v[16];
 #pragma unroll
-				for (int k = 0; k < HOPSEG; ++k) {
-					v[k].x = q[256 * k];
-					v[k].y = q[HOP + 256 * k];
-				}
-			} else {
+		for (int k = 0; k < HOPSEG; ++k) {
+			v[k] = make_float2 (it == 0 ? 0.f : nx[k], nx[HOPSEG + k]); // it == 0: alignment block, contributes nothing
+		}
 #pragma unroll
-				for (int k = 0; k < HOPSEG; ++k) {
-					v[k].x = ldv (in, n_in, hist, p.hist_len, iA + t + 256 * k);
-					v[k].y = ldv (in, n_in, hist, p.hist_len, iA + HOP + t + 256 * k);
-				}
-			}
-			if (it == 0) { // alignment block in front of the halo: contributes nothing
-#pragma unroll
-				for (int k = 0; k < HOPSEG; ++k) {
-					v[k].x = 0.f;
-				}
-			}
-#pragma unroll
-			for (int k = HOPSEG; k < 16; ++k) {
-				v[k] = make_float2 (0.f, 0.f); // zero padding (pruned by the compiler)
-			}
+		for (int k = HOPSEG; k < 16; ++k) {
+			v[k] = make_float2 (0.f, 0.f); // zero padding (pruned by the compiler)
 		}
 
 		// ---- forward pass 1 (over n2), twiddle W^{t k0} ---------------------
@@ -139,20 +159,19 @@ __global__ __launch_bounds__ (256) void ola4096_kernel (const OlaParams p)
 		for (int k = 1; k < 16; ++k) {
 			v[k] = cmulw<1> (v[k], tw1[k]);
 		}
-		if (NREG == 1) {
-			__syncthreads ();
-		}
 		{
-			float2* w = &lds[0][t];
+			// no barrier in front of these stores: every thread overwrites exactly the
+			// slots it read itself at the end of the previous pair (k*kL1 + t)
+			float2* w = &lds[NREG - 1][t];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
-				w[k * kL1] = v[k];
+				if (!(ABL & 1)) w[k * kL1] = v[k];
 			}
-			__syncthreads ();
-			const float2* r = &lds[0][th * kL1 + tl];
+			PROT_SYNC ();
+			const float2* r = &lds[NREG - 1][th * kL1 + tl];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
-				v[k] = r[16 * k];
+				if (!(ABL & 1)) v[k] = r[16 * k];
 			}
 		}
 		// ---- forward pass 2 (over n1), twiddle W256^{n0 k1} -----------------
@@ -162,32 +181,58 @@ __global__ __launch_bounds__ (256) void ola4096_kernel (const OlaParams p)
 			v[k] = cmulw<1> (v[k], twm[k * 16 + tl]);
 		}
 		if (NREG == 1) {
-			__syncthreads ();
+			PROT_SYNC ();
 		}
 		{
-			float2* w = &lds[NREG - 1][tl * kL2 + th];
+			float2* w = &lds[0][tl * kL2 + th];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
-				w[16 * k] = v[k];
+				if (!(ABL & 1)) w[16 * k] = v[k];
 			}
-			__syncthreads ();
-			const float2* r = &lds[NREG - 1][t];
+			PROT_SYNC ();
+			const float2* r = &lds[0][t];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
-				v[k] = r[k * kL2];
+				if (!(ABL & 1)) v[k] = r[k * kL2];
 			}
 		}
 		// ---- forward pass 3 (over n0): v[k2] = X[t + 256 k2] ----------------
 		fft16<1> (v);
 
 		// ---- x H: Hilbert FIR spectrum, 1/fftlen folded in -------------------
-		{
-			const float2* __restrict__ hp = p.H + t;
 #pragma unroll
-			for (int k = 0; k < 16; ++k) {
-				v[k] = cmulw<1> (v[k], hp[256 * k]);
+		for (int k = 0; k < 8; ++k) {
+			v[k] = cmulw<1> (v[k], (ABL & 4) ? make_float2 (0.5f + k, 0.25f) : Hs[t + 256 * k]);
+		}
+#pragma unroll
+		for (int k = 8; k < 16; ++k) { // bins >= 2048: conjugate of the mirrored bin
+			v[k] = cmulw<-1> (v[k], (ABL & 4) ? make_float2 (0.5f + k, 0.25f) : Hs[256 * (16 - k) - t]);
+		}
+
+		// ---- request the next pair's frames (after the H loads: vmcnt retires in order)
+		__builtin_amdgcn_sched_barrier (0);
+		if (it + 1 < n_pairs && !(ABL & 8)) {
+			load_pair<HOPSEG> (nx, in, n_in, hist, p.hist_len, sA + 2 * HOP - Dc, t);
+		}
+		// ... and the delayed dry frames of this pair (L2 hits: read as FFT input earlier)
+		float      dry[2 * HOPSEG];
+		const bool emit     = sA >= r0; // uniform: halo blocks emit nothing
+		const bool fast_out = (sA - Dd >= 0) && (sA + 2 * HOP <= n_in + Dd) && (sA + 2 * HOP <= r1);
+		if (MODE != MODE_HILBERT && emit) {
+			if (fast_out) {
+				const float* __restrict__ dq = in + (sA - Dd) + t;
+#pragma unroll
+				for (int k = 0; k < 2 * HOPSEG; ++k) {
+					dry[k] = (ABL & 8) ? 0.25f * k : dq[256 * k];
+				}
+			} else {
+#pragma unroll
+				for (int k = 0; k < 2 * HOPSEG; ++k) {
+					dry[k] = ldv (in, n_in, hist, p.hist_len, sA + t + 256 * k - Dd);
+				}
 			}
 		}
+		__builtin_amdgcn_sched_barrier (0);
 
 		// ---- inverse pass 1 (over k2), twiddle conj W256^{n0 k1} ------------
 		fft16<-1> (v);
@@ -195,38 +240,36 @@ __global__ __launch_bounds__ (256) void ola4096_kernel (const OlaParams p)
 		for (int k = 1; k < 16; ++k) {
 			v[k] = cmulw<-1> (v[k], twm[th * 16 + k]);
 		}
-		if (NREG == 1) {
-			__syncthreads ();
-		}
 		{
+			// no barrier: same slots this thread read in forward exchange 2
 			float2* w = &lds[0][t];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
-				w[k * kL3] = v[k];
+				if (!(ABL & 1)) w[k * kL3] = v[k];
 			}
-			__syncthreads ();
+			PROT_SYNC ();
 			const float2* r = &lds[0][tl * kL3 + th];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
-				v[k] = r[16 * k];
+				if (!(ABL & 1)) v[k] = r[16 * k];
 			}
 		}
 		// ---- inverse pass 2 (over k1) ----------------------------------------
 		fft16<-1> (v);
 		if (NREG == 1) {
-			__syncthreads ();
+			PROT_SYNC ();
 		}
 		{
 			float2* w = &lds[NREG - 1][th * kL1 + tl];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
-				w[16 * k] = v[k];
+				if (!(ABL & 1)) w[16 * k] = v[k];
 			}
-			__syncthreads ();
+			PROT_SYNC ();
 			const float2* r = &lds[NREG - 1][t];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
-				v[k] = r[k * kL1];
+				if (!(ABL & 1)) v[k] = r[k * kL1];
 			}
 		}
 		// ---- twiddle conj W^{t k0}, inverse pass 3 (over k0) -----------------
@@ -238,13 +281,13 @@ __global__ __launch_bounds__ (256) void ola4096_kernel (const OlaParams p)
 		// v[k].x = (fir * A)[t + 256k], v[k].y = (fir * B)[t + 256k]
 
 		// ---- overlap-add in registers ----------------------------------------
-		float uA[HOPSEG], uB[HOPSEG];
+		float u[2 * HOPSEG];
 #pragma unroll
 		for (int j = 0; j < HOPSEG; ++j) {
-			uA[j] = acc[j] + v[j].x;
-			uB[j] = v[HOPSEG + j].x + v[j].y;
+			u[j]          = acc[j] + v[j].x;
+			u[HOPSEG + j] = v[HOPSEG + j].x + v[j].y;
 			if (NS > 2) {
-				uB[j] += acc[HOPSEG + j];
+				u[HOPSEG + j] += acc[HOPSEG + j];
 			}
 		}
 #pragma unroll
@@ -263,34 +306,80 @@ __global__ __launch_bounds__ (256) void ola4096_kernel (const OlaParams p)
 		}
 
 		// ---- rotate and store --------------------------------------------------
-		if (sA >= r0) { // uniform: halo blocks emit nothing
-			const bool fast = (!p.hilbert_only) && (sA - Dd >= 0) && (sA + 2 * HOP <= n_in + Dd) && (sA + 2 * HOP <= r1);
+		if (emit) {
+			if (MODE == MODE_HILBERT) {
 #pragma unroll
-			for (int h = 0; h < 2; ++h) {
+				for (int k = 0; k < 2 * HOPSEG; ++k) {
+					const int64_t pos = sA + t + 256 * k;
+					if (pos < r1) {
+						out[pos] = u[k];
+					}
+				}
+			} else if (MODE == MODE_ROT && fast_out) {
+				float* __restrict__ oq = out + sA + t;
 #pragma unroll
-				for (int j = 0; j < HOPSEG; ++j) {
-					const int64_t pos = sA + h * HOP + t + 256 * j;
-					const float   u   = h ? uB[j] : uA[j];
-					if (p.hilbert_only) {
-						if (pos < r1) {
-							out[pos] = u;
-						}
-					} else if (fast && p.rot_s == nullptr) {
-						out[pos] = ca * in[pos - Dd] + sa * u;
-					} else if (pos < r1) {
-						const float dry = ldv (in, n_in, hist, p.hist_len, pos - Dd);
-						float       cc = ca, ss = sa;
-						if (p.rot_s != nullptr) {
+				for (int k = 0; k < 2 * HOPSEG; ++k) {
+					oq[256 * k] = ca * dry[k] + sa * u[k];
+				}
+			} else {
+#pragma unroll
+				for (int k = 0; k < 2 * HOPSEG; ++k) {
+					const int64_t pos = sA + t + 256 * k;
+					if (pos < r1) {
+						float cc = ca, ss = sa;
+						if (MODE == MODE_RAMP) {
 							const float2 cs = reinterpret_cast<const float2*> (p.rot_s)[(int64_t)c * p.n_out + pos];
 							cc              = cs.x;
 							ss              = cs.y;
 						}
-						out[pos] = cc * dry + ss * u;
+						out[pos] = cc * dry[k] + ss * u[k];
 					}
 				}
 			}
 		}
 	}
+}
+
+// PROT_OLA_VARIANT (debug/tuning only): 0 = default
+static int ola_variant ()
+{
+	static int v = -1;
+	if (v < 0) {
+		const char* e = getenv ("PROT_OLA_VARIANT");
+		v             = e ? atoi (e) : 0;
+	}
+	return v;
+}
+
+template <int HOPSEG, int MODE>
+static hipError_t launch_ola4096_m (const OlaParams& p, dim3 grid, hipStream_t s)
+{
+	dim3 block (256);
+	switch (ola_variant ()) {
+		case 1: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 2, MODE>), grid, block, 0, s, p); break;
+		case 2: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 2, 2, MODE>), grid, block, 0, s, p); break;
+		case 4: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 4, MODE>), grid, block, 0, s, p); break;
+		case 11: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 1>), grid, block, 0, s, p); break;
+		case 12: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 2>), grid, block, 0, s, p); break;
+		case 13: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 3>), grid, block, 0, s, p); break;
+		case 14: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 4>), grid, block, 0, s, p); break;
+		case 18: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 8>), grid, block, 0, s, p); break;
+		case 25: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 15>), grid, block, 0, s, p); break;
+		default: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE>), grid, block, 0, s, p); break;
+	}
+	return hipGetLastError ();
+}
+
+template <int HOPSEG>
+static hipError_t launch_ola4096_t (const OlaParams& p, dim3 grid, hipStream_t s)
+{
+	if (p.hilbert_only) {
+		return launch_ola4096_m<HOPSEG, MODE_HILBERT> (p, grid, s);
+	}
+	if (p.rot_s != nullptr) {
+		return launch_ola4096_m<HOPSEG, MODE_RAMP> (p, grid, s);
+	}
+	return launch_ola4096_m<HOPSEG, MODE_ROT> (p, grid, s);
 }
 
 hipError_t launch_ola4096 (const OlaParams& p, int hopseg, int n_chn, hipStream_t s)
@@ -299,15 +388,13 @@ hipError_t launch_ola4096 (const OlaParams& p, int hopseg, int n_chn, hipStream_
 		return hipSuccess;
 	}
 	const int64_t runs = (p.n_out + p.run_frames - 1) / p.run_frames;
-	dim3          grid ((unsigned)runs, (unsigned)n_chn), block (256);
+	dim3          grid ((unsigned)runs, (unsigned)n_chn);
 	if (hopseg == 4) {
-		hipLaunchKernelGGL ((ola4096_kernel<4, 1>), grid, block, 0, s, p);
+		return launch_ola4096_t<4> (p, grid, s);
 	} else if (hopseg == 8) {
-		hipLaunchKernelGGL ((ola4096_kernel<8, 1>), grid, block, 0, s, p);
-	} else {
-		return hipErrorInvalidValue;
+		return launch_ola4096_t<8> (p, grid, s);
 	}
-	return hipGetLastError ();
+	return hipErrorInvalidValue;
 }
 
 hipError_t launch_ola8192 (const OlaParams&, int, int, hipStream_t)
