@@ -143,6 +143,11 @@ int prot_engine_sync (prot_engine* e);
 int prot_lv2_run (prot_engine* e, const float* const* in, float* const* out,
                   uint32_t n_samples, const float* angle_deg);
 
+/* Channel.angle (src/phaserotate.c:53, :560, :725): the interpolated rotation
+ * state in turns after the last run; the host compares it with the port's
+ * target to arm its delayed meter reset (src/phaserotate.c:611). */
+int prot_lv2_get_angle (prot_engine* e, uint32_t chn, float* angle_turns);
+
 /* PhaseRotate::apply (cli/phase-rotate.cc:467-485): one interleaved block of
  * blksiz frames, processed in place; angles are half-degree indices, reduced
  * (a + 360) % 360 exactly as :463 (Q9). */

@@ -29,7 +29,7 @@ ABI_SYMBOLS = (
     "prot_engine_create", "prot_engine_destroy", "prot_engine_reset", "prot_engine_info",
     "prot_engine_fir", "prot_engine_sync",
     "prot_apply_dev", "prot_apply_dev_ramp", "prot_sweep_dev",
-    "prot_lv2_run", "prot_cli_apply", "prot_cli_analyze", "prot_cli_analyze_file",
+    "prot_lv2_run", "prot_lv2_get_angle", "prot_cli_apply", "prot_cli_analyze", "prot_cli_analyze_file",
     "prot_cli_apply_file", "prot_cli_peak", "prot_cli_peak_all", "prot_cli_peaks",
     "prot_cli_peaks_dev",
 )
@@ -104,6 +104,7 @@ def load_library():
                                    C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.prot_lv2_run.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                  C.c_uint32, _f32p]
+    lib.prot_lv2_get_angle.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
     lib.prot_cli_apply.argtypes = [C.c_void_p, _f32p, _i32p]
     lib.prot_cli_analyze.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.prot_cli_analyze_file.argtypes = [C.c_void_p, _f32p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int]

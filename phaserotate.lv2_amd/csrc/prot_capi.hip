@@ -914,6 +914,15 @@ int prot_lv2_run (prot_engine* e, const float* const* in, float* const* out, uin
 	return PROT_OK;
 }
 
+int prot_lv2_get_angle (prot_engine* e, uint32_t chn, float* angle_turns)
+{
+	if (!e || !angle_turns || e->info.kind != PROT_KIND_LV2 || chn >= e->lv2.size ()) {
+		return PROT_EINVAL;
+	}
+	*angle_turns = e->lv2[chn].angle;
+	return PROT_OK;
+}
+
 int prot_cli_apply (prot_engine* e, float* buf, const int* angles)
 {
 	if (!e || !buf || !angles || e->info.kind != PROT_KIND_CLI) {

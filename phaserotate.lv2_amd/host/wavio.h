@@ -1,0 +1,214 @@
+// wavio.h -- minimal RIFF/WAVE reader/writer for the phase-rotate CLI.
+//
+// Stands where libsndfile stands in the reference (sf_open / sf_readf_float /
+// sf_writef_float, cli/phase-rotate.cc:683-702, :565-587, :950-1003): PCM
+// 16/24/32-bit and IEEE float 32/64-bit, plain or WAVE_FORMAT_EXTENSIBLE,
+// any channel count.  The output file takes the input's format (the reference
+// copies SF_INFO, :697).  Sample conversion follows libsndfile's defaults:
+// integer PCM <-> float by 2^(bits-1) on read and (2^(bits-1) - 1) on write.
+// Metadata chunks (cue, bext, LIST) are not copied (copy_metadata, :541-563,
+// is outside the hot path).
+#pragma once
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace wavio {
+
+struct Info {
+	uint32_t samplerate = 0;
+	uint16_t channels   = 0;
+	uint16_t bits       = 0;     // container bits per sample
+	bool     is_float   = false;
+	uint64_t frames     = 0;
+};
+
+inline uint32_t rd32 (const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline uint16_t rd16 (const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+// Reads the whole file as interleaved float32.  Returns "" on success, else an error text.
+inline std::string read_file (const char* path, Info& nfo, std::vector<float>& data)
+{
+	FILE* f = fopen (path, "rb");
+	if (!f) {
+		return std::string ("System error : ") + strerror (errno) + ".";
+	}
+	uint8_t hdr[12];
+	if (fread (hdr, 1, 12, f) != 12 || memcmp (hdr, "RIFF", 4) || memcmp (hdr + 8, "WAVE", 4)) {
+		fclose (f);
+		return "File contains data in an unknown format.";
+	}
+	bool     have_fmt = false;
+	uint16_t tag      = 0;
+	for (;;) {
+		uint8_t ch[8];
+		if (fread (ch, 1, 8, f) != 8) {
+			break;
+		}
+		uint32_t sz = rd32 (ch + 4);
+		if (!memcmp (ch, "fmt ", 4)) {
+			std::vector<uint8_t> b (sz);
+			if (sz < 16 || fread (b.data (), 1, sz, f) != sz) {
+				break;
+			}
+			tag            = rd16 (&b[0]);
+			nfo.channels   = rd16 (&b[2]);
+			nfo.samplerate = rd32 (&b[4]);
+			nfo.bits       = rd16 (&b[14]);
+			if (tag == 0xFFFE && sz >= 26) {
+				tag = rd16 (&b[24]); // sub-format GUID starts with the plain tag
+			}
+			nfo.is_float = (tag == 3);
+			have_fmt     = (tag == 1 || tag == 3) && nfo.channels > 0;
+			if (sz & 1) {
+				fseek (f, 1, SEEK_CUR);
+			}
+		} else if (!memcmp (ch, "data", 4)) {
+			if (!have_fmt) {
+				break;
+			}
+			const uint32_t bps = nfo.bits / 8;
+			if (!((nfo.is_float && (bps == 4 || bps == 8)) || (!nfo.is_float && (bps == 2 || bps == 3 || bps == 4)))) {
+				fclose (f);
+				return "Unsupported sample format.";
+			}
+			long here = ftell (f);
+			fseek (f, 0, SEEK_END);
+			long end = ftell (f);
+			fseek (f, here, SEEK_SET);
+			uint64_t avail = (uint64_t)(end - here);
+			uint64_t bytes = sz == 0xFFFFFFFFu || sz > avail ? avail : sz;
+			nfo.frames     = bytes / ((uint64_t)bps * nfo.channels);
+			const uint64_t n = nfo.frames * nfo.channels;
+			data.resize (n);
+			std::vector<uint8_t> raw ((size_t)1 << 20);
+			uint64_t done = 0;
+			while (done < n) {
+				const uint64_t want = std::min<uint64_t> ((raw.size () / bps), n - done);
+				if (fread (raw.data (), bps, want, f) != want) {
+					fclose (f);
+					return "Unexpected end of file.";
+				}
+				const uint8_t* p = raw.data ();
+				for (uint64_t i = 0; i < want; ++i, p += bps) {
+					float v;
+					if (nfo.is_float) {
+						if (bps == 4) {
+							memcpy (&v, p, 4);
+						} else {
+							double d;
+							memcpy (&d, p, 8);
+							v = (float)d;
+						}
+					} else if (bps == 2) {
+						v = (float)(int16_t)rd16 (p) / 32768.f;
+					} else if (bps == 3) {
+						int32_t s = (int32_t)((uint32_t)p[0] << 8 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 24);
+						v         = (float)s / 2147483648.f;
+					} else {
+						v = (float)(int32_t)rd32 (p) / 2147483648.f;
+					}
+					data[done + i] = v;
+				}
+				done += want;
+			}
+			fclose (f);
+			return "";
+		} else {
+			fseek (f, (long)(sz + (sz & 1)), SEEK_CUR);
+		}
+	}
+	fclose (f);
+	return "File contains data in an unknown format.";
+}
+
+class Writer
+{
+public:
+	// "" on success
+	std::string open (const char* path, const Info& nfo)
+	{
+		_nfo = nfo;
+		_f   = fopen (path, "wb");
+		if (!_f) {
+			return std::string ("System error : ") + strerror (errno) + ".";
+		}
+		uint8_t h[44];
+		memset (h, 0, sizeof (h));
+		fwrite (h, 1, 44, _f); // patched in close()
+		return "";
+	}
+
+	// returns frames written
+	uint64_t writef (const float* buf, uint64_t frames)
+	{
+		const uint32_t bps = _nfo.bits / 8;
+		const uint64_t n   = frames * _nfo.channels;
+		std::vector<uint8_t> raw (n * bps);
+		uint8_t* p = raw.data ();
+		for (uint64_t i = 0; i < n; ++i, p += bps) {
+			const float v = buf[i];
+			if (_nfo.is_float) {
+				if (bps == 4) {
+					memcpy (p, &v, 4);
+				} else {
+					const double d = v;
+					memcpy (p, &d, 8);
+				}
+			} else {
+				double  scale = bps == 2 ? 32767.0 : (bps == 3 ? 8388607.0 : 2147483647.0);
+				double  s     = std::nearbyint ((double)v * scale);
+				s             = std::min (std::max (s, -scale - 1.0), scale);
+				int32_t q     = (int32_t)s;
+				for (uint32_t b = 0; b < bps; ++b) {
+					p[b] = (uint8_t)((uint32_t)q >> (8 * b));
+				}
+			}
+		}
+		const uint64_t w = fwrite (raw.data (), (size_t)bps * _nfo.channels, frames, _f);
+		_frames += w;
+		return w;
+	}
+
+	void close ()
+	{
+		if (!_f) {
+			return;
+		}
+		const uint32_t bps  = _nfo.bits / 8;
+		const uint64_t data = _frames * bps * _nfo.channels;
+		uint8_t        h[44];
+		auto w32 = [] (uint8_t* p, uint32_t v) { p[0] = v; p[1] = v >> 8; p[2] = v >> 16; p[3] = v >> 24; };
+		auto w16 = [] (uint8_t* p, uint16_t v) { p[0] = v; p[1] = v >> 8; };
+		memcpy (h, "RIFF", 4);
+		w32 (h + 4, (uint32_t)std::min<uint64_t> (36 + data, 0xFFFFFFFFu));
+		memcpy (h + 8, "WAVEfmt ", 8);
+		w32 (h + 16, 16);
+		w16 (h + 20, _nfo.is_float ? 3 : 1);
+		w16 (h + 22, _nfo.channels);
+		w32 (h + 24, _nfo.samplerate);
+		w32 (h + 28, _nfo.samplerate * bps * _nfo.channels);
+		w16 (h + 32, (uint16_t)(bps * _nfo.channels));
+		w16 (h + 34, _nfo.bits);
+		memcpy (h + 36, "data", 4);
+		w32 (h + 40, (uint32_t)std::min<uint64_t> (data, 0xFFFFFFFFu));
+		fseek (_f, 0, SEEK_SET);
+		fwrite (h, 1, 44, _f);
+		fclose (_f);
+		_f = nullptr;
+	}
+
+	~Writer () { close (); }
+
+private:
+	FILE*    _f = nullptr;
+	Info     _nfo;
+	uint64_t _frames = 0;
+};
+
+} // namespace wavio
