@@ -48,7 +48,7 @@ typedef struct {
 	double   param;   /* CLI: blksiz (power of two 1024..32768); LV2: sample rate */
 	uint32_t n_chn;   /* channel-streams (LV2: 1..2 via the plugin; engine itself: 1..65535) */
 	int32_t  device;  /* HIP device ordinal */
-	uint32_t fftlen;  /* 0 = smallest supported (4096 or 8192) */
+	uint32_t fftlen;  /* 0 or 4096: the device transform length */
 	uint32_t flags;   /* reserved, 0 */
 } prot_config;
 
@@ -63,6 +63,7 @@ typedef struct {
 	uint32_t conv_delay;  /* extra delay in front of the FIR */
 	uint32_t history;     /* input frames of state kept per channel */
 	uint32_t blksiz;      /* CLI: parsiz; LV2: reference parsiz (ramp granularity) */
+	uint32_t partitions;  /* FIR partitions of <= fftlen/2 taps convolved per hop (1 if firlen <= 3072) */
 } prot_info;
 
 typedef struct prot_engine prot_engine;

@@ -48,7 +48,7 @@ class Info(C.Structure):
     _fields_ = [("kind", C.c_int32), ("n_chn", C.c_uint32), ("fftlen", C.c_uint32),
                 ("hop", C.c_uint32), ("firlen", C.c_uint32), ("latency", C.c_uint32),
                 ("dry_delay", C.c_uint32), ("conv_delay", C.c_uint32), ("history", C.c_uint32),
-                ("blksiz", C.c_uint32)]
+                ("blksiz", C.c_uint32), ("partitions", C.c_uint32)]
 
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")

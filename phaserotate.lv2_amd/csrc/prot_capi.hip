@@ -179,6 +179,7 @@ struct prot_engine {
 	int         hopseg  = 0;
 	hipStream_t stream  = nullptr;
 	std::vector<float> fir;
+	uint32_t    part_len = 0; // taps per FIR partition
 
 	DevBuf<float2> d_H, d_tw;
 	DevBuf<float>  d_lut, d_rot, d_hist[2], d_peaks, d_in, d_out, d_u, d_inter, d_rot_s;
@@ -249,18 +250,20 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 	p.out          = d_out + (int64_t)chn0 * out_stride;
 	p.out_stride   = out_stride;
 	p.n_out        = (int64_t)n_out;
-	p.H            = e->d_H.p;
 	p.tw           = e->d_tw.p;
 	p.rot          = d_rot ? d_rot + 2 * chn0 : nullptr;
 	p.rot_s        = d_rot_s ? d_rot_s + 2 * (int64_t)chn0 * (int64_t)n_out : nullptr;
 	p.run_frames   = pick_run_frames (e, n_out, n_chn);
-	p.conv_delay   = (int)e->info.conv_delay;
 	p.dry_delay    = (int)e->info.dry_delay;
 	p.hilbert_only = hilbert_only ? 1 : 0;
-	hipError_t err = e->info.fftlen == 4096 ? prot::launch_ola4096 (p, e->hopseg, n_chn, s)
-	                                        : prot::launch_ola8192 (p, e->hopseg, n_chn, s);
-	if (err != hipSuccess) {
-		return hip_fail (err, "ola kernel launch");
+	for (uint32_t sp = 0; sp < e->info.partitions; ++sp) {
+		p.H          = e->d_H.p + (size_t)sp * e->info.fftlen;
+		p.conv_delay = (int)(e->info.conv_delay + sp * e->part_len);
+		p.accumulate = sp > 0;
+		hipError_t err = prot::launch_ola4096 (p, e->hopseg, n_chn, s);
+		if (err != hipSuccess) {
+			return hip_fail (err, "ola kernel launch");
+		}
 	}
 	return PROT_OK;
 }
@@ -379,24 +382,36 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 		st = PROT_EINVAL;
 		return nullptr;
 	}
-	// device OLA geometry: smallest supported power-of-two FFT that holds
-	// firlen + hop - 1 with hop a multiple of fftlen/16
-	uint32_t F = cfg->fftlen ? cfg->fftlen : (inf.firlen <= 3072 ? 4096u : 8192u);
-	if (F != 4096) { // the 8192-point workgroup kernel is not built yet
+	// device OLA geometry.  One 4096-point FFT per hop pair; FIRs of up to 3072 taps
+	// fit one transform (hop = 4096 - 3072 = 1024, or 2048 for <= 2049 taps).  Longer
+	// FIRs (CLI blksiz >= 4096, LV2 >= 64 kHz) are split into 2048-tap partitions, each
+	// convolved with hop 2048 and delayed by 2048 frames more than the one before; the
+	// partial Hilbert branches add up in the output (uniformly partitioned OLA, the
+	// scheme the reference's own LV2 engine uses with 256..1024-frame partitions,
+	// src/phaserotate.c:640-655).
+	const uint32_t F = 4096;
+	if (cfg->fftlen != 0 && cfg->fftlen != F) {
 		st = PROT_EUNSUPPORTED;
-		snprintf (g_err, sizeof (g_err), "fftlen %u (firlen %u) not supported yet; only 4096", F, inf.firlen);
-		return nullptr;
-	}
-	if (inf.firlen > F - F / 4) {
-		st = PROT_EUNSUPPORTED;
+		snprintf (g_err, sizeof (g_err), "fftlen %u not supported; the device transform is 4096 points", cfg->fftlen);
 		return nullptr;
 	}
 	const uint32_t seg = F / 16;
-	int hopseg = (inf.firlen - 1 <= F / 2) ? 8 : 4;  // hop = F/2 or F/4
-	inf.fftlen  = F;
-	inf.hop     = hopseg * seg;
-	// history: conv delay + the halo the OLA run start reaches back, and the dry delay
-	uint32_t H = inf.conv_delay + (F / inf.hop) * inf.hop;
+	int      hopseg;
+	uint32_t n_part, part_len;
+	if (inf.firlen <= F - F / 4) {
+		n_part   = 1;
+		part_len = inf.firlen;
+		hopseg   = (inf.firlen - 1 <= F / 2) ? 8 : 4; // hop = F/2 or F/4
+	} else {
+		part_len = F / 2;
+		n_part   = (inf.firlen + part_len - 1) / part_len;
+		hopseg   = 8;
+	}
+	inf.fftlen     = F;
+	inf.hop        = hopseg * seg;
+	inf.partitions = n_part;
+	// history: conv delay (+ partition delays) + the halo the OLA run start reaches back, and the dry delay
+	uint32_t H = inf.conv_delay + (n_part - 1) * part_len + F;
 	H          = std::max (H, inf.dry_delay);
 	inf.history = (H + 255) & ~255u;
 
@@ -444,26 +459,31 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	// FIR -> spectrum / F (the 1/fftlen of the OLA c2r, cli/phase-rotate.cc:142,
 	// src/phaserotate.c:393, folded into the table)
 	fir_design ((int)inf.firlen, e->fir);
-	std::vector<double> re (F, 0.0), im (F, 0.0);
-	for (uint32_t i = 0; i < inf.firlen; ++i) {
-		re[i] = e->fir[i];
+	e->part_len = part_len;
+	std::vector<float2> H_h ((size_t)F * n_part), tw_h (F);
+	for (uint32_t sp = 0; sp < n_part; ++sp) {
+		std::vector<double> re (F, 0.0), im (F, 0.0);
+		for (uint32_t i = 0; i < part_len && sp * part_len + i < inf.firlen; ++i) {
+			re[i] = e->fir[sp * part_len + i];
+		}
+		fft_f64 (re, im);
+		for (uint32_t k = 0; k < F; ++k) {
+			H_h[(size_t)sp * F + k] = make_float2 ((float)(re[k] / F), (float)(im[k] / F));
+		}
 	}
-	fft_f64 (re, im);
-	std::vector<float2> H_h (F), tw_h (F);
 	for (uint32_t k = 0; k < F; ++k) {
-		H_h[k] = make_float2 ((float)(re[k] / F), (float)(im[k] / F));
 		const double a = -2.0 * M_PI * (double)k / (double)F;
 		tw_h[k] = make_float2 ((float)std::cos (a), (float)std::sin (a));
 	}
 	const size_t hn = (size_t)inf.history * inf.n_chn;
 	int rc;
-	if ((rc = e->d_H.ensure (F)) || (rc = e->d_tw.ensure (F)) || (rc = e->d_lut.ensure (PROT_MAXSAMPLE * 2)) ||
+	if ((rc = e->d_H.ensure ((size_t)F * n_part)) || (rc = e->d_tw.ensure (F)) || (rc = e->d_lut.ensure (PROT_MAXSAMPLE * 2)) ||
 	    (rc = e->d_rot.ensure (2 * (size_t)inf.n_chn)) || (rc = e->d_hist[0].ensure (hn)) ||
 	    (rc = e->d_hist[1].ensure (hn)) || (rc = e->d_peaks.ensure ((size_t)PROT_MAXSAMPLE * inf.n_chn)) ||
 	    (rc = e->d_angles.ensure (PROT_MAXSAMPLE + 8))) {
 		return fail (rc);
 	}
-	if (hipMemcpy (e->d_H.p, H_h.data (), F * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess ||
+	if (hipMemcpy (e->d_H.p, H_h.data (), H_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMemcpy (e->d_tw.p, tw_h.data (), F * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMemcpy (e->d_lut.p, g_lut, sizeof (g_lut), hipMemcpyHostToDevice) != hipSuccess) {
 		return fail (PROT_EHIP);

@@ -27,12 +27,11 @@ struct OlaParams {
 	int32_t       conv_delay; // Dc
 	int32_t       dry_delay;  // Dd
 	int32_t       hilbert_only;
+	int32_t       accumulate; // add sa*u to out instead of storing ca*dry + sa*u (FIR partitions > 0)
 };
 
 // fftlen 4096; hop = 256 * hopseg, hopseg in {4, 8}
 hipError_t launch_ola4096 (const OlaParams& p, int hopseg, int n_chn, hipStream_t s);
-// fftlen 8192; hop = 512 * hopseg, hopseg in {4, 8}   (512-thread workgroups)
-hipError_t launch_ola8192 (const OlaParams& p, int hopseg, int n_chn, hipStream_t s);
 
 // Rotated abs-max sweep over t in [t_begin, t_end) of one chunk:
 //   v = ca[a] * (t_abs >= dry_from ? x[t - delay] : 0) + sa[a] * u[t]

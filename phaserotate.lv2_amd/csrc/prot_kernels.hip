@@ -80,7 +80,7 @@ PROT_DEV void load_pair (float (&nx)[2 * HOPSEG], const float* __restrict__ in, 
 	}
 }
 
-template <int HOPSEG, int NREG, int WAVES, int MODE, int ABL = 0>
+template <int HOPSEG, int NREG, int WAVES, int MODE, int ABL = 0, bool ACC = false>
 __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p)
 {
 	constexpr int HOP  = HOPSEG * 256;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 		float      dry[2 * HOPSEG];
 		const bool emit     = sA >= r0; // uniform: halo blocks emit nothing
 		const bool fast_out = (sA - Dd >= 0) && (sA + 2 * HOP <= n_in + Dd) && (sA + 2 * HOP <= r1);
-		if (MODE != MODE_HILBERT && emit) {
+		if (MODE != MODE_HILBERT && !ACC && emit) {
 			if (fast_out) {
 				const float* __restrict__ dq = in + (sA - Dd) + t;
 #pragma unroll
@@ -306,20 +306,22 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 		}
 
 		// ---- rotate and store --------------------------------------------------
+		// ACC: a later FIR partition adds its share of the Hilbert branch to what the
+		// first partition stored (partitioned convolution for FIRs longer than one FFT)
 		if (emit) {
 			if (MODE == MODE_HILBERT) {
 #pragma unroll
 				for (int k = 0; k < 2 * HOPSEG; ++k) {
 					const int64_t pos = sA + t + 256 * k;
 					if (pos < r1) {
-						out[pos] = u[k];
+						out[pos] = ACC ? out[pos] + u[k] : u[k];
 					}
 				}
 			} else if (MODE == MODE_ROT && fast_out) {
 				float* __restrict__ oq = out + sA + t;
 #pragma unroll
 				for (int k = 0; k < 2 * HOPSEG; ++k) {
-					oq[256 * k] = ca * dry[k] + sa * u[k];
+					oq[256 * k] = ACC ? oq[256 * k] + sa * u[k] : ca * dry[k] + sa * u[k];
 				}
 			} else {
 #pragma unroll
@@ -332,7 +334,7 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 							cc              = cs.x;
 							ss              = cs.y;
 						}
-						out[pos] = cc * dry[k] + ss * u[k];
+						out[pos] = ACC ? out[pos] + ss * u[k] : cc * dry[k] + ss * u[k];
 					}
 				}
 			}
@@ -355,15 +357,13 @@ template <int HOPSEG, int MODE>
 static hipError_t launch_ola4096_m (const OlaParams& p, dim3 grid, hipStream_t s)
 {
 	dim3 block (256);
+	if (p.accumulate) {
+		hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, true>), grid, block, 0, s, p);
+		return hipGetLastError ();
+	}
 	switch (ola_variant ()) {
 		case 1: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 2, MODE>), grid, block, 0, s, p); break;
-		case 2: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 2, 2, MODE>), grid, block, 0, s, p); break;
-		case 4: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 4, MODE>), grid, block, 0, s, p); break;
-		case 11: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 1>), grid, block, 0, s, p); break;
 		case 12: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 2>), grid, block, 0, s, p); break;
-		case 13: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 3>), grid, block, 0, s, p); break;
-		case 14: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 4>), grid, block, 0, s, p); break;
-		case 18: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 8>), grid, block, 0, s, p); break;
 		case 25: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 15>), grid, block, 0, s, p); break;
 		default: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE>), grid, block, 0, s, p); break;
 	}
@@ -395,11 +395,6 @@ hipError_t launch_ola4096 (const OlaParams& p, int hopseg, int n_chn, hipStream_
 		return launch_ola4096_t<8> (p, grid, s);
 	}
 	return hipErrorInvalidValue;
-}
-
-hipError_t launch_ola8192 (const OlaParams&, int, int, hipStream_t)
-{
-	return hipErrorNotSupported;
 }
 
 // ------------------------------------------------------------------- sweep

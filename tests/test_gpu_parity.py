@@ -20,7 +20,8 @@ def db(x):
 
 
 # ------------------------------------------------------------------ FIR ---
-@pytest.mark.parametrize("kind,param,n", [(0, 2048, 2048), (0, 1024, 1024), (1, 48000, 3072)])
+@pytest.mark.parametrize("kind,param,n", [(0, 2048, 2048), (0, 1024, 1024), (1, 48000, 3072),
+                                          (0, 8192, 8192), (1, 96000, 4096), (1, 192000, 8192)])
 def test_engine_fir_matches_reference_design(pkg, kind, param, n):
     e = pkg.Engine(kind, param, 1)
     f = e.fir()
@@ -42,6 +43,10 @@ def test_engine_fir_matches_reference_design(pkg, kind, param, n):
     (2048, 2, [20, 40], 8),    # -a 10,20
     (1024, 1, [340], 12),      # 170 deg
     (2048, 1, [360], 4),       # +-180 deg is a no-op rotation index 0 (Q9)
+    (4096, 1, [180], 9),       # "8192-pt FFT" in the reference = 2 FIR partitions here
+    (8192, 2, [340, -100], 6), # CLI default at 48 kHz = 4 partitions
+    (16384, 1, [77], 4),       # CLI default at 96 kHz = 8 partitions
+    (32768, 1, [-359], 3),     # largest block the CLI accepts = 16 partitions
 ])
 def test_cli_apply_blocks(pkg, blksiz, n_chn, angles, nblk):
     x = xorshift_uniform(blksiz * n_chn * nblk, seed=blksiz + n_chn)
@@ -97,18 +102,21 @@ def test_cli_apply_file_ragged_length(pkg):
     (48000, 4096, 180.0, 1),
     (44100, 333, -77.0, 1),
     (48000, 1024, (30.0, -45.0), 2),
+    (96000, 1024, 45.0, 1),             # 4096-tap FIR: 2 partitions (BASELINE config 3 filter)
+    (96000, 256, (10.0, -170.0), 2),
+    (192000, 333, -77.0, 1),            # 8192-tap FIR: 4 partitions
 ])
 def test_lv2_run_stream(pkg, rate, bufsize, angle, n_chn):
-    n = 20000
+    n = 20000 if rate < 64000 else 40000
     x = xorshift_uniform(n * n_chn, seed=int(rate) + bufsize).reshape(n_chn, n)
     g = pkg.Lv2Instance(rate, n_chn)
     g.activate()
     o = orc.Lv2Engine(rate, n_chn)
-    assert g.latency == o.latency == 1792
+    assert g.latency == o.latency == {48000: 1792, 44100: 1792, 96000: 2560, 192000: 5120}[rate]
     yg = g.run_stream(x, angle, bufsize)
     yo = o.run_stream(x, angle, bufsize)
     d = np.abs(yg - yo)
-    ramp_end = 1792 + 2304  # Q10: first blocks ramp from 0 deg
+    ramp_end = g.latency + 2304  # Q10: first blocks ramp from 0 deg
     assert d[:, ramp_end:].max() < TOL, d[:, ramp_end:].max()
     assert d[:, :ramp_end].max() < TOL_RAMP, d[:, :ramp_end].max()
     g.close()
@@ -150,7 +158,8 @@ def _signal(n, n_chn, seed):
     return np.stack(chans, axis=1).astype(np.float32).reshape(-1)  # interleaved
 
 
-@pytest.mark.parametrize("blksiz,n_chn,nblk_frac", [(2048, 1, 10.0), (2048, 2, 7.37), (1024, 1, 9.5)])
+@pytest.mark.parametrize("blksiz,n_chn,nblk_frac", [(2048, 1, 10.0), (2048, 2, 7.37), (1024, 1, 9.5),
+                                                    (8192, 2, 4.2), (16384, 1, 3.5)])
 def test_sweep_full_table(pkg, blksiz, n_chn, nblk_frac):
     n = int(blksiz * nblk_frac)
     data = _signal(n, n_chn, seed=11)
