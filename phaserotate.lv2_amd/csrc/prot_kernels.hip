@@ -80,7 +80,7 @@ PROT_DEV void load_pair (float (&nx)[2 * HOPSEG], const float* __restrict__ in, 
 	}
 }
 
-template <int HOPSEG, int NREG, int WAVES, int MODE, int ABL = 0, bool ACC = false>
+template <int HOPSEG, int NREG, int WAVES, int MODE, int ABL = 0, bool ACC = false, int DH = 0>
 __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p)
 {
 	constexpr int HOP  = HOPSEG * 256;
@@ -142,11 +142,33 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 	load_pair<HOPSEG> (nx, in, n_in, hist, p.hist_len, sA - Dc, t);
 	PROT_SYNC ();
 
+	// DH > 0: the dry path (x delayed by dry_delay) is served from registers: its
+	// frames are the FFT input of this pair (cur) and the last DH 256-frame segments of
+	// the previous pair (dh) -- (dry_delay - conv_delay) = 256 * DH.  No second read of
+	// the stream, so HBM traffic stays at the algorithmic 4 B in + 4 B out per frame.
+	constexpr int NDH = DH > 0 ? DH : 1;
+	float         dh[NDH];
+#pragma unroll
+	for (int i = 0; i < NDH; ++i) {
+		dh[i] = 0.f;
+	}
+	if (DH > 0) { // frames in front of the first (halo) pair: never emitted, but keep them exact
+#pragma unroll
+		for (int i = 0; i < NDH; ++i) {
+			dh[i] = ldv (in, n_in, hist, p.hist_len, sA - Dc - 256 * (DH - i) + t);
+		}
+	}
+
 	for (int it = 0; it < n_pairs; ++it, sA += 2 * HOP) {
 		float2 v[16];
+		float  cur[2 * HOPSEG];
+#pragma unroll
+		for (int k = 0; k < 2 * HOPSEG; ++k) {
+			cur[k] = nx[k];
+		}
 #pragma unroll
 		for (int k = 0; k < HOPSEG; ++k) {
-			v[k] = make_float2 (it == 0 ? 0.f : nx[k], nx[HOPSEG + k]); // it == 0: alignment block, contributes nothing
+			v[k] = make_float2 (it == 0 ? 0.f : cur[k], cur[HOPSEG + k]); // it == 0: alignment block, contributes nothing
 		}
 #pragma unroll
 		for (int k = HOPSEG; k < 16; ++k) {
@@ -218,7 +240,16 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 		float      dry[2 * HOPSEG];
 		const bool emit     = sA >= r0; // uniform: halo blocks emit nothing
 		const bool fast_out = (sA - Dd >= 0) && (sA + 2 * HOP <= n_in + Dd) && (sA + 2 * HOP <= r1);
-		if (MODE != MODE_HILBERT && !ACC && emit) {
+		if (DH > 0) {
+#pragma unroll
+			for (int k = 0; k < 2 * HOPSEG; ++k) {
+				dry[k] = (k - DH >= 0) ? cur[k - DH >= 0 ? k - DH : 0] : dh[k - DH < 0 ? NDH + (k - DH) : 0];
+			}
+#pragma unroll
+			for (int i = 0; i < NDH; ++i) {
+				dh[i] = cur[2 * HOPSEG - NDH + i];
+			}
+		} else if (MODE != MODE_HILBERT && !ACC && emit) {
 			if (fast_out) {
 				const float* __restrict__ dq = in + (sA - Dd) + t;
 #pragma unroll
@@ -361,9 +392,25 @@ static hipError_t launch_ola4096_m (const OlaParams& p, dim3 grid, hipStream_t s
 		hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, true>), grid, block, 0, s, p);
 		return hipGetLastError ();
 	}
+	// dry path from registers when the delay difference is a small multiple of 256 frames
+	const int dd = p.dry_delay - p.conv_delay;
+	if (MODE != MODE_HILBERT && ola_variant () == 0 && dd > 0 && dd % 256 == 0) {
+		switch (dd / 256) {
+			case 2: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, false, 2>), grid, block, 0, s, p); return hipGetLastError ();
+			case 4: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, false, 4>), grid, block, 0, s, p); return hipGetLastError ();
+			case 6: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, false, 6>), grid, block, 0, s, p); return hipGetLastError ();
+			default: break;
+		}
+	}
 	switch (ola_variant ()) {
-		case 1: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 2, MODE>), grid, block, 0, s, p); break;
+		case 1: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE>), grid, block, 0, s, p); break; // global dry loads
+		case 11: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 1>), grid, block, 0, s, p); break;
 		case 12: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 2>), grid, block, 0, s, p); break;
+		case 13: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 3>), grid, block, 0, s, p); break;
+		case 18: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 8>), grid, block, 0, s, p); break;
+		case 19: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 9>), grid, block, 0, s, p); break;
+		case 20: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 10>), grid, block, 0, s, p); break;
+		case 21: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 11>), grid, block, 0, s, p); break;
 		case 25: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 15>), grid, block, 0, s, p); break;
 		default: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE>), grid, block, 0, s, p); break;
 	}
