@@ -171,6 +171,34 @@ def main():
                        "roofline_frac": 8.0 * n / (kmsA * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": kmsA}
         engA.close()
 
+    if not args.no_extra:
+        # BASELINE config 5: fp16 sample path of the headline workload (4 B per frame)
+        engH = pkg.Engine(pkg.KIND_LV2, 48000, 1, device=local_rank)
+        xh, yh = x.half(), torch.empty(n, device=dev, dtype=torch.float16)
+
+        def step_h():
+            engH.apply_dev_f16(xh.data_ptr(), n, n, yh.data_ptr(), n, n, rot, st)
+        for _ in range(args.warmup):
+            step_h()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        e0.record(ts)
+        for _ in range(args.steps):
+            step_h()
+        e1.record(ts)
+        barrier()
+        kmsH = e0.elapsed_time(e1) / args.steps
+        y32 = torch.empty_like(x)
+        engH.apply_dev(xh.float().data_ptr(), n, n, y32.data_ptr(), n, n, rot, pkg.F_STATELESS, st)
+        torch.cuda.synchronize()
+        errh = (yh[: 1 << 22].float() - y32[: 1 << 22]).abs()
+        out["fp16"] = {"workload": "same as config, fp16 samples (2 B in + 2 B out per frame), packed-half butterflies, fp32 accumulate",
+                       "value": world * n / (kmsH * 1e-3), "unit": "frames/s", "kernel_ms": kmsH,
+                       "roofline_frac": 4.0 * n / (kmsH * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "max_abs_err_vs_fp32": float(errh.max()), "rms_err_vs_fp32": float(torch.sqrt(torch.mean(errh ** 2)))}
+        del xh, yh, y32
+        engH.close()
+
     if not args.no_sweep:
         out["sweep"] = bench_sweep(args, pkg, torch, dist, dev, st, world, rank, local_rank, barrier)
 

@@ -111,6 +111,14 @@ int prot_apply_dev_ramp (prot_engine* e, const float* d_in, int64_t in_stride, u
                          float* d_out, int64_t out_stride, uint64_t n_out,
                          const float* d_rot, uint32_t flags, void* stream);
 
+/* fp16 sample path (BASELINE config 5): d_in/d_out are DEVICE arrays of IEEE
+ * half (2 bytes per frame), planar; packed-half butterflies, fp32 overlap-add
+ * and rotation.  Always stateless (history = silence), steady rotation, single
+ * FIR partition engines only.  Same maths as prot_apply_dev at ~1e-3 accuracy. */
+int prot_apply_dev_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint64_t n_in,
+                        void* d_out, int64_t out_stride, uint64_t n_out,
+                        const float* rot, void* stream);
+
 #define PROT_F_STREAM_START 4u /* first chunk of a file: block 0 gets the Q1 treatment */
 #define PROT_F_STREAM_END   8u /* last chunk: zero-pad the partial block and add the flush block */
 

@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "prot_abi_version", "prot_strerror", "prot_last_error", "prot_sincos_lut",
     "prot_engine_create", "prot_engine_destroy", "prot_engine_reset", "prot_engine_info",
     "prot_engine_fir", "prot_engine_sync",
-    "prot_apply_dev", "prot_apply_dev_ramp", "prot_sweep_dev",
+    "prot_apply_dev", "prot_apply_dev_ramp", "prot_apply_dev_f16", "prot_sweep_dev",
     "prot_lv2_run", "prot_lv2_get_angle", "prot_cli_apply", "prot_cli_analyze", "prot_cli_analyze_file",
     "prot_cli_apply_file", "prot_cli_peak", "prot_cli_peak_all", "prot_cli_peaks",
     "prot_cli_peaks_dev",
@@ -100,6 +100,8 @@ def load_library():
     lib.prot_apply_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p,
                                    C.c_int64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.prot_apply_dev_ramp.argtypes = lib.prot_apply_dev.argtypes
+    lib.prot_apply_dev_f16.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p,
+                                       C.c_int64, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.prot_sweep_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.prot_lv2_run.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
@@ -179,6 +181,13 @@ class Engine:
         assert rot.size == 2 * self.n_chn
         _check(self._lib.prot_apply_dev(self._h, d_in, in_stride, n_in, d_out, out_stride, n_out,
                                         rot.ctypes.data, flags, stream), "prot_apply_dev")
+
+    def apply_dev_f16(self, d_in, in_stride, n_in, d_out, out_stride, n_out, rot, stream=0):
+        """fp16 sample path: device arrays of torch.float16 / IEEE half."""
+        rot = np.ascontiguousarray(rot, np.float32).reshape(-1)
+        assert rot.size == 2 * self.n_chn
+        _check(self._lib.prot_apply_dev_f16(self._h, d_in, in_stride, n_in, d_out, out_stride, n_out,
+                                            rot.ctypes.data, stream), "prot_apply_dev_f16")
 
     def hilbert_dev(self, d_in, in_stride, n_in, d_out, out_stride, n_out, flags=0, stream=0):
         _check(self._lib.prot_apply_dev(self._h, d_in, in_stride, n_in, d_out, out_stride, n_out,

@@ -53,6 +53,7 @@ def build_lib(force=False, verbose=False):
         # no SLP: hipcc otherwise packs the butterflies into v_pk_*_f32 with ~500 v_mov per
         # iteration to marshal register pairs (measured: 1500 -> 1240 VALU, 255 -> 165 VGPRs)
         ("prot_kernels.hip", ["-ffast-math", "-fno-slp-vectorize"]),
+        ("prot_kernels_f16.hip", ["-ffast-math"]),
         # host logic mirrors the reference's float arithmetic: no fast-math
         ("prot_capi.hip", []),
     ]

@@ -628,6 +628,39 @@ int prot_apply_dev_ramp (prot_engine* e, const float* d_in, int64_t in_stride, u
 	return rc;
 }
 
+int prot_apply_dev_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint64_t n_in, void* d_out,
+                        int64_t out_stride, uint64_t n_out, const float* rot, void* stream)
+{
+	if (!e || !d_in || !d_out || !rot) {
+		return PROT_EINVAL;
+	}
+	if (e->info.partitions != 1) {
+		return PROT_EUNSUPPORTED;
+	}
+	HIP_TRY (hipSetDevice (e->device));
+	hipStream_t s  = pick_stream (e, stream);
+	const int   nc = (int)e->info.n_chn;
+	HIP_TRY (hipMemcpyAsync (e->d_rot.p, rot, 2 * (size_t)nc * sizeof (float), hipMemcpyHostToDevice, s));
+	prot::OlaParamsH p {};
+	p.in         = (const _Float16*)d_in;
+	p.in_stride  = in_stride;
+	p.n_in       = (int64_t)n_in;
+	p.out        = (_Float16*)d_out;
+	p.out_stride = out_stride;
+	p.n_out      = (int64_t)n_out;
+	p.H          = e->d_H.p;
+	p.tw         = e->d_tw.p;
+	p.rot        = e->d_rot.p;
+	p.run_frames = pick_run_frames (e, n_out, nc);
+	p.conv_delay = (int)e->info.conv_delay;
+	p.dry_delay  = (int)e->info.dry_delay;
+	hipError_t err = prot::launch_ola4096_f16 (p, e->hopseg, nc, s);
+	if (err != hipSuccess) {
+		return hip_fail (err, "fp16 ola kernel launch");
+	}
+	return PROT_OK;
+}
+
 int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_frames, int ang_start,
                     int ang_end, int ang_stride, int chn, float* d_peaks, uint32_t flags, void* stream)
 {

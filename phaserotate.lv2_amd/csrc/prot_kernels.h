@@ -33,6 +33,22 @@ struct OlaParams {
 // fftlen 4096; hop = 256 * hopseg, hopseg in {4, 8}
 hipError_t launch_ola4096 (const OlaParams& p, int hopseg, int n_chn, hipStream_t s);
 
+// fp16 sample path (BASELINE config 5): half samples in HBM, packed-half butterflies,
+// fp32 overlap-add + rotation.  Stateless, steady rotation.
+struct OlaParamsH {
+	const _Float16* in;
+	int64_t         in_stride;
+	int64_t         n_in;
+	_Float16*       out;
+	int64_t         out_stride;
+	int64_t         n_out;
+	const float2*   H;   // same fp32 tables as the fp32 path; rounded to half when staged into LDS
+	const float2*   tw;
+	const float*    rot; // device [n_chn][2]
+	int32_t         run_frames, conv_delay, dry_delay;
+};
+hipError_t launch_ola4096_f16 (const OlaParamsH& p, int hopseg, int n_chn, hipStream_t s);
+
 // Rotated abs-max sweep over t in [t_begin, t_end) of one chunk:
 //   v = ca[a] * (t_abs >= dry_from ? x[t - delay] : 0) + sa[a] * u[t]
 //   peaks[c][a] = max(peaks[c][a], |v|)
