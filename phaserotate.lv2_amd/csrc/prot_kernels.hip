@@ -80,7 +80,7 @@ PROT_DEV void load_pair (float (&nx)[2 * HOPSEG], const float* __restrict__ in, 
 	}
 }
 
-template <int HOPSEG, int NREG, int WAVES, int MODE, int ABL = 0, bool ACC = false, int DH = 0>
+template <int HOPSEG, int NREG, int WAVES, int MODE, int ABL = 0, bool ACC = false, int DH = 0, bool PK = true>
 __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p)
 {
 	constexpr int HOP  = HOPSEG * 256;
@@ -88,12 +88,12 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 	constexpr int NH   = NS - 1;             // halo blocks that reach into a run
 	constexpr int NACC = (NS - 1) * HOPSEG;  // OLA tail registers
 
-	__shared__ float2 lds[NREG][kLdsRegion];
-	__shared__ float2 twm[256];              // twm[k1*16 + n0] = W256^{n0 k1}
+	__shared__ f2 lds[NREG][kLdsRegion];
+	__shared__ f2 twm[256];              // twm[k1*16 + n0] = W256^{n0 k1}
 	// FIR spectrum, bins 0..2048 (the FIR is real: H[4096-k] = conj H[k]).  Kept in LDS
 	// (16 KiB; 3 workgroups still fit a CU) because 32 KiB of L2 reads per hop pair from
 	// every workgroup was the largest single stall source (ablation: -28 % time at hop 2048)
-	__shared__ float2 Hs[2049];
+	__shared__ f2 Hs[2049];
 
 	const int     t  = threadIdx.x;
 	const int     c  = blockIdx.y;
@@ -110,14 +110,15 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 	const int     Dc = p.conv_delay, Dd = p.dry_delay;
 
 	// pass-1 twiddles W4096^{t k0}, k0 = 1..15, live in registers for the run
-	float2 tw1[16];
+	const f2* __restrict__ twp = reinterpret_cast<const f2*> (p.tw);
+	f2 tw1[16];
 #pragma unroll
 	for (int k = 1; k < 16; ++k) {
-		tw1[k] = p.tw[(t * k) & 4095];
+		tw1[k] = twp[(t * k) & 4095];
 	}
-	twm[t] = p.tw[16 * (((t & 15) * (t >> 4)) & 255)];
+	twm[t] = twp[16 * (((t & 15) * (t >> 4)) & 255)];
 	for (int i = t; i <= 2048; i += 256) {
-		Hs[i] = p.H[i];
+		Hs[i] = reinterpret_cast<const f2*> (p.H)[i];
 	}
 
 	float ca = 0.f, sa = 1.f;
@@ -160,7 +161,7 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 	}
 
 	for (int it = 0; it < n_pairs; ++it, sA += 2 * HOP) {
-		float2 v[16];
+		f2 v[16];
 		float  cur[2 * HOPSEG];
 #pragma unroll
 		for (int k = 0; k < 2 * HOPSEG; ++k) {
@@ -168,67 +169,83 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 		}
 #pragma unroll
 		for (int k = 0; k < HOPSEG; ++k) {
-			v[k] = make_float2 (it == 0 ? 0.f : cur[k], cur[HOPSEG + k]); // it == 0: alignment block, contributes nothing
+			v[k] = mkf2 (it == 0 ? 0.f : cur[k], cur[HOPSEG + k]); // it == 0: alignment block, contributes nothing
 		}
 #pragma unroll
 		for (int k = HOPSEG; k < 16; ++k) {
-			v[k] = make_float2 (0.f, 0.f); // zero padding (pruned by the compiler)
+			v[k] = mkf2 (0.f, 0.f); // zero padding (pruned by the compiler)
 		}
 
 		// ---- forward pass 1 (over n2), twiddle W^{t k0} ---------------------
-		fft16<1> (v);
+		if (PK) {
+			pk_fft16_fwd_pruned<HOPSEG> (v);
+		} else {
+			if (PK) {
+			pk_fft16<1> (v);
+		} else {
+			fft16<1> (v);
+		}
+		}
 #pragma unroll
 		for (int k = 1; k < 16; ++k) {
-			v[k] = cmulw<1> (v[k], tw1[k]);
+			v[k] = PK ? pk_cmul<1> (v[k], tw1[k]) : cmulw<1> (v[k], tw1[k]);
 		}
 		{
 			// no barrier in front of these stores: every thread overwrites exactly the
 			// slots it read itself at the end of the previous pair (k*kL1 + t)
-			float2* w = &lds[NREG - 1][t];
+			f2* w = &lds[NREG - 1][t];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
 				if (!(ABL & 1)) w[k * kL1] = v[k];
 			}
 			PROT_SYNC ();
-			const float2* r = &lds[NREG - 1][th * kL1 + tl];
+			const f2* r = &lds[NREG - 1][th * kL1 + tl];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
 				if (!(ABL & 1)) v[k] = r[16 * k];
 			}
 		}
 		// ---- forward pass 2 (over n1), twiddle W256^{n0 k1} -----------------
-		fft16<1> (v);
+		if (PK) {
+			pk_fft16<1> (v);
+		} else {
+			fft16<1> (v);
+		}
 #pragma unroll
 		for (int k = 1; k < 16; ++k) {
-			v[k] = cmulw<1> (v[k], twm[k * 16 + tl]);
+			v[k] = PK ? pk_cmul<1> (v[k], twm[k * 16 + tl]) : cmulw<1> (v[k], twm[k * 16 + tl]);
 		}
 		if (NREG == 1) {
 			PROT_SYNC ();
 		}
 		{
-			float2* w = &lds[0][tl * kL2 + th];
+			f2* w = &lds[0][tl * kL2 + th];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
 				if (!(ABL & 1)) w[16 * k] = v[k];
 			}
 			PROT_SYNC ();
-			const float2* r = &lds[0][t];
+			const f2* r = &lds[0][t];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
 				if (!(ABL & 1)) v[k] = r[k * kL2];
 			}
 		}
 		// ---- forward pass 3 (over n0): v[k2] = X[t + 256 k2] ----------------
-		fft16<1> (v);
+		if (PK) {
+			pk_fft16<1> (v);
+		} else {
+			fft16<1> (v);
+		}
 
 		// ---- x H: Hilbert FIR spectrum, 1/fftlen folded in -------------------
 #pragma unroll
 		for (int k = 0; k < 8; ++k) {
-			v[k] = cmulw<1> (v[k], (ABL & 4) ? make_float2 (0.5f + k, 0.25f) : Hs[t + 256 * k]);
+			v[k] = PK ? pk_cmul<1> (v[k], (ABL & 4) ? mkf2 (0.5f + k, 0.25f) : Hs[t + 256 * k]) : cmulw<1> (v[k], (ABL & 4) ? mkf2 (0.5f + k, 0.25f) : Hs[t + 256 * k]);
 		}
 #pragma unroll
 		for (int k = 8; k < 16; ++k) { // bins >= 2048: conjugate of the mirrored bin
-			v[k] = cmulw<-1> (v[k], (ABL & 4) ? make_float2 (0.5f + k, 0.25f) : Hs[256 * (16 - k) - t]);
+			v[k] = PK ? pk_cmul<-1> (v[k], (ABL & 4) ? mkf2 (0.5f + k, 0.25f) : Hs[256 * (16 - k) - t]) : cmulw<-1> (v[k], (ABL & 4) ? mkf2 (0.5f + k, 0.25f) : Hs[256 * (16 - k) - t]);
 		}
 
 		// ---- request the next pair's frames (after the H loads: vmcnt retires in order)
@@ -266,38 +283,46 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 		__builtin_amdgcn_sched_barrier (0);
 
 		// ---- inverse pass 1 (over k2), twiddle conj W256^{n0 k1} ------------
-		fft16<-1> (v);
+		if (PK) {
+			pk_fft16<-1> (v);
+		} else {
+			fft16<-1> (v);
+		}
 #pragma unroll
 		for (int k = 1; k < 16; ++k) {
-			v[k] = cmulw<-1> (v[k], twm[th * 16 + k]);
+			v[k] = PK ? pk_cmul<-1> (v[k], twm[th * 16 + k]) : cmulw<-1> (v[k], twm[th * 16 + k]);
 		}
 		{
 			// no barrier: same slots this thread read in forward exchange 2
-			float2* w = &lds[0][t];
+			f2* w = &lds[0][t];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
 				if (!(ABL & 1)) w[k * kL3] = v[k];
 			}
 			PROT_SYNC ();
-			const float2* r = &lds[0][tl * kL3 + th];
+			const f2* r = &lds[0][tl * kL3 + th];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
 				if (!(ABL & 1)) v[k] = r[16 * k];
 			}
 		}
 		// ---- inverse pass 2 (over k1) ----------------------------------------
-		fft16<-1> (v);
+		if (PK) {
+			pk_fft16<-1> (v);
+		} else {
+			fft16<-1> (v);
+		}
 		if (NREG == 1) {
 			PROT_SYNC ();
 		}
 		{
-			float2* w = &lds[NREG - 1][th * kL1 + tl];
+			f2* w = &lds[NREG - 1][th * kL1 + tl];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
 				if (!(ABL & 1)) w[16 * k] = v[k];
 			}
 			PROT_SYNC ();
-			const float2* r = &lds[NREG - 1][t];
+			const f2* r = &lds[NREG - 1][t];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
 				if (!(ABL & 1)) v[k] = r[k * kL1];
@@ -306,9 +331,13 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 		// ---- twiddle conj W^{t k0}, inverse pass 3 (over k0) -----------------
 #pragma unroll
 		for (int k = 1; k < 16; ++k) {
-			v[k] = cmulw<-1> (v[k], tw1[k]);
+			v[k] = PK ? pk_cmul<-1> (v[k], tw1[k]) : cmulw<-1> (v[k], tw1[k]);
 		}
-		fft16<-1> (v);
+		if (PK) {
+			pk_fft16<-1> (v);
+		} else {
+			fft16<-1> (v);
+		}
 		// v[k].x = (fir * A)[t + 256k], v[k].y = (fir * B)[t + 256k]
 
 		// ---- overlap-add in registers ----------------------------------------
@@ -361,7 +390,7 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 					if (pos < r1) {
 						float cc = ca, ss = sa;
 						if (MODE == MODE_RAMP) {
-							const float2 cs = reinterpret_cast<const float2*> (p.rot_s)[(int64_t)c * p.n_out + pos];
+							const f2 cs = reinterpret_cast<const f2*> (p.rot_s)[(int64_t)c * p.n_out + pos];
 							cc              = cs.x;
 							ss              = cs.y;
 						}
@@ -404,6 +433,7 @@ static hipError_t launch_ola4096_m (const OlaParams& p, dim3 grid, hipStream_t s
 	}
 	switch (ola_variant ()) {
 		case 1: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE>), grid, block, 0, s, p); break; // global dry loads
+		case 3: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, false, 0, false>), grid, block, 0, s, p); break; // scalar butterflies
 		case 11: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 1>), grid, block, 0, s, p); break;
 		case 12: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 2>), grid, block, 0, s, p); break;
 		case 13: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 3>), grid, block, 0, s, p); break;
