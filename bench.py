@@ -157,7 +157,8 @@ def main():
                    "parallelism": "independent streams x%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "prot::ola4096_kernel<4,1>", "kernel_ms": kern_ms,
+                     "kernel": "prot::ola4096_kernel<4, 1, 3, 0, 0, false, 6, true> (HOPSEG 4 = hop 1024, steady rotation, "
+                               "dry path from registers, packed-fp32 butterflies)", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": bytes_per_launch},
     }
     eng.close()
@@ -199,6 +200,11 @@ def main():
         del xh, yh, y32
         engH.close()
 
+    if not args.no_extra:
+        out["lv2_stereo_batched"] = bench_cfg3(args, pkg, torch, np, dev, ts, st, local_rank, barrier, world)
+        if rank == 0:
+            out["lv2_run_host"] = bench_run_host(pkg, np, local_rank)
+
     if not args.no_sweep:
         out["sweep"] = bench_sweep(args, pkg, torch, dist, dev, st, world, rank, local_rank, barrier)
 
@@ -210,6 +216,56 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_cfg3(args, pkg, torch, np, dev, ts, st, local_rank, barrier, world):
+    """BASELINE config 3: LV2 stereo, the 96 kHz filter (4096 taps; an 8192-pt FFT in the
+    reference's terms, two 4096-pt FIR partitions here), 256 buffers of 1024 frames batched
+    per launch (2 x 1 MiB in, 2 x 1 MiB out), back-to-back stateful launches on one stream."""
+    n_chn, nbuf, bs = 2, 256, 1024
+    n = nbuf * bs
+    eng = pkg.Engine(pkg.KIND_LV2, 96000, n_chn, device=local_rank)
+    x = torch.rand((n_chn, n), device=dev) - 0.5
+    y = torch.empty_like(x)
+    rot = np.array([0.0, -1.0, 0.6, 0.8], np.float32)
+    launches = 200
+
+    def step():
+        eng.apply_dev(x.data_ptr(), n, n, y.data_ptr(), n, n, rot, 0, st)  # stateful: history carried
+    for _ in range(10):
+        step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    e0.record(ts)
+    for _ in range(launches):
+        step()
+    e1.record(ts)
+    barrier()
+    ms = e0.elapsed_time(e1) / launches
+    eng.close()
+    return {"workload": "LV2 stereo, 96 kHz filter (4096 taps = 2 FIR partitions of the 4096-pt kernel), "
+                        "256 x 1024-frame buffers per channel per launch, stateful back-to-back launches",
+            "value": world * n_chn * n / (ms * 1e-3), "unit": "channel-frames/s", "ms_per_launch": ms,
+            "roofline_frac": 8.0 * n_chn * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
+def bench_run_host(pkg, np, local_rank):
+    """BASELINE config 2, literal form: the LV2 run() drop-in on HOST buffers, 1024 frames per
+    call (upload + kernel + download + sync per call).  PCIe/latency-bound; never `value`."""
+    g = pkg.Lv2Instance(48000, 1, device=local_rank)
+    g.activate()
+    x = (np.random.default_rng(3).random((1, 1024), dtype=np.float32) - 0.5)
+    for _ in range(20):
+        g.run(x, 90.0)
+    calls = 500
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        g.run(x, 90.0)
+    dt = (time.perf_counter() - t0) / calls
+    g.close()
+    return {"workload": "prot_lv2_run, mono 48 kHz, 1024-frame host buffers (H2D + kernel + D2H + sync per call, "
+                        "ctypes call overhead included)",
+            "us_per_run": dt * 1e6, "frames_per_s": 1024 / dt, "realtime_factor_48k": 1024 / dt / 48000.0}
 
 
 def bench_sweep(args, pkg, torch, dist, dev, st, world, rank, local_rank, barrier):
