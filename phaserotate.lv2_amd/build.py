@@ -51,8 +51,9 @@ def build_lib(force=False, verbose=False):
     units = [
         # device code: fast-math lets the compiler prune the zero-padded radix-16 inputs;
         # no SLP: hipcc otherwise packs the butterflies into v_pk_*_f32 with ~500 v_mov per
-        # iteration to marshal register pairs (measured: 1500 -> 1240 VALU, 255 -> 165 VGPRs)
-        ("prot_kernels.hip", ["-ffast-math", "-fno-slp-vectorize"]),
+        # iteration to marshal register pairs (measured: 1500 -> 1240 VALU, 255 -> 165 VGPRs);
+        # MFMA results in VGPRs (unified file on gfx950) so the sweep's v_max3 reads them directly
+        ("prot_kernels.hip", ["-ffast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
         ("prot_kernels_f16.hip", ["-ffast-math"]),
         # host logic mirrors the reference's float arithmetic: no fast-math
         ("prot_capi.hip", []),

@@ -29,6 +29,7 @@
 #include "prot_fft.h"
 #include "prot_kernels.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 // ABL (ablation, timing experiments only -- results are wrong): 1 no LDS exchange, 2 no barriers,
@@ -491,6 +492,8 @@ PROT_DEV float wave_max_nonneg (float v)
 	return v;
 }
 
+hipError_t launch_sweep_valu (const SweepParams& p, int n_chn, hipStream_t s);
+
 constexpr int kSweepE    = 32;                // frames per thread per tile
 constexpr int kSweepTile = 256 * kSweepE;     // frames per workgroup iteration
 
@@ -573,7 +576,188 @@ __global__ __launch_bounds__ (256) void sweep_kernel (const SweepParams p)
 	}
 }
 
+// ---- matrix-core form of the same sweep ---------------------------------------------
+// |ca_a d_i + sa_a h_i| for 32 angles x 32 frames is the rank-2 product
+// [ca sa] (32x2) . [d; h] (2x32): one v_mfma_f32_32x32x2_f32.  f32 MFMA is an exact
+// k-ordered fmaf chain, fma(sa, h, ca*d) -- bit-identical to the vector kernel above --
+// and runs beside the VALU, which is left with the |.|/max (v_max3_f32 over two tiles).
+// Lane l of the 32x32 result holds frame (l & 31) for 16 of the 32 angles, so running
+// maxima stay lane-local for the whole launch: no per-tile cross-lane reduction at all.
+// A wave owns up to 3 blocks of 32 angles (48 VGPRs of maxima); the 4 waves of a
+// workgroup cover the 360 angles (12 blocks) and read the same frames.
+typedef float f32x16 __attribute__ ((ext_vector_type (16)));
+
+constexpr int kMfmaSuper = 256; // 32-frame tiles per workgroup iteration (8192 frames)
+
+template <int NBLK>
+__global__ __launch_bounds__ (256) void sweep_mfma_kernel (const SweepParams p)
+{
+	const int tid  = threadIdx.x;
+	const int w    = __builtin_amdgcn_readfirstlane (tid >> 6); // wave-uniform by construction
+	const int lane = tid & 63;
+	const int j    = lane & 31; // frame within a tile / angle within a block (A operand)
+	const int kk   = lane >> 5; // k index of the rank-2 product: 0 -> (cos, dry), 1 -> (sin, hilbert)
+	const int c    = p.chn0 + blockIdx.y;
+
+	const float* __restrict__ x    = p.x + (int64_t)c * p.x_stride;
+	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
+	const float* __restrict__ u    = p.u + (int64_t)c * p.u_stride;
+
+	const int nb   = (p.n_angles + 31) >> 5;      // angle blocks in this call (<= 12)
+	const int G    = nb >= 3 ? 4 : nb;            // wave groups: 4, 2 or 1
+	const int g    = w % G;                       // my group -> blocks g, g + G, g + 2G
+	const int sub  = w / G;                       // waves of one group split the tiles
+	const int nsub = 4 / G;
+
+	// NBLK = blocks per wave (1..3); a wave whose group has fewer blocks multiplies by an
+	// all-zero A operand there (maxima stay 0, nothing is published for them)
+	float a_op[NBLK];
+#pragma unroll
+	for (int q = 0; q < NBLK; ++q) {
+		const int idx = (g + q * G) * 32 + j;
+		float     v   = 0.f;
+		if (g + q * G < nb && idx < p.n_angles) {
+			const int a = p.angles[idx];
+			v           = p.lut[2 * a + (kk ? 0 : 1)]; // lut = {sin, cos}
+		}
+		a_op[q] = v;
+	}
+	f32x16 m[NBLK];
+#pragma unroll
+	for (int q = 0; q < NBLK; ++q) {
+#pragma unroll
+		for (int r = 0; r < 16; ++r) {
+			m[q][r] = 0.f;
+		}
+	}
+	const f32x16 zero = m[0];
+
+	const int64_t span = (int64_t)kMfmaSuper * 32;
+	for (int64_t base = p.t_begin + (int64_t)blockIdx.x * span; base < p.t_end; base += (int64_t)gridDim.x * span) {
+		const bool fast = (base + span <= p.t_end) && (base - p.delay >= 0) && (base + span - p.delay <= p.n_x) &&
+		                  (base + p.t_abs0 >= p.dry_from);
+		// NT tiles per step; the frames of step s+1 are requested before the MFMAs of step s
+		// (double-buffered registers), so HBM latency never idles the matrix pipe
+		constexpr int NT = 8;
+		auto load_tiles = [&] (float (&bt)[NT], int tp) {
+			const int64_t t0 = base + (int64_t)tp * 32 + j;
+			if (fast) {
+				const float* __restrict__ src = kk ? (u + t0) : (x + t0 - p.delay);
+#pragma unroll
+				for (int i = 0; i < NT; ++i) {
+					bt[i] = src[32 * i];
+				}
+			} else {
+#pragma unroll
+				for (int i = 0; i < NT; ++i) {
+					const int64_t ti = t0 + 32 * i;
+					float         v  = 0.f;
+					if (ti < p.t_end) {
+						v = kk ? u[ti] : (ti + p.t_abs0 >= p.dry_from ? ldv (x, p.n_x, hist, p.hist_len, ti - p.delay) : 0.f);
+					}
+					bt[i] = v;
+				}
+			}
+		};
+		float bcur[NT], bnxt[NT];
+		load_tiles (bcur, sub * NT);
+		for (int tp = sub * NT; tp < kMfmaSuper; tp += NT * nsub) {
+			if (tp + NT * nsub < kMfmaSuper) {
+				load_tiles (bnxt, tp + NT * nsub);
+			}
+#pragma unroll
+			for (int i = 0; i < NT; i += 2) {
+#pragma unroll
+				for (int q = 0; q < NBLK; ++q) {
+					const f32x16 r0 = __builtin_amdgcn_mfma_f32_32x32x2f32 (a_op[q], bcur[i], zero, 0, 0, 0);
+					const f32x16 r1 = __builtin_amdgcn_mfma_f32_32x32x2f32 (a_op[q], bcur[i + 1], zero, 0, 0, 0);
+#pragma unroll
+					for (int r = 0; r < 16; ++r) {
+						m[q][r] = fmaxf (m[q][r], fmaxf (fabsf (r0[r]), fabsf (r1[r])));
+					}
+				}
+			}
+#pragma unroll
+			for (int i = 0; i < NT; ++i) {
+				bcur[i] = bnxt[i];
+			}
+		}
+	}
+
+	// reduce over the 32 frames (lanes of one half), then one atomic per angle
+	unsigned* gp = reinterpret_cast<unsigned*> (p.peaks + (int64_t)c * kMaxSample);
+#pragma unroll
+	for (int q = 0; q < NBLK; ++q) {
+		{
+#pragma unroll
+			for (int r = 0; r < 16; ++r) {
+				float v = m[q][r];
+				v       = fmaxf (v, __shfl_xor (v, 1));
+				v       = fmaxf (v, __shfl_xor (v, 2));
+				v       = fmaxf (v, __shfl_xor (v, 4));
+				v       = fmaxf (v, __shfl_xor (v, 8));
+				v       = fmaxf (v, __shfl_xor (v, 16));
+				// C/D layout of 32x32: row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column = lane & 31
+				const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+				const int idx = (g + q * G) * 32 + row;
+				if (j == 0 && g + q * G < nb && idx < p.n_angles) {
+					atomicMax (&gp[p.angles[idx]], __float_as_uint (v));
+				}
+			}
+		}
+	}
+}
+
+static int sweep_variant ()
+{
+	static int v = -1;
+	if (v < 0) {
+		const char* e = getenv ("PROT_SWEEP_VARIANT");
+		v             = e ? atoi (e) : 0;
+	}
+	return v;
+}
+
 hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s)
+{
+	if (sweep_variant () == 0 && p.t_end > p.t_begin && p.n_angles > 0 && n_chn > 0) {
+		const int  nb   = (p.n_angles + 31) / 32;
+		const int  nblk = nb >= 3 ? (nb + 3) / 4 : 1;
+		// persistent grid: exactly the workgroups the chip keeps resident, so the
+		// grid-stride loop ends without a ragged last round
+		static int slots[4] = { 0, 0, 0, 0 };
+		if (slots[nblk] == 0) {
+			int dev = 0, cus = 256, occ = 2;
+			(void)hipGetDevice (&dev);
+			(void)hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, dev);
+			const void* fn = nblk == 1 ? (const void*)sweep_mfma_kernel<1>
+			                           : nblk == 2 ? (const void*)sweep_mfma_kernel<2> : (const void*)sweep_mfma_kernel<3>;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor (&occ, fn, 256, 0) != hipSuccess || occ < 1) {
+				occ = 2;
+			}
+			slots[nblk] = cus * occ;
+		}
+		const int64_t span  = (int64_t)kMfmaSuper * 32;
+		const int64_t tiles = (p.t_end - p.t_begin + span - 1) / span;
+		int64_t       gx    = tiles;
+		const int64_t cap   = std::max (1, slots[nblk] / n_chn);
+		if (gx > cap) {
+			gx = cap;
+		}
+		const dim3 grid ((unsigned)gx, (unsigned)n_chn), block (256);
+		if (nblk == 1) {
+			hipLaunchKernelGGL (sweep_mfma_kernel<1>, grid, block, 0, s, p);
+		} else if (nblk == 2) {
+			hipLaunchKernelGGL (sweep_mfma_kernel<2>, grid, block, 0, s, p);
+		} else {
+			hipLaunchKernelGGL (sweep_mfma_kernel<3>, grid, block, 0, s, p);
+		}
+		return hipGetLastError ();
+	}
+	return launch_sweep_valu (p, n_chn, s);
+}
+
+hipError_t launch_sweep_valu (const SweepParams& p, int n_chn, hipStream_t s)
 {
 	if (p.t_end <= p.t_begin || p.n_angles <= 0 || n_chn <= 0) {
 		return hipSuccess;

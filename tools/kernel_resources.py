@@ -3,7 +3,7 @@
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "phaserotate.lv2_amd", "csrc")
-flags = sys.argv[1:] or ["-ffast-math", "-fno-slp-vectorize"]
+flags = sys.argv[1:] or ["-ffast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 src = os.path.join(CSRC, "prot_kernels.hip")
 r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
                     "-c", src, "-o", "/tmp/_kr.o", "-Rpass-analysis=kernel-resource-usage"] + flags,
