@@ -20,17 +20,22 @@ MAXSAMPLE = 360
 SUBSAMPLE = 2
 
 
-def plan_shards(n_frames, blksiz, world):
+def plan_shards(n_frames, blksiz, world, align=2):
     """Split ceil(n_frames / blksiz) data blocks into `world` contiguous ranges
     [(b0, b1), ...]; earlier ranks get the remainder.  Empty ranges are allowed
-    (more ranks than blocks)."""
+    (more ranks than blocks).  Interior boundaries fall on multiples of `align`
+    blocks: the device engine transforms hops in pairs, and a shard that starts
+    on a pair boundary reproduces the single-GPU arithmetic bit for bit (so the
+    merged table, and its argmin, are identical, not just within tolerance)."""
     nb = (n_frames + blksiz - 1) // blksiz
-    base, rem = divmod(nb, world)
+    units = (nb + align - 1) // align
+    base, rem = divmod(units, world)
     out, b = [], 0
     for r in range(world):
         k = base + (1 if r < rem else 0)
-        out.append((b, b + k))
-        b += k
+        e = min(nb, b + k * align)
+        out.append((b, e))
+        b = e
     return out
 
 

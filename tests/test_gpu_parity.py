@@ -244,6 +244,7 @@ def test_apply_dev_large_stream_properties(pkg):
     y2 = torch.empty_like(x)
     s, c = np.sin(-np.pi / 2), np.cos(-np.pi / 2)
     rot = np.array([c, s], np.float32)
+    torch.cuda.synchronize()  # the engine uses its own non-blocking stream
     e.apply_dev(x.data_ptr(), n, n, y1.data_ptr(), n, n, rot, pkg.F_STATELESS)
     e.apply_dev(y1.data_ptr(), n, n, y2.data_ptr(), n, n, rot, pkg.F_STATELESS)
     e.sync()
@@ -257,6 +258,7 @@ def test_apply_dev_large_stream_properties(pkg):
     # linearity: A(2x) == 2 A(x) bit-exactly (power-of-two scaling)
     x2 = 2 * x
     y3 = torch.empty_like(x)
+    torch.cuda.synchronize()
     e.apply_dev(x2.data_ptr(), n, n, y3.data_ptr(), n, n, rot, pkg.F_STATELESS)
     e.sync()
     assert torch.equal(y3, 2 * y1)
@@ -265,6 +267,7 @@ def test_apply_dev_large_stream_properties(pkg):
     xs = torch.zeros_like(x)
     xs[hop:] = x[:-hop]
     y4 = torch.empty_like(x)
+    torch.cuda.synchronize()
     e.apply_dev(xs.data_ptr(), n, n, y4.data_ptr(), n, n, rot, pkg.F_STATELESS)
     e.sync()
     assert (y4[hop:] - y1[:-hop]).abs().max().item() < TOL
@@ -279,12 +282,14 @@ def test_apply_dev_stateful_chunks_equal_one_shot(pkg):
     x = torch.from_numpy(xorshift_uniform(2 * n, seed=8).reshape(2, n)).to(dev)
     rot = np.array([0.6, 0.8, -0.8, 0.6], np.float32)
     y_one = torch.empty_like(x)
+    torch.cuda.synchronize()
     e.apply_dev(x.data_ptr(), n, n, y_one.data_ptr(), n, n, rot, pkg.F_STATELESS)
     y_chunks = torch.zeros_like(x)
     pos = 0
     for sz in (1, 1023, 2048, 4097, 10000, 32831):
         xin = x[:, pos:pos + sz].contiguous()
         yo = torch.empty_like(xin)
+        torch.cuda.synchronize()
         e.apply_dev(xin.data_ptr(), sz, sz, yo.data_ptr(), sz, sz, rot, 0)
         e.sync()
         y_chunks[:, pos:pos + sz] = yo
@@ -308,7 +313,9 @@ def test_fp16_sample_path_tolerance_report(pkg, kind, param, capsys):
     y32 = torch.empty_like(x32)
     y16 = torch.empty_like(x16)
     rot = np.array([np.cos(-0.7), np.sin(-0.7)], np.float32)
-    e.apply_dev(x16.float().contiguous().data_ptr(), n, n, y32.data_ptr(), n, n, rot, pkg.F_STATELESS)
+    x16f = x16.float().contiguous()
+    torch.cuda.synchronize()
+    e.apply_dev(x16f.data_ptr(), n, n, y32.data_ptr(), n, n, rot, pkg.F_STATELESS)
     e.apply_dev_f16(x16.data_ptr(), n, n, y16.data_ptr(), n, n, rot)
     e.sync()
     torch.cuda.synchronize()
@@ -320,3 +327,103 @@ def test_fp16_sample_path_tolerance_report(pkg, kind, param, capsys):
               % (kind, param, float(err.max()), rms, ref_rms, 20 * np.log10(ref_rms / rms)))
     assert float(err.max()) < 2e-2 and rms < 3e-3  # stated tolerance: ~1e-3 rms at |y| <= 1
     e.close()
+
+
+# --------------------------------------------------------- BASELINE sizes ---
+def test_full_size_stream_2p27_properties(pkg):
+    """The bench workload itself (LV2 48 kHz filter, 2^27 frames, one launch), checked through
+    size-independent properties: (1) three random windows against the float64 LTI model,
+    (2) a checksum of the one-shot output equals the checksum of a stateful two-chunk pass
+    to within float tolerance, (3) exact linearity under scaling by 2."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 1 << 27
+    e = pkg.Engine(pkg.KIND_LV2, 48000, 1)
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.rand(n, generator=g, device=dev) - 0.5
+    y = torch.empty_like(x)
+    ang = 33.0
+    th = -2 * np.pi * ang / 360
+    rot = np.array([np.cos(th), np.sin(th)], np.float32)
+    torch.cuda.synchronize()  # inputs come from torch's stream; the engine has its own
+    e.apply_dev(x.data_ptr(), n, n, y.data_ptr(), n, n, rot, pkg.F_STATELESS)
+    e.sync()
+    L, P, N = e.info.latency, e.info.blksiz, e.info.firlen
+    fir = orc.fir_closed_form(N)
+    rng = np.random.default_rng(5)
+    for t0 in [0, int(rng.integers(1 << 20, n - (1 << 20))), n - 8192]:
+        W = 8192
+        lo = max(0, t0 - (P + N))
+        xs = x[lo:t0 + W].cpu().numpy().astype(np.float64)
+        u = np.convolve(xs, fir)[:xs.size]
+        pad = t0 - lo
+
+        def at(arr, d):  # arr delayed by d frames, window [t0, t0 + W)
+            idx = np.arange(pad, pad + W) - d
+            out = np.zeros(W)
+            ok = idx >= 0
+            out[ok] = arr[idx[ok]]
+            return out
+        ym = np.cos(th) * at(xs, L) + np.sin(th) * at(u, P)
+        if lo > 0:  # the model window lacks history older than lo: only frames with full support count
+            valid = np.arange(W) + pad >= P + N
+        else:
+            valid = np.ones(W, bool)
+        got = y[t0:t0 + W].cpu().numpy()
+        assert np.abs(got - ym)[valid].max() < TOL
+    # stateful two-chunk pass == one shot
+    e.reset()
+    y2 = torch.empty_like(x)
+    h = (n // 2) + 12345
+    torch.cuda.synchronize()
+    e.apply_dev(x.data_ptr(), h, h, y2.data_ptr(), h, h, rot, 0)
+    e.apply_dev(x[h:].data_ptr(), n - h, n - h, y2[h:].data_ptr(), n - h, n - h, rot, 0)
+    e.sync()
+    assert (y2 - y).abs().max().item() < TOL
+    assert abs(y2.double().sum().item() - y.double().sum().item()) < 1e-2
+    # linearity
+    x2 = 2 * x
+    torch.cuda.synchronize()
+    e.apply_dev(x2.data_ptr(), n, n, y2.data_ptr(), n, n, rot, pkg.F_STATELESS)
+    e.sync()
+    assert torch.equal(y2, 2 * y)
+    e.close()
+
+
+def test_full_size_sweep_shards_equal_single_pass(pkg):
+    """The multi-GPU sweep plumbing on ONE device: two engines sweep the two halves of a
+    stereo stream (second one primed with the history in front of its shard), the tables
+    are MAX-merged -- bit-identical to the single-engine table."""
+    import torch
+    from phaserotate_lv2_amd import sweep_dist
+    dev = torch.device("cuda:0")
+    P, n_chn = 2048, 2
+    nb = 3001
+    n = nb * P - 777  # ragged last block
+    g = torch.Generator(device=dev).manual_seed(2)
+    x = (torch.rand((n_chn, n), generator=g, device=dev) - 0.5) * 0.9
+    one = pkg.Engine(pkg.KIND_CLI, P, n_chn)
+    pk1 = torch.zeros((n_chn, 360), device=dev)
+    torch.cuda.synchronize()
+    one.sweep_dev(x.data_ptr(), n, n, 0, 360, 1, -1, pk1.data_ptr(), pkg.F_STREAM_START | pkg.F_STREAM_END)
+    one.sync()
+    plan = sweep_dist.plan_shards(n, P, 2)
+    pk2 = torch.zeros((n_chn, 360), device=dev)
+    for r, (b0, b1) in enumerate(plan):
+        f0, nf = sweep_dist.shard_frames(n, P, plan, r)
+        eng = pkg.Engine(pkg.KIND_CLI, P, n_chn)
+        H = eng.info.history
+        if r > 0:
+            halo = x[:, f0 - H:f0].contiguous()
+            torch.cuda.synchronize()
+            keep = sweep_dist.prime_history(eng, halo)
+        xs = x[:, f0:f0 + nf].contiguous()
+        part = torch.zeros((n_chn, 360), device=dev)
+        torch.cuda.synchronize()
+        flags = (pkg.F_STREAM_START if r == 0 else 0) | (pkg.F_STREAM_END if r == len(plan) - 1 else 0)
+        eng.sweep_dev(xs.data_ptr(), nf, nf, 0, 360, 1, -1, part.data_ptr(), flags)
+        eng.sync()
+        pk2 = torch.maximum(pk2, part)
+        eng.close()
+    assert torch.equal(pk1, pk2)
+    one.close()
