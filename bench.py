@@ -150,20 +150,30 @@ def main():
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "LV2 mono 48 kHz: 3072-tap Hilbert FIR, 4096-pt OLA, hop 1024, angle 90 deg, "
+        "config": {"workload": "LV2 mono 48 kHz: 3072-tap Hilbert FIR (latency 1792), 4096-pt OLA, two 2048-tap "
+                               "partitions sharing one forward FFT per 2048-frame hop, angle 90 deg, "
                                "device-resident stream of 2^%d frames per GPU per step" % args.frames_log2,
+                   "partitions": int(eng.info.partitions),
                    "fftlen": int(eng.info.fftlen), "hop": int(eng.info.hop), "firlen": int(eng.info.firlen),
                    "latency": int(eng.info.latency), "frames_per_gpu": n, "streams_per_gpu": 1,
                    "parallelism": "independent streams x%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "prot::ola4096_kernel<4, 1, 3, 0, 0, false, 6, true> (HOPSEG 4 = hop 1024, steady rotation, "
-                               "dry path from registers, packed-fp32 butterflies)", "kernel_ms": kern_ms,
+                     "kernel": "prot::ola4096p2_kernel<0, 6> (steady rotation, dry path from registers, "
+                               "packed-fp32 butterflies)", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": bytes_per_launch},
     }
     eng.close()
 
     if not args.no_extra:
+        # same filter, literal blocking: one zero-padded 4096-pt FFT per 1024-frame hop
+        eng1 = pkg.Engine(pkg.KIND_LV2, 48000, 1, device=local_rank, flags=pkg.CFG_SINGLE_FFT_PER_HOP)
+        wall1, kms1 = timed(eng1, args.steps, args.warmup, n)
+        out["single_fft_per_hop"] = {
+            "workload": "LV2 mono 48 kHz filter, one zero-padded 4096-pt FFT per 1024-frame hop (ola4096_kernel<4,...>)",
+            "value": world * n * args.steps / wall1, "unit": "frames/s",
+            "roofline_frac": 8.0 * n / (kms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": kms1}
+        eng1.close()
         # the CLI engine A (blksiz 2048: 2048-tap FIR, 4096-pt OLA, hop 2048) on the same stream
         engA = pkg.Engine(pkg.KIND_CLI, 2048, 1, device=local_rank)
         wallA, kmsA = timed(engA, args.steps, args.warmup, n)
@@ -174,7 +184,7 @@ def main():
 
     if not args.no_extra:
         # BASELINE config 5: fp16 sample path of the headline workload (4 B per frame)
-        engH = pkg.Engine(pkg.KIND_LV2, 48000, 1, device=local_rank)
+        engH = pkg.Engine(pkg.KIND_LV2, 48000, 1, device=local_rank, flags=pkg.CFG_SINGLE_FFT_PER_HOP)
         xh, yh = x.half(), torch.empty(n, device=dev, dtype=torch.float16)
 
         def step_h():

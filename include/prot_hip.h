@@ -49,8 +49,13 @@ typedef struct {
 	uint32_t n_chn;   /* channel-streams (LV2: 1..2 via the plugin; engine itself: 1..65535) */
 	int32_t  device;  /* HIP device ordinal */
 	uint32_t fftlen;  /* 0 or 4096: the device transform length */
-	uint32_t flags;   /* reserved, 0 */
+	uint32_t flags;   /* PROT_CFG_* */
 } prot_config;
+
+/* FIRs of 2049..3072 taps (LV2 < 64 kHz): keep ONE zero-padded transform per 1024-frame hop
+ * (the literal "one 4096-pt FFT per 1024-frame run()" blocking) instead of two 2048-tap
+ * partitions sharing a forward transform.  Same filter, ~1.6x the transforms per frame. */
+#define PROT_CFG_SINGLE_FFT_PER_HOP 1u
 
 typedef struct {
 	int32_t  kind;

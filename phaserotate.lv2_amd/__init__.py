@@ -22,6 +22,7 @@ MAXSAMPLE = 360          # cli/phase-rotate.cc:39
 SUBSAMPLE = 2            # cli/phase-rotate.cc:38
 KIND_CLI, KIND_LV2 = 0, 1
 F_STATELESS, F_HILBERT, F_STREAM_START, F_STREAM_END = 1, 2, 4, 8
+CFG_SINGLE_FFT_PER_HOP = 1
 
 # every symbol include/prot_hip.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = (
@@ -140,9 +141,9 @@ def sincos_lut(a):
 class Engine:
     """Opaque prot_engine handle + the device-resident streaming API."""
 
-    def __init__(self, kind, param, n_chn=1, device=0, fftlen=0):
+    def __init__(self, kind, param, n_chn=1, device=0, fftlen=0, flags=0):
         self._lib = load_library()
-        cfg = Config(kind, float(param), n_chn, device, fftlen, 0)
+        cfg = Config(kind, float(param), n_chn, device, fftlen, flags)
         st = C.c_int(0)
         self._h = self._lib.prot_engine_create(C.byref(cfg), C.byref(st))
         if not self._h:

@@ -180,6 +180,7 @@ struct prot_engine {
 	hipStream_t stream  = nullptr;
 	std::vector<float> fir;
 	uint32_t    part_len = 0; // taps per FIR partition
+	bool        use_p2   = false; // two partitions in one launch (frequency-domain delay line)
 
 	DevBuf<float2> d_H, d_tw;
 	DevBuf<float>  d_lut, d_rot, d_hist[2], d_peaks, d_in, d_out, d_u, d_inter, d_rot_s;
@@ -256,6 +257,16 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 	p.run_frames   = pick_run_frames (e, n_out, n_chn);
 	p.dry_delay    = (int)e->info.dry_delay;
 	p.hilbert_only = hilbert_only ? 1 : 0;
+	if (e->use_p2) {
+		p.H          = e->d_H.p;
+		p.conv_delay = (int)e->info.conv_delay;
+		p.accumulate = 0;
+		hipError_t err = prot::launch_ola4096_p2 (p, n_chn, s);
+		if (err != hipSuccess) {
+			return hip_fail (err, "ola p2 kernel launch");
+		}
+		return PROT_OK;
+	}
 	for (uint32_t sp = 0; sp < e->info.partitions; ++sp) {
 		p.H          = e->d_H.p + (size_t)sp * e->info.fftlen;
 		p.conv_delay = (int)(e->info.conv_delay + sp * e->part_len);
@@ -398,7 +409,17 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	const uint32_t seg = F / 16;
 	int      hopseg;
 	uint32_t n_part, part_len;
-	if (inf.firlen <= F - F / 4) {
+	// 2049..4096 taps with a dry-delay difference of 6 or 8 segments (LV2 48/96 kHz, CLI
+	// blksiz 4096): two partitions sharing one forward transform (ola4096p2_kernel)
+	const uint32_t ddseg  = (inf.dry_delay - inf.conv_delay) / 256;
+	const bool     no_p2  = getenv ("PROT_NO_P2") != nullptr || (cfg->flags & PROT_CFG_SINGLE_FFT_PER_HOP);
+	bool           use_p2 = !no_p2 && inf.firlen > F / 2 + 1 && inf.firlen <= F &&
+	                        (inf.dry_delay - inf.conv_delay) % 256 == 0 && (ddseg == 6 || ddseg == 8);
+	if (use_p2) {
+		part_len = F / 2;
+		n_part   = 2;
+		hopseg   = 8;
+	} else if (inf.firlen <= F - F / 4) {
 		n_part   = 1;
 		part_len = inf.firlen;
 		hopseg   = (inf.firlen - 1 <= F / 2) ? 8 : 4; // hop = F/2 or F/4
@@ -436,10 +457,11 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	e->info   = inf;
 	e->device = cfg->device;
 	e->hopseg = hopseg;
+	e->use_p2 = use_p2;
 	{
 		int cus = 0;
 		if (hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) {
-			e->wg_slots = cus * 3; // 53 KiB of LDS per workgroup -> 3 per 160 KiB CU
+			e->wg_slots = cus * (use_p2 ? 2 : 3); // 53 KiB (70 KiB for the p2 kernel) of LDS per workgroup
 		}
 	}
 	if (const char* o = getenv ("PROT_PAIRS_PER_RUN")) {

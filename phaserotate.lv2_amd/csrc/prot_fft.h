@@ -162,6 +162,21 @@ PROT_DEV f2 pk_cmul (f2 a, f2 w)
 	return d;
 }
 
+// acc + a * w (DIR > 0) or acc + a * conj(w) (DIR < 0)
+template <int DIR>
+PROT_DEV f2 pk_cmul_acc (f2 acc, f2 a, f2 w)
+{
+	f2 r, d;
+	if (DIR > 0) {
+		asm ("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(acc));
+		asm ("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "v"(w), "v"(r));
+	} else {
+		asm ("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(acc));
+		asm ("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(w), "v"(r));
+	}
+	return d;
+}
+
 // 4-point DFT on packed values; CROT: operand c arrives un-rotated and still
 // has to be multiplied by -j (DIR > 0) / +j (DIR < 0) -- the W16^4 twiddle
 // folded into the butterfly.

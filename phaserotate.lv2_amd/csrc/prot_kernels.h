@@ -33,6 +33,11 @@ struct OlaParams {
 // fftlen 4096; hop = 256 * hopseg, hopseg in {4, 8}
 hipError_t launch_ola4096 (const OlaParams& p, int hopseg, int n_chn, hipStream_t s);
 
+// two 2048-tap FIR partitions sharing one forward transform (frequency-domain delay line);
+// p.H = [2][4096] spectra, p.conv_delay = delay of partition 0, (dry_delay - conv_delay)/256 in {6, 8},
+// p.run_frames a multiple of 4096
+hipError_t launch_ola4096_p2 (const OlaParams& p, int n_chn, hipStream_t s);
+
 // fp16 sample path (BASELINE config 5): half samples in HBM, packed-half butterflies,
 // fp32 overlap-add + rotation.  Stateless, steady rotation.
 struct OlaParamsH {

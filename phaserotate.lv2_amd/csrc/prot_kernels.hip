@@ -403,6 +403,300 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 	}
 }
 
+// --------------------------------------------------------------------------------------
+// ola4096p2_kernel -- FIRs of 2049..4096 taps (LV2 48 kHz: 3072, LV2 96 kHz / CLI blksiz
+// 4096: 4096) as TWO 2048-tap partitions that share one forward transform: a uniformly
+// partitioned overlap-add with a frequency-domain delay line,
+//     Y_b = X_b H0 + X_{b-1} H1,      hop 2048, 4096-point FFT
+// -- the reference LV2 engine's own scheme (src/phaserotate.c:640-657: n_segm partitions,
+// one c2r per block) at a partition size that suits the GPU.  Compared with four
+// zero-padded 1024-frame hops per 4096 frames it halves the transforms per frame.
+// The re/im packing pairs block b of two SUB-RUNS of the workgroup's run (first and second
+// half), so the delayed spectrum X_{b-1} of the pair is simply last iteration's registers.
+// --------------------------------------------------------------------------------------
+PROT_DEV void xchg_fwd1 (f2 (&v)[16], f2* lds, int t, int tl, int th)
+{
+	f2* w = &lds[t]; // own slots (k*kL1 + t): no barrier in front
+#pragma unroll
+	for (int k = 0; k < 16; ++k) {
+		w[k * kL1] = v[k];
+	}
+	__syncthreads ();
+	const f2* r = &lds[th * kL1 + tl];
+#pragma unroll
+	for (int k = 0; k < 16; ++k) {
+		v[k] = r[16 * k];
+	}
+}
+
+template <int NNZ>
+PROT_DEV void fwd4096 (f2 (&v)[16], f2* lds, const f2* twm, const f2 (&tw1)[16], int t, int tl, int th)
+{
+	pk_fft16_fwd_pruned<NNZ> (v);
+#pragma unroll
+	for (int k = 1; k < 16; ++k) {
+		v[k] = pk_cmul<1> (v[k], tw1[k]);
+	}
+	xchg_fwd1 (v, lds, t, tl, th);
+	pk_fft16<1> (v);
+#pragma unroll
+	for (int k = 1; k < 16; ++k) {
+		v[k] = pk_cmul<1> (v[k], twm[k * 16 + tl]);
+	}
+	__syncthreads ();
+	{
+		f2* w = &lds[tl * kL2 + th];
+#pragma unroll
+		for (int k = 0; k < 16; ++k) {
+			w[16 * k] = v[k];
+		}
+		__syncthreads ();
+		const f2* r = &lds[t];
+#pragma unroll
+		for (int k = 0; k < 16; ++k) {
+			v[k] = r[k * kL2];
+		}
+	}
+	pk_fft16<1> (v);
+}
+
+PROT_DEV void inv4096 (f2 (&v)[16], f2* lds, const f2* twm, const f2 (&tw1)[16], int t, int tl, int th)
+{
+	pk_fft16<-1> (v);
+#pragma unroll
+	for (int k = 1; k < 16; ++k) {
+		v[k] = pk_cmul<-1> (v[k], twm[th * 16 + k]);
+	}
+	{
+		f2* w = &lds[t]; // own slots (n0*kL2 + t) read at the end of fwd4096: no barrier in front
+#pragma unroll
+		for (int k = 0; k < 16; ++k) {
+			w[k * kL3] = v[k];
+		}
+		__syncthreads ();
+		const f2* r = &lds[tl * kL3 + th];
+#pragma unroll
+		for (int k = 0; k < 16; ++k) {
+			v[k] = r[16 * k];
+		}
+	}
+	pk_fft16<-1> (v);
+	__syncthreads ();
+	{
+		f2* w = &lds[th * kL1 + tl];
+#pragma unroll
+		for (int k = 0; k < 16; ++k) {
+			w[16 * k] = v[k];
+		}
+		__syncthreads ();
+		const f2* r = &lds[t];
+#pragma unroll
+		for (int k = 0; k < 16; ++k) {
+			v[k] = r[k * kL1];
+		}
+	}
+#pragma unroll
+	for (int k = 1; k < 16; ++k) {
+		v[k] = pk_cmul<-1> (v[k], tw1[k]);
+	}
+	pk_fft16<-1> (v);
+}
+
+template <int MODE, int DH>
+__global__ __launch_bounds__ (256, 2) void ola4096p2_kernel (const OlaParams p)
+{
+	constexpr int HOP = 2048;
+	static_assert (DH >= 1 && DH <= 8, "dry delay difference within one block");
+
+	__shared__ f2 lds[kLdsRegion];
+	__shared__ f2 twm[256];
+	__shared__ f2 Hs0[2049];
+	__shared__ f2 Hs1[2049];
+
+	const int     t  = threadIdx.x;
+	const int     c  = blockIdx.y;
+	const int64_t r0 = (int64_t)blockIdx.x * p.run_frames;
+	if (r0 >= p.n_out) {
+		return;
+	}
+	const int64_t r1 = (r0 + p.run_frames < p.n_out) ? r0 + p.run_frames : p.n_out;
+	const int64_t Lh = p.run_frames / 2;                      // sub-run length (multiple of HOP)
+	const int64_t eP = (r0 + Lh < r1) ? r0 + Lh : r1;         // sub-run P = [r0, eP), Q = [r0 + Lh, r1)
+
+	const float* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
+	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
+	float* __restrict__ out        = p.out + (int64_t)c * p.out_stride;
+	const int64_t n_in             = p.n_in;
+	const int     Dc               = p.conv_delay;
+
+	const f2* __restrict__ twp = reinterpret_cast<const f2*> (p.tw);
+	f2 tw1[16];
+#pragma unroll
+	for (int k = 1; k < 16; ++k) {
+		tw1[k] = twp[(t * k) & 4095];
+	}
+	twm[t] = twp[16 * (((t & 15) * (t >> 4)) & 255)];
+	for (int i = t; i <= 2048; i += 256) {
+		Hs0[i] = reinterpret_cast<const f2*> (p.H)[i];
+		Hs1[i] = reinterpret_cast<const f2*> (p.H)[4096 + i];
+	}
+	float ca = 0.f, sa = 1.f;
+	if (MODE == MODE_ROT) {
+		ca = p.rot[2 * c];
+		sa = p.rot[2 * c + 1];
+	}
+
+	const int tl = t & 15, th = t >> 4;
+	const int n_it = 2 + (int)((Lh + HOP - 1) / HOP);         // two halo blocks: OLA tail + X_{b-1}
+	int64_t   sP = r0 - 2 * HOP, sQ = sP + Lh;
+
+	float acc[16], dh[2 * DH], nx[16];
+	f2    zp[16];
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		acc[i] = 0.f;
+		zp[i]  = mkf2 (0.f, 0.f);
+	}
+#pragma unroll
+	for (int i = 0; i < DH; ++i) {
+		dh[i]      = ldv (in, n_in, hist, p.hist_len, sP - Dc - 256 * (DH - i) + t);
+		dh[DH + i] = ldv (in, n_in, hist, p.hist_len, sQ - Dc - 256 * (DH - i) + t);
+	}
+	auto load_blocks = [&] (int64_t aP, int64_t aQ) {
+		const bool fast = (aP >= 0) && (aQ + HOP <= n_in);
+		if (fast) {
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				nx[k]     = in[aP + t + 256 * k];
+				nx[8 + k] = in[aQ + t + 256 * k];
+			}
+		} else {
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				nx[k]     = ldv (in, n_in, hist, p.hist_len, aP + t + 256 * k);
+				nx[8 + k] = ldv (in, n_in, hist, p.hist_len, aQ + t + 256 * k);
+			}
+		}
+	};
+	load_blocks (sP - Dc, sQ - Dc);
+	__syncthreads ();
+
+	for (int it = 0; it < n_it; ++it, sP += HOP, sQ += HOP) {
+		f2    v[16];
+		float cur[16];
+#pragma unroll
+		for (int k = 0; k < 16; ++k) {
+			cur[k] = nx[k];
+		}
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			v[k]     = mkf2 (cur[k], cur[8 + k]);
+			v[8 + k] = mkf2 (0.f, 0.f);
+		}
+		fwd4096<8> (v, lds, twm, tw1, t, tl, th);
+
+		// Y = Z H0 + Z_prev H1; bins >= 2048 use the conjugate of the mirrored bin
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const f2 z = v[k];
+			v[k]       = pk_cmul_acc<1> (pk_cmul<1> (z, Hs0[t + 256 * k]), zp[k], Hs1[t + 256 * k]);
+			zp[k]      = z;
+		}
+#pragma unroll
+		for (int k = 8; k < 16; ++k) {
+			const f2 z = v[k];
+			v[k]       = pk_cmul_acc<-1> (pk_cmul<-1> (z, Hs0[256 * (16 - k) - t]), zp[k], Hs1[256 * (16 - k) - t]);
+			zp[k]      = z;
+		}
+
+		__builtin_amdgcn_sched_barrier (0);
+		if (it + 1 < n_it) {
+			load_blocks (sP + HOP - Dc, sQ + HOP - Dc);
+		}
+		__builtin_amdgcn_sched_barrier (0);
+
+		// dry path from registers: (dry_delay - conv_delay) = 256 * DH frames back
+		float dry[16];
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				dry[8 * h + k] = (k >= DH) ? cur[8 * h + (k >= DH ? k - DH : 0)] : dh[DH * h + (k < DH ? k : 0)];
+			}
+#pragma unroll
+			for (int i = 0; i < DH; ++i) {
+				dh[DH * h + i] = cur[8 * h + 8 - DH + i];
+			}
+		}
+
+		inv4096 (v, lds, twm, tw1, t, tl, th);
+
+		float u[16];
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			u[j]       = acc[j] + v[j].x;
+			u[8 + j]   = acc[8 + j] + v[j].y;
+			acc[j]     = v[8 + j].x;
+			acc[8 + j] = v[8 + j].y;
+		}
+
+		if (it >= 2) {
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				const int64_t s0  = h ? sQ : sP;
+				const int64_t end = h ? r1 : eP;
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					const int64_t pos = s0 + t + 256 * k;
+					if (pos < end) {
+						if (MODE == MODE_HILBERT) {
+							out[pos] = u[8 * h + k];
+						} else {
+							float cc = ca, ss = sa;
+							if (MODE == MODE_RAMP) {
+								const f2 cs = reinterpret_cast<const f2*> (p.rot_s)[(int64_t)c * p.n_out + pos];
+								cc          = cs.x;
+								ss          = cs.y;
+							}
+							out[pos] = cc * dry[8 * h + k] + ss * u[8 * h + k];
+						}
+					}
+				}
+			}
+		}
+	}
+}
+
+template <int MODE>
+static hipError_t launch_p2_m (const OlaParams& p, dim3 grid, hipStream_t s)
+{
+	const int dd = (p.dry_delay - p.conv_delay) / 256;
+	if (dd == 6) {
+		hipLaunchKernelGGL ((ola4096p2_kernel<MODE, 6>), grid, dim3 (256), 0, s, p);
+	} else if (dd == 8) {
+		hipLaunchKernelGGL ((ola4096p2_kernel<MODE, 8>), grid, dim3 (256), 0, s, p);
+	} else {
+		return hipErrorInvalidValue;
+	}
+	return hipGetLastError ();
+}
+
+hipError_t launch_ola4096_p2 (const OlaParams& p, int n_chn, hipStream_t s)
+{
+	if (p.n_out <= 0) {
+		return hipSuccess;
+	}
+	const int64_t runs = (p.n_out + p.run_frames - 1) / p.run_frames;
+	dim3          grid ((unsigned)runs, (unsigned)n_chn);
+	if (p.hilbert_only) {
+		return launch_p2_m<MODE_HILBERT> (p, grid, s);
+	}
+	if (p.rot_s != nullptr) {
+		return launch_p2_m<MODE_RAMP> (p, grid, s);
+	}
+	return launch_p2_m<MODE_ROT> (p, grid, s);
+}
+
 // PROT_OLA_VARIANT (debug/tuning only): 0 = default
 static int ola_variant ()
 {

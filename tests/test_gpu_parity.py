@@ -122,6 +122,27 @@ def test_lv2_run_stream(pkg, rate, bufsize, angle, n_chn):
     g.close()
 
 
+def test_lv2_single_fft_per_hop_geometry_matches_two_partition_geometry(pkg):
+    """LV2 48 kHz filter: one zero-padded 4096-pt FFT per 1024-frame hop (flag) vs two
+    2048-tap partitions sharing a forward transform (default) -- same LTI filter."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 300000
+    x = torch.from_numpy(xorshift_uniform(n, seed=31)).to(dev)
+    rot = np.array([0.28, -0.96], np.float32)
+    ys = []
+    for flags in (0, pkg.CFG_SINGLE_FFT_PER_HOP):
+        e = pkg.Engine(pkg.KIND_LV2, 48000, 1, flags=flags)
+        assert (e.info.partitions, e.info.hop) == ((2, 2048) if flags == 0 else (1, 1024))
+        y = torch.empty_like(x)
+        torch.cuda.synchronize()
+        e.apply_dev(x.data_ptr(), n, n, y.data_ptr(), n, n, rot, pkg.F_STATELESS)
+        e.sync()
+        ys.append(y)
+        e.close()
+    assert (ys[0] - ys[1]).abs().max().item() < TOL
+
+
 def test_lv2_angle_change_mid_stream(pkg):
     n, bs = 24000, 512
     x = xorshift_uniform(n, seed=99).reshape(1, n)
@@ -307,7 +328,7 @@ def test_fp16_sample_path_tolerance_report(pkg, kind, param, capsys):
     import torch
     dev = torch.device("cuda:0")
     n = 1 << 20
-    e = pkg.Engine(kind, param, 1)
+    e = pkg.Engine(kind, param, 1, flags=pkg.CFG_SINGLE_FFT_PER_HOP)  # the fp16 kernel is single-partition
     x32 = torch.from_numpy(0.9 * harmonic_stack(n) + 0.05 * xorshift_uniform(n, seed=4)).to(dev)
     x16 = x32.half()
     y32 = torch.empty_like(x32)

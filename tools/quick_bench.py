@@ -4,9 +4,9 @@ import numpy as np, torch
 from __graft_entry__ import load_package
 pkg = load_package()
 dev = torch.device("cuda:0")
-for kind, param, name in ((pkg.KIND_LV2, 48000, "lv2-48k hop1024"), (pkg.KIND_CLI, 2048, "cli-2048 hop2048")):
+for kind, param, fl, name in ((pkg.KIND_LV2, 48000, 1, "lv2-48k hop1024"), (pkg.KIND_LV2, 48000, 0, "lv2-48k p2"), (pkg.KIND_LV2, 96000, 0, "lv2-96k p2"), (pkg.KIND_CLI, 2048, 0, "cli-2048 hop2048")):
     n = 1 << 27
-    e = pkg.Engine(kind, param, 1)
+    e = pkg.Engine(kind, param, 1, flags=fl)
     x = (torch.rand(n, device=dev) - 0.5)
     y = torch.empty_like(x)
     rot = np.array([0.0, -1.0], np.float32)
