@@ -84,11 +84,19 @@ def main():
                          "--nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # PROT_BENCH_DEBUG_ONE_GPU=1: exercise the multi-rank code path on a single-GPU box (all ranks on
+    # device 0, gloo instead of RCCL).  Debug only -- its numbers mean nothing.
+    one_gpu_debug = os.environ.get("PROT_BENCH_DEBUG_ONE_GPU") == "1"
+    if one_gpu_debug:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if one_gpu_debug:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
     from __graft_entry__ import load_package
     pkg = load_package()
@@ -142,7 +150,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch") if args.frames_log2 == 27 else None
         except Exception:
             traffic = None
     out = {

@@ -186,6 +186,13 @@ struct prot_engine {
 	DevBuf<float>  d_lut, d_rot, d_hist[2], d_peaks, d_in, d_out, d_u, d_inter, d_rot_s;
 	DevBuf<int>    d_angles;
 	PinBuf<float>  h_io;
+	// small host->device parameter copies (rotation pairs, angle lists) are staged through a ring of
+	// pinned slots owned by the engine, each guarded by an event: the caller's array may die as soon
+	// as the call returns, and a slot is never rewritten before its previous copy has been consumed
+	static constexpr int kSlots = 64, kSlotBytes = 4096;
+	PinBuf<char>   h_slots;
+	hipEvent_t     slot_ev[kSlots] = {};
+	int            slot_next = 0;
 	int            hist_cur = 0;
 	uint64_t       pos      = 0; // frames consumed since reset (CLI stream position)
 	int            pairs_per_run_override = 0;
@@ -304,6 +311,24 @@ int hist_advance (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t
 hipStream_t pick_stream (prot_engine* e, void* stream)
 {
 	return stream ? (hipStream_t)stream : e->stream;
+}
+
+// copy a small host array to device memory in stream order without keeping a reference to `src`
+int stage_small (prot_engine* e, void* dst_dev, const void* src, size_t bytes, hipStream_t s)
+{
+	if (bytes > (size_t)prot_engine::kSlotBytes) { // many channels: rare, take the synchronous route
+		HIP_TRY (hipStreamSynchronize (s));
+		HIP_TRY (hipMemcpy (dst_dev, src, bytes, hipMemcpyHostToDevice));
+		return PROT_OK;
+	}
+	const int i = e->slot_next;
+	e->slot_next = (i + 1) % prot_engine::kSlots;
+	HIP_TRY (hipEventSynchronize (e->slot_ev[i])); // no-op unless 64 copies are still in flight
+	char* slot = e->h_slots.p + (size_t)i * prot_engine::kSlotBytes;
+	memcpy (slot, src, bytes);
+	HIP_TRY (hipMemcpyAsync (dst_dev, slot, bytes, hipMemcpyHostToDevice, s));
+	HIP_TRY (hipEventRecord (e->slot_ev[i], s));
+	return PROT_OK;
 }
 
 } // namespace
@@ -477,6 +502,14 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	if (hipStreamCreateWithFlags (&e->stream, hipStreamNonBlocking) != hipSuccess) {
 		return fail (PROT_EHIP);
 	}
+	if (e->h_slots.ensure ((size_t)prot_engine::kSlots * prot_engine::kSlotBytes) != PROT_OK) {
+		return fail (PROT_ENOMEM);
+	}
+	for (int i = 0; i < prot_engine::kSlots; ++i) {
+		if (hipEventCreateWithFlags (&e->slot_ev[i], hipEventDisableTiming) != hipSuccess) {
+			return fail (PROT_EHIP);
+		}
+	}
 
 	// FIR -> spectrum / F (the 1/fftlen of the OLA c2r, cli/phase-rotate.cc:142,
 	// src/phaserotate.c:393, folded into the table)
@@ -552,6 +585,12 @@ void prot_engine_destroy (prot_engine* e)
 	e->d_rot_s.release ();
 	e->d_angles.release ();
 	e->h_io.release ();
+	e->h_slots.release ();
+	for (int i = 0; i < prot_engine::kSlots; ++i) {
+		if (e->slot_ev[i]) {
+			(void)hipEventDestroy (e->slot_ev[i]);
+		}
+	}
 	if (e->stream) {
 		(void)hipStreamDestroy (e->stream);
 	}
@@ -614,7 +653,10 @@ int prot_apply_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 	hipStream_t s = pick_stream (e, stream);
 	const int   nc = (int)e->info.n_chn;
 	if (rot) {
-		HIP_TRY (hipMemcpyAsync (e->d_rot.p, rot, 2 * (size_t)nc * sizeof (float), hipMemcpyHostToDevice, s));
+		int rcs = stage_small (e, e->d_rot.p, rot, 2 * (size_t)nc * sizeof (float), s);
+		if (rcs) {
+			return rcs;
+		}
 	}
 	const bool stateless = flags & PROT_F_STATELESS;
 	int rc = ola_launch (e, d_in, in_stride, n_in, d_out, out_stride, n_out, e->d_rot.p, nullptr,
@@ -662,7 +704,12 @@ int prot_apply_dev_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uin
 	HIP_TRY (hipSetDevice (e->device));
 	hipStream_t s  = pick_stream (e, stream);
 	const int   nc = (int)e->info.n_chn;
-	HIP_TRY (hipMemcpyAsync (e->d_rot.p, rot, 2 * (size_t)nc * sizeof (float), hipMemcpyHostToDevice, s));
+	{
+		int rcs = stage_small (e, e->d_rot.p, rot, 2 * (size_t)nc * sizeof (float), s);
+		if (rcs) {
+			return rcs;
+		}
+	}
 	prot::OlaParamsH p {};
 	p.in         = (const _Float16*)d_in;
 	p.in_stride  = in_stride;
@@ -742,7 +789,10 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 	}
 	// 2. rotated peaks
 	if (n_ang > 0) {
-		HIP_TRY (hipMemcpyAsync (e->d_angles.p, lut_idx, n_ang * sizeof (int), hipMemcpyHostToDevice, s));
+		rc = stage_small (e, e->d_angles.p, lut_idx, n_ang * sizeof (int), s);
+		if (rc) {
+			return rc;
+		}
 		prot::SweepParams sp {};
 		sp.x        = d_in;
 		sp.x_stride = in_stride;
