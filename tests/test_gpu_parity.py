@@ -448,3 +448,25 @@ def test_full_size_sweep_shards_equal_single_pass(pkg):
         eng.close()
     assert torch.equal(pk1, pk2)
     one.close()
+
+
+def test_lv2_random_buffer_sizes_and_angle_moves(pkg):
+    """run() with ragged host buffer sizes (1..5000 frames) and the angle port moving at
+    random times: every reference block boundary / ramp start lands somewhere else."""
+    rng = np.random.default_rng(2024)
+    n = 60000
+    x = xorshift_uniform(2 * n, seed=17).reshape(2, n)
+    g = pkg.Lv2Instance(48000, 2)
+    g.activate()
+    o = orc.Lv2Engine(48000, 2)
+    yg, yo = np.empty_like(x), np.empty_like(x)
+    pos, ang = 0, np.array([10.0, -20.0], np.float32)
+    while pos < n:
+        sz = int(min(n - pos, rng.choice([1, 7, 64, 255, 256, 257, 1000, 1024, 3333, 5000])))
+        if rng.random() < 0.15:
+            ang = rng.uniform(-200, 200, 2).astype(np.float32)  # beyond +-180: clamped (src/phaserotate.c:566-571)
+        yg[:, pos:pos + sz] = g.run(x[:, pos:pos + sz], ang)
+        yo[:, pos:pos + sz] = o.run(x[:, pos:pos + sz], ang)
+        pos += sz
+    assert np.abs(yg - yo).max() < TOL_RAMP
+    g.close()
