@@ -192,7 +192,7 @@ def main():
 
     if not args.no_extra:
         # BASELINE config 5: fp16 sample path of the headline workload (4 B per frame)
-        engH = pkg.Engine(pkg.KIND_LV2, 48000, 1, device=local_rank, flags=pkg.CFG_SINGLE_FFT_PER_HOP)
+        engH = pkg.Engine(pkg.KIND_LV2, 48000, 1, device=local_rank)
         xh, yh = x.half(), torch.empty(n, device=dev, dtype=torch.float16)
 
         def step_h():

@@ -698,7 +698,7 @@ int prot_apply_dev_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uin
 	if (!e || !d_in || !d_out || !rot) {
 		return PROT_EINVAL;
 	}
-	if (e->info.partitions != 1) {
+	if (e->info.partitions != 1 && !e->use_p2) {
 		return PROT_EUNSUPPORTED;
 	}
 	HIP_TRY (hipSetDevice (e->device));
@@ -723,7 +723,7 @@ int prot_apply_dev_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uin
 	p.run_frames = pick_run_frames (e, n_out, nc);
 	p.conv_delay = (int)e->info.conv_delay;
 	p.dry_delay  = (int)e->info.dry_delay;
-	hipError_t err = prot::launch_ola4096_f16 (p, e->hopseg, nc, s);
+	hipError_t err = e->use_p2 ? prot::launch_ola4096_p2_f16 (p, nc, s) : prot::launch_ola4096_f16 (p, e->hopseg, nc, s);
 	if (err != hipSuccess) {
 		return hip_fail (err, "fp16 ola kernel launch");
 	}

@@ -124,115 +124,134 @@ PROT_DEV void fft16 (f2 (&v)[16])
 
 
 // --------------------------------------------------------------------------
-// Packed-fp32 butterflies (v_pk_add/mul/fma_f32 with op_sel / neg modifiers).
+// Packed butterflies: v_pk_{add,mul,fma}_{f32,f16} with op_sel / neg modifiers.
 // Same arithmetic as above, half the instruction count: one instruction per
 // complex add, two per complex multiply, and the +-j rotations are free
 // operand swizzles.  v_pk_*_f32 has the scalar ops' lane-op rate on gfx950
 // (measured, tools/ubench/valu_rate.hip) but needs half the issue slots, which
-// is what a barrier/LDS-stalled wave is short of.  hipcc's SLP vectoriser
-// cannot produce this form: it marshals register pairs with ~500 v_mov per
-// iteration instead of using the swizzle modifiers.
+// is what a barrier/LDS-stalled wave is short of; v_pk_*_f16 also doubles the
+// arithmetic rate.  hipcc's SLP vectoriser cannot produce this form: it
+// marshals register pairs with ~500 v_mov per iteration instead of using the
+// swizzle modifiers.
+//
+// One complex value is one f2 (aligned VGPR pair) or one h2 (one VGPR); the
+// VOP3P modifiers mean the same for both widths: op_sel[i] / op_sel_hi[i] pick
+// the low or high element of source i for the low / high result, neg_lo /
+// neg_hi negate it.
 // --------------------------------------------------------------------------
-// a + (-j) b = (a.x + b.y, a.y - b.x)
-PROT_DEV f2 pk_add_mj (f2 a, f2 b)
-{
-	f2 d;
-	asm ("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-	return d;
-}
-// a - (-j) b = a + j b = (a.x - b.y, a.y + b.x)
-PROT_DEV f2 pk_sub_mj (f2 a, f2 b)
-{
-	f2 d;
-	asm ("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-	return d;
-}
-// a * w (DIR > 0), a * conj(w) (DIR < 0)
-template <int DIR>
-PROT_DEV f2 pk_cmul (f2 a, f2 w)
-{
-	f2 r, d;
-	if (DIR > 0) {
-		asm ("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(w));               // (ax wx, ax wy)
-		asm ("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "v"(w), "v"(r)); // (-ay wy + ., ay wx + .)
-	} else {
-		asm ("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(w));  // (ax wx, -ax wy)
-		asm ("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(w), "v"(r)); // (ay wy + ., ay wx + .)
-	}
-	return d;
-}
+typedef _Float16 h2 __attribute__ ((ext_vector_type (2)));
 
-// acc + a * w (DIR > 0) or acc + a * conj(w) (DIR < 0)
-template <int DIR>
-PROT_DEV f2 pk_cmul_acc (f2 acc, f2 a, f2 w)
-{
-	f2 r, d;
-	if (DIR > 0) {
-		asm ("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(acc));
-		asm ("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "v"(w), "v"(r));
-	} else {
-		asm ("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(acc));
-		asm ("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(w), "v"(r));
+#define PROT_PK_OPS(NAME, C, E, SFX)                                                                         \
+	struct NAME {                                                                                            \
+		typedef C cplx;                                                                                      \
+		PROT_DEV C mk (float x, float y) { return C{ (E)x, (E)y }; }                                         \
+		/* a + (-j) b = (a.x + b.y, a.y - b.x) */                                                            \
+		PROT_DEV C add_mj (C a, C b)                                                                         \
+		{                                                                                                    \
+			C d;                                                                                             \
+			asm ("v_pk_add_" SFX " %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); \
+			return d;                                                                                        \
+		}                                                                                                    \
+		/* a - (-j) b = a + j b = (a.x - b.y, a.y + b.x) */                                                  \
+		PROT_DEV C sub_mj (C a, C b)                                                                         \
+		{                                                                                                    \
+			C d;                                                                                             \
+			asm ("v_pk_add_" SFX " %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b)); \
+			return d;                                                                                        \
+		}                                                                                                    \
+		/* a * w (DIR > 0), a * conj(w) (DIR < 0) */                                                         \
+		template <int DIR>                                                                                   \
+		PROT_DEV C cmul (C a, C w)                                                                           \
+		{                                                                                                    \
+			C r, d;                                                                                          \
+			if (DIR > 0) {                                                                                   \
+				asm ("v_pk_mul_" SFX " %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(w)); \
+				asm ("v_pk_fma_" SFX " %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"      \
+				     : "=v"(d) : "v"(a), "v"(w), "v"(r));                                                    \
+			} else {                                                                                         \
+				asm ("v_pk_mul_" SFX " %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(w)); \
+				asm ("v_pk_fma_" SFX " %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(w), "v"(r)); \
+			}                                                                                                \
+			return d;                                                                                        \
+		}                                                                                                    \
+		/* acc + a * w (DIR > 0) or acc + a * conj(w) (DIR < 0) */                                           \
+		template <int DIR>                                                                                   \
+		PROT_DEV C cmul_acc (C acc, C a, C w)                                                                \
+		{                                                                                                    \
+			C r, d;                                                                                          \
+			if (DIR > 0) {                                                                                   \
+				asm ("v_pk_fma_" SFX " %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(acc)); \
+				asm ("v_pk_fma_" SFX " %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"      \
+				     : "=v"(d) : "v"(a), "v"(w), "v"(r));                                                    \
+			} else {                                                                                         \
+				asm ("v_pk_fma_" SFX " %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"      \
+				     : "=v"(r) : "v"(a), "v"(w), "v"(acc));                                                  \
+				asm ("v_pk_fma_" SFX " %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(w), "v"(r)); \
+			}                                                                                                \
+			return d;                                                                                        \
+		}                                                                                                    \
 	}
-	return d;
-}
+
+PROT_PK_OPS (pk32, f2, float, "f32");
+PROT_PK_OPS (pk16, h2, _Float16, "f16");
+#undef PROT_PK_OPS
 
 // 4-point DFT on packed values; CROT: operand c arrives un-rotated and still
 // has to be multiplied by -j (DIR > 0) / +j (DIR < 0) -- the W16^4 twiddle
 // folded into the butterfly.
-template <int DIR, bool CROT = false>
-PROT_DEV void pk_radix4 (f2& a, f2& b, f2& c, f2& d)
+template <class O, int DIR, bool CROT = false>
+PROT_DEV void pkt_radix4 (typename O::cplx& a, typename O::cplx& b, typename O::cplx& c, typename O::cplx& d)
 {
-	f2 t0, t1;
+	typename O::cplx t0, t1;
 	if (!CROT) {
 		t0 = a + c;
 		t1 = a - c;
 	} else if (DIR > 0) {
-		t0 = pk_add_mj (a, c);
-		t1 = pk_sub_mj (a, c);
+		t0 = O::add_mj (a, c);
+		t1 = O::sub_mj (a, c);
 	} else {
-		t0 = pk_sub_mj (a, c);
-		t1 = pk_add_mj (a, c);
+		t0 = O::sub_mj (a, c);
+		t1 = O::add_mj (a, c);
 	}
-	const f2 t2 = b + d;
-	const f2 t3 = b - d;
-	a           = t0 + t2;
-	c           = t0 - t2;
+	const typename O::cplx t2 = b + d;
+	const typename O::cplx t3 = b - d;
+	a = t0 + t2;
+	c = t0 - t2;
 	if (DIR > 0) {
-		b = pk_add_mj (t1, t3);
-		d = pk_sub_mj (t1, t3);
+		b = O::add_mj (t1, t3);
+		d = O::sub_mj (t1, t3);
 	} else {
-		b = pk_sub_mj (t1, t3);
-		d = pk_add_mj (t1, t3);
+		b = O::sub_mj (t1, t3);
+		d = O::add_mj (t1, t3);
 	}
 }
 
-template <int DIR, int M>
-PROT_DEV f2 pk_mul_w16 (f2 a)
+template <class O, int DIR, int M>
+PROT_DEV typename O::cplx pkt_mul_w16 (typename O::cplx a)
 {
 	constexpr float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f, R = 0.70710678118654752440f;
 	constexpr int   m  = M & 15;
 	static_assert (m == 1 || m == 2 || m == 3 || m == 6 || m == 9, "twiddle not used by fft16");
 	if (m == 2) { // R(1 -+ j) a
-		return (DIR > 0 ? pk_add_mj (a, a) : pk_sub_mj (a, a)) * f2{ R, R };
+		return (DIR > 0 ? O::add_mj (a, a) : O::sub_mj (a, a)) * O::mk (R, R);
 	} else if (m == 6) { // R(-1 -+ j) a
-		return (DIR > 0 ? pk_sub_mj (a, a) : pk_add_mj (a, a)) * f2{ -R, -R };
+		return (DIR > 0 ? O::sub_mj (a, a) : O::add_mj (a, a)) * O::mk (-R, -R);
 	} else {
 		constexpr float cw = (m == 1) ? C1 : (m == 3) ? S1 : /* 9 */ -C1;
 		constexpr float sw = (m == 1) ? S1 : (m == 3) ? C1 : /* 9 */ -S1;
-		return pk_cmul<DIR> (a, f2{ cw, -sw });
+		return O::template cmul<DIR> (a, O::mk (cw, -sw));
 	}
 }
 
 // second half of the radix-16 (after stage 1 and its twiddles): four DFT-4 and the un-permute
-template <int DIR>
-PROT_DEV void pk_fft16_stage2 (f2 (&v)[16])
+template <class O, int DIR>
+PROT_DEV void pkt_fft16_stage2 (typename O::cplx (&v)[16])
 {
-	pk_radix4<DIR> (v[0], v[1], v[2], v[3]);
-	pk_radix4<DIR> (v[4], v[5], v[6], v[7]);
-	pk_radix4<DIR, true> (v[8], v[9], v[10], v[11]); // v[10] carries the pending W16^4 = -+j
-	pk_radix4<DIR> (v[12], v[13], v[14], v[15]);
-	f2 t;
+	pkt_radix4<O, DIR> (v[0], v[1], v[2], v[3]);
+	pkt_radix4<O, DIR> (v[4], v[5], v[6], v[7]);
+	pkt_radix4<O, DIR, true> (v[8], v[9], v[10], v[11]); // v[10] carries the pending W16^4 = -+j
+	pkt_radix4<O, DIR> (v[12], v[13], v[14], v[15]);
+	typename O::cplx t;
 	t = v[1];  v[1]  = v[4];  v[4]  = t;
 	t = v[2];  v[2]  = v[8];  v[8]  = t;
 	t = v[3];  v[3]  = v[12]; v[12] = t;
@@ -241,35 +260,35 @@ PROT_DEV void pk_fft16_stage2 (f2 (&v)[16])
 	t = v[11]; v[11] = v[14]; v[14] = t;
 }
 
-template <int DIR>
-PROT_DEV void pk_stage1_twiddles (f2 (&v)[16])
+template <class O, int DIR>
+PROT_DEV void pkt_stage1_twiddles (typename O::cplx (&v)[16])
 {
-	v[5]  = pk_mul_w16<DIR, 1> (v[5]);
-	v[6]  = pk_mul_w16<DIR, 2> (v[6]);
-	v[7]  = pk_mul_w16<DIR, 3> (v[7]);
-	v[9]  = pk_mul_w16<DIR, 2> (v[9]);
+	v[5]  = pkt_mul_w16<O, DIR, 1> (v[5]);
+	v[6]  = pkt_mul_w16<O, DIR, 2> (v[6]);
+	v[7]  = pkt_mul_w16<O, DIR, 3> (v[7]);
+	v[9]  = pkt_mul_w16<O, DIR, 2> (v[9]);
 	/* v[10]: W16^4 folded into stage 2 */
-	v[11] = pk_mul_w16<DIR, 6> (v[11]);
-	v[13] = pk_mul_w16<DIR, 3> (v[13]);
-	v[14] = pk_mul_w16<DIR, 6> (v[14]);
-	v[15] = pk_mul_w16<DIR, 9> (v[15]);
+	v[11] = pkt_mul_w16<O, DIR, 6> (v[11]);
+	v[13] = pkt_mul_w16<O, DIR, 3> (v[13]);
+	v[14] = pkt_mul_w16<O, DIR, 6> (v[14]);
+	v[15] = pkt_mul_w16<O, DIR, 9> (v[15]);
 }
 
-template <int DIR>
-PROT_DEV void pk_fft16 (f2 (&v)[16])
+template <class O, int DIR>
+PROT_DEV void pkt_fft16 (typename O::cplx (&v)[16])
 {
-	pk_radix4<DIR> (v[0], v[4], v[8], v[12]);
-	pk_radix4<DIR> (v[1], v[5], v[9], v[13]);
-	pk_radix4<DIR> (v[2], v[6], v[10], v[14]);
-	pk_radix4<DIR> (v[3], v[7], v[11], v[15]);
-	pk_stage1_twiddles<DIR> (v);
-	pk_fft16_stage2<DIR> (v);
+	pkt_radix4<O, DIR> (v[0], v[4], v[8], v[12]);
+	pkt_radix4<O, DIR> (v[1], v[5], v[9], v[13]);
+	pkt_radix4<O, DIR> (v[2], v[6], v[10], v[14]);
+	pkt_radix4<O, DIR> (v[3], v[7], v[11], v[15]);
+	pkt_stage1_twiddles<O, DIR> (v);
+	pkt_fft16_stage2<O, DIR> (v);
 }
 
 // forward radix-16 of a zero-padded column: only v[0..NNZ) are non-zero (NNZ = 4 or 8).
 // The asm butterflies are opaque to constant folding, so the pruning is spelled out.
-template <int NNZ>
-PROT_DEV void pk_fft16_fwd_pruned (f2 (&v)[16])
+template <class O, int NNZ>
+PROT_DEV void pkt_fft16_fwd_pruned (typename O::cplx (&v)[16])
 {
 	static_assert (NNZ == 4 || NNZ == 8, "hop is 1/4 or 1/2 of the transform");
 	if (NNZ == 4) { // stage 1 degenerates to copies: y[be][ka] = x[be]
@@ -280,15 +299,23 @@ PROT_DEV void pk_fft16_fwd_pruned (f2 (&v)[16])
 	} else { // inputs al = 0, 1 only: DFT-4 of (a, b, 0, 0) = (a + b, a - j b, a - b, a + j b)
 #pragma unroll
 		for (int be = 0; be < 4; ++be) {
-			const f2 a = v[be], b = v[4 + be];
+			const typename O::cplx a = v[be], b = v[4 + be];
 			v[be]      = a + b;
-			v[4 + be]  = pk_add_mj (a, b);
+			v[4 + be]  = O::add_mj (a, b);
 			v[8 + be]  = a - b;
-			v[12 + be] = pk_sub_mj (a, b);
+			v[12 + be] = O::sub_mj (a, b);
 		}
 	}
-	pk_stage1_twiddles<1> (v);
-	pk_fft16_stage2<1> (v);
+	pkt_stage1_twiddles<O, 1> (v);
+	pkt_fft16_stage2<O, 1> (v);
 }
+
+// fp32 names used by the kernels
+PROT_DEV f2 pk_add_mj (f2 a, f2 b) { return pk32::add_mj (a, b); }
+PROT_DEV f2 pk_sub_mj (f2 a, f2 b) { return pk32::sub_mj (a, b); }
+template <int DIR> PROT_DEV f2 pk_cmul (f2 a, f2 w) { return pk32::cmul<DIR> (a, w); }
+template <int DIR> PROT_DEV f2 pk_cmul_acc (f2 acc, f2 a, f2 w) { return pk32::cmul_acc<DIR> (acc, a, w); }
+template <int DIR> PROT_DEV void pk_fft16 (f2 (&v)[16]) { pkt_fft16<pk32, DIR> (v); }
+template <int NNZ> PROT_DEV void pk_fft16_fwd_pruned (f2 (&v)[16]) { pkt_fft16_fwd_pruned<pk32, NNZ> (v); }
 
 } // namespace prot

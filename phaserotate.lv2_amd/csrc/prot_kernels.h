@@ -9,17 +9,18 @@ namespace prot {
 constexpr int kMaxSample = 360; // cli/phase-rotate.cc:39
 
 // One launch of the overlap-add kernel: every workgroup owns a run of
-// consecutive hops of one channel-stream.
-struct OlaParams {
-	const float*  in;         // device, planar; channel c at in + c*in_stride
+// consecutive hops of one channel-stream.  S = sample type in HBM (float or _Float16).
+template <class S>
+struct OlaParamsT {
+	const S*      in;         // device, planar; channel c at in + c*in_stride
 	int64_t       in_stride;
 	int64_t       n_in;       // valid input frames; reads at >= n_in are silence
-	const float*  hist;       // device, [n_chn][hist_len]: frames before in[0]; NULL = silence
+	const S*      hist;       // device, [n_chn][hist_len]: frames before in[0]; NULL = silence
 	int32_t       hist_len;
-	float*        out;        // device, planar
+	S*            out;        // device, planar
 	int64_t       out_stride;
 	int64_t       n_out;      // emit t in [0, n_out)
-	const float2* H;          // device, [fftlen] FIR spectrum / fftlen, natural bin order
+	const float2* H;          // device, [partitions][fftlen] FIR spectrum / fftlen, natural bin order
 	const float2* tw;         // device, [fftlen] e^{-2 pi i m / fftlen}
 	const float*  rot;        // device, [n_chn][2] {ca, sa}              (steady)
 	const float*  rot_s;      // device, [n_chn][n_out][2] per-frame      (ramp) or NULL
@@ -29,6 +30,8 @@ struct OlaParams {
 	int32_t       hilbert_only;
 	int32_t       accumulate; // add sa*u to out instead of storing ca*dry + sa*u (FIR partitions > 0)
 };
+typedef OlaParamsT<float>    OlaParams;
+typedef OlaParamsT<_Float16> OlaParamsH; // fp16 sample path (BASELINE config 5)
 
 // fftlen 4096; hop = 256 * hopseg, hopseg in {4, 8}
 hipError_t launch_ola4096 (const OlaParams& p, int hopseg, int n_chn, hipStream_t s);
@@ -40,19 +43,8 @@ hipError_t launch_ola4096_p2 (const OlaParams& p, int n_chn, hipStream_t s);
 
 // fp16 sample path (BASELINE config 5): half samples in HBM, packed-half butterflies,
 // fp32 overlap-add + rotation.  Stateless, steady rotation.
-struct OlaParamsH {
-	const _Float16* in;
-	int64_t         in_stride;
-	int64_t         n_in;
-	_Float16*       out;
-	int64_t         out_stride;
-	int64_t         n_out;
-	const float2*   H;   // same fp32 tables as the fp32 path; rounded to half when staged into LDS
-	const float2*   tw;
-	const float*    rot; // device [n_chn][2]
-	int32_t         run_frames, conv_delay, dry_delay;
-};
 hipError_t launch_ola4096_f16 (const OlaParamsH& p, int hopseg, int n_chn, hipStream_t s);
+hipError_t launch_ola4096_p2_f16 (const OlaParamsH& p, int n_chn, hipStream_t s);
 
 // Rotated abs-max sweep over t in [t_begin, t_end) of one chunk:
 //   v = ca[a] * (t_abs >= dry_from ? x[t - delay] : 0) + sa[a] * u[t]

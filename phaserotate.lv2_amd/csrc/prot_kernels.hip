@@ -40,14 +40,14 @@ namespace prot {
 
 // ------------------------------------------------------------------ helpers
 // virtual stream [hist | in | silence] at index i (i may be negative)
-PROT_DEV float ldv (const float* __restrict__ in, int64_t n_in, const float* __restrict__ hist,
-                    int hist_len, int64_t i)
+template <class S>
+PROT_DEV float ldv (const S* __restrict__ in, int64_t n_in, const S* __restrict__ hist, int hist_len, int64_t i)
 {
 	if (i >= 0) {
-		return i < n_in ? in[i] : 0.f;
+		return i < n_in ? (float)in[i] : 0.f;
 	}
 	const int64_t h = i + hist_len;
-	return (hist != nullptr && h >= 0) ? hist[h] : 0.f;
+	return (hist != nullptr && h >= 0) ? (float)hist[h] : 0.f;
 }
 
 // ------------------------------------------------------------ OLA, FFT-4096
@@ -414,82 +414,103 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 // The re/im packing pairs block b of two SUB-RUNS of the workgroup's run (first and second
 // half), so the delayed spectrum X_{b-1} of the pair is simply last iteration's registers.
 // --------------------------------------------------------------------------------------
-PROT_DEV void xchg_fwd1 (f2 (&v)[16], f2* lds, int t, int tl, int th)
+// precision traits: fp32 (aligned VGPR pair per complex) and fp16 (one VGPR per complex)
+struct T32 {
+	typedef pk32  ops;
+	typedef f2    cplx;
+	typedef float samp;
+};
+struct T16 {
+	typedef pk16     ops;
+	typedef h2       cplx;
+	typedef _Float16 samp;
+};
+
+template <class T>
+PROT_DEV void xchg_fwd1 (typename T::cplx (&v)[16], typename T::cplx* lds, int t, int tl, int th)
 {
-	f2* w = &lds[t]; // own slots (k*kL1 + t): no barrier in front
+	typedef typename T::cplx C;
+	C* w = &lds[t]; // own slots (k*kL1 + t): no barrier in front
 #pragma unroll
 	for (int k = 0; k < 16; ++k) {
 		w[k * kL1] = v[k];
 	}
 	__syncthreads ();
-	const f2* r = &lds[th * kL1 + tl];
+	const C* r = &lds[th * kL1 + tl];
 #pragma unroll
 	for (int k = 0; k < 16; ++k) {
 		v[k] = r[16 * k];
 	}
 }
 
-template <int NNZ>
-PROT_DEV void fwd4096 (f2 (&v)[16], f2* lds, const f2* twm, const f2 (&tw1)[16], int t, int tl, int th)
+template <class T, int NNZ>
+PROT_DEV void fwd4096 (typename T::cplx (&v)[16], typename T::cplx* lds, const typename T::cplx* twm,
+                       const typename T::cplx (&tw1)[16], int t, int tl, int th)
 {
-	pk_fft16_fwd_pruned<NNZ> (v);
+	typedef typename T::cplx C;
+	typedef typename T::ops  O;
+	pkt_fft16_fwd_pruned<O, NNZ> (v);
 #pragma unroll
 	for (int k = 1; k < 16; ++k) {
-		v[k] = pk_cmul<1> (v[k], tw1[k]);
+		v[k] = O::template cmul<1> (v[k], tw1[k]);
 	}
-	xchg_fwd1 (v, lds, t, tl, th);
-	pk_fft16<1> (v);
+	xchg_fwd1<T> (v, lds, t, tl, th);
+	pkt_fft16<O, 1> (v);
 #pragma unroll
 	for (int k = 1; k < 16; ++k) {
-		v[k] = pk_cmul<1> (v[k], twm[k * 16 + tl]);
+		v[k] = O::template cmul<1> (v[k], twm[k * 16 + tl]);
 	}
 	__syncthreads ();
 	{
-		f2* w = &lds[tl * kL2 + th];
+		C* w = &lds[tl * kL2 + th];
 #pragma unroll
 		for (int k = 0; k < 16; ++k) {
 			w[16 * k] = v[k];
 		}
 		__syncthreads ();
-		const f2* r = &lds[t];
+		const C* r = &lds[t];
 #pragma unroll
 		for (int k = 0; k < 16; ++k) {
 			v[k] = r[k * kL2];
 		}
 	}
-	pk_fft16<1> (v);
+	pkt_fft16<O, 1> (v);
 }
 
-PROT_DEV void inv4096 (f2 (&v)[16], f2* lds, const f2* twm, const f2 (&tw1)[16], int t, int tl, int th)
+template <class T>
+PROT_DEV void inv4096 (typename T::cplx (&v)[16], typename T::cplx* lds, const typename T::cplx* twm,
+                       const typename T::cplx (&tw1)[16], int t, int tl, int th)
 {
-	pk_fft16<-1> (v);
+	typedef typename T::cplx C;
+	typedef typename T::ops  O;
+	pkt_fft16<O, -1> (v);
 #pragma unroll
 	for (int k = 1; k < 16; ++k) {
-		v[k] = pk_cmul<-1> (v[k], twm[th * 16 + k]);
+		v[k] = O::template cmul<-1> (v[k], twm[th * 16 + k]);
 	}
 	{
-		f2* w = &lds[t]; // own slots (n0*kL2 + t) read at the end of fwd4096: no barrier in front
+		C* w = &lds[t]; // own slots (n0*kL2 + t) read at the end of fwd4096: no barrier in front
 #pragma unroll
 		for (int k = 0; k < 16; ++k) {
 			w[k * kL3] = v[k];
 		}
 		__syncthreads ();
-		const f2* r = &lds[tl * kL3 + th];
+		const C* r = &lds[tl * kL3 + th];
 #pragma unroll
 		for (int k = 0; k < 16; ++k) {
 			v[k] = r[16 * k];
 		}
 	}
-	pk_fft16<-1> (v);
+	pkt_fft16<O, -1> (v);
 	__syncthreads ();
 	{
-		f2* w = &lds[th * kL1 + tl];
+		C* w = &lds[th * kL1 + tl];
 #pragma unroll
 		for (int k = 0; k < 16; ++k) {
 			w[16 * k] = v[k];
 		}
 		__syncthreads ();
-		const f2* r = &lds[t];
+		const C* r = &lds[t];
 #pragma unroll
 		for (int k = 0; k < 16; ++k) {
 			v[k] = r[k * kL1];
@@ -497,21 +518,24 @@ PROT_DEV void inv4096 (f2 (&v)[16], f2* lds, const f2* twm, const f2 (&tw1)[16],
 	}
 #pragma unroll
 	for (int k = 1; k < 16; ++k) {
-		v[k] = pk_cmul<-1> (v[k], tw1[k]);
+		v[k] = O::template cmul<-1> (v[k], tw1[k]);
 	}
-	pk_fft16<-1> (v);
+	pkt_fft16<O, -1> (v);
 }
 
-template <int MODE, int DH>
-__global__ __launch_bounds__ (256, 2) void ola4096p2_kernel (const OlaParams p)
+template <class T, int MODE, int DH>
+__global__ __launch_bounds__ (256, 2) void ola4096p2_kernel (const OlaParamsT<typename T::samp> p)
 {
+	typedef typename T::cplx C;
+	typedef typename T::ops  O;
+	typedef typename T::samp S;
 	constexpr int HOP = 2048;
 	static_assert (DH >= 1 && DH <= 8, "dry delay difference within one block");
 
-	__shared__ f2 lds[kLdsRegion];
-	__shared__ f2 twm[256];
-	__shared__ f2 Hs0[2049];
-	__shared__ f2 Hs1[2049];
+	__shared__ C lds[kLdsRegion];
+	__shared__ C twm[256];
+	__shared__ C Hs0[2049];
+	__shared__ C Hs1[2049];
 
 	const int     t  = threadIdx.x;
 	const int     c  = blockIdx.y;
@@ -523,22 +547,27 @@ __global__ __launch_bounds__ (256, 2) void ola4096p2_kernel (const OlaParams p)
 	const int64_t Lh = p.run_frames / 2;                      // sub-run length (multiple of HOP)
 	const int64_t eP = (r0 + Lh < r1) ? r0 + Lh : r1;         // sub-run P = [r0, eP), Q = [r0 + Lh, r1)
 
-	const float* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
-	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
-	float* __restrict__ out        = p.out + (int64_t)c * p.out_stride;
+	const S* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
+	const S* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
+	S* __restrict__ out        = p.out + (int64_t)c * p.out_stride;
 	const int64_t n_in             = p.n_in;
 	const int     Dc               = p.conv_delay;
 
 	const f2* __restrict__ twp = reinterpret_cast<const f2*> (p.tw);
-	f2 tw1[16];
+	C tw1[16];
 #pragma unroll
 	for (int k = 1; k < 16; ++k) {
-		tw1[k] = twp[(t * k) & 4095];
+		const f2 w = twp[(t * k) & 4095];
+		tw1[k]     = O::mk (w.x, w.y);
 	}
-	twm[t] = twp[16 * (((t & 15) * (t >> 4)) & 255)];
-	for (int i = t; i <= 2048; i += 256) {
-		Hs0[i] = reinterpret_cast<const f2*> (p.H)[i];
-		Hs1[i] = reinterpret_cast<const f2*> (p.H)[4096 + i];
+	{
+		const f2 w = twp[16 * (((t & 15) * (t >> 4)) & 255)];
+		twm[t]     = O::mk (w.x, w.y);
+	}
+	for (int i = t; i <= 2048; i += 256) { // |H|/4096 = 2.4e-4 is still a normal fp16 number
+		const f2 h0 = reinterpret_cast<const f2*> (p.H)[i], h1 = reinterpret_cast<const f2*> (p.H)[4096 + i];
+		Hs0[i]      = O::mk (h0.x, h0.y);
+		Hs1[i]      = O::mk (h1.x, h1.y);
 	}
 	float ca = 0.f, sa = 1.f;
 	if (MODE == MODE_ROT) {
@@ -551,11 +580,11 @@ __global__ __launch_bounds__ (256, 2) void ola4096p2_kernel (const OlaParams p)
 	int64_t   sP = r0 - 2 * HOP, sQ = sP + Lh;
 
 	float acc[16], dh[2 * DH], nx[16];
-	f2    zp[16];
+	C     zp[16];
 #pragma unroll
 	for (int i = 0; i < 16; ++i) {
 		acc[i] = 0.f;
-		zp[i]  = mkf2 (0.f, 0.f);
+		zp[i]  = O::mk (0.f, 0.f);
 	}
 #pragma unroll
 	for (int i = 0; i < DH; ++i) {
@@ -567,8 +596,8 @@ __global__ __launch_bounds__ (256, 2) void ola4096p2_kernel (const OlaParams p)
 		if (fast) {
 #pragma unroll
 			for (int k = 0; k < 8; ++k) {
-				nx[k]     = in[aP + t + 256 * k];
-				nx[8 + k] = in[aQ + t + 256 * k];
+				nx[k]     = (float)in[aP + t + 256 * k];
+				nx[8 + k] = (float)in[aQ + t + 256 * k];
 			}
 		} else {
 #pragma unroll
@@ -582,7 +611,7 @@ __global__ __launch_bounds__ (256, 2) void ola4096p2_kernel (const OlaParams p)
 	__syncthreads ();
 
 	for (int it = 0; it < n_it; ++it, sP += HOP, sQ += HOP) {
-		f2    v[16];
+		C     v[16];
 		float cur[16];
 #pragma unroll
 		for (int k = 0; k < 16; ++k) {
@@ -590,22 +619,22 @@ __global__ __launch_bounds__ (256, 2) void ola4096p2_kernel (const OlaParams p)
 		}
 #pragma unroll
 		for (int k = 0; k < 8; ++k) {
-			v[k]     = mkf2 (cur[k], cur[8 + k]);
-			v[8 + k] = mkf2 (0.f, 0.f);
+			v[k]     = O::mk (cur[k], cur[8 + k]);
+			v[8 + k] = O::mk (0.f, 0.f);
 		}
-		fwd4096<8> (v, lds, twm, tw1, t, tl, th);
+		fwd4096<T, 8> (v, lds, twm, tw1, t, tl, th);
 
 		// Y = Z H0 + Z_prev H1; bins >= 2048 use the conjugate of the mirrored bin
 #pragma unroll
 		for (int k = 0; k < 8; ++k) {
-			const f2 z = v[k];
-			v[k]       = pk_cmul_acc<1> (pk_cmul<1> (z, Hs0[t + 256 * k]), zp[k], Hs1[t + 256 * k]);
+			const C z = v[k];
+			v[k]      = O::template cmul_acc<1> (O::template cmul<1> (z, Hs0[t + 256 * k]), zp[k], Hs1[t + 256 * k]);
 			zp[k]      = z;
 		}
 #pragma unroll
 		for (int k = 8; k < 16; ++k) {
-			const f2 z = v[k];
-			v[k]       = pk_cmul_acc<-1> (pk_cmul<-1> (z, Hs0[256 * (16 - k) - t]), zp[k], Hs1[256 * (16 - k) - t]);
+			const C z = v[k];
+			v[k]      = O::template cmul_acc<-1> (O::template cmul<-1> (z, Hs0[256 * (16 - k) - t]), zp[k], Hs1[256 * (16 - k) - t]);
 			zp[k]      = z;
 		}
 
@@ -629,15 +658,15 @@ __global__ __launch_bounds__ (256, 2) void ola4096p2_kernel (const OlaParams p)
 			}
 		}
 
-		inv4096 (v, lds, twm, tw1, t, tl, th);
+		inv4096<T> (v, lds, twm, tw1, t, tl, th);
 
 		float u[16];
 #pragma unroll
 		for (int j = 0; j < 8; ++j) {
-			u[j]       = acc[j] + v[j].x;
-			u[8 + j]   = acc[8 + j] + v[j].y;
-			acc[j]     = v[8 + j].x;
-			acc[8 + j] = v[8 + j].y;
+			u[j]       = acc[j] + (float)v[j].x;
+			u[8 + j]   = acc[8 + j] + (float)v[j].y;
+			acc[j]     = (float)v[8 + j].x;
+			acc[8 + j] = (float)v[8 + j].y;
 		}
 
 		if (it >= 2) {
@@ -650,7 +679,7 @@ __global__ __launch_bounds__ (256, 2) void ola4096p2_kernel (const OlaParams p)
 					const int64_t pos = s0 + t + 256 * k;
 					if (pos < end) {
 						if (MODE == MODE_HILBERT) {
-							out[pos] = u[8 * h + k];
+							out[pos] = (S)u[8 * h + k];
 						} else {
 							float cc = ca, ss = sa;
 							if (MODE == MODE_RAMP) {
@@ -658,7 +687,7 @@ __global__ __launch_bounds__ (256, 2) void ola4096p2_kernel (const OlaParams p)
 								cc          = cs.x;
 								ss          = cs.y;
 							}
-							out[pos] = cc * dry[8 * h + k] + ss * u[8 * h + k];
+							out[pos] = (S)(cc * dry[8 * h + k] + ss * u[8 * h + k]);
 						}
 					}
 				}
@@ -667,21 +696,22 @@ __global__ __launch_bounds__ (256, 2) void ola4096p2_kernel (const OlaParams p)
 	}
 }
 
-template <int MODE>
-static hipError_t launch_p2_m (const OlaParams& p, dim3 grid, hipStream_t s)
+template <class T, int MODE>
+static hipError_t launch_p2_m (const OlaParamsT<typename T::samp>& p, dim3 grid, hipStream_t s)
 {
 	const int dd = (p.dry_delay - p.conv_delay) / 256;
 	if (dd == 6) {
-		hipLaunchKernelGGL ((ola4096p2_kernel<MODE, 6>), grid, dim3 (256), 0, s, p);
+		hipLaunchKernelGGL ((ola4096p2_kernel<T, MODE, 6>), grid, dim3 (256), 0, s, p);
 	} else if (dd == 8) {
-		hipLaunchKernelGGL ((ola4096p2_kernel<MODE, 8>), grid, dim3 (256), 0, s, p);
+		hipLaunchKernelGGL ((ola4096p2_kernel<T, MODE, 8>), grid, dim3 (256), 0, s, p);
 	} else {
 		return hipErrorInvalidValue;
 	}
 	return hipGetLastError ();
 }
 
-hipError_t launch_ola4096_p2 (const OlaParams& p, int n_chn, hipStream_t s)
+template <class T>
+static hipError_t launch_p2_t (const OlaParamsT<typename T::samp>& p, int n_chn, hipStream_t s)
 {
 	if (p.n_out <= 0) {
 		return hipSuccess;
@@ -689,12 +719,22 @@ hipError_t launch_ola4096_p2 (const OlaParams& p, int n_chn, hipStream_t s)
 	const int64_t runs = (p.n_out + p.run_frames - 1) / p.run_frames;
 	dim3          grid ((unsigned)runs, (unsigned)n_chn);
 	if (p.hilbert_only) {
-		return launch_p2_m<MODE_HILBERT> (p, grid, s);
+		return launch_p2_m<T, MODE_HILBERT> (p, grid, s);
 	}
 	if (p.rot_s != nullptr) {
-		return launch_p2_m<MODE_RAMP> (p, grid, s);
+		return launch_p2_m<T, MODE_RAMP> (p, grid, s);
 	}
-	return launch_p2_m<MODE_ROT> (p, grid, s);
+	return launch_p2_m<T, MODE_ROT> (p, grid, s);
+}
+
+hipError_t launch_ola4096_p2 (const OlaParams& p, int n_chn, hipStream_t s)
+{
+	return launch_p2_t<T32> (p, n_chn, s);
+}
+
+hipError_t launch_ola4096_p2_f16 (const OlaParamsH& p, int n_chn, hipStream_t s)
+{
+	return launch_p2_t<T16> (p, n_chn, s);
 }
 
 // PROT_OLA_VARIANT (debug/tuning only): 0 = default

@@ -6,93 +6,17 @@
 // pattern and thread<->frame map as ola4096_kernel (prot_kernels.hip).
 // Stateless, steady rotation only: it is the throughput/tolerance variant of
 // the roofline path, not a second implementation of the plugin semantics.
+#include "prot_fft.h"
 #include "prot_kernels.h"
 
 
 namespace prot {
 
-typedef _Float16 h2 __attribute__ ((ext_vector_type (2)));
-
 #define PROT_DEVH static __device__ __forceinline__
 
-PROT_DEVH h2 swp (h2 a) { return __builtin_shufflevector (a, a, 1, 0); }
-PROT_DEVH h2 mk (float x, float y) { return h2{ (_Float16)x, (_Float16)y }; }
-// a * (-j) = (a.y, -a.x);  a * (+j) = (-a.y, a.x)
-PROT_DEVH h2 mul_mj (h2 a) { return swp (a) * h2{ (_Float16)1, (_Float16)-1 }; }
-PROT_DEVH h2 mul_pj (h2 a) { return swp (a) * h2{ (_Float16)-1, (_Float16)1 }; }
-
-// a * w (DIR > 0) or a * conj(w) (DIR < 0)
-template <int DIR>
-PROT_DEVH h2 cmulh (h2 a, h2 w)
-{
-	const h2 axx = __builtin_shufflevector (a, a, 0, 0);
-	const h2 ayy = __builtin_shufflevector (a, a, 1, 1);
-	if (DIR > 0) { // (ax wx - ay wy, ax wy + ay wx)
-		return axx * w + ayy * (swp (w) * h2{ (_Float16)-1, (_Float16)1 });
-	} else {       // (ax wx + ay wy, ay wx - ax wy)
-		return axx * (w * h2{ (_Float16)1, (_Float16)-1 }) + ayy * swp (w);
-	}
-}
-
-template <int DIR>
-PROT_DEVH void radix4h (h2& a, h2& b, h2& c, h2& d)
-{
-	const h2 t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
-	a           = t0 + t2;
-	c           = t0 - t2;
-	const h2 j3 = DIR > 0 ? mul_mj (t3) : mul_pj (t3);
-	b           = t1 + j3;
-	d           = t1 - j3;
-}
-
-template <int DIR, int M>
-PROT_DEVH h2 mul_w16h (h2 a)
-{
-	constexpr float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f, R = 0.70710678118654752440f;
-	constexpr int   m  = M & 15;
-	if (m == 0) {
-		return a;
-	} else if (m == 4) {
-		return DIR > 0 ? mul_mj (a) : mul_pj (a);
-	} else if (m == 2) { // R(1 - j) a = R (a + (-j) a)
-		return (a + (DIR > 0 ? mul_mj (a) : mul_pj (a))) * h2{ (_Float16)R, (_Float16)R };
-	} else if (m == 6) { // R(-1 - j) a = R ((-j) a - a)
-		return ((DIR > 0 ? mul_mj (a) : mul_pj (a)) - a) * h2{ (_Float16)R, (_Float16)R };
-	} else {
-		constexpr float cw = (m == 1) ? C1 : (m == 3) ? S1 : /* 9 */ -C1;
-		constexpr float sw = (m == 1) ? S1 : (m == 3) ? C1 : /* 9 */ -S1;
-		return cmulh<DIR> (a, h2{ (_Float16)cw, (_Float16)-sw });
-	}
-}
-
-template <int DIR>
-PROT_DEVH void fft16h (h2 (&v)[16])
-{
-	radix4h<DIR> (v[0], v[4], v[8], v[12]);
-	radix4h<DIR> (v[1], v[5], v[9], v[13]);
-	radix4h<DIR> (v[2], v[6], v[10], v[14]);
-	radix4h<DIR> (v[3], v[7], v[11], v[15]);
-	v[5]  = mul_w16h<DIR, 1> (v[5]);
-	v[6]  = mul_w16h<DIR, 2> (v[6]);
-	v[7]  = mul_w16h<DIR, 3> (v[7]);
-	v[9]  = mul_w16h<DIR, 2> (v[9]);
-	v[10] = mul_w16h<DIR, 4> (v[10]);
-	v[11] = mul_w16h<DIR, 6> (v[11]);
-	v[13] = mul_w16h<DIR, 3> (v[13]);
-	v[14] = mul_w16h<DIR, 6> (v[14]);
-	v[15] = mul_w16h<DIR, 9> (v[15]);
-	radix4h<DIR> (v[0], v[1], v[2], v[3]);
-	radix4h<DIR> (v[4], v[5], v[6], v[7]);
-	radix4h<DIR> (v[8], v[9], v[10], v[11]);
-	radix4h<DIR> (v[12], v[13], v[14], v[15]);
-	h2 t;
-	t = v[1];  v[1]  = v[4];  v[4]  = t;
-	t = v[2];  v[2]  = v[8];  v[8]  = t;
-	t = v[3];  v[3]  = v[12]; v[12] = t;
-	t = v[6];  v[6]  = v[9];  v[9]  = t;
-	t = v[7];  v[7]  = v[13]; v[13] = t;
-	t = v[11]; v[11] = v[14]; v[14] = t;
-}
+PROT_DEVH h2 mk (float x, float y) { return pk16::mk (x, y); }
+template <int DIR> PROT_DEVH h2 cmulh (h2 a, h2 w) { return pk16::cmul<DIR> (a, w); }
+template <int DIR> PROT_DEVH void fft16h (h2 (&v)[16]) { pkt_fft16<pk16, DIR> (v); }
 
 // LDS exchange strides in 4-byte slots: ds_read/write_b32 use 32 banks of 4 B; a wave is
 // served in two 32-lane groups.
@@ -184,7 +108,7 @@ __global__ __launch_bounds__ (256, 4) void ola4096h_kernel (const OlaParamsH p)
 			}
 		}
 		// inputs |x| <= 1: the 1024/2048-term sums stay far below the fp16 maximum (65504)
-		fft16h<1> (v);
+		pkt_fft16_fwd_pruned<pk16, HOPSEG> (v);
 #pragma unroll
 		for (int k = 1; k < 16; ++k) {
 			v[k] = cmulh<1> (v[k], tw1[k]);

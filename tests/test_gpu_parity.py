@@ -321,14 +321,14 @@ def test_apply_dev_stateful_chunks_equal_one_shot(pkg):
 
 
 # ------------------------------------------------------- fp16 sample path ---
-@pytest.mark.parametrize("kind,param", [(1, 48000), (0, 2048)])
-def test_fp16_sample_path_tolerance_report(pkg, kind, param, capsys):
+@pytest.mark.parametrize("kind,param,flags", [(1, 48000, 0), (1, 48000, 1), (1, 96000, 0), (0, 2048, 0)])
+def test_fp16_sample_path_tolerance_report(pkg, kind, param, flags, capsys):
     """BASELINE config 5: half samples + packed-half butterflies, fp32 accumulate.
     No gate beyond a stated tolerance: report the error against the fp32 path."""
     import torch
     dev = torch.device("cuda:0")
     n = 1 << 20
-    e = pkg.Engine(kind, param, 1, flags=pkg.CFG_SINGLE_FFT_PER_HOP)  # the fp16 kernel is single-partition
+    e = pkg.Engine(kind, param, 1, flags=flags)  # two-partition (p2) and single-transform geometries
     x32 = torch.from_numpy(0.9 * harmonic_stack(n) + 0.05 * xorshift_uniform(n, seed=4)).to(dev)
     x16 = x32.half()
     y32 = torch.empty_like(x32)
@@ -344,8 +344,8 @@ def test_fp16_sample_path_tolerance_report(pkg, kind, param, capsys):
     rms = float(torch.sqrt(torch.mean(err ** 2)))
     ref_rms = float(torch.sqrt(torch.mean(y32 ** 2)))
     with capsys.disabled():
-        print("\n[fp16 path, kind=%d param=%d] max abs err %.3e, rms err %.3e (signal rms %.3f, SNR %.1f dB)"
-              % (kind, param, float(err.max()), rms, ref_rms, 20 * np.log10(ref_rms / rms)))
+        print("\n[fp16 path, kind=%d param=%d flags=%d] max abs err %.3e, rms err %.3e (signal rms %.3f, SNR %.1f dB)"
+              % (kind, param, flags, float(err.max()), rms, ref_rms, 20 * np.log10(ref_rms / rms)))
     assert float(err.max()) < 2e-2 and rms < 3e-3  # stated tolerance: ~1e-3 rms at |y| <= 1
     e.close()
 
