@@ -419,11 +419,13 @@ struct T32 {
 	typedef pk32  ops;
 	typedef f2    cplx;
 	typedef float samp;
+	static constexpr int kWaves = 2; // workgroups per CU the register budget is sized for
 };
 struct T16 {
 	typedef pk16     ops;
 	typedef h2       cplx;
 	typedef _Float16 samp;
+	static constexpr int kWaves = 3;
 };
 
 template <class T>
@@ -524,7 +526,7 @@ PROT_DEV void inv4096 (typename T::cplx (&v)[16], typename T::cplx* lds, const t
 }
 
 template <class T, int MODE, int DH>
-__global__ __launch_bounds__ (256, 2) void ola4096p2_kernel (const OlaParamsT<typename T::samp> p)
+__global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaParamsT<typename T::samp> p)
 {
 	typedef typename T::cplx C;
 	typedef typename T::ops  O;
