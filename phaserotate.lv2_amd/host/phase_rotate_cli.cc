@@ -1,17 +1,19 @@
-// phase_rotate_cli.cc -- `phase-rotate`, the drop-in for cli/phase-rotate.cc on
-// MI355X.  Same options, validation, messages, exit codes and result text;
-// same analysis procedure (coarse pass -> candidate minima -> fine passes ->
-// channel phase-distance unwrapping, cli/phase-rotate.cc:784-947) and apply
-// loop (:950-1003).  All DSP -- Hilbert FFT convolution, rotation, the
-// per-angle abs-max sweep -- runs in the gfx950 kernels behind the C ABI
-// (include/prot_hip.h); this file is option parsing, file I/O and the
-// selection logic on the reduced [n_chn][360] peak table.
+// phase_rotate_cli.cc -- `phase-rotate`, the drop-in for the reference's
+// command-line tool (cli/phase-rotate.cc) on MI355X.
 //
-// Differences, all outside the hot path: WAV only (own reader/writer instead
-// of libsndfile, no metadata copy); the whole file is read once and kept in
-// memory instead of being re-read from disk for every fine pass (:872); a
-// partial last block is applied correctly (the reference's tail is broken,
-// SURVEY Q3).  No CPU DSP fallback: without a GPU the tool exits with failure.
+// Same options, validation, messages, exit codes and result text; same analysis
+// procedure (coarse pass -> candidate minima -> fine passes -> channel
+// phase-distance unwrapping, cli/phase-rotate.cc:784-947) and apply semantics
+// (:950-1003).  All DSP -- Hilbert FFT convolution, rotation, per-angle abs-max
+// sweep -- runs in the gfx950 kernels behind the C ABI (include/prot_hip.h);
+// this file is option parsing, file I/O and the selection logic on the reduced
+// [n_chn][360] peak table.
+//
+// Differences, all outside the hot path: WAV only (own reader/writer instead of
+// libsndfile, no metadata copy); the file is read once and kept in memory
+// instead of being re-read for every fine pass (:872); a partial last block is
+// applied correctly (the reference's tail is broken).  No CPU DSP
+// fallback: without a GPU the tool exits with failure.
 #include <algorithm>
 #include <cerrno>
 #include <cmath>
@@ -21,6 +23,7 @@
 #include <getopt.h>
 #include <limits>
 #include <map>
+#include <string>
 #include <vector>
 
 #include "prot_hip.h"
@@ -30,66 +33,19 @@
 #define VERSION "0.5-mi355x"
 #endif
 
-#define SUBSAMPLE PROT_SUBSAMPLE
-#define MAXSAMPLE PROT_MAXSAMPLE
+namespace {
 
-static float
-coeff_to_dB (float coeff) // cli/phase-rotate.cc:76-83
+constexpr int   kHalfDeg  = PROT_SUBSAMPLE;  // angle indices are half degrees
+constexpr int   kAngles   = PROT_MAXSAMPLE;  // 360 indices = 180 degrees
+constexpr float kInf      = std::numeric_limits<float>::infinity ();
+
+[[noreturn]] void die (const char* msg)
 {
-	if (coeff < 1e-15) {
-		return -std::numeric_limits<float>::infinity ();
-	}
-	return 20.0f * log10f (coeff);
+	fputs (msg, stderr);
+	::exit (EXIT_FAILURE);
 }
 
-static void
-usage ()
-{
-	printf ("phase-rotate - Audio File Phase Rotation Util.\n\n");
-	printf ("Usage: phase-rotate [ OPTIONS ] <file> [out-file]\n\n");
-	printf ("Options:\n"
-	        "  -a, --angle <n>[,<n>]*     specify phase angle to apply\n"
-	        "  -f, --fftlen <num>         process-block size, freq. resolution\n"
-	        "  -h, --help                 display this help and exit\n"
-	        "  -l, --link-channels        use downmixed mono peak for analysis\n"
-	        "  -s, --stride <num>         analysis step-size\n"
-	        "  -v, --verbose              show processing information\n"
-	        "  -V, --version              print version information and exit\n"
-	        "\n");
-	printf ("\n"
-	        "This utility analyzes the given audio file to find a phase-rotation\n"
-	        "angle that results in minimal digital-peak, while retaining overall\n"
-	        "sound and loudness.\n"
-	        "\n"
-	        "If both input and output file are given, the analysis results applied, and\n"
-	        "a new file with optimized phase is written. Otherwise the analysis results\n"
-	        "are only printed to standard output.\n"
-	        "\n"
-	        "Analysis is performed in two steps, first a coarse analysis is performed,\n"
-	        "calculating peak for angles distanced `stride' degrees apart. Then local\n"
-	        "minimums are explored in a second step.\n"
-	        "\n"
-	        "Verbose analysis allows to plot the digital peak vs phase-rotation.\n"
-	        "The output is in gnuplot(1) data file format.\n"
-	        "\n"
-	        "If the -a option is specified, no analysis is performed but the given,\n"
-	        "phase-angle(s) are directly applied. This requires both input and output\n"
-	        "files to be given. If a single angle is given it is applied to all channels\n"
-	        "of the file. Otherwise one has to specify the same number of phase-angles as\n"
-	        "there are channels in the file.\n"
-	        "\n");
-	printf ("\n"
-	        "Examples:\n"
-	        "phase-rotate -l my-music.wav out-file.wav\n\n"
-	        "phase-rotate -vv -s 3 my-music.wav\n\n"
-	        "phase-rotate -a 10,20 in.wav out.wav\n\n");
-	printf ("This build runs the DSP on an AMD MI355X (gfx950) through libprot_hip.\n"
-	        "Environment: PROT_DEVICE=<n> selects the HIP device.\n");
-	::exit (EXIT_SUCCESS);
-}
-
-static void
-must (int rc, const char* what)
+void gpu_call (int rc, const char* what)
 {
 	if (rc != PROT_OK) {
 		fprintf (stderr, "Error: %s failed: %s (%s)\n", what, prot_strerror (rc), prot_last_error ());
@@ -97,336 +53,387 @@ must (int rc, const char* what)
 	}
 }
 
-// pr.peak(c, a) / peak_all(a) on a host copy of the table (cli/phase-rotate.cc:275-299)
-struct PeakTable {
-	std::vector<float> v;
-	int                n_chn;
-	float all (int a) const
-	{
-		a       = ((a % MAXSAMPLE) + MAXSAMPLE) % MAXSAMPLE;
-		float p = 0;
-		for (int c = 0; c < n_chn; ++c) {
-			p = std::max (p, v[(size_t)c * MAXSAMPLE + a]);
-		}
-		return p;
-	}
-	float at (int c, int a) const
-	{
-		if (c < 0 || c >= n_chn) {
-			return all (a);
-		}
-		a = ((a % MAXSAMPLE) + MAXSAMPLE) % MAXSAMPLE;
-		return v[(size_t)c * MAXSAMPLE + a];
-	}
-};
-
-static PeakTable
-fetch_peaks (prot_engine* e, int n_chn)
+float to_dB (float coeff) // cli/phase-rotate.cc:76-83
 {
-	PeakTable t;
-	t.n_chn = n_chn;
-	t.v.resize ((size_t)n_chn * MAXSAMPLE);
-	must (prot_cli_peaks (e, t.v.data ()), "prot_cli_peaks");
-	return t;
+	return coeff < 1e-15 ? -kInf : 20.0f * log10f (coeff);
 }
 
-int
-main (int argc, char** argv)
+// help2man-compatible text, word for word the reference's (cli/phase-rotate.cc:489-539)
+// plus two lines about this build
+const char* const kHelp =
+    "phase-rotate - Audio File Phase Rotation Util.\n\n"
+    "Usage: phase-rotate [ OPTIONS ] <file> [out-file]\n\n"
+    "Options:\n"
+    "  -a, --angle <n>[,<n>]*     specify phase angle to apply\n"
+    "  -f, --fftlen <num>         process-block size, freq. resolution\n"
+    "  -h, --help                 display this help and exit\n"
+    "  -l, --link-channels        use downmixed mono peak for analysis\n"
+    "  -s, --stride <num>         analysis step-size\n"
+    "  -v, --verbose              show processing information\n"
+    "  -V, --version              print version information and exit\n"
+    "\n\n"
+    "This utility analyzes the given audio file to find a phase-rotation\n"
+    "angle that results in minimal digital-peak, while retaining overall\n"
+    "sound and loudness.\n\n"
+    "If both input and output file are given, the analysis results applied, and\n"
+    "a new file with optimized phase is written. Otherwise the analysis results\n"
+    "are only printed to standard output.\n\n"
+    "Analysis is performed in two steps, first a coarse analysis is performed,\n"
+    "calculating peak for angles distanced `stride' degrees apart. Then local\n"
+    "minimums are explored in a second step.\n\n"
+    "Verbose analysis allows to plot the digital peak vs phase-rotation.\n"
+    "The output is in gnuplot(1) data file format.\n\n"
+    "If the -a option is specified, no analysis is performed but the given,\n"
+    "phase-angle(s) are directly applied. This requires both input and output\n"
+    "files to be given. If a single angle is given it is applied to all channels\n"
+    "of the file. Otherwise one has to specify the same number of phase-angles as\n"
+    "there are channels in the file.\n\n\n"
+    "Examples:\n"
+    "phase-rotate -l my-music.wav out-file.wav\n\n"
+    "phase-rotate -vv -s 3 my-music.wav\n\n"
+    "phase-rotate -a 10,20 in.wav out.wav\n\n"
+    "This build runs the DSP on an AMD MI355X (gfx950) through libprot_hip.\n"
+    "Environment: PROT_DEVICE=<n> selects the HIP device.\n";
+
+struct Options {
+	const char*      in_path  = nullptr;
+	const char*      out_path = nullptr;
+	char*            angle_arg = nullptr;
+	int              stride   = 12 * kHalfDeg;
+	int              verbose  = 0;
+	bool             link     = false;
+	unsigned         blksiz   = 0;
+};
+
+Options parse_args (int argc, char** argv)
 {
-	char*        angles_opt = NULL;
-	int          stride     = 12 * SUBSAMPLE;
-	int          verbose    = 0;
-	FILE*        verbose_fd = stdout;
-	bool         find_min   = true;
-	bool         link_chn   = false;
-	unsigned int blksiz     = 0;
-
-	std::vector<int> angles;
-
-	const char*         optstring = "a:f:hls:Vv";
-	const struct option longopts[] = {
-		{ "angle", required_argument, 0, 'a' },
-		{ "fftlen", required_argument, 0, 'f' },
-		{ "stride", required_argument, 0, 's' },
-		{ "help", no_argument, 0, 'h' },
-		{ "link-channels", no_argument, 0, 'l' },
-		{ "version", no_argument, 0, 'V' },
-		{ "verbose", no_argument, 0, 'v' },
-		{ 0, 0, 0, 0 },
+	static const struct option longopts[] = {
+		{ "angle", required_argument, 0, 'a' },   { "fftlen", required_argument, 0, 'f' },
+		{ "stride", required_argument, 0, 's' },  { "help", no_argument, 0, 'h' },
+		{ "link-channels", no_argument, 0, 'l' }, { "version", no_argument, 0, 'V' },
+		{ "verbose", no_argument, 0, 'v' },       { 0, 0, 0, 0 },
 	};
-
-	int c = 0;
-	while (EOF != (c = getopt_long (argc, argv, optstring, longopts, (int*)0))) {
+	Options o;
+	int     c;
+	while ((c = getopt_long (argc, argv, "a:f:hls:Vv", longopts, nullptr)) != EOF) {
 		switch (c) {
-			case 'a': angles_opt = optarg; break;
-			case 'f': blksiz = atoi (optarg); break;
-			case 'h': usage (); break;
-			case 'l': link_chn = true; break;
-			case 's': stride = atoi (optarg); break;
+			case 'a': o.angle_arg = optarg; break;
+			case 'f': o.blksiz = (unsigned)atoi (optarg); break;
+			case 'l': o.link = true; break;
+			case 's': o.stride = atoi (optarg); break;
+			case 'v': ++o.verbose; break;
+			case 'h':
+				fputs (kHelp, stdout);
+				::exit (EXIT_SUCCESS);
 			case 'V':
 				printf ("phase-rotate version %s\n\n", VERSION);
 				printf ("MI355X/HIP implementation of x42 phase-rotate (GPL, Robin Gareus <robin@gareus.org>)\n");
-				exit (EXIT_SUCCESS);
-				break;
-			case 'v': ++verbose; break;
-			default:
-				fprintf (stderr, "Error: unrecognized option. See --help for usage information.\n");
-				::exit (EXIT_FAILURE);
-				break;
+				::exit (EXIT_SUCCESS);
+			default: die ("Error: unrecognized option. See --help for usage information.\n");
+		}
+	}
+	// validation order and texts of cli/phase-rotate.cc:663-681
+	if (optind + 1 > argc) {
+		die ("Error: Missing parameter. See --help for usage information.\n");
+	}
+	if (o.stride < 1 || o.stride > 45 * kHalfDeg || (kAngles % o.stride) != 0) {
+		die ("Error: 180 deg is not evenly dividable by given stride.\n");
+	}
+	if (o.blksiz != 0 && (o.blksiz < 1024 || o.blksiz > 32768)) {
+		die ("Error: fft-len is out of bounds; valid range 1024..32768\n");
+	}
+	if (o.angle_arg && optind + 2 > argc) {
+		die ("Error: -a, --angle option requires an output file to be given.\n");
+	}
+	o.in_path = argv[optind];
+	if (optind + 1 < argc) {
+		o.out_path = argv[optind + 1];
+	}
+	return o;
+}
+
+// "-a n[,n]*" -> half-degree indices, one per channel (cli/phase-rotate.cc:718-740)
+std::vector<int> parse_angles (char* arg, int n_channels)
+{
+	std::vector<int> idx;
+	char*            save = nullptr;
+	for (char* tok = strtok_r (arg, ",", &save); tok; tok = strtok_r (nullptr, ",", &save)) {
+		char*        end = nullptr;
+		const double deg = strtod (tok, &end);
+		if (*end != '\0' || deg < -180 || deg > 180) {
+			die ("Error: Invalid angle speficied, value needs to be -180 .. +180.\n");
+		}
+		idx.push_back ((int)round (deg * (float)kHalfDeg));
+	}
+	if (idx.size () == 1) {
+		idx.resize ((size_t)n_channels, idx[0]);
+	}
+	if (idx.size () < (size_t)n_channels) {
+		die ("Error: file has more channels than angles were specified.\n");
+	}
+	return idx;
+}
+
+// process block size: -f value or samplerate/8, next power of two, clamped (cli/phase-rotate.cc:749-755)
+unsigned pick_block_size (unsigned requested, unsigned samplerate)
+{
+	unsigned want = (requested == 0 || requested > 32768) ? samplerate / 8 : requested;
+	unsigned p2   = 2;
+	while (p2 < want) {
+		p2 <<= 1;
+	}
+	return std::min (32768u, std::max (1024u, p2));
+}
+
+// host copy of the engine's peak table with the reference's accessors (cli/phase-rotate.cc:275-299)
+class Peaks
+{
+public:
+	Peaks (prot_engine* e, int n_chn) : _n (n_chn), _v ((size_t)n_chn * kAngles)
+	{
+		gpu_call (prot_cli_peaks (e, _v.data ()), "prot_cli_peaks");
+	}
+	float mono (int a) const
+	{
+		float p = 0;
+		for (int c = 0; c < _n; ++c) {
+			p = std::max (p, _v[(size_t)c * kAngles + wrap (a)]);
+		}
+		return p;
+	}
+	float chn (int c, int a) const { return (c < 0 || c >= _n) ? mono (a) : _v[(size_t)c * kAngles + wrap (a)]; }
+
+private:
+	static int wrap (int a) { return ((a % kAngles) + kAngles) % kAngles; }
+	int                _n;
+	std::vector<float> _v;
+};
+
+void print_table_row (const Peaks& pk, int n_chn, int a)
+{
+	printf ("%.2f %.4f", (((a % kAngles) + kAngles) % kAngles) / (float)kHalfDeg, to_dB (pk.mono (a)));
+	for (int c = 0; c < n_chn; ++c) {
+		printf (" %.4f", to_dB (pk.chn (c, a)));
+	}
+	printf ("\n");
+}
+
+struct Result {
+	std::vector<int>   angle;  // half-degree index, possibly negative after unwrapping
+	std::vector<float> best;   // peak the search minimised (mono peak with -l), inf = "cannot find min."
+	std::vector<float> at_zero, at_min;
+};
+
+// the minimum search of cli/phase-rotate.cc:784-929 on the whole file
+Result find_minimum (prot_engine* pr, const std::vector<float>& file, uint64_t n_frames, int n_chn,
+                     const Options& opt, FILE* vfd)
+{
+	const int stride = opt.stride;
+	Result    r;
+	r.angle.assign (n_chn, 0);
+	r.best.assign (n_chn, kInf);
+	r.at_zero.assign (n_chn, 0.f);
+	r.at_min.assign (n_chn, 0.f);
+
+	// coarse pass, all channels (:784)
+	gpu_call (prot_cli_analyze_file (pr, file.data (), n_frames, 0, kAngles, stride, -1), "analysis");
+	const Peaks coarse (pr, n_chn);
+	if (opt.verbose > 1) { // gnuplot table (:800-813)
+		printf ("# Angle mono-peak");
+		for (int c = 0; c < n_chn; ++c) {
+			printf (" chn-%d", c + 1);
+		}
+		printf ("\n");
+		for (int a = 0; a < kAngles; a += stride) {
+			print_table_row (coarse, n_chn, a);
 		}
 	}
 
-	if (optind + 1 > argc) {
-		fprintf (stderr, "Error: Missing parameter. See --help for usage information.\n");
-		::exit (EXIT_FAILURE);
+	// candidates: coarse angles within 7 % of the channel's peak range above its minimum
+	// (:823-857); an ordered map, so later passes visit them by ascending angle
+	std::map<int, std::vector<int>> candidates;
+	for (int c = 0; c < n_chn; ++c) {
+		const int src = opt.link ? -1 : c;
+		float     lo = kInf, hi = 0;
+		r.at_zero[c] = coarse.chn (c, 0);
+		for (int a = 0; a < kAngles; a += stride) {
+			lo = std::min (lo, coarse.chn (src, a));
+			hi = std::max (hi, coarse.chn (src, a));
+		}
+		float window = hi - lo;
+		if (window == 0) {
+			candidates[0].push_back (c); // flat: "cannot find min." unless a fine pass finds one
+			continue;
+		}
+		if (stride > 1) {
+			window *= .07;
+		} else {
+			window    = 0;
+			r.best[c] = lo;
+		}
+		for (int a = 0; a < kAngles; a += stride) {
+			const float p = coarse.chn (src, a);
+			if (p <= lo + window) {
+				candidates[a].push_back (c);
+				if (opt.verbose > 1) {
+					fprintf (vfd, "Consider min: %f (< %f) chn: %d @ %.2f deg\n", p, lo + window, c, a / (float)kHalfDeg);
+				}
+			}
+		}
 	}
-	if (stride < 1 || stride > 45 * SUBSAMPLE || (MAXSAMPLE % stride) != 0) {
-		fprintf (stderr, "Error: 180 deg is not evenly dividable by given stride.\n");
-		::exit (EXIT_FAILURE);
+
+	if (stride == 1) { // every angle was measured: the last candidate in ascending order wins (:859-865)
+		for (const auto& cand : candidates) {
+			for (int c : cand.second) {
+				r.angle[c]  = cand.first;
+				r.at_min[c] = coarse.chn (c, cand.first);
+			}
+		}
+	} else { // one fine pass of +-(stride+1)/2 half-degrees around every candidate (:866-903)
+		const int reach = (stride + 1) / 2;
+		for (const auto& cand : candidates) {
+			const int centre = cand.first;
+			gpu_call (prot_engine_reset (pr), "reset");
+			gpu_call (prot_cli_analyze_file (pr, file.data (), n_frames, centre - reach, centre + reach + 1, 1,
+			                                 cand.second.size () > 1 ? -1 : cand.second.front ()),
+			          "analysis");
+			const Peaks fine (pr, n_chn);
+			for (int c : cand.second) {
+				for (int a = centre - reach; a < centre + reach + 1; ++a) {
+					const float p = fine.chn (opt.link ? -1 : c, a);
+					if (p <= r.best[c]) { // ties: the later angle wins
+						r.best[c]   = p;
+						r.at_min[c] = fine.chn (c, a);
+						r.angle[c]  = (a + kAngles) % kAngles;
+					}
+					if (opt.verbose > 1) {
+						print_table_row (fine, n_chn, a);
+					}
+				}
+			}
+		}
 	}
-	if (blksiz != 0 && (blksiz < 1024 || blksiz > 32768)) {
-		fprintf (stderr, "Error: fft-len is out of bounds; valid range 1024..32768\n");
-		::exit (EXIT_FAILURE);
+
+	// keep the channels' rotations close together: angles beyond 90 degrees may be expressed
+	// as negative ones (:905-929)
+	float mean = 0;
+	int   n_ok = 0;
+	for (int c = 0; c < n_chn; ++c) {
+		if (r.best[c] != kInf) {
+			mean += r.angle[c];
+			++n_ok;
+		}
 	}
-	if (angles_opt && optind + 2 > argc) {
-		fprintf (stderr, "Error: -a, --angle option requires an output file to be given.\n");
-		::exit (EXIT_FAILURE);
+	mean /= n_ok;
+	const float spread = kAngles / (float)n_ok;
+	for (int c = 0; c < n_chn; ++c) {
+		if (r.best[c] == kInf) {
+			r.angle[c] = 0;
+		} else if ((r.angle[c] > 90 * kHalfDeg && fabsf (r.angle[c] - mean) > spread) || mean > 90 * kHalfDeg) {
+			r.angle[c] -= kAngles;
+		}
 	}
+	return r;
+}
+
+void print_result (const Result& r, int n_chn, FILE* fd) // :931-947
+{
+	fprintf (fd, "# Result -- Minimize digital peak\n");
+	for (int c = 0; c < n_chn; ++c) {
+		if (r.best[c] == kInf) {
+			fprintf (fd, "Channel: %2d Phase:   0 deg # cannot find min.\n", c + 1);
+			continue;
+		}
+		fprintf (fd, "Channel: %2d Phase: %5.2f deg", c + 1, r.angle[c] / (float)kHalfDeg);
+		if (r.angle[c] != 0) {
+			fprintf (fd, ", gain: %5.2f dB (att. %4.2f to %4.2f dBFS)", to_dB (r.at_zero[c]) - to_dB (r.at_min[c]),
+			         to_dB (r.at_zero[c]), to_dB (r.at_min[c]));
+		}
+		fprintf (fd, "\n");
+	}
+}
+
+} // namespace
+
+int main (int argc, char** argv)
+{
+	Options opt = parse_args (argc, argv);
 
 	wavio::Info        nfo;
 	std::vector<float> file;
 	{
-		std::string err = wavio::read_file (argv[optind], nfo, file);
+		const std::string err = wavio::read_file (opt.in_path, nfo, file);
 		if (!err.empty ()) {
-			fprintf (stderr, "Cannot open '%s' for reading: ", argv[optind]);
-			fputs (err.c_str (), stderr);
-			::exit (EXIT_FAILURE);
+			fprintf (stderr, "Cannot open '%s' for reading: ", opt.in_path);
+			die (err.c_str ());
 		}
 	}
-	const int      n_channels = nfo.channels;
-	const uint64_t n_frames   = nfo.frames;
+	const int      n_chn    = nfo.channels;
+	const uint64_t n_frames = nfo.frames;
 
 	wavio::Writer outfile;
-	const bool    have_out = optind + 1 < argc;
-	if (have_out) {
-		std::string err = outfile.open (argv[optind + 1], nfo);
+	if (opt.out_path) {
+		const std::string err = outfile.open (opt.out_path, nfo);
 		if (!err.empty ()) {
-			fprintf (stderr, "Cannot open '%s' for writing: ", argv[optind + 1]);
-			fputs (err.c_str (), stderr);
-			::exit (EXIT_FAILURE);
+			fprintf (stderr, "Cannot open '%s' for writing: ", opt.out_path);
+			die (err.c_str ());
 		}
 	}
 
-	if (verbose > 1) {
-		verbose_fd = stderr;
-	}
-	if (verbose) {
-		fprintf (verbose_fd, "Input File      : %s\n", argv[optind]);
-		fprintf (verbose_fd, "Sample Rate     : %d Hz\n", (int)nfo.samplerate);
-		fprintf (verbose_fd, "Channels        : %d\n", n_channels);
+	FILE* vfd = opt.verbose > 1 ? stderr : stdout; // :704-706
+	if (opt.verbose) {
+		fprintf (vfd, "Input File      : %s\n", opt.in_path);
+		fprintf (vfd, "Sample Rate     : %d Hz\n", (int)nfo.samplerate);
+		fprintf (vfd, "Channels        : %d\n", n_chn);
 	}
 
-	if (angles_opt) { // cli/phase-rotate.cc:718-747
-		find_min = false;
-		char* saveptr;
-		char* ang;
-		while ((ang = strtok_r (angles_opt, ",", &saveptr)) != NULL) {
-			char*  ep;
-			double a = strtod (ang, &ep);
-			if (*ep != '\0' || a < -180 || a > 180) {
-				fprintf (stderr, "Error: Invalid angle speficied, value needs to be -180 .. +180.\n");
-				::exit (EXIT_FAILURE);
-			}
-			angles_opt = NULL;
-			angles.push_back (round (a * (float)SUBSAMPLE));
-		}
-		if (angles.size () == 1) {
-			while (angles.size () < (size_t)n_channels) {
-				angles.push_back (angles.back ());
-			}
-		}
-		if (angles.size () < (size_t)n_channels) {
-			fprintf (stderr, "Error: file has more channels than angles were specified.\n");
-			::exit (EXIT_FAILURE);
-		}
-		if (verbose) {
-			fprintf (verbose_fd, "# Apply phase-shift\n");
-			for (int ch = 0; ch < n_channels; ++ch) {
-				fprintf (verbose_fd, "Channel: %2d Phase: %5.2f deg\n", ch + 1, angles[ch] / (float)SUBSAMPLE);
+	std::vector<int> angles;
+	const bool       analyse = opt.angle_arg == nullptr;
+	if (!analyse) {
+		angles = parse_angles (opt.angle_arg, n_chn);
+		if (opt.verbose) {
+			fprintf (vfd, "# Apply phase-shift\n");
+			for (int c = 0; c < n_chn; ++c) {
+				fprintf (vfd, "Channel: %2d Phase: %5.2f deg\n", c + 1, angles[c] / (float)kHalfDeg);
 			}
 		}
 	}
 
-	if (blksiz == 0 || blksiz > 32768) { // :749-755
-		blksiz = nfo.samplerate / 8;
-	}
-	unsigned power_of_two;
-	for (power_of_two = 1; 1U << power_of_two < blksiz; ++power_of_two) ;
-	blksiz = std::min (32768, std::max (1024, 1 << power_of_two));
-
-	if (verbose > 1) {
-		fprintf (verbose_fd, "Process block-size %d\n", blksiz);
+	const unsigned blksiz = pick_block_size (opt.blksiz, nfo.samplerate);
+	if (opt.verbose > 1) {
+		fprintf (vfd, "Process block-size %d\n", blksiz);
 	}
 
 	prot_config cfg;
 	memset (&cfg, 0, sizeof (cfg));
 	cfg.kind   = PROT_KIND_CLI;
 	cfg.param  = blksiz;
-	cfg.n_chn  = (uint32_t)n_channels;
+	cfg.n_chn  = (uint32_t)n_chn;
 	cfg.device = getenv ("PROT_DEVICE") ? atoi (getenv ("PROT_DEVICE")) : 0;
 	int          status = 0;
 	prot_engine* pr     = prot_engine_create (&cfg, &status);
 	if (!pr) {
 		fprintf (stderr, "Error: cannot create the GPU engine: %s (%s)\n", prot_strerror (status), prot_last_error ());
-		::exit (EXIT_FAILURE);
+		return EXIT_FAILURE;
 	}
 
-	if (find_min) {
-		if (verbose > 1) {
-			fprintf (verbose_fd, "Analyzing using %d process threads, stride = %d\n", n_channels, stride);
+	if (analyse) {
+		if (opt.verbose > 1) {
+			fprintf (vfd, "Analyzing using %d process threads, stride = %d\n", n_chn, opt.stride);
 		}
-
-		// coarse pass over all channels (:784)
-		must (prot_cli_analyze_file (pr, file.data (), n_frames, 0, MAXSAMPLE, stride, -1), "analysis");
-		PeakTable pk = fetch_peaks (pr, n_channels);
-
-		if (verbose > 1) { // :800-813
-			printf ("# Angle mono-peak");
-			for (int ch = 0; ch < n_channels; ++ch) {
-				printf (" chn-%d", ch + 1);
-			}
-			printf ("\n");
-			for (uint32_t a = 0; a < MAXSAMPLE; a += stride) {
-				printf ("%.2f %.4f", a / (float)SUBSAMPLE, coeff_to_dB (pk.all (a)));
-				for (int ch = 0; ch < n_channels; ++ch) {
-					printf (" %.4f", coeff_to_dB (pk.at (ch, a)));
-				}
-				printf ("\n");
-			}
-		}
-
-		// candidate minima per channel (:815-857); key order = ascending angle, as std::map there
-		std::map<int, std::vector<int>> mins;
-		angles.clear ();
-		std::vector<int>   min_angle (n_channels, 0);
-		std::vector<float> p_min (n_channels, std::numeric_limits<float>::infinity ());
-		std::vector<float> r_zro (n_channels, 0.f), r_min (n_channels, 0.f);
-
-		for (int ch = 0; ch < n_channels; ++ch) {
-			float c_min = std::numeric_limits<float>::infinity ();
-			float c_max = 0;
-			r_zro[ch]   = pk.at (ch, 0);
-			for (uint32_t a = 0; a < MAXSAMPLE; a += stride) {
-				const float p = pk.at (link_chn ? -1 : ch, a);
-				c_min         = std::min (c_min, p);
-				c_max         = std::max (c_max, p);
-			}
-			float range = c_max - c_min;
-			if (range == 0) {
-				mins[0].push_back (ch); // flat table: "cannot find min." unless refined
-				continue;
-			}
-			if (stride > 1) {
-				range *= .07;
-				p_min[ch] = std::numeric_limits<float>::infinity ();
-			} else {
-				range     = 0;
-				p_min[ch] = c_min;
-			}
-			for (uint32_t a = 0; a < MAXSAMPLE; a += stride) {
-				const float p = pk.at (link_chn ? -1 : ch, a);
-				if (p <= c_min + range) {
-					mins[a].push_back (ch);
-					if (verbose > 1) {
-						fprintf (verbose_fd, "Consider min: %f (< %f) chn: %d @ %.2f deg\n", p, c_min + range, ch, a / (float)SUBSAMPLE);
-					}
-				}
-			}
-		}
-
-		if (stride == 1) { // :859-865: the last candidate in ascending order wins
-			for (auto& mp : mins) {
-				for (auto& cn : mp.second) {
-					min_angle[cn] = mp.first;
-					r_min[cn]     = pk.at (cn, mp.first);
-				}
-			}
-		} else { // fine passes around every candidate (:866-903)
-			const int stride_2 = (stride + 1) / 2;
-			for (auto& mp : mins) {
-				must (prot_engine_reset (pr), "reset");
-				const int ma = mp.first;
-				must (prot_cli_analyze_file (pr, file.data (), n_frames, ma - stride_2, ma + stride_2 + 1, 1,
-				                             mp.second.size () > 1 ? -1 : mp.second.front ()),
-				      "analysis");
-				PeakTable fp = fetch_peaks (pr, n_channels);
-				for (auto& cn : mp.second) {
-					for (int a = ma - stride_2; a < ma + stride_2 + 1; ++a) {
-						const float p = fp.at (link_chn ? -1 : cn, a);
-						if (p <= p_min[cn]) { // ties: the later angle wins
-							p_min[cn]     = p;
-							r_min[cn]     = fp.at (cn, a);
-							min_angle[cn] = (a + MAXSAMPLE) % MAXSAMPLE;
-						}
-						if (verbose > 1) {
-							printf ("%.2f %.4f", ((a + MAXSAMPLE) % MAXSAMPLE) / (float)SUBSAMPLE, coeff_to_dB (fp.all (a)));
-							for (int ch = 0; ch < n_channels; ++ch) {
-								printf (" %.4f", coeff_to_dB (fp.at (ch, a)));
-							}
-							printf ("\n");
-						}
-					}
-				}
-			}
-		}
-
-		// minimise the phase distance between channels (:905-929)
-		float avg_rotate = 0;
-		int   avg_count  = 0;
-		for (int ch = 0; ch < n_channels; ++ch) {
-			if (p_min[ch] != std::numeric_limits<float>::infinity ()) {
-				avg_rotate += min_angle[ch];
-				++avg_count;
-			}
-		}
-		avg_rotate /= avg_count;
-		const float avg_dist = MAXSAMPLE / (float)avg_count;
-		for (int ch = 0; ch < n_channels; ++ch) {
-			if (p_min[ch] == std::numeric_limits<float>::infinity ()) {
-				angles.push_back (0);
-			} else {
-				if (min_angle[ch] > 90 * SUBSAMPLE && fabsf (min_angle[ch] - avg_rotate) > avg_dist) {
-					min_angle[ch] -= MAXSAMPLE;
-				} else if (avg_rotate > 90 * SUBSAMPLE) {
-					min_angle[ch] -= MAXSAMPLE;
-				}
-				angles.push_back (min_angle[ch]);
-			}
-		}
-
-		if (!have_out || verbose) { // :931-947
-			fprintf (verbose_fd, "# Result -- Minimize digital peak\n");
-			for (int ch = 0; ch < n_channels; ++ch) {
-				if (p_min[ch] == std::numeric_limits<float>::infinity ()) {
-					fprintf (verbose_fd, "Channel: %2d Phase:   0 deg # cannot find min.\n", ch + 1);
-				} else {
-					fprintf (verbose_fd, "Channel: %2d Phase: %5.2f deg", ch + 1, min_angle[ch] / (float)SUBSAMPLE);
-					if (min_angle[ch] != 0) {
-						fprintf (verbose_fd, ", gain: %5.2f dB (att. %4.2f to %4.2f dBFS)",
-						         coeff_to_dB (r_zro[ch]) - coeff_to_dB (r_min[ch]), coeff_to_dB (r_zro[ch]), coeff_to_dB (r_min[ch]));
-					}
-					fprintf (verbose_fd, "\n");
-				}
-			}
+		const Result res = find_minimum (pr, file, n_frames, n_chn, opt, vfd);
+		angles           = res.angle;
+		if (!opt.out_path || opt.verbose) {
+			print_result (res, n_chn, vfd);
 		}
 	}
 
-	if (have_out) { // :950-1003
-		if (find_min) {
-			must (prot_engine_reset (pr), "reset");
+	if (opt.out_path) { // apply and write (:950-1003): latency removed, tail flushed
+		if (analyse) {
+			gpu_call (prot_engine_reset (pr), "reset");
 		}
-		std::vector<float> out ((size_t)n_frames * n_channels);
-		must (prot_cli_apply_file (pr, file.data (), n_frames, angles.data (), out.data ()), "apply");
+		std::vector<float> out ((size_t)n_frames * n_chn);
+		gpu_call (prot_cli_apply_file (pr, file.data (), n_frames, angles.data (), out.data ()), "apply");
 		if (n_frames != outfile.writef (out.data (), n_frames)) {
 			fprintf (stderr, "Error writing to output file.\n");
 		}
