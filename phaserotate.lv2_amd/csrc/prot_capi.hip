@@ -265,12 +265,14 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 	p.dry_delay    = (int)e->info.dry_delay;
 	p.hilbert_only = hilbert_only ? 1 : 0;
 	if (e->use_p2) {
-		p.H          = e->d_H.p;
-		p.conv_delay = (int)e->info.conv_delay;
-		p.accumulate = 0;
-		hipError_t err = prot::launch_ola4096_p2 (p, n_chn, s);
-		if (err != hipSuccess) {
-			return hip_fail (err, "ola p2 kernel launch");
+		for (uint32_t pair = 0; pair < e->info.partitions / 2; ++pair) {
+			p.H          = e->d_H.p + (size_t)(2 * pair) * e->info.fftlen;
+			p.conv_delay = (int)(e->info.conv_delay + 2 * pair * e->part_len);
+			p.accumulate = pair > 0;
+			hipError_t err = prot::launch_ola4096_p2 (p, n_chn, s);
+			if (err != hipSuccess) {
+				return hip_fail (err, "ola p2 kernel launch");
+			}
 		}
 		return PROT_OK;
 	}
@@ -432,17 +434,16 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 		return nullptr;
 	}
 	const uint32_t seg = F / 16;
-	int      hopseg;
-	uint32_t n_part, part_len;
-	// 2049..4096 taps with a dry-delay difference of 6 or 8 segments (LV2 48/96 kHz, CLI
-	// blksiz 4096): two partitions sharing one forward transform (ola4096p2_kernel)
-	const uint32_t ddseg  = (inf.dry_delay - inf.conv_delay) / 256;
-	const bool     no_p2  = getenv ("PROT_NO_P2") != nullptr || (cfg->flags & PROT_CFG_SINGLE_FFT_PER_HOP);
-	bool           use_p2 = !no_p2 && inf.firlen > F / 2 + 1 && inf.firlen <= F &&
-	                        (inf.dry_delay - inf.conv_delay) % 256 == 0 && (ddseg == 6 || ddseg == 8);
+	// FIRs longer than one 2048-tap partition: partitions are convolved in PAIRS that share a
+	// forward transform (ola4096p2_kernel); pair s covers taps [4096 s, 4096 s + 4096) and is
+	// delayed by 4096 s frames; pairs after the first accumulate into the output.
+	const bool no_p2  = getenv ("PROT_NO_P2") != nullptr || (cfg->flags & PROT_CFG_SINGLE_FFT_PER_HOP);
+	bool       use_p2 = !no_p2 && inf.firlen > F / 2 + 1;
+	int        hopseg;
+	uint32_t   n_part, part_len;
 	if (use_p2) {
 		part_len = F / 2;
-		n_part   = 2;
+		n_part   = 2 * ((inf.firlen + F - 1) / F); // whole pairs (a missing last partition is all-zero taps)
 		hopseg   = 8;
 	} else if (inf.firlen <= F - F / 4) {
 		n_part   = 1;
@@ -698,7 +699,7 @@ int prot_apply_dev_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uin
 	if (!e || !d_in || !d_out || !rot) {
 		return PROT_EINVAL;
 	}
-	if (e->info.partitions != 1 && !e->use_p2) {
+	if (e->info.partitions != 1 && !(e->use_p2 && e->info.partitions == 2)) {
 		return PROT_EUNSUPPORTED;
 	}
 	HIP_TRY (hipSetDevice (e->device));

@@ -525,14 +525,18 @@ PROT_DEV void inv4096 (typename T::cplx (&v)[16], typename T::cplx* lds, const t
 	pkt_fft16<O, -1> (v);
 }
 
-template <class T, int MODE, int DH>
+// DH: dry path from registers, (dry_delay - conv_delay) / 256 in 1..8; DH = 0: dry frames re-read
+// from the stream (larger delays); ACC: add this partition pair's share to what an earlier launch stored
+// (FIRs of more than 4096 taps: partitions 2s, 2s+1 per launch)
+template <class T, int MODE, int DH, bool ACC = false>
 __global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaParamsT<typename T::samp> p)
 {
 	typedef typename T::cplx C;
 	typedef typename T::ops  O;
 	typedef typename T::samp S;
 	constexpr int HOP = 2048;
-	static_assert (DH >= 1 && DH <= 8, "dry delay difference within one block");
+	static_assert (DH >= 0 && DH <= 8, "dry delay difference within one block, or 0");
+	constexpr int NDH = DH > 0 ? DH : 1;
 
 	__shared__ C lds[kLdsRegion];
 	__shared__ C twm[256];
@@ -553,7 +557,7 @@ __global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaPa
 	const S* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
 	S* __restrict__ out        = p.out + (int64_t)c * p.out_stride;
 	const int64_t n_in             = p.n_in;
-	const int     Dc               = p.conv_delay;
+	const int     Dc = p.conv_delay, Dd = p.dry_delay;
 
 	const f2* __restrict__ twp = reinterpret_cast<const f2*> (p.tw);
 	C tw1[16];
@@ -581,7 +585,7 @@ __global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaPa
 	const int n_it = 2 + (int)((Lh + HOP - 1) / HOP);         // two halo blocks: OLA tail + X_{b-1}
 	int64_t   sP = r0 - 2 * HOP, sQ = sP + Lh;
 
-	float acc[16], dh[2 * DH], nx[16];
+	float acc[16], dh[2 * NDH], nx[16];
 	C     zp[16];
 #pragma unroll
 	for (int i = 0; i < 16; ++i) {
@@ -589,9 +593,9 @@ __global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaPa
 		zp[i]  = O::mk (0.f, 0.f);
 	}
 #pragma unroll
-	for (int i = 0; i < DH; ++i) {
-		dh[i]      = ldv (in, n_in, hist, p.hist_len, sP - Dc - 256 * (DH - i) + t);
-		dh[DH + i] = ldv (in, n_in, hist, p.hist_len, sQ - Dc - 256 * (DH - i) + t);
+	for (int i = 0; i < NDH; ++i) {
+		dh[i]       = DH > 0 ? ldv (in, n_in, hist, p.hist_len, sP - Dc - 256 * (DH - i) + t) : 0.f;
+		dh[NDH + i] = DH > 0 ? ldv (in, n_in, hist, p.hist_len, sQ - Dc - 256 * (DH - i) + t) : 0.f;
 	}
 	auto load_blocks = [&] (int64_t aP, int64_t aQ) {
 		const bool fast = (aP >= 0) && (aQ + HOP <= n_in);
@@ -646,17 +650,26 @@ __global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaPa
 		}
 		__builtin_amdgcn_sched_barrier (0);
 
-		// dry path from registers: (dry_delay - conv_delay) = 256 * DH frames back
+		// dry path: from registers ((dry_delay - conv_delay) = 256 * DH frames back) or, for
+		// larger delays, re-read from the stream (L2/MALL)
 		float dry[16];
+		if (DH > 0) {
 #pragma unroll
-		for (int h = 0; h < 2; ++h) {
+			for (int h = 0; h < 2; ++h) {
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					dry[8 * h + k] = (k >= DH) ? cur[8 * h + (k >= DH ? k - DH : 0)] : dh[NDH * h + (k < DH ? k : 0)];
+				}
+#pragma unroll
+				for (int i = 0; i < NDH; ++i) {
+					dh[NDH * h + i] = cur[8 * h + 8 - NDH + i];
+				}
+			}
+		} else if (MODE != MODE_HILBERT && !ACC && it >= 2) {
 #pragma unroll
 			for (int k = 0; k < 8; ++k) {
-				dry[8 * h + k] = (k >= DH) ? cur[8 * h + (k >= DH ? k - DH : 0)] : dh[DH * h + (k < DH ? k : 0)];
-			}
-#pragma unroll
-			for (int i = 0; i < DH; ++i) {
-				dh[DH * h + i] = cur[8 * h + 8 - DH + i];
+				dry[k]     = ldv (in, n_in, hist, p.hist_len, sP + t + 256 * k - Dd);
+				dry[8 + k] = ldv (in, n_in, hist, p.hist_len, sQ + t + 256 * k - Dd);
 			}
 		}
 
@@ -681,7 +694,7 @@ __global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaPa
 					const int64_t pos = s0 + t + 256 * k;
 					if (pos < end) {
 						if (MODE == MODE_HILBERT) {
-							out[pos] = (S)u[8 * h + k];
+							out[pos] = ACC ? (S)((float)out[pos] + u[8 * h + k]) : (S)u[8 * h + k];
 						} else {
 							float cc = ca, ss = sa;
 							if (MODE == MODE_RAMP) {
@@ -689,7 +702,7 @@ __global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaPa
 								cc          = cs.x;
 								ss          = cs.y;
 							}
-							out[pos] = (S)(cc * dry[8 * h + k] + ss * u[8 * h + k]);
+							out[pos] = ACC ? (S)((float)out[pos] + ss * u[8 * h + k]) : (S)(cc * dry[8 * h + k] + ss * u[8 * h + k]);
 						}
 					}
 				}
@@ -701,13 +714,17 @@ __global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaPa
 template <class T, int MODE>
 static hipError_t launch_p2_m (const OlaParamsT<typename T::samp>& p, dim3 grid, hipStream_t s)
 {
-	const int dd = (p.dry_delay - p.conv_delay) / 256;
-	if (dd == 6) {
-		hipLaunchKernelGGL ((ola4096p2_kernel<T, MODE, 6>), grid, dim3 (256), 0, s, p);
-	} else if (dd == 8) {
-		hipLaunchKernelGGL ((ola4096p2_kernel<T, MODE, 8>), grid, dim3 (256), 0, s, p);
+	const int  diff = p.dry_delay - p.conv_delay;
+	const int  dd   = (diff > 0 && diff % 256 == 0) ? diff / 256 : 0;
+	const dim3 block (256);
+	if (p.accumulate) {
+		hipLaunchKernelGGL ((ola4096p2_kernel<T, MODE, 0, true>), grid, block, 0, s, p);
+	} else if (MODE != MODE_HILBERT && dd == 6) {
+		hipLaunchKernelGGL ((ola4096p2_kernel<T, MODE, 6>), grid, block, 0, s, p);
+	} else if (MODE != MODE_HILBERT && dd == 8) {
+		hipLaunchKernelGGL ((ola4096p2_kernel<T, MODE, 8>), grid, block, 0, s, p);
 	} else {
-		return hipErrorInvalidValue;
+		hipLaunchKernelGGL ((ola4096p2_kernel<T, MODE, 0>), grid, block, 0, s, p);
 	}
 	return hipGetLastError ();
 }

@@ -340,6 +340,21 @@ def test_cli_analysis_result_matches_oracle(tmp_path, n_chn, stride, link):
 
 
 @pytest.mark.gpu
+def test_cli_default_block_size_48k(tmp_path):
+    """No -f: blksiz = pow2ceil(48000 / 8) = 8192 (cli/phase-rotate.cc:749-755) = two FIR partition pairs here."""
+    rate, n = 48000, 100000
+    x = (0.8 * harmonic_stack(n, rate, f0=82.4) + 0.02 * xorshift_uniform(n, seed=13)).astype(np.float32)
+    wav = str(tmp_path / "in.wav")
+    write_wav(wav, x, rate)
+    rc, out, err = cli("-vv", wav)
+    assert rc == 0 and "Process block-size 8192" in err
+    ma, fo, rz, rm, _ = orc.cli_find_min(8192, 1, x, stride=24)
+    want = _fmt_result(ma, fo, rz, rm).splitlines()[-1]
+    got = err.splitlines()[-1]  # -vv sends the result to stderr (verbose_fd)
+    assert got.split(",")[0] == want.split(",")[0]
+
+
+@pytest.mark.gpu
 def test_cli_verbose_table_and_apply(tmp_path):
     rate, P = 48000, 2048
     n = P * 12
