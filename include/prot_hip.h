@@ -191,6 +191,25 @@ int prot_cli_peaks (prot_engine* e, float* out);
 /* DEVICE pointer of the engine's own table (for an external MAX all-reduce) */
 float* prot_cli_peaks_dev (prot_engine* e);
 
+/* ---- several GPUs of one node, single process --------------------------- */
+/* MAX all-reduce of the engines' OWN peak tables (prot_cli_peaks_dev) across
+ * their GPUs: one ncclAllReduce(ncclMax, float[n_chn][360]) per engine inside
+ * an RCCL group (ncclCommInitAll, one communicator per device, over xGMI).
+ * 2.9 KB for stereo: latency-bound.  Engines must sit on distinct devices and
+ * have equal n_chn; for engines sharing a device (tests) or when librccl is
+ * not loadable the tables are merged through the host instead.  Replaces the
+ * thread join + peak_all() max of cli/phase-rotate.cc:441-443, :287-299.
+ * After the call every engine holds the merged table. */
+int prot_allreduce_peaks (prot_engine* const* engines, int n);
+
+/* analyze_file (cli/phase-rotate.cc:565-587) sharded over n engines: engine r
+ * sweeps a pair-aligned range of frame blocks for all requested angles, primed
+ * with the input history in front of its range; the first-block rule stays
+ * with engine 0, zero-padding and the flush block with the last one; then
+ * prot_allreduce_peaks.  Bit-identical to prot_cli_analyze_file on one engine. */
+int prot_cli_analyze_file_multi (prot_engine* const* engines, int n, const float* data, uint64_t n_frames,
+                                 int ang_start, int ang_end, int ang_stride, int chn);
+
 /* SinCosLut::sincos (cli/phase-rotate.cc:41-74) -- the table the device uses */
 void prot_sincos_lut (int a, float* s, float* c);
 

@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "prot_apply_dev", "prot_apply_dev_ramp", "prot_apply_dev_f16", "prot_sweep_dev",
     "prot_lv2_run", "prot_lv2_get_angle", "prot_cli_apply", "prot_cli_analyze", "prot_cli_analyze_file",
     "prot_cli_apply_file", "prot_cli_peak", "prot_cli_peak_all", "prot_cli_peaks",
-    "prot_cli_peaks_dev",
+    "prot_cli_peaks_dev", "prot_allreduce_peaks", "prot_cli_analyze_file_multi",
 )
 
 
@@ -119,6 +119,9 @@ def load_library():
     lib.prot_cli_peaks.argtypes = [C.c_void_p, _f32p]
     lib.prot_cli_peaks_dev.restype = C.c_void_p
     lib.prot_cli_peaks_dev.argtypes = [C.c_void_p]
+    lib.prot_allreduce_peaks.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.prot_cli_analyze_file_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, _f32p, C.c_uint64,
+                                                C.c_int, C.c_int, C.c_int, C.c_int]
     _lib = lib
     return lib
 
@@ -264,6 +267,15 @@ class PhaseRotate(Engine):
                                              np.ascontiguousarray(angles, np.int32), out),
                "prot_cli_apply_file")
         return out
+
+
+def analyze_file_multi(engines, data, ang_start, ang_end, ang_stride, chn=-1):
+    """prot_cli_analyze_file_multi: one in-memory file sharded over several PhaseRotate engines."""
+    lib = load_library()
+    data = np.ascontiguousarray(data, np.float32).reshape(-1)
+    hs = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    _check(lib.prot_cli_analyze_file_multi(hs, len(engines), data, data.size // engines[0].n_chn,
+                                           ang_start, ang_end, ang_stride, chn), "prot_cli_analyze_file_multi")
 
 
 class Lv2Instance(Engine):

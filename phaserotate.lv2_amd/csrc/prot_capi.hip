@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <dlfcn.h>
+#include <thread>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -1154,6 +1156,222 @@ int prot_cli_analyze_file (prot_engine* e, const float* data, uint64_t n_frames,
 		first = false;
 	} while (pos < n_frames);
 	return PROT_OK;
+}
+
+// ------------------------------------------------------------------ several GPUs
+namespace {
+
+// RCCL through dlopen: the library is only needed by multi-GPU callers
+struct Rccl {
+	void* lib = nullptr;
+	int (*CommInitAll) (void**, int, const int*) = nullptr;
+	int (*CommDestroy) (void*)                    = nullptr;
+	int (*GroupStart) ()                          = nullptr;
+	int (*GroupEnd) ()                            = nullptr;
+	int (*AllReduce) (const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+	bool load ()
+	{
+		if (lib) {
+			return true;
+		}
+		for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
+			lib = dlopen (name, RTLD_NOW | RTLD_LOCAL);
+			if (lib) {
+				break;
+			}
+		}
+		if (!lib) {
+			return false;
+		}
+		CommInitAll = (int (*) (void**, int, const int*))dlsym (lib, "ncclCommInitAll");
+		CommDestroy = (int (*) (void*))dlsym (lib, "ncclCommDestroy");
+		GroupStart  = (int (*) ())dlsym (lib, "ncclGroupStart");
+		GroupEnd    = (int (*) ())dlsym (lib, "ncclGroupEnd");
+		AllReduce   = (int (*) (const void*, void*, size_t, int, int, void*, hipStream_t))dlsym (lib, "ncclAllReduce");
+		return CommInitAll && CommDestroy && GroupStart && GroupEnd && AllReduce;
+	}
+};
+Rccl       g_rccl;
+std::mutex g_rccl_lock;
+
+constexpr int kNcclFloat32 = 7, kNcclMax = 2; // rccl.h: ncclDataType_t / ncclRedOp_t
+
+// sweep frames [f0, f0 + nf) of an in-memory interleaved file on one engine
+int analyze_range (prot_engine* e, const float* data, uint64_t f0, uint64_t nf, bool is_first, bool is_last,
+                   int ang_start, int ang_end, int ang_stride, int chn)
+{
+	HIP_TRY (hipSetDevice (e->device));
+	const uint32_t nc = e->info.n_chn;
+	const uint64_t P  = e->info.blksiz;
+	hipStream_t    s  = e->stream;
+	const uint64_t chunk = std::max<uint64_t> (P, ((uint64_t)1 << 22) / P * P);
+	const uint64_t H     = e->info.history;
+	const uint64_t cap   = std::max<uint64_t> (std::min<uint64_t> (chunk, std::max<uint64_t> (nf, 1)), H);
+	int rc;
+	if ((rc = e->d_inter.ensure (cap * nc)) || (rc = e->d_in.ensure (cap * nc)) || (rc = e->d_out.ensure (cap * nc))) {
+		return rc;
+	}
+	if (!is_first) {
+		// prime the input history with the H frames in front of the range (Hilbert output discarded)
+		const uint64_t h = std::min<uint64_t> (H, f0);
+		HIP_TRY (hipMemcpyAsync (e->d_inter.p, data + (f0 - h) * nc, h * nc * sizeof (float), hipMemcpyHostToDevice, s));
+		hipError_t err = prot::launch_deinterleave (e->d_inter.p, e->d_in.p, (int64_t)cap, (int64_t)h, (int)nc, s);
+		if (err != hipSuccess) {
+			return hip_fail (err, "deinterleave launch");
+		}
+		rc = prot_apply_dev (e, e->d_in.p, (int64_t)cap, h, e->d_out.p, (int64_t)cap, h, nullptr, PROT_F_HILBERT, s);
+		if (rc) {
+			return rc;
+		}
+		HIP_TRY (hipStreamSynchronize (s));
+	}
+	uint64_t pos   = 0;
+	bool     first = true;
+	do {
+		const uint64_t n    = std::min (chunk, nf - pos);
+		const bool     last = pos + n >= nf;
+		if (n) {
+			HIP_TRY (hipMemcpyAsync (e->d_inter.p, data + (f0 + pos) * nc, n * nc * sizeof (float), hipMemcpyHostToDevice, s));
+			hipError_t err = prot::launch_deinterleave (e->d_inter.p, e->d_in.p, (int64_t)cap, (int64_t)n, (int)nc, s);
+			if (err != hipSuccess) {
+				return hip_fail (err, "deinterleave launch");
+			}
+		}
+		// an empty file never sets `start` (cli/phase-rotate.cc:573-576)
+		const uint32_t fl = (first && n && is_first ? PROT_F_STREAM_START : 0) | (last && is_last ? PROT_F_STREAM_END : 0);
+		if (n || (last && is_last)) {
+			rc = prot_sweep_dev (e, e->d_in.p, (int64_t)cap, n, ang_start, ang_end, ang_stride, chn, nullptr, fl, s);
+			if (rc) {
+				return rc;
+			}
+		}
+		HIP_TRY (hipStreamSynchronize (s)); // staging buffers are reused by the next chunk
+		pos += n;
+		first = false;
+	} while (pos < nf);
+	return PROT_OK;
+}
+
+} // namespace
+
+int prot_allreduce_peaks (prot_engine* const* engines, int n)
+{
+	if (!engines || n < 1) {
+		return PROT_EINVAL;
+	}
+	const size_t count = (size_t)PROT_MAXSAMPLE * engines[0]->info.n_chn;
+	bool distinct = true;
+	for (int i = 0; i < n; ++i) {
+		if (!engines[i] || engines[i]->info.n_chn != engines[0]->info.n_chn) {
+			return PROT_EINVAL;
+		}
+		engines[i]->h_peaks_valid = false;
+		for (int k = 0; k < i; ++k) {
+			distinct = distinct && engines[k]->device != engines[i]->device;
+		}
+	}
+	if (n == 1) {
+		return PROT_OK;
+	}
+	const bool want_host = getenv ("PROT_ALLREDUCE") && !strcmp (getenv ("PROT_ALLREDUCE"), "host");
+	std::lock_guard<std::mutex> lk (g_rccl_lock);
+	if (distinct && !want_host && g_rccl.load ()) {
+		std::vector<int>   devs (n);
+		std::vector<void*> comms (n, nullptr);
+		for (int i = 0; i < n; ++i) {
+			devs[i] = engines[i]->device;
+		}
+		if (g_rccl.CommInitAll (comms.data (), n, devs.data ()) != 0) {
+			snprintf (g_err, sizeof (g_err), "ncclCommInitAll failed");
+			return PROT_EHIP;
+		}
+		int bad = g_rccl.GroupStart ();
+		for (int i = 0; i < n && !bad; ++i) {
+			HIP_TRY (hipSetDevice (engines[i]->device));
+			bad = g_rccl.AllReduce (engines[i]->d_peaks.p, engines[i]->d_peaks.p, count, kNcclFloat32, kNcclMax, comms[i],
+			                        engines[i]->stream);
+		}
+		bad = g_rccl.GroupEnd () || bad;
+		for (int i = 0; i < n; ++i) {
+			(void)hipSetDevice (engines[i]->device);
+			(void)hipStreamSynchronize (engines[i]->stream);
+			g_rccl.CommDestroy (comms[i]);
+		}
+		if (bad) {
+			snprintf (g_err, sizeof (g_err), "ncclAllReduce failed");
+			return PROT_EHIP;
+		}
+		return PROT_OK;
+	}
+	// same-device engines (tests) or no RCCL: merge through the host
+	std::vector<float> acc (count, 0.f), tmp (count);
+	for (int i = 0; i < n; ++i) {
+		int rc = prot_cli_peaks (engines[i], tmp.data ());
+		if (rc) {
+			return rc;
+		}
+		for (size_t k = 0; k < count; ++k) {
+			acc[k] = std::max (acc[k], tmp[k]);
+		}
+	}
+	for (int i = 0; i < n; ++i) {
+		HIP_TRY (hipSetDevice (engines[i]->device));
+		HIP_TRY (hipMemcpy (engines[i]->d_peaks.p, acc.data (), count * sizeof (float), hipMemcpyHostToDevice));
+		engines[i]->h_peaks_valid = false;
+	}
+	return PROT_OK;
+}
+
+int prot_cli_analyze_file_multi (prot_engine* const* engines, int n, const float* data, uint64_t n_frames, int ang_start,
+                                 int ang_end, int ang_stride, int chn)
+{
+	if (!engines || n < 1 || (!data && n_frames)) {
+		return PROT_EINVAL;
+	}
+	for (int i = 0; i < n; ++i) {
+		if (!engines[i] || engines[i]->info.kind != PROT_KIND_CLI || engines[i]->info.blksiz != engines[0]->info.blksiz ||
+		    engines[i]->info.n_chn != engines[0]->info.n_chn) {
+			return PROT_EINVAL;
+		}
+	}
+	// contiguous block ranges on pair boundaries (2 blocks): a shard that starts on a hop-pair
+	// boundary reproduces the single-engine arithmetic bit for bit
+	const uint64_t P     = engines[0]->info.blksiz;
+	const uint64_t nb    = (n_frames + P - 1) / P;
+	const uint64_t units = (nb + 1) / 2;
+	std::vector<uint64_t> b0 (n + 1, 0);
+	for (int r = 0; r < n; ++r) {
+		const uint64_t k = units / n + ((uint64_t)r < units % n ? 1 : 0);
+		b0[r + 1]        = std::min (nb, b0[r] + 2 * k);
+	}
+	std::vector<int>         rcs (n, PROT_OK);
+	std::vector<std::thread> th;
+	int                      last_nonempty = 0;
+	for (int r = 0; r < n; ++r) {
+		if (b0[r + 1] > b0[r]) {
+			last_nonempty = r;
+		}
+	}
+	for (int r = 0; r < n; ++r) {
+		const uint64_t f0 = b0[r] * P;
+		const uint64_t f1 = std::min (b0[r + 1] * P, n_frames);
+		const bool     is_last = r == last_nonempty;
+		if (f1 <= f0 && !(is_last && r == 0)) {
+			continue; // more engines than block pairs
+		}
+		th.emplace_back ([=, &rcs] () {
+			rcs[r] = analyze_range (engines[r], data, f0, f1 - f0, r == 0, is_last, ang_start, ang_end, ang_stride, chn);
+		});
+	}
+	for (auto& t : th) {
+		t.join ();
+	}
+	for (int r = 0; r < n; ++r) {
+		if (rcs[r]) {
+			return rcs[r];
+		}
+	}
+	return prot_allreduce_peaks (engines, n);
 }
 
 int prot_cli_apply_file (prot_engine* e, const float* data, uint64_t n_frames, const int* angles, float* out)

@@ -93,7 +93,8 @@ const char* const kHelp =
     "phase-rotate -vv -s 3 my-music.wav\n\n"
     "phase-rotate -a 10,20 in.wav out.wav\n\n"
     "This build runs the DSP on an AMD MI355X (gfx950) through libprot_hip.\n"
-    "Environment: PROT_DEVICE=<n> selects the HIP device.\n";
+    "Environment: PROT_DEVICE=<n> selects the HIP device; PROT_GPUS=<n> shards the\n"
+    "analysis over n GPUs of the node (peak tables merged with an RCCL all-reduce).\n";
 
 struct Options {
 	const char*      in_path  = nullptr;
@@ -225,9 +226,23 @@ struct Result {
 };
 
 // the minimum search of cli/phase-rotate.cc:784-929 on the whole file
-Result find_minimum (prot_engine* pr, const std::vector<float>& file, uint64_t n_frames, int n_chn,
+// analysis pass over the whole file: one engine, or PROT_GPUS engines each sweeping a range of
+// frame blocks followed by a MAX all-reduce of their peak tables
+void analysis_pass (const std::vector<prot_engine*>& gpus, const std::vector<float>& file, uint64_t n_frames,
+                    int a0, int a1, int step, int chn)
+{
+	if (gpus.size () == 1) {
+		gpu_call (prot_cli_analyze_file (gpus[0], file.data (), n_frames, a0, a1, step, chn), "analysis");
+	} else {
+		gpu_call (prot_cli_analyze_file_multi (gpus.data (), (int)gpus.size (), file.data (), n_frames, a0, a1, step, chn),
+		          "analysis");
+	}
+}
+
+Result find_minimum (const std::vector<prot_engine*>& gpus, const std::vector<float>& file, uint64_t n_frames, int n_chn,
                      const Options& opt, FILE* vfd)
 {
+	prot_engine* pr = gpus[0]; // after a pass every engine holds the merged table
 	const int stride = opt.stride;
 	Result    r;
 	r.angle.assign (n_chn, 0);
@@ -236,7 +251,7 @@ Result find_minimum (prot_engine* pr, const std::vector<float>& file, uint64_t n
 	r.at_min.assign (n_chn, 0.f);
 
 	// coarse pass, all channels (:784)
-	gpu_call (prot_cli_analyze_file (pr, file.data (), n_frames, 0, kAngles, stride, -1), "analysis");
+	analysis_pass (gpus, file, n_frames, 0, kAngles, stride, -1);
 	const Peaks coarse (pr, n_chn);
 	if (opt.verbose > 1) { // gnuplot table (:800-813)
 		printf ("# Angle mono-peak");
@@ -293,10 +308,11 @@ Result find_minimum (prot_engine* pr, const std::vector<float>& file, uint64_t n
 		const int reach = (stride + 1) / 2;
 		for (const auto& cand : candidates) {
 			const int centre = cand.first;
-			gpu_call (prot_engine_reset (pr), "reset");
-			gpu_call (prot_cli_analyze_file (pr, file.data (), n_frames, centre - reach, centre + reach + 1, 1,
-			                                 cand.second.size () > 1 ? -1 : cand.second.front ()),
-			          "analysis");
+			for (prot_engine* g : gpus) {
+				gpu_call (prot_engine_reset (g), "reset");
+			}
+			analysis_pass (gpus, file, n_frames, centre - reach, centre + reach + 1, 1,
+			               cand.second.size () > 1 ? -1 : cand.second.front ());
 			const Peaks fine (pr, n_chn);
 			for (int c : cand.second) {
 				for (int a = centre - reach; a < centre + reach + 1; ++a) {
@@ -404,24 +420,34 @@ int main (int argc, char** argv)
 		fprintf (vfd, "Process block-size %d\n", blksiz);
 	}
 
-	prot_config cfg;
-	memset (&cfg, 0, sizeof (cfg));
-	cfg.kind   = PROT_KIND_CLI;
-	cfg.param  = blksiz;
-	cfg.n_chn  = (uint32_t)n_chn;
-	cfg.device = getenv ("PROT_DEVICE") ? atoi (getenv ("PROT_DEVICE")) : 0;
-	int          status = 0;
-	prot_engine* pr     = prot_engine_create (&cfg, &status);
-	if (!pr) {
-		fprintf (stderr, "Error: cannot create the GPU engine: %s (%s)\n", prot_strerror (status), prot_last_error ());
-		return EXIT_FAILURE;
+	// engines: one, or PROT_GPUS of them on consecutive devices (PROT_GPUS_SAME_DEVICE=1 keeps them
+	// all on PROT_DEVICE -- a functional test of the sharding on a single-GPU box)
+	const int n_gpus   = std::max (1, getenv ("PROT_GPUS") ? atoi (getenv ("PROT_GPUS")) : 1);
+	const int dev0     = getenv ("PROT_DEVICE") ? atoi (getenv ("PROT_DEVICE")) : 0;
+	const bool same_dev = getenv ("PROT_GPUS_SAME_DEVICE") != nullptr;
+	std::vector<prot_engine*> gpus;
+	for (int g = 0; g < n_gpus; ++g) {
+		prot_config cfg;
+		memset (&cfg, 0, sizeof (cfg));
+		cfg.kind   = PROT_KIND_CLI;
+		cfg.param  = blksiz;
+		cfg.n_chn  = (uint32_t)n_chn;
+		cfg.device = same_dev ? dev0 : dev0 + g;
+		int          status = 0;
+		prot_engine* e      = prot_engine_create (&cfg, &status);
+		if (!e) {
+			fprintf (stderr, "Error: cannot create the GPU engine: %s (%s)\n", prot_strerror (status), prot_last_error ());
+			return EXIT_FAILURE;
+		}
+		gpus.push_back (e);
 	}
+	prot_engine* pr = gpus[0];
 
 	if (analyse) {
 		if (opt.verbose > 1) {
 			fprintf (vfd, "Analyzing using %d process threads, stride = %d\n", n_chn, opt.stride);
 		}
-		const Result res = find_minimum (pr, file, n_frames, n_chn, opt, vfd);
+		const Result res = find_minimum (gpus, file, n_frames, n_chn, opt, vfd);
 		angles           = res.angle;
 		if (!opt.out_path || opt.verbose) {
 			print_result (res, n_chn, vfd);
@@ -440,6 +466,8 @@ int main (int argc, char** argv)
 		outfile.close ();
 	}
 
-	prot_engine_destroy (pr);
+	for (prot_engine* g : gpus) {
+		prot_engine_destroy (g);
+	}
 	return 0;
 }

@@ -389,3 +389,53 @@ def test_cli_verbose_table_and_apply(tmp_path):
     x16 = np.clip(np.rint(x * 32767.0), -32768, 32767).astype(np.float32) / 32768.0
     yo = orc.cli_apply_file_mono(P, x16.astype(np.float32), -61)
     assert np.abs(y16 - np.clip(np.rint(yo * 32767.0), -32768, 32767)).max() <= 1.0
+
+
+@pytest.mark.gpu
+def test_multi_engine_sharded_analysis_is_bit_identical(pkg):
+    """prot_cli_analyze_file_multi with 3 engines (all on device 0: host-merged tables) ==
+    prot_cli_analyze_file on one engine, bit for bit; ragged file, stereo, coarse stride."""
+    P, n_chn = 2048, 2
+    n = P * 37 + 911
+    chans = [0.8 * harmonic_stack(n, f0=120.0 * (1 + 0.23 * c)) + 0.05 * xorshift_uniform(n, seed=c) for c in range(n_chn)]
+    data = np.stack(chans, axis=1).astype(np.float32)
+    one = pkg.PhaseRotate(P, n_chn)
+    one.analyze_file(data, 0, 360, 1)
+    want = one.peaks()
+    engines = [pkg.PhaseRotate(P, n_chn) for _ in range(3)]
+    pkg.analyze_file_multi(engines, data, 0, 360, 1)
+    for e in engines:
+        assert np.array_equal(e.peaks(), want)
+    # a single-channel fine pass with negative angles through the same path
+    for e in engines + [one]:
+        e.reset()
+    one.analyze_file(data, -12, 13, 1, 1)
+    pkg.analyze_file_multi(engines, data, -12, 13, 1, 1)
+    assert np.array_equal(engines[0].peaks(), one.peaks())
+    # more engines than block pairs
+    tiny = data[:P + 5]
+    for e in engines + [one]:
+        e.reset()
+    one.analyze_file(tiny, 0, 360, 24)
+    pkg.analyze_file_multi(engines, tiny, 0, 360, 24)
+    assert np.array_equal(engines[2].peaks(), one.peaks())
+    # RCCL path with one communicator (n = 1) must be a no-op success
+    lib = pkg.load_library()
+    hs = (C.c_void_p * 1)(one._h)
+    assert lib.prot_allreduce_peaks(hs, 1) == 0
+    for e in engines + [one]:
+        e.close()
+
+
+@pytest.mark.gpu
+def test_cli_prot_gpus_env_gives_same_result(tmp_path):
+    rate, n = 48000, 90000
+    x = np.stack([0.8 * harmonic_stack(n, rate, f0=98.0 * (1 + 0.3 * c)) + 0.02 * xorshift_uniform(n, seed=c)
+                  for c in range(2)], axis=1).astype(np.float32)
+    wav = str(tmp_path / "in.wav")
+    write_wav(wav, x, rate)
+    rc1, out1, err1 = cli("-f", "2048", wav)
+    env = dict(os.environ, PROT_GPUS="3", PROT_GPUS_SAME_DEVICE="1")
+    r = subprocess.run([CLI, "-f", "2048", wav], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    assert rc1 == 0 and r.returncode == 0, r.stderr
+    assert r.stdout == out1
