@@ -16,7 +16,8 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libprot_hip.so")
+# PROT_LIB_PATH: tuning only (tools/ab_bench.py times alternative builds of the same sources)
+LIB_PATH = os.environ.get("PROT_LIB_PATH") or os.path.join(_PKG, "lib", "libprot_hip.so")
 
 MAXSAMPLE = 360          # cli/phase-rotate.cc:39
 SUBSAMPLE = 2            # cli/phase-rotate.cc:38

@@ -174,6 +174,27 @@ typedef _Float16 h2 __attribute__ ((ext_vector_type (2)));
 			}                                                                                                \
 			return d;                                                                                        \
 		}                                                                                                    \
+		/* two independent products, interleaved: a0 *= w0, a1 *= w1 (conj(w) for DIR < 0) */               \
+		template <int DIR>                                                                                   \
+		PROT_DEV void cmul2 (C& a0, C w0, C& a1, C w1)                                                       \
+		{                                                                                                    \
+			C r0, r1, d0, d1;                                                                                \
+			if (DIR > 0) {                                                                                   \
+				asm ("v_pk_mul_" SFX " %0, %4, %5 op_sel:[0,0] op_sel_hi:[0,1]\n\t"                          \
+				     "v_pk_mul_" SFX " %1, %6, %7 op_sel:[0,0] op_sel_hi:[0,1]\n\t"                          \
+				     "v_pk_fma_" SFX " %2, %4, %5, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"   \
+				     "v_pk_fma_" SFX " %3, %6, %7, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"        \
+				     : "=&v"(r0), "=&v"(r1), "=&v"(d0), "=&v"(d1) : "v"(a0), "v"(w0), "v"(a1), "v"(w1));      \
+			} else {                                                                                         \
+				asm ("v_pk_mul_" SFX " %0, %4, %5 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"             \
+				     "v_pk_mul_" SFX " %1, %6, %7 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"             \
+				     "v_pk_fma_" SFX " %2, %4, %5, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"                  \
+				     "v_pk_fma_" SFX " %3, %6, %7, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1]"                       \
+				     : "=&v"(r0), "=&v"(r1), "=&v"(d0), "=&v"(d1) : "v"(a0), "v"(w0), "v"(a1), "v"(w1));      \
+			}                                                                                                \
+			a0 = d0;                                                                                         \
+			a1 = d1;                                                                                         \
+		}                                                                                                    \
 		/* acc + a * w (DIR > 0) or acc + a * conj(w) (DIR < 0) */                                           \
 		template <int DIR>                                                                                   \
 		PROT_DEV C cmul_acc (C acc, C a, C w)                                                                \

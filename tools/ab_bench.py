@@ -1,0 +1,56 @@
+"""Time variant libraries (tools/ab_build.py) against each other on ONE box, interleaved:
+`python tools/ab_bench.py [--rounds 3] [--cases p2,cli] tagA tagB ...` ("main" = the shipped library)."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r'''
+import sys, os
+sys.path.insert(0, %r)
+import numpy as np, torch
+from __graft_entry__ import load_package
+pkg = load_package()
+dev = torch.device("cuda:0")
+cases = {"hop1024": (pkg.KIND_LV2, 48000, 1), "p2": (pkg.KIND_LV2, 48000, 0), "p2_96k": (pkg.KIND_LV2, 96000, 0),
+         "cli": (pkg.KIND_CLI, 2048, 0), "cli8192": (pkg.KIND_CLI, 8192, 0)}
+n = 1 << 27
+x = (torch.rand(n, device=dev) - 0.5); y = torch.empty_like(x)
+rot = np.array([0.0, -1.0], np.float32)
+ts = torch.cuda.Stream(); torch.cuda.set_stream(ts); st = ts.cuda_stream
+out = []
+for name in sys.argv[1].split(","):
+    kind, param, fl = cases[name]
+    e = pkg.Engine(kind, param, 1, flags=fl)
+    for _ in range(2):
+        e.apply_dev(x.data_ptr(), n, n, y.data_ptr(), n, n, rot, pkg.F_STATELESS, st)
+    torch.cuda.synchronize()
+    best = 1e9
+    for rep in range(3):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(5):
+            e.apply_dev(x.data_ptr(), n, n, y.data_ptr(), n, n, rot, pkg.F_STATELESS, st)
+        ev1.record(); torch.cuda.synchronize()
+        best = min(best, ev0.elapsed_time(ev1) / 5)
+    out.append("%%s %%.4f" %% (name, best))
+    e.close()
+print("RESULT " + " ".join(out))
+''' % ROOT
+args = sys.argv[1:]
+rounds, cases = 3, "p2"
+while args and args[0].startswith("--"):
+    if args[0] == "--rounds": rounds = int(args[1])
+    elif args[0] == "--cases": cases = args[1]
+    args = args[2:]
+tags = args or ["main"]
+res = {t: [] for t in tags}
+for r in range(rounds):
+    for t in tags:
+        env = dict(os.environ)
+        if t != "main":
+            env["PROT_LIB_PATH"] = os.path.join(ROOT, "phaserotate.lv2_amd", "lib", "variants", "libprot_hip_%s.so" % t)
+        p = subprocess.run([sys.executable, "-c", CHILD, cases], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")]
+        if not line:
+            print(t, "FAILED", p.stdout[-2000:]); continue
+        res[t].append(line[0][7:])
+for t in tags:
+    print("%-16s %s" % (t, " | ".join(res[t])), flush=True)
