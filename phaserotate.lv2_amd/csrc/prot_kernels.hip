@@ -50,6 +50,20 @@ PROT_DEV float ldv (const S* __restrict__ in, int64_t n_in, const S* __restrict_
 	return (hist != nullptr && h >= 0) ? (float)hist[h] : 0.f;
 }
 
+// pin a wave-uniform pointer in an SGPR pair: the loads/stores that use it take the
+// "saddr + 32-bit lane offset + immediate" form (half the address traffic of 64-bit per-lane
+// addresses and no VALU pointer arithmetic); opaque to loop strength reduction, which would
+// otherwise turn the bases back into per-lane pointer induction variables
+#define PROT_GLOBAL __attribute__ ((address_space (1)))
+template <class P>
+PROT_DEV PROT_GLOBAL P* uniform_ptr (P* q)
+{
+	const uint64_t b  = reinterpret_cast<uint64_t> (q);
+	const uint32_t lo = __builtin_amdgcn_readfirstlane ((uint32_t)b);
+	const uint32_t hi = __builtin_amdgcn_readfirstlane ((uint32_t)(b >> 32));
+	return (PROT_GLOBAL P*)(((uint64_t)hi << 32) | lo);
+}
+
 // ------------------------------------------------------------ OLA, FFT-4096
 constexpr int kL1 = 272; // exchange between pass 1 and 2 (and inverse mirror)
 constexpr int kL2 = 258; // forward exchange 2 and inverse exchange A share slots (n0*kL2 + t):
@@ -445,6 +459,10 @@ struct T16 {
 #ifndef PROT_ABL2
 #define PROT_ABL2 0
 #endif
+// where the next block's stream loads are issued: 0 = top of the iteration, 1 = after the spectrum multiply
+#ifndef PROT_PREFETCH_AT
+#define PROT_PREFETCH_AT 1
+#endif
 
 // ---- FFT-4096 with wave-local inner exchanges (2 workgroup barriers per transform pair) ----
 // Pass-2 threads are (n1 = tl, k1 = th), so the 16 threads of one `th` hold a full n1 x k2 tile:
@@ -689,10 +707,18 @@ __global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaPa
 				nx[k] = 0.001f * (float)(t + k);
 			}
 		} else if (fast) {
+			// uniform base (SGPR pair) + 32-bit lane offset: saddr addressing, no 64-bit VALU address math
+			// (the immediate offset reaches 4 KiB: one base per 1024 frames)
+			const PROT_GLOBAL S* __restrict__ bP0 = uniform_ptr (in + aP);
+			const PROT_GLOBAL S* __restrict__ bP1 = uniform_ptr (in + aP + 1024);
+			const PROT_GLOBAL S* __restrict__ bQ0 = uniform_ptr (in + aQ);
+			const PROT_GLOBAL S* __restrict__ bQ1 = uniform_ptr (in + aQ + 1024);
 #pragma unroll
-			for (int k = 0; k < 8; ++k) {
-				nx[k]     = (float)in[aP + t + 256 * k];
-				nx[8 + k] = (float)in[aQ + t + 256 * k];
+			for (int k = 0; k < 4; ++k) {
+				nx[k]      = (float)bP0[(unsigned)t + 256u * k];
+				nx[4 + k]  = (float)bP1[(unsigned)t + 256u * k];
+				nx[8 + k]  = (float)bQ0[(unsigned)t + 256u * k];
+				nx[12 + k] = (float)bQ1[(unsigned)t + 256u * k];
 			}
 		} else {
 #pragma unroll
@@ -717,6 +743,13 @@ __global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaPa
 			v[k]     = O::mk (cur[k], cur[8 + k]);
 			v[8 + k] = O::mk (0.f, 0.f);
 		}
+#if PROT_PREFETCH_AT == 0
+		// next block's frames: requested a whole iteration ahead of their use
+		if (it + 1 < n_it) {
+			load_blocks (sP + HOP - Dc, sQ + HOP - Dc);
+		}
+		__builtin_amdgcn_sched_barrier (0);
+#endif
 		// spectrum tables, 4 bins (8 reads) per batch, one batch in flight ahead of the multiplies
 		typedef PROT_LDS_PTR (T) VC;
 		C    hb[2][8];
@@ -752,11 +785,13 @@ __global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaPa
 			__builtin_amdgcn_sched_barrier (0);
 		}
 
+#if PROT_PREFETCH_AT != 0
 		__builtin_amdgcn_sched_barrier (0);
 		if (it + 1 < n_it) {
 			load_blocks (sP + HOP - Dc, sQ + HOP - Dc);
 		}
 		__builtin_amdgcn_sched_barrier (0);
+#endif
 
 		// dry path: from registers ((dry_delay - conv_delay) = 256 * DH frames back) or, for
 		// larger delays, re-read from the stream (L2/MALL)
@@ -792,7 +827,30 @@ __global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaPa
 			acc[8 + j] = (float)v[8 + j].y;
 		}
 
-		if (it >= 2) {
+		// whole blocks (all but a run's last): no per-frame bounds predicates, constant offsets
+		const bool full = (sP + HOP <= eP) && (sQ + HOP <= r1);
+		if (it >= 2 && full && MODE == MODE_ROT && !ACC && !(PROT_ABL2 & 64)) {
+			PROT_GLOBAL S* __restrict__ oP0 = uniform_ptr (out + sP);
+			PROT_GLOBAL S* __restrict__ oP1 = uniform_ptr (out + sP + 1024);
+			PROT_GLOBAL S* __restrict__ oQ0 = uniform_ptr (out + sQ);
+			PROT_GLOBAL S* __restrict__ oQ1 = uniform_ptr (out + sQ + 1024);
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				oP0[(unsigned)t + 256u * k] = (S)(ca * dry[k] + sa * u[k]);
+			}
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				oP1[(unsigned)t + 256u * k] = (S)(ca * dry[4 + k] + sa * u[4 + k]);
+			}
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				oQ0[(unsigned)t + 256u * k] = (S)(ca * dry[8 + k] + sa * u[8 + k]);
+			}
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				oQ1[(unsigned)t + 256u * k] = (S)(ca * dry[12 + k] + sa * u[12 + k]);
+			}
+		} else if (it >= 2) {
 #pragma unroll
 			for (int h = 0; h < 2; ++h) {
 				const int64_t s0  = h ? sQ : sP;
