@@ -647,6 +647,9 @@ __global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaPa
 		}
 	}
 #endif
+#ifdef PROT_CLOCKDBG
+	const uint64_t dbg_c0 = __builtin_readcyclecounter (), dbg_r0 = __builtin_amdgcn_s_memrealtime ();
+#endif
 	const int64_t r1 = (r0 + p.run_frames < p.n_out) ? r0 + p.run_frames : p.n_out;
 	const int64_t Lh = p.run_frames / 2;                      // sub-run length (multiple of HOP)
 	const int64_t eP = (r0 + Lh < r1) ? r0 + Lh : r1;         // sub-run P = [r0, eP), Q = [r0 + Lh, r1)
@@ -875,6 +878,16 @@ __global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaPa
 			}
 		}
 	}
+#ifdef PROT_CLOCKDBG
+	if (t == 0) { // debug build only: per-workgroup timeline into the first output frames (4 words each)
+		const uint64_t dc = __builtin_readcyclecounter () - dbg_c0, r1t = __builtin_amdgcn_s_memrealtime ();
+		uint32_t* d = reinterpret_cast<uint32_t*> (p.out) + 4 * blockIdx.x;
+		d[0] = (uint32_t)dc;
+		d[1] = (uint32_t)dbg_r0;
+		d[2] = (uint32_t)r1t;
+		d[3] = __builtin_amdgcn_s_getreg ((31 << 11) | 4) | (__builtin_amdgcn_s_getreg ((3 << 11) | 20) << 28); // HW_ID, XCC_ID
+	}
+#endif
 }
 
 template <class T, int MODE>
