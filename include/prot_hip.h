@@ -56,19 +56,25 @@ typedef struct {
  * (the literal "one 4096-pt FFT per 1024-frame run()" blocking) instead of two 2048-tap
  * partitions sharing a forward transform.  Same filter, ~1.6x the transforms per frame. */
 #define PROT_CFG_SINGLE_FFT_PER_HOP 1u
+/* FIRs of more than 2049 taps: keep the direct form (2048-tap partitions of the FIR, pairs sharing
+ * a forward transform) instead of the polyphase form (the FIR is zero at every even tap, so the
+ * stream read as complex samples x[2j-1] + i x[2j] is convolved with the odd taps only: half the
+ * partitions, 4096-frame blocks).  Same filter; kept for cross-checks. */
+#define PROT_CFG_DIRECT_FORM 2u
 
 typedef struct {
 	int32_t  kind;
 	uint32_t n_chn;
 	uint32_t fftlen;      /* device OLA FFT length */
-	uint32_t hop;         /* new frames per FFT block */
+	uint32_t hop;         /* new frames per FFT block (polyphase engines: 4096 = 2048 complex samples) */
 	uint32_t firlen;      /* Hilbert FIR taps */
 	uint32_t latency;     /* LV2: latency port value; CLI: blksiz/2 (cli/phase-rotate.cc:963) */
 	uint32_t dry_delay;   /* frames the dry path is delayed by */
 	uint32_t conv_delay;  /* extra delay in front of the FIR */
 	uint32_t history;     /* input frames of state kept per channel */
 	uint32_t blksiz;      /* CLI: parsiz; LV2: reference parsiz (ramp granularity) */
-	uint32_t partitions;  /* FIR partitions of <= fftlen/2 taps convolved per hop (1 if firlen <= 3072) */
+	uint32_t partitions;  /* FIR partitions of <= fftlen/2 taps convolved per hop (polyphase engines: partitions
+	                       * of the odd taps) */
 } prot_info;
 
 typedef struct prot_engine prot_engine;

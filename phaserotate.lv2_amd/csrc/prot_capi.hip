@@ -183,6 +183,8 @@ struct prot_engine {
 	std::vector<float> fir;
 	uint32_t    part_len = 0; // taps per FIR partition
 	bool        use_p2   = false; // two partitions in one launch (frequency-domain delay line)
+	bool        use_poly = false; // polyphase form: partitions of g[s] = fir[2 s + 1], blocks of 4096 frames
+	DevBuf<float2> d_Hd;          // direct-form spectra of a <= 4096-tap FIR for the fp16 sample path (poly engines)
 
 	DevBuf<float2> d_H, d_tw;
 	DevBuf<float>  d_lut, d_rot, d_hist[2], d_peaks, d_in, d_out, d_u, d_inter, d_rot_s;
@@ -227,7 +229,7 @@ int pick_run_frames (const prot_engine* e, uint64_t n_out, int n_chn)
 	// One workgroup per run.  Long streams: fill every resident-workgroup slot of the
 	// chip (CUs x 3, LDS-limited) a whole number of times so no partial last round is
 	// left, with runs long enough (<= 96 pairs) that the halo re-computation stays ~2 %.
-	const int     pair  = 2 * (int)e->info.hop;
+	const int     pair  = e->use_poly ? (int)e->info.hop : 2 * (int)e->info.hop;
 	const int64_t pairs = (int64_t)((n_out + pair - 1) / pair);
 	int64_t       ppr   = 1;
 	if (e->pairs_per_run_override > 0) {
@@ -266,6 +268,19 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 	p.run_frames   = pick_run_frames (e, n_out, n_chn);
 	p.dry_delay    = (int)e->info.dry_delay;
 	p.hilbert_only = hilbert_only ? 1 : 0;
+	if (e->use_poly) {
+		const uint32_t np = std::min<uint32_t> (2, e->info.partitions); // partitions of g per launch
+		for (uint32_t l = 0; l < e->info.partitions / np; ++l) {
+			p.H          = e->d_H.p + (size_t)(np * l) * e->info.fftlen;
+			p.conv_delay = (int)(e->info.conv_delay + np * l * e->info.fftlen); // a partition of g spans 4096 frames
+			p.accumulate = l > 0;
+			hipError_t err = prot::launch_ola_poly (p, (int)np, n_chn, s);
+			if (err != hipSuccess) {
+				return hip_fail (err, "polyphase ola kernel launch");
+			}
+		}
+		return PROT_OK;
+	}
 	if (e->use_p2) {
 		for (uint32_t pair = 0; pair < e->info.partitions / 2; ++pair) {
 			p.H          = e->d_H.p + (size_t)(2 * pair) * e->info.fftlen;
@@ -441,9 +456,26 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	// delayed by 4096 s frames; pairs after the first accumulate into the output.
 	const bool no_p2  = getenv ("PROT_NO_P2") != nullptr || (cfg->flags & PROT_CFG_SINGLE_FFT_PER_HOP);
 	bool       use_p2 = !no_p2 && inf.firlen > F / 2 + 1;
+	// ... and, the Hilbert FIR being zero at every even tap (checked below on the designed taps),
+	// in POLYPHASE form: the stream read as complex samples x[2j-1] + i x[2j] is convolved with
+	// g[s] = fir[2 s + 1] (olapoly_kernel) -- half the taps, blocks of 4096 frames, one launch per
+	// PAIR of 2048-tap partitions of g.  PROT_CFG_DIRECT_FORM keeps the two-partition direct form.
+	std::vector<float> fir_taps;
+	fir_design ((int)inf.firlen, fir_taps);
+	bool use_poly = use_p2 && getenv ("PROT_NO_POLY") == nullptr && !(cfg->flags & PROT_CFG_DIRECT_FORM) &&
+	                inf.firlen % 4 == 0 && inf.conv_delay % 2 == 0;
+	for (uint32_t i = 0; use_poly && i < inf.firlen; i += 2) {
+		use_poly = fir_taps[i] == 0.f;
+	}
 	int        hopseg;
 	uint32_t   n_part, part_len;
-	if (use_p2) {
+	if (use_poly) {
+		part_len = F / 2;                                         // taps of g per partition
+		n_part   = (inf.firlen / 2 + part_len - 1) / part_len;
+		n_part   = n_part > 1 ? (n_part + 1) & ~1u : 1;           // one partition, or whole pairs
+		hopseg   = 16;                                            // 4096 new frames per block
+		use_p2   = false;
+	} else if (use_p2) {
 		part_len = F / 2;
 		n_part   = 2 * ((inf.firlen + F - 1) / F); // whole pairs (a missing last partition is all-zero taps)
 		hopseg   = 8;
@@ -461,6 +493,9 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	inf.partitions = n_part;
 	// history: conv delay (+ partition delays) + the halo the OLA run start reaches back, and the dry delay
 	uint32_t H = inf.conv_delay + (n_part - 1) * part_len + F;
+	if (use_poly) { // every partition of g spans 4096 frames; one more frame for the x[2j-1] of the first sample
+		H = inf.conv_delay + n_part * F + 2;
+	}
 	H          = std::max (H, inf.dry_delay);
 	inf.history = (H + 255) & ~255u;
 
@@ -484,12 +519,13 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	}
 	e->info   = inf;
 	e->device = cfg->device;
-	e->hopseg = hopseg;
-	e->use_p2 = use_p2;
+	e->hopseg   = hopseg;
+	e->use_p2   = use_p2;
+	e->use_poly = use_poly;
 	{
 		int cus = 0;
 		if (hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) {
-			e->wg_slots = cus * (use_p2 ? 2 : 3); // 53 KiB (70 KiB for the p2 kernel) of LDS per workgroup
+			e->wg_slots = cus * ((use_p2 || use_poly) ? 2 : 3); // 53 KiB (70 KiB for the p2 kernel) of LDS per workgroup
 		}
 	}
 	if (const char* o = getenv ("PROT_PAIRS_PER_RUN")) {
@@ -516,18 +552,34 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 
 	// FIR -> spectrum / F (the 1/fftlen of the OLA c2r, cli/phase-rotate.cc:142,
 	// src/phaserotate.c:393, folded into the table)
-	fir_design ((int)inf.firlen, e->fir);
+	e->fir      = fir_taps;
 	e->part_len = part_len;
-	std::vector<float2> H_h ((size_t)F * n_part), tw_h (F);
-	for (uint32_t sp = 0; sp < n_part; ++sp) {
-		std::vector<double> re (F, 0.0), im (F, 0.0);
-		for (uint32_t i = 0; i < part_len && sp * part_len + i < inf.firlen; ++i) {
-			re[i] = e->fir[sp * part_len + i];
+	// spectra / F of the partitions of `taps` (n partitions of plen taps)
+	auto spectra = [&] (const std::vector<float>& taps, uint32_t n, uint32_t plen, std::vector<float2>& dst) {
+		dst.assign ((size_t)F * n, make_float2 (0.f, 0.f));
+		for (uint32_t sp = 0; sp < n; ++sp) {
+			std::vector<double> re (F, 0.0), im (F, 0.0);
+			for (uint32_t i = 0; i < plen && (size_t)sp * plen + i < taps.size (); ++i) {
+				re[i] = taps[(size_t)sp * plen + i];
+			}
+			fft_f64 (re, im);
+			for (uint32_t k = 0; k < F; ++k) {
+				dst[(size_t)sp * F + k] = make_float2 ((float)(re[k] / F), (float)(im[k] / F));
+			}
 		}
-		fft_f64 (re, im);
-		for (uint32_t k = 0; k < F; ++k) {
-			H_h[(size_t)sp * F + k] = make_float2 ((float)(re[k] / F), (float)(im[k] / F));
+	};
+	std::vector<float2> H_h, Hd_h, tw_h (F);
+	if (use_poly) {
+		std::vector<float> g (inf.firlen / 2);
+		for (size_t i = 0; i < g.size (); ++i) {
+			g[i] = fir_taps[2 * i + 1];
 		}
+		spectra (g, n_part, part_len, H_h);
+		if (inf.firlen <= F) { // the fp16 sample path keeps the direct two-partition form
+			spectra (fir_taps, 2, F / 2, Hd_h);
+		}
+	} else {
+		spectra (fir_taps, n_part, part_len, H_h);
 	}
 	for (uint32_t k = 0; k < F; ++k) {
 		const double a = -2.0 * M_PI * (double)k / (double)F;
@@ -535,13 +587,14 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	}
 	const size_t hn = (size_t)inf.history * inf.n_chn;
 	int rc;
-	if ((rc = e->d_H.ensure ((size_t)F * n_part)) || (rc = e->d_tw.ensure (F)) || (rc = e->d_lut.ensure (PROT_MAXSAMPLE * 2)) ||
+	if ((rc = e->d_H.ensure ((size_t)F * n_part)) || (!Hd_h.empty () && (rc = e->d_Hd.ensure (Hd_h.size ()))) || (rc = e->d_tw.ensure (F)) || (rc = e->d_lut.ensure (PROT_MAXSAMPLE * 2)) ||
 	    (rc = e->d_rot.ensure (2 * (size_t)inf.n_chn)) || (rc = e->d_hist[0].ensure (hn)) ||
 	    (rc = e->d_hist[1].ensure (hn)) || (rc = e->d_peaks.ensure ((size_t)PROT_MAXSAMPLE * inf.n_chn)) ||
 	    (rc = e->d_angles.ensure (PROT_MAXSAMPLE + 8))) {
 		return fail (rc);
 	}
-	if (hipMemcpy (e->d_H.p, H_h.data (), H_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess ||
+	if ((!Hd_h.empty () && hipMemcpy (e->d_Hd.p, Hd_h.data (), Hd_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess) ||
+	    hipMemcpy (e->d_H.p, H_h.data (), H_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMemcpy (e->d_tw.p, tw_h.data (), F * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMemcpy (e->d_lut.p, g_lut, sizeof (g_lut), hipMemcpyHostToDevice) != hipSuccess) {
 		return fail (PROT_EHIP);
@@ -575,6 +628,7 @@ void prot_engine_destroy (prot_engine* e)
 		(void)hipStreamSynchronize (e->stream);
 	}
 	e->d_H.release ();
+	e->d_Hd.release ();
 	e->d_tw.release ();
 	e->d_lut.release ();
 	e->d_rot.release ();
@@ -701,7 +755,8 @@ int prot_apply_dev_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uin
 	if (!e || !d_in || !d_out || !rot) {
 		return PROT_EINVAL;
 	}
-	if (e->info.partitions != 1 && !(e->use_p2 && e->info.partitions == 2)) {
+	const bool f16_p2 = (e->use_p2 && e->info.partitions == 2) || (e->use_poly && e->d_Hd.p != nullptr);
+	if (!f16_p2 && (e->use_poly || e->info.partitions != 1)) {
 		return PROT_EUNSUPPORTED;
 	}
 	HIP_TRY (hipSetDevice (e->device));
@@ -720,13 +775,13 @@ int prot_apply_dev_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uin
 	p.out        = (_Float16*)d_out;
 	p.out_stride = out_stride;
 	p.n_out      = (int64_t)n_out;
-	p.H          = e->d_H.p;
+	p.H          = e->use_poly ? e->d_Hd.p : e->d_H.p;
 	p.tw         = e->d_tw.p;
 	p.rot        = e->d_rot.p;
 	p.run_frames = pick_run_frames (e, n_out, nc);
 	p.conv_delay = (int)e->info.conv_delay;
 	p.dry_delay  = (int)e->info.dry_delay;
-	hipError_t err = e->use_p2 ? prot::launch_ola4096_p2_f16 (p, nc, s) : prot::launch_ola4096_f16 (p, e->hopseg, nc, s);
+	hipError_t err = f16_p2 ? prot::launch_ola4096_p2_f16 (p, nc, s) : prot::launch_ola4096_f16 (p, e->hopseg, nc, s);
 	if (err != hipSuccess) {
 		return hip_fail (err, "fp16 ola kernel launch");
 	}

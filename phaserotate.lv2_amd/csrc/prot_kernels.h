@@ -41,6 +41,12 @@ hipError_t launch_ola4096 (const OlaParams& p, int hopseg, int n_chn, hipStream_
 // p.run_frames a multiple of 4096
 hipError_t launch_ola4096_p2 (const OlaParams& p, int n_chn, hipStream_t s);
 
+// polyphase form for FIRs that are zero at every even tap (the Hilbert FIRs of > 2049 taps):
+// p.H = [n_part][4096] spectra of the 2048-tap partitions of g[s] = fir[2 s + 1] (/ 4096),
+// n_part in {1, 2}; p.conv_delay even; (dry_delay - conv_delay)/512 in {3, 4, 8} served from
+// registers, other values re-read the stream; p.run_frames a multiple of 4096
+hipError_t launch_ola_poly (const OlaParams& p, int n_part, int n_chn, hipStream_t s);
+
 // fp16 sample path (BASELINE config 5): half samples in HBM, packed-half butterflies,
 // fp32 overlap-add + rotation.  Stateless, steady rotation.
 hipError_t launch_ola4096_f16 (const OlaParamsH& p, int hopseg, int n_chn, hipStream_t s);

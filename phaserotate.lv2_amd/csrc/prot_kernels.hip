@@ -935,6 +935,316 @@ hipError_t launch_ola4096_p2_f16 (const OlaParamsH& p, int n_chn, hipStream_t s)
 	return launch_p2_t<T16> (p, n_chn, s);
 }
 
+// --------------------------------------------------------------------------------------
+// olapoly_kernel -- FIRs longer than 2049 taps in POLYPHASE form.
+//
+// The Hilbert FIR is zero at every even tap (src/phaserotate.c:374-401, cli/phase-rotate.cc:
+// 128-165: h[n] ~ cot(pi m/N) for odd m = n - N/2 only, N/2 even), so
+//     v[2j]   = sum_s g[s] x[2(j-s) - 1],     v[2j+1] = sum_s g[s] x[2(j-s)],     g[s] = h[2s+1]:
+// even and odd output frames are the SAME half-length filter g applied to the odd resp. even
+// input frames.  Reading the stream as complex samples  z[j] = x[2j-1] + i x[2j]  (a plain
+// reinterpretation of consecutive frames) turns the convolution into ONE complex convolution
+// g * z = v[2j] + i v[2j+1]  -- so the two real signals that ride in the re/im of the complex
+// transform are the two phases of one stream, the filter is half as long (3072 / 4096 taps fit
+// ONE 2048-tap partition: no second spectrum multiply, no delayed spectrum in registers, half
+// the table), and a block is 4096 consecutive frames of one stream (one halo block per run).
+// FIRs of 8192 taps and more take NP = 2 partitions of g per launch (frequency-domain delay
+// line as in ola4096p2_kernel), i.e. half the launches of the direct form.
+// The dry frames (x delayed by dry_delay) pair up as (x[2j], x[2j+1]), one frame off the
+// transform's input pairs, so a thread loads three consecutive frames per sample: p = x[a-1]
+// (dword) and (q, c) = x[a], x[a+1] (one aligned 8-byte load); (p, q) feeds the transform,
+// (q, c) is kept for the dry path -- the stream is still read from HBM once.
+// --------------------------------------------------------------------------------------
+template <int NP, int MODE, int DH, bool ACC>
+__global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
+{
+	typedef T32  T;
+	typedef f2   C;
+	typedef pk32 O;
+	typedef PROT_LDS_PTR (T) VC;
+	constexpr int BLK = 4096; // frames per block = 2048 complex samples
+	static_assert (NP == 1 || NP == 2, "one or two partitions of g per launch");
+	static_assert (DH >= 0 && DH <= 8, "dry delay difference / 512 within one block, or 0");
+	constexpr int NDH = DH > 0 ? DH : 1;
+
+	__shared__ C lds[kLdsRegion];
+	__shared__ C twm[256];
+	__shared__ C Hs[NP][2049];
+
+	const int     t  = threadIdx.x;
+	const int     c  = blockIdx.y;
+	const int64_t r0 = (int64_t)blockIdx.x * p.run_frames;
+	if (r0 >= p.n_out) {
+		return;
+	}
+	const int64_t r1 = (r0 + p.run_frames < p.n_out) ? r0 + p.run_frames : p.n_out;
+
+	const float* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
+	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
+	float* __restrict__ out        = p.out + (int64_t)c * p.out_stride;
+	const int64_t n_in             = p.n_in;
+	const int     Dc = p.conv_delay, Dd = p.dry_delay; // Dc even (host guarantees)
+	// 8-byte alignment of the frame pairs (block starts and Dc are even): uniform per workgroup
+	const bool in_al8  = (reinterpret_cast<uintptr_t> (in) & 7) == 0;
+	const bool out_al8 = (reinterpret_cast<uintptr_t> (out) & 7) == 0;
+
+	const f2* __restrict__ twp = reinterpret_cast<const f2*> (p.tw);
+	C tw1[16];
+#pragma unroll
+	for (int k = 1; k < 16; ++k) {
+		tw1[k] = twp[(t * k) & 4095];
+	}
+	twm[t] = twp[16 * (((t & 15) * (t >> 4)) & 255)];
+	for (int i = t; i <= 2048; i += 256) {
+		const int j = swap_lo_digits (i);
+#pragma unroll
+		for (int pp = 0; pp < NP; ++pp) {
+			Hs[pp][j] = reinterpret_cast<const f2*> (p.H)[pp * 4096 + i];
+		}
+	}
+	float ca = 0.f, sa = 1.f;
+	if (MODE == MODE_ROT) {
+		ca = p.rot[2 * c];
+		sa = p.rot[2 * c + 1];
+	}
+
+	const int tl = t & 15, th = t >> 4;
+	const int q  = th + 16 * tl;
+	const int mq = q == 0 ? 256 : swap_lo_digits (256 - q); // mirrored bin of (th + 16 tl + 256 k), k >= 8
+	const int n_it = NP + (int)((r1 - r0 + BLK - 1) / BLK);  // NP halo blocks: OLA tail (+ X_{b-1})
+	int64_t   s    = r0 - (int64_t)NP * BLK;
+
+	C acc[8], zp[NP == 2 ? 16 : 1];
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		acc[i] = mkf2 (0.f, 0.f);
+	}
+#pragma unroll
+	for (int i = 0; i < (NP == 2 ? 16 : 1); ++i) {
+		zp[i] = mkf2 (0.f, 0.f);
+	}
+	// (q, c) pairs of the DH sample rows in front of the current block: the dry path's source
+	f2 dh[NDH];
+#pragma unroll
+	for (int i = 0; i < NDH; ++i) {
+		const int64_t a = s - Dc + 2 * (int64_t)(t + 256 * (i - DH));
+		dh[i]           = DH > 0 ? mkf2 (ldv (in, n_in, hist, p.hist_len, a), ldv (in, n_in, hist, p.hist_len, a + 1)) : mkf2 (0.f, 0.f);
+	}
+
+	// frames a-1 | a, a+1 of sample j = t + 256 k, a = a0 + 2 j
+	float nxp[8];
+	f2    nxqc[8];
+	auto  load_block = [&] (int64_t a0) {
+		const bool fast = (a0 - 1 >= 0) && (a0 + BLK <= n_in);
+		if (fast && in_al8) {
+#pragma unroll
+			for (int m = 0; m < 4; ++m) { // one SGPR base per 1024 frames: the immediate offset reaches 4 KiB
+				const PROT_GLOBAL float* __restrict__ b = uniform_ptr (in + a0 + 1024 * m);
+#pragma unroll
+				for (int e = 0; e < 2; ++e) {
+					nxqc[2 * m + e] = reinterpret_cast<const PROT_GLOBAL f2*> (b)[(unsigned)t + 256u * e];
+					nxp[2 * m + e]  = (b - 1)[2u * (unsigned)t + 512u * e];
+				}
+			}
+		} else if (fast) {
+#pragma unroll
+			for (int m = 0; m < 4; ++m) {
+				const PROT_GLOBAL float* __restrict__ b = uniform_ptr (in + a0 + 1024 * m);
+#pragma unroll
+				for (int e = 0; e < 2; ++e) {
+					nxp[2 * m + e]  = (b - 1)[2u * (unsigned)t + 512u * e];
+					nxqc[2 * m + e] = mkf2 (b[2u * (unsigned)t + 512u * e], (b + 1)[2u * (unsigned)t + 512u * e]);
+				}
+			}
+		} else {
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				const int64_t a = a0 + 2 * (int64_t)(t + 256 * k);
+				nxp[k]          = ldv (in, n_in, hist, p.hist_len, a - 1);
+				nxqc[k]         = mkf2 (ldv (in, n_in, hist, p.hist_len, a), ldv (in, n_in, hist, p.hist_len, a + 1));
+			}
+		}
+	};
+	load_block (s - Dc);
+	__syncthreads ();
+
+	for (int it = 0; it < n_it; ++it, s += BLK) {
+		C  v[16];
+		f2 cur[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			cur[k]   = nxqc[k];
+			v[k]     = mkf2 (nxp[k], nxqc[k].x);
+			v[8 + k] = mkf2 (0.f, 0.f);
+		}
+
+		// spectrum tables, HB bins per batch, one batch in flight ahead of the multiplies
+		constexpr int HB = 4;
+		C             hb[2][NP * HB];
+		auto          h_fetch = [&] (int j) {
+#pragma unroll
+			for (int i = 0; i < HB; ++i) {
+				const int k   = HB * j + i;
+				const int idx = k < 8 ? t + 256 * k : 256 * (15 - k) + mq;
+#pragma unroll
+				for (int pp = 0; pp < NP; ++pp) {
+					hb[j & 1][pp * HB + i] = ((const VC*)Hs[pp])[idx];
+				}
+			}
+		};
+		fwd4096w<T, 8> (v, lds, twm, tw1, t, tl, th, [&] () { h_fetch (0); });
+
+		// Y = Z G0 (+ Z_prev G1); bins >= 2048 use the conjugate of the mirrored bin
+#pragma unroll
+		for (int j = 0; j < 16 / HB; ++j) {
+			if (j + 1 < 16 / HB) {
+				h_fetch (j + 1);
+			}
+			__builtin_amdgcn_sched_barrier (0);
+			if (NP == 1) {
+#pragma unroll
+				for (int i = 0; i < HB; i += 2) {
+					const int k = HB * j + i;
+					if (k < 8) {
+						O::template cmul2<1> (v[k], hb[j & 1][i], v[k + 1], hb[j & 1][i + 1]);
+					} else {
+						O::template cmul2<-1> (v[k], hb[j & 1][i], v[k + 1], hb[j & 1][i + 1]);
+					}
+				}
+			} else {
+#pragma unroll
+				for (int i = 0; i < HB; ++i) {
+					const int k = HB * j + i;
+					const C   z = v[k];
+					if (k < 8) {
+						v[k] = O::template cmul_acc<1> (O::template cmul<1> (z, hb[j & 1][i]), zp[k], hb[j & 1][HB + i]);
+					} else {
+						v[k] = O::template cmul_acc<-1> (O::template cmul<-1> (z, hb[j & 1][i]), zp[k], hb[j & 1][HB + i]);
+					}
+					zp[NP == 2 ? k : 0] = z;
+				}
+			}
+			__builtin_amdgcn_sched_barrier (0);
+		}
+
+		__builtin_amdgcn_sched_barrier (0);
+		if (it + 1 < n_it) {
+			load_block (s + BLK - Dc);
+		}
+		__builtin_amdgcn_sched_barrier (0);
+
+		// dry path: frames (s + 2j - Dd, s + 2j + 1 - Dd) = the (q, c) pair DH sample rows back
+		f2 dry[8];
+		if (DH > 0) {
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				dry[k] = (k >= DH) ? cur[k >= DH ? k - DH : 0] : dh[k < DH ? k : 0];
+			}
+#pragma unroll
+			for (int i = 0; i < NDH; ++i) {
+				dh[i] = cur[8 - NDH + i];
+			}
+		} else if (MODE != MODE_HILBERT && !ACC && it >= NP) {
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				const int64_t d0 = s + 2 * (int64_t)(t + 256 * k) - Dd;
+				dry[k]           = mkf2 (ldv (in, n_in, hist, p.hist_len, d0), ldv (in, n_in, hist, p.hist_len, d0 + 1));
+			}
+		}
+
+		inv4096w<T> (v, lds, twm, tw1, t, tl, th);
+
+		C u[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			u[k]   = acc[k] + v[k];
+			acc[k] = v[8 + k];
+		}
+
+		if (it >= NP) {
+			const bool full = s + BLK <= r1;
+			if (MODE == MODE_ROT && !ACC && full && out_al8) {
+				const f2 ca2 = mkf2 (ca, ca), sa2 = mkf2 (sa, sa);
+#pragma unroll
+				for (int m = 0; m < 4; ++m) {
+					PROT_GLOBAL f2* __restrict__ ob = reinterpret_cast<PROT_GLOBAL f2*> (uniform_ptr (out + s + 1024 * m));
+#pragma unroll
+					for (int e = 0; e < 2; ++e) {
+						ob[(unsigned)t + 256u * e] = ca2 * dry[2 * m + e] + sa2 * u[2 * m + e];
+					}
+				}
+			} else {
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+#pragma unroll
+					for (int h = 0; h < 2; ++h) {
+						const int64_t pos = s + 2 * (int64_t)(t + 256 * k) + h;
+						const float   uu  = h ? u[k].y : u[k].x;
+						if (pos < r1) {
+							if (MODE == MODE_HILBERT) {
+								out[pos] = ACC ? out[pos] + uu : uu;
+							} else {
+								float cc = ca, ss = sa;
+								if (MODE == MODE_RAMP) {
+									const f2 cs = reinterpret_cast<const f2*> (p.rot_s)[(int64_t)c * p.n_out + pos];
+									cc          = cs.x;
+									ss          = cs.y;
+								}
+								out[pos] = ACC ? out[pos] + ss * uu : cc * (h ? dry[k].y : dry[k].x) + ss * uu;
+							}
+						}
+					}
+				}
+			}
+		}
+	}
+}
+
+template <int NP, int MODE>
+static hipError_t launch_poly_m (const OlaParams& p, dim3 grid, hipStream_t s)
+{
+	const int  diff = p.dry_delay - p.conv_delay;
+	const int  dd   = (diff > 0 && diff % 512 == 0) ? diff / 512 : 0;
+	const dim3 block (256);
+	if (p.accumulate) {
+		hipLaunchKernelGGL ((olapoly_kernel<NP, MODE, 0, true>), grid, block, 0, s, p);
+	} else if (MODE != MODE_HILBERT && dd == 3) {
+		hipLaunchKernelGGL ((olapoly_kernel<NP, MODE, 3, false>), grid, block, 0, s, p);
+	} else if (MODE != MODE_HILBERT && dd == 4) {
+		hipLaunchKernelGGL ((olapoly_kernel<NP, MODE, 4, false>), grid, block, 0, s, p);
+	} else if (MODE != MODE_HILBERT && dd == 8) {
+		hipLaunchKernelGGL ((olapoly_kernel<NP, MODE, 8, false>), grid, block, 0, s, p);
+	} else {
+		hipLaunchKernelGGL ((olapoly_kernel<NP, MODE, 0, false>), grid, block, 0, s, p);
+	}
+	return hipGetLastError ();
+}
+
+template <int NP>
+static hipError_t launch_poly_n (const OlaParams& p, int n_chn, hipStream_t s)
+{
+	if (p.n_out <= 0) {
+		return hipSuccess;
+	}
+	const int64_t runs = (p.n_out + p.run_frames - 1) / p.run_frames;
+	dim3          grid ((unsigned)runs, (unsigned)n_chn);
+	if (p.hilbert_only) {
+		return launch_poly_m<NP, MODE_HILBERT> (p, grid, s);
+	}
+	if (p.rot_s != nullptr) {
+		return launch_poly_m<NP, MODE_RAMP> (p, grid, s);
+	}
+	return launch_poly_m<NP, MODE_ROT> (p, grid, s);
+}
+
+hipError_t launch_ola_poly (const OlaParams& p, int n_part, int n_chn, hipStream_t s)
+{
+	if ((p.conv_delay & 1) || (p.run_frames % 4096) != 0 || (n_part != 1 && n_part != 2)) {
+		return hipErrorInvalidValue;
+	}
+	return n_part == 1 ? launch_poly_n<1> (p, n_chn, s) : launch_poly_n<2> (p, n_chn, s);
+}
+
 // PROT_OLA_VARIANT (debug/tuning only): 0 = default
 static int ola_variant ()
 {

@@ -122,18 +122,21 @@ def test_lv2_run_stream(pkg, rate, bufsize, angle, n_chn):
     g.close()
 
 
-def test_lv2_single_fft_per_hop_geometry_matches_two_partition_geometry(pkg):
-    """LV2 48 kHz filter: one zero-padded 4096-pt FFT per 1024-frame hop (flag) vs two
-    2048-tap partitions sharing a forward transform (default) -- same LTI filter."""
+def test_lv2_three_device_geometries_are_the_same_filter(pkg):
+    """LV2 48 kHz filter in the three device forms: polyphase (default: the odd taps on the
+    stream read as complex samples, one 2048-tap partition, 4096-frame blocks), direct form
+    with two 2048-tap partitions sharing a forward transform, and one zero-padded 4096-pt FFT
+    per 1024-frame hop -- same LTI filter."""
     import torch
     dev = torch.device("cuda:0")
-    n = 300000
+    n = 300001  # odd: the last complex sample of the polyphase form is half outside
     x = torch.from_numpy(xorshift_uniform(n, seed=31)).to(dev)
     rot = np.array([0.28, -0.96], np.float32)
     ys = []
-    for flags in (0, pkg.CFG_SINGLE_FFT_PER_HOP):
+    want = {0: (1, 4096), pkg.CFG_DIRECT_FORM: (2, 2048), pkg.CFG_SINGLE_FFT_PER_HOP: (1, 1024)}
+    for flags in want:
         e = pkg.Engine(pkg.KIND_LV2, 48000, 1, flags=flags)
-        assert (e.info.partitions, e.info.hop) == ((2, 2048) if flags == 0 else (1, 1024))
+        assert (e.info.partitions, e.info.hop) == want[flags]
         y = torch.empty_like(x)
         torch.cuda.synchronize()
         e.apply_dev(x.data_ptr(), n, n, y.data_ptr(), n, n, rot, pkg.F_STATELESS)
@@ -141,6 +144,45 @@ def test_lv2_single_fft_per_hop_geometry_matches_two_partition_geometry(pkg):
         ys.append(y)
         e.close()
     assert (ys[0] - ys[1]).abs().max().item() < TOL
+    assert (ys[0] - ys[2]).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("kind,param", [(1, 96000), (1, 192000), (0, 4096), (0, 8192), (0, 16384)])
+def test_polyphase_equals_direct_form(pkg, kind, param):
+    """Every FIR of more than 2049 taps, polyphase vs direct form, on misaligned (odd-offset)
+    stereo streams, stateless and stateful in uneven chunks."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, stride = 150001, 150003            # odd stride: channel 1 starts 4 bytes off an 8-byte boundary
+    xb = torch.from_numpy(xorshift_uniform(2 * stride + 1, seed=7)).to(dev)
+    x = xb[1:]                            # channel 0 misaligned too
+    rot = np.array([0.6, 0.8, -0.8, 0.6], np.float32)
+    res = []
+    for flags in (0, pkg.CFG_DIRECT_FORM):
+        e = pkg.Engine(kind, param, 2, flags=flags)
+        yb = torch.zeros(2 * stride + 1, device=dev)
+        y = yb[1:]
+        torch.cuda.synchronize()
+        e.apply_dev(x.data_ptr(), stride, n, y.data_ptr(), stride, n, rot, pkg.F_STATELESS)
+        e.sync()
+        # the same stream in uneven stateful chunks (history carried between calls)
+        zb = torch.zeros(2 * stride + 1, device=dev)
+        z = zb[1:]
+        pos = 0
+        for m in (1, 4095, 4097, 50000, n):
+            m = min(m, n - pos)
+            if m <= 0:
+                break
+            e.apply_dev(x.data_ptr() + 4 * pos, stride, m, z.data_ptr() + 4 * pos, stride, m, rot, 0)
+            pos += m
+        e.sync()
+        res.append((y[:n].clone(), y[stride:stride + n].clone(), z[:n].clone(), z[stride:stride + n].clone()))
+        e.close()
+    for a, b in zip(res[0], res[1]):
+        assert (a - b).abs().max().item() < TOL
+    # stateful == one-shot within one form
+    assert (res[0][0] - res[0][2]).abs().max().item() < TOL
+    assert (res[0][1] - res[0][3]).abs().max().item() < TOL
 
 
 def test_lv2_angle_change_mid_stream(pkg):
