@@ -35,6 +35,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--preroll", type=int, default=30,
+                    help="untimed launches of the same step BEFORE the W warmup steps of every timed line: the first "
+                         "measurement in a fresh process otherwise runs ~15%% slow (clock ramp; see DESIGN.md section 5). "
+                         "0 = cold figures")
     ap.add_argument("--frames-log2", type=int, default=27, help="frames per GPU per step (2^k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
@@ -122,6 +126,8 @@ def main():
         def step():
             engine.apply_dev(x.data_ptr(), n_frames, n_frames, y.data_ptr(), n_frames, n_frames, rot,
                              pkg.F_STATELESS, st)
+        for _ in range(args.preroll):  # disclosed in the JSON line as preroll_steps
+            step()
         for _ in range(warmup):
             step()
         ev0 = torch.cuda.Event(enable_timing=True)
@@ -156,10 +162,11 @@ def main():
     out = {
         "metric": "mono-sample frames/s through 4096-pt OLA phase-rotate",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": wall / args.steps * 1e3, "preroll_steps": args.preroll,
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "LV2 mono 48 kHz: 3072-tap Hilbert FIR (latency 1792), 4096-pt OLA, two 2048-tap "
-                               "partitions sharing one forward FFT per 2048-frame hop, angle 90 deg, "
+        "config": {"workload": "LV2 mono 48 kHz: 3072-tap Hilbert FIR (latency 1792), 4096-pt OLA in polyphase form "
+                               "(odd taps on the stream read as complex samples, 4096-frame blocks), angle 90 deg, "
                                "device-resident stream of 2^%d frames per GPU per step" % args.frames_log2,
                    "partitions": int(eng.info.partitions),
                    "fftlen": int(eng.info.fftlen), "hop": int(eng.info.hop), "firlen": int(eng.info.firlen),
@@ -167,13 +174,29 @@ def main():
                    "parallelism": "independent streams x%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "prot::ola4096p2_kernel<0, 6> (steady rotation, dry path from registers, "
-                               "packed-fp32 butterflies)", "kernel_ms": kern_ms,
+                     "kernel": "prot::olapoly_kernel<1, 0, 3, false> (one partition of the odd taps, steady rotation, "
+                               "dry path from registers, packed-fp32 butterflies)", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": bytes_per_launch},
     }
     eng.close()
 
     if not args.no_extra:
+        # same filter, direct form: two 2048-tap partitions sharing one forward FFT per 2048-frame hop
+        eng2 = pkg.Engine(pkg.KIND_LV2, 48000, 1, device=local_rank, flags=pkg.CFG_DIRECT_FORM)
+        wall2, kms2 = timed(eng2, args.steps, args.warmup, n)
+        out["direct_form"] = {
+            "workload": "LV2 mono 48 kHz filter, direct form: two 2048-tap partitions, frequency-domain delay line (ola4096p2_kernel)",
+            "value": world * n * args.steps / wall2, "unit": "frames/s",
+            "roofline_frac": 8.0 * n / (kms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": kms2}
+        eng2.close()
+        # CLI default block size at 48 kHz (8192-tap FIR): one polyphase launch with two partitions
+        eng3 = pkg.Engine(pkg.KIND_CLI, 8192, 1, device=local_rank)
+        wall3, kms3 = timed(eng3, args.steps, args.warmup, n)
+        out["cli_8192"] = {
+            "workload": "CLI engine blksiz 8192 (8192-tap FIR): polyphase, two 2048-tap partitions of the odd taps in one launch",
+            "value": world * n * args.steps / wall3, "unit": "frames/s",
+            "roofline_frac": 8.0 * n / (kms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": kms3}
+        eng3.close()
         # same filter, literal blocking: one zero-padded 4096-pt FFT per 1024-frame hop
         eng1 = pkg.Engine(pkg.KIND_LV2, 48000, 1, device=local_rank, flags=pkg.CFG_SINGLE_FFT_PER_HOP)
         wall1, kms1 = timed(eng1, args.steps, args.warmup, n)
@@ -238,7 +261,7 @@ def main():
 
 def bench_cfg3(args, pkg, torch, np, dev, ts, st, local_rank, barrier, world):
     """BASELINE config 3: LV2 stereo, the 96 kHz filter (4096 taps; an 8192-pt FFT in the
-    reference's terms, two 4096-pt FIR partitions here), 256 buffers of 1024 frames batched
+    reference's terms; here the 2048 odd taps in one polyphase partition), 256 buffers of 1024 frames batched
     per launch (2 x 1 MiB in, 2 x 1 MiB out), back-to-back stateful launches on one stream."""
     n_chn, nbuf, bs = 2, 256, 1024
     n = nbuf * bs
@@ -261,7 +284,7 @@ def bench_cfg3(args, pkg, torch, np, dev, ts, st, local_rank, barrier, world):
     barrier()
     ms = e0.elapsed_time(e1) / launches
     eng.close()
-    return {"workload": "LV2 stereo, 96 kHz filter (4096 taps = 2 FIR partitions of the 4096-pt kernel), "
+    return {"workload": "LV2 stereo, 96 kHz filter (4096 taps = one polyphase partition of the 4096-pt kernel), "
                         "256 x 1024-frame buffers per channel per launch, stateful back-to-back launches",
             "value": world * n_chn * n / (ms * 1e-3), "unit": "channel-frames/s", "ms_per_launch": ms,
             "roofline_frac": 8.0 * n_chn * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
