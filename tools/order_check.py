@@ -1,6 +1,8 @@
-# Discriminate "slow first measurement" from "poly genuinely slower": interleave, many repetitions, no discarding.
-import sys, time
-sys.path.insert(0, "/root/repo")
+"""Interleaved A/B of the polyphase and direct forms of the 48 kHz and 96 kHz LV2 filters in ONE process:
+R rounds, each round times every variant (20 launches after 3 untimed), order rotated per round.
+Prints median / min / max per variant -- the spread is the run-to-run noise any comparison has to beat."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from __graft_entry__ import load_package
 pkg = load_package()
@@ -9,7 +11,9 @@ n = 1 << 27
 x = (torch.rand(n, device=dev) - 0.5); y = torch.empty_like(x)
 rot = np.array([0.0, -1.0], np.float32)
 ts = torch.cuda.Stream(); torch.cuda.set_stream(ts); st = ts.cuda_stream
-engs = {"poly": pkg.Engine(pkg.KIND_LV2, 48000, 1, flags=0), "direct": pkg.Engine(pkg.KIND_LV2, 48000, 1, flags=pkg.CFG_DIRECT_FORM)}
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+engs = {"poly48": pkg.Engine(pkg.KIND_LV2, 48000, 1, flags=0), "direct48": pkg.Engine(pkg.KIND_LV2, 48000, 1, flags=pkg.CFG_DIRECT_FORM),
+        "poly96": pkg.Engine(pkg.KIND_LV2, 96000, 1, flags=0), "direct96": pkg.Engine(pkg.KIND_LV2, 96000, 1, flags=pkg.CFG_DIRECT_FORM)}
 def run(e, k):
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
@@ -17,7 +21,14 @@ def run(e, k):
         e.apply_dev(x.data_ptr(), n, n, y.data_ptr(), n, n, rot, pkg.F_STATELESS, st)
     ev1.record(); torch.cuda.synchronize()
     return ev0.elapsed_time(ev1) / k
-# cold first: exactly what bench.py does for the headline (3 warmup + 20 timed), on a fresh process
-for name in ("poly", "direct", "poly", "direct", "direct", "poly"):
-    w = run(engs[name], 3); t = run(engs[name], 20)
-    print("%-7s warmup-avg %.4f ms  timed-avg %.4f ms" % (name, w, t), flush=True)
+for e in engs.values():
+    run(e, 30)  # clock ramp, discarded for every variant alike
+names = list(engs)
+res = {k: [] for k in names}
+for r in range(R):
+    for name in names[r % len(names):] + names[:r % len(names)]:
+        run(engs[name], 3)
+        res[name].append(run(engs[name], 20))
+for name in names:
+    v = np.array(res[name])
+    print("%-9s median %.4f  min %.4f  max %.4f  (n=%d)" % (name, np.median(v), v.min(), v.max(), len(v)))
