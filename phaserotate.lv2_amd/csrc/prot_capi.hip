@@ -995,8 +995,13 @@ int prot_lv2_run (prot_engine* e, const float* const* in, float* const* out, uin
 	hipStream_t    s  = e->stream;
 
 	int rc;
-	if ((rc = e->h_io.ensure (n * nc * 4)) || (rc = e->d_in.ensure (n * nc)) || (rc = e->d_out.ensure (n * nc)) ||
-	    (rc = e->d_rot_s.ensure (2 * n * nc))) {
+	// Zero-copy (default): the kernels read the input, the per-frame rotation and write the output
+	// straight from / to the pinned host block over the host link -- a run() call is two kernel
+	// launches and one stream sync, no copy commands.  PROT_LV2_STAGED=1 keeps the staged route
+	// (H2D copies -> device buffers -> D2H copy) for comparison.
+	static const bool staged = getenv ("PROT_LV2_STAGED") != nullptr;
+	if ((rc = e->h_io.ensure (n * nc * 4 + 2 * (size_t)nc)) ||
+	    (staged && ((rc = e->d_in.ensure (n * nc)) || (rc = e->d_out.ensure (n * nc)) || (rc = e->d_rot_s.ensure (2 * n * nc))))) {
 		return rc;
 	}
 	float* h_in  = e->h_io.p;
@@ -1074,6 +1079,31 @@ int prot_lv2_run (prot_engine* e, const float* const* in, float* const* out, uin
 		}
 	}
 
+	if (!staged) {
+		const float* d_rot_c = nullptr;
+		if (steady) {
+			float* h_rotc = e->h_io.p + 4 * n * nc; // [nc][2]
+			for (uint32_t c = 0; c < nc; ++c) {
+				h_rotc[2 * c]     = h_rot[2 * n * c];
+				h_rotc[2 * c + 1] = h_rot[2 * n * c + 1];
+			}
+			d_rot_c = h_rotc;
+		}
+		rc = ola_launch (e, h_in, (int64_t)n, n, h_out, (int64_t)n, n, d_rot_c, steady ? nullptr : h_rot, false, false, 0, (int)nc, s);
+		if (rc) {
+			return rc;
+		}
+		rc = hist_advance (e, h_in, (int64_t)n, n, 0, (int)nc, s);
+		e->pos += n;
+		if (rc) {
+			return rc;
+		}
+		HIP_TRY (hipStreamSynchronize (s));
+		for (uint32_t c = 0; c < nc; ++c) {
+			memcpy (out[c], h_out + c * n, n * sizeof (float));
+		}
+		return PROT_OK;
+	}
 	HIP_TRY (hipMemcpyAsync (e->d_in.p, h_in, n * nc * sizeof (float), hipMemcpyHostToDevice, s));
 	if (steady) {
 		float rot[2 * 64];

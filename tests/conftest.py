@@ -18,6 +18,22 @@ def pkg():
     return load_package()
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _one_hip_runtime():
+    """Test-order independence: PyTorch bundles its own HIP runtime, and whichever runtime initialises
+    the GPU first owns it.  A test that dlopens a C front end (phaserotate.so -> libprot_hip.so) before
+    any torch test ran would bind /opt/rocm's runtime, and every later torch.cuda call in the process
+    then fails with "No HIP GPUs are available" (seen when test_host_frontends.py ran before
+    test_gpu_parity.py).  Loading the library through the package first preloads torch's runtime
+    (phaserotate.lv2_amd.__init__._share_hip_runtime_with_torch), whatever the order of the tests."""
+    try:
+        from __graft_entry__ import load_package
+        load_package().load_library()
+    except Exception:
+        pass  # library not built: the tests that need it report that themselves
+    yield
+
+
 def xorshift_uniform(n, seed=1):
     """The documented synthetic input: 32-bit xorshift -> uniform [-0.5, 0.5) float32
     (SURVEY.md section 8d)."""
