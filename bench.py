@@ -247,6 +247,7 @@ def main():
         out["lv2_stereo_batched"] = bench_cfg3(args, pkg, torch, np, dev, ts, st, local_rank, barrier, world)
         if rank == 0:
             out["lv2_run_host"] = bench_run_host(pkg, np, local_rank)
+            out["cli_file_host"] = bench_file_host(pkg, np, local_rank)
 
     if not args.no_sweep:
         out["sweep"] = bench_sweep(args, pkg, torch, dist, dev, st, world, rank, local_rank, barrier)
@@ -310,6 +311,41 @@ def bench_run_host(pkg, np, local_rank):
     return {"workload": "prot_lv2_run, mono 48 kHz, 1024-frame host buffers (zero-copy pinned host block: OLA kernel + "
                         "history kernel + stream sync per call, ctypes call overhead included)",
             "us_per_run": dt * 1e6, "frames_per_s": 1024 / dt, "realtime_factor_48k": 1024 / dt / 48000.0}
+
+
+def bench_file_host(pkg, np, local_rank):
+    """The CLI's whole-file calls on HOST buffers (pageable numpy memory, as a file reader hands them
+    over): prot_cli_apply_file = upload + de-interleave + OLA + interleave + download, and
+    prot_cli_analyze_file = upload + de-interleave + Hilbert pass + 15-angle coarse sweep + reading the
+    peak table back.  Host-link-inclusive; never `value`.  Bounded: 2^24 stereo frames (128 MiB each way).
+    The output array is allocated and touched BEFORE the timed region: a fresh np.zeros per call costs
+    12 ms of page faults here, 3x the call itself (tools/hostlink_probe.py)."""
+    n, nc, P = 1 << 24, 2, 8192
+    x = (np.random.default_rng(5).random(n * nc, dtype=np.float32) - 0.5)
+    out = np.ones_like(x)
+    pr = pkg.PhaseRotate(P, nc, device=local_rank)
+    pr.apply_file(x[: P * nc * 4], [90, -90])  # allocate staging once
+
+    def med(f, k=5):
+        ts = []
+        for _ in range(k):
+            t0 = time.perf_counter()
+            f()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[k // 2]
+
+    def ana():
+        pr.reset()
+        pr.analyze_file(x, 0, 360, 24)
+        pr.peak_all(0)
+    ta = med(lambda: pr.apply_file(x, [90, -90], out=out))
+    tn = med(ana)
+    pr.close()
+    return {"workload": "CLI blksiz 8192, stereo, 2^24 frames from/to pageable host memory (median of 5, output "
+                        "buffer pre-touched)",
+            "apply_file_ms": ta * 1e3, "apply_file_channel_frames_per_s": n * nc / ta,
+            "apply_file_host_GBps_each_way": n * nc * 4 / ta / 1e9,
+            "analyze_file_ms": tn * 1e3, "analyze_file_channel_frames_per_s": n * nc / tn}
 
 
 def bench_sweep(args, pkg, torch, dist, dev, st, world, rank, local_rank, barrier):

@@ -263,9 +263,11 @@ class PhaseRotate(Engine):
         _check(self._lib.prot_cli_analyze_file(self._h, data, data.size // self.n_chn, ang_start,
                                                ang_end, ang_stride, chn), "prot_cli_analyze_file")
 
-    def apply_file(self, data, angles):
+    def apply_file(self, data, angles, out=None):
         data = np.ascontiguousarray(data, np.float32).reshape(-1)
-        out = np.zeros_like(data)
+        if out is None:
+            out = np.zeros_like(data)
+        assert out.dtype == np.float32 and out.size == data.size and out.flags["C_CONTIGUOUS"]
         _check(self._lib.prot_cli_apply_file(self._h, data, data.size // self.n_chn,
                                              np.ascontiguousarray(angles, np.int32), out),
                "prot_cli_apply_file")
