@@ -195,11 +195,7 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 		if (PK) {
 			pk_fft16_fwd_pruned<HOPSEG> (v);
 		} else {
-			if (PK) {
-			pk_fft16<1> (v);
-		} else {
 			fft16<1> (v);
-		}
 		}
 #pragma unroll
 		for (int k = 1; k < 16; ++k) {
@@ -637,16 +633,6 @@ __global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaPa
 	if (r0 >= p.n_out) {
 		return;
 	}
-#ifdef PROT_PHASE_SLEEP
-	// HW_ID[3:0] = wave slot on the SIMD: co-resident workgroups differ in it
-	if (PROT_PHASE_SHIFT < 0 ? (__builtin_amdgcn_s_getreg (((4 - 1) << 11) | 4) & 1)
-	                         : (((blockIdx.x + gridDim.x * blockIdx.y) >> PROT_PHASE_SHIFT) & 1)) {
-#pragma unroll
-		for (int i = 0; i < PROT_PHASE_REP; ++i) {
-			__builtin_amdgcn_s_sleep (PROT_PHASE_SLEEP);
-		}
-	}
-#endif
 #ifdef PROT_CLOCKDBG
 	const uint64_t dbg_c0 = __builtin_readcyclecounter (), dbg_r0 = __builtin_amdgcn_s_memrealtime ();
 #endif
