@@ -200,6 +200,15 @@ int prot_cli_peaks (prot_engine* e, float* out);
 /* DEVICE pointer of the engine's own table (for an external MAX all-reduce) */
 float* prot_cli_peaks_dev (prot_engine* e);
 
+/* How much of the sweep the engine had to evaluate since the last reset.  The per-angle abs-max
+ * (calc_rotated_peak, cli/phase-rotate.cc:98-121) is bounded by r = sqrt(dry^2 + hilbert^2) for
+ * every angle, so groups of 256 frames whose r stays below a lower bound of every final peak are
+ * skipped -- the table is bit-identical to evaluating everything.  `seen` counts (wave, group)
+ * pairs offered, `evaluated` those that went through the full per-angle evaluation; the ratio is
+ * signal-dependent (stationary material: small; a signal that keeps growing: 1).  Work on the
+ * engine's own stream is awaited first; launches on a caller's stream are the caller's to await. */
+int prot_sweep_stats (prot_engine* e, uint64_t* evaluated, uint64_t* seen);
+
 /* ---- several GPUs of one node, single process --------------------------- */
 /* MAX all-reduce of the engines' OWN peak tables (prot_cli_peaks_dev) across
  * their GPUs: one ncclAllReduce(ncclMax, float[n_chn][360]) per engine inside

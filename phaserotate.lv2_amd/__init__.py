@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     "prot_apply_dev", "prot_apply_dev_ramp", "prot_apply_dev_f16", "prot_sweep_dev",
     "prot_lv2_run", "prot_lv2_get_angle", "prot_cli_apply", "prot_cli_analyze", "prot_cli_analyze_file",
     "prot_cli_apply_file", "prot_cli_peak", "prot_cli_peak_all", "prot_cli_peaks",
-    "prot_cli_peaks_dev", "prot_allreduce_peaks", "prot_cli_analyze_file_multi",
+    "prot_cli_peaks_dev", "prot_allreduce_peaks", "prot_cli_analyze_file_multi", "prot_sweep_stats",
 )
 
 
@@ -111,6 +111,7 @@ def load_library():
     lib.prot_lv2_run.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                  C.c_uint32, _f32p]
     lib.prot_lv2_get_angle.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
+    lib.prot_sweep_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.prot_cli_apply.argtypes = [C.c_void_p, _f32p, _i32p]
     lib.prot_cli_analyze.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.prot_cli_analyze_file.argtypes = [C.c_void_p, _f32p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -203,6 +204,12 @@ class Engine:
     def apply_dev_ramp(self, d_in, in_stride, n_in, d_out, out_stride, n_out, d_rot, flags=0, stream=0):
         _check(self._lib.prot_apply_dev_ramp(self._h, d_in, in_stride, n_in, d_out, out_stride,
                                              n_out, d_rot, flags, stream), "prot_apply_dev_ramp")
+
+    def sweep_stats(self):
+        """(evaluated, seen) tile groups of the sweep since the last reset (prot_sweep_stats)."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(self._lib.prot_sweep_stats(self._h, C.byref(a), C.byref(b)), "prot_sweep_stats")
+        return a.value, b.value
 
     def sweep_dev(self, d_in, in_stride, n_frames, ang_start, ang_end, ang_stride, chn=-1,
                   d_peaks=0, flags=0, stream=0):

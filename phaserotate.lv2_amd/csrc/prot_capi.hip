@@ -189,6 +189,8 @@ struct prot_engine {
 	DevBuf<float2> d_H, d_tw;
 	DevBuf<float>  d_lut, d_rot, d_hist[2], d_peaks, d_in, d_out, d_u, d_inter, d_rot_s;
 	DevBuf<int>    d_angles;
+	DevBuf<float>  d_thr;   // [n_chn][4] shared pruning bounds of one sweep launch
+	DevBuf<unsigned long long> d_stats; // {tile groups evaluated, tile groups seen} since the last reset
 	PinBuf<float>  h_io;
 	// small host->device parameter copies (rotation pairs, angle lists) are staged through a ring of
 	// pinned slots owned by the engine, each guarded by an event: the caller's array may die as soon
@@ -218,6 +220,7 @@ int zero_state (prot_engine* e)
 	HIP_TRY (hipMemsetAsync (e->d_hist[0].p, 0, hn * sizeof (float), e->stream));
 	HIP_TRY (hipMemsetAsync (e->d_hist[1].p, 0, hn * sizeof (float), e->stream));
 	HIP_TRY (hipMemsetAsync (e->d_peaks.p, 0, (size_t)PROT_MAXSAMPLE * e->info.n_chn * sizeof (float), e->stream));
+	HIP_TRY (hipMemsetAsync (e->d_stats.p, 0, 2 * sizeof (unsigned long long), e->stream));
 	e->hist_cur      = 0;
 	e->pos           = 0;
 	e->h_peaks_valid = false;
@@ -596,7 +599,8 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	if ((rc = e->d_H.ensure ((size_t)F * n_part)) || (!Hd_h.empty () && (rc = e->d_Hd.ensure (Hd_h.size ()))) || (rc = e->d_tw.ensure (F)) || (rc = e->d_lut.ensure (PROT_MAXSAMPLE * 2)) ||
 	    (rc = e->d_rot.ensure (2 * (size_t)inf.n_chn)) || (rc = e->d_hist[0].ensure (hn)) ||
 	    (rc = e->d_hist[1].ensure (hn)) || (rc = e->d_peaks.ensure ((size_t)PROT_MAXSAMPLE * inf.n_chn)) ||
-	    (rc = e->d_angles.ensure (PROT_MAXSAMPLE + 8))) {
+	    (rc = e->d_angles.ensure (PROT_MAXSAMPLE + 8)) || (rc = e->d_thr.ensure (4 * (size_t)inf.n_chn)) ||
+	    (rc = e->d_stats.ensure (2))) {
 		return fail (rc);
 	}
 	if ((!Hd_h.empty () && hipMemcpy (e->d_Hd.p, Hd_h.data (), Hd_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess) ||
@@ -647,6 +651,8 @@ void prot_engine_destroy (prot_engine* e)
 	e->d_inter.release ();
 	e->d_rot_s.release ();
 	e->d_angles.release ();
+	e->d_thr.release ();
+	e->d_stats.release ();
 	e->h_io.release ();
 	e->h_slots.release ();
 	for (int i = 0; i < prot_engine::kSlots; ++i) {
@@ -875,6 +881,12 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		sp.lut      = e->d_lut.p;
 		sp.peaks    = pk;
 		sp.chn0     = c0;
+		const char* pe = getenv ("PROT_SWEEP_PRUNE"); // read per call: tests flip it inside one process
+		sp.prune       = (pe && atoi (pe) == 0) ? 0 : 1; // exact either way; 0 = the unpruned sweep, for timing and tests
+		sp.thr         = e->d_thr.p;
+		sp.stats       = e->d_stats.p;
+		// bounds are per launch: they refer to THIS call's angle set
+		HIP_TRY (hipMemsetAsync (e->d_thr.p, 0, 4 * (size_t)e->info.n_chn * sizeof (float), s));
 		hipError_t err = prot::launch_sweep (sp, nc, s);
 		if (err != hipSuccess) {
 			return hip_fail (err, "sweep kernel launch");
@@ -920,6 +932,20 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 float* prot_cli_peaks_dev (prot_engine* e)
 {
 	return e ? e->d_peaks.p : nullptr;
+}
+
+int prot_sweep_stats (prot_engine* e, uint64_t* evaluated, uint64_t* seen)
+{
+	if (!e || !evaluated || !seen) {
+		return PROT_EINVAL;
+	}
+	HIP_TRY (hipSetDevice (e->device));
+	HIP_TRY (hipStreamSynchronize (e->stream));
+	unsigned long long h[2] = { 0, 0 };
+	HIP_TRY (hipMemcpy (h, e->d_stats.p, sizeof (h), hipMemcpyDeviceToHost));
+	*evaluated = h[0];
+	*seen      = h[1];
+	return PROT_OK;
 }
 
 int prot_cli_peaks (prot_engine* e, float* out)

@@ -72,6 +72,9 @@ struct SweepParams {
 	const float* lut;         // device, [360][2] = {sin, cos}  (SinCosLut)
 	float*       peaks;       // device, [n_chn][360], max-accumulated
 	int32_t      chn0;        // first channel handled by blockIdx.y = 0
+	int32_t      prune;       // skip tile groups that cannot raise any maximum (exact; see sweep_mfma_kernel)
+	float*       thr;         // device, [n_chn][4], ZEROED before the launch: shared pruning bounds, or NULL
+	unsigned long long* stats; // device, [2] += {tile groups evaluated, tile groups seen}, or NULL
 };
 hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s);
 

@@ -1460,8 +1460,93 @@ __global__ __launch_bounds__ (256) void sweep_mfma_kernel (const SweepParams p)
 	}
 	const f32x16 zero = m[0];
 
+	// ---- pruning --------------------------------------------------------------------------
+	// |ca d + sa h| <= sqrt(d^2 + h^2) =: r for every angle, so a frame whose r is below a LOWER
+	// BOUND of the smallest final peak among this wave's angles cannot change any maximum: the
+	// whole group of tiles is skipped after one r^2 per frame (mul, half-swap, add, max) and one
+	// ballot instead of 2 NBLK MFMAs + 16 NBLK max3 per tile pair.  The result is bit-identical
+	// to the unpruned sweep (skipped frames would have lost every max); how much is skipped
+	// depends on the signal -- record-setting frames become rare quickly in anything stationary,
+	// a monotonically growing signal skips nothing.  The bound: the smallest of the table
+	// entries as they stand at launch (earlier chunks; they only grow) and, refreshed once per
+	// super-tile, the smallest of this wave's own lane-local running maxima.  1e-4 of relative
+	// margin on r^2 covers the rounding of the float evaluation against the exact inequality.
+	unsigned vmask[NBLK]; // bit r set: m[q][r] belongs to a requested angle
+#pragma unroll
+	for (int q = 0; q < NBLK; ++q) {
+		vmask[q] = 0;
+#pragma unroll
+		for (int r = 0; r < 16; ++r) {
+			const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+			const int idx = (g + q * G) * 32 + row;
+			if (g + q * G < nb && idx < p.n_angles) {
+				vmask[q] |= 1u << r;
+			}
+		}
+	}
+	auto wave_min = [] (float v) {
+		v = fminf (v, __shfl_xor (v, 1));
+		v = fminf (v, __shfl_xor (v, 2));
+		v = fminf (v, __shfl_xor (v, 4));
+		v = fminf (v, __shfl_xor (v, 8));
+		v = fminf (v, __shfl_xor (v, 16));
+		v = fminf (v, __shfl_xor (v, 32));
+		return v;
+	};
+	int n_groups = 0, n_live = 0; // tile groups seen / evaluated by this wave (statistics)
+	float thr2 = 0.f;
+	if (p.prune) {
+		float lo = __builtin_inff ();
+#pragma unroll
+		for (int q = 0; q < NBLK; ++q) {
+			const int idx = (g + q * G) * 32 + j;
+			if (g + q * G < nb && idx < p.n_angles) {
+				lo = fminf (lo, __builtin_nontemporal_load (&p.peaks[(int64_t)c * kMaxSample + p.angles[idx]]));
+			}
+		}
+		lo   = wave_min (lo);
+		thr2 = lo * lo; // +inf for a wave without angles: it has nothing to do
+	}
+	// Every wave of angle group g (of this channel) bounds the SAME quantity -- the smallest final
+	// peak among the group's angles -- from below, so the largest bound any of them has found is
+	// valid for all: one atomicMax per wave per super-tile on p.thr[c][g] (non-negative floats
+	// order as their bit patterns; zeroed by the host before the launch) shares it.  Without it a
+	// wave whose own stripes are quiet never learns that another wave has already seen the peaks.
+	unsigned* const thr_slot = p.thr ? reinterpret_cast<unsigned*> (p.thr) + ((int64_t)c * 4 + g) : nullptr;
+	auto share = [&] (float lo) { // lo: this wave's bound (not squared); returns the best bound known
+		if (thr_slot != nullptr && lo < __builtin_inff ()) {
+			float best = lo;
+			if (lane == 0) {
+				const unsigned old = atomicMax (thr_slot, __float_as_uint (lo));
+				best               = fmaxf (lo, __uint_as_float (old));
+			}
+			lo = __shfl (best, 0);
+		}
+		return lo;
+	};
+	if (p.prune && thr2 > 0.f) {
+		const float b = share (sqrtf (thr2));
+		thr2          = b * b;
+	}
+
 	const int64_t span = (int64_t)kMfmaSuper * 32;
+	bool          first = true;
 	for (int64_t base = p.t_begin + (int64_t)blockIdx.x * span; base < p.t_end; base += (int64_t)gridDim.x * span) {
+		if (p.prune && !first) {
+			float lo = __builtin_inff ();
+#pragma unroll
+			for (int q = 0; q < NBLK; ++q) {
+#pragma unroll
+				for (int r = 0; r < 16; ++r) {
+					if (vmask[q] & (1u << r)) {
+						lo = fminf (lo, m[q][r]);
+					}
+				}
+			}
+			lo   = share (wave_min (lo));
+			thr2 = fmaxf (thr2, lo * lo);
+		}
+		first = false;
 		const bool fast = (base + span <= p.t_end) && (base - p.delay >= 0) && (base + span - p.delay <= p.n_x) &&
 		                  (base + p.t_abs0 >= p.dry_from);
 		// NT tiles per step; the frames of step s+1 are requested before the MFMAs of step s
@@ -1493,6 +1578,20 @@ __global__ __launch_bounds__ (256) void sweep_mfma_kernel (const SweepParams p)
 			if (tp + NT * nsub < kMfmaSuper) {
 				load_tiles (bnxt, tp + NT * nsub);
 			}
+			bool live = true;
+			n_groups++;
+			if (p.prune) {
+				float r2m = 0.f;
+#pragma unroll
+				for (int i = 0; i < NT; ++i) {
+					const unsigned b2 = __float_as_uint (bcur[i] * bcur[i]);
+					const auto     sw = __builtin_amdgcn_permlane32_swap (b2, b2, false, false); // {d^2, h^2} of my frame
+					r2m               = fmaxf (r2m, __uint_as_float (sw[0]) + __uint_as_float (sw[1]));
+				}
+				live = __builtin_amdgcn_ballot_w64 (r2m * 1.0001f > thr2) != 0;
+			}
+			n_live += live ? 1 : 0;
+			if (live) {
 #pragma unroll
 			for (int i = 0; i < NT; i += 2) {
 #pragma unroll
@@ -1505,6 +1604,7 @@ __global__ __launch_bounds__ (256) void sweep_mfma_kernel (const SweepParams p)
 					}
 				}
 			}
+			}
 #pragma unroll
 			for (int i = 0; i < NT; ++i) {
 				bcur[i] = bnxt[i];
@@ -1512,6 +1612,10 @@ __global__ __launch_bounds__ (256) void sweep_mfma_kernel (const SweepParams p)
 		}
 	}
 
+	if (p.stats != nullptr && lane == 0) {
+		atomicAdd (&p.stats[0], (unsigned long long)n_live);
+		atomicAdd (&p.stats[1], (unsigned long long)n_groups);
+	}
 	// reduce over the 32 frames (lanes of one half), then one atomic per angle
 	unsigned* gp = reinterpret_cast<unsigned*> (p.peaks + (int64_t)c * kMaxSample);
 #pragma unroll

@@ -2,6 +2,8 @@
 same seeded inputs.  Tolerances: samples 2e-6 abs at
 |y| <= 1, ramp regions 1e-5, peak table 1e-3 dB, min-peak angle index exact.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -514,3 +516,70 @@ def test_lv2_random_buffer_sizes_and_angle_moves(pkg):
         pos += sz
     assert np.abs(yg - yo).max() < TOL_RAMP
     g.close()
+
+
+def _sweep_table(pkg, x, P, stride, prune, passes=((0, 360, 24), (100, 140, 1))):
+    """Peak table [n_chn][360] after a coarse and a fine pass over the interleaved file x, and the
+    fraction of tile groups the sweep actually evaluated."""
+    os.environ["PROT_SWEEP_PRUNE"] = "1" if prune else "0"
+    try:
+        pr = pkg.PhaseRotate(P, x.shape[1])
+        for a0, a1, st in passes:
+            pr.analyze_file(x, a0, a1, st)
+        tab = np.array([[pr.peak(c, a) for a in range(360)] for c in range(x.shape[1])], np.float32)
+        ev, seen = pr.sweep_stats()
+        pr.close()
+    finally:
+        os.environ.pop("PROT_SWEEP_PRUNE", None)
+    return tab, ev / max(seen, 1)
+
+
+@pytest.mark.parametrize("signal", ["noise+harmonics", "growing", "silence-then-burst", "long-multichunk", "constant"])
+def test_pruned_sweep_is_bit_identical_to_unpruned(pkg, signal):
+    """The sweep skips tile groups whose r = sqrt(d^2 + h^2) is below a lower bound of every final
+    peak.  That must not change a single bit of the table -- including when nothing can be skipped
+    (monotonically growing signal), when the bound starts at zero (leading silence), across chunks
+    (> 2^22 frames: later chunks start from the table of the earlier ones) and across passes.
+    The evaluated fraction is asserted too, both ways: a test in which nothing was skipped would
+    compare the unpruned sweep with itself (that happened with the first, per-wave version of the
+    bound), and the growing signal must NOT be skippable."""
+    P = 2048
+    rng = np.random.default_rng(11)
+    if signal == "noise+harmonics":
+        n = 600000
+        x = np.stack([0.5 * harmonic_stack(n, 48000) + 0.1 * xorshift_uniform(n, seed=3), xorshift_uniform(n, seed=4)], 1)
+    elif signal == "growing":
+        n = 400000
+        x = (xorshift_uniform(n, seed=5) * np.linspace(0.01, 1.0, n, dtype=np.float32))[:, None]
+    elif signal == "silence-then-burst":
+        n = 300000
+        x = np.zeros((n, 2), np.float32)
+        x[200000:200700, 0] = xorshift_uniform(700, seed=6)
+        x[299990:, 1] = 0.9
+    elif signal == "long-multichunk":
+        # four device chunks (2^22 frames each): loud material in the first, 40 dB quieter afterwards --
+        # the later chunks (3/4 of the groups) start from the bound the first one left in the table and
+        # are skipped -- plus one late click louder than everything, which must still land in the table
+        n = (1 << 22) * 3 + 12345
+        x = (0.8 * harmonic_stack(n, 48000) + 0.05 * xorshift_uniform(n, seed=8))[:, None].astype(np.float32)
+        x[1 << 22:] *= 0.01
+        x[n - 3000:n - 2990] = 0.97
+    else:
+        n = 100000
+        x = np.full((n, 1), 0.25, np.float32)
+    x = np.ascontiguousarray(x, np.float32)
+    a, frac_pruned = _sweep_table(pkg, x, P, 24, prune=True)
+    b, frac_plain = _sweep_table(pkg, x, P, 24, prune=False)
+    assert a.tobytes() == b.tobytes()
+    assert a.max() > 0            # every signal here has energy
+    assert frac_plain == 1.0      # the switch really switches: unpruned evaluates everything
+    print("\n[sweep pruning, %s] evaluated %.1f %% of the tile groups" % (signal, 100 * frac_pruned))
+    # ... and the comparison is not vacuous: pruning must have skipped work where the signal allows it
+    # (no expectation for "constant": its Hilbert branch is ~0, so the peaks near 90 degrees are ~0 and
+    # nothing is skippable -- 95 % evaluated, correctly; nor for the noise mixture)
+    if signal == "silence-then-burst":
+        assert frac_pruned < 0.5, frac_pruned   # the silences cannot raise anything
+    if signal == "long-multichunk":
+        assert frac_pruned < 0.45, frac_pruned  # at most the loud quarter (+ margin) is evaluated
+    if signal == "growing":
+        assert frac_pruned > 0.9, frac_pruned  # every group holds a new record: nothing may be skipped
