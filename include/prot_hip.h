@@ -205,7 +205,8 @@ float* prot_cli_peaks_dev (prot_engine* e);
  * every angle, so groups of 256 frames whose r stays below a lower bound of every final peak are
  * skipped -- the table is bit-identical to evaluating everything.  `seen` counts (wave, group)
  * pairs offered, `evaluated` those that went through the full per-angle evaluation; the ratio is
- * signal-dependent (stationary material: small; a signal that keeps growing: 1).  Work on the
+ * signal-dependent (stationary material: small; a signal that keeps growing: 1); launches with the
+ * pruning switched off (PROT_SWEEP_PRUNE=0) run the plain kernel and count nothing.  Work on the
  * engine's own stream is awaited first; launches on a caller's stream are the caller's to await. */
 int prot_sweep_stats (prot_engine* e, uint64_t* evaluated, uint64_t* seen);
 

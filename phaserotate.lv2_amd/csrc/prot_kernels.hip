@@ -1417,8 +1417,8 @@ typedef float f32x16 __attribute__ ((ext_vector_type (16)));
 
 constexpr int kMfmaSuper = 256; // 32-frame tiles per workgroup iteration (8192 frames)
 
-template <int NBLK>
-__global__ __launch_bounds__ (256) void sweep_mfma_kernel (const SweepParams p)
+template <int NBLK, bool PRUNE>
+__global__ __launch_bounds__ (256, 3) void sweep_mfma_kernel (const SweepParams p)
 {
 	const int tid  = threadIdx.x;
 	const int w    = __builtin_amdgcn_readfirstlane (tid >> 6); // wave-uniform by construction
@@ -1471,19 +1471,15 @@ __global__ __launch_bounds__ (256) void sweep_mfma_kernel (const SweepParams p)
 	// entries as they stand at launch (earlier chunks; they only grow) and, refreshed once per
 	// super-tile, the smallest of this wave's own lane-local running maxima.  1e-4 of relative
 	// margin on r^2 covers the rounding of the float evaluation against the exact inequality.
-	unsigned vmask[NBLK]; // bit r set: m[q][r] belongs to a requested angle
-#pragma unroll
-	for (int q = 0; q < NBLK; ++q) {
-		vmask[q] = 0;
-#pragma unroll
-		for (int r = 0; r < 16; ++r) {
-			const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
-			const int idx = (g + q * G) * 32 + row;
-			if (g + q * G < nb && idx < p.n_angles) {
-				vmask[q] |= 1u << r;
-			}
-		}
-	}
+	// (all pruning state is wave-uniform and forced into SGPRs: with NBLK = 3 the kernel sits at the
+	// 168-VGPR boundary of 3 waves per SIMD, and a first version that kept it in VGPRs fell to 2
+	// waves per SIMD -- 10-13 % slower on every signal, pruning on or off)
+	auto valid = [&] (int q, int r) { // m[q][r] belongs to a requested angle
+		const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+		const int idx = (g + q * G) * 32 + row;
+		return g + q * G < nb && idx < p.n_angles;
+	};
+	auto uniform_f = [] (float v) { return __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (v))); };
 	auto wave_min = [] (float v) {
 		v = fminf (v, __shfl_xor (v, 1));
 		v = fminf (v, __shfl_xor (v, 2));
@@ -1495,7 +1491,7 @@ __global__ __launch_bounds__ (256) void sweep_mfma_kernel (const SweepParams p)
 	};
 	int n_groups = 0, n_live = 0; // tile groups seen / evaluated by this wave (statistics)
 	float thr2 = 0.f;
-	if (p.prune) {
+	if (PRUNE) {
 		float lo = __builtin_inff ();
 #pragma unroll
 		for (int q = 0; q < NBLK; ++q) {
@@ -1505,7 +1501,7 @@ __global__ __launch_bounds__ (256) void sweep_mfma_kernel (const SweepParams p)
 			}
 		}
 		lo   = wave_min (lo);
-		thr2 = lo * lo; // +inf for a wave without angles: it has nothing to do
+		thr2 = uniform_f (lo * lo); // +inf for a wave without angles: it has nothing to do
 	}
 	// Every wave of angle group g (of this channel) bounds the SAME quantity -- the smallest final
 	// peak among the group's angles -- from below, so the largest bound any of them has found is
@@ -1524,27 +1520,27 @@ __global__ __launch_bounds__ (256) void sweep_mfma_kernel (const SweepParams p)
 		}
 		return lo;
 	};
-	if (p.prune && thr2 > 0.f) {
+	if (PRUNE && thr2 > 0.f) {
 		const float b = share (sqrtf (thr2));
-		thr2          = b * b;
+		thr2          = uniform_f (b * b);
 	}
 
 	const int64_t span = (int64_t)kMfmaSuper * 32;
 	bool          first = true;
 	for (int64_t base = p.t_begin + (int64_t)blockIdx.x * span; base < p.t_end; base += (int64_t)gridDim.x * span) {
-		if (p.prune && !first) {
+		if (PRUNE && !first) {
 			float lo = __builtin_inff ();
 #pragma unroll
 			for (int q = 0; q < NBLK; ++q) {
 #pragma unroll
 				for (int r = 0; r < 16; ++r) {
-					if (vmask[q] & (1u << r)) {
+					if (valid (q, r)) {
 						lo = fminf (lo, m[q][r]);
 					}
 				}
 			}
 			lo   = share (wave_min (lo));
-			thr2 = fmaxf (thr2, lo * lo);
+			thr2 = uniform_f (fmaxf (thr2, lo * lo));
 		}
 		first = false;
 		const bool fast = (base + span <= p.t_end) && (base - p.delay >= 0) && (base + span - p.delay <= p.n_x) &&
@@ -1579,8 +1575,12 @@ __global__ __launch_bounds__ (256) void sweep_mfma_kernel (const SweepParams p)
 				load_tiles (bnxt, tp + NT * nsub);
 			}
 			bool live = true;
-			n_groups++;
-			if (p.prune) {
+			if (PRUNE) {
+				n_groups++;
+			}
+			// adaptive: a wave that found (nearly) every group live so far stops paying for the test
+			// (noise-like or steadily growing material); its statistics still count every group
+			if (PRUNE && !(n_groups > 64 && n_live * 16 > n_groups * 15)) {
 				float r2m = 0.f;
 #pragma unroll
 				for (int i = 0; i < NT; ++i) {
@@ -1590,7 +1590,9 @@ __global__ __launch_bounds__ (256) void sweep_mfma_kernel (const SweepParams p)
 				}
 				live = __builtin_amdgcn_ballot_w64 (r2m * 1.0001f > thr2) != 0;
 			}
-			n_live += live ? 1 : 0;
+			if (PRUNE) {
+				n_live += live ? 1 : 0;
+			}
 			if (live) {
 #pragma unroll
 			for (int i = 0; i < NT; i += 2) {
@@ -1612,7 +1614,7 @@ __global__ __launch_bounds__ (256) void sweep_mfma_kernel (const SweepParams p)
 		}
 	}
 
-	if (p.stats != nullptr && lane == 0) {
+	if (PRUNE && p.stats != nullptr && lane == 0) {
 		atomicAdd (&p.stats[0], (unsigned long long)n_live);
 		atomicAdd (&p.stats[1], (unsigned long long)n_groups);
 	}
@@ -1657,33 +1659,32 @@ hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s)
 		const int  nblk = nb >= 3 ? (nb + 3) / 4 : 1;
 		// persistent grid: exactly the workgroups the chip keeps resident, so the
 		// grid-stride loop ends without a ragged last round
-		static int slots[4] = { 0, 0, 0, 0 };
-		if (slots[nblk] == 0) {
+		typedef void (*kern_t) (SweepParams);
+		static const kern_t kern[2][4] = {
+			{ nullptr, sweep_mfma_kernel<1, false>, sweep_mfma_kernel<2, false>, sweep_mfma_kernel<3, false> },
+			{ nullptr, sweep_mfma_kernel<1, true>, sweep_mfma_kernel<2, true>, sweep_mfma_kernel<3, true> },
+		};
+		const int    pr = p.prune ? 1 : 0;
+		const kern_t fn = kern[pr][nblk];
+		static int   slots[2][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+		if (slots[pr][nblk] == 0) {
 			int dev = 0, cus = 256, occ = 2;
 			(void)hipGetDevice (&dev);
 			(void)hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, dev);
-			const void* fn = nblk == 1 ? (const void*)sweep_mfma_kernel<1>
-			                           : nblk == 2 ? (const void*)sweep_mfma_kernel<2> : (const void*)sweep_mfma_kernel<3>;
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor (&occ, fn, 256, 0) != hipSuccess || occ < 1) {
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor (&occ, (const void*)fn, 256, 0) != hipSuccess || occ < 1) {
 				occ = 2;
 			}
-			slots[nblk] = cus * occ;
+			slots[pr][nblk] = cus * occ;
 		}
 		const int64_t span  = (int64_t)kMfmaSuper * 32;
 		const int64_t tiles = (p.t_end - p.t_begin + span - 1) / span;
 		int64_t       gx    = tiles;
-		const int64_t cap   = std::max (1, slots[nblk] / n_chn);
+		const int64_t cap   = std::max (1, slots[pr][nblk] / n_chn);
 		if (gx > cap) {
 			gx = cap;
 		}
 		const dim3 grid ((unsigned)gx, (unsigned)n_chn), block (256);
-		if (nblk == 1) {
-			hipLaunchKernelGGL (sweep_mfma_kernel<1>, grid, block, 0, s, p);
-		} else if (nblk == 2) {
-			hipLaunchKernelGGL (sweep_mfma_kernel<2>, grid, block, 0, s, p);
-		} else {
-			hipLaunchKernelGGL (sweep_mfma_kernel<3>, grid, block, 0, s, p);
-		}
+		hipLaunchKernelGGL (fn, grid, block, 0, s, p);
 		return hipGetLastError ();
 	}
 	return launch_sweep_valu (p, n_chn, s);
