@@ -18,18 +18,25 @@ x = (torch.rand(n, device=dev) - 0.5); y = torch.empty_like(x)
 rot = np.array([0.0, -1.0], np.float32)
 ts = torch.cuda.Stream(); torch.cuda.set_stream(ts); st = ts.cuda_stream
 out = []
+xh, yh = x.half(), torch.empty(n, device=dev, dtype=torch.float16)
 for name in sys.argv[1].split(","):
-    kind, param, fl = cases[name]
-    e = pkg.Engine(kind, param, 1, flags=fl)
+    if name.startswith("f16_"):  # fp16 sample path of the named case
+        kind, param, fl = cases[name[4:]]
+        e = pkg.Engine(kind, param, 1, flags=fl)
+        call = lambda: e.apply_dev_f16(xh.data_ptr(), n, n, yh.data_ptr(), n, n, rot, st)
+    else:
+        kind, param, fl = cases[name]
+        e = pkg.Engine(kind, param, 1, flags=fl)
+        call = lambda: e.apply_dev(x.data_ptr(), n, n, y.data_ptr(), n, n, rot, pkg.F_STATELESS, st)
     for _ in range(2):
-        e.apply_dev(x.data_ptr(), n, n, y.data_ptr(), n, n, rot, pkg.F_STATELESS, st)
+        call()
     torch.cuda.synchronize()
     best = 1e9
     for rep in range(3):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         for _ in range(5):
-            e.apply_dev(x.data_ptr(), n, n, y.data_ptr(), n, n, rot, pkg.F_STATELESS, st)
+            call()
         ev1.record(); torch.cuda.synchronize()
         best = min(best, ev0.elapsed_time(ev1) / 5)
     out.append("%%s %%.4f" %% (name, best))
