@@ -465,11 +465,11 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	// PAIR of 2048-tap partitions of g.  PROT_CFG_DIRECT_FORM keeps the two-partition direct form.
 	std::vector<float> fir_taps;
 	fir_design ((int)inf.firlen, fir_taps);
-	// Measured (tools/order_check.py, 12 interleaved rounds, +-2 %): for FIRs of <= 4096 taps the direct
-	// two-partition form is 2.4 % (3072 taps) / 1.7 % (4096 taps) FASTER than one polyphase partition --
-	// the three-frames-per-sample loads cost more than the saved spectrum multiply -- so polyphase is the
-	// default only from 8192 taps up, where it halves the launches (1.31 -> 0.40 ms, 5.95 -> 2.63 ms per
-	// 2^27 frames at 8192 / 32768 taps).  PROT_CFG_POLYPHASE forces it for the shorter FIRs (cross-checks).
+	// Measured (tools/order_check.py, 12 interleaved rounds, +-2 %): for FIRs of <= 4096 taps one polyphase
+	// partition and the direct two-partition form take the same time (0.3599 vs 0.3615 ms at 3072 taps,
+	// 0.3611 vs 0.3609 at 4096), so the direct form stays the default there; polyphase is the default from
+	// 8192 taps up, where it halves the launches (1.31 -> 0.40 ms, 5.95 -> 2.63 ms per 2^27 frames at
+	// 8192 / 32768 taps).  PROT_CFG_POLYPHASE forces it for the shorter FIRs (cross-checks).
 	const bool poly_wanted = (inf.firlen > F) || (cfg->flags & PROT_CFG_POLYPHASE);
 	bool use_poly = use_p2 && poly_wanted && getenv ("PROT_NO_POLY") == nullptr && !(cfg->flags & PROT_CFG_DIRECT_FORM) &&
 	                inf.firlen % 4 == 0 && inf.conv_delay % 2 == 0;

@@ -1018,18 +1018,24 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 	}
 
 	// frames a-1 | a, a+1 of sample j = t + 256 k, a = a0 + 2 j
-	float nxp[8];
+	float nxp[8], nxb[8];
 	f2    nxqc[8];
+	bool  nx_shift = false; // (wave-uniform) nxp is to be derived from nxqc / nxb
 	auto  load_block = [&] (int64_t a0) {
 		const bool fast = (a0 - 1 >= 0) && (a0 + BLK <= n_in);
+		nx_shift = fast && in_al8;
 		if (fast && in_al8) {
+			// the stream exactly once, as aligned 8-byte pairs (q, c); p = x[a-1] is the c of the previous
+			// sample, i.e. of lane t-1 (one DPP wave shift at the point of use), except in lane 0 of a
+			// wave, which gets it from a wave-uniform scalar load (nxb)
+			const unsigned w128 = (unsigned)__builtin_amdgcn_readfirstlane (t >> 6) * 128u;
 #pragma unroll
 			for (int m = 0; m < 4; ++m) { // one SGPR base per 1024 frames: the immediate offset reaches 4 KiB
 				const PROT_GLOBAL float* __restrict__ b = uniform_ptr (in + a0 + 1024 * m);
 #pragma unroll
 				for (int e = 0; e < 2; ++e) {
 					nxqc[2 * m + e] = reinterpret_cast<const PROT_GLOBAL f2*> (b)[(unsigned)t + 256u * e];
-					nxp[2 * m + e]  = (b - 1)[2u * (unsigned)t + 512u * e];
+					nxb[2 * m + e]  = (b - 1)[w128 + 512u * e];
 				}
 			}
 		} else if (fast) {
@@ -1059,8 +1065,12 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 		f2 cur[8];
 #pragma unroll
 		for (int k = 0; k < 8; ++k) {
-			cur[k]   = nxqc[k];
-			v[k]     = mkf2 (nxp[k], nxqc[k].x);
+			cur[k] = nxqc[k];
+			float pk_ = nxp[k];
+			if (nx_shift) { // wave_shr:1 -- lane i reads lane i-1, lane 0 keeps `old` = the scalar-loaded frame
+				pk_ = __uint_as_float (__builtin_amdgcn_update_dpp (__float_as_uint (nxb[k]), __float_as_uint (nxqc[k].y), 0x138, 0xf, 0xf, false));
+			}
+			v[k]     = mkf2 (pk_, nxqc[k].x);
 			v[8 + k] = mkf2 (0.f, 0.f);
 		}
 
