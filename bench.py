@@ -356,10 +356,11 @@ def bench_sweep(args, pkg, torch, dist, dev, st, world, rank, local_rank, barrie
     from phaserotate_lv2_amd import sweep_dist
     P, n_chn = 2048, 2
     total = int(args.sweep_seconds * 96000) // P * P
-    plan = sweep_dist.plan_shards(total, P, world)
+    eng = pkg.Engine(pkg.KIND_CLI, P, n_chn, device=local_rank)
+    # shard starts on whole device transform blocks: the merged table is bit-identical to a single pass
+    plan = sweep_dist.plan_shards(total, P, world, align=eng.shard_align_blocks())
     b0, b1 = plan[rank]
     n = (b1 - b0) * P
-    eng = pkg.Engine(pkg.KIND_CLI, P, n_chn, device=local_rank)
     H = int(eng.info.history)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = (torch.rand((n_chn, n), generator=gen, device=dev) - 0.5) * 0.9

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define PROT_ABI_VERSION 1
+#define PROT_ABI_VERSION 2
 #define PROT_SUBSAMPLE 2                      /* cli/phase-rotate.cc:38 */
 #define PROT_MAXSAMPLE (180 * PROT_SUBSAMPLE) /* cli/phase-rotate.cc:39 */
 
@@ -61,8 +61,9 @@ typedef struct {
  * stream read as complex samples x[2j-1] + i x[2j] is convolved with the odd taps only: half the
  * partitions, 4096-frame blocks).  Same filter; kept for cross-checks. */
 #define PROT_CFG_DIRECT_FORM 2u
-/* Polyphase form also for FIRs of 2050..4096 taps, where the default is the direct form (it measured
- * 2 % faster there); FIRs of 8192 taps and more are polyphase by default. */
+/* Polyphase form also for the 4096-tap FIRs (LV2 96 kHz, CLI blksiz 4096), where the default is the
+ * direct form (measured 6-7 % faster there: no longer hop to gain); every other FIR length is polyphase
+ * by default (1024..3072 taps: longer hops; 8192 and more: half the launches). */
 #define PROT_CFG_POLYPHASE 4u
 
 typedef struct {
@@ -78,6 +79,9 @@ typedef struct {
 	uint32_t blksiz;      /* CLI: parsiz; LV2: reference parsiz (ramp granularity) */
 	uint32_t partitions;  /* FIR partitions of <= fftlen/2 taps convolved per hop (polyphase engines: partitions
 	                       * of the odd taps) */
+	uint32_t run_align;   /* frames: a stream cut at multiples of this (CLI: of lcm(run_align, blksiz)) and fed to
+	                       * separate engines / launches reproduces the single-pass arithmetic BIT FOR BIT -- it is
+	                       * the span of one device transform block (pair); shard and chunk boundaries use it */
 } prot_info;
 
 typedef struct prot_engine prot_engine;
@@ -222,7 +226,7 @@ int prot_sweep_stats (prot_engine* e, uint64_t* evaluated, uint64_t* seen);
 int prot_allreduce_peaks (prot_engine* const* engines, int n);
 
 /* analyze_file (cli/phase-rotate.cc:565-587) sharded over n engines: engine r
- * sweeps a pair-aligned range of frame blocks for all requested angles, primed
+ * sweeps a run_align-aligned range of frame blocks for all requested angles, primed
  * with the input history in front of its range; the first-block rule stays
  * with engine 0, zero-padding and the flush block with the last one; then
  * prot_allreduce_peaks.  Bit-identical to prot_cli_analyze_file on one engine. */

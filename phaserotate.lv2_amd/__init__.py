@@ -52,7 +52,7 @@ class Info(C.Structure):
     _fields_ = [("kind", C.c_int32), ("n_chn", C.c_uint32), ("fftlen", C.c_uint32),
                 ("hop", C.c_uint32), ("firlen", C.c_uint32), ("latency", C.c_uint32),
                 ("dry_delay", C.c_uint32), ("conv_delay", C.c_uint32), ("history", C.c_uint32),
-                ("blksiz", C.c_uint32), ("partitions", C.c_uint32)]
+                ("blksiz", C.c_uint32), ("partitions", C.c_uint32), ("run_align", C.c_uint32)]
 
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
@@ -204,6 +204,13 @@ class Engine:
     def apply_dev_ramp(self, d_in, in_stride, n_in, d_out, out_stride, n_out, d_rot, flags=0, stream=0):
         _check(self._lib.prot_apply_dev_ramp(self._h, d_in, in_stride, n_in, d_out, out_stride,
                                              n_out, d_rot, flags, stream), "prot_apply_dev_ramp")
+
+    def shard_align_blocks(self):
+        """Blocks of `blksiz` frames per alignment unit: shards / chunks that start on a multiple of it are
+        bit-identical to a single pass (lcm(blksiz, info.run_align) / blksiz)."""
+        import math
+        P, A = int(self.info.blksiz), max(1, int(self.info.run_align))
+        return P // math.gcd(P, A) * A // P
 
     def sweep_stats(self):
         """(evaluated, seen) tile groups of the sweep since the last reset (prot_sweep_stats)."""

@@ -227,6 +227,31 @@ int zero_state (prot_engine* e)
 	return PROT_OK;
 }
 
+uint64_t gcd_u64 (uint64_t a, uint64_t b)
+{
+	while (b) {
+		const uint64_t t = a % b;
+		a                = b;
+		b                = t;
+	}
+	return a;
+}
+
+// frames: CLI files are cut (into device chunks, into shards for several engines) only at multiples of this,
+// so that every piece starts on a blksiz block AND on a device transform block: bit-identical to one pass
+uint64_t file_align_frames (const prot_engine* e)
+{
+	const uint64_t P = e->info.blksiz, A = std::max<uint32_t> (1, e->info.run_align);
+	return P / gcd_u64 (P, A) * A;
+}
+
+// whole alignment units, <= 2^22 frames per channel (<= 16 MiB per channel per staging buffer)
+uint64_t file_chunk_frames (const prot_engine* e)
+{
+	const uint64_t L = file_align_frames (e);
+	return std::max<uint64_t> (L, ((uint64_t)1 << 22) / L * L);
+}
+
 int pick_run_frames (const prot_engine* e, uint64_t n_out, int n_chn)
 {
 	// One workgroup per run.  Long streams: fill every resident-workgroup slot of the
@@ -277,7 +302,7 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 			p.H          = e->d_H.p + (size_t)(np * l) * e->info.fftlen;
 			p.conv_delay = (int)(e->info.conv_delay + np * l * e->info.fftlen); // a partition of g spans 4096 frames
 			p.accumulate = l > 0;
-			hipError_t err = prot::launch_ola_poly (p, (int)np, n_chn, s);
+			hipError_t err = prot::launch_ola_poly (p, (int)np, e->hopseg / 2, n_chn, s);
 			if (err != hipSuccess) {
 				return hip_fail (err, "polyphase ola kernel launch");
 			}
@@ -465,14 +490,18 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	// PAIR of 2048-tap partitions of g.  PROT_CFG_DIRECT_FORM keeps the two-partition direct form.
 	std::vector<float> fir_taps;
 	fir_design ((int)inf.firlen, fir_taps);
-	// Measured (tools/order_check.py, 12 interleaved rounds, +-2 %): for FIRs of <= 4096 taps one polyphase
-	// partition and the direct two-partition form take the same time (0.3599 vs 0.3615 ms at 3072 taps,
-	// 0.3611 vs 0.3609 at 4096), so the direct form stays the default there; polyphase is the default from
-	// 8192 taps up, where it halves the launches (1.31 -> 0.40 ms, 5.95 -> 2.63 ms per 2^27 frames at
-	// 8192 / 32768 taps).  PROT_CFG_POLYPHASE forces it for the shorter FIRs (cross-checks).
-	const bool poly_wanted = (inf.firlen > F) || (cfg->flags & PROT_CFG_POLYPHASE);
-	bool use_poly = use_p2 && poly_wanted && getenv ("PROT_NO_POLY") == nullptr && !(cfg->flags & PROT_CFG_DIRECT_FORM) &&
-	                inf.firlen % 4 == 0 && inf.conv_delay % 2 == 0;
+	// Which form is the default is decided by measurement (tools/order_check.py, 10 interleaved rounds on
+	// two boxes, ranges disjoint): polyphase wins wherever the odd taps leave room for a longer hop --
+	// 3072 taps (LV2 48 kHz, 5120 frames per block) -9 / -10 %, 2048 taps (CLI 2048, 6144) -9 / -11 %,
+	// 1024 taps (CLI 1024, 7168) -21 / -24 % -- and from 8192 taps up, where it halves the launches
+	// (1.31 -> 0.40 ms, 5.95 -> 2.63 ms per 2^27 frames at 8192 / 32768 taps); at 4096 taps (LV2 96 kHz,
+	// CLI 4096: hop 4096 either way) the direct two-partition form is 6-7 % faster and stays the default.
+	// PROT_CFG_POLYPHASE / PROT_CFG_DIRECT_FORM force one or the other (cross-checks).
+	const bool long_hop    = inf.firlen >= 1024 && inf.firlen / 2 <= 1537; // g leaves >= 2 extra rows of 256 samples
+	const bool poly_wanted = (inf.firlen > F) || long_hop || (cfg->flags & PROT_CFG_POLYPHASE);
+	bool use_poly = (use_p2 || long_hop || (cfg->flags & PROT_CFG_POLYPHASE)) && poly_wanted && getenv ("PROT_NO_POLY") == nullptr &&
+	                !(cfg->flags & (PROT_CFG_DIRECT_FORM | PROT_CFG_SINGLE_FFT_PER_HOP)) && inf.firlen % 4 == 0 &&
+	                inf.firlen >= 1024 && inf.conv_delay % 2 == 0;
 	for (uint32_t i = 0; use_poly && i < inf.firlen; i += 2) {
 		use_poly = fir_taps[i] == 0.f;
 	}
@@ -482,7 +511,15 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 		part_len = F / 2;                                         // taps of g per partition
 		n_part   = (inf.firlen / 2 + part_len - 1) / part_len;
 		n_part   = n_part > 1 ? (n_part + 1) & ~1u : 1;           // one partition, or whole pairs
-		hopseg   = 16;                                            // 4096 new frames per block
+		// rows of 256 complex samples that are new per block: 16 minus what the tail of g needs
+		// (g of 2048 taps: 8; 1536 taps, the LV2 48 kHz filter: 10 -> 5120 frames per transform pair)
+		const uint32_t glen = inf.firlen / 2;
+		uint32_t       rows = 8;
+		if (n_part == 1) {
+			rows = 16 - (glen - 1 + 255) / 256;
+			rows = std::min<uint32_t> (14, std::max<uint32_t> (8, rows & ~1u));
+		}
+		hopseg   = (int)(2 * rows);                               // x 256 = new frames per block
 		use_p2   = false;
 	} else if (use_p2) {
 		part_len = F / 2;
@@ -500,10 +537,14 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	inf.fftlen     = F;
 	inf.hop        = hopseg * seg;
 	inf.partitions = n_part;
+	// one device transform covers hop frames (polyphase) or a PAIR of hops (direct forms: two hops ride as re/im)
+	inf.run_align  = use_poly ? inf.hop : 2 * inf.hop;
 	// history: conv delay (+ partition delays) + the halo the OLA run start reaches back, and the dry delay
 	uint32_t H = inf.conv_delay + (n_part - 1) * part_len + F;
-	if (use_poly) { // every partition of g spans 4096 frames; one more frame for the x[2j-1] of the first sample
-		H = inf.conv_delay + n_part * F + 2;
+	if (use_poly) { // a run starts n_part' blocks early (n_part' = partitions per launch), later launches are delayed by
+		            // 4096 frames per partition of g; one more frame for the x[2j-1] of the first sample
+		const uint32_t blk = (uint32_t)hopseg * seg;
+		H = inf.conv_delay + (n_part > 2 ? (n_part - 2) * F : 0) + std::min<uint32_t> (2, n_part) * blk + 2;
 	}
 	H          = std::max (H, inf.dry_delay);
 	inf.history = (H + 255) & ~255u;
@@ -1243,8 +1284,8 @@ int prot_cli_analyze_file (prot_engine* e, const float* data, uint64_t n_frames,
 	const uint32_t nc = e->info.n_chn;
 	const uint64_t P  = e->info.blksiz;
 	hipStream_t    s  = e->stream;
-	// chunk: whole blocks, <= 2^22 frames per channel (<= 16 MiB per channel per buffer)
-	const uint64_t chunk = std::max<uint64_t> (P, ((uint64_t)1 << 22) / P * P);
+	// chunk: whole alignment units (blocks AND device transform blocks), <= 2^22 frames per channel
+	const uint64_t chunk = file_chunk_frames (e);
 	int rc;
 	const uint64_t cap = std::min<uint64_t> (chunk, std::max<uint64_t> (n_frames, 1));
 	if ((rc = e->d_inter.ensure (cap * nc)) || (rc = e->d_in.ensure (cap * nc))) {
@@ -1321,7 +1362,7 @@ int analyze_range (prot_engine* e, const float* data, uint64_t f0, uint64_t nf, 
 	const uint32_t nc = e->info.n_chn;
 	const uint64_t P  = e->info.blksiz;
 	hipStream_t    s  = e->stream;
-	const uint64_t chunk = std::max<uint64_t> (P, ((uint64_t)1 << 22) / P * P);
+	const uint64_t chunk = file_chunk_frames (e);
 	const uint64_t H     = e->info.history;
 	const uint64_t cap   = std::max<uint64_t> (std::min<uint64_t> (chunk, std::max<uint64_t> (nf, 1)), H);
 	int rc;
@@ -1451,15 +1492,17 @@ int prot_cli_analyze_file_multi (prot_engine* const* engines, int n, const float
 			return PROT_EINVAL;
 		}
 	}
-	// contiguous block ranges on pair boundaries (2 blocks): a shard that starts on a hop-pair
-	// boundary reproduces the single-engine arithmetic bit for bit
+	// contiguous block ranges on alignment-unit boundaries (whole blksiz blocks AND whole device
+	// transform blocks, file_align_frames): a shard that starts there reproduces the single-engine
+	// arithmetic bit for bit
 	const uint64_t P     = engines[0]->info.blksiz;
 	const uint64_t nb    = (n_frames + P - 1) / P;
-	const uint64_t units = (nb + 1) / 2;
+	const uint64_t ab    = file_align_frames (engines[0]) / P; // blocks per alignment unit
+	const uint64_t units = (nb + ab - 1) / ab;
 	std::vector<uint64_t> b0 (n + 1, 0);
 	for (int r = 0; r < n; ++r) {
 		const uint64_t k = units / n + ((uint64_t)r < units % n ? 1 : 0);
-		b0[r + 1]        = std::min (nb, b0[r] + 2 * k);
+		b0[r + 1]        = std::min (nb, b0[r] + ab * k);
 	}
 	std::vector<int>         rcs (n, PROT_OK);
 	std::vector<std::thread> th;
@@ -1504,7 +1547,7 @@ int prot_cli_apply_file (prot_engine* e, const float* data, uint64_t n_frames, c
 	const uint64_t P   = e->info.blksiz;
 	const uint64_t lat = P / 2; // cli/phase-rotate.cc:963
 	hipStream_t    s   = e->stream;
-	const uint64_t chunk = std::max<uint64_t> (P, ((uint64_t)1 << 22) / P * P);
+	const uint64_t chunk = file_chunk_frames (e);
 	const uint64_t cap   = std::min<uint64_t> (chunk, n_frames) + lat;
 	int rc;
 	if ((rc = e->d_inter.ensure (cap * nc)) || (rc = e->d_in.ensure (cap * nc)) || (rc = e->d_out.ensure (cap * nc))) {

@@ -306,25 +306,34 @@ PROT_DEV void pkt_fft16 (typename O::cplx (&v)[16])
 	pkt_fft16_stage2<O, DIR> (v);
 }
 
-// forward radix-16 of a zero-padded column: only v[0..NNZ) are non-zero (NNZ = 4 or 8).
-// The asm butterflies are opaque to constant folding, so the pruning is spelled out.
+// forward radix-16 of a zero-padded column: only v[0..NNZ) are non-zero (NNZ = 4, 8, 10, 12, 14 or 16).
+// The asm butterflies are opaque to constant folding, so the pruning is spelled out: stage 1 is four
+// DFT-4 over (v[be], v[be+4], v[be+8], v[be+12]); with n of the four inputs non-zero it costs
+// 0 (n = 1: copies), 4 (n = 2), 6 (n = 3) or 8 (n = 4) packed instructions.
 template <class O, int NNZ>
 PROT_DEV void pkt_fft16_fwd_pruned (typename O::cplx (&v)[16])
 {
-	static_assert (NNZ == 4 || NNZ == 8, "hop is 1/4 or 1/2 of the transform");
-	if (NNZ == 4) { // stage 1 degenerates to copies: y[be][ka] = x[be]
+	static_assert (NNZ == 4 || (NNZ >= 8 && NNZ <= 16 && NNZ % 2 == 0), "zero-padded rows come in pairs");
 #pragma unroll
-		for (int be = 0; be < 4; ++be) {
+	for (int be = 0; be < 4; ++be) {
+		const int n = (NNZ - be + 3) / 4; // non-zero inputs of this butterfly: rows be, be+4, ... < NNZ
+		if (n == 1) { // y[al] = x[be]
 			v[4 + be] = v[8 + be] = v[12 + be] = v[be];
-		}
-	} else { // inputs al = 0, 1 only: DFT-4 of (a, b, 0, 0) = (a + b, a - j b, a - b, a + j b)
-#pragma unroll
-		for (int be = 0; be < 4; ++be) {
+		} else if (n == 2) { // DFT-4 of (a, b, 0, 0) = (a + b, a - j b, a - b, a + j b)
 			const typename O::cplx a = v[be], b = v[4 + be];
 			v[be]      = a + b;
 			v[4 + be]  = O::add_mj (a, b);
 			v[8 + be]  = a - b;
 			v[12 + be] = O::sub_mj (a, b);
+		} else if (n == 3) { // DFT-4 of (a, b, c, 0): s = a + c, d = a - c; (s + b, d - j b, s - b, d + j b)
+			const typename O::cplx a = v[be], b = v[4 + be], c = v[8 + be];
+			const typename O::cplx sm = a + c, df = a - c;
+			v[be]      = sm + b;
+			v[4 + be]  = O::add_mj (df, b);
+			v[8 + be]  = sm - b;
+			v[12 + be] = O::sub_mj (df, b);
+		} else {
+			pkt_radix4<O, 1> (v[be], v[4 + be], v[8 + be], v[12 + be]);
 		}
 	}
 	pkt_stage1_twiddles<O, 1> (v);

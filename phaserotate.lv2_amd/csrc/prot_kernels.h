@@ -43,9 +43,9 @@ hipError_t launch_ola4096_p2 (const OlaParams& p, int n_chn, hipStream_t s);
 
 // polyphase form for FIRs that are zero at every even tap (the Hilbert FIRs of > 2049 taps):
 // p.H = [n_part][4096] spectra of the 2048-tap partitions of g[s] = fir[2 s + 1] (/ 4096),
-// n_part in {1, 2}; p.conv_delay even; (dry_delay - conv_delay)/512 in {3, 4, 8} served from
-// registers, other values re-read the stream; p.run_frames a multiple of 4096
-hipError_t launch_ola_poly (const OlaParams& p, int n_part, int n_chn, hipStream_t s);
+// n_part in {1, 2}; hop_rows in {8, 10, 12, 14} (x 512 new frames per block; > 8 only for one partition
+// of at most 256 (16 - hop_rows) + 1 taps); p.conv_delay even; p.run_frames a multiple of 512 hop_rows
+hipError_t launch_ola_poly (const OlaParams& p, int n_part, int hop_rows, int n_chn, hipStream_t s);
 
 // fp16 sample path (BASELINE config 5): half samples in HBM, packed-half butterflies,
 // fp32 overlap-add + rotation.  Stateless, steady rotation.

@@ -941,15 +941,21 @@ hipError_t launch_ola4096_p2_f16 (const OlaParamsH& p, int n_chn, hipStream_t s)
 // (dword) and (q, c) = x[a], x[a+1] (one aligned 8-byte load); (p, q) feeds the transform,
 // (q, c) is kept for the dry path -- the stream is still read from HBM once.
 // --------------------------------------------------------------------------------------
-template <int NP, int MODE, int DH, bool ACC>
+template <int NP, int HS, int MODE, int DH, bool ACC>
 __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 {
 	typedef T32  T;
 	typedef f2   C;
 	typedef pk32 O;
 	typedef PROT_LDS_PTR (T) VC;
-	constexpr int BLK = 4096; // frames per block = 2048 complex samples
+	// HS rows of 256 complex samples are new per block, 16 - HS rows are the overlap-add tail: g may
+	// have up to 256 (16 - HS) + 1 taps.  HS = 8 for 2048-tap partitions; a shorter g (1536 taps for
+	// the 3072-tap LV2 filter: HS = 10; 1024: 12; 512: 14) takes proportionally more frames per
+	// transform pair -- the zero padding of the OLA is only as long as the filter needs.
+	constexpr int BLK = 512 * HS; // frames per block
+	constexpr int NT  = 16 - HS;  // tail rows
 	static_assert (NP == 1 || NP == 2, "one or two partitions of g per launch");
+	static_assert (HS == 8 || ((HS == 10 || HS == 12 || HS == 14) && NP == 1), "long hops only for a single short partition");
 	static_assert (DH >= 0 && DH <= 8, "dry delay difference / 512 within one block, or 0");
 	constexpr int NDH = DH > 0 ? DH : 1;
 
@@ -1000,9 +1006,9 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 	const int n_it = NP + (int)((r1 - r0 + BLK - 1) / BLK);  // NP halo blocks: OLA tail (+ X_{b-1})
 	int64_t   s    = r0 - (int64_t)NP * BLK;
 
-	C acc[8], zp[NP == 2 ? 16 : 1];
+	C acc[NT], zp[NP == 2 ? 16 : 1];
 #pragma unroll
-	for (int i = 0; i < 8; ++i) {
+	for (int i = 0; i < NT; ++i) {
 		acc[i] = mkf2 (0.f, 0.f);
 	}
 #pragma unroll
@@ -1018,8 +1024,8 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 	}
 
 	// frames a-1 | a, a+1 of sample j = t + 256 k, a = a0 + 2 j
-	float nxp[8], nxb[8];
-	f2    nxqc[8];
+	float nxp[HS], nxb[HS];
+	f2    nxqc[HS];
 	bool  nx_shift = false; // (wave-uniform) nxp is to be derived from nxqc / nxb
 	auto  load_block = [&] (int64_t a0) {
 		const bool fast = (a0 - 1 >= 0) && (a0 + BLK <= n_in);
@@ -1030,7 +1036,7 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 			// wave, which gets it from a wave-uniform scalar load (nxb)
 			const unsigned w128 = (unsigned)__builtin_amdgcn_readfirstlane (t >> 6) * 128u;
 #pragma unroll
-			for (int m = 0; m < 4; ++m) { // one SGPR base per 1024 frames: the immediate offset reaches 4 KiB
+			for (int m = 0; m < HS / 2; ++m) { // one SGPR base per 1024 frames: the immediate offset reaches 4 KiB
 				const PROT_GLOBAL float* __restrict__ b = uniform_ptr (in + a0 + 1024 * m);
 #pragma unroll
 				for (int e = 0; e < 2; ++e) {
@@ -1040,7 +1046,7 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 			}
 		} else if (fast) {
 #pragma unroll
-			for (int m = 0; m < 4; ++m) {
+			for (int m = 0; m < HS / 2; ++m) {
 				const PROT_GLOBAL float* __restrict__ b = uniform_ptr (in + a0 + 1024 * m);
 #pragma unroll
 				for (int e = 0; e < 2; ++e) {
@@ -1050,7 +1056,7 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 			}
 		} else {
 #pragma unroll
-			for (int k = 0; k < 8; ++k) {
+			for (int k = 0; k < HS; ++k) {
 				const int64_t a = a0 + 2 * (int64_t)(t + 256 * k);
 				nxp[k]          = ldv (in, n_in, hist, p.hist_len, a - 1);
 				nxqc[k]         = mkf2 (ldv (in, n_in, hist, p.hist_len, a), ldv (in, n_in, hist, p.hist_len, a + 1));
@@ -1062,16 +1068,19 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 
 	for (int it = 0; it < n_it; ++it, s += BLK) {
 		C  v[16];
-		f2 cur[8];
+		f2 cur[HS];
 #pragma unroll
-		for (int k = 0; k < 8; ++k) {
+		for (int k = HS; k < 16; ++k) {
+			v[k] = mkf2 (0.f, 0.f);
+		}
+#pragma unroll
+		for (int k = 0; k < HS; ++k) {
 			cur[k] = nxqc[k];
 			float pk_ = nxp[k];
 			if (nx_shift) { // wave_shr:1 -- lane i reads lane i-1, lane 0 keeps `old` = the scalar-loaded frame
 				pk_ = __uint_as_float (__builtin_amdgcn_update_dpp (__float_as_uint (nxb[k]), __float_as_uint (nxqc[k].y), 0x138, 0xf, 0xf, false));
 			}
-			v[k]     = mkf2 (pk_, nxqc[k].x);
-			v[8 + k] = mkf2 (0.f, 0.f);
+			v[k] = mkf2 (pk_, nxqc[k].x);
 		}
 
 		// spectrum tables, HB bins per batch, one batch in flight ahead of the multiplies
@@ -1088,7 +1097,7 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 				}
 			}
 		};
-		fwd4096w<T, 8> (v, lds, twm, tw1, t, tl, th, [&] () { h_fetch (0); });
+		fwd4096w<T, HS> (v, lds, twm, tw1, t, tl, th, [&] () { h_fetch (0); });
 
 		// Y = Z G0 (+ Z_prev G1); bins >= 2048 use the conjugate of the mirrored bin
 #pragma unroll
@@ -1130,19 +1139,19 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 		__builtin_amdgcn_sched_barrier (0);
 
 		// dry path: frames (s + 2j - Dd, s + 2j + 1 - Dd) = the (q, c) pair DH sample rows back
-		f2 dry[8];
+		f2 dry[HS];
 		if (DH > 0) {
 #pragma unroll
-			for (int k = 0; k < 8; ++k) {
+			for (int k = 0; k < HS; ++k) {
 				dry[k] = (k >= DH) ? cur[k >= DH ? k - DH : 0] : dh[k < DH ? k : 0];
 			}
 #pragma unroll
 			for (int i = 0; i < NDH; ++i) {
-				dh[i] = cur[8 - NDH + i];
+				dh[i] = cur[HS - NDH + i];
 			}
 		} else if (MODE != MODE_HILBERT && !ACC && it >= NP) {
 #pragma unroll
-			for (int k = 0; k < 8; ++k) {
+			for (int k = 0; k < HS; ++k) {
 				const int64_t d0 = s + 2 * (int64_t)(t + 256 * k) - Dd;
 				dry[k]           = mkf2 (ldv (in, n_in, hist, p.hist_len, d0), ldv (in, n_in, hist, p.hist_len, d0 + 1));
 			}
@@ -1150,11 +1159,14 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 
 		inv4096w<T> (v, lds, twm, tw1, t, tl, th);
 
-		C u[8];
+		C u[HS];
 #pragma unroll
-		for (int k = 0; k < 8; ++k) {
-			u[k]   = acc[k] + v[k];
-			acc[k] = v[8 + k];
+		for (int k = 0; k < HS; ++k) {
+			u[k] = k < NT ? acc[k < NT ? k : 0] + v[k] : v[k];
+		}
+#pragma unroll
+		for (int k = 0; k < NT; ++k) {
+			acc[k] = v[HS + k];
 		}
 
 		if (it >= NP) {
@@ -1162,7 +1174,7 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 			if (MODE == MODE_ROT && !ACC && full && out_al8) {
 				const f2 ca2 = mkf2 (ca, ca), sa2 = mkf2 (sa, sa);
 #pragma unroll
-				for (int m = 0; m < 4; ++m) {
+				for (int m = 0; m < HS / 2; ++m) {
 					PROT_GLOBAL f2* __restrict__ ob = reinterpret_cast<PROT_GLOBAL f2*> (uniform_ptr (out + s + 1024 * m));
 #pragma unroll
 					for (int e = 0; e < 2; ++e) {
@@ -1171,7 +1183,7 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 				}
 			} else {
 #pragma unroll
-				for (int k = 0; k < 8; ++k) {
+				for (int k = 0; k < HS; ++k) {
 #pragma unroll
 					for (int h = 0; h < 2; ++h) {
 						const int64_t pos = s + 2 * (int64_t)(t + 256 * k) + h;
@@ -1196,27 +1208,27 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 	}
 }
 
-template <int NP, int MODE>
+template <int NP, int HS, int MODE>
 static hipError_t launch_poly_m (const OlaParams& p, dim3 grid, hipStream_t s)
 {
+	// dry frames from registers when (dry_delay - conv_delay) is a whole number of 512-frame sample rows
+	// that the hop geometry in use actually meets: LV2 48 kHz 3 (HS 10), 96 kHz / CLI 4096 4, CLI 8192 /
+	// LV2 192 kHz 8 (HS 8), CLI 2048 2 (HS 12), CLI 1024 1 (HS 14); anything else re-reads the stream
 	const int  diff = p.dry_delay - p.conv_delay;
 	const int  dd   = (diff > 0 && diff % 512 == 0) ? diff / 512 : 0;
+	constexpr int DHS = HS == 8 ? (NP == 2 ? 8 : 4) : HS == 10 ? 3 : HS == 12 ? 2 : 1;
 	const dim3 block (256);
 	if (p.accumulate) {
-		hipLaunchKernelGGL ((olapoly_kernel<NP, MODE, 0, true>), grid, block, 0, s, p);
-	} else if (MODE != MODE_HILBERT && dd == 3) {
-		hipLaunchKernelGGL ((olapoly_kernel<NP, MODE, 3, false>), grid, block, 0, s, p);
-	} else if (MODE != MODE_HILBERT && dd == 4) {
-		hipLaunchKernelGGL ((olapoly_kernel<NP, MODE, 4, false>), grid, block, 0, s, p);
-	} else if (MODE != MODE_HILBERT && dd == 8) {
-		hipLaunchKernelGGL ((olapoly_kernel<NP, MODE, 8, false>), grid, block, 0, s, p);
+		hipLaunchKernelGGL ((olapoly_kernel<NP, HS, MODE, 0, true>), grid, block, 0, s, p);
+	} else if (MODE != MODE_HILBERT && dd == DHS) {
+		hipLaunchKernelGGL ((olapoly_kernel<NP, HS, MODE, DHS, false>), grid, block, 0, s, p);
 	} else {
-		hipLaunchKernelGGL ((olapoly_kernel<NP, MODE, 0, false>), grid, block, 0, s, p);
+		hipLaunchKernelGGL ((olapoly_kernel<NP, HS, MODE, 0, false>), grid, block, 0, s, p);
 	}
 	return hipGetLastError ();
 }
 
-template <int NP>
+template <int NP, int HS>
 static hipError_t launch_poly_n (const OlaParams& p, int n_chn, hipStream_t s)
 {
 	if (p.n_out <= 0) {
@@ -1225,20 +1237,29 @@ static hipError_t launch_poly_n (const OlaParams& p, int n_chn, hipStream_t s)
 	const int64_t runs = (p.n_out + p.run_frames - 1) / p.run_frames;
 	dim3          grid ((unsigned)runs, (unsigned)n_chn);
 	if (p.hilbert_only) {
-		return launch_poly_m<NP, MODE_HILBERT> (p, grid, s);
+		return launch_poly_m<NP, HS, MODE_HILBERT> (p, grid, s);
 	}
 	if (p.rot_s != nullptr) {
-		return launch_poly_m<NP, MODE_RAMP> (p, grid, s);
+		return launch_poly_m<NP, HS, MODE_RAMP> (p, grid, s);
 	}
-	return launch_poly_m<NP, MODE_ROT> (p, grid, s);
+	return launch_poly_m<NP, HS, MODE_ROT> (p, grid, s);
 }
 
-hipError_t launch_ola_poly (const OlaParams& p, int n_part, int n_chn, hipStream_t s)
+hipError_t launch_ola_poly (const OlaParams& p, int n_part, int hop_rows, int n_chn, hipStream_t s)
 {
-	if ((p.conv_delay & 1) || (p.run_frames % 4096) != 0 || (n_part != 1 && n_part != 2)) {
+	if ((p.conv_delay & 1) || (p.run_frames % (512 * hop_rows)) != 0 || (n_part != 1 && n_part != 2) ||
+	    (hop_rows != 8 && (n_part != 1 || (hop_rows != 10 && hop_rows != 12 && hop_rows != 14)))) {
 		return hipErrorInvalidValue;
 	}
-	return n_part == 1 ? launch_poly_n<1> (p, n_chn, s) : launch_poly_n<2> (p, n_chn, s);
+	if (n_part == 2) {
+		return launch_poly_n<2, 8> (p, n_chn, s);
+	}
+	switch (hop_rows) {
+		case 8: return launch_poly_n<1, 8> (p, n_chn, s);
+		case 10: return launch_poly_n<1, 10> (p, n_chn, s);
+		case 12: return launch_poly_n<1, 12> (p, n_chn, s);
+		default: return launch_poly_n<1, 14> (p, n_chn, s);
+	}
 }
 
 // PROT_OLA_VARIANT (debug/tuning only): 0 = default
@@ -1500,9 +1521,15 @@ __global__ __launch_bounds__ (256, 3) void sweep_mfma_kernel (const SweepParams 
 		return v;
 	};
 	int n_groups = 0, n_live = 0; // tile groups seen / evaluated by this wave (statistics)
+	// This file is compiled with -ffast-math (finite-math-only): no infinities as sentinels.  A wave
+	// whose group has no angle block (g >= nb: 65..96 angles put three blocks on four groups) is
+	// `idle` -- integer logic -- and skips everything; every other wave has at least one valid entry,
+	// so the minima below always end up on real data and kBig never survives a wave_min.
+	const bool      idle = g >= nb;
+	constexpr float kBig = 1.0e18f; // finite, and its square still is
 	float thr2 = 0.f;
-	if (PRUNE) {
-		float lo = __builtin_inff ();
+	if (PRUNE && !idle) {
+		float lo = kBig;
 #pragma unroll
 		for (int q = 0; q < NBLK; ++q) {
 			const int idx = (g + q * G) * 32 + j;
@@ -1511,7 +1538,7 @@ __global__ __launch_bounds__ (256, 3) void sweep_mfma_kernel (const SweepParams 
 			}
 		}
 		lo   = wave_min (lo);
-		thr2 = uniform_f (lo * lo); // +inf for a wave without angles: it has nothing to do
+		thr2 = uniform_f (lo * lo);
 	}
 	// Every wave of angle group g (of this channel) bounds the SAME quantity -- the smallest final
 	// peak among the group's angles -- from below, so the largest bound any of them has found is
@@ -1520,7 +1547,7 @@ __global__ __launch_bounds__ (256, 3) void sweep_mfma_kernel (const SweepParams 
 	// wave whose own stripes are quiet never learns that another wave has already seen the peaks.
 	unsigned* const thr_slot = p.thr ? reinterpret_cast<unsigned*> (p.thr) + ((int64_t)c * 4 + g) : nullptr;
 	auto share = [&] (float lo) { // lo: this wave's bound (not squared); returns the best bound known
-		if (thr_slot != nullptr && lo < __builtin_inff ()) {
+		if (thr_slot != nullptr && !idle) {
 			float best = lo;
 			if (lane == 0) {
 				const unsigned old = atomicMax (thr_slot, __float_as_uint (lo));
@@ -1538,8 +1565,8 @@ __global__ __launch_bounds__ (256, 3) void sweep_mfma_kernel (const SweepParams 
 	const int64_t span = (int64_t)kMfmaSuper * 32;
 	bool          first = true;
 	for (int64_t base = p.t_begin + (int64_t)blockIdx.x * span; base < p.t_end; base += (int64_t)gridDim.x * span) {
-		if (PRUNE && !first) {
-			float lo = __builtin_inff ();
+		if (PRUNE && !first && !idle) {
+			float lo = kBig;
 #pragma unroll
 			for (int q = 0; q < NBLK; ++q) {
 #pragma unroll
@@ -1599,6 +1626,9 @@ __global__ __launch_bounds__ (256, 3) void sweep_mfma_kernel (const SweepParams 
 					r2m               = fmaxf (r2m, __uint_as_float (sw[0]) + __uint_as_float (sw[1]));
 				}
 				live = __builtin_amdgcn_ballot_w64 (r2m * 1.0001f > thr2) != 0;
+			}
+			if (PRUNE && idle) {
+				live = false; // no angles in this wave's group: its products are all zero
 			}
 			if (PRUNE) {
 				n_live += live ? 1 : 0;

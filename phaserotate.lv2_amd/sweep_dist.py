@@ -24,9 +24,11 @@ def plan_shards(n_frames, blksiz, world, align=2):
     """Split ceil(n_frames / blksiz) data blocks into `world` contiguous ranges
     [(b0, b1), ...]; earlier ranks get the remainder.  Empty ranges are allowed
     (more ranks than blocks).  Interior boundaries fall on multiples of `align`
-    blocks: the device engine transforms hops in pairs, and a shard that starts
-    on a pair boundary reproduces the single-GPU arithmetic bit for bit (so the
-    merged table, and its argmin, are identical, not just within tolerance)."""
+    blocks -- pass Engine.shard_align_blocks(): the device engine works in transform blocks of
+    info.run_align frames (a pair of hops, or 4096..7168 frames in polyphase form), and a shard that
+    starts on such a boundary reproduces the single-GPU arithmetic bit for bit (so the merged
+    table, and its argmin, are identical, not just within tolerance).  The default 2 is the
+    direct form at blksiz >= 2048."""
     nb = (n_frames + blksiz - 1) // blksiz
     units = (nb + align - 1) // align
     base, rem = divmod(units, world)

@@ -28,7 +28,9 @@ def test_library_exports_every_declared_symbol(pkg):
     out = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
     exported = set(re.findall(r" T (prot_[a-z0-9_]+)", out))
     assert set(declared_symbols()) <= exported
-    assert lib.prot_abi_version() == 1
+    # library and header agree on the ABI revision (2: prot_info.run_align, prot_sweep_stats, PROT_CFG_* flags)
+    declared = int(re.search(r"#define\s+PROT_ABI_VERSION\s+(\d+)", open(HDR).read()).group(1))
+    assert lib.prot_abi_version() == declared == 2
 
 
 def test_header_is_plain_c():

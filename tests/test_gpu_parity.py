@@ -125,10 +125,10 @@ def test_lv2_run_stream(pkg, rate, bufsize, angle, n_chn):
 
 
 def test_lv2_three_device_geometries_are_the_same_filter(pkg):
-    """LV2 48 kHz filter in the three device forms: direct form with two 2048-tap partitions
-    sharing a forward transform (default), polyphase (the odd taps on the stream read as complex
-    samples, one 2048-tap partition, 4096-frame blocks) and one zero-padded 4096-pt FFT per
-    1024-frame hop -- same LTI filter."""
+    """LV2 48 kHz filter in the three device forms: polyphase (default: the odd taps on the stream
+    read as complex samples, one partition, 5120-frame blocks), direct form with two 2048-tap
+    partitions sharing a forward transform, and one zero-padded 4096-pt FFT per 1024-frame hop --
+    same LTI filter."""
     import torch
     dev = torch.device("cuda:0")
     n = 300001  # odd: the last complex sample of the polyphase form is half outside
@@ -136,7 +136,8 @@ def test_lv2_three_device_geometries_are_the_same_filter(pkg):
     rot = np.array([0.28, -0.96], np.float32)
     ys = []
     # default for <= 4096 taps is the direct form (measured 2 % faster than polyphase there)
-    want = {0: (2, 2048), pkg.CFG_POLYPHASE: (1, 4096), pkg.CFG_DIRECT_FORM: (2, 2048), pkg.CFG_SINGLE_FFT_PER_HOP: (1, 1024)}
+    # (polyphase, the default: the 1536 odd taps need a 6-row tail, so 10 rows x 512 = 5120 frames are new per block)
+    want = {0: (1, 5120), pkg.CFG_POLYPHASE: (1, 5120), pkg.CFG_DIRECT_FORM: (2, 2048), pkg.CFG_SINGLE_FFT_PER_HOP: (1, 1024)}
     for flags in want:
         e = pkg.Engine(pkg.KIND_LV2, 48000, 1, flags=flags)
         assert (e.info.partitions, e.info.hop) == want[flags]
@@ -150,10 +151,11 @@ def test_lv2_three_device_geometries_are_the_same_filter(pkg):
         assert (ys[0] - other).abs().max().item() < TOL
 
 
-@pytest.mark.parametrize("kind,param", [(1, 96000), (1, 192000), (0, 4096), (0, 8192), (0, 16384)])
-def test_polyphase_equals_direct_form(pkg, kind, param):
-    """Every FIR of more than 2049 taps, polyphase vs direct form, on misaligned (odd-offset)
-    stereo streams, stateless and stateful in uneven chunks."""
+@pytest.mark.parametrize("kind,param,hop", [(1, 48000, 5120), (1, 96000, 4096), (1, 192000, 4096), (0, 1024, 7168),
+                                            (0, 2048, 6144), (0, 4096, 4096), (0, 8192, 4096), (0, 16384, 4096)])
+def test_polyphase_equals_direct_form(pkg, kind, param, hop):
+    """Every FIR length, polyphase vs direct form, on misaligned (odd-offset) stereo streams, stateless
+    and stateful in uneven chunks.  Short partitions take long hops (5120 / 6144 / 7168 frames per block)."""
     import torch
     dev = torch.device("cuda:0")
     n, stride = 150001, 150003            # odd stride: channel 1 starts 4 bytes off an 8-byte boundary
@@ -163,7 +165,7 @@ def test_polyphase_equals_direct_form(pkg, kind, param):
     res = []
     for flags in (pkg.CFG_POLYPHASE, pkg.CFG_DIRECT_FORM):
         e = pkg.Engine(kind, param, 2, flags=flags)
-        assert (e.info.hop == 4096) == (flags == pkg.CFG_POLYPHASE)  # really two different forms
+        assert (e.info.hop == hop) == (flags == pkg.CFG_POLYPHASE)  # really two different forms
         yb = torch.zeros(2 * stride + 1, device=dev)
         y = yb[1:]
         torch.cuda.synchronize()
@@ -474,7 +476,9 @@ def test_full_size_sweep_shards_equal_single_pass(pkg):
     torch.cuda.synchronize()
     one.sweep_dev(x.data_ptr(), n, n, 0, 360, 1, -1, pk1.data_ptr(), pkg.F_STREAM_START | pkg.F_STREAM_END)
     one.sync()
-    plan = sweep_dist.plan_shards(n, P, 2)
+    # shard boundaries on whole device transform blocks (6144 frames = 3 blocks for this engine)
+    plan = sweep_dist.plan_shards(n, P, 2, align=one.shard_align_blocks())
+    assert all(b0 % one.shard_align_blocks() == 0 for b0, _ in plan)
     pk2 = torch.zeros((n_chn, 360), device=dev)
     for r, (b0, b1) in enumerate(plan):
         f0, nf = sweep_dist.shard_frames(n, P, plan, r)
@@ -583,3 +587,28 @@ def test_pruned_sweep_is_bit_identical_to_unpruned(pkg, signal):
         assert frac_pruned < 0.45, frac_pruned  # at most the loud quarter (+ margin) is evaluated
     if signal == "growing":
         assert frac_pruned > 0.9, frac_pruned  # every group holds a new record: nothing may be skipped
+
+
+@pytest.mark.parametrize("stride,blocks", [(1, 12), (3, 4), (4, 3), (5, 3), (6, 2), (8, 2), (24, 1)])
+def test_pruned_sweep_every_angle_block_layout(pkg, stride, blocks):
+    """The sweep kernel spreads 32-angle blocks over four wave groups; 65..96 angles (3 blocks) leave one
+    group without a block -- its waves must neither evaluate nor publish a bound --, 33..64 use two groups,
+    <= 32 one.  Pruned and unpruned tables must be bit-identical in every layout, and equal to the oracle's
+    within the gate."""
+    from phaserotate_lv2_amd import sweep_dist
+    P, n = 2048, 300000
+    x = np.ascontiguousarray(np.stack([0.6 * harmonic_stack(n, 48000) + 0.05 * xorshift_uniform(n, seed=21),
+                                       0.3 * xorshift_uniform(n, seed=22)], 1), np.float32)
+    x[150000:, :] *= 0.05  # something to skip
+    swept = [k for k in sweep_dist.angle_list(0, 360, stride) if k != 0]  # angle 0 is the raw peak, not swept
+    assert (len(swept) + 31) // 32 == blocks
+    passes = ((0, 360, stride),)
+    a, frac = _sweep_table(pkg, x, P, stride, prune=True, passes=passes)
+    b, _ = _sweep_table(pkg, x, P, stride, prune=False, passes=passes)
+    assert a.tobytes() == b.tobytes()
+    assert (a[:, swept] > 0).all()
+    o = orc.CliEngine(P, 2)
+    o.analyze_file(x, 0, 360, stride)
+    ref = o.peaks()
+    d_db = np.abs(20 * np.log10(a[:, swept] / ref[:, swept]))
+    assert d_db.max() < 1e-3, d_db.max()

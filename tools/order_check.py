@@ -12,8 +12,13 @@ x = (torch.rand(n, device=dev) - 0.5); y = torch.empty_like(x)
 rot = np.array([0.0, -1.0], np.float32)
 ts = torch.cuda.Stream(); torch.cuda.set_stream(ts); st = ts.cuda_stream
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-engs = {"poly48": pkg.Engine(pkg.KIND_LV2, 48000, 1, flags=0), "direct48": pkg.Engine(pkg.KIND_LV2, 48000, 1, flags=pkg.CFG_DIRECT_FORM),
-        "poly96": pkg.Engine(pkg.KIND_LV2, 96000, 1, flags=0), "direct96": pkg.Engine(pkg.KIND_LV2, 96000, 1, flags=pkg.CFG_DIRECT_FORM)}
+PF, DF = pkg.CFG_POLYPHASE, pkg.CFG_DIRECT_FORM
+engs = {"poly48": pkg.Engine(pkg.KIND_LV2, 48000, 1, flags=PF), "direct48": pkg.Engine(pkg.KIND_LV2, 48000, 1, flags=DF),
+        "poly96": pkg.Engine(pkg.KIND_LV2, 96000, 1, flags=PF), "direct96": pkg.Engine(pkg.KIND_LV2, 96000, 1, flags=DF),
+        "poly_cli2048": pkg.Engine(pkg.KIND_CLI, 2048, 1, flags=PF), "direct_cli2048": pkg.Engine(pkg.KIND_CLI, 2048, 1, flags=DF),
+        "poly_cli1024": pkg.Engine(pkg.KIND_CLI, 1024, 1, flags=PF), "direct_cli1024": pkg.Engine(pkg.KIND_CLI, 1024, 1, flags=DF)}
+for k, e in engs.items():
+    print("%-15s partitions %d hop %d" % (k, e.info.partitions, e.info.hop))
 def run(e, k):
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
@@ -31,4 +36,4 @@ for r in range(R):
         res[name].append(run(engs[name], 20))
 for name in names:
     v = np.array(res[name])
-    print("%-9s median %.4f  min %.4f  max %.4f  (n=%d)" % (name, np.median(v), v.min(), v.max(), len(v)))
+    print("%-15s median %.4f  min %.4f  max %.4f  (n=%d)" % (name, np.median(v), v.min(), v.max(), len(v)))
