@@ -6,9 +6,9 @@ phase-rotate, % of the HBM roofline at 1 GPU.
 
 Workload (BASELINE.json configs[1], "LV2 mono run(), 4096-pt OLA, 48 kHz"):
 the LV2 48 kHz filter (3072-tap windowed Hilbert FIR, latency 1792) on 4096-point
-overlap-add FFTs, two 2048-tap partitions sharing one forward FFT per 2048-frame hop,
-over a device-resident mono stream of 2^27 frames per GPU (512 MiB in + 512 MiB out,
-beyond the 256 MiB Infinity Cache).  One "step" = one pass of the hot path over that
+overlap-add FFTs in polyphase form (the FIR's 1536 odd taps applied to the stream read
+as complex samples; 5120 new frames per transform pair), over a device-resident mono
+stream of 2^27 frames per GPU (512 MiB in + 512 MiB out, beyond the 256 MiB Infinity Cache).  One "step" = one pass of the hot path over that
 stream = one kernel launch.  Inputs are resident in HBM before the timed
 region; outputs stay in HBM.
 
@@ -158,7 +158,7 @@ def main():
         try:
             tj = json.load(open(tpath))
             # PMC traffic is per kernel: never attach another kernel's bytes to this line
-            traffic = tj.get("hbm_bytes_per_launch") if (args.frames_log2 == 27 and "ola4096p2_kernel<prot::T32, 0, 6" in tj.get("kernel", "")) else None
+            traffic = tj.get("hbm_bytes_per_launch") if (args.frames_log2 == 27 and "olapoly_kernel<1, 10, 0, 3" in tj.get("kernel", "")) else None
         except Exception:
             traffic = None
     out = {
@@ -167,8 +167,8 @@ def main():
         "ms_per_step": wall / args.steps * 1e3, "preroll_steps": args.preroll,
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "LV2 mono 48 kHz: 3072-tap Hilbert FIR (latency 1792), 4096-pt OLA, two 2048-tap "
-                               "partitions sharing one forward FFT per 2048-frame hop, angle 90 deg, "
+        "config": {"workload": "LV2 mono 48 kHz: 3072-tap Hilbert FIR (latency 1792), 4096-pt OLA in polyphase form (1536 odd taps "
+                               "on the stream read as complex samples, 5120 new frames per transform pair), angle 90 deg, "
                                "device-resident stream of 2^%d frames per GPU per step" % args.frames_log2,
                    "partitions": int(eng.info.partitions),
                    "fftlen": int(eng.info.fftlen), "hop": int(eng.info.hop), "firlen": int(eng.info.firlen),
@@ -176,18 +176,19 @@ def main():
                    "parallelism": "independent streams x%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "prot::ola4096p2_kernel<T32, 0, 6, false> (steady rotation, dry path from registers, "
-                               "packed-fp32 butterflies)", "kernel_ms": kern_ms,
+                     "kernel": "prot::olapoly_kernel<1, 10, 0, 3, false> (one partition of the odd taps, 10 new sample rows per "
+                               "block, steady rotation, dry path from registers, packed-fp32 butterflies)", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": bytes_per_launch},
     }
     eng.close()
 
     if not args.no_extra:
-        # same filter, polyphase form (not the default at <= 4096 taps: it measures ~2 % slower there)
-        eng2 = pkg.Engine(pkg.KIND_LV2, 48000, 1, device=local_rank, flags=pkg.CFG_POLYPHASE)
+        # same filter, direct form: two 2048-tap partitions sharing one forward FFT per 2048-frame hop
+        eng2 = pkg.Engine(pkg.KIND_LV2, 48000, 1, device=local_rank, flags=pkg.CFG_DIRECT_FORM)
         wall2, kms2 = timed(eng2, args.steps, args.warmup, n)
-        out["polyphase_form"] = {
-            "workload": "LV2 mono 48 kHz filter, polyphase form: odd taps on the stream read as complex samples, one partition (olapoly_kernel<1,...>)",
+        out["direct_form"] = {
+            "workload": "LV2 mono 48 kHz filter, direct form: two 2048-tap partitions, frequency-domain delay line, 4096 frames "
+                        "per transform pair (ola4096p2_kernel); interleaved A/B vs the headline: tools/order_check.py",
             "value": world * n * args.steps / wall2, "unit": "frames/s",
             "roofline_frac": 8.0 * n / (kms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": kms2}
         eng2.close()
@@ -210,7 +211,7 @@ def main():
         # the CLI engine A (blksiz 2048: 2048-tap FIR, 4096-pt OLA, hop 2048) on the same stream
         engA = pkg.Engine(pkg.KIND_CLI, 2048, 1, device=local_rank)
         wallA, kmsA = timed(engA, args.steps, args.warmup, n)
-        out["also"] = {"workload": "CLI engine blksiz 2048: 2048-tap FIR, 4096-pt OLA, hop 2048",
+        out["also"] = {"workload": "CLI engine blksiz 2048: 2048-tap FIR, 4096-pt OLA, polyphase (1024 odd taps, 6144 new frames per transform pair)",
                        "value": world * n * args.steps / wallA, "unit": "frames/s",
                        "roofline_frac": 8.0 * n / (kmsA * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": kmsA}
         engA.close()

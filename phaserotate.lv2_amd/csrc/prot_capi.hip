@@ -252,12 +252,13 @@ uint64_t file_chunk_frames (const prot_engine* e)
 	return std::max<uint64_t> (L, ((uint64_t)1 << 22) / L * L);
 }
 
-int pick_run_frames (const prot_engine* e, uint64_t n_out, int n_chn)
+int pick_run_frames (const prot_engine* e, uint64_t n_out, int n_chn, int unit_frames = 0)
 {
 	// One workgroup per run.  Long streams: fill every resident-workgroup slot of the
 	// chip (CUs x 3, LDS-limited) a whole number of times so no partial last round is
 	// left, with runs long enough (<= 96 pairs) that the halo re-computation stays ~2 %.
-	const int     pair  = e->use_poly ? (int)e->info.hop : 2 * (int)e->info.hop;
+	// unit_frames: the transform block of the kernel that will run (default: this engine's own geometry)
+	const int     pair  = unit_frames > 0 ? unit_frames : (int)e->info.run_align;
 	const int64_t pairs = (int64_t)((n_out + pair - 1) / pair);
 	int64_t       ppr   = 1;
 	if (e->pairs_per_run_override > 0) {
@@ -831,7 +832,8 @@ int prot_apply_dev_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uin
 	p.H          = e->use_poly ? e->d_Hd.p : e->d_H.p;
 	p.tw         = e->d_tw.p;
 	p.rot        = e->d_rot.p;
-	p.run_frames = pick_run_frames (e, n_out, nc);
+	// the fp16 kernels are direct-form (pairs of 2048-frame hops) whatever form the fp32 engine uses
+	p.run_frames = pick_run_frames (e, n_out, nc, f16_p2 ? 4096 : 2 * 256 * e->hopseg);
 	p.conv_delay = (int)e->info.conv_delay;
 	p.dry_delay  = (int)e->info.dry_delay;
 	hipError_t err = f16_p2 ? prot::launch_ola4096_p2_f16 (p, nc, s) : prot::launch_ola4096_f16 (p, e->hopseg, nc, s);
