@@ -277,10 +277,12 @@ int pick_run_frames (const prot_engine* e, uint64_t n_out, int n_chn, int unit_f
 	return (int)std::min<int64_t> (ppr * pair, INT_MAX / 2);
 }
 
+int hist_advance (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_in, int chn0, int n_chn, hipStream_t s);
+
 // core of prot_apply_dev / the Hilbert pass of the sweep
 int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_in, float* d_out,
                 int64_t out_stride, uint64_t n_out, const float* d_rot, const float* d_rot_s,
-                bool hilbert_only, bool stateless, int chn0, int n_chn, hipStream_t s)
+                bool hilbert_only, bool stateless, int chn0, int n_chn, hipStream_t s, bool advance_hist = false)
 {
 	prot::OlaParams p {};
 	p.in           = d_in + (int64_t)chn0 * in_stride;
@@ -288,6 +290,10 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 	p.n_in         = (int64_t)n_in;
 	p.hist         = stateless ? nullptr : e->d_hist[e->hist_cur].p + (size_t)chn0 * e->info.history;
 	p.hist_len     = (int)e->info.history;
+	// all channels, something to launch: the first OLA launch also writes the next call's history
+	// (other buffer of the pair) and the separate history kernel is skipped
+	const bool fuse_hist = advance_hist && !stateless && n_out > 0 && chn0 == 0 && n_chn == (int)e->info.n_chn;
+	p.hist_out     = fuse_hist ? e->d_hist[1 - e->hist_cur].p : nullptr;
 	p.out          = d_out + (int64_t)chn0 * out_stride;
 	p.out_stride   = out_stride;
 	p.n_out        = (int64_t)n_out;
@@ -297,6 +303,17 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 	p.run_frames   = pick_run_frames (e, n_out, n_chn);
 	p.dry_delay    = (int)e->info.dry_delay;
 	p.hilbert_only = hilbert_only ? 1 : 0;
+	// history bookkeeping of an advancing call: flip the buffer pair (fused) or run the history kernel
+	auto finish = [&] () -> int {
+		if (!advance_hist || stateless) {
+			return PROT_OK;
+		}
+		if (fuse_hist) {
+			e->hist_cur = 1 - e->hist_cur;
+			return PROT_OK;
+		}
+		return hist_advance (e, d_in, in_stride, n_in, chn0, n_chn, s);
+	};
 	if (e->use_poly) {
 		const uint32_t np = std::min<uint32_t> (2, e->info.partitions); // partitions of g per launch
 		for (uint32_t l = 0; l < e->info.partitions / np; ++l) {
@@ -307,8 +324,9 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 			if (err != hipSuccess) {
 				return hip_fail (err, "polyphase ola kernel launch");
 			}
+			p.hist_out = nullptr;
 		}
-		return PROT_OK;
+		return finish ();
 	}
 	if (e->use_p2) {
 		for (uint32_t pair = 0; pair < e->info.partitions / 2; ++pair) {
@@ -319,8 +337,9 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 			if (err != hipSuccess) {
 				return hip_fail (err, "ola p2 kernel launch");
 			}
+			p.hist_out = nullptr;
 		}
-		return PROT_OK;
+		return finish ();
 	}
 	for (uint32_t sp = 0; sp < e->info.partitions; ++sp) {
 		p.H          = e->d_H.p + (size_t)sp * e->info.fftlen;
@@ -330,8 +349,9 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 		if (err != hipSuccess) {
 			return hip_fail (err, "ola kernel launch");
 		}
+		p.hist_out = nullptr;
 	}
-	return PROT_OK;
+	return finish ();
 }
 
 // advance the per-channel input history by one chunk (channels [chn0, chn0+n_chn))
@@ -771,12 +791,11 @@ int prot_apply_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 	}
 	const bool stateless = flags & PROT_F_STATELESS;
 	int rc = ola_launch (e, d_in, in_stride, n_in, d_out, out_stride, n_out, e->d_rot.p, nullptr,
-	                     flags & PROT_F_HILBERT, stateless, 0, nc, s);
+	                     flags & PROT_F_HILBERT, stateless, 0, nc, s, /*advance_hist*/ true);
 	if (rc) {
 		return rc;
 	}
 	if (!stateless) {
-		rc = hist_advance (e, d_in, in_stride, n_in, 0, nc, s);
 		e->pos += n_in;
 	}
 	return rc;
@@ -792,12 +811,12 @@ int prot_apply_dev_ramp (prot_engine* e, const float* d_in, int64_t in_stride, u
 	hipStream_t s         = pick_stream (e, stream);
 	const int   nc        = (int)e->info.n_chn;
 	const bool  stateless = flags & PROT_F_STATELESS;
-	int rc = ola_launch (e, d_in, in_stride, n_in, d_out, out_stride, n_out, nullptr, d_rot, false, stateless, 0, nc, s);
+	int rc = ola_launch (e, d_in, in_stride, n_in, d_out, out_stride, n_out, nullptr, d_rot, false, stateless, 0, nc, s,
+	                     /*advance_hist*/ true);
 	if (rc) {
 		return rc;
 	}
 	if (!stateless) {
-		rc = hist_advance (e, d_in, in_stride, n_in, 0, nc, s);
 		e->pos += n_in;
 	}
 	return rc;
@@ -1068,7 +1087,10 @@ int prot_lv2_run (prot_engine* e, const float* const* in, float* const* out, uin
 	// straight from / to the pinned host block over the host link -- a run() call is two kernel
 	// launches and one stream sync, no copy commands.  PROT_LV2_STAGED=1 keeps the staged route
 	// (H2D copies -> device buffers -> D2H copy) for comparison.
-	static const bool staged = getenv ("PROT_LV2_STAGED") != nullptr;
+	// Measured (tools/run_latency.py): 64..1024-frame buffers 37..42 us zero-copy vs 46..47 us staged; at 8192 frames the
+	// DMA copies win (70 vs 76 us: 64 KiB over the host link from inside a latency-bound kernel) -- staged above 4096 samples.
+	static const bool force_staged = getenv ("PROT_LV2_STAGED") != nullptr;
+	const bool        staged       = force_staged || n * nc > 4096;
 	if ((rc = e->h_io.ensure (n * nc * 4 + 2 * (size_t)nc)) ||
 	    (staged && ((rc = e->d_in.ensure (n * nc)) || (rc = e->d_out.ensure (n * nc)) || (rc = e->d_rot_s.ensure (2 * n * nc))))) {
 		return rc;
@@ -1158,16 +1180,13 @@ int prot_lv2_run (prot_engine* e, const float* const* in, float* const* out, uin
 			}
 			d_rot_c = h_rotc;
 		}
-		rc = ola_launch (e, h_in, (int64_t)n, n, h_out, (int64_t)n, n, d_rot_c, steady ? nullptr : h_rot, false, false, 0, (int)nc, s);
-		if (rc) {
-			return rc;
-		}
-		rc = hist_advance (e, h_in, (int64_t)n, n, 0, (int)nc, s);
+		rc = ola_launch (e, h_in, (int64_t)n, n, h_out, (int64_t)n, n, d_rot_c, steady ? nullptr : h_rot, false, false, 0, (int)nc, s,
+		                 /*advance_hist*/ true); // one kernel per run(): the OLA launch writes the next history as well
 		e->pos += n;
 		if (rc) {
 			return rc;
 		}
-		HIP_TRY (hipStreamSynchronize (s));
+		HIP_TRY (hipStreamSynchronize (s)); // (polling hipStreamQuery instead measured the same: the runtime already spins)
 		for (uint32_t c = 0; c < nc; ++c) {
 			memcpy (out[c], h_out + c * n, n * sizeof (float));
 		}

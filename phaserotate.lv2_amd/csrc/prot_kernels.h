@@ -17,6 +17,9 @@ struct OlaParamsT {
 	int64_t       n_in;       // valid input frames; reads at >= n_in are silence
 	const S*      hist;       // device, [n_chn][hist_len]: frames before in[0]; NULL = silence
 	int32_t       hist_len;
+	S*            hist_out;   // device, [n_chn][hist_len] or NULL: the kernel also writes the NEXT call's history
+	                          // (the last hist_len frames of [hist | in]) here, every workgroup one slice;
+	                          // must not alias hist or in
 	S*            out;        // device, planar
 	int64_t       out_stride;
 	int64_t       n_out;      // emit t in [0, n_out)

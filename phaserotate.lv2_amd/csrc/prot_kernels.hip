@@ -64,6 +64,26 @@ PROT_DEV PROT_GLOBAL P* uniform_ptr (P* q)
 	return (PROT_GLOBAL P*)(((uint64_t)hi << 32) | lo);
 }
 
+// Fused history advance: workgroup b of a channel copies slice b of the next call's history (the last
+// hist_len frames of [hist | in | silence]) -- saves the separate history kernel and its launch gap on
+// small stateful launches (LV2 run(), batched buffers).  Called before any early return.
+template <class S>
+PROT_DEV void hist_write_slice (const OlaParamsT<S>& p, int c, int t)
+{
+	if (p.hist_out == nullptr) {
+		return;
+	}
+	const int per = (p.hist_len + (int)gridDim.x - 1) / (int)gridDim.x;
+	const int i0  = (int)blockIdx.x * per;
+	const int i1  = i0 + per < p.hist_len ? i0 + per : p.hist_len;
+	const S* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
+	const S* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
+	S* __restrict__ ho         = p.hist_out + (int64_t)c * p.hist_len;
+	for (int i = i0 + t; i < i1; i += 256) {
+		ho[i] = (S)ldv (in, p.n_in, hist, p.hist_len, p.n_in - p.hist_len + i);
+	}
+}
+
 // ------------------------------------------------------------ OLA, FFT-4096
 constexpr int kL1 = 272; // exchange between pass 1 and 2 (and inverse mirror)
 constexpr int kL2 = 258; // forward exchange 2 and inverse exchange A share slots (n0*kL2 + t):
@@ -113,6 +133,7 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 	const int     t  = threadIdx.x;
 	const int     c  = blockIdx.y;
 	const int64_t r0 = (int64_t)blockIdx.x * p.run_frames;
+	hist_write_slice (p, blockIdx.y, threadIdx.x);
 	if (r0 >= p.n_out) {
 		return;
 	}
@@ -630,6 +651,7 @@ __global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaPa
 	const int     t  = threadIdx.x;
 	const int     c  = blockIdx.y;
 	const int64_t r0 = (int64_t)blockIdx.x * p.run_frames;
+	hist_write_slice (p, blockIdx.y, threadIdx.x);
 	if (r0 >= p.n_out) {
 		return;
 	}
@@ -966,6 +988,7 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 	const int     t  = threadIdx.x;
 	const int     c  = blockIdx.y;
 	const int64_t r0 = (int64_t)blockIdx.x * p.run_frames;
+	hist_write_slice (p, blockIdx.y, threadIdx.x);
 	if (r0 >= p.n_out) {
 		return;
 	}

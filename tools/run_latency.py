@@ -19,7 +19,8 @@ for nchn, bs in ((1, 64), (1, 256), (1, 1024), (2, 1024), (1, 8192)):
     print("  chn %%d buf %%5d: median %%.1f us  p10 %%.1f  p99 %%.1f" %% (nchn, bs, np.median(ts), np.percentile(ts, 10), np.percentile(ts, 99)), flush=True)
     g.close()
 ''' % ROOT
-for name, env in (("zero-copy", {}), ("staged", {"PROT_LV2_STAGED": "1"}), ("zero-copy", {}), ("staged", {"PROT_LV2_STAGED": "1"})):
+for name, env in (("default (zero-copy up to 4096 samples per call)", {}), ("staged", {"PROT_LV2_STAGED": "1"}),
+                  ("default (zero-copy up to 4096 samples per call)", {}), ("staged", {"PROT_LV2_STAGED": "1"})):
     print(name, flush=True)
     e = dict(os.environ); e.update(env)
     subprocess.run([sys.executable, "-c", CHILD], env=e)
