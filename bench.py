@@ -296,8 +296,8 @@ def bench_cfg3(args, pkg, torch, np, dev, ts, st, local_rank, barrier, world):
 
 def bench_run_host(pkg, np, local_rank):
     """BASELINE config 2, literal form: the LV2 run() drop-in on HOST buffers, 1024 frames per
-    call (zero-copy: the kernels read/write the pinned host block over the host link; two launches
-    + one stream sync per call).  Launch/sync-latency-bound; never `value`."""
+    call (zero-copy: the kernel reads/writes the pinned host block over the host link and writes the
+    next call's input history; one launch + one stream sync per call).  Latency-bound; never `value`."""
     g = pkg.Lv2Instance(48000, 1, device=local_rank)
     g.activate()
     x = (np.random.default_rng(3).random((1, 1024), dtype=np.float32) - 0.5)
@@ -309,8 +309,8 @@ def bench_run_host(pkg, np, local_rank):
         g.run(x, 90.0)
     dt = (time.perf_counter() - t0) / calls
     g.close()
-    return {"workload": "prot_lv2_run, mono 48 kHz, 1024-frame host buffers (zero-copy pinned host block: OLA kernel + "
-                        "history kernel + stream sync per call, ctypes call overhead included)",
+    return {"workload": "prot_lv2_run, mono 48 kHz, 1024-frame host buffers (zero-copy pinned host block: one OLA launch, which "
+                        "also writes the next history, + stream sync per call; ctypes call overhead included)",
             "us_per_run": dt * 1e6, "frames_per_s": 1024 / dt, "realtime_factor_48k": 1024 / dt / 48000.0}
 
 
