@@ -1,6 +1,18 @@
 // prot_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the phase-rotation
-// hot path.  wave64 throughout; no hipFFT/rocFFT, no MFMA (the path is a
-// butterfly network, not a contraction).
+// hot path.  wave64 throughout; no hipFFT/rocFFT; MFMA only in the sweep (the OLA
+// path is a butterfly network, not a contraction).
+//
+// Three OLA kernels share the 4096-point transform pair (fwd4096w / inv4096w or the
+// inline version of ola4096_kernel), the register-resident overlap-add tail and dry path,
+// the halo scheme and the fused history write:
+//   olapoly_kernel   -- polyphase form (odd taps on the stream read as complex samples,
+//                       512 HS new frames per block): default except at 4096 taps, the
+//                       headline kernel; described at its definition
+//   ola4096p2_kernel -- direct form, two 2048-tap partitions sharing a forward transform:
+//                       default at 4096 taps (LV2 96 kHz, CLI blksiz 4096), fp16 path
+//   ola4096_kernel   -- direct form, one partition (<= 3072 taps), described here:
+// sweep_mfma_kernel  -- K7, the per-angle abs-max as rank-2 MFMA products, with exact
+//                       pruning of frame groups that cannot raise a maximum
 //
 // ola4096_kernel -- overlap-add Hilbert convolution + rotation, one
 //   workgroup (256 threads = 4 waves) per run of consecutive hops of one
@@ -944,7 +956,7 @@ hipError_t launch_ola4096_p2_f16 (const OlaParamsH& p, int n_chn, hipStream_t s)
 }
 
 // --------------------------------------------------------------------------------------
-// olapoly_kernel -- FIRs longer than 2049 taps in POLYPHASE form.
+// olapoly_kernel -- POLYPHASE form: the default for every FIR length except 4096 taps.
 //
 // The Hilbert FIR is zero at every even tap (src/phaserotate.c:374-401, cli/phase-rotate.cc:
 // 128-165: h[n] ~ cot(pi m/N) for odd m = n - N/2 only, N/2 even), so
@@ -954,14 +966,17 @@ hipError_t launch_ola4096_p2_f16 (const OlaParamsH& p, int n_chn, hipStream_t s)
 // reinterpretation of consecutive frames) turns the convolution into ONE complex convolution
 // g * z = v[2j] + i v[2j+1]  -- so the two real signals that ride in the re/im of the complex
 // transform are the two phases of one stream, the filter is half as long (3072 / 4096 taps fit
-// ONE 2048-tap partition: no second spectrum multiply, no delayed spectrum in registers, half
-// the table), and a block is 4096 consecutive frames of one stream (one halo block per run).
+// ONE partition: no second spectrum multiply, no delayed spectrum in registers, half the
+// table), and a block is 512 HS consecutive frames of one stream (one halo block per run):
+// the zero padding only has to cover the tail of g, so 1536 / 1024 / 512 taps take HS = 10 /
+// 12 / 14 rows of 256 new samples per 4096-point transform instead of 8.
 // FIRs of 8192 taps and more take NP = 2 partitions of g per launch (frequency-domain delay
 // line as in ola4096p2_kernel), i.e. half the launches of the direct form.
 // The dry frames (x delayed by dry_delay) pair up as (x[2j], x[2j+1]), one frame off the
-// transform's input pairs, so a thread loads three consecutive frames per sample: p = x[a-1]
-// (dword) and (q, c) = x[a], x[a+1] (one aligned 8-byte load); (p, q) feeds the transform,
-// (q, c) is kept for the dry path -- the stream is still read from HBM once.
+// transform's input pairs (x[2j-1], x[2j]): a thread needs p = x[a-1], q = x[a], c = x[a+1].
+// The stream is read exactly once as aligned 8-byte pairs (q, c); p is the c of lane t-1 (one
+// DPP wave shift at the point of use; lane 0 of a wave gets it from a scalar load).  (p, q) feeds
+// the transform, (q, c) is kept for the dry path.
 // --------------------------------------------------------------------------------------
 template <int NP, int HS, int MODE, int DH, bool ACC>
 __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
