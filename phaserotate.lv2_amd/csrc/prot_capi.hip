@@ -292,7 +292,8 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 	p.hist_len     = (int)e->info.history;
 	// all channels, something to launch: the first OLA launch also writes the next call's history
 	// (other buffer of the pair) and the separate history kernel is skipped
-	const bool fuse_hist = advance_hist && !stateless && n_out > 0 && chn0 == 0 && n_chn == (int)e->info.n_chn;
+	const bool fuse_hist = advance_hist && !stateless && n_out > 0 && chn0 == 0 && n_chn == (int)e->info.n_chn &&
+	                       !(e->use_poly && e->info.partitions >= 2); // the two-partition polyphase kernel does not write history
 	p.hist_out     = fuse_hist ? e->d_hist[1 - e->hist_cur].p : nullptr;
 	p.out          = d_out + (int64_t)chn0 * out_stride;
 	p.out_stride   = out_stride;

@@ -78,7 +78,9 @@ PROT_DEV PROT_GLOBAL P* uniform_ptr (P* q)
 
 // Fused history advance: workgroup b of a channel copies slice b of the next call's history (the last
 // hist_len frames of [hist | in | silence]) -- saves the separate history kernel and its launch gap on
-// small stateful launches (LV2 run(), batched buffers).  Called before any early return.
+// small stateful launches (LV2 run(), batched buffers).  Called by every workgroup exactly once: on its early
+// return, or at the very END of the kernel (after the main loop, when the loop's registers are dead -- called
+// up front it perturbed the allocation of kernels that sit at the 256-VGPR limit into spilling inside the loop).
 template <class S>
 PROT_DEV void hist_write_slice (const OlaParamsT<S>& p, int c, int t)
 {
@@ -145,8 +147,8 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 	const int     t  = threadIdx.x;
 	const int     c  = blockIdx.y;
 	const int64_t r0 = (int64_t)blockIdx.x * p.run_frames;
-	hist_write_slice (p, blockIdx.y, threadIdx.x);
 	if (r0 >= p.n_out) {
+		hist_write_slice (p, blockIdx.y, threadIdx.x);
 		return;
 	}
 	const int64_t r1 = (r0 + p.run_frames < p.n_out) ? r0 + p.run_frames : p.n_out;
@@ -444,6 +446,7 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 			}
 		}
 	}
+	hist_write_slice (p, blockIdx.y, threadIdx.x);
 }
 
 // --------------------------------------------------------------------------------------
@@ -663,8 +666,8 @@ __global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaPa
 	const int     t  = threadIdx.x;
 	const int     c  = blockIdx.y;
 	const int64_t r0 = (int64_t)blockIdx.x * p.run_frames;
-	hist_write_slice (p, blockIdx.y, threadIdx.x);
 	if (r0 >= p.n_out) {
+		hist_write_slice (p, blockIdx.y, threadIdx.x);
 		return;
 	}
 #ifdef PROT_CLOCKDBG
@@ -908,6 +911,7 @@ __global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaPa
 		d[3] = __builtin_amdgcn_s_getreg ((31 << 11) | 4) | (__builtin_amdgcn_s_getreg ((3 << 11) | 20) << 28); // HW_ID, XCC_ID
 	}
 #endif
+	hist_write_slice (p, blockIdx.y, threadIdx.x);
 }
 
 template <class T, int MODE>
@@ -1003,8 +1007,10 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 	const int     t  = threadIdx.x;
 	const int     c  = blockIdx.y;
 	const int64_t r0 = (int64_t)blockIdx.x * p.run_frames;
-	hist_write_slice (p, blockIdx.y, threadIdx.x);
 	if (r0 >= p.n_out) {
+		if (NP == 1) {
+			hist_write_slice (p, blockIdx.y, threadIdx.x);
+		}
 		return;
 	}
 	const int64_t r1 = (r0 + p.run_frames < p.n_out) ? r0 + p.run_frames : p.n_out;
@@ -1122,7 +1128,7 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 		}
 
 		// spectrum tables, HB bins per batch, one batch in flight ahead of the multiplies
-		constexpr int HB = 4;
+		constexpr int HB = NP == 2 ? 2 : 4; // two partitions: half the batch, the kernel is at the 256-VGPR limit
 		C             hb[2][NP * HB];
 		auto          h_fetch = [&] (int j) {
 #pragma unroll
@@ -1243,6 +1249,11 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 				}
 			}
 		}
+	}
+	// (two partitions: the kernel is at the 256-VGPR / 106-SGPR limit and the extra live parameters pushed spills
+	// into its main loop, +22 % time at 8192 taps -- those engines keep the separate history kernel)
+	if (NP == 1) {
+		hist_write_slice (p, blockIdx.y, threadIdx.x);
 	}
 }
 
