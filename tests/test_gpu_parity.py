@@ -612,3 +612,42 @@ def test_pruned_sweep_every_angle_block_layout(pkg, stride, blocks):
     ref = o.peaks()
     d_db = np.abs(20 * np.log10(a[:, swept] / ref[:, swept]))
     assert d_db.max() < 1e-3, d_db.max()
+
+
+@pytest.mark.parametrize("stride", [70004, 70003])
+@pytest.mark.parametrize("kind,param", [(1, 48000), (1, 96000), (0, 1024), (0, 8192)])
+def test_many_channels_equal_independent_mono_streams(pkg, kind, param, stride):
+    """A 5-channel engine (per-channel rotation) processes a stream in three stateful chunks; every channel
+    must equal a mono engine run on that channel alone.  With an even channel stride every channel takes the
+    same (8-byte aligned) code path as the mono run: bit-identical.  With an odd stride channels 1 and 3 take
+    the 4-byte-aligned load/store path, whose rotation epilogue is scalar instead of packed (the compiler may
+    contract it differently under -ffast-math): equal to a rounding error.  Covers channel indexing and the
+    fused per-channel history write of every default kernel form (polyphase long hop, direct two-partition,
+    polyphase two-partition)."""
+    import torch
+    dev = torch.device("cuda:0")
+    nc, n = 5, 70001
+    x = torch.from_numpy(xorshift_uniform(nc * stride, seed=77)).to(dev)
+    rot = np.array([[np.cos(0.3 * c), np.sin(0.3 * c)] for c in range(nc)], np.float32).reshape(-1)
+    cuts = [0, 333, 40000, n]
+    e = pkg.Engine(kind, param, nc)
+    y = torch.zeros(nc * stride, device=dev)
+    torch.cuda.synchronize()
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        e.apply_dev(x.data_ptr() + 4 * a, stride, b - a, y.data_ptr() + 4 * a, stride, b - a, rot, 0)
+    e.sync()
+    e.close()
+    for c in range(nc):
+        m = pkg.Engine(kind, param, 1)
+        ym = torch.zeros(n, device=dev)
+        xc = x[c * stride:c * stride + n].contiguous()
+        torch.cuda.synchronize()
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            m.apply_dev(xc.data_ptr() + 4 * a, n, b - a, ym.data_ptr() + 4 * a, n, b - a, rot[2 * c:2 * c + 2].copy(), 0)
+        m.sync()
+        m.close()
+        got = y[c * stride:c * stride + n]
+        if stride % 2 == 0:
+            assert torch.equal(got, ym), c
+        else:
+            assert (got - ym).abs().max().item() < 2.5e-7, (c, (got - ym).abs().max().item())
