@@ -86,3 +86,10 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".c", ".cc", ".cpp")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "prot_oracle" not in txt and "liborc" not in txt and "import orc" not in txt, f
+
+
+def test_graft_entry_build_succeeds():
+    """__graft_entry__.build() is the driver's "does it build" check: it must run clean on a CPU-only box
+    (hipcc cross-compiles) -- including its own consistency checks, which once pinned a stale ABI number."""
+    import __graft_entry__ as g
+    g.build()
