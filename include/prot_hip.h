@@ -118,7 +118,10 @@ int prot_abi_version (void);
  * process_channel (src/phaserotate.c:629-720, steady branch :710-717) and
  * PhaseRotateProc::process (cli/phase-rotate.cc:181-232) for a whole run of
  * blocks per launch.  Unless PROT_F_STATELESS, the last `history` input
- * frames are kept for the next call.  Asynchronous on `stream`. */
+ * frames are kept for the next call.  Asynchronous on `stream`.
+ * d_out must not overlap d_in (PROT_EINVAL): workgroups read the input of
+ * neighbouring runs while others store output.  The LV2 front end, where hosts
+ * do run in place (src/phaserotate.c:779-785), goes through its own buffers. */
 int prot_apply_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_in,
                     float* d_out, int64_t out_stride, uint64_t n_out,
                     const float* rot, uint32_t flags, void* stream);

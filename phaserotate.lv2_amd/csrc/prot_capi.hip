@@ -377,6 +377,25 @@ int hist_advance (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t
 	return PROT_OK;
 }
 
+// device calls read the input of neighbouring runs (halo blocks) while other workgroups store output:
+// input and output must not share frames.  Exact per-channel interval test (skipped beyond 64 channels).
+bool io_overlap (const float* in, int64_t in_stride, uint64_t n_in, const float* out, int64_t out_stride, uint64_t n_out, int nc)
+{
+	if (nc > 64 || n_in == 0 || n_out == 0) {
+		return false;
+	}
+	for (int ci = 0; ci < nc; ++ci) {
+		const uintptr_t a0 = (uintptr_t)(in + (int64_t)ci * in_stride), a1 = a0 + n_in * sizeof (float);
+		for (int co = 0; co < nc; ++co) {
+			const uintptr_t b0 = (uintptr_t)(out + (int64_t)co * out_stride), b1 = b0 + n_out * sizeof (float);
+			if (a0 < b1 && b0 < a1) {
+				return true;
+			}
+		}
+	}
+	return false;
+}
+
 hipStream_t pick_stream (prot_engine* e, void* stream)
 {
 	return stream ? (hipStream_t)stream : e->stream;
@@ -781,6 +800,10 @@ int prot_apply_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 	if (!e || !d_in || !d_out || (!rot && !(flags & PROT_F_HILBERT))) {
 		return PROT_EINVAL;
 	}
+	if (io_overlap (d_in, in_stride, n_in, d_out, out_stride, n_out, (int)e->info.n_chn)) {
+		snprintf (g_err, sizeof (g_err), "prot_apply_dev: d_out overlaps d_in (in-place processing is not supported on device streams)");
+		return PROT_EINVAL;
+	}
 	HIP_TRY (hipSetDevice (e->device));
 	hipStream_t s = pick_stream (e, stream);
 	const int   nc = (int)e->info.n_chn;
@@ -806,6 +829,10 @@ int prot_apply_dev_ramp (prot_engine* e, const float* d_in, int64_t in_stride, u
                          int64_t out_stride, uint64_t n_out, const float* d_rot, uint32_t flags, void* stream)
 {
 	if (!e || !d_in || !d_out || !d_rot) {
+		return PROT_EINVAL;
+	}
+	if (io_overlap (d_in, in_stride, n_in, d_out, out_stride, n_out, (int)e->info.n_chn)) {
+		snprintf (g_err, sizeof (g_err), "prot_apply_dev_ramp: d_out overlaps d_in (in-place processing is not supported on device streams)");
 		return PROT_EINVAL;
 	}
 	HIP_TRY (hipSetDevice (e->device));

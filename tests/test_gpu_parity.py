@@ -675,3 +675,22 @@ def test_many_channels_equal_independent_mono_streams(pkg, kind, param, stride):
             assert torch.equal(got, ym), c
         else:
             assert (got - ym).abs().max().item() < 2.5e-7, (c, (got - ym).abs().max().item())
+
+
+def test_in_place_device_call_is_rejected(pkg):
+    """Device streams cannot be processed in place (workgroups read each other's input regions): the call
+    must say so instead of racing.  Adjacent, non-overlapping buffers are fine."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 20000
+    buf = torch.zeros(3 * n, device=dev)
+    rot = np.array([0.6, 0.8], np.float32)
+    e = pkg.Engine(pkg.KIND_LV2, 48000, 1)
+    torch.cuda.synchronize()
+    with pytest.raises(pkg.ProtError):
+        e.apply_dev(buf.data_ptr(), n, n, buf.data_ptr(), n, n, rot, pkg.F_STATELESS)
+    with pytest.raises(pkg.ProtError):
+        e.apply_dev(buf.data_ptr(), n, n, buf.data_ptr() + 4 * (n - 1), n, n, rot, pkg.F_STATELESS)
+    e.apply_dev(buf.data_ptr(), n, n, buf.data_ptr() + 4 * n, n, n, rot, pkg.F_STATELESS)  # adjacent: allowed
+    e.sync()
+    e.close()
