@@ -185,6 +185,7 @@ struct prot_engine {
 	bool        use_p2   = false; // two partitions in one launch (frequency-domain delay line)
 	bool        use_poly = false; // polyphase form: partitions of g[s] = fir[2 s + 1], blocks of 4096 frames
 	DevBuf<float2> d_Hd;          // direct-form spectra of a <= 4096-tap FIR for the fp16 sample path (poly engines)
+	DevBuf<float2> d_Hp;          // LV2 4096-tap engines (direct form): spectrum of the 2048 odd taps, for SHORT launches
 
 	DevBuf<float2> d_H, d_tw;
 	DevBuf<float>  d_lut, d_rot, d_hist[2], d_peaks, d_in, d_out, d_u, d_inter, d_rot_s;
@@ -315,6 +316,21 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 		}
 		return hist_advance (e, d_in, in_stride, n_in, chn0, n_chn, s);
 	};
+	if (e->use_p2 && e->d_Hp.p != nullptr) {
+		// short launch of a direct-form LV2 engine: blocks per workgroup (k) against halo blocks -- direct (k + 2),
+		// polyphase 1.07 (k + 1): polyphase below k ~ 13
+		const int64_t k = p.run_frames / 4096;
+		if (k < 12) {
+			p.H          = e->d_Hp.p;
+			p.conv_delay = (int)e->info.conv_delay;
+			p.accumulate = 0;
+			hipError_t err = prot::launch_ola_poly (p, 1, 8, n_chn, s);
+			if (err != hipSuccess) {
+				return hip_fail (err, "polyphase ola kernel launch (short launch)");
+			}
+			return finish ();
+		}
+	}
 	if (e->use_poly) {
 		const uint32_t np = std::min<uint32_t> (2, e->info.partitions); // partitions of g per launch
 		for (uint32_t l = 0; l < e->info.partitions / np; ++l) {
@@ -672,20 +688,40 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	} else {
 		spectra (fir_taps, n_part, part_len, H_h);
 	}
+	// LV2 engines with the 4096-tap FIR run the direct form (faster per block), which needs TWO halo blocks
+	// per run; the polyphase form needs one.  For launches so short that a workgroup gets only a few blocks
+	// (run() buffers, batched buffers) the halo dominates, so those launches use the polyphase kernel --
+	// same filter, results equal to a rounding error.  LV2 only: CLI engines keep one form per engine, which
+	// is what makes sharded sweeps bit-identical whatever the shard sizes.
+	std::vector<float2> Hp_h;
+	bool                poly_taps_ok = inf.firlen % 4 == 0 && inf.conv_delay % 2 == 0;
+	for (uint32_t i = 0; poly_taps_ok && i < inf.firlen; i += 2) {
+		poly_taps_ok = fir_taps[i] == 0.f;
+	}
+	if (cfg->kind == PROT_KIND_LV2 && use_p2 && !use_poly && inf.firlen == F && poly_taps_ok && cfg->flags == 0 &&
+	    getenv ("PROT_NO_POLY") == nullptr) {
+		std::vector<float> g (inf.firlen / 2);
+		for (size_t i = 0; i < g.size (); ++i) {
+			g[i] = fir_taps[2 * i + 1];
+		}
+		spectra (g, 1, F / 2, Hp_h);
+	}
 	for (uint32_t k = 0; k < F; ++k) {
 		const double a = -2.0 * M_PI * (double)k / (double)F;
 		tw_h[k] = make_float2 ((float)std::cos (a), (float)std::sin (a));
 	}
 	const size_t hn = (size_t)inf.history * inf.n_chn;
 	int rc;
-	if ((rc = e->d_H.ensure ((size_t)F * n_part)) || (!Hd_h.empty () && (rc = e->d_Hd.ensure (Hd_h.size ()))) || (rc = e->d_tw.ensure (F)) || (rc = e->d_lut.ensure (PROT_MAXSAMPLE * 2)) ||
+	if ((rc = e->d_H.ensure ((size_t)F * n_part)) || (!Hd_h.empty () && (rc = e->d_Hd.ensure (Hd_h.size ()))) ||
+	    (!Hp_h.empty () && (rc = e->d_Hp.ensure (Hp_h.size ()))) || (rc = e->d_tw.ensure (F)) || (rc = e->d_lut.ensure (PROT_MAXSAMPLE * 2)) ||
 	    (rc = e->d_rot.ensure (2 * (size_t)inf.n_chn)) || (rc = e->d_hist[0].ensure (hn)) ||
 	    (rc = e->d_hist[1].ensure (hn)) || (rc = e->d_peaks.ensure ((size_t)PROT_MAXSAMPLE * inf.n_chn)) ||
 	    (rc = e->d_angles.ensure (PROT_MAXSAMPLE + 8)) || (rc = e->d_thr.ensure (4 * (size_t)inf.n_chn)) ||
 	    (rc = e->d_stats.ensure (2))) {
 		return fail (rc);
 	}
-	if ((!Hd_h.empty () && hipMemcpy (e->d_Hd.p, Hd_h.data (), Hd_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess) ||
+	if ((!Hp_h.empty () && hipMemcpy (e->d_Hp.p, Hp_h.data (), Hp_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess) ||
+	    (!Hd_h.empty () && hipMemcpy (e->d_Hd.p, Hd_h.data (), Hd_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess) ||
 	    hipMemcpy (e->d_H.p, H_h.data (), H_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMemcpy (e->d_tw.p, tw_h.data (), F * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMemcpy (e->d_lut.p, g_lut, sizeof (g_lut), hipMemcpyHostToDevice) != hipSuccess) {
@@ -721,6 +757,7 @@ void prot_engine_destroy (prot_engine* e)
 	}
 	e->d_H.release ();
 	e->d_Hd.release ();
+	e->d_Hp.release ();
 	e->d_tw.release ();
 	e->d_lut.release ();
 	e->d_rot.release ();

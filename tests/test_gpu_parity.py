@@ -694,3 +694,31 @@ def test_in_place_device_call_is_rejected(pkg):
     e.apply_dev(buf.data_ptr(), n, n, buf.data_ptr() + 4 * n, n, n, rot, pkg.F_STATELESS)  # adjacent: allowed
     e.sync()
     e.close()
+
+
+def test_lv2_96k_engine_switches_form_between_long_and_short_launches(pkg):
+    """The 96 kHz LV2 engine runs the direct two-partition form on long launches and the polyphase form on
+    short ones (fewer halo blocks).  State is input history only, so a stream may alternate between them:
+    long chunk (direct), short chunks (polyphase), long again -- equal to one long launch within the gate,
+    with no step at the seams."""
+    import torch
+    dev = torch.device("cuda:0")
+    big = 1 << 25                      # 16 blocks per workgroup: direct form
+    cuts = [0, big, big + 700, big + 700 + 4096 * 3, 2 * big + 5000]
+    n = cuts[-1]
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.rand(n, generator=g, device=dev) - 0.5
+    rot = np.array([0.6, -0.8], np.float32)
+    e = pkg.Engine(pkg.KIND_LV2, 96000, 1)
+    y1 = torch.empty_like(x)
+    torch.cuda.synchronize()
+    e.apply_dev(x.data_ptr(), n, n, y1.data_ptr(), n, n, rot, pkg.F_STATELESS)   # one launch (direct form)
+    y2 = torch.empty_like(x)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        e.apply_dev(x.data_ptr() + 4 * a, n, b - a, y2.data_ptr() + 4 * a, n, b - a, rot, 0)
+    e.sync()
+    e.close()
+    d = (y1 - y2).abs()
+    assert d.max().item() < TOL, (d.max().item(), int(d.argmax().item()))
+    for c in cuts[1:-1]:
+        assert d[c - 6000:c + 6000].max().item() < TOL
