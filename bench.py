@@ -237,7 +237,7 @@ def main():
         engH.apply_dev(xh.float().data_ptr(), n, n, y32.data_ptr(), n, n, rot, pkg.F_STATELESS, st)
         torch.cuda.synchronize()
         errh = (yh[: 1 << 22].float() - y32[: 1 << 22]).abs()
-        out["fp16"] = {"workload": "same as config, fp16 samples (2 B in + 2 B out per frame), packed-half butterflies, fp32 accumulate",
+        out["fp16"] = {"workload": "same as config (polyphase form), fp16 samples (2 B in + 2 B out per frame), packed-half butterflies, fp32 overlap-add and rotation",
                        "value": world * n / (kmsH * 1e-3), "unit": "frames/s", "kernel_ms": kmsH,
                        "roofline_frac": 4.0 * n / (kmsH * 1e-3) / 1e9 / HBM_PEAK_GBS,
                        "max_abs_err_vs_fp32": float(errh.max()), "rms_err_vs_fp32": float(torch.sqrt(torch.mean(errh ** 2)))}

@@ -184,7 +184,6 @@ struct prot_engine {
 	uint32_t    part_len = 0; // taps per FIR partition
 	bool        use_p2   = false; // two partitions in one launch (frequency-domain delay line)
 	bool        use_poly = false; // polyphase form: partitions of g[s] = fir[2 s + 1], blocks of 4096 frames
-	DevBuf<float2> d_Hd;          // direct-form spectra of a <= 4096-tap FIR for the fp16 sample path (poly engines)
 	DevBuf<float2> d_Hp;          // LV2 4096-tap engines (direct form): spectrum of the 2048 odd taps, for SHORT launches
 
 	DevBuf<float2> d_H, d_tw;
@@ -675,16 +674,13 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 			}
 		}
 	};
-	std::vector<float2> H_h, Hd_h, tw_h (F);
+	std::vector<float2> H_h, tw_h (F);
 	if (use_poly) {
 		std::vector<float> g (inf.firlen / 2);
 		for (size_t i = 0; i < g.size (); ++i) {
 			g[i] = fir_taps[2 * i + 1];
 		}
 		spectra (g, n_part, part_len, H_h);
-		if (inf.firlen <= F) { // the fp16 sample path keeps the direct two-partition form
-			spectra (fir_taps, 2, F / 2, Hd_h);
-		}
 	} else {
 		spectra (fir_taps, n_part, part_len, H_h);
 	}
@@ -712,7 +708,7 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	}
 	const size_t hn = (size_t)inf.history * inf.n_chn;
 	int rc;
-	if ((rc = e->d_H.ensure ((size_t)F * n_part)) || (!Hd_h.empty () && (rc = e->d_Hd.ensure (Hd_h.size ()))) ||
+	if ((rc = e->d_H.ensure ((size_t)F * n_part)) ||
 	    (!Hp_h.empty () && (rc = e->d_Hp.ensure (Hp_h.size ()))) || (rc = e->d_tw.ensure (F)) || (rc = e->d_lut.ensure (PROT_MAXSAMPLE * 2)) ||
 	    (rc = e->d_rot.ensure (2 * (size_t)inf.n_chn)) || (rc = e->d_hist[0].ensure (hn)) ||
 	    (rc = e->d_hist[1].ensure (hn)) || (rc = e->d_peaks.ensure ((size_t)PROT_MAXSAMPLE * inf.n_chn)) ||
@@ -721,7 +717,6 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 		return fail (rc);
 	}
 	if ((!Hp_h.empty () && hipMemcpy (e->d_Hp.p, Hp_h.data (), Hp_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess) ||
-	    (!Hd_h.empty () && hipMemcpy (e->d_Hd.p, Hd_h.data (), Hd_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess) ||
 	    hipMemcpy (e->d_H.p, H_h.data (), H_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMemcpy (e->d_tw.p, tw_h.data (), F * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMemcpy (e->d_lut.p, g_lut, sizeof (g_lut), hipMemcpyHostToDevice) != hipSuccess) {
@@ -756,7 +751,6 @@ void prot_engine_destroy (prot_engine* e)
 		(void)hipStreamSynchronize (e->stream);
 	}
 	e->d_H.release ();
-	e->d_Hd.release ();
 	e->d_Hp.release ();
 	e->d_tw.release ();
 	e->d_lut.release ();
@@ -893,8 +887,10 @@ int prot_apply_dev_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uin
 	if (!e || !d_in || !d_out || !rot) {
 		return PROT_EINVAL;
 	}
-	const bool f16_p2 = (e->use_p2 && e->info.partitions == 2) || (e->use_poly && e->d_Hd.p != nullptr);
-	if (!f16_p2 && (e->use_poly || e->info.partitions != 1)) {
+	// the fp16 kernels exist for one polyphase partition, two direct partitions, one direct partition
+	const bool f16_poly = e->use_poly && e->info.partitions == 1;
+	const bool f16_p2   = e->use_p2 && e->info.partitions == 2;
+	if (!f16_poly && !f16_p2 && (e->use_poly || e->info.partitions != 1)) {
 		return PROT_EUNSUPPORTED;
 	}
 	HIP_TRY (hipSetDevice (e->device));
@@ -913,14 +909,15 @@ int prot_apply_dev_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uin
 	p.out        = (_Float16*)d_out;
 	p.out_stride = out_stride;
 	p.n_out      = (int64_t)n_out;
-	p.H          = e->use_poly ? e->d_Hd.p : e->d_H.p;
+	p.H          = e->d_H.p;
 	p.tw         = e->d_tw.p;
 	p.rot        = e->d_rot.p;
-	// the fp16 kernels are direct-form (pairs of 2048-frame hops) whatever form the fp32 engine uses
-	p.run_frames = pick_run_frames (e, n_out, nc, f16_p2 ? 4096 : 2 * 256 * e->hopseg);
+	p.run_frames = pick_run_frames (e, n_out, nc); // the engine's own transform block: the fp16 kernels share its form
 	p.conv_delay = (int)e->info.conv_delay;
 	p.dry_delay  = (int)e->info.dry_delay;
-	hipError_t err = f16_p2 ? prot::launch_ola4096_p2_f16 (p, nc, s) : prot::launch_ola4096_f16 (p, e->hopseg, nc, s);
+	hipError_t err = f16_poly ? prot::launch_ola_poly_f16 (p, e->hopseg / 2, nc, s)
+	               : f16_p2   ? prot::launch_ola4096_p2_f16 (p, nc, s)
+	                          : prot::launch_ola4096_f16 (p, e->hopseg, nc, s);
 	if (err != hipSuccess) {
 		return hip_fail (err, "fp16 ola kernel launch");
 	}

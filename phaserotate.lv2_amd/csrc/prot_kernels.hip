@@ -982,12 +982,15 @@ hipError_t launch_ola4096_p2_f16 (const OlaParamsH& p, int n_chn, hipStream_t s)
 // DPP wave shift at the point of use; lane 0 of a wave gets it from a scalar load).  (p, q) feeds
 // the transform, (q, c) is kept for the dry path.
 // --------------------------------------------------------------------------------------
-template <int NP, int HS, int MODE, int DH, bool ACC>
-__global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
+template <class T, int NP, int HS, int MODE, int DH, bool ACC>
+__global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParamsT<typename T::samp> p)
 {
-	typedef T32  T;
-	typedef f2   C;
-	typedef pk32 O;
+	typedef typename T::cplx C;  // one complex of the transform = one PAIR of stream frames in HBM
+	typedef typename T::ops  O;
+	typedef typename T::samp S;
+	// frame pairs, dry path, overlap-add tail and rotation are fp32 registers for both precisions
+	auto to_f2 = [] (C v) { return mkf2 ((float)v.x, (float)v.y); };
+	auto to_sp = [] (f2 v) { return C{ (S)v.x, (S)v.y }; };
 	typedef PROT_LDS_PTR (T) VC;
 	// HS rows of 256 complex samples are new per block, 16 - HS rows are the overlap-add tail: g may
 	// have up to 256 (16 - HS) + 1 taps.  HS = 8 for 2048-tap partitions; a shorter g (1536 taps for
@@ -1015,27 +1018,28 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 	}
 	const int64_t r1 = (r0 + p.run_frames < p.n_out) ? r0 + p.run_frames : p.n_out;
 
-	const float* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
-	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
-	float* __restrict__ out        = p.out + (int64_t)c * p.out_stride;
+	const S* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
+	const S* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
+	S* __restrict__ out        = p.out + (int64_t)c * p.out_stride;
 	const int64_t n_in             = p.n_in;
 	const int     Dc = p.conv_delay, Dd = p.dry_delay; // Dc even (host guarantees)
 	// 8-byte alignment of the frame pairs (block starts and Dc are even): uniform per workgroup
-	const bool in_al8  = (reinterpret_cast<uintptr_t> (in) & 7) == 0;
-	const bool out_al8 = (reinterpret_cast<uintptr_t> (out) & 7) == 0;
+	const bool in_al8  = (reinterpret_cast<uintptr_t> (in) & (2 * sizeof (S) - 1)) == 0;  // a frame pair is one aligned access
+	const bool out_al8 = (reinterpret_cast<uintptr_t> (out) & (2 * sizeof (S) - 1)) == 0;
 
 	const f2* __restrict__ twp = reinterpret_cast<const f2*> (p.tw);
 	C tw1[16];
 #pragma unroll
 	for (int k = 1; k < 16; ++k) {
-		tw1[k] = twp[(t * k) & 4095];
+		tw1[k] = O::mk (twp[(t * k) & 4095].x, twp[(t * k) & 4095].y);
 	}
-	twm[t] = twp[16 * (((t & 15) * (t >> 4)) & 255)];
+	twm[t] = O::mk (twp[16 * (((t & 15) * (t >> 4)) & 255)].x, twp[16 * (((t & 15) * (t >> 4)) & 255)].y);
 	for (int i = t; i <= 2048; i += 256) {
 		const int j = swap_lo_digits (i);
 #pragma unroll
 		for (int pp = 0; pp < NP; ++pp) {
-			Hs[pp][j] = reinterpret_cast<const f2*> (p.H)[pp * 4096 + i];
+			const f2 hv = reinterpret_cast<const f2*> (p.H)[pp * 4096 + i];
+			Hs[pp][j]   = O::mk (hv.x, hv.y);
 		}
 	}
 	float ca = 0.f, sa = 1.f;
@@ -1050,14 +1054,15 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 	const int n_it = NP + (int)((r1 - r0 + BLK - 1) / BLK);  // NP halo blocks: OLA tail (+ X_{b-1})
 	int64_t   s    = r0 - (int64_t)NP * BLK;
 
-	C acc[NT], zp[NP == 2 ? 16 : 1];
+	f2 acc[NT];
+	C  zp[NP == 2 ? 16 : 1];
 #pragma unroll
 	for (int i = 0; i < NT; ++i) {
 		acc[i] = mkf2 (0.f, 0.f);
 	}
 #pragma unroll
 	for (int i = 0; i < (NP == 2 ? 16 : 1); ++i) {
-		zp[i] = mkf2 (0.f, 0.f);
+		zp[i] = O::mk (0.f, 0.f);
 	}
 	// (q, c) pairs of the DH sample rows in front of the current block: the dry path's source
 	f2 dh[NDH];
@@ -1081,21 +1086,21 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 			const unsigned w128 = (unsigned)__builtin_amdgcn_readfirstlane (t >> 6) * 128u;
 #pragma unroll
 			for (int m = 0; m < HS / 2; ++m) { // one SGPR base per 1024 frames: the immediate offset reaches 4 KiB
-				const PROT_GLOBAL float* __restrict__ b = uniform_ptr (in + a0 + 1024 * m);
+				const PROT_GLOBAL S* __restrict__ b = uniform_ptr (in + a0 + 1024 * m);
 #pragma unroll
 				for (int e = 0; e < 2; ++e) {
-					nxqc[2 * m + e] = reinterpret_cast<const PROT_GLOBAL f2*> (b)[(unsigned)t + 256u * e];
-					nxb[2 * m + e]  = (b - 1)[w128 + 512u * e];
+					nxqc[2 * m + e] = to_f2 (reinterpret_cast<const PROT_GLOBAL C*> (b)[(unsigned)t + 256u * e]);
+					nxb[2 * m + e]  = (float)(b - 1)[w128 + 512u * e];
 				}
 			}
 		} else if (fast) {
 #pragma unroll
 			for (int m = 0; m < HS / 2; ++m) {
-				const PROT_GLOBAL float* __restrict__ b = uniform_ptr (in + a0 + 1024 * m);
+				const PROT_GLOBAL S* __restrict__ b = uniform_ptr (in + a0 + 1024 * m);
 #pragma unroll
 				for (int e = 0; e < 2; ++e) {
-					nxp[2 * m + e]  = (b - 1)[2u * (unsigned)t + 512u * e];
-					nxqc[2 * m + e] = mkf2 (b[2u * (unsigned)t + 512u * e], (b + 1)[2u * (unsigned)t + 512u * e]);
+					nxp[2 * m + e]  = (float)(b - 1)[2u * (unsigned)t + 512u * e];
+					nxqc[2 * m + e] = mkf2 ((float)b[2u * (unsigned)t + 512u * e], (float)(b + 1)[2u * (unsigned)t + 512u * e]);
 				}
 			}
 		} else {
@@ -1115,7 +1120,7 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 		f2 cur[HS];
 #pragma unroll
 		for (int k = HS; k < 16; ++k) {
-			v[k] = mkf2 (0.f, 0.f);
+			v[k] = O::mk (0.f, 0.f);
 		}
 #pragma unroll
 		for (int k = 0; k < HS; ++k) {
@@ -1124,7 +1129,7 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 			if (nx_shift) { // wave_shr:1 -- lane i reads lane i-1, lane 0 keeps `old` = the scalar-loaded frame
 				pk_ = __uint_as_float (__builtin_amdgcn_update_dpp (__float_as_uint (nxb[k]), __float_as_uint (nxqc[k].y), 0x138, 0xf, 0xf, false));
 			}
-			v[k] = mkf2 (pk_, nxqc[k].x);
+			v[k] = O::mk (pk_, nxqc[k].x);
 		}
 
 		// spectrum tables, HB bins per batch, one batch in flight ahead of the multiplies
@@ -1203,14 +1208,14 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 
 		inv4096w<T> (v, lds, twm, tw1, t, tl, th);
 
-		C u[HS];
+		f2 u[HS];
 #pragma unroll
 		for (int k = 0; k < HS; ++k) {
-			u[k] = k < NT ? acc[k < NT ? k : 0] + v[k] : v[k];
+			u[k] = k < NT ? acc[k < NT ? k : 0] + to_f2 (v[k]) : to_f2 (v[k]);
 		}
 #pragma unroll
 		for (int k = 0; k < NT; ++k) {
-			acc[k] = v[HS + k];
+			acc[k] = to_f2 (v[HS + k]);
 		}
 
 		if (it >= NP) {
@@ -1219,10 +1224,10 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 				const f2 ca2 = mkf2 (ca, ca), sa2 = mkf2 (sa, sa);
 #pragma unroll
 				for (int m = 0; m < HS / 2; ++m) {
-					PROT_GLOBAL f2* __restrict__ ob = reinterpret_cast<PROT_GLOBAL f2*> (uniform_ptr (out + s + 1024 * m));
+					PROT_GLOBAL C* __restrict__ ob = reinterpret_cast<PROT_GLOBAL C*> (uniform_ptr (out + s + 1024 * m));
 #pragma unroll
 					for (int e = 0; e < 2; ++e) {
-						ob[(unsigned)t + 256u * e] = ca2 * dry[2 * m + e] + sa2 * u[2 * m + e];
+						ob[(unsigned)t + 256u * e] = to_sp (ca2 * dry[2 * m + e] + sa2 * u[2 * m + e]);
 					}
 				}
 			} else {
@@ -1234,7 +1239,7 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 						const float   uu  = h ? u[k].y : u[k].x;
 						if (pos < r1) {
 							if (MODE == MODE_HILBERT) {
-								out[pos] = ACC ? out[pos] + uu : uu;
+								out[pos] = ACC ? (S)((float)out[pos] + uu) : (S)uu;
 							} else {
 								float cc = ca, ss = sa;
 								if (MODE == MODE_RAMP) {
@@ -1242,7 +1247,7 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 									cc          = cs.x;
 									ss          = cs.y;
 								}
-								out[pos] = ACC ? out[pos] + ss * uu : cc * (h ? dry[k].y : dry[k].x) + ss * uu;
+								out[pos] = ACC ? (S)((float)out[pos] + ss * uu) : (S)(cc * (h ? dry[k].y : dry[k].x) + ss * uu);
 							}
 						}
 					}
@@ -1257,8 +1262,8 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParams p)
 	}
 }
 
-template <int NP, int HS, int MODE>
-static hipError_t launch_poly_m (const OlaParams& p, dim3 grid, hipStream_t s)
+template <class T, int NP, int HS, int MODE>
+static hipError_t launch_poly_m (const OlaParamsT<typename T::samp>& p, dim3 grid, hipStream_t s)
 {
 	// dry frames from registers when (dry_delay - conv_delay) is a whole number of 512-frame sample rows
 	// that the hop geometry in use actually meets: LV2 48 kHz 3 (HS 10), 96 kHz / CLI 4096 4, CLI 8192 /
@@ -1268,17 +1273,17 @@ static hipError_t launch_poly_m (const OlaParams& p, dim3 grid, hipStream_t s)
 	constexpr int DHS = HS == 8 ? (NP == 2 ? 8 : 4) : HS == 10 ? 3 : HS == 12 ? 2 : 1;
 	const dim3 block (256);
 	if (p.accumulate) {
-		hipLaunchKernelGGL ((olapoly_kernel<NP, HS, MODE, 0, true>), grid, block, 0, s, p);
+		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, 0, true>), grid, block, 0, s, p);
 	} else if (MODE != MODE_HILBERT && dd == DHS) {
-		hipLaunchKernelGGL ((olapoly_kernel<NP, HS, MODE, DHS, false>), grid, block, 0, s, p);
+		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, DHS, false>), grid, block, 0, s, p);
 	} else {
-		hipLaunchKernelGGL ((olapoly_kernel<NP, HS, MODE, 0, false>), grid, block, 0, s, p);
+		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, 0, false>), grid, block, 0, s, p);
 	}
 	return hipGetLastError ();
 }
 
-template <int NP, int HS>
-static hipError_t launch_poly_n (const OlaParams& p, int n_chn, hipStream_t s)
+template <class T, int NP, int HS>
+static hipError_t launch_poly_n (const OlaParamsT<typename T::samp>& p, int n_chn, hipStream_t s)
 {
 	if (p.n_out <= 0) {
 		return hipSuccess;
@@ -1286,12 +1291,12 @@ static hipError_t launch_poly_n (const OlaParams& p, int n_chn, hipStream_t s)
 	const int64_t runs = (p.n_out + p.run_frames - 1) / p.run_frames;
 	dim3          grid ((unsigned)runs, (unsigned)n_chn);
 	if (p.hilbert_only) {
-		return launch_poly_m<NP, HS, MODE_HILBERT> (p, grid, s);
+		return launch_poly_m<T, NP, HS, MODE_HILBERT> (p, grid, s);
 	}
 	if (p.rot_s != nullptr) {
-		return launch_poly_m<NP, HS, MODE_RAMP> (p, grid, s);
+		return launch_poly_m<T, NP, HS, MODE_RAMP> (p, grid, s);
 	}
-	return launch_poly_m<NP, HS, MODE_ROT> (p, grid, s);
+	return launch_poly_m<T, NP, HS, MODE_ROT> (p, grid, s);
 }
 
 hipError_t launch_ola_poly (const OlaParams& p, int n_part, int hop_rows, int n_chn, hipStream_t s)
@@ -1301,13 +1306,39 @@ hipError_t launch_ola_poly (const OlaParams& p, int n_part, int hop_rows, int n_
 		return hipErrorInvalidValue;
 	}
 	if (n_part == 2) {
-		return launch_poly_n<2, 8> (p, n_chn, s);
+		return launch_poly_n<T32, 2, 8> (p, n_chn, s);
 	}
 	switch (hop_rows) {
-		case 8: return launch_poly_n<1, 8> (p, n_chn, s);
-		case 10: return launch_poly_n<1, 10> (p, n_chn, s);
-		case 12: return launch_poly_n<1, 12> (p, n_chn, s);
-		default: return launch_poly_n<1, 14> (p, n_chn, s);
+		case 8: return launch_poly_n<T32, 1, 8> (p, n_chn, s);
+		case 10: return launch_poly_n<T32, 1, 10> (p, n_chn, s);
+		case 12: return launch_poly_n<T32, 1, 12> (p, n_chn, s);
+		default: return launch_poly_n<T32, 1, 14> (p, n_chn, s);
+	}
+}
+
+// fp16 sample path in polyphase form: one partition, steady rotation, stateless (what prot_apply_dev_f16 offers)
+template <int HS>
+static hipError_t launch_poly_h (const OlaParamsH& p, int n_chn, hipStream_t s)
+{
+	const int64_t runs = (p.n_out + p.run_frames - 1) / p.run_frames;
+	dim3          grid ((unsigned)runs, (unsigned)n_chn);
+	return launch_poly_m<T16, 1, HS, MODE_ROT> (p, grid, s);
+}
+
+hipError_t launch_ola_poly_f16 (const OlaParamsH& p, int hop_rows, int n_chn, hipStream_t s)
+{
+	if ((p.conv_delay & 1) || (p.run_frames % (512 * hop_rows)) != 0 || p.hilbert_only || p.rot_s != nullptr || p.accumulate) {
+		return hipErrorInvalidValue;
+	}
+	if (p.n_out <= 0) {
+		return hipSuccess;
+	}
+	switch (hop_rows) {
+		case 8: return launch_poly_h<8> (p, n_chn, s);
+		case 10: return launch_poly_h<10> (p, n_chn, s);
+		case 12: return launch_poly_h<12> (p, n_chn, s);
+		case 14: return launch_poly_h<14> (p, n_chn, s);
+		default: return hipErrorInvalidValue;
 	}
 }
 
