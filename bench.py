@@ -223,7 +223,7 @@ def main():
 
         def step_h():
             engH.apply_dev_f16(xh.data_ptr(), n, n, yh.data_ptr(), n, n, rot, st)
-        for _ in range(args.warmup):
+        for _ in range(args.preroll + args.warmup):  # the same pre-roll as every other timed line
             step_h()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier()
