@@ -722,3 +722,37 @@ def test_lv2_96k_engine_switches_form_between_long_and_short_launches(pkg):
     assert d.max().item() < TOL, (d.max().item(), int(d.argmax().item()))
     for c in cuts[1:-1]:
         assert d[c - 6000:c + 6000].max().item() < TOL
+
+
+@pytest.mark.parametrize("kind,param", [(1, 48000), (0, 2048), (1, 96000)])
+def test_fp16_path_misaligned_and_multichannel(pkg, kind, param):
+    """fp16 streams that start on an odd sample (2-byte aligned only: the frame-pair loads/stores fall back
+    to single halfs) with an odd channel stride, two channels, ragged length: each channel must equal the
+    aligned mono run to an fp16 rounding error, and the frames around the buffers must stay untouched."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, stride = 100001, 100003
+    g = torch.Generator(device=dev).manual_seed(9)
+    big = ((torch.rand(2 * stride + 8, generator=g, device=dev) - 0.5) * 0.9).half()
+    x = big[1:]                               # odd offset
+    ybig = torch.full((2 * stride + 8,), 7.0, device=dev, dtype=torch.float16)
+    y = ybig[1:]
+    rot = np.array([0.6, 0.8, -0.8, 0.6], np.float32)
+    e = pkg.Engine(kind, param, 2)
+    torch.cuda.synchronize()
+    e.apply_dev_f16(x.data_ptr(), stride, n, y.data_ptr(), stride, n, rot)
+    e.sync()
+    e.close()
+    for c in range(2):
+        m = pkg.Engine(kind, param, 1)
+        xc = x[c * stride:c * stride + n].clone()    # fresh allocation: aligned
+        yc = torch.empty_like(xc)
+        torch.cuda.synchronize()
+        m.apply_dev_f16(xc.data_ptr(), n, n, yc.data_ptr(), n, n, rot[2 * c:2 * c + 2].copy())
+        m.sync()
+        m.close()
+        d = (y[c * stride:c * stride + n].float() - yc.float()).abs().max().item()
+        assert d < 2e-3, (c, d)                # one fp16 ulp at |y| <= 1 is 4.9e-4
+    # guard frames: before the first sample, between the channels' ends, after the last sample
+    assert ybig[0].item() == 7.0
+    assert (y[n:stride] == 7.0).all() and (y[stride + n:2 * stride + 7] == 7.0).all()
