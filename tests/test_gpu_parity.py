@@ -756,3 +756,28 @@ def test_fp16_path_misaligned_and_multichannel(pkg, kind, param):
     # guard frames: before the first sample, between the channels' ends, after the last sample
     assert ybig[0].item() == 7.0
     assert (y[n:stride] == 7.0).all() and (y[stride + n:2 * stride + 7] == 7.0).all()
+
+
+@pytest.mark.parametrize("kind,param", [(1, 48000), (1, 96000), (1, 192000), (0, 1024), (0, 2048), (0, 8192)])
+@pytest.mark.parametrize("n", [1, 2, 4095, 5121, 70001])
+def test_no_frame_written_outside_the_requested_range(pkg, kind, param, n):
+    """Every default kernel form stores frame PAIRS on its fast path: with ragged lengths (1 frame, odd counts,
+    one frame past a transform block) and both buffer alignments nothing outside [0, n) of each channel may be
+    touched."""
+    import torch
+    dev = torch.device("cuda:0")
+    stride = n + 5
+    for off in (0, 1):
+        xb = torch.zeros(2 * stride + 2, device=dev)
+        xb[:] = torch.from_numpy(xorshift_uniform(2 * stride + 2, seed=n + off)).to(dev)
+        yb = torch.full((2 * stride + 2,), 9.0, device=dev)
+        x, y = xb[off:], yb[off:]
+        rot = np.array([0.6, 0.8, 0.8, -0.6], np.float32)
+        e = pkg.Engine(kind, param, 2)
+        torch.cuda.synchronize()
+        e.apply_dev(x.data_ptr(), stride, n, y.data_ptr(), stride, n, rot, 0)
+        e.sync()
+        e.close()
+        assert (y[:n] != 9.0).any() or n < 3
+        assert (y[n:stride] == 9.0).all() and (y[stride + n:2 * stride] == 9.0).all(), (off, n)
+        assert (yb[:off] == 9.0).all() and (yb[off + 2 * stride:] == 9.0).all()
