@@ -184,7 +184,7 @@ struct prot_engine {
 	uint32_t    part_len = 0; // taps per FIR partition
 	bool        use_p2   = false; // two partitions in one launch (frequency-domain delay line)
 	bool        use_poly = false; // polyphase form: partitions of g[s] = fir[2 s + 1], blocks of 4096 frames
-	DevBuf<float2> d_Hp;          // LV2 4096-tap engines (direct form): spectrum of the 2048 odd taps, for SHORT launches
+	DevBuf<float2> d_Hp;          // 4096-tap engines (direct form): spectrum of the 2048 odd taps -- short LV2 launches, fp16 path
 
 	DevBuf<float2> d_H, d_tw;
 	DevBuf<float>  d_lut, d_rot, d_hist[2], d_peaks, d_in, d_out, d_u, d_inter, d_rot_s;
@@ -315,7 +315,7 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 		}
 		return hist_advance (e, d_in, in_stride, n_in, chn0, n_chn, s);
 	};
-	if (e->use_p2 && e->d_Hp.p != nullptr) {
+	if (e->use_p2 && e->d_Hp.p != nullptr && e->info.kind == PROT_KIND_LV2) {
 		// short launch of a direct-form LV2 engine: blocks per workgroup (k) against halo blocks -- direct (k + 2),
 		// polyphase 1.07 (k + 1): polyphase below k ~ 13
 		const int64_t k = p.run_frames / 4096;
@@ -687,15 +687,15 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	// LV2 engines with the 4096-tap FIR run the direct form (faster per block), which needs TWO halo blocks
 	// per run; the polyphase form needs one.  For launches so short that a workgroup gets only a few blocks
 	// (run() buffers, batched buffers) the halo dominates, so those launches use the polyphase kernel --
-	// same filter, results equal to a rounding error.  LV2 only: CLI engines keep one form per engine, which
-	// is what makes sharded sweeps bit-identical whatever the shard sizes.
+	// same filter, results equal to a rounding error.  fp32 launches of LV2 engines only: CLI engines keep one fp32
+	// form per engine, which is what makes sharded sweeps bit-identical whatever the shard sizes.  The fp16 sample
+	// path of every 4096-tap engine uses these tables too (prot_apply_dev_f16).
 	std::vector<float2> Hp_h;
 	bool                poly_taps_ok = inf.firlen % 4 == 0 && inf.conv_delay % 2 == 0;
 	for (uint32_t i = 0; poly_taps_ok && i < inf.firlen; i += 2) {
 		poly_taps_ok = fir_taps[i] == 0.f;
 	}
-	if (cfg->kind == PROT_KIND_LV2 && use_p2 && !use_poly && inf.firlen == F && poly_taps_ok && cfg->flags == 0 &&
-	    getenv ("PROT_NO_POLY") == nullptr) {
+	if (use_p2 && !use_poly && inf.firlen == F && poly_taps_ok && cfg->flags == 0 && getenv ("PROT_NO_POLY") == nullptr) {
 		std::vector<float> g (inf.firlen / 2);
 		for (size_t i = 0; i < g.size (); ++i) {
 			g[i] = fir_taps[2 * i + 1];
@@ -888,7 +888,10 @@ int prot_apply_dev_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uin
 		return PROT_EINVAL;
 	}
 	// the fp16 kernels exist for one polyphase partition, two direct partitions, one direct partition
-	const bool f16_poly = e->use_poly && e->info.partitions == 1;
+	// 4096-tap engines run fp32 in direct form but fp16 in polyphase form: measured 0.317 vs 0.338 ms (fp16 kernels keep
+	// 3 waves per SIMD either way, so the saved spectrum multiply shows; in fp32 the direct form is 7 % faster)
+	const bool f16_alt  = e->use_p2 && e->d_Hp.p != nullptr;
+	const bool f16_poly = (e->use_poly && e->info.partitions == 1) || f16_alt;
 	const bool f16_p2   = e->use_p2 && e->info.partitions == 2;
 	if (!f16_poly && !f16_p2 && (e->use_poly || e->info.partitions != 1)) {
 		return PROT_EUNSUPPORTED;
@@ -909,13 +912,13 @@ int prot_apply_dev_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uin
 	p.out        = (_Float16*)d_out;
 	p.out_stride = out_stride;
 	p.n_out      = (int64_t)n_out;
-	p.H          = e->d_H.p;
+	p.H          = f16_alt ? e->d_Hp.p : e->d_H.p;
 	p.tw         = e->d_tw.p;
 	p.rot        = e->d_rot.p;
 	p.run_frames = pick_run_frames (e, n_out, nc); // the engine's own transform block: the fp16 kernels share its form
 	p.conv_delay = (int)e->info.conv_delay;
 	p.dry_delay  = (int)e->info.dry_delay;
-	hipError_t err = f16_poly ? prot::launch_ola_poly_f16 (p, e->hopseg / 2, nc, s)
+	hipError_t err = f16_poly ? prot::launch_ola_poly_f16 (p, f16_alt ? 8 : e->hopseg / 2, nc, s)
 	               : f16_p2   ? prot::launch_ola4096_p2_f16 (p, nc, s)
 	                          : prot::launch_ola4096_f16 (p, e->hopseg, nc, s);
 	if (err != hipSuccess) {
