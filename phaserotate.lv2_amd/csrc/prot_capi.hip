@@ -634,6 +634,11 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 			e->wg_slots = cus * ((use_p2 || use_poly) ? 2 : 3); // 53 KiB (70 KiB for the p2 kernel) of LDS per workgroup
 		}
 	}
+	if (const char* o = getenv ("PROT_WG_PER_CU")) { // tuning
+		int cus = 256;
+		(void)hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, cfg->device);
+		e->wg_slots = cus * atoi (o);
+	}
 	if (const char* o = getenv ("PROT_PAIRS_PER_RUN")) {
 		e->pairs_per_run_override = atoi (o);
 	}

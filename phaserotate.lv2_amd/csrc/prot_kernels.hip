@@ -50,6 +50,35 @@
 
 namespace prot {
 
+// PROT_STAMPS (diagnostic build only, tools/phase_stamps.py): per-phase shader-cycle sums of the polyphase kernel's
+// main loop, accumulated per wave in SGPRs and added to g_stamps at the end.  Each stamp is an s_memtime, which
+// drains lgkmcnt: the stamped build runs ~10 % slower and nothing of it exists in the shipped library.
+#ifdef PROT_STAMPS
+__device__ unsigned long long g_stamps[32];
+struct Stamps {
+	uint64_t last, acc[16];
+	__device__ __forceinline__ void start ()
+	{
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			acc[i] = 0;
+		}
+		last = __builtin_readcyclecounter ();
+	}
+	__device__ __forceinline__ void tick (int i)
+	{
+		const uint64_t now = __builtin_readcyclecounter ();
+		acc[i] += now - last;
+		last = now;
+	}
+};
+#else
+struct Stamps {
+	__device__ __forceinline__ void start () {}
+	__device__ __forceinline__ void tick (int) {}
+};
+#endif
+
 // ------------------------------------------------------------------ helpers
 // virtual stream [hist | in | silence] at index i (i may be negative)
 template <class S>
@@ -561,19 +590,73 @@ PROT_DEV void twiddle_store (typename T::cplx (&v)[16], const typename T::cplx (
 	}
 }
 
+// the same with the W256 twiddles fetched from LDS four at a time, one batch ahead of its multiplies (QB = 4:
+// 16 VGPRs of twiddles in flight instead of 30) -- the register diet of the 3-workgroups-per-CU instantiations.
+// `r` = &twm[tl]; q0 = batch 0 (k = 1..3), fetched by the caller ahead of the butterfly
+template <class T, int DIR, int STRIDE>
+PROT_DEV void twiddle_store_lean (typename T::cplx (&v)[16], const PROT_LDS_PTR (T) * r, const typename T::cplx (&q0)[4],
+                                  PROT_LDS_PTR (T) * dst)
+{
+	typedef typename T::ops  O;
+	typedef typename T::cplx C;
+	C q[2][4];
+#pragma unroll
+	for (int i = 1; i < 4; ++i) {
+		q[0][i] = q0[i];
+	}
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		if (j < 3) {
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				q[(j + 1) & 1][i] = r[16 * (4 * (j + 1) + i)];
+			}
+		}
+		if (j == 0) {
+			dst[0] = v[0];
+			v[1]   = O::template cmul<DIR> (v[1], q[0][1]);
+			dst[STRIDE] = v[1];
+			O::template cmul2<DIR> (v[2], q[0][2], v[3], q[0][3]);
+			dst[2 * STRIDE] = v[2];
+			dst[3 * STRIDE] = v[3];
+		} else {
+#pragma unroll
+			for (int i = 0; i < 4; i += 2) {
+				const int k = 4 * j + i;
+				O::template cmul2<DIR> (v[k], q[j & 1][i], v[k + 1], q[j & 1][i + 1]);
+				dst[k * STRIDE]       = v[k];
+				dst[(k + 1) * STRIDE] = v[k + 1];
+			}
+		}
+	}
+}
+
 // forward transform up to (not including) the last radix-16 pass; `before_last` runs between the
 // issue of the last exchange reads and that pass (the caller fetches its first table entries there)
-template <class T, int NNZ, class F>
+template <class T, int NNZ, bool LEAN, class F>
 PROT_DEV void fwd4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const typename T::cplx* twm,
-                        const typename T::cplx (&tw1)[16], int t, int tl, int th, F&& before_last)
+                        const typename T::cplx (&tw1)[16], int t, int tl, int th, F&& before_last, Stamps& st)
 {
 	typedef typename T::cplx C;
 	typedef PROT_LDS_PTR (T) VC;
 	typedef typename T::ops  O;
-	if (!(PROT_ABL2 & 4)) pkt_fft16_fwd_pruned<O, NNZ> (v);
 	// own slots (k*kL1 + t) -- read by this thread at the end of the previous inverse: no barrier in front
-	twiddle_store<T, 1, kL1> (v, tw1, (VC*)&lds[t]);
+	if (LEAN) { // split outer twiddles: tw1[1..3] = W^{t i}, tw1[5..7] = W^{4 t i}
+		const C (&A)[4] = reinterpret_cast<const C (&)[4]> (tw1[0]);
+		const C (&B)[4] = reinterpret_cast<const C (&)[4]> (tw1[4]);
+		pkt_fft16_fwd_pruned_twout<O, NNZ> (v, A, B);
+		VC* w = (VC*)&lds[t];
+#pragma unroll
+		for (int k = 0; k < 16; ++k) {
+			w[k * kL1] = v[k];
+		}
+	} else {
+		if (!(PROT_ABL2 & 4)) pkt_fft16_fwd_pruned<O, NNZ> (v);
+		twiddle_store<T, 1, kL1> (v, tw1, (VC*)&lds[t]);
+	}
+	st.tick (1);
 	if (!(PROT_ABL2 & 2)) __syncthreads ();
+	st.tick (2);
 	{
 		const VC* r = (const VC*)&lds[th * kL1 + tl];
 #pragma unroll
@@ -581,11 +664,22 @@ PROT_DEV void fwd4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 			if (!(PROT_ABL2 & 1)) v[k] = r[16 * k];
 		}
 	}
-	C q[16];
-	twm_fetch<T> (q, twm, tl);
-	__builtin_amdgcn_sched_barrier (0);
-	if (!(PROT_ABL2 & 4)) pkt_fft16<O, 1> (v);
-	twiddle_store<T, 1, 1> (v, q, (VC*)&lds[th * kL1 + tl * kG]);
+	if (LEAN) {
+		C q0[4];
+		const VC* rq = (const VC*)&twm[tl];
+#pragma unroll
+		for (int i = 1; i < 4; ++i) {
+			q0[i] = rq[16 * i];
+		}
+		pkt_fft16<O, 1> (v);
+		twiddle_store_lean<T, 1, 1> (v, rq, q0, (VC*)&lds[th * kL1 + tl * kG]);
+	} else {
+		C q[16];
+		twm_fetch<T> (q, twm, tl);
+		__builtin_amdgcn_sched_barrier (0);
+		if (!(PROT_ABL2 & 4)) pkt_fft16<O, 1> (v);
+		twiddle_store<T, 1, 1> (v, q, (VC*)&lds[th * kL1 + tl * kG]);
+	}
 	wave_sync ();
 	{
 		const VC* r = (const VC*)&lds[th * kL1 + tl];
@@ -594,23 +688,45 @@ PROT_DEV void fwd4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 			if (!(PROT_ABL2 & 1)) v[k] = r[k * kG];
 		}
 	}
+	st.tick (3);
 	before_last ();
-	__builtin_amdgcn_sched_barrier (0);
+	if (!LEAN) {
+		__builtin_amdgcn_sched_barrier (0);
+	}
 	if (!(PROT_ABL2 & 4)) pkt_fft16<O, 1> (v);
+	st.tick (4);
+}
+template <class T, int NNZ, class F>
+PROT_DEV void fwd4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const typename T::cplx* twm,
+                        const typename T::cplx (&tw1)[16], int t, int tl, int th, F&& before_last)
+{
+	Stamps st;
+	fwd4096w<T, NNZ, false> (v, lds, twm, tw1, t, tl, th, before_last, st);
 }
 
-template <class T>
+template <class T, bool LEAN>
 PROT_DEV void inv4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const typename T::cplx* twm,
-                        const typename T::cplx (&tw1)[16], int t, int tl, int th)
+                        const typename T::cplx (&tw1)[16], int t, int tl, int th, Stamps& st)
 {
 	typedef typename T::cplx C;
 	typedef PROT_LDS_PTR (T) VC;
 	typedef typename T::ops  O;
-	C q[16];
-	twm_fetch<T> (q, twm, tl); // W256^{k2 n1}: the table is symmetric, so lanes read neighbours here too
-	__builtin_amdgcn_sched_barrier (0);
-	if (!(PROT_ABL2 & 4)) pkt_fft16<O, -1> (v);
-	twiddle_store<T, -1, kG> (v, q, (VC*)&lds[th * kL1 + tl]);
+	if (LEAN) {
+		C q0[4];
+		const VC* rq = (const VC*)&twm[tl];
+#pragma unroll
+		for (int i = 1; i < 4; ++i) {
+			q0[i] = rq[16 * i];
+		}
+		pkt_fft16<O, -1> (v);
+		twiddle_store_lean<T, -1, kG> (v, rq, q0, (VC*)&lds[th * kL1 + tl]);
+	} else {
+		C q[16];
+		twm_fetch<T> (q, twm, tl); // W256^{k2 n1}: the table is symmetric, so lanes read neighbours here too
+		__builtin_amdgcn_sched_barrier (0);
+		if (!(PROT_ABL2 & 4)) pkt_fft16<O, -1> (v);
+		twiddle_store<T, -1, kG> (v, q, (VC*)&lds[th * kL1 + tl]);
+	}
 	wave_sync ();
 	{
 		const VC* r = (const VC*)&lds[th * kL1 + tl * kG];
@@ -628,21 +744,37 @@ PROT_DEV void inv4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 		for (int k = 0; k < 16; ++k) {
 			if (!(PROT_ABL2 & 1)) w[16 * k] = v[k];
 		}
+		st.tick (7);
 		if (!(PROT_ABL2 & 2)) __syncthreads ();
+		st.tick (8);
 		const VC* r = (const VC*)&lds[t];
 #pragma unroll
 		for (int k = 0; k < 16; ++k) {
 			if (!(PROT_ABL2 & 1)) v[k] = r[k * kL1];
 		}
 	}
-	if (!(PROT_ABL2 & 8)) {
-		v[1] = O::template cmul<-1> (v[1], tw1[1]);
+	if (LEAN) {
+		const C (&A)[4] = reinterpret_cast<const C (&)[4]> (tw1[0]);
+		const C (&B)[4] = reinterpret_cast<const C (&)[4]> (tw1[4]);
+		pkt_fft16_inv_twin<O> (v, A, B);
+	} else {
+		if (!(PROT_ABL2 & 8)) {
+			v[1] = O::template cmul<-1> (v[1], tw1[1]);
 #pragma unroll
-		for (int k = 2; k < 16; k += 2) {
-			O::template cmul2<-1> (v[k], tw1[k], v[k + 1], tw1[k + 1]);
+			for (int k = 2; k < 16; k += 2) {
+				O::template cmul2<-1> (v[k], tw1[k], v[k + 1], tw1[k + 1]);
+			}
 		}
+		if (!(PROT_ABL2 & 4)) pkt_fft16<O, -1> (v);
 	}
-	if (!(PROT_ABL2 & 4)) pkt_fft16<O, -1> (v);
+	st.tick (9);
+}
+template <class T>
+PROT_DEV void inv4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const typename T::cplx* twm,
+                        const typename T::cplx (&tw1)[16], int t, int tl, int th)
+{
+	Stamps st;
+	inv4096w<T, false> (v, lds, twm, tw1, t, tl, th, st);
 }
 
 // DH: dry path from registers, (dry_delay - conv_delay) / 256 in 1..8; DH = 0: dry frames re-read
@@ -914,6 +1046,22 @@ __global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaPa
 	hist_write_slice (p, blockIdx.y, threadIdx.x);
 }
 
+// PROT_TUNING builds only (tools/ab_build.py): PROT_DBG_DYNLDS = bytes of dynamic LDS added to every OLA launch, to
+// take resident workgroups away from a CU without touching the code
+static unsigned dbg_dyn_lds ()
+{
+#ifdef PROT_TUNING
+	static int v = -1;
+	if (v < 0) {
+		const char* e = getenv ("PROT_DBG_DYNLDS");
+		v             = e ? atoi (e) : 0;
+	}
+	return (unsigned)v;
+#else
+	return 0;
+#endif
+}
+
 template <class T, int MODE>
 static hipError_t launch_p2_m (const OlaParamsT<typename T::samp>& p, dim3 grid, hipStream_t s)
 {
@@ -982,9 +1130,12 @@ hipError_t launch_ola4096_p2_f16 (const OlaParamsH& p, int n_chn, hipStream_t s)
 // DPP wave shift at the point of use; lane 0 of a wave gets it from a scalar load).  (p, q) feeds
 // the transform, (q, c) is kept for the dry path.
 // --------------------------------------------------------------------------------------
-template <class T, int NP, int HS, int MODE, int DH, bool ACC>
-__global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParamsT<typename T::samp> p)
+// WPS = workgroups per CU (= waves per SIMD) the register budget is sized for: 2 (<= 256 VGPRs, tables fetched a whole
+// butterfly ahead) or 3 (<= 168 VGPRs: tables fetched in small batches, 3 x 53 KiB of LDS is the whole CU)
+template <class T, int NP, int HS, int MODE, int DH, bool ACC, int WPS = 2>
+__global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<typename T::samp> p)
 {
+	constexpr bool LEAN = WPS >= 3;
 	typedef typename T::cplx C;  // one complex of the transform = one PAIR of stream frames in HBM
 	typedef typename T::ops  O;
 	typedef typename T::samp S;
@@ -1029,9 +1180,17 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParamsT<type
 
 	const f2* __restrict__ twp = reinterpret_cast<const f2*> (p.tw);
 	C tw1[16];
+	if (LEAN) { // split form (pkt_fft16_fwd_pruned_twout): [1..3] = W^{t i}, [5..7] = W^{4 t i}; the rest is never read
 #pragma unroll
-	for (int k = 1; k < 16; ++k) {
-		tw1[k] = O::mk (twp[(t * k) & 4095].x, twp[(t * k) & 4095].y);
+		for (int i = 1; i < 4; ++i) {
+			tw1[i]     = O::mk (twp[(t * i) & 4095].x, twp[(t * i) & 4095].y);
+			tw1[4 + i] = O::mk (twp[(4 * t * i) & 4095].x, twp[(4 * t * i) & 4095].y);
+		}
+	} else {
+#pragma unroll
+		for (int k = 1; k < 16; ++k) {
+			tw1[k] = O::mk (twp[(t * k) & 4095].x, twp[(t * k) & 4095].y);
+		}
 	}
 	twm[t] = O::mk (twp[16 * (((t & 15) * (t >> 4)) & 255)].x, twp[16 * (((t & 15) * (t >> 4)) & 255)].y);
 	for (int i = t; i <= 2048; i += 256) {
@@ -1072,48 +1231,63 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParamsT<type
 		dh[i]           = DH > 0 ? mkf2 (ldv (in, n_in, hist, p.hist_len, a), ldv (in, n_in, hist, p.hist_len, a + 1)) : mkf2 (0.f, 0.f);
 	}
 
-	// frames a-1 | a, a+1 of sample j = t + 256 k, a = a0 + 2 j
-	float nxp[HS], nxb[HS];
+	// frames a, a+1 of sample j = t + 256 k, a = a0 + 2 j, as the pair (q, c); the frame in front, p = x[a-1], is the c of
+	// the previous sample, i.e. of lane t-1 (one DPP wave shift at the point of use), except in lane 0 of a wave:
+	// those HS frames (one per row) come with ONE gather load per wave, lane k fetching row k's into nxg.
+	// (A vector load on purpose: scalar loads of fresh stream data sit in lgkmcnt for a whole HBM round trip, and
+	// every LDS wait of the transform behind them then waits for that.)  The bounds-checked and unaligned forms
+	// load the same registers, so the loop carries one representation.
+	float nxg = 0.f;
 	f2    nxqc[HS];
-	bool  nx_shift = false; // (wave-uniform) nxp is to be derived from nxqc / nxb
 	auto  load_block = [&] (int64_t a0) {
-		const bool fast = (a0 - 1 >= 0) && (a0 + BLK <= n_in);
-		nx_shift = fast && in_al8;
-		if (fast && in_al8) {
-			// the stream exactly once, as aligned 8-byte pairs (q, c); p = x[a-1] is the c of the previous
-			// sample, i.e. of lane t-1 (one DPP wave shift at the point of use), except in lane 0 of a
-			// wave, which gets it from a wave-uniform scalar load (nxb)
-			const unsigned w128 = (unsigned)__builtin_amdgcn_readfirstlane (t >> 6) * 128u;
+		const bool     fast = (a0 - 1 >= 0) && (a0 + BLK <= n_in);
+		const unsigned l    = (unsigned)t & 63u;
+		const unsigned grow = l < (unsigned)HS ? l : 0u; // row whose leading frame this lane gathers
+		if (PROT_ABL2 & 32) { // no stream loads
+#pragma unroll
+			for (int k = 0; k < HS; ++k) {
+				nxqc[k] = mkf2 (0.002f * (float)(t - k), 0.003f * (float)(t + 2 * k));
+			}
+			nxg = 0.001f * (float)t;
+		} else if (fast && in_al8) {
+			// the stream exactly once, as aligned 8-byte pairs
 #pragma unroll
 			for (int m = 0; m < HS / 2; ++m) { // one SGPR base per 1024 frames: the immediate offset reaches 4 KiB
 				const PROT_GLOBAL S* __restrict__ b = uniform_ptr (in + a0 + 1024 * m);
 #pragma unroll
 				for (int e = 0; e < 2; ++e) {
 					nxqc[2 * m + e] = to_f2 (reinterpret_cast<const PROT_GLOBAL C*> (b)[(unsigned)t + 256u * e]);
-					nxb[2 * m + e]  = (float)(b - 1)[w128 + 512u * e];
 				}
 			}
+			const PROT_GLOBAL S* __restrict__ b = uniform_ptr (in + a0 - 1);
+			nxg = (float)b[((unsigned)t & ~63u) * 2u + 512u * grow];
 		} else if (fast) {
 #pragma unroll
 			for (int m = 0; m < HS / 2; ++m) {
 				const PROT_GLOBAL S* __restrict__ b = uniform_ptr (in + a0 + 1024 * m);
 #pragma unroll
 				for (int e = 0; e < 2; ++e) {
-					nxp[2 * m + e]  = (float)(b - 1)[2u * (unsigned)t + 512u * e];
 					nxqc[2 * m + e] = mkf2 ((float)b[2u * (unsigned)t + 512u * e], (float)(b + 1)[2u * (unsigned)t + 512u * e]);
 				}
 			}
+			const PROT_GLOBAL S* __restrict__ b = uniform_ptr (in + a0 - 1);
+			nxg = (float)b[((unsigned)t & ~63u) * 2u + 512u * grow];
 		} else {
 #pragma unroll
 			for (int k = 0; k < HS; ++k) {
 				const int64_t a = a0 + 2 * (int64_t)(t + 256 * k);
-				nxp[k]          = ldv (in, n_in, hist, p.hist_len, a - 1);
 				nxqc[k]         = mkf2 (ldv (in, n_in, hist, p.hist_len, a), ldv (in, n_in, hist, p.hist_len, a + 1));
 			}
+			nxg = ldv (in, n_in, hist, p.hist_len, a0 + 2 * (int64_t)(((unsigned)t & ~63u) + 256u * grow) - 1);
 		}
 	};
 	load_block (s - Dc);
 	__syncthreads ();
+	Stamps st;
+	st.start ();
+#ifdef PROT_STAMPS
+	const uint64_t st_c0 = __builtin_readcyclecounter (), st_r0 = __builtin_amdgcn_s_memrealtime ();
+#endif
 
 	for (int it = 0; it < n_it; ++it, s += BLK) {
 		C  v[16];
@@ -1125,15 +1299,14 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParamsT<type
 #pragma unroll
 		for (int k = 0; k < HS; ++k) {
 			cur[k] = nxqc[k];
-			float pk_ = nxp[k];
-			if (nx_shift) { // wave_shr:1 -- lane i reads lane i-1, lane 0 keeps `old` = the scalar-loaded frame
-				pk_ = __uint_as_float (__builtin_amdgcn_update_dpp (__float_as_uint (nxb[k]), __float_as_uint (nxqc[k].y), 0x138, 0xf, 0xf, false));
-			}
+			// wave_shr:1 -- lane i reads lane i-1, lane 0 keeps `old` = the gathered frame of this row
+			const unsigned first = (unsigned)__builtin_amdgcn_readlane ((int)__float_as_uint (nxg), k);
+			const float    pk_   = __uint_as_float (__builtin_amdgcn_update_dpp (first, __float_as_uint (nxqc[k].y), 0x138, 0xf, 0xf, false));
 			v[k] = O::mk (pk_, nxqc[k].x);
 		}
 
 		// spectrum tables, HB bins per batch, one batch in flight ahead of the multiplies
-		constexpr int HB = NP == 2 ? 2 : 4; // two partitions: half the batch, the kernel is at the 256-VGPR limit
+		constexpr int HB = (NP == 2 || LEAN) ? 2 : 4; // two partitions: half the batch, the kernel is at the 256-VGPR limit
 		C             hb[2][NP * HB];
 		auto          h_fetch = [&] (int j) {
 #pragma unroll
@@ -1146,7 +1319,8 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParamsT<type
 				}
 			}
 		};
-		fwd4096w<T, HS> (v, lds, twm, tw1, t, tl, th, [&] () { h_fetch (0); });
+		st.tick (0);
+		fwd4096w<T, HS, LEAN> (v, lds, twm, tw1, t, tl, th, [&] () { h_fetch (0); }, st);
 
 		// Y = Z G0 (+ Z_prev G1); bins >= 2048 use the conjugate of the mirrored bin
 #pragma unroll
@@ -1181,6 +1355,7 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParamsT<type
 			__builtin_amdgcn_sched_barrier (0);
 		}
 
+		st.tick (5);
 		__builtin_amdgcn_sched_barrier (0);
 		if (it + 1 < n_it) {
 			load_block (s + BLK - Dc);
@@ -1206,7 +1381,8 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParamsT<type
 			}
 		}
 
-		inv4096w<T> (v, lds, twm, tw1, t, tl, th);
+		st.tick (6);
+		inv4096w<T, LEAN> (v, lds, twm, tw1, t, tl, th, st);
 
 		f2 u[HS];
 #pragma unroll
@@ -1220,7 +1396,7 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParamsT<type
 
 		if (it >= NP) {
 			const bool full = s + BLK <= r1;
-			if (MODE == MODE_ROT && !ACC && full && out_al8) {
+			if (MODE == MODE_ROT && !ACC && full && out_al8 && !(PROT_ABL2 & 64)) {
 				const f2 ca2 = mkf2 (ca, ca), sa2 = mkf2 (sa, sa);
 #pragma unroll
 				for (int m = 0; m < HS / 2; ++m) {
@@ -1237,7 +1413,7 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParamsT<type
 					for (int h = 0; h < 2; ++h) {
 						const int64_t pos = s + 2 * (int64_t)(t + 256 * k) + h;
 						const float   uu  = h ? u[k].y : u[k].x;
-						if (pos < r1) {
+						if ((PROT_ABL2 & 64) ? (pos < r1 && uu == 123.456f) : (pos < r1)) { // 64: (almost) no stores
 							if (MODE == MODE_HILBERT) {
 								out[pos] = ACC ? (S)((float)out[pos] + uu) : (S)uu;
 							} else {
@@ -1254,7 +1430,20 @@ __global__ __launch_bounds__ (256, 2) void olapoly_kernel (const OlaParamsT<type
 				}
 			}
 		}
+		st.tick (10);
 	}
+#ifdef PROT_STAMPS
+	if ((t & 63) == 0) {
+#pragma unroll
+		for (int i = 0; i < 11; ++i) {
+			atomicAdd (&g_stamps[i], (unsigned long long)st.acc[i]);
+		}
+		atomicAdd (&g_stamps[16], (unsigned long long)n_it);
+		atomicAdd (&g_stamps[17], (unsigned long long)(__builtin_readcyclecounter () - st_c0));
+		atomicAdd (&g_stamps[18], (unsigned long long)(__builtin_amdgcn_s_memrealtime () - st_r0));
+		atomicAdd (&g_stamps[19], 1ull);
+	}
+#endif
 	// (two partitions: the kernel is at the 256-VGPR / 106-SGPR limit and the extra live parameters pushed spills
 	// into its main loop, +22 % time at 8192 taps -- those engines keep the separate history kernel)
 	if (NP == 1) {
@@ -1273,11 +1462,15 @@ static hipError_t launch_poly_m (const OlaParamsT<typename T::samp>& p, dim3 gri
 	constexpr int DHS = HS == 8 ? (NP == 2 ? 8 : 4) : HS == 10 ? 3 : HS == 12 ? 2 : 1;
 	const dim3 block (256);
 	if (p.accumulate) {
-		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, 0, true>), grid, block, 0, s, p);
+		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, 0, true>), grid, block, dbg_dyn_lds (), s, p);
+#ifdef PROT_TUNING
+	} else if (MODE == MODE_ROT && NP == 1 && dd == DHS && getenv ("PROT_POLY_WPS") && atoi (getenv ("PROT_POLY_WPS")) == 3) {
+		hipLaunchKernelGGL ((olapoly_kernel<T, 1, HS, MODE_ROT, DHS, false, 3>), grid, block, dbg_dyn_lds (), s, p);
+#endif
 	} else if (MODE != MODE_HILBERT && dd == DHS) {
-		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, DHS, false>), grid, block, 0, s, p);
+		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, DHS, false>), grid, block, dbg_dyn_lds (), s, p);
 	} else {
-		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, 0, false>), grid, block, 0, s, p);
+		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, 0, false>), grid, block, dbg_dyn_lds (), s, p);
 	}
 	return hipGetLastError ();
 }
@@ -1358,31 +1551,31 @@ static hipError_t launch_ola4096_m (const OlaParams& p, dim3 grid, hipStream_t s
 {
 	dim3 block (256);
 	if (p.accumulate) {
-		hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, true>), grid, block, 0, s, p);
+		hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, true>), grid, block, dbg_dyn_lds (), s, p);
 		return hipGetLastError ();
 	}
 	// dry path from registers when the delay difference is a small multiple of 256 frames
 	const int dd = p.dry_delay - p.conv_delay;
 	if (MODE != MODE_HILBERT && ola_variant () == 0 && dd > 0 && dd % 256 == 0) {
 		switch (dd / 256) {
-			case 2: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, false, 2>), grid, block, 0, s, p); return hipGetLastError ();
-			case 4: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, false, 4>), grid, block, 0, s, p); return hipGetLastError ();
-			case 6: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, false, 6>), grid, block, 0, s, p); return hipGetLastError ();
+			case 2: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, false, 2>), grid, block, dbg_dyn_lds (), s, p); return hipGetLastError ();
+			case 4: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, false, 4>), grid, block, dbg_dyn_lds (), s, p); return hipGetLastError ();
+			case 6: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, false, 6>), grid, block, dbg_dyn_lds (), s, p); return hipGetLastError ();
 			default: break;
 		}
 	}
 	switch (ola_variant ()) {
-		case 1: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE>), grid, block, 0, s, p); break; // global dry loads
-		case 3: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, false, 0, false>), grid, block, 0, s, p); break; // scalar butterflies
-		case 11: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 1>), grid, block, 0, s, p); break;
-		case 12: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 2>), grid, block, 0, s, p); break;
-		case 13: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 3>), grid, block, 0, s, p); break;
-		case 18: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 8>), grid, block, 0, s, p); break;
-		case 19: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 9>), grid, block, 0, s, p); break;
-		case 20: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 10>), grid, block, 0, s, p); break;
-		case 21: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 11>), grid, block, 0, s, p); break;
-		case 25: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 15>), grid, block, 0, s, p); break;
-		default: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE>), grid, block, 0, s, p); break;
+		case 1: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE>), grid, block, dbg_dyn_lds (), s, p); break; // global dry loads
+		case 3: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, false, 0, false>), grid, block, dbg_dyn_lds (), s, p); break; // scalar butterflies
+		case 11: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 1>), grid, block, dbg_dyn_lds (), s, p); break;
+		case 12: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 2>), grid, block, dbg_dyn_lds (), s, p); break;
+		case 13: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 3>), grid, block, dbg_dyn_lds (), s, p); break;
+		case 18: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 8>), grid, block, dbg_dyn_lds (), s, p); break;
+		case 19: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 9>), grid, block, dbg_dyn_lds (), s, p); break;
+		case 20: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 10>), grid, block, dbg_dyn_lds (), s, p); break;
+		case 21: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 11>), grid, block, dbg_dyn_lds (), s, p); break;
+		case 25: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 15>), grid, block, dbg_dyn_lds (), s, p); break;
+		default: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE>), grid, block, dbg_dyn_lds (), s, p); break;
 	}
 	return hipGetLastError ();
 }
@@ -1932,3 +2125,23 @@ hipError_t launch_interleave (const float* planar, int64_t stride, float* inter,
 }
 
 } // namespace prot
+
+#ifdef PROT_STAMPS
+extern "C" int prot_debug_stamps (unsigned long long* out, int n, int reset)
+{
+	unsigned long long h[32];
+	if (hipMemcpyFromSymbol (h, HIP_SYMBOL (prot::g_stamps), sizeof (h)) != hipSuccess) {
+		return -1;
+	}
+	for (int i = 0; i < n && i < 32; ++i) {
+		out[i] = h[i];
+	}
+	if (reset) {
+		unsigned long long z[32] = {};
+		if (hipMemcpyToSymbol (HIP_SYMBOL (prot::g_stamps), z, sizeof (z)) != hipSuccess) {
+			return -1;
+		}
+	}
+	return 0;
+}
+#endif

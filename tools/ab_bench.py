@@ -12,7 +12,7 @@ dev = torch.device("cuda:0")
 cases = {"hop1024": (pkg.KIND_LV2, 48000, 1), "p2": (pkg.KIND_LV2, 48000, 2), "p2_96k": (pkg.KIND_LV2, 96000, 2),
          "poly": (pkg.KIND_LV2, 48000, 0), "poly_96k": (pkg.KIND_LV2, 96000, 0), "poly_192k": (pkg.KIND_LV2, 192000, 0),
          "polyf_48k": (pkg.KIND_LV2, 48000, 4), "polyf_96k": (pkg.KIND_LV2, 96000, 4), "polyf_cli2048": (pkg.KIND_CLI, 2048, 4),
-         "cli": (pkg.KIND_CLI, 2048, 0), "cli4096": (pkg.KIND_CLI, 4096, 0), "cli8192": (pkg.KIND_CLI, 8192, 0),
+         "cli": (pkg.KIND_CLI, 2048, 0), "cli1024": (pkg.KIND_CLI, 1024, 0), "cli_direct": (pkg.KIND_CLI, 2048, 2), "cli4096": (pkg.KIND_CLI, 4096, 0), "cli8192": (pkg.KIND_CLI, 8192, 0),
          "cli8192_direct": (pkg.KIND_CLI, 8192, 2), "cli32768": (pkg.KIND_CLI, 32768, 0), "cli32768_direct": (pkg.KIND_CLI, 32768, 2)}
 n = 1 << 27
 x = (torch.rand(n, device=dev) - 0.5); y = torch.empty_like(x)
