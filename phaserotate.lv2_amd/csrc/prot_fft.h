@@ -18,6 +18,7 @@ namespace prot {
 // complex value = one aligned VGPR pair; .x = re, .y = im
 typedef float f2 __attribute__ ((ext_vector_type (2)));
 PROT_DEV f2 mkf2 (float x, float y) { return f2{ x, y }; }
+typedef float f4 __attribute__ ((ext_vector_type (4)));
 
 // a * w for DIR > 0, a * conj(w) for DIR < 0   (w = forward twiddle e^{-i phi})
 template <int DIR>

@@ -55,6 +55,7 @@ namespace prot {
 // drains lgkmcnt: the stamped build runs ~10 % slower and nothing of it exists in the shipped library.
 #ifdef PROT_STAMPS
 __device__ unsigned long long g_stamps[32];
+__device__ unsigned long long g_wg_t[4 * 4096]; // per workgroup: entry, loop start, end (s_memrealtime, 100 MHz), HW_ID
 struct Stamps {
 	uint64_t last, acc[16];
 	__device__ __forceinline__ void start ()
@@ -521,6 +522,9 @@ struct T16 {
 #define PROT_ABL2 0
 #endif
 // where the next block's stream loads are issued: 0 = top of the iteration, 1 = after the spectrum multiply
+#ifndef PROT_LEAN_PIN
+#define PROT_LEAN_PIN 0
+#endif
 #ifndef PROT_PREFETCH_AT
 #define PROT_PREFETCH_AT 1
 #endif
@@ -612,6 +616,9 @@ PROT_DEV void twiddle_store_lean (typename T::cplx (&v)[16], const PROT_LDS_PTR 
 				q[(j + 1) & 1][i] = r[16 * (4 * (j + 1) + i)];
 			}
 		}
+#if PROT_LEAN_PIN
+		__builtin_amdgcn_sched_barrier (0);
+#endif
 		if (j == 0) {
 			dst[0] = v[0];
 			v[1]   = O::template cmul<DIR> (v[1], q[0][1]);
@@ -704,9 +711,9 @@ PROT_DEV void fwd4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 	fwd4096w<T, NNZ, false> (v, lds, twm, tw1, t, tl, th, before_last, st);
 }
 
-template <class T, bool LEAN>
+template <class T, bool LEAN, class F>
 PROT_DEV void inv4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const typename T::cplx* twm,
-                        const typename T::cplx (&tw1)[16], int t, int tl, int th, Stamps& st)
+                        const typename T::cplx (&tw1)[16], int t, int tl, int th, Stamps& st, F&& before_last)
 {
 	typedef typename T::cplx C;
 	typedef PROT_LDS_PTR (T) VC;
@@ -753,6 +760,7 @@ PROT_DEV void inv4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 			if (!(PROT_ABL2 & 1)) v[k] = r[k * kL1];
 		}
 	}
+	before_last ();
 	if (LEAN) {
 		const C (&A)[4] = reinterpret_cast<const C (&)[4]> (tw1[0]);
 		const C (&B)[4] = reinterpret_cast<const C (&)[4]> (tw1[4]);
@@ -774,7 +782,7 @@ PROT_DEV void inv4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
                         const typename T::cplx (&tw1)[16], int t, int tl, int th)
 {
 	Stamps st;
-	inv4096w<T, false> (v, lds, twm, tw1, t, tl, th, st);
+	inv4096w<T, false> (v, lds, twm, tw1, t, tl, th, st, [] () {});
 }
 
 // DH: dry path from registers, (dry_delay - conv_delay) / 256 in 1..8; DH = 0: dry frames re-read
@@ -1160,6 +1168,9 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 
 	const int     t  = threadIdx.x;
 	const int     c  = blockIdx.y;
+#ifdef PROT_STAMPS
+	const uint64_t st_entry = __builtin_amdgcn_s_memrealtime ();
+#endif
 	const int64_t r0 = (int64_t)blockIdx.x * p.run_frames;
 	if (r0 >= p.n_out) {
 		if (NP == 1) {
@@ -1239,7 +1250,7 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 	// load the same registers, so the loop carries one representation.
 	float nxg = 0.f;
 	f2    nxqc[HS];
-	auto  load_block = [&] (int64_t a0) {
+	auto  load_block = [&] (int64_t a0, int t) { // t: the thread id, passed in so that the loop can hide its loop-invariance
 		const bool     fast = (a0 - 1 >= 0) && (a0 + BLK <= n_in);
 		const unsigned l    = (unsigned)t & 63u;
 		const unsigned grow = l < (unsigned)HS ? l : 0u; // row whose leading frame this lane gathers
@@ -1281,7 +1292,7 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 			nxg = ldv (in, n_in, hist, p.hist_len, a0 + 2 * (int64_t)(((unsigned)t & ~63u) + 256u * grow) - 1);
 		}
 	};
-	load_block (s - Dc);
+	load_block (s - Dc, t);
 	__syncthreads ();
 	Stamps st;
 	st.start ();
@@ -1289,7 +1300,14 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 	const uint64_t st_c0 = __builtin_readcyclecounter (), st_r0 = __builtin_amdgcn_s_memrealtime ();
 #endif
 
+	const int t0 = t, tl0 = tl, th0 = th;
 	for (int it = 0; it < n_it; ++it, s += BLK) {
+		// the thread id, opaque per iteration: per-lane address terms (64-bit pointers of the bounds-checked paths, LDS
+		// addresses of the table reads) are otherwise hoisted out of the loop as loop invariants and sit in ~30 VGPRs
+		// for the whole run; recomputed in place they fold into immediate offsets or stay inside their rare branch
+		int t = t0;
+		asm volatile ("" : "+v"(t));
+		const int tl = t & 15, th = t >> 4;
 		C  v[16];
 		f2 cur[HS];
 #pragma unroll
@@ -1358,7 +1376,7 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 		st.tick (5);
 		__builtin_amdgcn_sched_barrier (0);
 		if (it + 1 < n_it) {
-			load_block (s + BLK - Dc);
+			load_block (s + BLK - Dc, t);
 		}
 		__builtin_amdgcn_sched_barrier (0);
 
@@ -1373,16 +1391,34 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 			for (int i = 0; i < NDH; ++i) {
 				dh[i] = cur[HS - NDH + i];
 			}
-		} else if (MODE != MODE_HILBERT && !ACC && it >= NP) {
-#pragma unroll
-			for (int k = 0; k < HS; ++k) {
-				const int64_t d0 = s + 2 * (int64_t)(t + 256 * k) - Dd;
-				dry[k]           = mkf2 (ldv (in, n_in, hist, p.hist_len, d0), ldv (in, n_in, hist, p.hist_len, d0 + 1));
-			}
 		}
+		// DH = 0: the dry frames are read again from the stream (L2 / Infinity Cache: this workgroup fetched them one or two
+		// blocks ago) -- late, between the last exchange and the last pass of the inverse, so that no copy of the block
+		// occupies 2 HS registers through both transforms
+		auto dry_reread = [&] () {
+			if (DH == 0 && MODE != MODE_HILBERT && !ACC && it >= NP) {
+				const int64_t d0 = s - Dd;
+				if (d0 >= 0 && d0 + BLK <= n_in && in_al8 && !(Dd & 1)) {
+#pragma unroll
+					for (int m = 0; m < HS / 2; ++m) {
+						const PROT_GLOBAL S* __restrict__ b = uniform_ptr (in + d0 + 1024 * m);
+#pragma unroll
+						for (int e = 0; e < 2; ++e) {
+							dry[2 * m + e] = to_f2 (reinterpret_cast<const PROT_GLOBAL C*> (b)[(unsigned)t + 256u * e]);
+						}
+					}
+				} else {
+#pragma unroll
+					for (int k = 0; k < HS; ++k) {
+						const int64_t a = d0 + 2 * (int64_t)(t + 256 * k);
+						dry[k]          = mkf2 (ldv (in, n_in, hist, p.hist_len, a), ldv (in, n_in, hist, p.hist_len, a + 1));
+					}
+				}
+			}
+		};
 
 		st.tick (6);
-		inv4096w<T, LEAN> (v, lds, twm, tw1, t, tl, th, st);
+		inv4096w<T, LEAN> (v, lds, twm, tw1, t, tl, th, st, dry_reread);
 
 		f2 u[HS];
 #pragma unroll
@@ -1443,6 +1479,12 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 		atomicAdd (&g_stamps[18], (unsigned long long)(__builtin_amdgcn_s_memrealtime () - st_r0));
 		atomicAdd (&g_stamps[19], 1ull);
 	}
+	if (t == 0 && blockIdx.x < 4096) {
+		g_wg_t[4 * blockIdx.x]     = st_entry;
+		g_wg_t[4 * blockIdx.x + 1] = (unsigned long long)(__builtin_readcyclecounter () - st_c0); // shader cycles, loop start to end
+		g_wg_t[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime ();
+		g_wg_t[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg ((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg ((3 << 11) | 20) << 32);
+	}
 #endif
 	// (two partitions: the kernel is at the 256-VGPR / 106-SGPR limit and the extra live parameters pushed spills
 	// into its main loop, +22 % time at 8192 taps -- those engines keep the separate history kernel)
@@ -1466,6 +1508,8 @@ static hipError_t launch_poly_m (const OlaParamsT<typename T::samp>& p, dim3 gri
 #ifdef PROT_TUNING
 	} else if (MODE == MODE_ROT && NP == 1 && dd == DHS && getenv ("PROT_POLY_WPS") && atoi (getenv ("PROT_POLY_WPS")) == 3) {
 		hipLaunchKernelGGL ((olapoly_kernel<T, 1, HS, MODE_ROT, DHS, false, 3>), grid, block, dbg_dyn_lds (), s, p);
+	} else if (MODE == MODE_ROT && NP == 1 && getenv ("PROT_POLY_WPS") && atoi (getenv ("PROT_POLY_WPS")) == 4) {
+		hipLaunchKernelGGL ((olapoly_kernel<T, 1, HS, MODE_ROT, 0, false, 3>), grid, block, dbg_dyn_lds (), s, p);
 #endif
 	} else if (MODE != MODE_HILBERT && dd == DHS) {
 		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, DHS, false>), grid, block, dbg_dyn_lds (), s, p);
@@ -2143,5 +2187,9 @@ extern "C" int prot_debug_stamps (unsigned long long* out, int n, int reset)
 		}
 	}
 	return 0;
+}
+extern "C" int prot_debug_wg_times (unsigned long long* out, int n_wg)
+{
+	return hipMemcpyFromSymbol (out, HIP_SYMBOL (prot::g_wg_t), sizeof (unsigned long long) * 4 * (size_t)n_wg) == hipSuccess ? 0 : -1;
 }
 #endif
