@@ -631,7 +631,8 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	{
 		int cus = 0;
 		if (hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) {
-			e->wg_slots = cus * ((use_p2 || use_poly) ? 2 : 3); // 53 KiB (70 KiB for the p2 kernel) of LDS per workgroup
+			// 53 KiB of LDS per workgroup, 3 per CU -- except the kernels with two partitions in one launch (70 KiB, 2 per CU)
+			e->wg_slots = cus * ((use_p2 || (use_poly && n_part >= 2)) ? 2 : 3);
 		}
 	}
 	if (const char* o = getenv ("PROT_WG_PER_CU")) { // tuning

@@ -1502,19 +1502,18 @@ static hipError_t launch_poly_m (const OlaParamsT<typename T::samp>& p, dim3 gri
 	const int  diff = p.dry_delay - p.conv_delay;
 	const int  dd   = (diff > 0 && diff % 512 == 0) ? diff / 512 : 0;
 	constexpr int DHS = HS == 8 ? (NP == 2 ? 8 : 4) : HS == 10 ? 3 : HS == 12 ? 2 : 1;
+	// fp32, one partition: the register diet of the 3-workgroups-per-CU form (3 x 53 KiB of LDS = one CU)
+	// (the per-frame rotation of the ramp form with 12 or 14 rows per block does not fit 168 VGPRs: 2 per CU there)
+	constexpr int WPS = (NP == 1 && sizeof (typename T::samp) == 4 && !(MODE == MODE_RAMP && HS >= 12)) ? 3 : 2;
 	const dim3 block (256);
 	if (p.accumulate) {
-		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, 0, true>), grid, block, dbg_dyn_lds (), s, p);
-#ifdef PROT_TUNING
-	} else if (MODE == MODE_ROT && NP == 1 && dd == DHS && getenv ("PROT_POLY_WPS") && atoi (getenv ("PROT_POLY_WPS")) == 3) {
-		hipLaunchKernelGGL ((olapoly_kernel<T, 1, HS, MODE_ROT, DHS, false, 3>), grid, block, dbg_dyn_lds (), s, p);
-	} else if (MODE == MODE_ROT && NP == 1 && getenv ("PROT_POLY_WPS") && atoi (getenv ("PROT_POLY_WPS")) == 4) {
-		hipLaunchKernelGGL ((olapoly_kernel<T, 1, HS, MODE_ROT, 0, false, 3>), grid, block, dbg_dyn_lds (), s, p);
-#endif
+		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, 0, true, WPS>), grid, block, dbg_dyn_lds (), s, p);
 	} else if (MODE != MODE_HILBERT && dd == DHS) {
-		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, DHS, false>), grid, block, dbg_dyn_lds (), s, p);
+		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, DHS, false, WPS>), grid, block, dbg_dyn_lds (), s, p);
 	} else {
-		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, 0, false>), grid, block, dbg_dyn_lds (), s, p);
+		// (dry frames re-read from the stream: with 12 or 14 rows per block that form does not fit 168 VGPRs)
+		constexpr int WPS0 = (HS >= 12 && MODE != MODE_HILBERT) ? 2 : WPS;
+		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, 0, false, WPS0>), grid, block, dbg_dyn_lds (), s, p);
 	}
 	return hipGetLastError ();
 }

@@ -40,6 +40,7 @@ print("%s: %.4f ms per launch (stamped build); %d waves, %.1f iterations per wav
     name, ev0.elapsed_time(ev1) / reps, waves / reps, wave_it / waves, v[17] / v[18] * 100.0))
 print("  per wave: %.0f cycles in the loop+epilogue = %.1f us wall (launch %.1f us); loop phases sum %.0f cycles" % (
     v[17] / waves, v[18] / waves / 100.0, ev0.elapsed_time(ev1) / reps * 1e3, v[:11].sum() / waves))
+print("  stealing (per launch): chunks stolen %.0f, failed claims %.0f, victim searches %.0f, searches that found nothing %.0f" % (v[20] / reps, v[21] / reps, v[22] / reps, v[23] / reps))
 tot = v[:11].sum()
 for i in range(11):
     print("  %-44s %8.0f cycles  %5.1f %%" % (names[i], v[i] / wave_it, 100.0 * v[i] / tot))
@@ -97,3 +98,16 @@ print("  loop cycles by xcc (k, median):", {int(x): int(np.median(w[:, 1][xcc_of
 order = np.argsort(end)
 print("  blockIdx of the 12 last workgroups to finish:", [int(i) for i in order[-12:]], "first:", [int(i) for i in order[:12]])
 print("  correlation(blockIdx, end) %.2f" % np.corrcoef(np.arange(nwg), end)[0, 1])
+
+w2 = (C.c_ulonglong * (2 * nwg))()
+if lib.prot_debug_wg_times(w2, -nwg) == 0:
+    a = np.array(list(w2), dtype=np.int64).reshape(nwg, 2)
+    own = a[:, 0] & 0xffffffff; stolen = a[:, 0] >> 32; thief_us = a[:, 1] / 100.0
+    if stolen.sum() > 0:
+        done = end - thief_us
+        print("  owner phase ends (us): deciles", [round(float(q), 1) for q in np.percentile(done, [0, 10, 25, 50, 75, 90, 100])])
+        print("  chunks claimed by owners: histogram", {int(k_): int((own == k_).sum()) for k_ in sorted(set(own))})
+        print("  chunks taken elsewhere per workgroup: histogram", {int(k_): int((stolen == k_).sum()) for k_ in sorted(set(stolen))})
+        print("  time as a thief (us): median %.1f max %.1f; per stolen chunk %.1f us" % (np.median(thief_us), thief_us.max(), thief_us.sum() / max(1, stolen.sum())))
+        slow = np.argsort(done)[-20:]
+        print("  the 20 slowest owners: claims", [int(own[i]) for i in slow], "owner-phase end", [round(float(done[i])) for i in slow])
