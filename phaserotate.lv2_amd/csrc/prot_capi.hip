@@ -332,6 +332,49 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 	}
 	if (e->use_poly) {
 		const uint32_t np = std::min<uint32_t> (2, e->info.partitions); // partitions of g per launch
+		// one-round launches of the 3-per-CU kernels: run lengths by dispatch rank (olapoly_kernel)
+		{
+			const int64_t blk  = (int64_t)e->info.run_align;
+			const int64_t runs = ((int64_t)n_out + p.run_frames - 1) / p.run_frames;
+			const int     cus  = e->wg_slots / 3;
+			// measured (tools/ab_bench.py, PROT_RANK_W sweeps, headline / CLI 2048 / CLI 1024, ms per 2^27 frames): equal runs
+			// 0.315-0.326 / 0.270 / 0.248-0.257; 1.3:1:0.75 0.312-0.318 / 0.249-0.252 / 0.233; 1.45:0.95:0.6 0.291-0.302 /
+			// 0.243-0.251 / 0.230-0.239; 1.6:0.9:0.5 0.291-0.293 / 0.258-0.265 / 0.247; 1.8:0.8:0.4 0.313-0.323 / 0.273-0.281 / 0.26
+			double        w[3] = { 1.45, 0.95, 0.6 };
+			const char*   we   = getenv ("PROT_RANK_W"); // tuning: "w0,w1,w2" ("1,1,1": equal runs)
+			if (we && sscanf (we, "%lf,%lf,%lf", &w[0], &w[1], &w[2]) != 3) {
+				w[0] = 1.45, w[1] = 0.95, w[2] = 0.6;
+			}
+			if (np == 1 && e->wg_slots % 3 == 0 && cus > 0 && (w[0] != w[1] || w[1] != w[2]) &&
+			    runs * n_chn <= e->wg_slots && runs * n_chn > 2 * cus && p.run_frames / blk >= 12) {
+				const int64_t total = ((int64_t)n_out + blk - 1) / blk; // blocks per channel
+				const double  wsum  = w[0] + w[1] + w[2];
+				int64_t       nb[3];
+				for (int k = 0; k < 3; ++k) {
+					nb[k] = std::max<int64_t> (1, (int64_t)std::llround ((double)(p.run_frames / blk) * 3.0 * w[k] / wsum));
+				}
+				// every channel must be covered: lengthen the last rank until the least-covered channel is
+				for (;;) {
+					int64_t worst = INT64_MAX;
+					for (int y = 0; y < n_chn; ++y) {
+						int64_t cov = 0;
+						for (int64_t x = 0; x < runs; ++x) {
+							const int64_t rk = std::min<int64_t> (2, (y * runs + x) / cus);
+							cov += nb[rk];
+						}
+						worst = std::min (worst, cov);
+					}
+					if (worst >= total) {
+						break;
+					}
+					++nb[2];
+				}
+				p.rank_cu = cus;
+				for (int k = 0; k < 3; ++k) {
+					p.rank_frames[k] = (int)(nb[k] * blk);
+				}
+			}
+		}
 		for (uint32_t l = 0; l < e->info.partitions / np; ++l) {
 			p.H          = e->d_H.p + (size_t)(np * l) * e->info.fftlen;
 			p.conv_delay = (int)(e->info.conv_delay + np * l * e->info.fftlen); // a partition of g spans 4096 frames

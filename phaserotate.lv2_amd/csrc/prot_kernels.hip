@@ -240,7 +240,12 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 		}
 	}
 
+	const int t0 = t;
 	for (int it = 0; it < n_pairs; ++it, sA += 2 * HOP) {
+		// the thread id, opaque per iteration (see olapoly_kernel: keeps slow-path pointers out of loop-long registers)
+		int t = t0;
+		asm volatile ("" : "+v"(t));
+		const int tl = t & 15, th = t >> 4;
 		f2 v[16];
 		float  cur[2 * HOPSEG];
 #pragma unroll
@@ -788,8 +793,9 @@ PROT_DEV void inv4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 // DH: dry path from registers, (dry_delay - conv_delay) / 256 in 1..8; DH = 0: dry frames re-read
 // from the stream (larger delays); ACC: add this partition pair's share to what an earlier launch stored
 // (FIRs of more than 4096 taps: partitions 2s, 2s+1 per launch)
+// (fp16 with the dry path in registers does not fit the 168 VGPRs of 3 workgroups per CU without scratch: 2 there)
 template <class T, int MODE, int DH, bool ACC = false>
-__global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaParamsT<typename T::samp> p)
+__global__ __launch_bounds__ (256, (T::kWaves == 3 && DH > 0 && MODE != MODE_HILBERT) ? 2 : T::kWaves) void ola4096p2_kernel (const OlaParamsT<typename T::samp> p)
 {
 	typedef typename T::cplx C;
 	typedef typename T::ops  O;
@@ -897,7 +903,13 @@ __global__ __launch_bounds__ (256, T::kWaves) void ola4096p2_kernel (const OlaPa
 	load_blocks (sP - Dc, sQ - Dc);
 	__syncthreads ();
 
+	const int t0 = t;
 	for (int it = 0; it < n_it; ++it, sP += HOP, sQ += HOP) {
+		// the thread id, opaque per iteration: keeps the per-lane pointers of the bounds-checked paths and the LDS
+		// addresses of the table reads from being hoisted out of the loop into registers (see olapoly_kernel)
+		int t = t0;
+		asm volatile ("" : "+v"(t));
+		const int tl = t & 15, th = t >> 4;
 		C     v[16];
 		float cur[16];
 #pragma unroll
@@ -1171,14 +1183,33 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 #ifdef PROT_STAMPS
 	const uint64_t st_entry = __builtin_amdgcn_s_memrealtime ();
 #endif
-	const int64_t r0 = (int64_t)blockIdx.x * p.run_frames;
+	// The run of this workgroup.  One-round launches (every workgroup resident at once, p.rank_cu > 0) give the runs
+	// unequal lengths by DISPATCH RANK: the hardware arbitrates oldest-first, so of the three workgroups of a CU the one
+	// dispatched first runs ahead and the last one finishes alone, long after (ends at 196 / 281 / 347 us for equal
+	// runs at the headline).  Workgroups are dealt out in id order, one per CU per round, so id / CUs is the rank;
+	// if a dispatcher ever does it differently the lengths are merely not ideal -- the runs still tile the stream.
+	int64_t r0, rlen = p.run_frames;
+	if (p.rank_cu > 0) {
+		const int id = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, id0 = (int)blockIdx.y * (int)gridDim.x;
+		r0           = 0;
+#pragma unroll
+		for (int k = 0; k < 3; ++k) { // runs of rank k in front of this one, within the channel
+			const int lo = k * p.rank_cu > id0 ? k * p.rank_cu : id0;
+			const int hi = (k == 2 || (k + 1) * p.rank_cu > id) ? id : (k + 1) * p.rank_cu;
+			r0 += hi > lo ? (int64_t)(hi - lo) * p.rank_frames[k] : 0;
+		}
+		const int rk = id / p.rank_cu;
+		rlen         = p.rank_frames[rk > 2 ? 2 : rk];
+	} else {
+		r0 = (int64_t)blockIdx.x * p.run_frames;
+	}
 	if (r0 >= p.n_out) {
 		if (NP == 1) {
 			hist_write_slice (p, blockIdx.y, threadIdx.x);
 		}
 		return;
 	}
-	const int64_t r1 = (r0 + p.run_frames < p.n_out) ? r0 + p.run_frames : p.n_out;
+	const int64_t r1 = (r0 + rlen < p.n_out) ? r0 + rlen : p.n_out;
 
 	const S* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
 	const S* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
@@ -1578,7 +1609,10 @@ hipError_t launch_ola_poly_f16 (const OlaParamsH& p, int hop_rows, int n_chn, hi
 	}
 }
 
-// PROT_OLA_VARIANT (debug/tuning only): 0 = default
+// PROT_ABLATIONS builds only (tools/ab_build.py ...:-DPROT_ABLATIONS=1): PROT_OLA_VARIANT selects timing variants of
+// ola4096_kernel that leave out parts of the work -- their results are WRONG by design, and none of them exists in
+// the shipped library
+#ifdef PROT_ABLATIONS
 static int ola_variant ()
 {
 	static int v = -1;
@@ -1588,6 +1622,7 @@ static int ola_variant ()
 	}
 	return v;
 }
+#endif
 
 template <int HOPSEG, int MODE>
 static hipError_t launch_ola4096_m (const OlaParams& p, dim3 grid, hipStream_t s)
@@ -1597,9 +1632,25 @@ static hipError_t launch_ola4096_m (const OlaParams& p, dim3 grid, hipStream_t s
 		hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, true>), grid, block, dbg_dyn_lds (), s, p);
 		return hipGetLastError ();
 	}
+#ifdef PROT_ABLATIONS
+	switch (ola_variant ()) {
+		case 0: break;
+		case 1: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE>), grid, block, 0, s, p); return hipGetLastError (); // global dry loads
+		case 3: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, false, 0, false>), grid, block, 0, s, p); return hipGetLastError (); // scalar butterflies
+		case 11: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 1>), grid, block, 0, s, p); return hipGetLastError ();
+		case 12: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 2>), grid, block, 0, s, p); return hipGetLastError ();
+		case 13: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 3>), grid, block, 0, s, p); return hipGetLastError ();
+		case 18: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 8>), grid, block, 0, s, p); return hipGetLastError ();
+		case 19: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 9>), grid, block, 0, s, p); return hipGetLastError ();
+		case 20: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 10>), grid, block, 0, s, p); return hipGetLastError ();
+		case 21: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 11>), grid, block, 0, s, p); return hipGetLastError ();
+		case 25: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 15>), grid, block, 0, s, p); return hipGetLastError ();
+		default: break;
+	}
+#endif
 	// dry path from registers when the delay difference is a small multiple of 256 frames
 	const int dd = p.dry_delay - p.conv_delay;
-	if (MODE != MODE_HILBERT && ola_variant () == 0 && dd > 0 && dd % 256 == 0) {
+	if (MODE != MODE_HILBERT && dd > 0 && dd % 256 == 0) {
 		switch (dd / 256) {
 			case 2: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, false, 2>), grid, block, dbg_dyn_lds (), s, p); return hipGetLastError ();
 			case 4: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, false, 4>), grid, block, dbg_dyn_lds (), s, p); return hipGetLastError ();
@@ -1607,19 +1658,7 @@ static hipError_t launch_ola4096_m (const OlaParams& p, dim3 grid, hipStream_t s
 			default: break;
 		}
 	}
-	switch (ola_variant ()) {
-		case 1: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE>), grid, block, dbg_dyn_lds (), s, p); break; // global dry loads
-		case 3: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, false, 0, false>), grid, block, dbg_dyn_lds (), s, p); break; // scalar butterflies
-		case 11: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 1>), grid, block, dbg_dyn_lds (), s, p); break;
-		case 12: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 2>), grid, block, dbg_dyn_lds (), s, p); break;
-		case 13: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 3>), grid, block, dbg_dyn_lds (), s, p); break;
-		case 18: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 8>), grid, block, dbg_dyn_lds (), s, p); break;
-		case 19: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 9>), grid, block, dbg_dyn_lds (), s, p); break;
-		case 20: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 10>), grid, block, dbg_dyn_lds (), s, p); break;
-		case 21: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 11>), grid, block, dbg_dyn_lds (), s, p); break;
-		case 25: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 15>), grid, block, dbg_dyn_lds (), s, p); break;
-		default: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE>), grid, block, dbg_dyn_lds (), s, p); break;
-	}
+	hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE>), grid, block, dbg_dyn_lds (), s, p);
 	return hipGetLastError ();
 }
 
