@@ -594,10 +594,12 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	// 3072 taps (LV2 48 kHz, 5120 frames per block) -9 / -10 %, 2048 taps (CLI 2048, 6144) -9 / -11 %,
 	// 1024 taps (CLI 1024, 7168) -21 / -24 % -- and from 8192 taps up, where it halves the launches
 	// (1.31 -> 0.40 ms, 5.95 -> 2.63 ms per 2^27 frames at 8192 / 32768 taps); at 4096 taps (LV2 96 kHz,
-	// CLI 4096: hop 4096 either way) the direct two-partition form is 6-7 % faster and stays the default.
+	// CLI 4096: hop 4096 either way) the direct two-partition form was 6-7 % faster in round 1, at 2 workgroups per CU.
 	// PROT_CFG_POLYPHASE / PROT_CFG_DIRECT_FORM force one or the other (cross-checks).
 	const bool long_hop    = inf.firlen >= 1024 && inf.firlen / 2 <= 1537; // g leaves >= 2 extra rows of 256 samples
-	const bool poly_wanted = (inf.firlen > F) || long_hop || (cfg->flags & PROT_CFG_POLYPHASE);
+	// (round 2: with three workgroups per CU the polyphase kernel also wins at 4096 taps, 0.33 against 0.43 ms for the
+	// two-partition direct form at LV2 96 kHz -- it is the default for every Hilbert FIR now)
+	const bool poly_wanted = true;
 	bool use_poly = (use_p2 || long_hop || (cfg->flags & PROT_CFG_POLYPHASE)) && poly_wanted && getenv ("PROT_NO_POLY") == nullptr &&
 	                !(cfg->flags & (PROT_CFG_DIRECT_FORM | PROT_CFG_SINGLE_FFT_PER_HOP)) && inf.firlen % 4 == 0 &&
 	                inf.firlen >= 1024 && inf.conv_delay % 2 == 0;
