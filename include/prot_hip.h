@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define PROT_ABI_VERSION 2
+#define PROT_ABI_VERSION 3
 #define PROT_SUBSAMPLE 2                      /* cli/phase-rotate.cc:38 */
 #define PROT_MAXSAMPLE (180 * PROT_SUBSAMPLE) /* cli/phase-rotate.cc:39 */
 
@@ -132,13 +132,19 @@ int prot_apply_dev_ramp (prot_engine* e, const float* d_in, int64_t in_stride, u
                          float* d_out, int64_t out_stride, uint64_t n_out,
                          const float* d_rot, uint32_t flags, void* stream);
 
-/* fp16 sample path (BASELINE config 5): d_in/d_out are DEVICE arrays of IEEE
- * half (2 bytes per frame), planar; packed-half butterflies, fp32 overlap-add
- * and rotation.  Always stateless (history = silence), steady rotation, single
- * FIR partition engines only.  Same maths as prot_apply_dev at ~1e-3 accuracy. */
+/* fp16 sample path (BASELINE config 5): d_in/d_out are DEVICE arrays of IEEE half (2 bytes per frame), planar;
+ * packed-half butterflies, fp32 overlap-add and rotation; flags as prot_apply_dev (PROT_F_STATELESS; without it
+ * the engine carries the fp16 stream's own input history from call to call -- a stream is EITHER fed through the
+ * fp32 calls OR through the fp16 calls between two resets).  Engines with FIRs of up to 8192 taps (LV2 at every
+ * rate, CLI blksiz <= 8192); longer FIRs would accumulate partitions in half precision: PROT_EUNSUPPORTED.
+ * Accuracy against the fp32 path on the same fp16-rounded input: rms ~2e-4, max ~2e-3 at |x| <= 0.5 (tests). */
 int prot_apply_dev_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint64_t n_in,
                         void* d_out, int64_t out_stride, uint64_t n_out,
-                        const float* rot, void* stream);
+                        const float* rot, uint32_t flags, void* stream);
+/* per-frame rotation, as prot_apply_dev_ramp: d_rot = DEVICE float[n_chn][n_out][2] {ca, sa} */
+int prot_apply_dev_f16_ramp (prot_engine* e, const void* d_in, int64_t in_stride, uint64_t n_in,
+                             void* d_out, int64_t out_stride, uint64_t n_out,
+                             const float* d_rot, uint32_t flags, void* stream);
 
 #define PROT_F_STREAM_START 4u /* first chunk of a file: block 0 gets the Q1 treatment */
 #define PROT_F_STREAM_END   8u /* last chunk: zero-pad the partial block and add the flush block */
@@ -172,6 +178,11 @@ int prot_engine_sync (prot_engine* e);
  * meters stay in host C (see host/lv2_plugin.c). */
 int prot_lv2_run (prot_engine* e, const float* const* in, float* const* out,
                   uint32_t n_samples, const float* angle_deg);
+
+/* The reference's run() never allocates (src/phaserotate.c:774-852).  Neither does prot_lv2_run: its staging
+ * buffers are reserved by prot_engine_create for 8192 frames per call and raised here (instantiate / activate
+ * time, e.g. from the host's options:maxBlockLength); longer calls are processed in chunks of that length. */
+int prot_lv2_set_max_block (prot_engine* e, uint32_t frames);
 
 /* Channel.angle (src/phaserotate.c:53, :560, :725): the interpolated rotation
  * state in turns after the last run; the host compares it with the port's

@@ -32,8 +32,8 @@ ABI_SYMBOLS = (
     "prot_abi_version", "prot_strerror", "prot_last_error", "prot_sincos_lut",
     "prot_engine_create", "prot_engine_destroy", "prot_engine_reset", "prot_engine_info",
     "prot_engine_fir", "prot_engine_sync",
-    "prot_apply_dev", "prot_apply_dev_ramp", "prot_apply_dev_f16", "prot_sweep_dev",
-    "prot_lv2_run", "prot_lv2_get_angle", "prot_cli_apply", "prot_cli_analyze", "prot_cli_analyze_file",
+    "prot_apply_dev", "prot_apply_dev_ramp", "prot_apply_dev_f16", "prot_apply_dev_f16_ramp", "prot_sweep_dev",
+    "prot_lv2_run", "prot_lv2_set_max_block", "prot_lv2_get_angle", "prot_cli_apply", "prot_cli_analyze", "prot_cli_analyze_file",
     "prot_cli_apply_file", "prot_cli_peak", "prot_cli_peak_all", "prot_cli_peaks",
     "prot_cli_peaks_dev", "prot_allreduce_peaks", "prot_cli_analyze_file_multi", "prot_sweep_stats",
 )
@@ -105,7 +105,9 @@ def load_library():
                                    C.c_int64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.prot_apply_dev_ramp.argtypes = lib.prot_apply_dev.argtypes
     lib.prot_apply_dev_f16.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p,
-                                       C.c_int64, C.c_uint64, C.c_void_p, C.c_void_p]
+                                       C.c_int64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.prot_apply_dev_f16_ramp.argtypes = lib.prot_apply_dev_f16.argtypes
+    lib.prot_lv2_set_max_block.argtypes = [C.c_void_p, C.c_uint32]
     lib.prot_sweep_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.prot_lv2_run.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
@@ -190,12 +192,20 @@ class Engine:
         _check(self._lib.prot_apply_dev(self._h, d_in, in_stride, n_in, d_out, out_stride, n_out,
                                         rot.ctypes.data, flags, stream), "prot_apply_dev")
 
-    def apply_dev_f16(self, d_in, in_stride, n_in, d_out, out_stride, n_out, rot, stream=0):
-        """fp16 sample path: device arrays of torch.float16 / IEEE half."""
+    def apply_dev_f16(self, d_in, in_stride, n_in, d_out, out_stride, n_out, rot, stream=0, flags=F_STATELESS):
+        """fp16 sample path: device arrays of torch.float16 / IEEE half (flags=0: the engine carries the stream's history)."""
         rot = np.ascontiguousarray(rot, np.float32).reshape(-1)
         assert rot.size == 2 * self.n_chn
         _check(self._lib.prot_apply_dev_f16(self._h, d_in, in_stride, n_in, d_out, out_stride, n_out,
-                                            rot.ctypes.data, stream), "prot_apply_dev_f16")
+                                            rot.ctypes.data, flags, stream), "prot_apply_dev_f16")
+
+    def apply_dev_f16_ramp(self, d_in, in_stride, n_in, d_out, out_stride, n_out, d_rot, flags=0, stream=0):
+        """fp16 samples, per-frame rotation: d_rot = device float32 [n_chn][n_out][2] {ca, sa}."""
+        _check(self._lib.prot_apply_dev_f16_ramp(self._h, d_in, in_stride, n_in, d_out, out_stride, n_out,
+                                                 d_rot, flags, stream), "prot_apply_dev_f16_ramp")
+
+    def lv2_set_max_block(self, frames):
+        _check(self._lib.prot_lv2_set_max_block(self._h, frames), "prot_lv2_set_max_block")
 
     def hilbert_dev(self, d_in, in_stride, n_in, d_out, out_stride, n_out, flags=0, stream=0):
         _check(self._lib.prot_apply_dev(self._h, d_in, in_stride, n_in, d_out, out_stride, n_out,

@@ -188,6 +188,8 @@ struct prot_engine {
 
 	DevBuf<float2> d_H, d_tw;
 	DevBuf<float>  d_lut, d_rot, d_hist[2], d_peaks, d_in, d_out, d_u, d_inter, d_rot_s;
+	DevBuf<uint16_t> d_hist16[2]; // fp16 sample path: its own input history (half precision), double-buffered
+	int            hist16_cur = 0;
 	DevBuf<int>    d_angles;
 	DevBuf<float>  d_thr;   // [n_chn][4] shared pruning bounds of one sweep launch
 	DevBuf<unsigned long long> d_stats; // {tile groups evaluated, tile groups seen} since the last reset
@@ -203,6 +205,7 @@ struct prot_engine {
 	uint64_t       pos      = 0; // frames consumed since reset (CLI stream position)
 	int            pairs_per_run_override = 0;
 	int            wg_slots = 768; // resident OLA workgroups on the device (CUs x 3)
+	uint32_t       lv2_max_block = 0; // frames per prot_lv2_run chunk the buffers are reserved for
 
 	// LV2 block-rate angle state (src/phaserotate.c:563-571, :673-717)
 	float   interp_th = 0.f, interp_nm = 0.f;
@@ -221,6 +224,11 @@ int zero_state (prot_engine* e)
 	HIP_TRY (hipMemsetAsync (e->d_hist[1].p, 0, hn * sizeof (float), e->stream));
 	HIP_TRY (hipMemsetAsync (e->d_peaks.p, 0, (size_t)PROT_MAXSAMPLE * e->info.n_chn * sizeof (float), e->stream));
 	HIP_TRY (hipMemsetAsync (e->d_stats.p, 0, 2 * sizeof (unsigned long long), e->stream));
+	if (e->d_hist16[0].p) {
+		HIP_TRY (hipMemsetAsync (e->d_hist16[0].p, 0, hn * sizeof (uint16_t), e->stream));
+		HIP_TRY (hipMemsetAsync (e->d_hist16[1].p, 0, hn * sizeof (uint16_t), e->stream));
+	}
+	e->hist16_cur    = 0;
 	e->hist_cur      = 0;
 	e->pos           = 0;
 	e->h_peaks_valid = false;
@@ -292,8 +300,7 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 	p.hist_len     = (int)e->info.history;
 	// all channels, something to launch: the first OLA launch also writes the next call's history
 	// (other buffer of the pair) and the separate history kernel is skipped
-	const bool fuse_hist = advance_hist && !stateless && n_out > 0 && chn0 == 0 && n_chn == (int)e->info.n_chn &&
-	                       !(e->use_poly && e->info.partitions >= 2); // the two-partition polyphase kernel does not write history
+	const bool fuse_hist = advance_hist && !stateless && n_out > 0 && chn0 == 0 && n_chn == (int)e->info.n_chn;
 	p.hist_out     = fuse_hist ? e->d_hist[1 - e->hist_cur].p : nullptr;
 	p.out          = d_out + (int64_t)chn0 * out_stride;
 	p.out_stride   = out_stride;
@@ -452,6 +459,20 @@ bool io_overlap (const float* in, int64_t in_stride, uint64_t n_in, const float*
 		}
 	}
 	return false;
+}
+
+// the buffers one prot_lv2_run chunk of `frames` frames needs: allocated by prot_engine_create (8192 frames) and
+// prot_lv2_set_max_block, never by the audio callback
+int lv2_reserve (prot_engine* e, uint32_t frames)
+{
+	const size_t n = frames, nc = e->info.n_chn;
+	int          rc;
+	if ((rc = e->h_io.ensure (n * nc * 4 + 2 * nc)) || (rc = e->d_in.ensure (n * nc)) || (rc = e->d_out.ensure (n * nc)) ||
+	    (rc = e->d_rot_s.ensure (2 * n * nc))) {
+		return rc;
+	}
+	e->lv2_max_block = std::max (e->lv2_max_block, frames);
+	return PROT_OK;
 }
 
 hipStream_t pick_stream (prot_engine* e, void* stream)
@@ -762,6 +783,7 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	if ((rc = e->d_H.ensure ((size_t)F * n_part)) ||
 	    (!Hp_h.empty () && (rc = e->d_Hp.ensure (Hp_h.size ()))) || (rc = e->d_tw.ensure (F)) || (rc = e->d_lut.ensure (PROT_MAXSAMPLE * 2)) ||
 	    (rc = e->d_rot.ensure (2 * (size_t)inf.n_chn)) || (rc = e->d_hist[0].ensure (hn)) ||
+	    (use_poly && n_part <= 2 && ((rc = e->d_hist16[0].ensure (hn)) || (rc = e->d_hist16[1].ensure (hn)))) ||
 	    (rc = e->d_hist[1].ensure (hn)) || (rc = e->d_peaks.ensure ((size_t)PROT_MAXSAMPLE * inf.n_chn)) ||
 	    (rc = e->d_angles.ensure (PROT_MAXSAMPLE + 8)) || (rc = e->d_thr.ensure (4 * (size_t)inf.n_chn)) ||
 	    (rc = e->d_stats.ensure (2))) {
@@ -778,6 +800,9 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	}
 
 	if (inf.kind == PROT_KIND_LV2) {
+		if (lv2_reserve (e, 8192) != PROT_OK) { // run() buffers up front; prot_lv2_set_max_block raises it
+			return fail (PROT_ENOMEM);
+		}
 		e->interp_th = inf.blksiz * 1e-6f; // src/phaserotate.c:295
 		e->interp_nm = 1.f / inf.blksiz;   // :296
 		e->lv2.resize (inf.n_chn);
@@ -808,6 +833,8 @@ void prot_engine_destroy (prot_engine* e)
 	e->d_rot.release ();
 	e->d_hist[0].release ();
 	e->d_hist[1].release ();
+	e->d_hist16[0].release ();
+	e->d_hist16[1].release ();
 	e->d_peaks.release ();
 	e->d_in.release ();
 	e->d_out.release ();
@@ -932,25 +959,32 @@ int prot_apply_dev_ramp (prot_engine* e, const float* d_in, int64_t in_stride, u
 	return rc;
 }
 
-int prot_apply_dev_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint64_t n_in, void* d_out,
-                        int64_t out_stride, uint64_t n_out, const float* rot, void* stream)
+// fp16 sample path (BASELINE config 5): half samples in HBM, packed-half butterflies, fp32 overlap-add + rotation.
+// Polyphase engines of one or two partitions per launch (FIRs up to 8192 taps) carry history (its own, in half
+// precision) and take per-frame rotations like the fp32 path; the direct-form cross-check engines (PROT_CFG_*) only
+// offer the stateless steady call.
+static int apply_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint64_t n_in, void* d_out, int64_t out_stride,
+                      uint64_t n_out, const float* rot, const float* d_rot_s, uint32_t flags, void* stream)
 {
-	if (!e || !d_in || !d_out || !rot) {
+	if (!e || !d_in || !d_out || (!rot && !d_rot_s)) {
 		return PROT_EINVAL;
 	}
-	// the fp16 kernels exist for one polyphase partition, two direct partitions, one direct partition
-	// 4096-tap engines run fp32 in direct form but fp16 in polyphase form: measured 0.317 vs 0.338 ms (fp16 kernels keep
-	// 3 waves per SIMD either way, so the saved spectrum multiply shows; in fp32 the direct form is 7 % faster)
-	const bool f16_alt  = e->use_p2 && e->d_Hp.p != nullptr;
-	const bool f16_poly = (e->use_poly && e->info.partitions == 1) || f16_alt;
-	const bool f16_p2   = e->use_p2 && e->info.partitions == 2;
-	if (!f16_poly && !f16_p2 && (e->use_poly || e->info.partitions != 1)) {
+	const bool stateless = flags & PROT_F_STATELESS;
+	const bool f16_poly  = e->use_poly && e->info.partitions <= 2;
+	const bool f16_p2    = e->use_p2 && e->info.partitions == 2;
+	const bool f16_one   = !e->use_poly && !e->use_p2 && e->info.partitions == 1;
+	if (!f16_poly && !f16_p2 && !f16_one) {
+		snprintf (g_err, sizeof (g_err), "fp16 sample path: FIRs of more than 8192 taps would accumulate partitions in half precision");
+		return PROT_EUNSUPPORTED;
+	}
+	if (!f16_poly && (!stateless || d_rot_s)) {
+		snprintf (g_err, sizeof (g_err), "fp16 sample path: the direct-form engines offer the stateless, steady call only");
 		return PROT_EUNSUPPORTED;
 	}
 	HIP_TRY (hipSetDevice (e->device));
 	hipStream_t s  = pick_stream (e, stream);
 	const int   nc = (int)e->info.n_chn;
-	{
+	if (rot) {
 		int rcs = stage_small (e, e->d_rot.p, rot, 2 * (size_t)nc * sizeof (float), s);
 		if (rcs) {
 			return rcs;
@@ -963,19 +997,42 @@ int prot_apply_dev_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uin
 	p.out        = (_Float16*)d_out;
 	p.out_stride = out_stride;
 	p.n_out      = (int64_t)n_out;
-	p.H          = f16_alt ? e->d_Hp.p : e->d_H.p;
+	p.H          = e->d_H.p;
 	p.tw         = e->d_tw.p;
 	p.rot        = e->d_rot.p;
+	p.rot_s      = d_rot_s;
 	p.run_frames = pick_run_frames (e, n_out, nc); // the engine's own transform block: the fp16 kernels share its form
 	p.conv_delay = (int)e->info.conv_delay;
 	p.dry_delay  = (int)e->info.dry_delay;
-	hipError_t err = f16_poly ? prot::launch_ola_poly_f16 (p, f16_alt ? 8 : e->hopseg / 2, nc, s)
+	p.hist_len   = (int)e->info.history;
+	const bool carry = !stateless && n_out > 0;
+	if (!stateless) {
+		p.hist     = (const _Float16*)e->d_hist16[e->hist16_cur].p;
+		p.hist_out = carry ? (_Float16*)e->d_hist16[1 - e->hist16_cur].p : nullptr;
+	}
+	hipError_t err = f16_poly ? prot::launch_ola_poly_f16 (p, (int)e->info.partitions, e->hopseg / 2, nc, s)
 	               : f16_p2   ? prot::launch_ola4096_p2_f16 (p, nc, s)
 	                          : prot::launch_ola4096_f16 (p, e->hopseg, nc, s);
 	if (err != hipSuccess) {
 		return hip_fail (err, "fp16 ola kernel launch");
 	}
+	if (carry) {
+		e->hist16_cur = 1 - e->hist16_cur;
+		e->pos += n_in;
+	}
 	return PROT_OK;
+}
+
+int prot_apply_dev_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint64_t n_in, void* d_out,
+                        int64_t out_stride, uint64_t n_out, const float* rot, uint32_t flags, void* stream)
+{
+	return rot ? apply_f16 (e, d_in, in_stride, n_in, d_out, out_stride, n_out, rot, nullptr, flags, stream) : PROT_EINVAL;
+}
+
+int prot_apply_dev_f16_ramp (prot_engine* e, const void* d_in, int64_t in_stride, uint64_t n_in, void* d_out,
+                             int64_t out_stride, uint64_t n_out, const float* d_rot, uint32_t flags, void* stream)
+{
+	return d_rot ? apply_f16 (e, d_in, in_stride, n_in, d_out, out_stride, n_out, nullptr, d_rot, flags, stream) : PROT_EINVAL;
 }
 
 int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_frames, int ang_start,
@@ -1183,16 +1240,20 @@ float prot_cli_peak (prot_engine* e, int c, int a)
 }
 
 // ------------------------------------------------------------ host drop-ins
-int prot_lv2_run (prot_engine* e, const float* const* in, float* const* out, uint32_t n_samples,
-                  const float* angle_deg)
+int prot_lv2_set_max_block (prot_engine* e, uint32_t frames)
 {
-	if (!e || !in || !out || !angle_deg || e->info.kind != PROT_KIND_LV2) {
+	if (!e || e->info.kind != PROT_KIND_LV2 || frames == 0 || frames > (1u << 24)) {
 		return PROT_EINVAL;
 	}
-	if (n_samples == 0) {
-		return PROT_OK;
-	}
 	HIP_TRY (hipSetDevice (e->device));
+	HIP_TRY (hipStreamSynchronize (e->stream));
+	return lv2_reserve (e, frames);
+}
+
+// one call of at most lv2_max_block frames, `off` frames into the host's port buffers
+static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* out, uint32_t off, uint32_t n_samples,
+                          const float* angle_deg)
+{
 	const uint32_t nc = e->info.n_chn;
 	const uint32_t P  = e->info.blksiz;
 	const size_t   n  = n_samples;
@@ -1207,10 +1268,7 @@ int prot_lv2_run (prot_engine* e, const float* const* in, float* const* out, uin
 	// DMA copies win (70 vs 76 us: 64 KiB over the host link from inside a latency-bound kernel) -- staged above 4096 samples.
 	static const bool force_staged = getenv ("PROT_LV2_STAGED") != nullptr;
 	const bool        staged       = force_staged || n * nc > 4096;
-	if ((rc = e->h_io.ensure (n * nc * 4 + 2 * (size_t)nc)) ||
-	    (staged && ((rc = e->d_in.ensure (n * nc)) || (rc = e->d_out.ensure (n * nc)) || (rc = e->d_rot_s.ensure (2 * n * nc))))) {
-		return rc;
-	}
+	// (buffers: lv2_reserve -- nothing is allocated on this path)
 	float* h_in  = e->h_io.p;
 	float* h_out = e->h_io.p + n * nc;
 	float* h_rot = e->h_io.p + 2 * n * nc; // [nc][n][2]
@@ -1219,7 +1277,7 @@ int prot_lv2_run (prot_engine* e, const float* const* in, float* const* out, uin
 	// (src/phaserotate.c:563-571 target, :673-709 ramp, :710-717 steady)
 	bool steady = true;
 	for (uint32_t c = 0; c < nc; ++c) {
-		memcpy (h_in + c * n, in[c], n * sizeof (float));
+		memcpy (h_in + c * n, in[c] + off, n * sizeof (float));
 		Lv2Chn& ch = e->lv2[c];
 		float target_angle = angle_deg[c] / -360.f;
 		if (target_angle < -.5f) {
@@ -1298,13 +1356,13 @@ int prot_lv2_run (prot_engine* e, const float* const* in, float* const* out, uin
 		}
 		rc = ola_launch (e, h_in, (int64_t)n, n, h_out, (int64_t)n, n, d_rot_c, steady ? nullptr : h_rot, false, false, 0, (int)nc, s,
 		                 /*advance_hist*/ true); // one kernel per run(): the OLA launch writes the next history as well
-		e->pos += n;
 		if (rc) {
 			return rc;
 		}
+		e->pos += n;
 		HIP_TRY (hipStreamSynchronize (s)); // (polling hipStreamQuery instead measured the same: the runtime already spins)
 		for (uint32_t c = 0; c < nc; ++c) {
-			memcpy (out[c], h_out + c * n, n * sizeof (float));
+			memcpy (out[c] + off, h_out + c * n, n * sizeof (float));
 		}
 		return PROT_OK;
 	}
@@ -1332,7 +1390,28 @@ int prot_lv2_run (prot_engine* e, const float* const* in, float* const* out, uin
 	HIP_TRY (hipMemcpyAsync (h_out, e->d_out.p, n * nc * sizeof (float), hipMemcpyDeviceToHost, s));
 	HIP_TRY (hipStreamSynchronize (s));
 	for (uint32_t c = 0; c < nc; ++c) {
-		memcpy (out[c], h_out + c * n, n * sizeof (float));
+		memcpy (out[c] + off, h_out + c * n, n * sizeof (float));
+	}
+	return PROT_OK;
+}
+
+int prot_lv2_run (prot_engine* e, const float* const* in, float* const* out, uint32_t n_samples,
+                  const float* angle_deg)
+{
+	if (!e || !in || !out || !angle_deg || e->info.kind != PROT_KIND_LV2) {
+		return PROT_EINVAL;
+	}
+	if (n_samples == 0) {
+		return PROT_OK;
+	}
+	HIP_TRY (hipSetDevice (e->device));
+	// calls longer than the reserved block length are cut up: the callback never allocates (src/phaserotate.c run()
+	// does not either).  In-place port buffers (in == out) are fine: a chunk's input is copied out before its output lands
+	for (uint32_t off = 0; off < n_samples; off += e->lv2_max_block) {
+		const int rc = lv2_run_chunk (e, in, out, off, std::min (e->lv2_max_block, n_samples - off), angle_deg);
+		if (rc) {
+			return rc;
+		}
 	}
 	return PROT_OK;
 }

@@ -53,8 +53,8 @@ hipError_t launch_ola4096_p2 (const OlaParams& p, int n_chn, hipStream_t s);
 // n_part in {1, 2}; hop_rows in {8, 10, 12, 14} (x 512 new frames per block; > 8 only for one partition
 // of at most 256 (16 - hop_rows) + 1 taps); p.conv_delay even; p.run_frames a multiple of 512 hop_rows
 hipError_t launch_ola_poly (const OlaParams& p, int n_part, int hop_rows, int n_chn, hipStream_t s);
-// the same on fp16 samples (one partition, steady rotation, stateless): BASELINE config 5
-hipError_t launch_ola_poly_f16 (const OlaParamsH& p, int hop_rows, int n_chn, hipStream_t s);
+// the same on fp16 samples (no accumulating launches: FIRs of up to 8192 taps): BASELINE config 5
+hipError_t launch_ola_poly_f16 (const OlaParamsH& p, int n_part, int hop_rows, int n_chn, hipStream_t s);
 
 // fp16 sample path (BASELINE config 5): half samples in HBM, packed-half butterflies,
 // fp32 overlap-add + rotation.  Stateless, steady rotation.

@@ -1204,9 +1204,7 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 		r0 = (int64_t)blockIdx.x * p.run_frames;
 	}
 	if (r0 >= p.n_out) {
-		if (NP == 1) {
-			hist_write_slice (p, blockIdx.y, threadIdx.x);
-		}
+		hist_write_slice (p, blockIdx.y, threadIdx.x);
 		return;
 	}
 	const int64_t r1 = (r0 + rlen < p.n_out) ? r0 + rlen : p.n_out;
@@ -1517,11 +1515,7 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 		g_wg_t[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg ((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg ((3 << 11) | 20) << 32);
 	}
 #endif
-	// (two partitions: the kernel is at the 256-VGPR / 106-SGPR limit and the extra live parameters pushed spills
-	// into its main loop, +22 % time at 8192 taps -- those engines keep the separate history kernel)
-	if (NP == 1) {
-		hist_write_slice (p, blockIdx.y, threadIdx.x);
-	}
+	hist_write_slice (p, blockIdx.y, threadIdx.x);
 }
 
 template <class T, int NP, int HS, int MODE>
@@ -1583,29 +1577,22 @@ hipError_t launch_ola_poly (const OlaParams& p, int n_part, int hop_rows, int n_
 	}
 }
 
-// fp16 sample path in polyphase form: one partition, steady rotation, stateless (what prot_apply_dev_f16 offers)
-template <int HS>
-static hipError_t launch_poly_h (const OlaParamsH& p, int n_chn, hipStream_t s)
+// fp16 sample path in polyphase form (prot_apply_dev_f16 / _ramp): one or two partitions of g per launch, steady or
+// per-frame rotation, with or without history
+hipError_t launch_ola_poly_f16 (const OlaParamsH& p, int n_part, int hop_rows, int n_chn, hipStream_t s)
 {
-	const int64_t runs = (p.n_out + p.run_frames - 1) / p.run_frames;
-	dim3          grid ((unsigned)runs, (unsigned)n_chn);
-	return launch_poly_m<T16, 1, HS, MODE_ROT> (p, grid, s);
-}
-
-hipError_t launch_ola_poly_f16 (const OlaParamsH& p, int hop_rows, int n_chn, hipStream_t s)
-{
-	if ((p.conv_delay & 1) || (p.run_frames % (512 * hop_rows)) != 0 || p.hilbert_only || p.rot_s != nullptr || p.accumulate) {
+	if ((p.conv_delay & 1) || (p.run_frames % (512 * hop_rows)) != 0 || p.accumulate || (n_part != 1 && n_part != 2) ||
+	    (hop_rows != 8 && (n_part != 1 || (hop_rows != 10 && hop_rows != 12 && hop_rows != 14)))) {
 		return hipErrorInvalidValue;
 	}
-	if (p.n_out <= 0) {
-		return hipSuccess;
+	if (n_part == 2) {
+		return launch_poly_n<T16, 2, 8> (p, n_chn, s);
 	}
 	switch (hop_rows) {
-		case 8: return launch_poly_h<8> (p, n_chn, s);
-		case 10: return launch_poly_h<10> (p, n_chn, s);
-		case 12: return launch_poly_h<12> (p, n_chn, s);
-		case 14: return launch_poly_h<14> (p, n_chn, s);
-		default: return hipErrorInvalidValue;
+		case 8: return launch_poly_n<T16, 1, 8> (p, n_chn, s);
+		case 10: return launch_poly_n<T16, 1, 10> (p, n_chn, s);
+		case 12: return launch_poly_n<T16, 1, 12> (p, n_chn, s);
+		default: return launch_poly_n<T16, 1, 14> (p, n_chn, s);
 	}
 }
 

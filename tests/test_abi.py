@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert set(declared_symbols()) <= exported
     # library and header agree on the ABI revision (2: prot_info.run_align, prot_sweep_stats, PROT_CFG_* flags)
     declared = int(re.search(r"#define\s+PROT_ABI_VERSION\s+(\d+)", open(HDR).read()).group(1))
-    assert lib.prot_abi_version() == declared == 2
+    assert lib.prot_abi_version() == declared == 3
 
 
 def test_header_is_plain_c():

@@ -1,0 +1,161 @@
+"""BASELINE configs[4]: the fp16 sample path against the CPU ORACLE (not against this library's own
+fp32 kernels).  The oracle is fed the fp16-ROUNDED input as float32, so what is measured is the error of
+the half-precision transform + the rounding of the output to half, nothing else.
+
+Stated tolerance (|x| <= 0.5, |y| <~ 1): max abs 4e-3, rms 6e-4 (the output rounding alone is up to
+2.4e-4 per sample at |y| < 1: half has 11 significant bits).  Every test prints what it measured.
+"""
+import numpy as np
+import pytest
+
+import orc
+from conftest import harmonic_stack, xorshift_uniform
+
+pytestmark = pytest.mark.gpu
+
+MAX_ABS, RMS = 4e-3, 6e-4
+
+
+def _report(capsys, what, err, ref):
+    rms, mx = float(np.sqrt(np.mean(err.astype(np.float64) ** 2))), float(err.max())
+    ref_rms = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+    with capsys.disabled():
+        print("\n[fp16 vs oracle] %s: max abs %.3e, rms %.3e (signal rms %.3f, SNR %.1f dB)"
+              % (what, mx, rms, ref_rms, 20 * np.log10(ref_rms / max(rms, 1e-30))))
+    return mx, rms
+
+
+def _signal(n, seed):
+    return (0.45 * harmonic_stack(n) / 0.8 + 0.05 * xorshift_uniform(n, seed=seed)).astype(np.float32)
+
+
+@pytest.mark.parametrize("rate,angle", [(48000, 90.0), (96000, -35.0)])
+def test_fp16_lv2_against_oracle(pkg, rate, angle, capsys):
+    """LV2 48 kHz (3072 taps) and 96 kHz (4096 taps): one stateless fp16 call over the stream against the
+    oracle's run() on the rounded input (steady region: Q10's start-up ramp only exists in run())."""
+    import torch
+    n = 120000
+    x16 = _signal(n, 5).astype(np.float16)
+    xr = x16.astype(np.float32)[None, :]
+    o = orc.Lv2Engine(rate, 1)
+    yo = o.run_stream(xr, angle, 1024)[0]
+    e = pkg.Engine(pkg.KIND_LV2, rate, 1)
+    dev = torch.device("cuda:0")
+    xd = torch.from_numpy(x16).to(dev)
+    yd = torch.empty_like(xd)
+    th = -2.0 * np.pi * angle / 360.0
+    rot = np.array([np.cos(th), np.sin(th)], np.float32)
+    torch.cuda.synchronize()
+    e.apply_dev_f16(xd.data_ptr(), n, n, yd.data_ptr(), n, n, rot)
+    e.sync()
+    yg = yd.float().cpu().numpy()
+    s0 = o.latency + 2304
+    mx, rms = _report(capsys, "LV2 %d Hz, %d frames" % (rate, n), np.abs(yg[s0:] - yo[s0:]), yo[s0:])
+    assert mx < MAX_ABS and rms < RMS
+    e.close()
+
+
+@pytest.mark.parametrize("blksiz", [2048, 8192])
+def test_fp16_cli_against_oracle(pkg, blksiz, capsys):
+    """CLI engines, blksiz 2048 (one partition of the odd taps) and 8192 (two partitions in one launch),
+    against PhaseRotateProc::process restated (block by block) on the rounded input."""
+    import torch
+    nblk = 96 if blksiz == 2048 else 24
+    n = nblk * blksiz
+    x16 = _signal(n, 6).astype(np.float16)
+    xr = x16.astype(np.float32)
+    o = orc.CliEngine(blksiz, 1)
+    a = 73  # half-degree index
+    yo = np.concatenate([o.apply(xr[b * blksiz:(b + 1) * blksiz], [a]) for b in range(nblk)])
+    e = pkg.Engine(pkg.KIND_CLI, blksiz, 1)
+    dev = torch.device("cuda:0")
+    xd = torch.from_numpy(x16).to(dev)
+    yd = torch.empty_like(xd)
+    s, c = orc.sincos_lut(a)
+    torch.cuda.synchronize()
+    e.apply_dev_f16(xd.data_ptr(), n, n, yd.data_ptr(), n, n, np.array([c, s], np.float32))
+    e.sync()
+    yg = yd.float().cpu().numpy()
+    mx, rms = _report(capsys, "CLI blksiz %d, %d frames" % (blksiz, n), np.abs(yg - yo), yo)
+    assert mx < MAX_ABS and rms < RMS
+    e.close()
+
+
+@pytest.mark.parametrize("kind,param", [(1, 48000), (1, 192000), (0, 2048)])
+def test_fp16_stateful_chunks_equal_one_shot(pkg, kind, param, capsys):
+    """The fp16 stream carries its own history: uneven stateful chunks against one stateless call.
+    Chunks that start on whole device transform blocks are bit-identical; arbitrary cuts move the block
+    grid and with it the half-precision rounding, so they are held to the fp16 tolerance."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 200000
+    x = torch.from_numpy(_signal(2 * n, 7).reshape(2, n)).to(dev).half().contiguous()
+    rot = np.array([0.6, -0.8, -0.28, 0.96], np.float32)
+    e = pkg.Engine(kind, param, 2)
+    y_one = torch.empty_like(x)
+    e.apply_dev_f16(x.data_ptr(), n, n, y_one.data_ptr(), n, n, rot)
+    e.sync()
+    A = int(e.info.run_align)
+    for cuts, exact in (((3 * A, 5 * A, A), True), ((1, 1023, 4097, 10000, 32831, 70001), False)):
+        e.reset()
+        y = torch.zeros_like(x)
+        pos = 0
+        sizes = list(cuts) + [n - sum(cuts)]
+        for sz in sizes:
+            xin = x[:, pos:pos + sz].contiguous()
+            yo = torch.empty_like(xin)
+            torch.cuda.synchronize()
+            e.apply_dev_f16(xin.data_ptr(), sz, sz, yo.data_ptr(), sz, sz, rot, flags=0)
+            e.sync()
+            y[:, pos:pos + sz] = yo
+            pos += sz
+        d = (y.float() - y_one.float()).abs().cpu().numpy()
+        mx, rms = _report(capsys, "kind %d param %d, %s chunks vs one shot" % (kind, param, "aligned" if exact else "uneven"), d,
+                          y_one.float().cpu().numpy())
+        if exact:
+            assert mx == 0.0
+        else:
+            assert mx < MAX_ABS and rms < RMS
+    e.close()
+
+
+def test_fp16_ramp_against_oracle(pkg, capsys):
+    """Per-frame rotation on fp16 samples (prot_apply_dev_f16_ramp), stateful in two chunks: the reference is
+    ca[t] * (oracle run at 0 deg) + sa[t] * (oracle run at -90 deg), both on the rounded input."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 90000
+    x16 = _signal(n, 8).astype(np.float16)
+    xr = x16.astype(np.float32)[None, :]
+    y0 = orc.Lv2Engine(48000, 1).run_stream(xr, 0.0, 1024)[0]     # dry, delayed by the latency
+    y90 = orc.Lv2Engine(48000, 1).run_stream(xr, -90.0, 1024)[0]  # (ca, sa) = (0, 1): the Hilbert branch
+    t = np.arange(n)
+    ang = np.where(t < 30000, 0.3, np.where(t < 50000, 0.3 + (t - 30000) * 1e-4, 2.3)).astype(np.float64)  # radians
+    rot = np.stack([np.cos(ang), np.sin(ang)], axis=1).astype(np.float32)
+    ref = rot[:, 0] * y0 + rot[:, 1] * y90
+    e = pkg.Engine(pkg.KIND_LV2, 48000, 1)
+    xd = torch.from_numpy(x16).to(dev)
+    yd = torch.empty_like(xd)
+    rd = torch.from_numpy(rot).to(dev).contiguous()
+    cut = 41001
+    torch.cuda.synchronize()
+    e.apply_dev_f16_ramp(xd.data_ptr(), cut, cut, yd.data_ptr(), cut, cut, rd.data_ptr())
+    e.apply_dev_f16_ramp(xd[cut:].data_ptr(), n - cut, n - cut, yd[cut:].data_ptr(), n - cut, n - cut, rd[cut:].data_ptr())
+    e.sync()
+    yg = yd.float().cpu().numpy()
+    s0 = 1792 + 2304
+    mx, rms = _report(capsys, "LV2 48 kHz ramp, two stateful chunks", np.abs(yg[s0:] - ref[s0:]), ref[s0:])
+    assert mx < MAX_ABS and rms < RMS
+    e.close()
+
+
+def test_fp16_long_fir_is_refused(pkg):
+    """FIRs beyond 8192 taps would accumulate partitions in half precision: refused, not approximated."""
+    import torch
+    dev = torch.device("cuda:0")
+    e = pkg.Engine(pkg.KIND_CLI, 16384, 1)
+    x = torch.zeros(65536, device=dev, dtype=torch.float16)
+    y = torch.empty_like(x)
+    with pytest.raises(pkg.ProtError):
+        e.apply_dev_f16(x.data_ptr(), 65536, 65536, y.data_ptr(), 65536, 65536, np.array([1, 0], np.float32))
+    e.close()
