@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <thread>
 #include <climits>
+#include <map>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -173,6 +174,58 @@ struct Lv2Chn {            // Channel angle state, src/phaserotate.c:52-55, :61
 	std::vector<float>  rotq;  // [parsiz][2] {ca, sa} of the block being delivered
 };
 
+struct Rccl {
+	void* lib = nullptr;
+	int (*CommInitAll) (void**, int, const int*) = nullptr;
+	int (*CommDestroy) (void*)                    = nullptr;
+	int (*GroupStart) ()                          = nullptr;
+	int (*GroupEnd) ()                            = nullptr;
+	int (*AllReduce) (const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+	bool load ()
+	{
+		if (lib) {
+			return true;
+		}
+		// PROT_RCCL_LIB: a library to use in place of the system's RCCL (tests load a counting stand-in)
+		const char* over = getenv ("PROT_RCCL_LIB");
+		for (const char* name : { over ? over : "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
+			lib = dlopen (name, RTLD_NOW | RTLD_LOCAL);
+			if (lib || over) {
+				break;
+			}
+		}
+		if (!lib) {
+			return false;
+		}
+		CommInitAll = (int (*) (void**, int, const int*))dlsym (lib, "ncclCommInitAll");
+		CommDestroy = (int (*) (void*))dlsym (lib, "ncclCommDestroy");
+		GroupStart  = (int (*) ())dlsym (lib, "ncclGroupStart");
+		GroupEnd    = (int (*) ())dlsym (lib, "ncclGroupEnd");
+		AllReduce   = (int (*) (const void*, void*, size_t, int, int, void*, hipStream_t))dlsym (lib, "ncclAllReduce");
+		return CommInitAll && CommDestroy && GroupStart && GroupEnd && AllReduce;
+	}
+};
+Rccl       g_rccl;
+std::mutex g_rccl_lock;
+// communicators are expensive (hundreds of ms for ncclCommInitAll on 8 GPUs against ~2 ms per GPU for a sharded
+// sweep, and the CLI all-reduces once per analysis pass): one set per list of devices, created on first use, kept
+// until the last engine of the process is destroyed
+std::map<std::vector<int>, std::vector<void*>> g_comms;
+int                                            g_engines = 0; // live engines (guarded by g_rccl_lock)
+
+void rccl_drop_comms_locked ()
+{
+	for (auto& kv : g_comms) {
+		for (size_t i = 0; i < kv.second.size (); ++i) {
+			if (kv.second[i]) {
+				(void)hipSetDevice (kv.first[i]);
+				g_rccl.CommDestroy (kv.second[i]);
+			}
+		}
+	}
+	g_comms.clear ();
+}
+
 } // namespace
 
 struct prot_engine {
@@ -206,6 +259,7 @@ struct prot_engine {
 	int            pairs_per_run_override = 0;
 	int            wg_slots = 768; // resident OLA workgroups on the device (CUs x 3)
 	uint32_t       lv2_max_block = 0; // frames per prot_lv2_run chunk the buffers are reserved for
+	bool           counted = false;   // in g_engines (communicator cache lifetime)
 
 	// LV2 block-rate angle state (src/phaserotate.c:563-571, :673-717)
 	float   interp_th = 0.f, interp_nm = 0.f;
@@ -814,6 +868,11 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 		}
 	}
 	e->h_peaks.assign ((size_t)PROT_MAXSAMPLE * inf.n_chn, 0.f);
+	{
+		std::lock_guard<std::mutex> lk (g_rccl_lock);
+		++g_engines;
+		e->counted = true;
+	}
 	return e;
 }
 
@@ -853,6 +912,12 @@ void prot_engine_destroy (prot_engine* e)
 	}
 	if (e->stream) {
 		(void)hipStreamDestroy (e->stream);
+	}
+	if (e->counted) {
+		std::lock_guard<std::mutex> lk (g_rccl_lock);
+		if (--g_engines == 0) {
+			rccl_drop_comms_locked (); // the last engine takes the cached communicators with it
+		}
 	}
 	delete e;
 }
@@ -1536,38 +1601,6 @@ int prot_cli_analyze_file (prot_engine* e, const float* data, uint64_t n_frames,
 namespace {
 
 // RCCL through dlopen: the library is only needed by multi-GPU callers
-struct Rccl {
-	void* lib = nullptr;
-	int (*CommInitAll) (void**, int, const int*) = nullptr;
-	int (*CommDestroy) (void*)                    = nullptr;
-	int (*GroupStart) ()                          = nullptr;
-	int (*GroupEnd) ()                            = nullptr;
-	int (*AllReduce) (const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
-	bool load ()
-	{
-		if (lib) {
-			return true;
-		}
-		for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
-			lib = dlopen (name, RTLD_NOW | RTLD_LOCAL);
-			if (lib) {
-				break;
-			}
-		}
-		if (!lib) {
-			return false;
-		}
-		CommInitAll = (int (*) (void**, int, const int*))dlsym (lib, "ncclCommInitAll");
-		CommDestroy = (int (*) (void*))dlsym (lib, "ncclCommDestroy");
-		GroupStart  = (int (*) ())dlsym (lib, "ncclGroupStart");
-		GroupEnd    = (int (*) ())dlsym (lib, "ncclGroupEnd");
-		AllReduce   = (int (*) (const void*, void*, size_t, int, int, void*, hipStream_t))dlsym (lib, "ncclAllReduce");
-		return CommInitAll && CommDestroy && GroupStart && GroupEnd && AllReduce;
-	}
-};
-Rccl       g_rccl;
-std::mutex g_rccl_lock;
-
 constexpr int kNcclFloat32 = 7, kNcclMax = 2; // rccl.h: ncclDataType_t / ncclRedOp_t
 
 // sweep frames [f0, f0 + nf) of an in-memory interleaved file on one engine
@@ -1647,32 +1680,42 @@ int prot_allreduce_peaks (prot_engine* const* engines, int n)
 	if (n == 1) {
 		return PROT_OK;
 	}
-	const bool want_host = getenv ("PROT_ALLREDUCE") && !strcmp (getenv ("PROT_ALLREDUCE"), "host");
+	// PROT_ALLREDUCE=host: merge through the host even on distinct devices; =rccl: take the collective even when the
+	// engines share a device (only meaningful with a stand-in library: real RCCL wants one rank per device)
+	const char* mode      = getenv ("PROT_ALLREDUCE");
+	const bool  want_host = mode && !strcmp (mode, "host");
+	const bool  force     = mode && !strcmp (mode, "rccl");
 	std::lock_guard<std::mutex> lk (g_rccl_lock);
-	if (distinct && !want_host && g_rccl.load ()) {
-		std::vector<int>   devs (n);
-		std::vector<void*> comms (n, nullptr);
+	if ((distinct || force) && !want_host && g_rccl.load ()) {
+		std::vector<int> devs (n);
 		for (int i = 0; i < n; ++i) {
 			devs[i] = engines[i]->device;
 		}
-		if (g_rccl.CommInitAll (comms.data (), n, devs.data ()) != 0) {
-			snprintf (g_err, sizeof (g_err), "ncclCommInitAll failed");
-			return PROT_EHIP;
+		auto it = g_comms.find (devs);
+		if (it == g_comms.end ()) {
+			std::vector<void*> comms (n, nullptr);
+			if (g_rccl.CommInitAll (comms.data (), n, devs.data ()) != 0) {
+				snprintf (g_err, sizeof (g_err), "ncclCommInitAll failed");
+				return PROT_EHIP;
+			}
+			it = g_comms.emplace (devs, comms).first;
 		}
+		const std::vector<void*>& comms = it->second;
+		// no early return between GroupStart and GroupEnd: an open group would swallow every later call
 		int bad = g_rccl.GroupStart ();
 		for (int i = 0; i < n && !bad; ++i) {
-			HIP_TRY (hipSetDevice (engines[i]->device));
-			bad = g_rccl.AllReduce (engines[i]->d_peaks.p, engines[i]->d_peaks.p, count, kNcclFloat32, kNcclMax, comms[i],
-			                        engines[i]->stream);
+			bad = hipSetDevice (engines[i]->device) != hipSuccess;
+			bad = bad || g_rccl.AllReduce (engines[i]->d_peaks.p, engines[i]->d_peaks.p, count, kNcclFloat32, kNcclMax, comms[i],
+			                               engines[i]->stream);
 		}
 		bad = g_rccl.GroupEnd () || bad;
 		for (int i = 0; i < n; ++i) {
 			(void)hipSetDevice (engines[i]->device);
-			(void)hipStreamSynchronize (engines[i]->stream);
-			g_rccl.CommDestroy (comms[i]);
+			bad = (hipStreamSynchronize (engines[i]->stream) != hipSuccess) || bad;
 		}
 		if (bad) {
 			snprintf (g_err, sizeof (g_err), "ncclAllReduce failed");
+			g_comms.erase (it); // do not reuse communicators after a failed collective (not destroyed: they may be wedged)
 			return PROT_EHIP;
 		}
 		return PROT_OK;

@@ -20,15 +20,17 @@ MAXSAMPLE = 360
 SUBSAMPLE = 2
 
 
-def plan_shards(n_frames, blksiz, world, align=2):
+def plan_shards(n_frames, blksiz, world, align):
     """Split ceil(n_frames / blksiz) data blocks into `world` contiguous ranges
     [(b0, b1), ...]; earlier ranks get the remainder.  Empty ranges are allowed
     (more ranks than blocks).  Interior boundaries fall on multiples of `align`
-    blocks -- pass Engine.shard_align_blocks(): the device engine works in transform blocks of
-    info.run_align frames (a pair of hops, or 4096..7168 frames in polyphase form), and a shard that
-    starts on such a boundary reproduces the single-GPU arithmetic bit for bit (so the merged
-    table, and its argmin, are identical, not just within tolerance).  The default 2 is the
-    direct form at blksiz >= 2048."""
+    blocks.  `align` is required: pass Engine.shard_align_blocks() -- the device engine works in
+    transform blocks of info.run_align frames (3 blocks of 2048 frames, 7 blocks of 1024 frames, ... in
+    polyphase form), and only a shard that starts on such a boundary reproduces the single-GPU arithmetic
+    bit for bit (so the merged table, and its argmin, are identical, not just within tolerance).
+    align=1 cuts anywhere (a CPU oracle as the per-shard engine has no block grid of its own)."""
+    if align is None or int(align) < 1:
+        raise ValueError("plan_shards: align must be a positive block count (Engine.shard_align_blocks())")
     nb = (n_frames + blksiz - 1) // blksiz
     units = (nb + align - 1) // align
     base, rem = divmod(units, world)

@@ -27,7 +27,7 @@ def run(rank, world, port, blksiz, n_chn, n_frames, outdir):
                      0.1 * xorshift_uniform(n_frames, seed=40 + c) for c in range(n_chn)], axis=1)
     data = data.astype(np.float32)  # [n_frames, n_chn] interleaved
 
-    plan = sweep_dist.plan_shards(n_frames, blksiz, world)
+    plan = sweep_dist.plan_shards(n_frames, blksiz, world, align=3)  # the polyphase engine's grid at blksiz 2048
     b0, b1 = plan[rank]
     eng = orc.CliEngine(blksiz, n_chn)
 

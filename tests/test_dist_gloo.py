@@ -26,17 +26,17 @@ def free_port():
 def test_plan_shards(pkg):
     from phaserotate_lv2_amd import sweep_dist as sd
     assert sd.plan_shards(10 * 2048, 2048, 2, align=1) == [(0, 5), (5, 10)]
-    assert sd.plan_shards(10 * 2048, 2048, 2) == [(0, 6), (6, 10)]          # pair-aligned boundaries
-    assert sd.plan_shards(10 * 2048 + 1, 2048, 4) == [(0, 4), (4, 8), (8, 10), (10, 11)]
-    assert sd.plan_shards(2048, 2048, 8) == [(0, 1)] + [(1, 1)] * 7
-    assert sd.plan_shards(0, 2048, 2) == [(0, 0), (0, 0)]
-    plan = sd.plan_shards(5 * 2048 + 100, 2048, 2)
+    assert sd.plan_shards(10 * 2048, 2048, 2, align=2) == [(0, 6), (6, 10)]  # pair-aligned boundaries
+    assert sd.plan_shards(10 * 2048 + 1, 2048, 4, align=2) == [(0, 4), (4, 8), (8, 10), (10, 11)]
+    assert sd.plan_shards(2048, 2048, 8, align=2) == [(0, 1)] + [(1, 1)] * 7
+    assert sd.plan_shards(0, 2048, 2, align=2) == [(0, 0), (0, 0)]
+    plan = sd.plan_shards(5 * 2048 + 100, 2048, 2, align=2)
     assert plan == [(0, 4), (4, 6)]
     assert sd.shard_frames(5 * 2048 + 100, 2048, plan, 1) == (4 * 2048, 1 * 2048 + 100)
     for n, w in ((345600000, 8), (12345678, 3)):
-        pl = sd.plan_shards(n, 2048, w)
+        pl = sd.plan_shards(n, 2048, w, align=3)
         assert pl[0][0] == 0 and pl[-1][1] == (n + 2047) // 2048
-        assert all(a[1] == b[0] for a, b in zip(pl, pl[1:])) and all(b0 % 2 == 0 for b0, _ in pl)
+        assert all(a[1] == b[0] for a, b in zip(pl, pl[1:])) and all(b0 % 3 == 0 for b0, _ in pl)
 
 
 @pytest.mark.parametrize("n_chn,n_frames", [(2, 2048 * 9 + 517), (1, 2048 * 4)])

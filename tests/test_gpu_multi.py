@@ -1,0 +1,125 @@
+"""Multi-GPU readiness that can be shown on a one-GPU box:
+ * the cfg4 workload at FULL size (60 min stereo 96 kHz = 345.6 M frames x 2 channels, generated on the device), swept
+   as 8 shards on one device and MAX-merged, equals the single pass bit for bit;
+ * prot_allreduce_peaks keeps ONE set of communicators for many all-reduces and destroys it with the last engine
+   (a counting stand-in for librccl, loaded through PROT_RCCL_LIB; the real library wants one rank per GPU).
+"""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cfg4_full_size_sharded_sweep_equals_single_pass(pkg):
+    import torch
+    from phaserotate_lv2_amd import sweep_dist
+    dev = torch.device("cuda:0")
+    P, n_chn, world = 2048, 2, 8
+    n = 3600 * 96000  # BASELINE configs[3]
+    x = torch.empty((n_chn, n), device=dev)
+    g = torch.Generator(device=dev).manual_seed(44)
+    L = 4 * 96000  # four seconds: a whole number of cycles of every harmonic below
+    tt = np.arange(L, dtype=np.float64) / 96000.0
+    u = torch.linspace(0.0, 1.0, n, dtype=torch.float64, device=dev)
+    for c in range(n_chn):  # an asymmetric harmonic stack (a real minimum) with a slow swell (maxima in several shards) + noise
+        f0 = 110.0 + 27.5 * c
+        pat = sum((0.5 / k) * np.cos(2 * np.pi * k * f0 * tt + 0.3 * k) for k in range(1, 9))
+        pat_d = torch.from_numpy(pat.astype(np.float32)).to(dev)
+        x[c] = pat_d.repeat(n // L + 1)[:n]
+        x[c] *= (0.6 + 0.3 * torch.sin(2 * np.pi * (3 + c) * u)).float()
+        x[c] += 0.02 * (torch.rand(n, generator=g, device=dev) - 0.5)
+    del u
+    one = pkg.Engine(pkg.KIND_CLI, P, n_chn)
+    pk1 = torch.zeros((n_chn, 360), device=dev)
+    torch.cuda.synchronize()
+    one.sweep_dev(x.data_ptr(), n, n, 0, 360, 1, -1, pk1.data_ptr(), pkg.F_STREAM_START | pkg.F_STREAM_END)
+    one.sync()
+    A = one.shard_align_blocks()
+    plan = sweep_dist.plan_shards(n, P, world, align=A)
+    assert len(plan) == world and all(b0 % A == 0 for b0, _ in plan)
+    one.close()
+    merged = torch.zeros((n_chn, 360), device=dev)
+    best_shard = np.zeros((n_chn, 360), np.int64)
+    for r in range(world):
+        f0, nf = sweep_dist.shard_frames(n, P, plan, r)
+        eng = pkg.Engine(pkg.KIND_CLI, P, n_chn)
+        H = int(eng.info.history)
+        if r > 0:
+            halo = x[:, f0 - H:f0].contiguous()
+            torch.cuda.synchronize()
+            keep = sweep_dist.prime_history(eng, halo)  # noqa: F841 (kept alive until the sync below)
+        xs = x[:, f0:f0 + nf]  # a view: rows n apart
+        part = torch.zeros((n_chn, 360), device=dev)
+        flags = (pkg.F_STREAM_START if r == 0 else 0) | (pkg.F_STREAM_END if r == world - 1 else 0)
+        torch.cuda.synchronize()
+        eng.sweep_dev(xs.data_ptr(), n, nf, 0, 360, 1, -1, part.data_ptr(), flags)
+        eng.sync()
+        best_shard[(part > merged).cpu().numpy()] = r
+        merged = torch.maximum(merged, part)
+        eng.close()
+    assert torch.equal(pk1, merged)
+    assert len(set(best_shard.reshape(-1).tolist())) > 1  # the table really is a merge of several shards
+    pk = pk1.cpu().numpy()
+    assert all(0 < int(pk[c].argmin()) < 360 for c in range(n_chn))  # a real minimum, not the raw-peak entry
+
+
+STUB = r"""
+#include <stddef.h>
+static int n_init, n_destroy, n_start, n_end, n_allreduce, open_groups;
+int ncclCommInitAll (void** comms, int n, const int* devs) { for (int i = 0; i < n; ++i) comms[i] = (void*)(size_t)(0x1000 + 16 * n_init + i); ++n_init; return 0; }
+int ncclCommDestroy (void* c) { (void)c; ++n_destroy; return 0; }
+int ncclGroupStart (void) { ++n_start; ++open_groups; return 0; }
+int ncclGroupEnd (void) { ++n_end; --open_groups; return 0; }
+int ncclAllReduce (const void* s, void* r, size_t count, int dt, int op, void* comm, void* stream) { (void)s; (void)r; (void)comm; (void)stream; ++n_allreduce; return (count == 720 && dt == 7 && op == 2 && open_groups == 1) ? 0 : 1; }
+void stub_counts (int* o) { o[0] = n_init; o[1] = n_destroy; o[2] = n_start; o[3] = n_end; o[4] = n_allreduce; o[5] = open_groups; }
+"""
+
+CHILD = r"""
+import ctypes, os, sys
+sys.path.insert(0, %(root)r)
+from __graft_entry__ import load_package
+pkg = load_package()
+stub = ctypes.CDLL(os.environ["PROT_RCCL_LIB"])
+def counts():
+    o = (ctypes.c_int * 6)(); stub.stub_counts(o); return list(o)
+lib = pkg.load_library()
+a, b = pkg.Engine(pkg.KIND_CLI, 2048, 2), pkg.Engine(pkg.KIND_CLI, 2048, 2)
+arr = (ctypes.c_void_p * 2)(a._h, b._h)
+for _ in range(25):
+    assert lib.prot_allreduce_peaks(arr, 2) == 0
+c1 = counts()
+c = pkg.Engine(pkg.KIND_CLI, 2048, 2)  # a third engine, another device list (a, c)
+arr2 = (ctypes.c_void_p * 2)(a._h, c._h)
+for _ in range(3):
+    assert lib.prot_allreduce_peaks(arr2, 2) == 0
+c2 = counts()
+a.close(); b.close()
+c3 = counts()   # one engine still alive: communicators kept
+c.close()
+c4 = counts()   # last engine gone: communicators destroyed
+print("COUNTS", [c1, c2, c3, c4])
+"""
+
+
+def test_allreduce_keeps_its_communicators(tmp_path):
+    src = tmp_path / "rccl_stub.c"
+    src.write_text(STUB)
+    so = str(tmp_path / "librccl_stub.so")
+    subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-o", so, str(src)], check=True)
+    env = dict(os.environ, PROT_RCCL_LIB=so, PROT_ALLREDUCE="rccl")
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    line = [l for l in r.stdout.splitlines() if l.startswith("COUNTS")]
+    assert r.returncode == 0 and line, r.stdout[-3000:]
+    c1, c2, c3, c4 = eval(line[0][7:])
+    # [init, destroy, group start, group end, all-reduce, open groups]
+    assert c1 == [1, 0, 25, 25, 50, 0]   # ONE ncclCommInitAll for 25 all-reduces of two engines, groups balanced
+    assert c2 == [1, 0, 28, 28, 56, 0]   # the same device list (0, 0) again: still the same communicators
+    assert c3 == [1, 0, 28, 28, 56, 0]   # kept while an engine lives
+    assert c4 == [1, 2, 28, 28, 56, 0]   # both destroyed with the last engine
