@@ -182,7 +182,7 @@ DEFINE_CFFT (cfft_f64, double, twd)
 		free (z);                                                             \
 	}
 
-DEFINE_R2C (orc_fft_r2c, float, cfft_f32, twf)
+DEFINE_R2C (orc_fft_r2c_own, float, cfft_f32, twf)
 DEFINE_R2C (orc_fft_r2c_f64, double, cfft_f64, twd)
 
 #define DEFINE_C2R(NAME, T, CFFT, TW)                                         \
@@ -212,8 +212,119 @@ DEFINE_R2C (orc_fft_r2c_f64, double, cfft_f64, twd)
 		free (z);                                                             \
 	}
 
-DEFINE_C2R (orc_fft_c2r, float, cfft_f32, twf)
+DEFINE_C2R (orc_fft_c2r_own, float, cfft_f32, twf)
 DEFINE_C2R (orc_fft_c2r_f64, double, cfft_f64, twd)
+
+/* ------------------------------------------------------------------------ */
+/* External FFT behind the same two calls (CPU baseline): a real   */
+/* libfftw3f.so.3 if the host has one, else MKL's FFTW3 interface (libmkl_rt) */
+/* -- the library the reference would link (src/phaserotate.c:648,657,        */
+/* cli/phase-rotate.cc:193,205).  Resolved with dlopen/dlsym against          */
+/* prototypes written out here (FFTW's documented API); never used unless     */
+/* orc_fft_use_external (1) is called: tests and parity run on the own FFT.   */
+#include <dlfcn.h>
+#include <pthread.h>
+typedef struct orc_ext_plan_s* orc_ext_plan;
+static struct {
+	void*        lib;
+	int          kind; /* 0 none, 1 fftw3f, 2 mkl */
+	int          on;
+	orc_ext_plan (*plan_r2c) (int, float*, float (*)[2], unsigned);
+	orc_ext_plan (*plan_c2r) (int, float (*)[2], float*, unsigned);
+	void (*exec_r2c) (orc_ext_plan, float*, float (*)[2]);
+	void (*exec_c2r) (orc_ext_plan, float (*)[2], float*);
+	struct { int n; orc_ext_plan r2c, c2r; } plans[16];
+	int             n_plans;
+	pthread_mutex_t lock;
+} g_ext = { .lock = PTHREAD_MUTEX_INITIALIZER };
+
+int orc_fft_use_external (int on)
+{
+	pthread_mutex_lock (&g_ext.lock);
+	if (on && !g_ext.lib) {
+		static const char* const names[][2] = { { "libfftw3f.so.3", "1" }, { "libfftw3f.so", "1" }, { "libmkl_rt.so", "2" },
+			                                    { "libmkl_rt.so.2", "2" }, { "/opt/conda/lib/libmkl_rt.so", "2" }, { "/opt/conda/lib/libmkl_rt.so.2", "2" } };
+		for (unsigned i = 0; i < sizeof (names) / sizeof (names[0]) && !g_ext.lib; ++i) {
+			void* l = dlopen (names[i][0], RTLD_NOW | RTLD_LOCAL);
+			if (!l) {
+				continue;
+			}
+			g_ext.plan_r2c = (orc_ext_plan (*) (int, float*, float (*)[2], unsigned))dlsym (l, "fftwf_plan_dft_r2c_1d");
+			g_ext.plan_c2r = (orc_ext_plan (*) (int, float (*)[2], float*, unsigned))dlsym (l, "fftwf_plan_dft_c2r_1d");
+			g_ext.exec_r2c = (void (*) (orc_ext_plan, float*, float (*)[2]))dlsym (l, "fftwf_execute_dft_r2c");
+			g_ext.exec_c2r = (void (*) (orc_ext_plan, float (*)[2], float*))dlsym (l, "fftwf_execute_dft_c2r");
+			if (g_ext.plan_r2c && g_ext.plan_c2r && g_ext.exec_r2c && g_ext.exec_c2r) {
+				g_ext.lib  = l;
+				g_ext.kind = names[i][1][0] - '0';
+			} else {
+				dlclose (l);
+			}
+		}
+	}
+	g_ext.on = on && g_ext.lib;
+	const int k = g_ext.on ? g_ext.kind : 0;
+	pthread_mutex_unlock (&g_ext.lock);
+	return k;
+}
+
+const char* orc_fft_backend_name (void)
+{
+	return !g_ext.on ? "own radix-2 FFT (oracle/prot_oracle.c)" : g_ext.kind == 1 ? "libfftw3f.so.3" : "libmkl_rt.so (MKL's FFTW3 interface)";
+}
+
+/* plans are made once per length, with FFTW_ESTIMATE | FFTW_UNALIGNED | FFTW_PRESERVE_INPUT, like the reference's
+ * FFTW_ESTIMATE plans (src/phaserotate.c:361-364, cli/phase-rotate.cc:137-141); execution is the thread-safe
+ * new-array form */
+static int ext_plans (int n, orc_ext_plan* r2c, orc_ext_plan* c2r)
+{
+	pthread_mutex_lock (&g_ext.lock);
+	for (int i = 0; i < g_ext.n_plans; ++i) {
+		if (g_ext.plans[i].n == n) {
+			*r2c = g_ext.plans[i].r2c;
+			*c2r = g_ext.plans[i].c2r;
+			pthread_mutex_unlock (&g_ext.lock);
+			return 1;
+		}
+	}
+	int ok = 0;
+	if (g_ext.n_plans < 16) {
+		float* a            = (float*)calloc ((size_t)n + 2, sizeof (float));
+		float (*b)[2]       = (float (*)[2])calloc ((size_t)n / 2 + 1, sizeof (float[2]));
+		const unsigned flag = (1u << 6) | (1u << 1) | (1u << 4);
+		orc_ext_plan p1 = g_ext.plan_r2c (n, a, b, flag), p2 = g_ext.plan_c2r (n, b, a, flag);
+		free (a);
+		free (b);
+		if (p1 && p2) {
+			g_ext.plans[g_ext.n_plans].n   = n;
+			g_ext.plans[g_ext.n_plans].r2c = *r2c = p1;
+			g_ext.plans[g_ext.n_plans].c2r = *c2r = p2;
+			++g_ext.n_plans;
+			ok = 1;
+		}
+	}
+	pthread_mutex_unlock (&g_ext.lock);
+	return ok;
+}
+
+void orc_fft_r2c (int n, const float* in, float* out)
+{
+	orc_ext_plan p1, p2;
+	if (g_ext.on && ext_plans (n, &p1, &p2)) {
+		g_ext.exec_r2c (p1, (float*)in, (float (*)[2])out); /* r2c preserves its input */
+		return;
+	}
+	orc_fft_r2c_own (n, in, out);
+}
+
+void orc_fft_c2r (int n, const float* in, float* out)
+{
+	orc_ext_plan p1, p2;
+	if (g_ext.on && ext_plans (n, &p1, &p2)) {
+		g_ext.exec_c2r (p2, (float (*)[2])in, out);
+		return;
+	}
+	orc_fft_c2r_own (n, in, out);
+}
 
 /* ------------------------------------------------------------------------ */
 /* peak: scalar variant cli/dsp_peak_calc.h:311-325 (the AVX variant :143-228 */

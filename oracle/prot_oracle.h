@@ -44,6 +44,11 @@ void orc_fft_r2c (int n, const float* in, float* out);
  * spectrum, unnormalised; Im(in[0]) and Im(in[n/2]) are ignored. `in` is
  * preserved (FFTW destroys it; nothing in the reference relies on that). */
 void orc_fft_c2r (int n, const float* in, float* out);
+/* CPU-baseline leg only (bench.py): route the two calls above through the FFT library the reference links --
+ * dlopen of libfftw3f.so.3, else of libmkl_rt.so (MKL's FFTW3 interface).  Returns 0 = none found (own FFT stays),
+ * 1 = FFTW, 2 = MKL.  Off by default: tests and parity always run on the own FFT. */
+int         orc_fft_use_external (int on);
+const char* orc_fft_backend_name (void);
 /* same transforms in double (tolerance accounting only) */
 void orc_fft_r2c_f64 (int n, const double* in, double* out);
 void orc_fft_c2r_f64 (int n, const double* in, double* out);

@@ -245,3 +245,32 @@ def test_cli_find_min_stride1_equals_argmin_and_coarse_fine_agree():
     # the fine pass lands on a local minimum of the full table
     a = (ma24[0] + 360) % 360
     assert pk[a] <= pk[(a - 1) % 360] and pk[a] <= pk[(a + 1) % 360]
+
+
+def test_oracle_fft_agrees_with_an_fftw_interface_library_if_the_host_has_one():
+    """A further pin of the restated FFTW semantics (unnormalised r2c / c2r, Im(DC) and Im(Nyquist) ignored, bin order):
+    when the host has libfftw3f.so.3 or MKL's FFTW3 interface (libmkl_rt.so: present in this image), the two engines
+    give the same samples on it as on the oracle's own FFT.  (bench.py's cpu_baseline times the oracle on that library.)"""
+    import ctypes as C
+    import os
+    os.environ.setdefault("MKL_NUM_THREADS", "1")
+    orc.lib.orc_fft_use_external.restype = C.c_int
+    orc.lib.orc_fft_backend_name.restype = C.c_char_p
+    x = xorshift_uniform(40000, seed=5).reshape(1, -1)
+    y_own = orc.Lv2Engine(48000, 1).run_stream(x, -60.0, 1024)
+    blk = xorshift_uniform(2048 * 6, seed=6)
+    o = orc.CliEngine(2048, 1)
+    c_own = np.concatenate([o.apply(blk[b * 2048:(b + 1) * 2048], [77]) for b in range(6)])
+    kind = orc.lib.orc_fft_use_external(1)
+    try:
+        if kind == 0:
+            pytest.skip("no libfftw3f.so.3 / libmkl_rt.so on this host")
+        fir_ext = orc.fir_design(3072)
+        y_ext = orc.Lv2Engine(48000, 1).run_stream(x, -60.0, 1024)
+        o = orc.CliEngine(2048, 1)
+        c_ext = np.concatenate([o.apply(blk[b * 2048:(b + 1) * 2048], [77]) for b in range(6)])
+    finally:
+        orc.lib.orc_fft_use_external(0)
+    assert np.abs(fir_ext - orc.fir_design(3072)).max() < 5e-7   # the 3072-point design transform (2^10 x 3); taps up to 0.64
+    assert np.abs(y_ext - y_own).max() < 1e-6
+    assert np.abs(c_ext - c_own).max() < 1e-6
