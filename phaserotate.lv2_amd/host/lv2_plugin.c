@@ -330,11 +330,19 @@ instantiate (const LV2_Descriptor* descriptor, double rate, const char* bundle_p
 #undef MAP
 
 	self->ui_scale = 1.0f; /* src/phaserotate.c:299-301 */
+	uint32_t max_block = 0;
 	if (options) {         /* src/phaserotate.c:261-276 (the reference then overwrites it with 1.0 at :300) */
 		const LV2_URID key = m->map (m->handle, "http://lv2plug.in/ns/extensions/ui#scaleFactor");
+		/* buf-size:maxBlockLength: the longest run() the host will ask for -- the engine reserves its staging buffers
+		 * for it here, so that run() never allocates (longer calls would be cut into reserved-size pieces) */
+		const LV2_URID kmb = m->map (m->handle, "http://lv2plug.in/ns/ext/buf-size#maxBlockLength");
 		for (const LV2_Options_Option* o = options; o->key; ++o) {
 			if (o->context == LV2_OPTIONS_INSTANCE && o->key == key && o->type == self->u.atom_Float) {
 				(void)*(const float*)o->value; /* parsed and, as in the reference, not kept */
+			}
+			if (o->context == LV2_OPTIONS_INSTANCE && o->key == kmb && o->type == self->u.atom_Int && o->value) {
+				const int32_t v = *(const int32_t*)o->value;
+				max_block       = v > 0 ? (uint32_t)v : 0;
 			}
 		}
 	}
@@ -353,6 +361,11 @@ instantiate (const LV2_Descriptor* descriptor, double rate, const char* bundle_p
 	if (!self->engine) {
 		fprintf (stderr, "phaserotate.lv2 error: cannot create the GPU engine: %s (%s)\n",
 		         prot_strerror (status), prot_last_error ());
+		cleanup ((LV2_Handle)self);
+		return NULL;
+	}
+	if (max_block > 8192 && prot_lv2_set_max_block (self->engine, max_block) != PROT_OK) { /* (8192 frames are reserved by default) */
+		fprintf (stderr, "phaserotate.lv2 error: cannot reserve buffers for %u-frame blocks: %s\n", max_block, prot_last_error ());
 		cleanup ((LV2_Handle)self);
 		return NULL;
 	}

@@ -62,7 +62,9 @@ def plugin(suffix, label, channels):
     return ("<%s%s>\n  a lv2:Plugin, doap:Project, lv2:UtilityPlugin ;\n"
             "  doap:license <http://usefulinc.com/doap/licenses/gpl> ;\n"
             "  doap:name \"Phaserotate%s (MI355X)\" ;\n"
-            "  lv2:optionalFeature lv2:hardRTCapable ;\n  lv2:requiredFeature urid:map ;\n"
+            # (no lv2:hardRTCapable, unlike lv2ttl/phaserotate.ports.in:7: run() here waits for a device stream -- it never
+            #  allocates or takes a lock, but its duration is a host-link round trip, not a bounded CPU computation)
+            "  lv2:optionalFeature <http://lv2plug.in/ns/ext/options#options> ;\n  lv2:requiredFeature urid:map ;\n"
             "  rdfs:comment \"Phase rotate signal; DSP on an AMD MI355X through libprot_hip.\" ;\n"
             "  lv2:port %s .\n" % (URI, suffix, label, " ,\n  ".join(ports)))
 

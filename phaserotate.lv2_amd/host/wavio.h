@@ -6,8 +6,10 @@
 // any channel count.  The output file takes the input's format (the reference
 // copies SF_INFO, :697).  Sample conversion follows libsndfile's defaults:
 // integer PCM <-> float by 2^(bits-1) on read and (2^(bits-1) - 1) on write.
-// Metadata chunks (cue, bext, LIST) are not copied (copy_metadata, :541-563,
-// is outside the hot path).
+// copy_metadata (cli/phase-rotate.cc:541-563: strings, cue points, broadcast info) becomes: the input's
+// "LIST" (INFO strings), "cue " and "bext" chunks are carried over verbatim, in front of the samples.
+// What libsndfile offers beyond that -- other containers (AIFF, FLAC, W64, ...), RF64, other sample encodings --
+// is refused with an error text, never guessed.
 #pragma once
 #include <algorithm>
 #include <cerrno>
@@ -20,12 +22,18 @@
 
 namespace wavio {
 
+struct Chunk {
+	char                 id[4];
+	std::vector<uint8_t> body;
+};
+
 struct Info {
 	uint32_t samplerate = 0;
 	uint16_t channels   = 0;
 	uint16_t bits       = 0;     // container bits per sample
 	bool     is_float   = false;
 	uint64_t frames     = 0;
+	std::vector<Chunk> meta;     // LIST / cue / bext chunks of the input, in file order (<= 1 MiB each, 16 in all)
 };
 
 inline uint32_t rd32 (const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -52,8 +60,11 @@ inline std::string read_file (const char* path, Info& nfo, std::vector<float>& d
 		}
 		uint32_t sz = rd32 (ch + 4);
 		if (!memcmp (ch, "fmt ", 4)) {
+			if (sz < 16 || sz > 4096) { // (plain 16, extensible 40: a crafted size must not become a 4 GiB allocation)
+				break;
+			}
 			std::vector<uint8_t> b (sz);
-			if (sz < 16 || fread (b.data (), 1, sz, f) != sz) {
+			if (fread (b.data (), 1, sz, f) != sz) {
 				break;
 			}
 			tag            = rd16 (&b[0]);
@@ -117,8 +128,44 @@ inline std::string read_file (const char* path, Info& nfo, std::vector<float>& d
 				}
 				done += want;
 			}
+			// chunks behind the samples (where many writers put LIST / cue / bext)
+			if (sz != 0xFFFFFFFFu && sz <= avail) {
+				fseek (f, here + (long)sz + (long)(sz & 1), SEEK_SET);
+				for (;;) {
+					uint8_t c2[8];
+					if (fread (c2, 1, 8, f) != 8) {
+						break;
+					}
+					const uint32_t s2 = rd32 (c2 + 4);
+					if ((!memcmp (c2, "LIST", 4) || !memcmp (c2, "cue ", 4) || !memcmp (c2, "bext", 4)) && s2 <= (1u << 20) && nfo.meta.size () < 16) {
+						Chunk c;
+						memcpy (c.id, c2, 4);
+						c.body.resize (s2);
+						if (fread (c.body.data (), 1, s2, f) != s2) {
+							break;
+						}
+						nfo.meta.push_back (std::move (c));
+						if (s2 & 1) {
+							fseek (f, 1, SEEK_CUR);
+						}
+					} else if (fseek (f, (long)(s2 + (s2 & 1)), SEEK_CUR) != 0) {
+						break;
+					}
+				}
+			}
 			fclose (f);
 			return "";
+		} else if ((!memcmp (ch, "LIST", 4) || !memcmp (ch, "cue ", 4) || !memcmp (ch, "bext", 4)) && sz <= (1u << 20) && nfo.meta.size () < 16) {
+			Chunk c;
+			memcpy (c.id, ch, 4);
+			c.body.resize (sz);
+			if (fread (c.body.data (), 1, sz, f) != sz) {
+				break;
+			}
+			nfo.meta.push_back (std::move (c));
+			if (sz & 1) {
+				fseek (f, 1, SEEK_CUR);
+			}
 		} else {
 			fseek (f, (long)(sz + (sz & 1)), SEEK_CUR);
 		}
@@ -138,9 +185,10 @@ public:
 		if (!_f) {
 			return std::string ("System error : ") + strerror (errno) + ".";
 		}
-		uint8_t h[44];
-		memset (h, 0, sizeof (h));
-		fwrite (h, 1, 44, _f); // patched in close()
+		// WAVE_FORMAT_EXTENSIBLE where the plain header is not defined: more than two channels or more than 16 bits of PCM
+		_ext = _nfo.channels > 2 || (!_nfo.is_float && _nfo.bits > 16);
+		std::vector<uint8_t> h (header_size (), 0);
+		fwrite (h.data (), 1, h.size (), _f); // patched in close()
 		return "";
 	}
 
@@ -182,23 +230,44 @@ public:
 		}
 		const uint32_t bps  = _nfo.bits / 8;
 		const uint64_t data = _frames * bps * _nfo.channels;
-		uint8_t        h[44];
+		if (data & 1) {
+			fputc (0, _f);
+		}
+		std::vector<uint8_t> h (header_size (), 0);
 		auto w32 = [] (uint8_t* p, uint32_t v) { p[0] = v; p[1] = v >> 8; p[2] = v >> 16; p[3] = v >> 24; };
 		auto w16 = [] (uint8_t* p, uint16_t v) { p[0] = v; p[1] = v >> 8; };
-		memcpy (h, "RIFF", 4);
-		w32 (h + 4, (uint32_t)std::min<uint64_t> (36 + data, 0xFFFFFFFFu));
-		memcpy (h + 8, "WAVEfmt ", 8);
-		w32 (h + 16, 16);
-		w16 (h + 20, _nfo.is_float ? 3 : 1);
-		w16 (h + 22, _nfo.channels);
-		w32 (h + 24, _nfo.samplerate);
-		w32 (h + 28, _nfo.samplerate * bps * _nfo.channels);
-		w16 (h + 32, (uint16_t)(bps * _nfo.channels));
-		w16 (h + 34, _nfo.bits);
-		memcpy (h + 36, "data", 4);
-		w32 (h + 40, (uint32_t)std::min<uint64_t> (data, 0xFFFFFFFFu));
+		uint8_t* p = h.data ();
+		memcpy (p, "RIFF", 4);
+		w32 (p + 4, (uint32_t)std::min<uint64_t> (h.size () - 8 + data + (data & 1), 0xFFFFFFFFu));
+		memcpy (p + 8, "WAVEfmt ", 8);
+		const uint16_t tag = _nfo.is_float ? 3 : 1;
+		w32 (p + 16, _ext ? 40 : 16);
+		w16 (p + 20, _ext ? 0xFFFE : tag);
+		w16 (p + 22, _nfo.channels);
+		w32 (p + 24, _nfo.samplerate);
+		w32 (p + 28, _nfo.samplerate * bps * _nfo.channels);
+		w16 (p + 32, (uint16_t)(bps * _nfo.channels));
+		w16 (p + 34, _nfo.bits);
+		p += 36;
+		if (_ext) {
+			static const uint8_t guid_tail[14] = { 0x00, 0x00, 0x00, 0x00, 0x10, 0x00, 0x80, 0x00, 0x00, 0xAA, 0x00, 0x38, 0x9B, 0x71 };
+			w16 (p, 22);          // cbSize
+			w16 (p + 2, _nfo.bits); // valid bits
+			w32 (p + 4, 0);       // channel mask: unspecified
+			w16 (p + 8, tag);     // sub-format GUID = tag + the fixed tail
+			memcpy (p + 10, guid_tail, 14);
+			p += 24;
+		}
+		for (const Chunk& c : _nfo.meta) { // copy_metadata, cli/phase-rotate.cc:541-563
+			memcpy (p, c.id, 4);
+			w32 (p + 4, (uint32_t)c.body.size ());
+			memcpy (p + 8, c.body.data (), c.body.size ());
+			p += 8 + c.body.size () + (c.body.size () & 1);
+		}
+		memcpy (p, "data", 4);
+		w32 (p + 4, (uint32_t)std::min<uint64_t> (data, 0xFFFFFFFFu));
 		fseek (_f, 0, SEEK_SET);
-		fwrite (h, 1, 44, _f);
+		fwrite (h.data (), 1, h.size (), _f);
 		fclose (_f);
 		_f = nullptr;
 	}
@@ -206,8 +275,17 @@ public:
 	~Writer () { close (); }
 
 private:
+	size_t header_size () const
+	{
+		size_t n = 12 + 8 + (_ext ? 40 : 16) + 8;
+		for (const Chunk& c : _nfo.meta) {
+			n += 8 + c.body.size () + (c.body.size () & 1);
+		}
+		return n;
+	}
 	FILE*    _f = nullptr;
 	Info     _nfo;
+	bool     _ext    = false;
 	uint64_t _frames = 0;
 };
 
