@@ -121,7 +121,12 @@ int prot_abi_version (void);
  * frames are kept for the next call.  Asynchronous on `stream`.
  * d_out must not overlap d_in (PROT_EINVAL): workgroups read the input of
  * neighbouring runs while others store output.  The LV2 front end, where hosts
- * do run in place (src/phaserotate.c:779-785), goes through its own buffers. */
+ * do run in place (src/phaserotate.c:779-785), goes through its own buffers.
+ * ONE STREAM AT A TIME PER ENGINE: every device call (this one, _ramp, _f16, prot_sweep_dev) stages its rotation,
+ * angle list, history pair and workspace in buffers the engine owns.  Calls queued on the same stream are ordered;
+ * before moving an engine to another stream the caller synchronises the old one (or makes the new stream wait on
+ * an event recorded there).  Two streams on one engine at once race on those buffers.  Different engines are
+ * independent -- one per thread / per plugin instance, like the reference's instances. */
 int prot_apply_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_in,
                     float* d_out, int64_t out_stride, uint64_t n_out,
                     const float* rot, uint32_t flags, void* stream);

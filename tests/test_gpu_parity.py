@@ -781,3 +781,30 @@ def test_no_frame_written_outside_the_requested_range(pkg, kind, param, n):
         assert (y[:n] != 9.0).any() or n < 3
         assert (y[n:stride] == 9.0).all() and (y[stride + n:2 * stride] == 9.0).all(), (off, n)
         assert (yb[:off] == 9.0).all() and (yb[off + 2 * stride:] == 9.0).all()
+
+
+def test_cfg3_shape_against_oracle(pkg):
+    """BASELINE configs[2] in its own shape: LV2 stereo at 96 kHz (4096-tap FIR), 256 buffers of 1024 frames per STATEFUL
+    device launch, three launches back to back -- against the oracle's run() over the same 786 432 frames per channel."""
+    import torch
+    dev = torch.device("cuda:0")
+    n_chn, per = 2, 256 * 1024
+    n = 3 * per
+    x = xorshift_uniform(n_chn * n, seed=96).reshape(n_chn, n)
+    angles = [40.0, -115.0]
+    yo = orc.Lv2Engine(96000, n_chn).run_stream(x, angles, 1024)
+    e = pkg.Engine(pkg.KIND_LV2, 96000, n_chn)
+    rot = np.array([[np.cos(-2 * np.pi * a / 360.0), np.sin(-2 * np.pi * a / 360.0)] for a in angles], np.float32).reshape(-1)
+    xd = torch.from_numpy(x).to(dev)
+    yd = torch.empty_like(xd)
+    for k in range(3):
+        xin = xd[:, k * per:(k + 1) * per].contiguous()
+        yout = torch.empty_like(xin)
+        torch.cuda.synchronize()
+        e.apply_dev(xin.data_ptr(), per, per, yout.data_ptr(), per, per, rot, 0)  # stateful: the history carries over
+        e.sync()
+        yd[:, k * per:(k + 1) * per] = yout
+    yg = yd.cpu().numpy()
+    s0 = 2560 + 2 * 1024  # Q10: run() ramps from 0 deg on its first blocks; the device call starts steady
+    assert np.abs(yg[:, s0:] - yo[:, s0:]).max() < TOL
+    e.close()

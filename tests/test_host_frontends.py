@@ -439,3 +439,57 @@ def test_cli_prot_gpus_env_gives_same_result(tmp_path):
     r = subprocess.run([CLI, "-f", "2048", wav], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
     assert rc1 == 0 and r.returncode == 0, r.stderr
     assert r.stdout == out1
+
+
+@pytest.mark.gpu
+def test_two_plugin_instances_run_concurrently():
+    """SURVEY 8b threading: several instances may run() at the same time (the reference guards only FFTW's planner,
+    src/phaserotate.c:43-44, :198-220).  Two hosts -- a mono and a stereo instance -- instantiate, run 200 buffers and
+    clean up from two threads at once (ctypes releases the GIL inside run()); each stream must match its oracle."""
+    import threading
+    n, bs = 200 * 256, 256
+    res, errs = {}, []
+
+    def worker(index, angles, seed):
+        try:
+            h = Lv2Host(index)
+            assert h.handle
+            h.setup(bs)
+            h.set_control(None)
+            x = xorshift_uniform(n * (index + 1), seed=seed).reshape(index + 1, n)
+            y = np.empty_like(x)
+            for s in range(0, n, bs):
+                y[:, s:s + bs] = h.run(x[:, s:s + bs], angles)
+            h.close()
+            res[index] = (x, y, angles)
+        except Exception as ex:  # noqa: BLE001 (reported by the asserting thread)
+            errs.append(repr(ex))
+
+    for rep in range(3):  # instantiate / cleanup race as well
+        th = [threading.Thread(target=worker, args=(0, [77.0], 5 + rep)), threading.Thread(target=worker, args=(1, [-30.0, 120.0], 9 + rep))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for index, (x, y, angles) in res.items():
+            yo = orc.Lv2Engine(48000, index + 1).run_stream(x, angles, bs)
+            assert np.abs(y[:, 4096:] - yo[:, 4096:]).max() < 2e-6
+            assert np.abs(y - yo).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_run_longer_than_the_reserved_block_is_chunked(pkg):
+    """prot_lv2_run never allocates: buffers are reserved for 8192 frames (or options:maxBlockLength) and longer calls are
+    cut up -- same samples as the oracle's run() with the same call sizes."""
+    n = 3 * 20000
+    x = xorshift_uniform(n, seed=3).reshape(1, n)
+    g = pkg.Lv2Instance(48000, 1)
+    g.activate()
+    o = orc.Lv2Engine(48000, 1)
+    yg, yo = np.empty_like(x), np.empty_like(x)
+    for s in range(0, n, 20000):  # 20000 > 8192: two full chunks and a rest per call
+        yg[:, s:s + 20000] = g.run(x[:, s:s + 20000], -45.0)
+        yo[:, s:s + 20000] = o.run(x[:, s:s + 20000], -45.0)
+    assert np.abs(yg - yo).max() < 1e-5 and np.abs(yg[:, 8192:] - yo[:, 8192:]).max() < 2e-6
+    g.close()
