@@ -530,6 +530,9 @@ struct T16 {
 #ifndef PROT_LEAN_PIN
 #define PROT_LEAN_PIN 0
 #endif
+#ifndef PROT_PREFETCH_EARLY
+#define PROT_PREFETCH_EARLY 1
+#endif
 #ifndef PROT_PREFETCH_AT
 #define PROT_PREFETCH_AT 1
 #endif
@@ -645,9 +648,9 @@ PROT_DEV void twiddle_store_lean (typename T::cplx (&v)[16], const PROT_LDS_PTR 
 
 // forward transform up to (not including) the last radix-16 pass; `before_last` runs between the
 // issue of the last exchange reads and that pass (the caller fetches its first table entries there)
-template <class T, int NNZ, bool LEAN, class F>
+template <class T, int NNZ, bool LEAN, class F, class G>
 PROT_DEV void fwd4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const typename T::cplx* twm,
-                        const typename T::cplx (&tw1)[16], int t, int tl, int th, F&& before_last, Stamps& st)
+                        const typename T::cplx (&tw1)[16], int t, int tl, int th, F&& before_last, Stamps& st, G&& after_barrier)
 {
 	typedef typename T::cplx C;
 	typedef PROT_LDS_PTR (T) VC;
@@ -676,6 +679,7 @@ PROT_DEV void fwd4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 			if (!(PROT_ABL2 & 1)) v[k] = r[16 * k];
 		}
 	}
+	after_barrier ();
 	if (LEAN) {
 		C q0[4];
 		const VC* rq = (const VC*)&twm[tl];
@@ -713,7 +717,7 @@ PROT_DEV void fwd4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
                         const typename T::cplx (&tw1)[16], int t, int tl, int th, F&& before_last)
 {
 	Stamps st;
-	fwd4096w<T, NNZ, false> (v, lds, twm, tw1, t, tl, th, before_last, st);
+	fwd4096w<T, NNZ, false> (v, lds, twm, tw1, t, tl, th, before_last, st, [] () {});
 }
 
 template <class T, bool LEAN, class F>
@@ -1366,8 +1370,19 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 				}
 			}
 		};
+#if PROT_PREFETCH_EARLY == 2
+		if (LEAN && it + 1 < n_it) {
+			load_block (s + BLK - Dc, t);
+		}
+#endif
 		st.tick (0);
-		fwd4096w<T, HS, LEAN> (v, lds, twm, tw1, t, tl, th, [&] () { h_fetch (0); }, st);
+		fwd4096w<T, HS, LEAN> (v, lds, twm, tw1, t, tl, th, [&] () { h_fetch (0); }, st, [&] () {
+#if PROT_PREFETCH_EARLY == 1
+			if (LEAN && it + 1 < n_it) { // the next block's frames go out right behind the first barrier: three quarters of an iteration ahead
+				load_block (s + BLK - Dc, t);
+			}
+#endif
+		});
 
 		// Y = Z G0 (+ Z_prev G1); bins >= 2048 use the conjugate of the mirrored bin
 #pragma unroll
@@ -1404,7 +1419,7 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 
 		st.tick (5);
 		__builtin_amdgcn_sched_barrier (0);
-		if (it + 1 < n_it) {
+		if (it + 1 < n_it && !(LEAN && PROT_PREFETCH_EARLY)) {
 			load_block (s + BLK - Dc, t);
 		}
 		__builtin_amdgcn_sched_barrier (0);

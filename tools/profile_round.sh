@@ -1,0 +1,23 @@
+#!/bin/bash
+# usage (on the GPU box): bash tools/profile_round.sh <tag>
+# rocprofv3 kernel stats of the default bench command, then separate --pmc passes (never combined with traces) for HBM
+# traffic and the SQ counters of the headline kernel and of the sweep; raw output under gpurun_out/prof_<tag>/, the
+# summaries that are meant to be judged are written to profiles/ by tools/summarize_round.py (run it there, copy back).
+TAG=${1:-r02}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+B="python3 bench.py --no-extra --no-cpu-baseline"
+S="--steps 4 --warmup 1 --preroll 2 --no-sweep"
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -- python3 bench.py --no-cpu-baseline > $OUT/bench_stats.json 2> $OUT/stats.err
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -- $B $S > /dev/null 2> $OUT/fetch.err
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write -- $B $S > /dev/null 2> $OUT/write.err
+rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS -d $OUT/sq1 -- $B $S > /dev/null 2> $OUT/sq1.err
+rocprofv3 --output-format csv --pmc SQ_INSTS_VMEM SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE -d $OUT/sq2 -- $B $S > /dev/null 2> $OUT/sq2.err
+# the sweep (one pass of each material is enough: --sweep-seconds 600 keeps the counter runs short)
+W="python3 bench.py --no-extra --no-cpu-baseline --steps 2 --warmup 1 --preroll 1 --sweep-seconds 600"
+rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA -d $OUT/sw1 -- $W > /dev/null 2> $OUT/sw1.err
+rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM SQ_INSTS_SALU GRBM_GUI_ACTIVE -d $OUT/sw2 -- $W > /dev/null 2> $OUT/sw2.err
+rocprofv3 -L 2>/dev/null | grep -i "mfma\|SQ_INSTS_VALU\b" | head -20 > $OUT/counters_available.txt
+python3 tools/summarize_round.py $TAG $OUT
+ls $OUT

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""profiles/<tag>_* from the raw rocprofv3 output of tools/profile_round.sh:
+  <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `python3 bench.py --no-cpu-baseline`
+  <tag>_bench.json         the JSON line that run printed
+  <tag>_pmc.json           FETCH_SIZE (x2 on gfx950, MI355X_MICROARCH.md section HBM) + WRITE_SIZE per launch of the headline kernel
+  <tag>_pmc_sq.json        SQ counters per launch: headline kernel and sweep kernel
+  traffic_latest.json      read by bench.py (roofline.traffic)"""
+import collections, csv, glob, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles")
+tag, out = sys.argv[1], sys.argv[2]
+HEAD, SWEEP = "olapoly_kernel<prot::T32, 1, 10, 0, 3, false, 3>", "sweep_mfma_kernel<3"
+
+
+def counters(d):
+    fs = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in fs:
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+def pick(agg, sub):
+    res = {}
+    for k, cs in agg.items():
+        if sub in k:
+            for c, v in cs.items():
+                res[c] = {"launches": len(v), "mean": sum(v) / len(v)}
+            res["_kernel"] = k[:160]
+    return res
+
+
+st = glob.glob(os.path.join(out, "stats", "**", "*_kernel_stats.csv"), recursive=True)
+if st:
+    shutil.copy(st[0], os.path.join(PROF, tag + "_kernel_stats.csv"))
+    for line in open(st[0]).read().splitlines()[:8]:
+        print(line[:220])
+bj = os.path.join(out, "bench_stats.json")
+if os.path.exists(bj):
+    lines = [l for l in open(bj).read().splitlines() if l.startswith("{")]
+    if lines:
+        open(os.path.join(PROF, tag + "_bench_under_rocprof.json"), "w").write(lines[-1] + "\n")
+fetch, write = pick(counters(os.path.join(out, "fetch")), HEAD), pick(counters(os.path.join(out, "write")), HEAD)
+if "FETCH_SIZE" in fetch and "WRITE_SIZE" in write:
+    rd, wr = 2.0 * fetch["FETCH_SIZE"]["mean"] * 1024, write["WRITE_SIZE"]["mean"] * 1024
+    t = {"kernel": fetch["_kernel"], "hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
+         "source": tag + "_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes, KiB -> bytes)"}
+    json.dump({"note": "separate --pmc passes; KiB; FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md, HBM section), WRITE_SIZE exact",
+               "FETCH_SIZE": fetch, "WRITE_SIZE": write, "per_launch": t}, open(os.path.join(PROF, tag + "_pmc.json"), "w"), indent=1)
+    json.dump(t, open(os.path.join(PROF, "traffic_latest.json"), "w"), indent=1)
+    print(json.dumps(t))
+sq = {"note": "separate --pmc passes (8 SQ slots each); per-launch means; SQ_* summed over the chip; *_CYCLES / WAIT / ACTIVE in quad-cycles"}
+h = {}
+for d in ("sq1", "sq2"):
+    h.update(pick(counters(os.path.join(out, d)), HEAD))
+s = {}
+for d in ("sw1", "sw2"):
+    s.update(pick(counters(os.path.join(out, d)), SWEEP))
+if h:
+    if "SQ_ACTIVE_INST_ANY" in h and "SQ_WAVE_CYCLES" in h:
+        h["active_fraction = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES"] = h["SQ_ACTIVE_INST_ANY"]["mean"] / h["SQ_WAVE_CYCLES"]["mean"]
+    sq["headline"] = h
+if s:
+    sq["sweep"] = s
+json.dump(sq, open(os.path.join(PROF, tag + "_pmc_sq.json"), "w"), indent=1)
+print(json.dumps({k: (v if not isinstance(v, dict) else v.get("mean")) for k, v in h.items()}, indent=0)[:1500])
+print(json.dumps({k: (v if not isinstance(v, dict) else v.get("mean")) for k, v in s.items()}, indent=0)[:1500])
