@@ -241,6 +241,11 @@ struct prot_engine {
 
 	DevBuf<float2> d_H, d_tw;
 	DevBuf<float>  d_lut, d_rot, d_hist[2], d_peaks, d_in, d_out, d_u, d_inter, d_rot_s;
+	// whole-file calls: two sets of staging buffers, a copy stream and events, so that chunk k+1 is uploaded and
+	// de-interleaved while chunk k is swept (cli/phase-rotate.cc:565-587 reads and analyses block by block)
+	DevBuf<float>  d_inter_b, d_in_b;
+	hipStream_t    copy_stream = nullptr;
+	hipEvent_t     ev_copied[2] = {}, ev_free[2] = {};
 	DevBuf<uint16_t> d_hist16[2]; // fp16 sample path: its own input history (half precision), double-buffered
 	int            hist16_cur = 0;
 	DevBuf<int>    d_angles;
@@ -340,6 +345,8 @@ int pick_run_frames (const prot_engine* e, uint64_t n_out, int n_chn, int unit_f
 }
 
 int hist_advance (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_in, int chn0, int n_chn, hipStream_t s);
+int analyze_range (prot_engine* e, const float* data, uint64_t f0, uint64_t nf, bool is_first, bool is_last, int ang_start,
+                   int ang_end, int ang_stride, int chn);
 
 // core of prot_apply_dev / the Hilbert pass of the sweep
 int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_in, float* d_out,
@@ -899,6 +906,19 @@ void prot_engine_destroy (prot_engine* e)
 	e->d_out.release ();
 	e->d_u.release ();
 	e->d_inter.release ();
+	e->d_inter_b.release ();
+	e->d_in_b.release ();
+	for (int i = 0; i < 2; ++i) {
+		if (e->ev_copied[i]) {
+			(void)hipEventDestroy (e->ev_copied[i]);
+		}
+		if (e->ev_free[i]) {
+			(void)hipEventDestroy (e->ev_free[i]);
+		}
+	}
+	if (e->copy_stream) {
+		(void)hipStreamDestroy (e->copy_stream);
+	}
 	e->d_rot_s.release ();
 	e->d_angles.release ();
 	e->d_thr.release ();
@@ -1565,36 +1585,10 @@ int prot_cli_analyze_file (prot_engine* e, const float* data, uint64_t n_frames,
 	const uint32_t nc = e->info.n_chn;
 	const uint64_t P  = e->info.blksiz;
 	hipStream_t    s  = e->stream;
-	// chunk: whole alignment units (blocks AND device transform blocks), <= 2^22 frames per channel
-	const uint64_t chunk = file_chunk_frames (e);
-	int rc;
-	const uint64_t cap = std::min<uint64_t> (chunk, std::max<uint64_t> (n_frames, 1));
-	if ((rc = e->d_inter.ensure (cap * nc)) || (rc = e->d_in.ensure (cap * nc))) {
-		return rc;
-	}
-	uint64_t pos   = 0;
-	bool     first = true;
-	do {
-		const uint64_t n    = std::min (chunk, n_frames - pos);
-		const bool     last = pos + n >= n_frames;
-		if (n) {
-			HIP_TRY (hipMemcpyAsync (e->d_inter.p, data + pos * nc, n * nc * sizeof (float), hipMemcpyHostToDevice, s));
-			hipError_t err = prot::launch_deinterleave (e->d_inter.p, e->d_in.p, (int64_t)cap, (int64_t)n, (int)nc, s);
-			if (err != hipSuccess) {
-				return hip_fail (err, "deinterleave launch");
-			}
-		}
-		// an empty file never sets `start` (cli/phase-rotate.cc:573-576)
-		uint32_t fl = (first && n ? PROT_F_STREAM_START : 0) | (last ? PROT_F_STREAM_END : 0);
-		rc = prot_sweep_dev (e, e->d_in.p, (int64_t)cap, n, ang_start, ang_end, ang_stride, chn, nullptr, fl, s);
-		if (rc) {
-			return rc;
-		}
-		HIP_TRY (hipStreamSynchronize (s)); // d_inter / d_in are reused by the next chunk
-		pos += n;
-		first = false;
-	} while (pos < n_frames);
-	return PROT_OK;
+	(void)nc;
+	(void)P;
+	(void)s;
+	return analyze_range (e, data, 0, n_frames, true, true, ang_start, ang_end, ang_stride, chn);
 }
 
 // ------------------------------------------------------------------ several GPUs
@@ -1609,14 +1603,22 @@ int analyze_range (prot_engine* e, const float* data, uint64_t f0, uint64_t nf, 
 {
 	HIP_TRY (hipSetDevice (e->device));
 	const uint32_t nc = e->info.n_chn;
-	const uint64_t P  = e->info.blksiz;
 	hipStream_t    s  = e->stream;
 	const uint64_t chunk = file_chunk_frames (e);
 	const uint64_t H     = e->info.history;
 	const uint64_t cap   = std::max<uint64_t> (std::min<uint64_t> (chunk, std::max<uint64_t> (nf, 1)), H);
+	const bool     dbl   = nf > chunk; // more than one chunk: upload of chunk k+1 under the sweep of chunk k
 	int rc;
-	if ((rc = e->d_inter.ensure (cap * nc)) || (rc = e->d_in.ensure (cap * nc)) || (rc = e->d_out.ensure (cap * nc))) {
+	if ((rc = e->d_inter.ensure (cap * nc)) || (rc = e->d_in.ensure (cap * nc)) || (rc = e->d_out.ensure (cap * nc)) ||
+	    (dbl && ((rc = e->d_inter_b.ensure (cap * nc)) || (rc = e->d_in_b.ensure (cap * nc))))) {
 		return rc;
+	}
+	if (dbl && !e->copy_stream) {
+		HIP_TRY (hipStreamCreateWithFlags (&e->copy_stream, hipStreamNonBlocking));
+		for (int i = 0; i < 2; ++i) {
+			HIP_TRY (hipEventCreateWithFlags (&e->ev_copied[i], hipEventDisableTiming));
+			HIP_TRY (hipEventCreateWithFlags (&e->ev_free[i], hipEventDisableTiming));
+		}
 	}
 	if (!is_first) {
 		// prime the input history with the H frames in front of the range (Hilbert output discarded)
@@ -1634,28 +1636,50 @@ int analyze_range (prot_engine* e, const float* data, uint64_t f0, uint64_t nf, 
 	}
 	uint64_t pos   = 0;
 	bool     first = true;
+	int      i     = 0;
+	bool     used[2] = { false, false };
 	do {
 		const uint64_t n    = std::min (chunk, nf - pos);
 		const bool     last = pos + n >= nf;
+		const int      b    = dbl ? (i & 1) : 0;
+		float*         di   = b ? e->d_inter_b.p : e->d_inter.p;
+		float*         dn   = b ? e->d_in_b.p : e->d_in.p;
+		hipStream_t    cs   = dbl ? e->copy_stream : s;
 		if (n) {
-			HIP_TRY (hipMemcpyAsync (e->d_inter.p, data + (f0 + pos) * nc, n * nc * sizeof (float), hipMemcpyHostToDevice, s));
-			hipError_t err = prot::launch_deinterleave (e->d_inter.p, e->d_in.p, (int64_t)cap, (int64_t)n, (int)nc, s);
+			if (dbl && used[b]) {
+				HIP_TRY (hipStreamWaitEvent (cs, e->ev_free[b], 0)); // the sweep that read this pair two chunks ago
+			}
+			HIP_TRY (hipMemcpyAsync (di, data + (f0 + pos) * nc, n * nc * sizeof (float), hipMemcpyHostToDevice, cs));
+			hipError_t err = prot::launch_deinterleave (di, dn, (int64_t)cap, (int64_t)n, (int)nc, cs);
 			if (err != hipSuccess) {
 				return hip_fail (err, "deinterleave launch");
+			}
+			if (dbl) {
+				HIP_TRY (hipEventRecord (e->ev_copied[b], cs));
+				HIP_TRY (hipStreamWaitEvent (s, e->ev_copied[b], 0));
 			}
 		}
 		// an empty file never sets `start` (cli/phase-rotate.cc:573-576)
 		const uint32_t fl = (first && n && is_first ? PROT_F_STREAM_START : 0) | (last && is_last ? PROT_F_STREAM_END : 0);
 		if (n || (last && is_last)) {
-			rc = prot_sweep_dev (e, e->d_in.p, (int64_t)cap, n, ang_start, ang_end, ang_stride, chn, nullptr, fl, s);
+			rc = prot_sweep_dev (e, dn, (int64_t)cap, n, ang_start, ang_end, ang_stride, chn, nullptr, fl, s);
 			if (rc) {
 				return rc;
 			}
 		}
-		HIP_TRY (hipStreamSynchronize (s)); // staging buffers are reused by the next chunk
+		if (dbl) {
+			HIP_TRY (hipEventRecord (e->ev_free[b], s));
+			used[b] = true;
+		} else {
+			HIP_TRY (hipStreamSynchronize (s)); // one pair of staging buffers: reused by the next chunk
+		}
 		pos += n;
 		first = false;
+		++i;
 	} while (pos < nf);
+	if (dbl) {
+		HIP_TRY (hipStreamSynchronize (s));
+	}
 	return PROT_OK;
 }
 

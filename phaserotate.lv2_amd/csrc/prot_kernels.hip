@@ -530,6 +530,9 @@ struct T16 {
 #ifndef PROT_LEAN_PIN
 #define PROT_LEAN_PIN 0
 #endif
+#ifndef PROT_XCD_ROTATE
+#define PROT_XCD_ROTATE 1
+#endif
 #ifndef PROT_PREFETCH_EARLY
 #define PROT_PREFETCH_EARLY 1
 #endif
@@ -621,26 +624,26 @@ PROT_DEV void twiddle_store_lean (typename T::cplx (&v)[16], const PROT_LDS_PTR 
 		if (j < 3) {
 #pragma unroll
 			for (int i = 0; i < 4; ++i) {
-				q[(j + 1) & 1][i] = r[16 * (4 * (j + 1) + i)];
+				if (!(PROT_ABL2 & 8)) q[(j + 1) & 1][i] = r[16 * (4 * (j + 1) + i)];
 			}
 		}
 #if PROT_LEAN_PIN
 		__builtin_amdgcn_sched_barrier (0);
 #endif
 		if (j == 0) {
-			dst[0] = v[0];
-			v[1]   = O::template cmul<DIR> (v[1], q[0][1]);
-			dst[STRIDE] = v[1];
-			O::template cmul2<DIR> (v[2], q[0][2], v[3], q[0][3]);
-			dst[2 * STRIDE] = v[2];
-			dst[3 * STRIDE] = v[3];
+			if (!(PROT_ABL2 & 1)) dst[0] = v[0];
+			if (!(PROT_ABL2 & 8)) v[1] = O::template cmul<DIR> (v[1], q[0][1]);
+			if (!(PROT_ABL2 & 1)) dst[STRIDE] = v[1];
+			if (!(PROT_ABL2 & 8)) O::template cmul2<DIR> (v[2], q[0][2], v[3], q[0][3]);
+			if (!(PROT_ABL2 & 1)) dst[2 * STRIDE] = v[2];
+			if (!(PROT_ABL2 & 1)) dst[3 * STRIDE] = v[3];
 		} else {
 #pragma unroll
 			for (int i = 0; i < 4; i += 2) {
 				const int k = 4 * j + i;
-				O::template cmul2<DIR> (v[k], q[j & 1][i], v[k + 1], q[j & 1][i + 1]);
-				dst[k * STRIDE]       = v[k];
-				dst[(k + 1) * STRIDE] = v[k + 1];
+				if (!(PROT_ABL2 & 8)) O::template cmul2<DIR> (v[k], q[j & 1][i], v[k + 1], q[j & 1][i + 1]);
+				if (!(PROT_ABL2 & 1)) dst[k * STRIDE] = v[k];
+				if (!(PROT_ABL2 & 1)) dst[(k + 1) * STRIDE] = v[k + 1];
 			}
 		}
 	}
@@ -659,11 +662,11 @@ PROT_DEV void fwd4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 	if (LEAN) { // split outer twiddles: tw1[1..3] = W^{t i}, tw1[5..7] = W^{4 t i}
 		const C (&A)[4] = reinterpret_cast<const C (&)[4]> (tw1[0]);
 		const C (&B)[4] = reinterpret_cast<const C (&)[4]> (tw1[4]);
-		pkt_fft16_fwd_pruned_twout<O, NNZ> (v, A, B);
+		if (!(PROT_ABL2 & 4)) pkt_fft16_fwd_pruned_twout<O, NNZ> (v, A, B);
 		VC* w = (VC*)&lds[t];
 #pragma unroll
 		for (int k = 0; k < 16; ++k) {
-			w[k * kL1] = v[k];
+			if (!(PROT_ABL2 & 1)) w[k * kL1] = v[k];
 		}
 	} else {
 		if (!(PROT_ABL2 & 4)) pkt_fft16_fwd_pruned<O, NNZ> (v);
@@ -685,9 +688,9 @@ PROT_DEV void fwd4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 		const VC* rq = (const VC*)&twm[tl];
 #pragma unroll
 		for (int i = 1; i < 4; ++i) {
-			q0[i] = rq[16 * i];
+			if (!(PROT_ABL2 & 8)) q0[i] = rq[16 * i];
 		}
-		pkt_fft16<O, 1> (v);
+		if (!(PROT_ABL2 & 4)) pkt_fft16<O, 1> (v);
 		twiddle_store_lean<T, 1, 1> (v, rq, q0, (VC*)&lds[th * kL1 + tl * kG]);
 	} else {
 		C q[16];
@@ -732,9 +735,9 @@ PROT_DEV void inv4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 		const VC* rq = (const VC*)&twm[tl];
 #pragma unroll
 		for (int i = 1; i < 4; ++i) {
-			q0[i] = rq[16 * i];
+			if (!(PROT_ABL2 & 8)) q0[i] = rq[16 * i];
 		}
-		pkt_fft16<O, -1> (v);
+		if (!(PROT_ABL2 & 4)) pkt_fft16<O, -1> (v);
 		twiddle_store_lean<T, -1, kG> (v, rq, q0, (VC*)&lds[th * kL1 + tl]);
 	} else {
 		C q[16];
@@ -773,7 +776,7 @@ PROT_DEV void inv4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 	if (LEAN) {
 		const C (&A)[4] = reinterpret_cast<const C (&)[4]> (tw1[0]);
 		const C (&B)[4] = reinterpret_cast<const C (&)[4]> (tw1[4]);
-		pkt_fft16_inv_twin<O> (v, A, B);
+		if (!(PROT_ABL2 & 4)) pkt_fft16_inv_twin<O> (v, A, B);
 	} else {
 		if (!(PROT_ABL2 & 8)) {
 			v[1] = O::template cmul<-1> (v[1], tw1[1]);
@@ -1192,9 +1195,20 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 	// dispatched first runs ahead and the last one finishes alone, long after (ends at 196 / 281 / 347 us for equal
 	// runs at the headline).  Workgroups are dealt out in id order, one per CU per round, so id / CUs is the rank;
 	// if a dispatcher ever does it differently the lengths are merely not ideal -- the runs still tile the stream.
+	// Which run: not simply blockIdx.x.  Workgroups are dealt round-robin over the 8 XCDs, so XCD k would own the runs
+	// k, k + 8, ... -- with runs of about 1 MiB that is one fixed residue of the address modulo 8 MiB per XCD, and the
+	// XCDs then differ by up to 1.5x in how long the same work takes them (end times 276 ... 421 us by XCD, the same
+	// pairs fast and slow on every box: the launch lasts as long as the slowest).  Rotating the position inside each
+	// group of eight consecutive runs by the group's number gives every XCD all eight residues in turn.
+	int bx = (int)blockIdx.x;
+#if PROT_XCD_ROTATE
+	if ((bx | 7) < (int)gridDim.x) {
+		bx = (bx & ~7) | ((bx + (bx >> 3)) & 7);
+	}
+#endif
 	int64_t r0, rlen = p.run_frames;
 	if (p.rank_cu > 0) {
-		const int id = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, id0 = (int)blockIdx.y * (int)gridDim.x;
+		const int id = (int)blockIdx.y * (int)gridDim.x + bx, id0 = (int)blockIdx.y * (int)gridDim.x;
 		r0           = 0;
 #pragma unroll
 		for (int k = 0; k < 3; ++k) { // runs of rank k in front of this one, within the channel
@@ -1205,7 +1219,7 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 		const int rk = id / p.rank_cu;
 		rlen         = p.rank_frames[rk > 2 ? 2 : rk];
 	} else {
-		r0 = (int64_t)blockIdx.x * p.run_frames;
+		r0 = (int64_t)bx * p.run_frames;
 	}
 	if (r0 >= p.n_out) {
 		hist_write_slice (p, blockIdx.y, threadIdx.x);
@@ -1376,7 +1390,7 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 		}
 #endif
 		st.tick (0);
-		fwd4096w<T, HS, LEAN> (v, lds, twm, tw1, t, tl, th, [&] () { h_fetch (0); }, st, [&] () {
+		fwd4096w<T, HS, LEAN> (v, lds, twm, tw1, t, tl, th, [&] () { if (!(PROT_ABL2 & 16)) h_fetch (0); }, st, [&] () {
 #if PROT_PREFETCH_EARLY == 1
 			if (LEAN && it + 1 < n_it) { // the next block's frames go out right behind the first barrier: three quarters of an iteration ahead
 				load_block (s + BLK - Dc, t);
@@ -1386,7 +1400,7 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 
 		// Y = Z G0 (+ Z_prev G1); bins >= 2048 use the conjugate of the mirrored bin
 #pragma unroll
-		for (int j = 0; j < 16 / HB; ++j) {
+		for (int j = 0; j < ((PROT_ABL2 & 16) ? 0 : 16 / HB); ++j) {
 			if (j + 1 < 16 / HB) {
 				h_fetch (j + 1);
 			}

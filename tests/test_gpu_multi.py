@@ -123,3 +123,27 @@ def test_allreduce_keeps_its_communicators(tmp_path):
     assert c2 == [1, 0, 28, 28, 56, 0]   # the same device list (0, 0) again: still the same communicators
     assert c3 == [1, 0, 28, 28, 56, 0]   # kept while an engine lives
     assert c4 == [1, 2, 28, 28, 56, 0]   # both destroyed with the last engine
+
+
+def test_file_analysis_double_buffered_equals_resident_pass(pkg):
+    """prot_cli_analyze_file on a host buffer of several device chunks (upload and de-interleave of chunk k+1 under the
+    sweep of chunk k: two staging pairs, a copy stream) against ONE resident prot_sweep_dev pass: the same table, bit for bit."""
+    import torch
+    dev = torch.device("cuda:0")
+    P, n_chn = 2048, 2
+    n = (1 << 22) * 3 + 54321
+    rng = np.random.default_rng(7)
+    x = (rng.random((n, n_chn), dtype=np.float32) - 0.5) * 0.8
+    x[:, 0] += 0.3 * np.sin(np.arange(n) * 0.01).astype(np.float32)
+    g = pkg.PhaseRotate(P, n_chn)
+    g.analyze_file(x.reshape(-1), 0, 360, 8)
+    tab = g.peaks()
+    g.close()
+    e = pkg.Engine(pkg.KIND_CLI, P, n_chn)
+    xd = torch.from_numpy(np.ascontiguousarray(x.T)).to(dev)
+    pk = torch.zeros((n_chn, 360), device=dev)
+    torch.cuda.synchronize()
+    e.sweep_dev(xd.data_ptr(), n, n, 0, 360, 8, -1, pk.data_ptr(), pkg.F_STREAM_START | pkg.F_STREAM_END)
+    e.sync()
+    assert np.array_equal(tab, pk.cpu().numpy())
+    e.close()

@@ -103,11 +103,33 @@ __global__ __launch_bounds__(256, 2) void k(const float* __restrict__ in, float*
 int main(int argc, char** argv) {
   const long n = 1L << 27;
   float *in, *out;
-  hipMalloc(&in, n * 4); hipMalloc(&out, n * 4);
+  hipMalloc(&in, (n + (1 << 22)) * 4); hipMalloc(&out, (n + (1 << 22)) * 4);
   hipMemset(in, 0x3c, n * 4);
   typedef void (*kern_t)(const float*, float*, long, int);
   kern_t ks[4] = {k<0>, k<1>, k<2>, k<3>};
   for (int i = 0; i < 4; ++i) hipFuncSetAttribute((const void*)ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const bool scan = argc > 1;  // any argument: scan the run length (pure stream, 3 workgroups per CU) instead of the mode table
+  if (scan) {
+    const int wgs = 3, grid = 256 * wgs;
+    const unsigned lds = (160 * 1024 / wgs) & ~1023u;
+    for (int nb = 18; nb <= 34; ++nb) { if ((long)nb * BLK * grid > n) break;   // blocks of 20 KiB per run: 24..40 (the whole buffer is not covered: rate only)
+      const long run = (long)nb * BLK;
+      for (int mode = 0; mode < 4; mode += 3) {
+        float best = 1e9;
+        for (int rep = 0; rep < 4; ++rep) {
+          hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+          hipEventRecord(e0);
+          hipLaunchKernelGGL(ks[mode], dim3(grid), dim3(256), lds, 0, in, out, run, 0);
+          hipEventRecord(e1); hipEventSynchronize(e1);
+          float ms; hipEventElapsedTime(&ms, e0, e1);
+          if (rep > 0 && ms < best) best = ms;
+        }
+        printf("run %2d blocks = %8ld B (mod 1 MiB %7ld) mode %d: %.4f ms  %.2f TB/s\n", nb, run * 4, (run * 4) % (1 << 20), mode, best, 8.0 * run * grid / best * 1e-9);
+      }
+    }
+    printf("status %s\n", hipGetErrorString(hipDeviceSynchronize()));
+    return 0;
+  }
   const int fillers[3] = {0, 330, 660};
   for (int wgs = 1; wgs <= 4; ++wgs) {
     const unsigned lds = (160 * 1024 / wgs) & ~1023u;          // forces `wgs` workgroups per CU
