@@ -35,10 +35,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--preroll", type=int, default=30,
-                    help="untimed launches of the same step BEFORE the W warmup steps of every timed line: the first "
-                         "measurement in a fresh process otherwise runs ~15%% slow (clock ramp; see DESIGN.md section 5). "
-                         "0 = cold figures")
+    ap.add_argument("--preroll", type=int, default=200,
+                    help="untimed launches of the same step BEFORE the W warmup steps of every timed line: after any idle "
+                         "time the launch takes ~150 launches (~50 ms of GPU time) to come down from 0.36 to its steady "
+                         "0.28 ms (tools/drift_probe.py; DESIGN.md section 5) -- the clocks, not the kernel.  Disclosed in "
+                         "the JSON line as preroll_steps.  0 = cold figures")
     ap.add_argument("--frames-log2", type=int, default=27, help="frames per GPU per step (2^k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
@@ -199,8 +200,32 @@ def main():
             wall = float(t.item())
         return wall, kern_ms
 
+    def oracle_check(windows=4, W=16384):
+        """The timed launch's own output (y: the last step), windows of it against the CPU oracle's LV2 run() fed the frames
+        in front of each window (filter memory 3072 + the oracle's start-up ramp): a fast kernel with wrong results must
+        not print a number.  Rank 0 only; the checker, never the thing measured."""
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orc
+        rng = np.random.default_rng(123)
+        starts = [0, n - W] + [int(v) for v in rng.integers(1 << 16, n - (1 << 16), size=max(0, windows - 2))]
+        worst = 0.0
+        for t0 in starts:
+            lo = max(0, t0 - 16384)
+            xs = x[lo:t0 + W].cpu().numpy()[None, :]
+            o = orc.Lv2Engine(48000, 1)
+            o.activate()
+            yo = o.run_stream(xs, 90.0, 1024)[0]
+            skip = 2304 if lo == 0 else 0  # Q10: the instance ramps from 0 deg on its first blocks
+            got = y[t0 + skip:t0 + W].cpu().numpy()
+            worst = max(worst, float(np.abs(got - yo[t0 - lo + skip:]).max()))
+        res = {"windows": len(starts), "frames_per_window": W, "max_abs_diff": worst, "tolerance": 2e-6, "ok": worst < 2e-6}
+        if not res["ok"]:
+            raise SystemExit("bench: the headline launch's output differs from the oracle: %r" % res)
+        return res
+
     eng = pkg.Engine(pkg.KIND_LV2, 48000, 1, device=local_rank)
     wall, kern_ms = timed(eng, args.steps, args.warmup, n)
+    head_check = oracle_check() if rank == 0 else None
     value = world * n * args.steps / wall
     bytes_per_launch = 8.0 * n  # 4 B read + 4 B written per frame (SURVEY 8d)
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
@@ -231,6 +256,7 @@ def main():
                      "kernel": "prot::olapoly_kernel<prot::T32, 1, 10, 0, 3, false, 3> (one partition of the odd taps, 10 new sample rows per "
                                "block, steady rotation, dry path from registers, packed-fp32 butterflies, 3 workgroups per CU)", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": bytes_per_launch},
+        "oracle_check": head_check,
     }
     eng.close()
 
@@ -293,6 +319,8 @@ def main():
                        "value": world * n / (kmsH * 1e-3), "unit": "frames/s", "kernel_ms": kmsH,
                        "roofline_frac": 4.0 * n / (kmsH * 1e-3) / 1e9 / HBM_PEAK_GBS,
                        "max_abs_err_vs_fp32": float(errh.max()), "rms_err_vs_fp32": float(torch.sqrt(torch.mean(errh ** 2)))}
+        if out["fp16"]["max_abs_err_vs_fp32"] > 0.02:  # half samples of +-0.5 through the filter: 1-2e-3 is the format's noise
+            raise SystemExit("bench: the fp16 path's output is wrong: %r" % out["fp16"])
         del xh, yh, y32
         engH.close()
 

@@ -68,9 +68,11 @@ struct Stamps {
 	}
 	__device__ __forceinline__ void tick (int i)
 	{
+#if PROT_STAMPS == 1 // (2: the per-workgroup timeline only -- the per-phase stamps slow the kernel by a third)
 		const uint64_t now = __builtin_readcyclecounter ();
 		acc[i] += now - last;
 		last = now;
+#endif
 	}
 };
 #else
@@ -522,7 +524,8 @@ struct T16 {
 
 // PROT_ABL2 (timing experiments only, results are wrong): 1 no LDS exchange, 2 no workgroup barriers,
 // 4 no radix-16 butterflies, 8 no twiddle multiplies, 16 no spectrum multiply, 32 no stream loads,
-// 64 no stores
+// 64 no stores, 128 the stream does not advance (each run re-reads and re-writes its first block: the same instructions,
+// served by the caches instead of HBM)
 #ifndef PROT_ABL2
 #define PROT_ABL2 0
 #endif
@@ -535,6 +538,22 @@ struct T16 {
 #endif
 #ifndef PROT_PREFETCH_EARLY
 #define PROT_PREFETCH_EARLY 1
+#endif
+#ifndef PROT_TABLES_LATE
+#define PROT_TABLES_LATE 1
+#endif
+#ifndef PROT_T_MASK
+#define PROT_T_MASK 1
+#endif
+// 1: on the last iteration (nothing to prefetch) the carried registers are "defined" by an empty asm instead of keeping
+// their values, which saves 2 HS register copies in front of the prefetch branch -- NOT USED: together with the
+// wait-before-stores asm below, hipcc 7.2 turned copies of the carried registers into KILLs at the loop top (rows 10, 11
+// of the 12-row kernels read garbage; smoke() and the CLI tests caught it).  Kept as a switch for the record only.
+#ifndef PROT_PREFETCH_ELSE
+#define PROT_PREFETCH_ELSE 0
+#endif
+#ifndef PROT_WAIT_BEFORE_STORES
+#define PROT_WAIT_BEFORE_STORES 1
 #endif
 #ifndef PROT_PREFETCH_AT
 #define PROT_PREFETCH_AT 1
@@ -1216,8 +1235,22 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 			const int hi = (k == 2 || (k + 1) * p.rank_cu > id) ? id : (k + 1) * p.rank_cu;
 			r0 += hi > lo ? (int64_t)(hi - lo) * p.rank_frames[k] : 0;
 		}
-		const int rk = id / p.rank_cu;
-		rlen         = p.rank_frames[rk > 2 ? 2 : rk];
+		const int rk = id / p.rank_cu > 2 ? 2 : id / p.rank_cu;
+		rlen         = p.rank_frames[rk];
+		// the XCD term: position j of this run in its group of eight, run at position i belongs to XCD (i - g) mod 8 when the
+		// positions are rotated by the group number g (above), to XCD i otherwise
+		if ((p.rank_cu & 7) == 0 && (gridDim.x & 7) == 0) {
+			const int j   = bx & 7;
+			const int rot = PROT_XCD_ROTATE ? (bx >> 3) : 0;
+			int       pre = 0;
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				const int a = p.xcd_adj[rk][(i - rot) & 7];
+				pre += i < j ? a : 0;
+				rlen += i == j ? (int64_t)a * BLK : 0;
+			}
+			r0 += (int64_t)pre * BLK;
+		}
 	} else {
 		r0 = (int64_t)bx * p.run_frames;
 	}
@@ -1238,6 +1271,9 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 
 	const f2* __restrict__ twp = reinterpret_cast<const f2*> (p.tw);
 	C tw1[16];
+	// the tables of this workgroup (outer twiddles in registers, W256 and the filter spectrum in LDS): set up BEHIND the
+	// first block's stream loads (below), so that the two latencies of the prologue overlap
+	auto setup_tables = [&] () {
 	if (LEAN) { // split form (pkt_fft16_fwd_pruned_twout): [1..3] = W^{t i}, [5..7] = W^{4 t i}; the rest is never read
 #pragma unroll
 		for (int i = 1; i < 4; ++i) {
@@ -1259,6 +1295,10 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 			Hs[pp][j]   = O::mk (hv.x, hv.y);
 		}
 	}
+	};
+#if !PROT_TABLES_LATE
+	setup_tables ();
+#endif
 	float ca = 0.f, sa = 1.f;
 	if (MODE == MODE_ROT) {
 		ca = p.rot[2 * c];
@@ -1340,6 +1380,9 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 		}
 	};
 	load_block (s - Dc, t);
+#if PROT_TABLES_LATE
+	setup_tables ();
+#endif
 	__syncthreads ();
 	Stamps st;
 	st.start ();
@@ -1354,6 +1397,9 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 		// for the whole run; recomputed in place they fold into immediate offsets or stay inside their rare branch
 		int t = t0;
 		asm volatile ("" : "+v"(t));
+#if PROT_T_MASK
+		t &= 255; // known range again: stream addresses become SGPR base + 32-bit lane offset + immediate (no 64-bit lane arithmetic)
+#endif
 		const int tl = t & 15, th = t >> 4;
 		C  v[16];
 		f2 cur[HS];
@@ -1386,15 +1432,24 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 		};
 #if PROT_PREFETCH_EARLY == 2
 		if (LEAN && it + 1 < n_it) {
-			load_block (s + BLK - Dc, t);
+			load_block (((PROT_ABL2 & 128) ? r0 : s + BLK) - Dc, t);
 		}
 #endif
 		st.tick (0);
 		fwd4096w<T, HS, LEAN> (v, lds, twm, tw1, t, tl, th, [&] () { if (!(PROT_ABL2 & 16)) h_fetch (0); }, st, [&] () {
 #if PROT_PREFETCH_EARLY == 1
 			if (LEAN && it + 1 < n_it) { // the next block's frames go out right behind the first barrier: three quarters of an iteration ahead
-				load_block (s + BLK - Dc, t);
+				load_block (((PROT_ABL2 & 128) ? r0 : s + BLK) - Dc, t);
 			}
+#if PROT_PREFETCH_ELSE
+			else if (LEAN) { // nothing carried over from the block just consumed: no copies in front of the branch
+#pragma unroll
+				for (int k = 0; k < HS; ++k) {
+					asm volatile ("" : "=v"(nxqc[k].x), "=v"(nxqc[k].y)); // "some value": no instruction
+				}
+				asm volatile ("" : "=v"(nxg));
+			}
+#endif
 #endif
 		});
 
@@ -1433,8 +1488,19 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 
 		st.tick (5);
 		__builtin_amdgcn_sched_barrier (0);
-		if (it + 1 < n_it && !(LEAN && PROT_PREFETCH_EARLY)) {
-			load_block (s + BLK - Dc, t);
+		if (!(LEAN && PROT_PREFETCH_EARLY)) {
+			if (it + 1 < n_it) {
+				load_block (((PROT_ABL2 & 128) ? r0 : s + BLK) - Dc, t);
+			}
+#if PROT_PREFETCH_ELSE
+			else {
+#pragma unroll
+				for (int k = 0; k < HS; ++k) {
+					asm volatile ("" : "=v"(nxqc[k].x), "=v"(nxqc[k].y));
+				}
+				asm volatile ("" : "=v"(nxg));
+			}
+#endif
 		}
 		__builtin_amdgcn_sched_barrier (0);
 
@@ -1488,13 +1554,27 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 			acc[k] = to_f2 (v[HS + k]);
 		}
 
+#if PROT_WAIT_BEFORE_STORES
+		// The prefetched block (issued three quarters of an iteration ago: long here) is waited for IN FRONT of the stores.
+		// vmcnt retires in order, so a wait for those loads placed behind the stores -- where the next iteration first
+		// reads them -- is a wait for the stores too (s_waitcnt vmcnt(0) at the loop end: every iteration then ends with a
+		// full write round trip).  Waited for here, the stores drain under the next block's forward transform.
+		if (!ACC || (LEAN && PROT_PREFETCH_EARLY)) {
+#pragma unroll
+			for (int k = 0; k < HS; ++k) {
+				asm volatile ("" : "+v"(nxqc[k].x), "+v"(nxqc[k].y));
+			}
+			asm volatile ("" : "+v"(nxg));
+			__builtin_amdgcn_sched_barrier (0);
+		}
+#endif
 		if (it >= NP) {
 			const bool full = s + BLK <= r1;
 			if (MODE == MODE_ROT && !ACC && full && out_al8 && !(PROT_ABL2 & 64)) {
 				const f2 ca2 = mkf2 (ca, ca), sa2 = mkf2 (sa, sa);
 #pragma unroll
 				for (int m = 0; m < HS / 2; ++m) {
-					PROT_GLOBAL C* __restrict__ ob = reinterpret_cast<PROT_GLOBAL C*> (uniform_ptr (out + s + 1024 * m));
+					PROT_GLOBAL C* __restrict__ ob = reinterpret_cast<PROT_GLOBAL C*> (uniform_ptr (out + ((PROT_ABL2 & 128) ? r0 : s) + 1024 * m));
 #pragma unroll
 					for (int e = 0; e < 2; ++e) {
 						ob[(unsigned)t + 256u * e] = to_sp (ca2 * dry[2 * m + e] + sa2 * u[2 * m + e]);
@@ -1528,14 +1608,23 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 	}
 #ifdef PROT_STAMPS
 	if ((t & 63) == 0) {
+#if PROT_STAMPS == 1
 #pragma unroll
 		for (int i = 0; i < 11; ++i) {
 			atomicAdd (&g_stamps[i], (unsigned long long)st.acc[i]);
 		}
+#endif
+#if PROT_STAMPS == 1
 		atomicAdd (&g_stamps[16], (unsigned long long)n_it);
 		atomicAdd (&g_stamps[17], (unsigned long long)(__builtin_readcyclecounter () - st_c0));
 		atomicAdd (&g_stamps[18], (unsigned long long)(__builtin_amdgcn_s_memrealtime () - st_r0));
 		atomicAdd (&g_stamps[19], 1ull);
+#else // (12 000 atomics on one cache line are 100 us of launch time: the timeline build counts workgroups only)
+		if (t == 0) {
+			atomicAdd (&g_stamps[16], 4ull * (unsigned long long)n_it);
+			atomicAdd (&g_stamps[19], 4ull);
+		}
+#endif
 	}
 	if (t == 0 && blockIdx.x < 4096) {
 		g_wg_t[4 * blockIdx.x]     = st_entry;

@@ -52,7 +52,7 @@ wt = (C.c_ulonglong * (4 * nwg))()
 lib.prot_debug_wg_times.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 lib.prot_debug_wg_times(wt, nwg)
 w = np.array(list(wt), dtype=np.int64).reshape(nwg, 4)
-t0 = w[:, 0].min()
+t0 = w[:, 0][w[:, 0] > 0].min()
 ent, end, hw = (w[:, 0] - t0) / 100.0, (w[:, 2] - t0) / 100.0, w[:, 3]
 loop = ent + 7.5
 wg_clk = w[:, 1] / np.maximum(end - ent - 7.5, 1.0)  # MHz, roughly (loop cycles / loop wall time)
@@ -95,6 +95,14 @@ for xc in range(8):
 xcc_of = (hw >> 32) & 0xf
 print("  shader clock by xcc (MHz, median over workgroups):", {int(x): int(np.median(wg_clk[xcc_of == x])) for x in sorted(set(xcc_of))})
 print("  loop cycles by xcc (k, median):", {int(x): int(np.median(w[:, 1][xcc_of == x]) / 1000) for x in sorted(set(xcc_of))})
+bid = np.arange(nwg)
+live = w[:, 2] > 0
+print("  by blockIdx % 8 (= the XCD a workgroup is dealt to): xcc id, median end us by dispatch rank 0/1/2, max end")
+for x in range(8):
+    m = live & ((bid % 8) == x)
+    rk = np.minimum(bid // 256, 2)
+    print("   %d: xcc %s  end %s  max %.1f  loop kcycles %s" % (x, sorted(set(int(v_) for v_ in xcc_of[m])), [round(float(np.median(end[m & (rk == k_)])), 1) for k_ in range(3) if (m & (rk == k_)).any()],
+          end[m].max(), [int(np.median(w[:, 1][m & (rk == k_)]) / 1000) for k_ in range(3) if (m & (rk == k_)).any()]))
 order = np.argsort(end)
 print("  blockIdx of the 12 last workgroups to finish:", [int(i) for i in order[-12:]], "first:", [int(i) for i in order[:12]])
 print("  correlation(blockIdx, end) %.2f" % np.corrcoef(np.arange(nwg), end)[0, 1])

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """profiles/<tag>_* from the raw rocprofv3 output of tools/profile_round.sh:
-  <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `python3 bench.py --no-cpu-baseline`
+  <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `python3 bench.py --no-extra --no-sweep --no-cpu-baseline` (headline only)
+  <tag>_kernel_stats_full.csv  the same of the full default bench (`python3 bench.py --no-cpu-baseline`)
   <tag>_bench.json         the JSON line that run printed
   <tag>_pmc.json           FETCH_SIZE (x2 on gfx950, MI355X_MICROARCH.md section HBM) + WRITE_SIZE per launch of the headline kernel
   <tag>_pmc_sq.json        SQ counters per launch: headline kernel and sweep kernel
@@ -36,6 +37,24 @@ if st:
     shutil.copy(st[0], os.path.join(PROF, tag + "_kernel_stats.csv"))
     for line in open(st[0]).read().splitlines()[:8]:
         print(line[:220])
+# the timed region of that run = the LAST `steps` dispatches of the headline kernel (the pre-roll in front of them runs
+# slower: clock ramp); their mean is what bench.py's kernel_ms must agree with
+tr = glob.glob(os.path.join(out, "stats", "**", "*_kernel_trace.csv"), recursive=True)
+if tr:
+    rows = [r for r in csv.DictReader(open(tr[0])) if HEAD in r.get("Kernel_Name", "")]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6 for r in rows]
+    steps = 200
+    if len(d) >= steps:
+        last = d[-steps:]
+        info = {"kernel": HEAD, "dispatches": len(d), "mean_ms_all": sum(d) / len(d), "timed_region": "last %d dispatches" % steps,
+                "mean_ms_timed_region": sum(last) / steps, "min_ms": min(last), "max_ms": max(last),
+                "mean_ms_first_50": sum(d[:50]) / 50}
+        json.dump(info, open(os.path.join(PROF, tag + "_headline_trace.json"), "w"), indent=1)
+        print(json.dumps(info))
+sf = glob.glob(os.path.join(out, "stats_full", "**", "*_kernel_stats.csv"), recursive=True)
+if sf:
+    shutil.copy(sf[0], os.path.join(PROF, tag + "_kernel_stats_full.csv"))
 bj = os.path.join(out, "bench_stats.json")
 if os.path.exists(bj):
     lines = [l for l in open(bj).read().splitlines() if l.startswith("{")]
