@@ -1215,10 +1215,11 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 	// runs at the headline).  Workgroups are dealt out in id order, one per CU per round, so id / CUs is the rank;
 	// if a dispatcher ever does it differently the lengths are merely not ideal -- the runs still tile the stream.
 	// Which run: not simply blockIdx.x.  Workgroups are dealt round-robin over the 8 XCDs, so XCD k would own the runs
-	// k, k + 8, ... -- with runs of about 1 MiB that is one fixed residue of the address modulo 8 MiB per XCD, and the
-	// XCDs then differ by up to 1.5x in how long the same work takes them (end times 276 ... 421 us by XCD, the same
-	// pairs fast and slow on every box: the launch lasts as long as the slowest).  Rotating the position inside each
-	// group of eight consecutive runs by the group's number gives every XCD all eight residues in turn.
+	// k, k + 8, ... -- with runs of about 1 MiB that is one fixed residue of the address modulo 8 MiB per XCD.  Rotating
+	// the position inside each group of eight consecutive runs by the group's number gives every XCD all eight residues
+	// in turn: measured -2 % (interleaved A/B of the shipped kernel).  (The 1.5x spread between XCDs that an earlier
+	// version of this comment quoted came from a stamped diagnostic build whose end-of-kernel atomics queued on one
+	// cache line; the timeline-only build shows the XCDs within +-3 %, tools/xcd_timeline.py.)
 	int bx = (int)blockIdx.x;
 #if PROT_XCD_ROTATE
 	if ((bx | 7) < (int)gridDim.x) {
