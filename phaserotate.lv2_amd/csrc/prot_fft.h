@@ -387,6 +387,67 @@ PROT_DEV void pkt_fft16_fwd_pruned_twout (typename O::cplx (&v)[16], const typen
 	}
 }
 
+// The radix-16 in two halves, for callers that want the outputs of stage 2 one DFT-4 at a time: after DFT-4 number i
+// its four results are X[i], X[i + 4], X[i + 8], X[i + 12] in natural order (the un-permute of pkt_fft16_stage2 becomes
+// the sink's addressing).  `sink(std::integral_constant<int, i>, x0, x1, x2, x3)` multiplies / stores them while the
+// next DFT-4 computes -- the LDS traffic of an exchange then runs under the wave's own butterflies instead of behind them.
+template <class O, int DIR>
+PROT_DEV void pkt_fft16_stage1 (typename O::cplx (&v)[16])
+{
+	pkt_radix4<O, DIR> (v[0], v[4], v[8], v[12]);
+	pkt_radix4<O, DIR> (v[1], v[5], v[9], v[13]);
+	pkt_radix4<O, DIR> (v[2], v[6], v[10], v[14]);
+	pkt_radix4<O, DIR> (v[3], v[7], v[11], v[15]);
+	pkt_stage1_twiddles<O, DIR> (v);
+}
+template <int I> struct pkt_idx { static constexpr int value = I; };
+template <class O, int DIR, class S>
+PROT_DEV void pkt_fft16_stage2_each (typename O::cplx (&v)[16], S&& sink)
+{
+	pkt_radix4<O, DIR> (v[0], v[1], v[2], v[3]);
+	sink (pkt_idx<0>{}, v[0], v[1], v[2], v[3]);
+	pkt_radix4<O, DIR> (v[4], v[5], v[6], v[7]);
+	sink (pkt_idx<1>{}, v[4], v[5], v[6], v[7]);
+	pkt_radix4<O, DIR, true> (v[8], v[9], v[10], v[11]); // v[10] carries the pending W16^4 = -+j
+	sink (pkt_idx<2>{}, v[8], v[9], v[10], v[11]);
+	pkt_radix4<O, DIR> (v[12], v[13], v[14], v[15]);
+	sink (pkt_idx<3>{}, v[12], v[13], v[14], v[15]);
+}
+// first half of pkt_fft16_fwd_pruned_twout: pruned stage 1, its twiddles, A on the stage-2 inputs
+template <class O, int NNZ>
+PROT_DEV void pkt_fft16_fwd_pruned_twout_stage1 (typename O::cplx (&v)[16], const typename O::cplx (&A)[4])
+{
+	static_assert (NNZ == 4 || (NNZ >= 8 && NNZ <= 16 && NNZ % 2 == 0), "zero-padded rows come in pairs");
+#pragma unroll
+	for (int be = 0; be < 4; ++be) {
+		const int n = (NNZ - be + 3) / 4;
+		if (n == 1) {
+			v[4 + be] = v[8 + be] = v[12 + be] = v[be];
+		} else if (n == 2) {
+			const typename O::cplx a = v[be], b = v[4 + be];
+			v[be]      = a + b;
+			v[4 + be]  = O::add_mj (a, b);
+			v[8 + be]  = a - b;
+			v[12 + be] = O::sub_mj (a, b);
+		} else if (n == 3) {
+			const typename O::cplx a = v[be], b = v[4 + be], c = v[8 + be];
+			const typename O::cplx sm = a + c, df = a - c;
+			v[be]      = sm + b;
+			v[4 + be]  = O::add_mj (df, b);
+			v[8 + be]  = sm - b;
+			v[12 + be] = O::sub_mj (df, b);
+		} else {
+			pkt_radix4<O, 1> (v[be], v[4 + be], v[8 + be], v[12 + be]);
+		}
+	}
+	pkt_stage1_twiddles<O, 1> (v);
+#pragma unroll
+	for (int ka = 1; ka < 4; ++ka) {
+		O::template cmul2<1> (v[4 * ka], A[ka], v[4 * ka + 1], A[ka]);
+		O::template cmul2<1> (v[4 * ka + 2], A[ka], v[4 * ka + 3], A[ka]);
+	}
+}
+
 template <class O>
 PROT_DEV void pkt_fft16_inv_twin (typename O::cplx (&v)[16], const typename O::cplx (&A)[4], const typename O::cplx (&B)[4])
 {

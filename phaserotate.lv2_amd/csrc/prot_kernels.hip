@@ -542,6 +542,13 @@ struct T16 {
 #ifndef PROT_TABLES_LATE
 #define PROT_TABLES_LATE 1
 #endif
+// 1: the exchanges' LDS stores are issued per DFT-4 of the second butterfly stage (pkt_fft16_stage2_each), pinned with
+// scheduling barriers, so that they run under the wave's own remaining butterflies.  Measured (interleaved A/B, four
+// engines): no difference to the compiler's own order (all stores behind the butterflies) -- with three workgroups per
+// CU the other waves already fill those cycles.  Off; kept as the record of the experiment.
+#ifndef PROT_PIPE_STORES
+#define PROT_PIPE_STORES 0
+#endif
 #ifndef PROT_T_MASK
 #define PROT_T_MASK 1
 #endif
@@ -668,6 +675,43 @@ PROT_DEV void twiddle_store_lean (typename T::cplx (&v)[16], const PROT_LDS_PTR 
 	}
 }
 
+// radix-16 + W256 twiddles (table in LDS, `r` = &twm[tl]) + store to dst[k * STRIDE], the second stage one DFT-4 at a
+// time: the four results of DFT-4 number i (outputs i, i + 4, i + 8, i + 12) are multiplied and stored while the next one
+// computes; the table entries of group i + 1 are fetched ahead of group i's multiplies (two groups = 16 VGPRs in flight,
+// as twiddle_store_lean).  The 3-per-CU instantiations' form of pkt_fft16 + twiddle_store_lean.
+template <class T, int DIR, int STRIDE>
+PROT_DEV void fft16_twiddle_store_each (typename T::cplx (&v)[16], const PROT_LDS_PTR (T) * r, PROT_LDS_PTR (T) * dst)
+{
+	typedef typename T::ops  O;
+	typedef typename T::cplx C;
+	C q[2][4];
+#pragma unroll
+	for (int j = 1; j < 4; ++j) {
+		q[0][j] = r[16 * (4 * j)];
+	}
+	pkt_fft16_stage1<O, DIR> (v);
+	pkt_fft16_stage2_each<O, DIR> (v, [&] (auto ic, C& x0, C& x1, C& x2, C& x3) {
+		constexpr int i = decltype (ic)::value;
+		if (i < 3) {
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				q[(i + 1) & 1][j] = r[16 * (i + 1 + 4 * j)];
+			}
+		}
+		if (i == 0) {
+			x1 = O::template cmul<DIR> (x1, q[0][1]);
+		} else {
+			O::template cmul2<DIR> (x0, q[i & 1][0], x1, q[i & 1][1]);
+		}
+		O::template cmul2<DIR> (x2, q[i & 1][2], x3, q[i & 1][3]);
+		dst[i * STRIDE]        = x0;
+		dst[(i + 4) * STRIDE]  = x1;
+		dst[(i + 8) * STRIDE]  = x2;
+		dst[(i + 12) * STRIDE] = x3;
+		__builtin_amdgcn_sched_barrier (0);
+	});
+}
+
 // forward transform up to (not including) the last radix-16 pass; `before_last` runs between the
 // issue of the last exchange reads and that pass (the caller fetches its first table entries there)
 template <class T, int NNZ, bool LEAN, class F, class G>
@@ -681,12 +725,26 @@ PROT_DEV void fwd4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 	if (LEAN) { // split outer twiddles: tw1[1..3] = W^{t i}, tw1[5..7] = W^{4 t i}
 		const C (&A)[4] = reinterpret_cast<const C (&)[4]> (tw1[0]);
 		const C (&B)[4] = reinterpret_cast<const C (&)[4]> (tw1[4]);
-		if (!(PROT_ABL2 & 4)) pkt_fft16_fwd_pruned_twout<O, NNZ> (v, A, B);
 		VC* w = (VC*)&lds[t];
+#if PROT_PIPE_STORES && PROT_ABL2 == 0
+		pkt_fft16_fwd_pruned_twout_stage1<O, NNZ> (v, A);
+		pkt_fft16_stage2_each<O, 1> (v, [&] (auto ic, C& x0, C& x1, C& x2, C& x3) { // B on the outputs, stored as they come
+			constexpr int i = decltype (ic)::value;
+			O::template cmul2<1> (x1, B[1], x2, B[2]);
+			x3             = O::template cmul<1> (x3, B[3]);
+			w[i * kL1]        = x0;
+			w[(i + 4) * kL1]  = x1;
+			w[(i + 8) * kL1]  = x2;
+			w[(i + 12) * kL1] = x3;
+			__builtin_amdgcn_sched_barrier (0);
+		});
+#else
+		if (!(PROT_ABL2 & 4)) pkt_fft16_fwd_pruned_twout<O, NNZ> (v, A, B);
 #pragma unroll
 		for (int k = 0; k < 16; ++k) {
 			if (!(PROT_ABL2 & 1)) w[k * kL1] = v[k];
 		}
+#endif
 	} else {
 		if (!(PROT_ABL2 & 4)) pkt_fft16_fwd_pruned<O, NNZ> (v);
 		twiddle_store<T, 1, kL1> (v, tw1, (VC*)&lds[t]);
@@ -703,14 +761,18 @@ PROT_DEV void fwd4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 	}
 	after_barrier ();
 	if (LEAN) {
-		C q0[4];
 		const VC* rq = (const VC*)&twm[tl];
+#if PROT_PIPE_STORES && PROT_ABL2 == 0
+		fft16_twiddle_store_each<T, 1, 1> (v, rq, (VC*)&lds[th * kL1 + tl * kG]);
+#else
+		C q0[4];
 #pragma unroll
 		for (int i = 1; i < 4; ++i) {
 			if (!(PROT_ABL2 & 8)) q0[i] = rq[16 * i];
 		}
 		if (!(PROT_ABL2 & 4)) pkt_fft16<O, 1> (v);
 		twiddle_store_lean<T, 1, 1> (v, rq, q0, (VC*)&lds[th * kL1 + tl * kG]);
+#endif
 	} else {
 		C q[16];
 		twm_fetch<T> (q, twm, tl);
@@ -750,14 +812,18 @@ PROT_DEV void inv4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 	typedef PROT_LDS_PTR (T) VC;
 	typedef typename T::ops  O;
 	if (LEAN) {
-		C q0[4];
 		const VC* rq = (const VC*)&twm[tl];
+#if PROT_PIPE_STORES && PROT_ABL2 == 0
+		fft16_twiddle_store_each<T, -1, kG> (v, rq, (VC*)&lds[th * kL1 + tl]);
+#else
+		C q0[4];
 #pragma unroll
 		for (int i = 1; i < 4; ++i) {
 			if (!(PROT_ABL2 & 8)) q0[i] = rq[16 * i];
 		}
 		if (!(PROT_ABL2 & 4)) pkt_fft16<O, -1> (v);
 		twiddle_store_lean<T, -1, kG> (v, rq, q0, (VC*)&lds[th * kL1 + tl]);
+#endif
 	} else {
 		C q[16];
 		twm_fetch<T> (q, twm, tl); // W256^{k2 n1}: the table is symmetric, so lanes read neighbours here too
@@ -773,6 +839,21 @@ PROT_DEV void inv4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 			if (!(PROT_ABL2 & 1)) v[k] = r[k];
 		}
 	}
+#if PROT_PIPE_STORES && PROT_ABL2 == 0
+	if (LEAN) {
+		pkt_fft16_stage1<O, -1> (v);
+		wave_sync ();
+		VC* w = (VC*)&lds[th * kL1 + tl];
+		pkt_fft16_stage2_each<O, -1> (v, [&] (auto ic, C& x0, C& x1, C& x2, C& x3) {
+			constexpr int i = decltype (ic)::value;
+			w[16 * i]        = x0;
+			w[16 * (i + 4)]  = x1;
+			w[16 * (i + 8)]  = x2;
+			w[16 * (i + 12)] = x3;
+			__builtin_amdgcn_sched_barrier (0);
+		});
+	} else
+#endif
 	if (!(PROT_ABL2 & 4)) pkt_fft16<O, -1> (v);
 	{
 		// the group's chunk again, in the pass-1 layout: nobody else touches it before the barrier
@@ -780,7 +861,7 @@ PROT_DEV void inv4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 		VC* w = (VC*)&lds[th * kL1 + tl];
 #pragma unroll
 		for (int k = 0; k < 16; ++k) {
-			if (!(PROT_ABL2 & 1)) w[16 * k] = v[k];
+			if (!(PROT_ABL2 & 1) && !(PROT_PIPE_STORES && PROT_ABL2 == 0 && LEAN)) w[16 * k] = v[k];
 		}
 		st.tick (7);
 		if (!(PROT_ABL2 & 2)) __syncthreads ();
@@ -1655,8 +1736,8 @@ static hipError_t launch_poly_m (const OlaParamsT<typename T::samp>& p, dim3 gri
 	} else if (MODE != MODE_HILBERT && dd == DHS) {
 		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, DHS, false, WPS>), grid, block, dbg_dyn_lds (), s, p);
 	} else {
-		// (dry frames re-read from the stream: with 12 or 14 rows per block that form does not fit 168 VGPRs)
-		constexpr int WPS0 = (HS >= 12 && MODE != MODE_HILBERT) ? 2 : WPS;
+		// (dry frames re-read from the stream: with 10 or more rows per block that form does not fit 168 VGPRs)
+		constexpr int WPS0 = (HS >= 10 && MODE != MODE_HILBERT) ? 2 : WPS;
 		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, 0, false, WPS0>), grid, block, dbg_dyn_lds (), s, p);
 	}
 	return hipGetLastError ();
