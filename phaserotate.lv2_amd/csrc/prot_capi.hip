@@ -441,36 +441,6 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 				for (int k = 0; k < 3; ++k) {
 					p.rank_frames[k] = (int)(nb[k] * blk);
 				}
-				// per-XCD term, in per mille of the run length ("PROT_XCD_ADJ=a0,...,a7", by workgroup id % 8), made zero-sum per rank
-				double      xa[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-				const char* xe    = getenv ("PROT_XCD_ADJ");
-				if (xe && sscanf (xe, "%lf,%lf,%lf,%lf,%lf,%lf,%lf,%lf", &xa[0], &xa[1], &xa[2], &xa[3], &xa[4], &xa[5], &xa[6], &xa[7]) != 8) {
-					for (int x = 0; x < 8; ++x) {
-						xa[x] = 0;
-					}
-				}
-				if (cus % 8 == 0 && runs % 8 == 0) {
-					for (int k = 0; k < 3; ++k) {
-						int sum = 0;
-						for (int x = 0; x < 8; ++x) {
-							p.xcd_adj[k][x] = (int16_t)std::llround ((double)nb[k] * xa[x] * 1e-3);
-							sum += p.xcd_adj[k][x];
-						}
-						for (int x = 0; sum != 0; x = (x + 1) & 7) { // spread the rounding remainder
-							const int d = sum > 0 ? -1 : 1;
-							p.xcd_adj[k][x] = (int16_t)(p.xcd_adj[k][x] + d);
-							sum += d;
-						}
-						for (int x = 0; x < 8; ++x) { // a run keeps at least one block
-							if (nb[k] + p.xcd_adj[k][x] < 1) {
-								for (int y = 0; y < 8; ++y) {
-									p.xcd_adj[k][y] = 0;
-								}
-								break;
-							}
-						}
-					}
-				}
 			}
 		}
 		for (uint32_t l = 0; l < e->info.partitions / np; ++l) {

@@ -36,10 +36,6 @@ struct OlaParamsT {
 	// the first, second, third workgroup a CU receives); rank_cu = 0: every run is run_frames long
 	int32_t       rank_cu;
 	int32_t       rank_frames[3];
-	// ... and by XCD (workgroup id % 8: workgroups are dealt round-robin over the 8 XCDs, and the XCDs do not stream at the
-	// same rate): blocks added to / taken from a run of rank k on XCD x; every row sums to zero, so eight consecutive runs
-	// of a rank still cover 8 x rank_frames[k]
-	int16_t       xcd_adj[3][8];
 };
 typedef OlaParamsT<float>    OlaParams;
 typedef OlaParamsT<_Float16> OlaParamsH; // fp16 sample path (BASELINE config 5)

@@ -1319,20 +1319,6 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 		}
 		const int rk = id / p.rank_cu > 2 ? 2 : id / p.rank_cu;
 		rlen         = p.rank_frames[rk];
-		// the XCD term: position j of this run in its group of eight, run at position i belongs to XCD (i - g) mod 8 when the
-		// positions are rotated by the group number g (above), to XCD i otherwise
-		if ((p.rank_cu & 7) == 0 && (gridDim.x & 7) == 0) {
-			const int j   = bx & 7;
-			const int rot = PROT_XCD_ROTATE ? (bx >> 3) : 0;
-			int       pre = 0;
-#pragma unroll
-			for (int i = 0; i < 8; ++i) {
-				const int a = p.xcd_adj[rk][(i - rot) & 7];
-				pre += i < j ? a : 0;
-				rlen += i == j ? (int64_t)a * BLK : 0;
-			}
-			r0 += (int64_t)pre * BLK;
-		}
 	} else {
 		r0 = (int64_t)bx * p.run_frames;
 	}
