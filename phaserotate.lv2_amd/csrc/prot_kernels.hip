@@ -549,6 +549,12 @@ struct T16 {
 #ifndef PROT_PIPE_STORES
 #define PROT_PIPE_STORES 0
 #endif
+#ifndef PROT_NT_STORE
+#define PROT_NT_STORE 0
+#endif
+#ifndef PROT_NT_LOAD
+#define PROT_NT_LOAD 0
+#endif
 #ifndef PROT_T_MASK
 #define PROT_T_MASK 1
 #endif
@@ -1422,7 +1428,11 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 				const PROT_GLOBAL S* __restrict__ b = uniform_ptr (in + a0 + 1024 * m);
 #pragma unroll
 				for (int e = 0; e < 2; ++e) {
+#if PROT_NT_LOAD
+					nxqc[2 * m + e] = to_f2 (__builtin_nontemporal_load (&reinterpret_cast<const PROT_GLOBAL C*> (b)[(unsigned)t + 256u * e]));
+#else
 					nxqc[2 * m + e] = to_f2 (reinterpret_cast<const PROT_GLOBAL C*> (b)[(unsigned)t + 256u * e]);
+#endif
 				}
 			}
 			const PROT_GLOBAL S* __restrict__ b = uniform_ptr (in + a0 - 1);
@@ -1645,7 +1655,11 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 					PROT_GLOBAL C* __restrict__ ob = reinterpret_cast<PROT_GLOBAL C*> (uniform_ptr (out + ((PROT_ABL2 & 128) ? r0 : s) + 1024 * m));
 #pragma unroll
 					for (int e = 0; e < 2; ++e) {
+#if PROT_NT_STORE
+						__builtin_nontemporal_store (to_sp (ca2 * dry[2 * m + e] + sa2 * u[2 * m + e]), &ob[(unsigned)t + 256u * e]);
+#else
 						ob[(unsigned)t + 256u * e] = to_sp (ca2 * dry[2 * m + e] + sa2 * u[2 * m + e]);
+#endif
 					}
 				}
 			} else {
