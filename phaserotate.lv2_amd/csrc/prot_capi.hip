@@ -319,7 +319,7 @@ uint64_t file_chunk_frames (const prot_engine* e)
 	return std::max<uint64_t> (L, ((uint64_t)1 << 22) / L * L);
 }
 
-int pick_run_frames (const prot_engine* e, uint64_t n_out, int n_chn, int unit_frames = 0)
+int pick_run_frames (const prot_engine* e, uint64_t n_out, int n_chn, int unit_frames = 0, int slots_override = 0)
 {
 	// One workgroup per run.  Long streams: fill every resident-workgroup slot of the
 	// chip (CUs x 3, LDS-limited) a whole number of times so no partial last round is
@@ -331,7 +331,7 @@ int pick_run_frames (const prot_engine* e, uint64_t n_out, int n_chn, int unit_f
 	if (e->pairs_per_run_override > 0) {
 		ppr = e->pairs_per_run_override;
 	} else {
-		const int64_t slots = std::max (1, e->wg_slots);
+		const int64_t slots = std::max (1, slots_override > 0 ? slots_override : e->wg_slots);
 		for (int k = 1; k <= 64; ++k) {
 			const int64_t runs = std::max<int64_t> (1, slots * k / std::max (1, n_chn));
 			ppr                = (pairs + runs - 1) / runs;
@@ -347,6 +347,76 @@ int pick_run_frames (const prot_engine* e, uint64_t n_out, int n_chn, int unit_f
 int hist_advance (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_in, int chn0, int n_chn, hipStream_t s);
 int analyze_range (prot_engine* e, const float* data, uint64_t f0, uint64_t nf, bool is_first, bool is_last, int ang_start,
                    int ang_end, int ang_stride, int chn);
+
+// One-round launches of the polyphase kernel (every workgroup resident at once): run lengths by DISPATCH RANK, see
+// olapoly_kernel.  `slots` = resident workgroups (CUs x 3 for fp32 samples, CUs x 4 for fp16 samples).
+// measured (tools/ab_bench.py, PROT_RANK_W sweeps, headline / CLI 2048 / CLI 1024, ms per 2^27 frames, r2a kernel): equal
+// runs 0.315-0.326 / 0.270 / 0.248-0.257; 1.3:1:0.75 0.312-0.318 / 0.249-0.252 / 0.233; 1.45:0.95:0.6 0.291-0.302 /
+// 0.243-0.251 / 0.230-0.239; 1.6:0.9:0.5 0.291-0.293 / 0.258-0.265 / 0.247; 1.8:0.8:0.4 0.313-0.323 / 0.273-0.281 / 0.26
+template <class P>
+void rank_runs (P& p, int64_t blk, int n_chn, uint64_t n_out, int slots, bool half)
+{
+	int cus = 0, dev = 0;
+	if (hipGetDevice (&dev) != hipSuccess || hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0 ||
+	    slots % cus != 0) {
+		return;
+	}
+	const int R = slots / cus;
+	if (R != 3 && R != 4) {
+		return;
+	}
+	double      w[4] = { 1.45, 0.95, 0.6, 0.0 };
+	if (R == 4) {
+		w[0] = 1.4, w[1] = 1.1, w[2] = 0.9, w[3] = 0.6; // fp16 headline / CLI 2048, ms per 2^27 frames: equal runs 0.247 / 0.238; 1.5:1.1:0.8:0.6 0.230 / 0.228;
+		                                                 // 1.4:1.1:0.9:0.6 0.229 / 0.226; 1.6:1.1:0.8:0.5 0.227 / 0.235; 1.3:1.1:0.9:0.7 0.234 / 0.229 (PROT_RANK_W16)
+	}
+	const char* we = getenv (half ? "PROT_RANK_W16" : "PROT_RANK_W"); // tuning: "w0,w1,w2[,w3]" ("1,1,1": equal runs)
+	if (we) {
+		double v[4] = { 0, 0, 0, 0 };
+		if (sscanf (we, "%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3]) >= R) {
+			for (int k = 0; k < R; ++k) {
+				w[k] = v[k];
+			}
+		}
+	}
+	bool equal = true;
+	for (int k = 1; k < R; ++k) {
+		equal = equal && w[k] == w[0];
+	}
+	const int64_t runs = ((int64_t)n_out + p.run_frames - 1) / p.run_frames;
+	if (equal || runs * n_chn > slots || runs * n_chn <= (int64_t)(R - 1) * cus || p.run_frames / blk < 12) {
+		return;
+	}
+	const int64_t total = ((int64_t)n_out + blk - 1) / blk; // blocks per channel
+	double        wsum  = 0;
+	for (int k = 0; k < R; ++k) {
+		wsum += w[k];
+	}
+	int64_t nb[4] = { 0, 0, 0, 0 };
+	for (int k = 0; k < R; ++k) {
+		nb[k] = std::max<int64_t> (1, (int64_t)std::llround ((double)(p.run_frames / blk) * (double)R * w[k] / wsum));
+	}
+	// every channel must be covered: lengthen the last rank until the least-covered channel is
+	for (;;) {
+		int64_t worst = INT64_MAX;
+		for (int y = 0; y < n_chn; ++y) {
+			int64_t cov = 0;
+			for (int64_t x = 0; x < runs; ++x) {
+				cov += nb[std::min<int64_t> (R - 1, (y * runs + x) / cus)];
+			}
+			worst = std::min (worst, cov);
+		}
+		if (worst >= total) {
+			break;
+		}
+		++nb[R - 1];
+	}
+	p.rank_cu = cus;
+	p.n_rank  = R;
+	for (int k = 0; k < R; ++k) {
+		p.rank_frames[k] = (int)(nb[k] * blk);
+	}
+}
 
 // core of prot_apply_dev / the Hilbert pass of the sweep
 int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_in, float* d_out,
@@ -400,48 +470,8 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 	}
 	if (e->use_poly) {
 		const uint32_t np = std::min<uint32_t> (2, e->info.partitions); // partitions of g per launch
-		// one-round launches of the 3-per-CU kernels: run lengths by dispatch rank (olapoly_kernel)
-		{
-			const int64_t blk  = (int64_t)e->info.run_align;
-			const int64_t runs = ((int64_t)n_out + p.run_frames - 1) / p.run_frames;
-			const int     cus  = e->wg_slots / 3;
-			// measured (tools/ab_bench.py, PROT_RANK_W sweeps, headline / CLI 2048 / CLI 1024, ms per 2^27 frames): equal runs
-			// 0.315-0.326 / 0.270 / 0.248-0.257; 1.3:1:0.75 0.312-0.318 / 0.249-0.252 / 0.233; 1.45:0.95:0.6 0.291-0.302 /
-			// 0.243-0.251 / 0.230-0.239; 1.6:0.9:0.5 0.291-0.293 / 0.258-0.265 / 0.247; 1.8:0.8:0.4 0.313-0.323 / 0.273-0.281 / 0.26
-			double        w[3] = { 1.45, 0.95, 0.6 };
-			const char*   we   = getenv ("PROT_RANK_W"); // tuning: "w0,w1,w2" ("1,1,1": equal runs)
-			if (we && sscanf (we, "%lf,%lf,%lf", &w[0], &w[1], &w[2]) != 3) {
-				w[0] = 1.45, w[1] = 0.95, w[2] = 0.6;
-			}
-			if (np == 1 && e->wg_slots % 3 == 0 && cus > 0 && (w[0] != w[1] || w[1] != w[2]) &&
-			    runs * n_chn <= e->wg_slots && runs * n_chn > 2 * cus && p.run_frames / blk >= 12) {
-				const int64_t total = ((int64_t)n_out + blk - 1) / blk; // blocks per channel
-				const double  wsum  = w[0] + w[1] + w[2];
-				int64_t       nb[3];
-				for (int k = 0; k < 3; ++k) {
-					nb[k] = std::max<int64_t> (1, (int64_t)std::llround ((double)(p.run_frames / blk) * 3.0 * w[k] / wsum));
-				}
-				// every channel must be covered: lengthen the last rank until the least-covered channel is
-				for (;;) {
-					int64_t worst = INT64_MAX;
-					for (int y = 0; y < n_chn; ++y) {
-						int64_t cov = 0;
-						for (int64_t x = 0; x < runs; ++x) {
-							const int64_t rk = std::min<int64_t> (2, (y * runs + x) / cus);
-							cov += nb[rk];
-						}
-						worst = std::min (worst, cov);
-					}
-					if (worst >= total) {
-						break;
-					}
-					++nb[2];
-				}
-				p.rank_cu = cus;
-				for (int k = 0; k < 3; ++k) {
-					p.rank_frames[k] = (int)(nb[k] * blk);
-				}
-			}
+		if (np == 1) {
+			rank_runs (p, (int64_t)e->info.run_align, n_chn, n_out, e->wg_slots, false);
 		}
 		for (uint32_t l = 0; l < e->info.partitions / np; ++l) {
 			p.H          = e->d_H.p + (size_t)(np * l) * e->info.fftlen;
@@ -1086,7 +1116,10 @@ static int apply_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint6
 	p.tw         = e->d_tw.p;
 	p.rot        = e->d_rot.p;
 	p.rot_s      = d_rot_s;
-	p.run_frames = pick_run_frames (e, n_out, nc); // the engine's own transform block: the fp16 kernels share its form
+	// fp16 samples, one partition: 104-128 VGPRs and 26 KiB of LDS per workgroup -- FOUR per CU (measured 0.269 -> 0.252 ms
+	// at the headline shape with equal runs; the fp32 kernel cannot: 158 VGPRs, 53 KiB)
+	const int slots16 = (f16_poly && e->info.partitions == 1 && e->wg_slots % 3 == 0 && !getenv ("PROT_WG_PER_CU")) ? e->wg_slots / 3 * 4 : e->wg_slots;
+	p.run_frames = pick_run_frames (e, n_out, nc, 0, slots16); // the engine's own transform block: the fp16 kernels share its form
 	p.conv_delay = (int)e->info.conv_delay;
 	p.dry_delay  = (int)e->info.dry_delay;
 	p.hist_len   = (int)e->info.history;
@@ -1094,6 +1127,9 @@ static int apply_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint6
 	if (!stateless) {
 		p.hist     = (const _Float16*)e->d_hist16[e->hist16_cur].p;
 		p.hist_out = carry ? (_Float16*)e->d_hist16[1 - e->hist16_cur].p : nullptr;
+	}
+	if (f16_poly && e->info.partitions == 1) {
+		rank_runs (p, (int64_t)e->info.run_align, nc, n_out, slots16, true);
 	}
 	hipError_t err = f16_poly ? prot::launch_ola_poly_f16 (p, (int)e->info.partitions, e->hopseg / 2, nc, s)
 	               : f16_p2   ? prot::launch_ola4096_p2_f16 (p, nc, s)

@@ -32,10 +32,11 @@ struct OlaParamsT {
 	int32_t       dry_delay;  // Dd
 	int32_t       hilbert_only;
 	int32_t       accumulate; // add sa*u to out instead of storing ca*dry + sa*u (FIR partitions > 0)
-	// polyphase kernel, one-round launches: runs of unequal length by dispatch rank (workgroup id / rank_cu = 0, 1, 2:
-	// the first, second, third workgroup a CU receives); rank_cu = 0: every run is run_frames long
+	// polyphase kernel, one-round launches: runs of unequal length by dispatch rank (workgroup id / rank_cu = 0, 1, 2 (, 3):
+	// the first, second, third (, fourth) workgroup a CU receives); rank_cu = 0: every run is run_frames long
 	int32_t       rank_cu;
-	int32_t       rank_frames[3];
+	int32_t       n_rank;     // 3 (fp32: 3 workgroups per CU) or 4 (fp16 samples)
+	int32_t       rank_frames[4];
 };
 typedef OlaParamsT<float>    OlaParams;
 typedef OlaParamsT<_Float16> OlaParamsH; // fp16 sample path (BASELINE config 5)

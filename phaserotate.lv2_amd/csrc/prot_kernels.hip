@@ -1317,13 +1317,14 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 	if (p.rank_cu > 0) {
 		const int id = (int)blockIdx.y * (int)gridDim.x + bx, id0 = (int)blockIdx.y * (int)gridDim.x;
 		r0           = 0;
+		const int last = p.n_rank - 1;
 #pragma unroll
-		for (int k = 0; k < 3; ++k) { // runs of rank k in front of this one, within the channel
+		for (int k = 0; k < 4; ++k) { // runs of rank k in front of this one, within the channel
 			const int lo = k * p.rank_cu > id0 ? k * p.rank_cu : id0;
-			const int hi = (k == 2 || (k + 1) * p.rank_cu > id) ? id : (k + 1) * p.rank_cu;
-			r0 += hi > lo ? (int64_t)(hi - lo) * p.rank_frames[k] : 0;
+			const int hi = (k >= last || (k + 1) * p.rank_cu > id) ? id : (k + 1) * p.rank_cu;
+			r0 += (k <= last && hi > lo) ? (int64_t)(hi - lo) * p.rank_frames[k] : 0;
 		}
-		const int rk = id / p.rank_cu > 2 ? 2 : id / p.rank_cu;
+		const int rk = id / p.rank_cu > last ? last : id / p.rank_cu;
 		rlen         = p.rank_frames[rk];
 	} else {
 		r0 = (int64_t)bx * p.run_frames;
