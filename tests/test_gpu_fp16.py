@@ -159,3 +159,33 @@ def test_fp16_long_fir_is_refused(pkg):
     with pytest.raises(pkg.ProtError):
         e.apply_dev_f16(x.data_ptr(), 65536, 65536, y.data_ptr(), 65536, 65536, np.array([1, 0], np.float32))
     e.close()
+
+
+@pytest.mark.parametrize("kind,param,chn", [("lv2", 48000, 1), ("cli", 2048, 1), ("lv2", 48000, 2)])
+def test_fp16_full_size_every_frame(pkg, kind, param, chn, capsys):
+    """The size at which the fp16 path runs FOUR workgroups per CU with run lengths by dispatch rank (2^27 frames in all;
+    smaller launches take equal runs): every output frame against the fp32 kernel on the same rounded input -- a run
+    that started or ended in the wrong place would be off by the signal's own amplitude, not by half-precision noise.
+    (The fp32 kernel at this size is itself checked against the float64 model and the oracle: test_gpu_parity.py,
+    bench.py's oracle_check.)"""
+    import torch
+    dev = torch.device("cuda:0")
+    n = (1 << 27) // chn
+    e = pkg.Engine(pkg.KIND_LV2 if kind == "lv2" else pkg.KIND_CLI, param, chn)
+    g = torch.Generator(device=dev).manual_seed(77)
+    x16 = ((torch.rand(chn * n, generator=g, device=dev) - 0.5) * 0.9).half()
+    x32 = x16.float()
+    y16 = torch.empty_like(x16)
+    y32 = torch.empty_like(x32)
+    rot = np.array([0.6, -0.8] * chn, np.float32)
+    torch.cuda.synchronize()
+    e.apply_dev_f16(x16.data_ptr(), n, n, y16.data_ptr(), n, n, rot)
+    e.apply_dev(x32.data_ptr(), n, n, y32.data_ptr(), n, n, rot, pkg.F_STATELESS)
+    e.sync()
+    d = (y16.float() - y32).abs()
+    mx, at = float(d.max()), int(d.argmax())
+    rms = float(torch.sqrt(torch.mean(d.double() ** 2)))
+    with capsys.disabled():
+        print("\n[fp16 full size] %s %d x%d, %d frames per channel: max |fp16 - fp32| %.3e at frame %d, rms %.3e" % (kind, param, chn, n, mx, at, rms))
+    assert mx < MAX_ABS and rms < RMS
+    e.close()
