@@ -1,3 +1,5 @@
+# the round's evidence on one GPU box: all -m gpu tests, smoke(), the default bench line, the rocprofv3 passes (tools/profile_round.sh r02b);
+# summaries land in gpurun_out/profiles_r02b/ (copy into profiles/), the bench line in gpurun_out/bench/bench.json
 mkdir -p gpurun_out/chk
 timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/chk/pytest.txt 2>&1; tail -3 gpurun_out/chk/pytest.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/chk/smoke.txt 2>&1; tail -2 gpurun_out/chk/smoke.txt
