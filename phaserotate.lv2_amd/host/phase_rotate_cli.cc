@@ -20,7 +20,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <getopt.h>
+#include <memory>
 #include <limits>
 #include <map>
 #include <string>
@@ -228,7 +230,7 @@ struct Result {
 // the minimum search of cli/phase-rotate.cc:784-929 on the whole file
 // analysis pass over the whole file: one engine, or PROT_GPUS engines each sweeping a range of
 // frame blocks followed by a MAX all-reduce of their peak tables
-void analysis_pass (const std::vector<prot_engine*>& gpus, const std::vector<float>& file, uint64_t n_frames,
+void analysis_pass (const std::vector<prot_engine*>& gpus, const wavio::Samples& file, uint64_t n_frames,
                     int a0, int a1, int step, int chn)
 {
 	if (gpus.size () == 1) {
@@ -239,7 +241,7 @@ void analysis_pass (const std::vector<prot_engine*>& gpus, const std::vector<flo
 	}
 }
 
-Result find_minimum (const std::vector<prot_engine*>& gpus, const std::vector<float>& file, uint64_t n_frames, int n_chn,
+Result find_minimum (const std::vector<prot_engine*>& gpus, const wavio::Samples& file, uint64_t n_frames, int n_chn,
                      const Options& opt, FILE* vfd)
 {
 	prot_engine* pr = gpus[0]; // after a pass every engine holds the merged table
@@ -374,9 +376,20 @@ void print_result (const Result& r, int n_chn, FILE* fd) // :931-947
 int main (int argc, char** argv)
 {
 	Options opt = parse_args (argc, argv);
+	// PROT_CLI_TIMING=1: wall time of each phase on stderr (not something the reference prints)
+	const bool timing = getenv ("PROT_CLI_TIMING") != nullptr;
+	auto       now    = [] () { return std::chrono::steady_clock::now (); };
+	auto       t_prev = now ();
+	auto       lap    = [&] (const char* what) {
+		if (timing) {
+			const auto t = now ();
+			fprintf (stderr, "[timing] %-28s %9.2f ms\n", what, std::chrono::duration<double, std::milli> (t - t_prev).count ());
+			t_prev = t;
+		}
+	};
 
 	wavio::Info        nfo;
-	std::vector<float> file;
+	wavio::Samples     file;
 	{
 		const std::string err = wavio::read_file (opt.in_path, nfo, file);
 		if (!err.empty ()) {
@@ -386,6 +399,7 @@ int main (int argc, char** argv)
 	}
 	const int      n_chn    = nfo.channels;
 	const uint64_t n_frames = nfo.frames;
+	lap ("read + decode input");
 
 	wavio::Writer outfile;
 	if (opt.out_path) {
@@ -442,6 +456,7 @@ int main (int argc, char** argv)
 		gpus.push_back (e);
 	}
 	prot_engine* pr = gpus[0];
+	lap ("create engine(s)");
 
 	if (analyse) {
 		if (opt.verbose > 1) {
@@ -452,18 +467,22 @@ int main (int argc, char** argv)
 		if (!opt.out_path || opt.verbose) {
 			print_result (res, n_chn, vfd);
 		}
+		lap ("analyse (find minimum)");
 	}
 
 	if (opt.out_path) { // apply and write (:950-1003): latency removed, tail flushed
 		if (analyse) {
 			gpu_call (prot_engine_reset (pr), "reset");
 		}
-		std::vector<float> out ((size_t)n_frames * n_chn);
-		gpu_call (prot_cli_apply_file (pr, file.data (), n_frames, angles.data (), out.data ()), "apply");
-		if (n_frames != outfile.writef (out.data (), n_frames)) {
+		std::unique_ptr<float[]> out (new float[(size_t)n_frames * n_chn]); // not zero-filled: every frame is written by the apply
+		lap ("allocate output");
+		gpu_call (prot_cli_apply_file (pr, file.data (), n_frames, angles.data (), out.get ()), "apply");
+		lap ("apply (rotate)");
+		if (n_frames != outfile.writef (out.get (), n_frames)) {
 			fprintf (stderr, "Error writing to output file.\n");
 		}
 		outfile.close ();
+		lap ("encode + write output");
 	}
 
 	for (prot_engine* g : gpus) {

@@ -17,10 +17,26 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <fcntl.h>
+#include <memory>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace wavio {
+
+// sample storage that is NOT zero-filled on resize (every element is written by the decoder; zero-filling 100 M floats
+// costs as much as decoding them)
+template <class T>
+struct no_init_alloc : std::allocator<T> {
+	template <class U> struct rebind { typedef no_init_alloc<U> other; };
+	template <class U> void construct (U* p) { ::new ((void*)p) U; }
+	template <class U, class A0, class... A> void construct (U* p, A0&& a0, A&&... a) { ::new ((void*)p) U (std::forward<A0> (a0), std::forward<A> (a)...); }
+};
+typedef std::vector<float, no_init_alloc<float>> Samples;
 
 struct Chunk {
 	char                 id[4];
@@ -39,8 +55,57 @@ struct Info {
 inline uint32_t rd32 (const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
 inline uint16_t rd16 (const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 
+// Sample conversion is the CLI's largest host cost on long files (a 10-minute stereo 96 kHz file is 115 M samples): the
+// chunks below are converted by `workers()` threads, each its own contiguous slice -- per-sample arithmetic unchanged.
+inline unsigned workers (uint64_t n_samples)
+{
+	const unsigned hw = std::thread::hardware_concurrency ();
+	const unsigned w  = std::min<unsigned> (hw ? hw : 1, 16);
+	return n_samples < (1u << 18) ? 1 : w;
+}
+template <class F>
+inline void parallel_slices (uint64_t n, F&& f) // f (begin, end)
+{
+	const unsigned w = workers (n);
+	if (w <= 1) {
+		f ((uint64_t)0, n);
+		return;
+	}
+	std::vector<std::thread> th;
+	for (unsigned i = 0; i < w; ++i) {
+		const uint64_t b = n * i / w, e = n * (i + 1) / w;
+		th.emplace_back ([&f, b, e] () { f (b, e); });
+	}
+	for (std::thread& t : th) {
+		t.join ();
+	}
+}
+
+// one sample of the data chunk -> float (libsndfile's defaults: integer PCM by 1 / 2^(bits-1))
+inline float decode_sample (const uint8_t* p, bool is_float, uint32_t bps)
+{
+	if (is_float) {
+		if (bps == 4) {
+			float v;
+			memcpy (&v, p, 4);
+			return v;
+		}
+		double d;
+		memcpy (&d, p, 8);
+		return (float)d;
+	}
+	if (bps == 2) {
+		return (float)(int16_t)rd16 (p) / 32768.f;
+	}
+	if (bps == 3) {
+		const int32_t s = (int32_t)((uint32_t)p[0] << 8 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 24);
+		return (float)s / 2147483648.f;
+	}
+	return (float)(int32_t)rd32 (p) / 2147483648.f;
+}
+
 // Reads the whole file as interleaved float32.  Returns "" on success, else an error text.
-inline std::string read_file (const char* path, Info& nfo, std::vector<float>& data)
+inline std::string read_file (const char* path, Info& nfo, Samples& data)
 {
 	FILE* f = fopen (path, "rb");
 	if (!f) {
@@ -97,7 +162,31 @@ inline std::string read_file (const char* path, Info& nfo, std::vector<float>& d
 			nfo.frames     = bytes / ((uint64_t)bps * nfo.channels);
 			const uint64_t n = nfo.frames * nfo.channels;
 			data.resize (n);
-			std::vector<uint8_t> raw ((size_t)1 << 20);
+			const bool is_float = nfo.is_float;
+			// the whole data chunk mapped and decoded in place by all workers (no copy through a staging buffer) ...
+			{
+				const int fd = open (path, O_RDONLY);
+				void*     mp = fd >= 0 ? mmap (nullptr, (size_t)end, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+				if (fd >= 0) {
+					close (fd);
+				}
+				if (mp != MAP_FAILED) {
+					float* const         dst = data.data ();
+					const uint8_t* const src = (const uint8_t*)mp + here;
+					parallel_slices (n, [=] (uint64_t b, uint64_t e) {
+						const uint8_t* p = src + b * bps;
+						for (uint64_t i = b; i < e; ++i, p += bps) {
+							dst[i] = decode_sample (p, is_float, bps);
+						}
+					});
+					munmap (mp, (size_t)end);
+					fseek (f, here + (long)(n * bps), SEEK_SET);
+					goto decoded;
+				}
+			}
+			// ... or, where the file cannot be mapped, read 48 MiB at a time
+			{
+			std::vector<uint8_t> raw ((size_t)48 << 20); // (a multiple of every sample size)
 			uint64_t done = 0;
 			while (done < n) {
 				const uint64_t want = std::min<uint64_t> ((raw.size () / bps), n - done);
@@ -105,29 +194,18 @@ inline std::string read_file (const char* path, Info& nfo, std::vector<float>& d
 					fclose (f);
 					return "Unexpected end of file.";
 				}
-				const uint8_t* p = raw.data ();
-				for (uint64_t i = 0; i < want; ++i, p += bps) {
-					float v;
-					if (nfo.is_float) {
-						if (bps == 4) {
-							memcpy (&v, p, 4);
-						} else {
-							double d;
-							memcpy (&d, p, 8);
-							v = (float)d;
-						}
-					} else if (bps == 2) {
-						v = (float)(int16_t)rd16 (p) / 32768.f;
-					} else if (bps == 3) {
-						int32_t s = (int32_t)((uint32_t)p[0] << 8 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 24);
-						v         = (float)s / 2147483648.f;
-					} else {
-						v = (float)(int32_t)rd32 (p) / 2147483648.f;
+				float* const         dst = data.data () + done;
+				const uint8_t* const src = raw.data ();
+				parallel_slices (want, [=] (uint64_t b, uint64_t e) {
+					const uint8_t* p = src + b * bps;
+					for (uint64_t i = b; i < e; ++i, p += bps) {
+						dst[i] = decode_sample (p, is_float, bps);
 					}
-					data[done + i] = v;
-				}
+				});
 				done += want;
 			}
+			}
+decoded:
 			// chunks behind the samples (where many writers put LIST / cue / bext)
 			if (sz != 0xFFFFFFFFu && sz <= avail) {
 				fseek (f, here + (long)sz + (long)(sz & 1), SEEK_SET);
@@ -195,32 +273,46 @@ public:
 	// returns frames written
 	uint64_t writef (const float* buf, uint64_t frames)
 	{
-		const uint32_t bps = _nfo.bits / 8;
-		const uint64_t n   = frames * _nfo.channels;
-		std::vector<uint8_t> raw (n * bps);
-		uint8_t* p = raw.data ();
-		for (uint64_t i = 0; i < n; ++i, p += bps) {
-			const float v = buf[i];
-			if (_nfo.is_float) {
-				if (bps == 4) {
-					memcpy (p, &v, 4);
-				} else {
-					const double d = v;
-					memcpy (p, &d, 8);
+		const uint32_t bps      = _nfo.bits / 8;
+		const uint32_t chn      = _nfo.channels;
+		const bool     is_float = _nfo.is_float;
+		const uint64_t step     = std::max<uint64_t> (1, ((uint64_t)48 << 20) / ((uint64_t)bps * chn)); // frames per 48 MiB of output
+		std::vector<uint8_t> raw ((size_t)std::min<uint64_t> (frames, step) * bps * chn);
+		uint64_t done = 0;
+		while (done < frames) {
+			const uint64_t nf = std::min<uint64_t> (step, frames - done), n = nf * chn;
+			const float* const src = buf + done * chn;
+			uint8_t* const     dst = raw.data ();
+			parallel_slices (n, [=] (uint64_t b0, uint64_t e0) {
+				uint8_t* p = dst + b0 * bps;
+				for (uint64_t i = b0; i < e0; ++i, p += bps) {
+					const float v = src[i];
+					if (is_float) {
+						if (bps == 4) {
+							memcpy (p, &v, 4);
+						} else {
+							const double d = v;
+							memcpy (p, &d, 8);
+						}
+					} else {
+						double  scale = bps == 2 ? 32767.0 : (bps == 3 ? 8388607.0 : 2147483647.0);
+						double  s     = std::nearbyint ((double)v * scale);
+						s             = std::min (std::max (s, -scale - 1.0), scale);
+						int32_t q     = (int32_t)s;
+						for (uint32_t b = 0; b < bps; ++b) {
+							p[b] = (uint8_t)((uint32_t)q >> (8 * b));
+						}
+					}
 				}
-			} else {
-				double  scale = bps == 2 ? 32767.0 : (bps == 3 ? 8388607.0 : 2147483647.0);
-				double  s     = std::nearbyint ((double)v * scale);
-				s             = std::min (std::max (s, -scale - 1.0), scale);
-				int32_t q     = (int32_t)s;
-				for (uint32_t b = 0; b < bps; ++b) {
-					p[b] = (uint8_t)((uint32_t)q >> (8 * b));
-				}
+			});
+			const uint64_t w = fwrite (raw.data (), (size_t)bps * chn, nf, _f);
+			_frames += w;
+			done += w;
+			if (w != nf) {
+				break;
 			}
 		}
-		const uint64_t w = fwrite (raw.data (), (size_t)bps * _nfo.channels, frames, _f);
-		_frames += w;
-		return w;
+		return done;
 	}
 
 	void close ()
