@@ -10,6 +10,8 @@
 // "LIST" (INFO strings), "cue " and "bext" chunks are carried over verbatim, in front of the samples.
 // What libsndfile offers beyond that -- other containers (AIFF, FLAC, W64, ...), RF64, other sample encodings --
 // is refused with an error text, never guessed.
+// The whole file is decoded at once (the device passes work on whole files): straight from a read-only mapping, by up
+// to 16 threads; the writer encodes 48 MiB at a time the same way.  Per-sample arithmetic is that of the scalar loop.
 #pragma once
 #include <algorithm>
 #include <cerrno>
