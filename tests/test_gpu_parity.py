@@ -808,3 +808,34 @@ def test_cfg3_shape_against_oracle(pkg):
     s0 = 2560 + 2 * 1024  # Q10: run() ramps from 0 deg on its first blocks; the device call starts steady
     assert np.abs(yg[:, s0:] - yo[:, s0:]).max() < TOL
     e.close()
+
+
+@pytest.mark.parametrize("kind,param,chn,n", [(1, 48000, 1, 50_000_017), (1, 48000, 2, 33_333_333), (0, 2048, 1, (1 << 27) - 3),
+                                              (0, 1024, 2, 40_000_001)])
+def test_rank_weighted_runs_ragged_sizes(pkg, kind, param, chn, n):
+    """One-round launches cut the stream into runs of unequal length by dispatch rank (olapoly_kernel, rank_runs in the C
+    ABI); sizes that are no multiple of anything, odd-offset channel rows, one and two channels: the one-shot stateless
+    result against the same stream pushed through in stateful chunks (whose launches are small enough for equal runs)."""
+    import torch
+    dev = torch.device("cuda:0")
+    e = pkg.Engine(kind, param, chn)
+    stride = n + 5  # rows start at odd offsets
+    g = torch.Generator(device=dev).manual_seed(1234)
+    xb = torch.rand(chn * stride + 1, generator=g, device=dev) - 0.5
+    x = xb[1:]
+    rot = np.array([0.28, -0.96, -0.6, 0.8][:2 * chn], np.float32)
+    y1 = torch.zeros(chn * stride + 1, device=dev)[1:]
+    y2 = torch.zeros(chn * stride + 1, device=dev)[1:]
+    torch.cuda.synchronize()
+    e.apply_dev(x.data_ptr(), stride, n, y1.data_ptr(), stride, n, rot, pkg.F_STATELESS)
+    pos, k = 0, 0
+    while pos < n:
+        m = min(n - pos, 1_100_003 + 7919 * (k % 5))
+        e.apply_dev(x.data_ptr() + 4 * pos, stride, m, y2.data_ptr() + 4 * pos, stride, m, rot, 0)
+        pos += m
+        k += 1
+    e.sync()
+    for c in range(chn):
+        d = (y1[c * stride:c * stride + n] - y2[c * stride:c * stride + n]).abs()
+        assert d.max().item() < TOL, (c, int(d.argmax()))
+    e.close()
