@@ -555,6 +555,9 @@ struct T16 {
 #ifndef PROT_NT_LOAD
 #define PROT_NT_LOAD 0
 #endif
+#ifndef PROT_PROBE4
+#define PROT_PROBE4 0
+#endif
 #ifndef PROT_T_MASK
 #define PROT_T_MASK 1
 #endif
@@ -1289,7 +1292,11 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 
 	__shared__ C lds[kLdsRegion];
 	__shared__ C twm[256];
+#if PROT_PROBE4 // timing probe only (wrong results): the spectrum table shrunk so that four workgroups fit a CU
+	__shared__ C Hs[NP][64];
+#else
 	__shared__ C Hs[NP][2049];
+#endif
 
 	const int     t  = threadIdx.x;
 	const int     c  = blockIdx.y;
@@ -1367,7 +1374,7 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 #pragma unroll
 		for (int pp = 0; pp < NP; ++pp) {
 			const f2 hv = reinterpret_cast<const f2*> (p.H)[pp * 4096 + i];
-			Hs[pp][j]   = O::mk (hv.x, hv.y);
+			Hs[pp][PROT_PROBE4 ? (j & 63) : j] = O::mk (hv.x, hv.y);
 		}
 	}
 	};
@@ -1505,7 +1512,7 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 				const int idx = k < 8 ? t + 256 * k : 256 * (15 - k) + mq;
 #pragma unroll
 				for (int pp = 0; pp < NP; ++pp) {
-					hb[j & 1][pp * HB + i] = ((const VC*)Hs[pp])[idx];
+					hb[j & 1][pp * HB + i] = ((const VC*)Hs[pp])[PROT_PROBE4 ? (idx & 63) : idx];
 				}
 			}
 		};
@@ -1730,7 +1737,7 @@ static hipError_t launch_poly_m (const OlaParamsT<typename T::samp>& p, dim3 gri
 	constexpr int DHS = HS == 8 ? (NP == 2 ? 8 : 4) : HS == 10 ? 3 : HS == 12 ? 2 : 1;
 	// fp32, one partition: the register diet of the 3-workgroups-per-CU form (3 x 53 KiB of LDS = one CU)
 	// (the per-frame rotation of the ramp form with 12 or 14 rows per block does not fit 168 VGPRs: 2 per CU there)
-	constexpr int WPS = (NP == 1 && sizeof (typename T::samp) == 4 && !(MODE == MODE_RAMP && HS >= 12)) ? 3 : 2;
+	constexpr int WPS = (NP == 1 && sizeof (typename T::samp) == 4 && !(MODE == MODE_RAMP && HS >= 12)) ? (PROT_PROBE4 ? 4 : 3) : 2;
 	const dim3 block (256);
 	if (p.accumulate) {
 		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, 0, true, WPS>), grid, block, dbg_dyn_lds (), s, p);
