@@ -263,6 +263,7 @@ struct prot_engine {
 	uint64_t       pos      = 0; // frames consumed since reset (CLI stream position)
 	int            pairs_per_run_override = 0;
 	int            wg_slots = 768; // resident OLA workgroups on the device (CUs x 3)
+	int            cus      = 256; // compute units of the device (read once, at create)
 	uint32_t       lv2_max_block = 0; // frames per prot_lv2_run chunk the buffers are reserved for
 	bool           counted = false;   // in g_engines (communicator cache lifetime)
 
@@ -354,15 +355,18 @@ int analyze_range (prot_engine* e, const float* data, uint64_t f0, uint64_t nf, 
 // runs 0.315-0.326 / 0.270 / 0.248-0.257; 1.3:1:0.75 0.312-0.318 / 0.249-0.252 / 0.233; 1.45:0.95:0.6 0.291-0.302 /
 // 0.243-0.251 / 0.230-0.239; 1.6:0.9:0.5 0.291-0.293 / 0.258-0.265 / 0.247; 1.8:0.8:0.4 0.313-0.323 / 0.273-0.281 / 0.26
 template <class P>
-void rank_runs (P& p, int64_t blk, int n_chn, uint64_t n_out, int slots, bool half)
+void rank_runs (P& p, int64_t blk, int n_chn, uint64_t n_out, int slots, int cus, bool half)
 {
-	int cus = 0, dev = 0;
-	if (hipGetDevice (&dev) != hipSuccess || hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0 ||
-	    slots % cus != 0) {
+	if (cus <= 0 || slots % cus != 0) {
 		return;
 	}
 	const int R = slots / cus;
 	if (R != 3 && R != 4) {
+		return;
+	}
+	// (the geometry test first: small launches -- every LV2 run() -- leave here without touching the environment)
+	const int64_t runs = ((int64_t)n_out + p.run_frames - 1) / p.run_frames;
+	if (runs * n_chn > slots || runs * n_chn <= (int64_t)(R - 1) * cus || p.run_frames / blk < 12) {
 		return;
 	}
 	double      w[4] = { 1.45, 0.95, 0.6, 0.0 };
@@ -383,8 +387,7 @@ void rank_runs (P& p, int64_t blk, int n_chn, uint64_t n_out, int slots, bool ha
 	for (int k = 1; k < R; ++k) {
 		equal = equal && w[k] == w[0];
 	}
-	const int64_t runs = ((int64_t)n_out + p.run_frames - 1) / p.run_frames;
-	if (equal || runs * n_chn > slots || runs * n_chn <= (int64_t)(R - 1) * cus || p.run_frames / blk < 12) {
+	if (equal) {
 		return;
 	}
 	const int64_t total = ((int64_t)n_out + blk - 1) / blk; // blocks per channel
@@ -471,7 +474,7 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 	if (e->use_poly) {
 		const uint32_t np = std::min<uint32_t> (2, e->info.partitions); // partitions of g per launch
 		if (np == 1) {
-			rank_runs (p, (int64_t)e->info.run_align, n_chn, n_out, e->wg_slots, false);
+			rank_runs (p, (int64_t)e->info.run_align, n_chn, n_out, e->wg_slots, e->cus, false);
 		}
 		for (uint32_t l = 0; l < e->info.partitions / np; ++l) {
 			p.H          = e->d_H.p + (size_t)(np * l) * e->info.fftlen;
@@ -790,12 +793,14 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 		if (hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) {
 			// 53 KiB of LDS per workgroup, 3 per CU -- except the kernels with two partitions in one launch (70 KiB, 2 per CU)
 			e->wg_slots = cus * ((use_p2 || (use_poly && n_part >= 2)) ? 2 : 3);
+			e->cus      = cus;
 		}
 	}
 	if (const char* o = getenv ("PROT_WG_PER_CU")) { // tuning
 		int cus = 256;
 		(void)hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, cfg->device);
 		e->wg_slots = cus * atoi (o);
+		e->cus      = cus;
 	}
 	if (const char* o = getenv ("PROT_PAIRS_PER_RUN")) {
 		e->pairs_per_run_override = atoi (o);
@@ -1118,7 +1123,8 @@ static int apply_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint6
 	p.rot_s      = d_rot_s;
 	// fp16 samples, one partition: 104-128 VGPRs and 26 KiB of LDS per workgroup -- FOUR per CU (measured 0.269 -> 0.252 ms
 	// at the headline shape with equal runs; the fp32 kernel cannot: 158 VGPRs, 53 KiB)
-	const int slots16 = (f16_poly && e->info.partitions == 1 && e->wg_slots % 3 == 0 && !getenv ("PROT_WG_PER_CU")) ? e->wg_slots / 3 * 4 : e->wg_slots;
+	static const bool slots_forced = getenv ("PROT_WG_PER_CU") != nullptr; // tuning
+	const int slots16 = (f16_poly && e->info.partitions == 1 && e->wg_slots % 3 == 0 && !slots_forced) ? e->wg_slots / 3 * 4 : e->wg_slots;
 	p.run_frames = pick_run_frames (e, n_out, nc, 0, slots16); // the engine's own transform block: the fp16 kernels share its form
 	p.conv_delay = (int)e->info.conv_delay;
 	p.dry_delay  = (int)e->info.dry_delay;
@@ -1129,7 +1135,7 @@ static int apply_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint6
 		p.hist_out = carry ? (_Float16*)e->d_hist16[1 - e->hist16_cur].p : nullptr;
 	}
 	if (f16_poly && e->info.partitions == 1) {
-		rank_runs (p, (int64_t)e->info.run_align, nc, n_out, slots16, true);
+		rank_runs (p, (int64_t)e->info.run_align, nc, n_out, slots16, e->cus, true);
 	}
 	hipError_t err = f16_poly ? prot::launch_ola_poly_f16 (p, (int)e->info.partitions, e->hopseg / 2, nc, s)
 	               : f16_p2   ? prot::launch_ola4096_p2_f16 (p, nc, s)
