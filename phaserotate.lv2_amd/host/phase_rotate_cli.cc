@@ -23,6 +23,7 @@
 #include <chrono>
 #include <getopt.h>
 #include <memory>
+#include <thread>
 #include <limits>
 #include <map>
 #include <string>
@@ -388,18 +389,55 @@ int main (int argc, char** argv)
 		}
 	};
 
+	// engines: one, or PROT_GPUS of them on consecutive devices (PROT_GPUS_SAME_DEVICE=1 keeps them
+	// all on PROT_DEVICE -- a functional test of the sharding on a single-GPU box).  Created on a second thread as soon as
+	// the file's header is known, under the decoding of the samples (the HIP runtime start-up is 0.1-0.2 s).
+	const int  n_gpus   = std::max (1, getenv ("PROT_GPUS") ? atoi (getenv ("PROT_GPUS")) : 1);
+	const int  dev0     = getenv ("PROT_DEVICE") ? atoi (getenv ("PROT_DEVICE")) : 0;
+	const bool same_dev = getenv ("PROT_GPUS_SAME_DEVICE") != nullptr;
+	std::vector<prot_engine*> gpus;
+	std::string               gpu_err;
+	std::thread               gpu_thread;
+	auto create_engines = [&] (unsigned blk, int chn) {
+		for (int g = 0; g < n_gpus; ++g) {
+			prot_config cfg;
+			memset (&cfg, 0, sizeof (cfg));
+			cfg.kind   = PROT_KIND_CLI;
+			cfg.param  = blk;
+			cfg.n_chn  = (uint32_t)chn;
+			cfg.device = same_dev ? dev0 : dev0 + g;
+			int          status = 0;
+			prot_engine* e      = prot_engine_create (&cfg, &status);
+			if (!e) {
+				gpu_err = std::string ("Error: cannot create the GPU engine: ") + prot_strerror (status) + " (" + prot_last_error () + ")\n";
+				return;
+			}
+			gpus.push_back (e);
+		}
+	};
+
 	wavio::Info        nfo;
 	wavio::Samples     file;
 	{
-		const std::string err = wavio::read_file (opt.in_path, nfo, file);
+		const std::string err = wavio::read_file (opt.in_path, nfo, file, [&] (const wavio::Info& h) {
+			const unsigned blk = pick_block_size (opt.blksiz, h.samplerate);
+			const int      chn = h.channels;
+			gpu_thread         = std::thread ([&create_engines, blk, chn] () { create_engines (blk, chn); });
+		});
 		if (!err.empty ()) {
+			if (gpu_thread.joinable ()) {
+				gpu_thread.join ();
+			}
 			fprintf (stderr, "Cannot open '%s' for reading: ", opt.in_path);
 			die (err.c_str ());
 		}
 	}
+	if (gpu_thread.joinable ()) { // (before any of the exits below: no runtime start-up left running behind an exit())
+		gpu_thread.join ();
+	}
 	const int      n_chn    = nfo.channels;
 	const uint64_t n_frames = nfo.frames;
-	lap ("read + decode input");
+	lap ("read + decode input, engine");
 
 	wavio::Writer outfile;
 	if (opt.out_path) {
@@ -434,29 +472,11 @@ int main (int argc, char** argv)
 		fprintf (vfd, "Process block-size %d\n", blksiz);
 	}
 
-	// engines: one, or PROT_GPUS of them on consecutive devices (PROT_GPUS_SAME_DEVICE=1 keeps them
-	// all on PROT_DEVICE -- a functional test of the sharding on a single-GPU box)
-	const int n_gpus   = std::max (1, getenv ("PROT_GPUS") ? atoi (getenv ("PROT_GPUS")) : 1);
-	const int dev0     = getenv ("PROT_DEVICE") ? atoi (getenv ("PROT_DEVICE")) : 0;
-	const bool same_dev = getenv ("PROT_GPUS_SAME_DEVICE") != nullptr;
-	std::vector<prot_engine*> gpus;
-	for (int g = 0; g < n_gpus; ++g) {
-		prot_config cfg;
-		memset (&cfg, 0, sizeof (cfg));
-		cfg.kind   = PROT_KIND_CLI;
-		cfg.param  = blksiz;
-		cfg.n_chn  = (uint32_t)n_chn;
-		cfg.device = same_dev ? dev0 : dev0 + g;
-		int          status = 0;
-		prot_engine* e      = prot_engine_create (&cfg, &status);
-		if (!e) {
-			fprintf (stderr, "Error: cannot create the GPU engine: %s (%s)\n", prot_strerror (status), prot_last_error ());
-			return EXIT_FAILURE;
-		}
-		gpus.push_back (e);
+	if (!gpu_err.empty () || gpus.empty ()) {
+		fputs (gpu_err.empty () ? "Error: cannot create the GPU engine\n" : gpu_err.c_str (), stderr);
+		return EXIT_FAILURE;
 	}
 	prot_engine* pr = gpus[0];
-	lap ("create engine(s)");
 
 	if (analyse) {
 		if (opt.verbose > 1) {

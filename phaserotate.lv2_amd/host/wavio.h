@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fcntl.h>
+#include <functional>
 #include <memory>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -107,7 +108,9 @@ inline float decode_sample (const uint8_t* p, bool is_float, uint32_t bps)
 }
 
 // Reads the whole file as interleaved float32.  Returns "" on success, else an error text.
-inline std::string read_file (const char* path, Info& nfo, Samples& data)
+// `on_header`, if given, is called once the format and the frame count are known and before the samples are decoded
+// (the CLI starts creating its GPU engine there, under the decode).
+inline std::string read_file (const char* path, Info& nfo, Samples& data, const std::function<void (const Info&)>& on_header = nullptr)
 {
 	FILE* f = fopen (path, "rb");
 	if (!f) {
@@ -163,6 +166,9 @@ inline std::string read_file (const char* path, Info& nfo, Samples& data)
 			uint64_t bytes = sz == 0xFFFFFFFFu || sz > avail ? avail : sz;
 			nfo.frames     = bytes / ((uint64_t)bps * nfo.channels);
 			const uint64_t n = nfo.frames * nfo.channels;
+			if (on_header) {
+				on_header (nfo);
+			}
 			data.resize (n);
 			const bool is_float = nfo.is_float;
 			// the whole data chunk mapped and decoded in place by all workers (no copy through a staging buffer) ...
