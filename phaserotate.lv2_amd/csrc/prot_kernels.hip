@@ -1670,6 +1670,16 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 #endif
 					}
 				}
+			} else if (MODE == MODE_HILBERT && !ACC && full && out_al8 && !(PROT_ABL2 & 64)) {
+				// the Hilbert pass of the sweep: whole blocks as aligned pairs too
+#pragma unroll
+				for (int m = 0; m < HS / 2; ++m) {
+					PROT_GLOBAL C* __restrict__ ob = reinterpret_cast<PROT_GLOBAL C*> (uniform_ptr (out + s + 1024 * m));
+#pragma unroll
+					for (int e = 0; e < 2; ++e) {
+						ob[(unsigned)t + 256u * e] = to_sp (u[2 * m + e]);
+					}
+				}
 			} else {
 #pragma unroll
 				for (int k = 0; k < HS; ++k) {
