@@ -1670,6 +1670,22 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 #endif
 					}
 				}
+			} else if (MODE == MODE_ROT && ACC && full && out_al8 && !(PROT_ABL2 & 64)) {
+				// a later partition of a long FIR (16384 / 32768 taps): its share added to what the earlier launches stored
+				const f2 sa2 = mkf2 (sa, sa);
+#pragma unroll
+				for (int m = 0; m < HS / 2; ++m) {
+					PROT_GLOBAL C* __restrict__ ob = reinterpret_cast<PROT_GLOBAL C*> (uniform_ptr (out + s + 1024 * m));
+					f2                          prev[2];
+#pragma unroll
+					for (int e = 0; e < 2; ++e) {
+						prev[e] = to_f2 (ob[(unsigned)t + 256u * e]);
+					}
+#pragma unroll
+					for (int e = 0; e < 2; ++e) {
+						ob[(unsigned)t + 256u * e] = to_sp (prev[e] + sa2 * u[2 * m + e]);
+					}
+				}
 			} else if (MODE == MODE_HILBERT && !ACC && full && out_al8 && !(PROT_ABL2 & 64)) {
 				// the Hilbert pass of the sweep: whole blocks as aligned pairs too
 #pragma unroll
