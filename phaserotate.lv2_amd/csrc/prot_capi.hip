@@ -361,7 +361,7 @@ void rank_runs (P& p, int64_t blk, int n_chn, uint64_t n_out, int slots, int cus
 		return;
 	}
 	const int R = slots / cus;
-	if (R != 3 && R != 4) {
+	if (R < 2 || R > 4) {
 		return;
 	}
 	// (the geometry test first: small launches -- every LV2 run() -- leave here without touching the environment)
@@ -370,6 +370,9 @@ void rank_runs (P& p, int64_t blk, int n_chn, uint64_t n_out, int slots, int cus
 		return;
 	}
 	double      w[4] = { 1.45, 0.95, 0.6, 0.0 };
+	if (R == 2) {
+		w[0] = 1.2, w[1] = 0.8;
+	}
 	if (R == 4) {
 		w[0] = 1.4, w[1] = 1.1, w[2] = 0.9, w[3] = 0.6; // fp16 headline / CLI 2048, ms per 2^27 frames: equal runs 0.247 / 0.238; 1.5:1.1:0.8:0.6 0.230 / 0.228;
 		                                                 // 1.4:1.1:0.9:0.6 0.229 / 0.226; 1.6:1.1:0.8:0.5 0.227 / 0.235; 1.3:1.1:0.9:0.7 0.234 / 0.229 (PROT_RANK_W16)
@@ -473,7 +476,9 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 	}
 	if (e->use_poly) {
 		const uint32_t np = std::min<uint32_t> (2, e->info.partitions); // partitions of g per launch
-		if (np == 1) {
+		// (two workgroups per CU, two partitions in one launch: 1.2 : 0.8, -4...6 % at 8192 taps; the accumulating launches
+		// of longer FIRs lose 6 % with it and keep equal runs)
+		if (e->info.partitions == np) {
 			rank_runs (p, (int64_t)e->info.run_align, n_chn, n_out, e->wg_slots, e->cus, false);
 		}
 		for (uint32_t l = 0; l < e->info.partitions / np; ++l) {
@@ -1124,7 +1129,8 @@ static int apply_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint6
 	// fp16 samples, one partition: 104-128 VGPRs and 26 KiB of LDS per workgroup -- FOUR per CU (measured 0.269 -> 0.252 ms
 	// at the headline shape with equal runs; the fp32 kernel cannot: 158 VGPRs, 53 KiB)
 	static const bool slots_forced = getenv ("PROT_WG_PER_CU") != nullptr; // tuning
-	const int slots16 = (f16_poly && e->info.partitions == 1 && e->wg_slots % 3 == 0 && !slots_forced) ? e->wg_slots / 3 * 4 : e->wg_slots;
+	// (two partitions per launch: 128-158 VGPRs, 34 KiB -- three per CU where the fp32 kernel has two; 0.367 -> 0.336 ms)
+	const int slots16 = (!f16_poly || slots_forced) ? e->wg_slots : e->cus * (e->info.partitions == 1 ? 4 : 3);
 	p.run_frames = pick_run_frames (e, n_out, nc, 0, slots16); // the engine's own transform block: the fp16 kernels share its form
 	p.conv_delay = (int)e->info.conv_delay;
 	p.dry_delay  = (int)e->info.dry_delay;
@@ -1134,7 +1140,7 @@ static int apply_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint6
 		p.hist     = (const _Float16*)e->d_hist16[e->hist16_cur].p;
 		p.hist_out = carry ? (_Float16*)e->d_hist16[1 - e->hist16_cur].p : nullptr;
 	}
-	if (f16_poly && e->info.partitions == 1) {
+	if (f16_poly) {
 		rank_runs (p, (int64_t)e->info.run_align, nc, n_out, slots16, e->cus, true);
 	}
 	hipError_t err = f16_poly ? prot::launch_ola_poly_f16 (p, (int)e->info.partitions, e->hopseg / 2, nc, s)
