@@ -161,7 +161,7 @@ def test_fp16_long_fir_is_refused(pkg):
     e.close()
 
 
-@pytest.mark.parametrize("kind,param,chn", [("lv2", 48000, 1), ("cli", 2048, 1), ("lv2", 48000, 2)])
+@pytest.mark.parametrize("kind,param,chn", [("lv2", 48000, 1), ("cli", 2048, 1), ("lv2", 48000, 2), ("cli", 8192, 1), ("lv2", 192000, 2)])
 def test_fp16_full_size_every_frame(pkg, kind, param, chn, capsys):
     """The size at which the fp16 path runs FOUR workgroups per CU with run lengths by dispatch rank (2^27 frames in all;
     smaller launches take equal runs): every output frame against the fp32 kernel on the same rounded input -- a run

@@ -811,7 +811,8 @@ def test_cfg3_shape_against_oracle(pkg):
 
 
 @pytest.mark.parametrize("kind,param,chn,n", [(1, 48000, 1, 50_000_017), (1, 48000, 2, 33_333_333), (0, 2048, 1, (1 << 27) - 3),
-                                              (0, 1024, 2, 40_000_001)])
+                                              (0, 1024, 2, 40_000_001), (0, 8192, 1, 70_000_001), (1, 192000, 2, 40_000_003),
+                                              (0, 16384, 1, 60_000_001)])
 def test_rank_weighted_runs_ragged_sizes(pkg, kind, param, chn, n):
     """One-round launches cut the stream into runs of unequal length by dispatch rank (olapoly_kernel, rank_runs in the C
     ABI); sizes that are no multiple of anything, odd-offset channel rows, one and two channels: the one-shot stateless
