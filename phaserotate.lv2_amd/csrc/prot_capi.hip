@@ -20,6 +20,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #ifndef M_PI
@@ -181,13 +182,14 @@ struct Rccl {
 	int (*GroupStart) ()                          = nullptr;
 	int (*GroupEnd) ()                            = nullptr;
 	int (*AllReduce) (const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+	std::string override_path;
 	bool load ()
 	{
 		if (lib) {
 			return true;
 		}
-		// PROT_RCCL_LIB: a library to use in place of the system's RCCL (tests load a counting stand-in)
-		const char* over = getenv ("PROT_RCCL_LIB");
+		// `override_path` (prot_internal_set_rccl_library, tests only: a counting stand-in) replaces the system's RCCL
+		const char* over = override_path.empty () ? nullptr : override_path.c_str ();
 		for (const char* name : { over ? over : "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
 			lib = dlopen (name, RTLD_NOW | RTLD_LOCAL);
 			if (lib || over) {
@@ -202,7 +204,14 @@ struct Rccl {
 		GroupStart  = (int (*) ())dlsym (lib, "ncclGroupStart");
 		GroupEnd    = (int (*) ())dlsym (lib, "ncclGroupEnd");
 		AllReduce   = (int (*) (const void*, void*, size_t, int, int, void*, hipStream_t))dlsym (lib, "ncclAllReduce");
-		return CommInitAll && CommDestroy && GroupStart && GroupEnd && AllReduce;
+		if (!(CommInitAll && CommDestroy && GroupStart && GroupEnd && AllReduce)) {
+			// not an RCCL: forget it, so that later calls fall back to the host merge instead of calling null pointers
+			dlclose (lib);
+			lib = nullptr;
+			CommInitAll = nullptr, CommDestroy = nullptr, GroupStart = nullptr, GroupEnd = nullptr, AllReduce = nullptr;
+			return false;
+		}
+		return true;
 	}
 };
 Rccl       g_rccl;
@@ -246,6 +255,8 @@ struct prot_engine {
 	DevBuf<float>  d_inter_b, d_in_b;
 	hipStream_t    copy_stream = nullptr;
 	hipEvent_t     ev_copied[2] = {}, ev_free[2] = {};
+	std::vector<int> angles_last;          // what d_angles holds, uploaded on angles_stream
+	hipStream_t      angles_stream = nullptr;
 	DevBuf<uint16_t> d_hist16[2]; // fp16 sample path: its own input history (half precision), double-buffered
 	int            hist16_cur = 0;
 	DevBuf<int>    d_angles;
@@ -402,20 +413,35 @@ void rank_runs (P& p, int64_t blk, int n_chn, uint64_t n_out, int slots, int cus
 	for (int k = 0; k < R; ++k) {
 		nb[k] = std::max<int64_t> (1, (int64_t)std::llround ((double)(p.run_frames / blk) * (double)R * w[k] / wsum));
 	}
-	// every channel must be covered: lengthen the last rank until the least-covered channel is
-	for (;;) {
+	// every channel must be covered: lengthen the LAST rank that occurs in the least-covered channel until it is (a channel
+	// of three or more may consist of lower-rank workgroups only: lengthening rank R-1 alone would never cover it)
+	for (int guard = 0;; ++guard) {
 		int64_t worst = INT64_MAX;
+		int     wy    = 0;
 		for (int y = 0; y < n_chn; ++y) {
 			int64_t cov = 0;
 			for (int64_t x = 0; x < runs; ++x) {
 				cov += nb[std::min<int64_t> (R - 1, (y * runs + x) / cus)];
 			}
-			worst = std::min (worst, cov);
+			if (cov < worst) {
+				worst = cov;
+				wy    = y;
+			}
 		}
 		if (worst >= total) {
 			break;
 		}
-		++nb[R - 1];
+		if (guard > (1 << 22)) { // cannot happen (every step raises the worst channel's coverage); equal runs if it does
+			return;
+		}
+		const int64_t last_id = (int64_t)wy * runs + runs - 1;
+		const int     rk      = (int)std::min<int64_t> (R - 1, last_id / cus);
+		// all of that rank's runs in the channel grow together: jump by the whole deficit at once
+		int64_t cnt = 0;
+		for (int64_t x = 0; x < runs; ++x) {
+			cnt += std::min<int64_t> (R - 1, ((int64_t)wy * runs + x) / cus) == rk;
+		}
+		nb[rk] += std::max<int64_t> (1, (total - worst + cnt - 1) / cnt);
 	}
 	p.rank_cu = cus;
 	p.n_rank  = R;
@@ -427,9 +453,13 @@ void rank_runs (P& p, int64_t blk, int n_chn, uint64_t n_out, int slots, int cus
 // core of prot_apply_dev / the Hilbert pass of the sweep
 int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_in, float* d_out,
                 int64_t out_stride, uint64_t n_out, const float* d_rot, const float* d_rot_s,
-                bool hilbert_only, bool stateless, int chn0, int n_chn, hipStream_t s, bool advance_hist = false)
+                bool hilbert_only, bool stateless, int chn0, int n_chn, hipStream_t s, bool advance_hist = false,
+                const float* h_rot = nullptr)
 {
 	prot::OlaParams p {};
+	if (h_rot) { // steady rotation of up to kRotInline channels: by value in the kernel arguments (d_rot == nullptr)
+		memcpy (p.rot_v, h_rot + 2 * chn0, 2 * sizeof (float) * (size_t)std::min (n_chn, prot::kRotInline));
+	}
 	p.in           = d_in + (int64_t)chn0 * in_stride;
 	p.in_stride    = in_stride;
 	p.n_in         = (int64_t)n_in;
@@ -543,21 +573,26 @@ int hist_advance (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t
 
 // device calls read the input of neighbouring runs (halo blocks) while other workgroups store output:
 // input and output must not share frames.  Exact per-channel interval test (skipped beyond 64 channels).
-bool io_overlap (const float* in, int64_t in_stride, uint64_t n_in, const float* out, int64_t out_stride, uint64_t n_out, int nc)
+bool io_overlap_bytes (const void* in, int64_t in_stride, uint64_t n_in, const void* out, int64_t out_stride, uint64_t n_out, int nc,
+                       size_t esz)
 {
 	if (nc > 64 || n_in == 0 || n_out == 0) {
 		return false;
 	}
 	for (int ci = 0; ci < nc; ++ci) {
-		const uintptr_t a0 = (uintptr_t)(in + (int64_t)ci * in_stride), a1 = a0 + n_in * sizeof (float);
+		const uintptr_t a0 = (uintptr_t)in + (uintptr_t)((int64_t)ci * in_stride * (int64_t)esz), a1 = a0 + n_in * esz;
 		for (int co = 0; co < nc; ++co) {
-			const uintptr_t b0 = (uintptr_t)(out + (int64_t)co * out_stride), b1 = b0 + n_out * sizeof (float);
+			const uintptr_t b0 = (uintptr_t)out + (uintptr_t)((int64_t)co * out_stride * (int64_t)esz), b1 = b0 + n_out * esz;
 			if (a0 < b1 && b0 < a1) {
 				return true;
 			}
 		}
 	}
 	return false;
+}
+bool io_overlap (const float* in, int64_t in_stride, uint64_t n_in, const float* out, int64_t out_stride, uint64_t n_out, int nc)
+{
+	return io_overlap_bytes (in, in_stride, n_in, out, out_stride, n_out, nc, sizeof (float));
 }
 
 // the buffers one prot_lv2_run chunk of `frames` frames needs: allocated by prot_engine_create (8192 frames) and
@@ -1041,15 +1076,16 @@ int prot_apply_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 	HIP_TRY (hipSetDevice (e->device));
 	hipStream_t s = pick_stream (e, stream);
 	const int   nc = (int)e->info.n_chn;
-	if (rot) {
+	const bool inl = rot && nc <= prot::kRotInline; // {ca, sa} per channel as kernel arguments: no copy in front of the launch
+	if (rot && !inl) {
 		int rcs = stage_small (e, e->d_rot.p, rot, 2 * (size_t)nc * sizeof (float), s);
 		if (rcs) {
 			return rcs;
 		}
 	}
 	const bool stateless = flags & PROT_F_STATELESS;
-	int rc = ola_launch (e, d_in, in_stride, n_in, d_out, out_stride, n_out, e->d_rot.p, nullptr,
-	                     flags & PROT_F_HILBERT, stateless, 0, nc, s, /*advance_hist*/ true);
+	int rc = ola_launch (e, d_in, in_stride, n_in, d_out, out_stride, n_out, inl ? nullptr : e->d_rot.p, nullptr,
+	                     flags & PROT_F_HILBERT, stateless, 0, nc, s, /*advance_hist*/ true, inl ? rot : nullptr);
 	if (rc) {
 		return rc;
 	}
@@ -1106,14 +1142,34 @@ static int apply_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint6
 		snprintf (g_err, sizeof (g_err), "fp16 sample path: the direct-form engines offer the stateless, steady call only");
 		return PROT_EUNSUPPORTED;
 	}
+	// (the same rule as prot_apply_dev: workgroups read neighbouring halo blocks while others store)
+	if (io_overlap_bytes (d_in, in_stride, n_in, d_out, out_stride, n_out, (int)e->info.n_chn, 2)) {
+		snprintf (g_err, sizeof (g_err), "prot_apply_dev_f16: d_out overlaps d_in (in-place processing is not supported on device streams)");
+		return PROT_EINVAL;
+	}
 	HIP_TRY (hipSetDevice (e->device));
 	hipStream_t s  = pick_stream (e, stream);
 	const int   nc = (int)e->info.n_chn;
-	if (rot) {
+	const bool inl = rot && nc <= prot::kRotInline;
+	if (rot && !inl) {
 		int rcs = stage_small (e, e->d_rot.p, rot, 2 * (size_t)nc * sizeof (float), s);
 		if (rcs) {
 			return rcs;
 		}
+	}
+	if (!stateless && n_out == 0) {
+		// nothing to emit, input consumed all the same: the half-precision history advances by n_in frames
+		if (n_in > 0) {
+			hipError_t herr = prot::launch_hist_update_f16 ((const _Float16*)d_in, in_stride, (int64_t)n_in,
+			                                                (const _Float16*)e->d_hist16[e->hist16_cur].p,
+			                                                (_Float16*)e->d_hist16[1 - e->hist16_cur].p, (int)e->info.history, nc, s);
+			if (herr != hipSuccess) {
+				return hip_fail (herr, "fp16 history update launch");
+			}
+			e->hist16_cur = 1 - e->hist16_cur;
+			e->pos += n_in;
+		}
+		return PROT_OK;
 	}
 	prot::OlaParamsH p {};
 	p.in         = (const _Float16*)d_in;
@@ -1124,7 +1180,10 @@ static int apply_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint6
 	p.n_out      = (int64_t)n_out;
 	p.H          = e->d_H.p;
 	p.tw         = e->d_tw.p;
-	p.rot        = e->d_rot.p;
+	p.rot        = inl ? nullptr : e->d_rot.p;
+	if (inl) {
+		memcpy (p.rot_v, rot, 2 * sizeof (float) * (size_t)nc);
+	}
 	p.rot_s      = d_rot_s;
 	// fp16 samples, one partition: 104-128 VGPRs and 26 KiB of LDS per workgroup -- FOUR per CU (measured 0.269 -> 0.252 ms
 	// at the headline shape with equal runs; the fp32 kernel cannot: 158 VGPRs, 53 KiB)
@@ -1227,9 +1286,14 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 	}
 	// 2. rotated peaks
 	if (n_ang > 0) {
-		rc = stage_small (e, e->d_angles.p, lut_idx, n_ang * sizeof (int), s);
-		if (rc) {
-			return rc;
+		// the angle list of a file analysis is the same for every chunk: uploaded when it changes (or the stream does)
+		if (e->angles_stream != s || e->angles_last.size () != (size_t)n_ang || memcmp (e->angles_last.data (), lut_idx, n_ang * sizeof (int))) {
+			rc = stage_small (e, e->d_angles.p, lut_idx, n_ang * sizeof (int), s);
+			if (rc) {
+				return rc;
+			}
+			e->angles_last.assign (lut_idx, lut_idx + n_ang);
+			e->angles_stream = s;
 		}
 		prot::SweepParams sp {};
 		sp.x        = d_in;
@@ -1646,8 +1710,24 @@ namespace {
 constexpr int kNcclFloat32 = 7, kNcclMax = 2; // rccl.h: ncclDataType_t / ncclRedOp_t
 
 // sweep frames [f0, f0 + nf) of an in-memory interleaved file on one engine
+static int analyze_range_impl (prot_engine* e, const float* data, uint64_t f0, uint64_t nf, bool is_first, bool is_last,
+                               int ang_start, int ang_end, int ang_stride, int chn);
 int analyze_range (prot_engine* e, const float* data, uint64_t f0, uint64_t nf, bool is_first, bool is_last,
                    int ang_start, int ang_end, int ang_stride, int chn)
+{
+	const int rc = analyze_range_impl (e, data, f0, nf, is_first, is_last, ang_start, ang_end, ang_stride, chn);
+	if (rc != PROT_OK) {
+		// an error exit of the double-buffered path may leave an upload from the caller's `data` or kernels on the
+		// staging buffers in flight: drain both streams before the caller frees the file or destroys the engine
+		if (e->copy_stream) {
+			(void)hipStreamSynchronize (e->copy_stream);
+		}
+		(void)hipStreamSynchronize (e->stream);
+	}
+	return rc;
+}
+static int analyze_range_impl (prot_engine* e, const float* data, uint64_t f0, uint64_t nf, bool is_first, bool is_last,
+                               int ang_start, int ang_end, int ang_stride, int chn)
 {
 	HIP_TRY (hipSetDevice (e->device));
 	const uint32_t nc = e->info.n_chn;
@@ -1919,6 +1999,20 @@ int prot_cli_apply_file (prot_engine* e, const float* data, uint64_t n_frames, c
 		HIP_TRY (hipStreamSynchronize (s));
 		pos += n;
 	}
+	return PROT_OK;
+}
+
+
+// TEST HOOK, not part of include/prot_hip.h (declared in csrc/prot_internal.h): the library that Rccl::load() opens in
+// place of the system's RCCL -- an explicit call of the test process, never the environment (the library is also
+// loaded into LV2 hosts).  Only before the first all-reduce; NULL / "" restores the default.
+int prot_internal_set_rccl_library (const char* path)
+{
+	std::lock_guard<std::mutex> lk (g_rccl_lock);
+	if (g_rccl.lib) {
+		return PROT_EINVAL;
+	}
+	g_rccl.override_path = path ? path : "";
 	return PROT_OK;
 }
 

@@ -7,6 +7,7 @@
 namespace prot {
 
 constexpr int kMaxSample = 360; // cli/phase-rotate.cc:39
+constexpr int kRotInline = 16;  // channels whose steady rotation constants travel as kernel arguments
 
 // One launch of the overlap-add kernel: every workgroup owns a run of
 // consecutive hops of one channel-stream.  S = sample type in HBM (float or _Float16).
@@ -25,7 +26,7 @@ struct OlaParamsT {
 	int64_t       n_out;      // emit t in [0, n_out)
 	const float2* H;          // device, [partitions][fftlen] FIR spectrum / fftlen, natural bin order
 	const float2* tw;         // device, [fftlen] e^{-2 pi i m / fftlen}
-	const float*  rot;        // device, [n_chn][2] {ca, sa}              (steady)
+	const float*  rot;        // device, [n_chn][2] {ca, sa}              (steady), or NULL: rot_v
 	const float*  rot_s;      // device, [n_chn][n_out][2] per-frame      (ramp) or NULL
 	int32_t       run_frames; // outputs per workgroup, multiple of 2*hop
 	int32_t       conv_delay; // Dc
@@ -37,6 +38,9 @@ struct OlaParamsT {
 	int32_t       rank_cu;
 	int32_t       n_rank;     // 3 (fp32: 3 workgroups per CU) or 4 (fp16 samples)
 	int32_t       rank_frames[4];
+	// steady rotation by value ({ca, sa} of channels 0..15, read when rot == NULL): two floats per channel ride in the
+	// kernel arguments instead of a host-to-device copy in front of every launch (4 us on a 20 us launch)
+	float         rot_v[2 * kRotInline];
 };
 typedef OlaParamsT<float>    OlaParams;
 typedef OlaParamsT<_Float16> OlaParamsH; // fp16 sample path (BASELINE config 5)
@@ -96,6 +100,9 @@ hipError_t launch_absmax (const float* x, int64_t x_stride, int64_t n, float* pe
 hipError_t launch_hist_update (const float* in, int64_t in_stride, int64_t n_in,
                                const float* hist_in, float* hist_out, int hist_len,
                                int n_chn, hipStream_t s);
+hipError_t launch_hist_update_f16 (const _Float16* in, int64_t in_stride, int64_t n_in,
+                                   const _Float16* hist_in, _Float16* hist_out, int hist_len,
+                                   int n_chn, hipStream_t s);
 
 // interleaved [n][n_chn] <-> planar [n_chn][stride]
 hipError_t launch_deinterleave (const float* inter, float* planar, int64_t stride, int64_t n,

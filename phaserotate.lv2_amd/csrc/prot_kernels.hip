@@ -205,8 +205,8 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 
 	float ca = 0.f, sa = 1.f;
 	if (MODE == MODE_ROT) {
-		ca = p.rot[2 * c];
-		sa = p.rot[2 * c + 1];
+		ca = p.rot ? p.rot[2 * c] : p.rot_v[2 * c];
+		sa = p.rot ? p.rot[2 * c + 1] : p.rot_v[2 * c + 1];
 	}
 
 	float acc[NACC];
@@ -964,8 +964,8 @@ __global__ __launch_bounds__ (256, (T::kWaves == 3 && DH > 0 && MODE != MODE_HIL
 	}
 	float ca = 0.f, sa = 1.f;
 	if (MODE == MODE_ROT) {
-		ca = p.rot[2 * c];
-		sa = p.rot[2 * c + 1];
+		ca = p.rot ? p.rot[2 * c] : p.rot_v[2 * c];
+		sa = p.rot ? p.rot[2 * c + 1] : p.rot_v[2 * c + 1];
 	}
 
 	const int tl = t & 15, th = t >> 4;
@@ -1383,8 +1383,8 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 #endif
 	float ca = 0.f, sa = 1.f;
 	if (MODE == MODE_ROT) {
-		ca = p.rot[2 * c];
-		sa = p.rot[2 * c + 1];
+		ca = p.rot ? p.rot[2 * c] : p.rot_v[2 * c];
+		sa = p.rot ? p.rot[2 * c + 1] : p.rot_v[2 * c + 1];
 	}
 
 	const int tl = t & 15, th = t >> 4;
@@ -1763,7 +1763,11 @@ static hipError_t launch_poly_m (const OlaParamsT<typename T::samp>& p, dim3 gri
 	constexpr int DHS = HS == 8 ? (NP == 2 ? 8 : 4) : HS == 10 ? 3 : HS == 12 ? 2 : 1;
 	// fp32, one partition: the register diet of the 3-workgroups-per-CU form (3 x 53 KiB of LDS = one CU)
 	// (the per-frame rotation of the ramp form with 12 or 14 rows per block does not fit 168 VGPRs: 2 per CU there)
-	constexpr int WPS = (NP == 1 && sizeof (typename T::samp) == 4 && !(MODE == MODE_RAMP && HS >= 12)) ? (PROT_PROBE4 ? 4 : 3) : 2;
+	// fp16 samples: the host sizes its one-round launches for FOUR resident workgroups per CU (one partition) or THREE (two
+	// partitions) -- the launch bounds say the same, so that a register count beyond that budget is a compile-time spill
+	// report (tools/kernel_resources.py) instead of a silently two-round launch
+	constexpr int WPS = sizeof (typename T::samp) == 2 ? (NP == 1 ? 4 : 3)
+	                  : (NP == 1 && !(MODE == MODE_RAMP && HS >= 12)) ? (PROT_PROBE4 ? 4 : 3) : 2;
 	const dim3 block (256);
 	if (p.accumulate) {
 		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, 0, true, WPS>), grid, block, dbg_dyn_lds (), s, p);
@@ -2354,16 +2358,17 @@ hipError_t launch_absmax (const float* x, int64_t x_stride, int64_t n, float* pe
 }
 
 // ------------------------------------------------------------ small movers
-__global__ void hist_update_kernel (const float* __restrict__ in, int64_t in_stride, int64_t n_in,
-                                    const float* __restrict__ hist_in, float* __restrict__ hist_out,
+template <class S>
+__global__ void hist_update_kernel (const S* __restrict__ in, int64_t in_stride, int64_t n_in,
+                                    const S* __restrict__ hist_in, S* __restrict__ hist_out,
                                     int hist_len)
 {
 	const int c = blockIdx.y;
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < hist_len) {
 		hist_out[(int64_t)c * hist_len + i] =
-		    ldv (in + (int64_t)c * in_stride, n_in, hist_in + (int64_t)c * hist_len, hist_len,
-		         n_in - hist_len + i);
+		    (S)ldv (in + (int64_t)c * in_stride, n_in, hist_in + (int64_t)c * hist_len, hist_len,
+		            n_in - hist_len + i);
 	}
 }
 
@@ -2371,7 +2376,15 @@ hipError_t launch_hist_update (const float* in, int64_t in_stride, int64_t n_in,
                                float* hist_out, int hist_len, int n_chn, hipStream_t s)
 {
 	dim3 grid ((unsigned)((hist_len + 255) / 256), (unsigned)n_chn), block (256);
-	hipLaunchKernelGGL (hist_update_kernel, grid, block, 0, s, in, in_stride, n_in, hist_in, hist_out, hist_len);
+	hipLaunchKernelGGL (hist_update_kernel<float>, grid, block, 0, s, in, in_stride, n_in, hist_in, hist_out, hist_len);
+	return hipGetLastError ();
+}
+
+hipError_t launch_hist_update_f16 (const _Float16* in, int64_t in_stride, int64_t n_in, const _Float16* hist_in,
+                                   _Float16* hist_out, int hist_len, int n_chn, hipStream_t s)
+{
+	dim3 grid ((unsigned)((hist_len + 255) / 256), (unsigned)n_chn), block (256);
+	hipLaunchKernelGGL (hist_update_kernel<_Float16>, grid, block, 0, s, in, in_stride, n_in, hist_in, hist_out, hist_len);
 	return hipGetLastError ();
 }
 

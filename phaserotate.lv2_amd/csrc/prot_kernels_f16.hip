@@ -67,7 +67,7 @@ __global__ __launch_bounds__ (256, 4) void ola4096h_kernel (const OlaParamsH p)
 		const float2 hh = p.H[i]; // |H|/4096 = 2.4e-4: a normal fp16 number
 		Hs[i]           = mk (hh.x, hh.y);
 	}
-	const float ca = p.rot[2 * c], sa = p.rot[2 * c + 1];
+	const float ca = p.rot ? p.rot[2 * c] : p.rot_v[2 * c], sa = p.rot ? p.rot[2 * c + 1] : p.rot_v[2 * c + 1];
 
 	float acc[NACC];
 #pragma unroll

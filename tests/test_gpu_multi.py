@@ -2,7 +2,7 @@
  * the cfg4 workload at FULL size (60 min stereo 96 kHz = 345.6 M frames x 2 channels, generated on the device), swept
    as 8 shards on one device and MAX-merged, equals the single pass bit for bit;
  * prot_allreduce_peaks keeps ONE set of communicators for many all-reduces and destroys it with the last engine
-   (a counting stand-in for librccl, loaded through PROT_RCCL_LIB; the real library wants one rank per GPU).
+   (a counting stand-in for librccl, loaded through the test hook prot_internal_set_rccl_library; the real library wants one rank per GPU).
 """
 import os
 import subprocess
@@ -86,10 +86,12 @@ import ctypes, os, sys
 sys.path.insert(0, %(root)r)
 from __graft_entry__ import load_package
 pkg = load_package()
-stub = ctypes.CDLL(os.environ["PROT_RCCL_LIB"])
+stub = ctypes.CDLL(os.environ["TEST_RCCL_STUB"])
 def counts():
     o = (ctypes.c_int * 6)(); stub.stub_counts(o); return list(o)
 lib = pkg.load_library()
+lib.prot_internal_set_rccl_library.argtypes = [ctypes.c_char_p]
+assert lib.prot_internal_set_rccl_library(os.environ["TEST_RCCL_STUB"].encode()) == 0
 a, b = pkg.Engine(pkg.KIND_CLI, 2048, 2), pkg.Engine(pkg.KIND_CLI, 2048, 2)
 arr = (ctypes.c_void_p * 2)(a._h, b._h)
 for _ in range(25):
@@ -113,7 +115,7 @@ def test_allreduce_keeps_its_communicators(tmp_path):
     src.write_text(STUB)
     so = str(tmp_path / "librccl_stub.so")
     subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-o", so, str(src)], check=True)
-    env = dict(os.environ, PROT_RCCL_LIB=so, PROT_ALLREDUCE="rccl")
+    env = dict(os.environ, TEST_RCCL_STUB=so, PROT_ALLREDUCE="rccl")
     r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("COUNTS")]
     assert r.returncode == 0 and line, r.stdout[-3000:]
