@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define PROT_ABI_VERSION 3
+#define PROT_ABI_VERSION 4
 #define PROT_SUBSAMPLE 2                      /* cli/phase-rotate.cc:38 */
 #define PROT_MAXSAMPLE (180 * PROT_SUBSAMPLE) /* cli/phase-rotate.cc:39 */
 
@@ -65,6 +65,10 @@ typedef struct {
  * direct form (measured 6-7 % faster there: no longer hop to gain); every other FIR length is polyphase
  * by default (1024..3072 taps: longer hops; 8192 and more: half the launches). */
 #define PROT_CFG_POLYPHASE 4u
+/* One-partition polyphase engines (LV2 48 / 96 kHz, CLI blksiz 1024..4096): keep the overlap-ADD kernel with its
+ * spectrum table (olapoly_kernel, three workgroups per CU) instead of the overlap-SAVE, table-free form
+ * (olasave_kernel, four per CU).  Same filter; kept for cross-checks. */
+#define PROT_CFG_OVERLAP_ADD 8u
 
 typedef struct {
 	int32_t  kind;

@@ -26,6 +26,7 @@ F_STATELESS, F_HILBERT, F_STREAM_START, F_STREAM_END = 1, 2, 4, 8
 CFG_SINGLE_FFT_PER_HOP = 1
 CFG_DIRECT_FORM = 2
 CFG_POLYPHASE = 4
+CFG_OVERLAP_ADD = 8
 
 # every symbol include/prot_hip.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = (

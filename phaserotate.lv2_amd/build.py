@@ -44,7 +44,7 @@ def build_lib(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
-    hdrs = [os.path.join(CSRC, h) for h in ("prot_fft.h", "prot_kernels.h")] + \
+    hdrs = [os.path.join(CSRC, h) for h in ("prot_fft.h", "prot_kernels.h", "prot_dev.h")] + \
            [os.path.join(ROOT, "include", "prot_hip.h")]
     common = [hipcc, "--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall",
               "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")]
@@ -55,6 +55,7 @@ def build_lib(force=False, verbose=False):
         # MFMA results in VGPRs (unified file on gfx950) so the sweep's v_max3 reads them directly
         ("prot_kernels.hip", ["-ffast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
         ("prot_kernels_f16.hip", ["-ffast-math"]),
+        ("prot_olasave.hip", ["-ffast-math", "-fno-slp-vectorize"]),
         # host logic mirrors the reference's float arithmetic: no fast-math
         ("prot_capi.hip", []),
     ]

@@ -107,6 +107,77 @@ void fft_f64 (std::vector<double>& re, std::vector<double>& im)
 	}
 }
 
+// Constants of olasave_kernel (prot_olasave.hip) for ONE partition of odd taps g (g[s] = fir[2 s + 1], Lg of them, a multiple
+// of 512): H[k] = sum g[s] W^{sk} = -i B[k] W^{(Lg/2) k} W^{-k/2} with B real IF g is antisymmetric about its centre.
+// Returns false (the engine keeps olapoly_kernel and its spectrum table) unless g is antisymmetric in its float values and
+// rho = -B is flat to 1.5e-7 outside `rows` x 256 bins on either side of DC for rows = 1 or 2.
+// Layout of `tab` (floats): f2[12][256] split outer twiddles of thread t (forward at the half-shifted index: W^{(t-1/2) i},
+// W^{(t-1/2) 4 i}; inverse: W^{t i}, W^{4 t i}; i = 1..3), f2[256] W256^{(c-1/2) k2} at [16 k2 + c], f2[rows][256]
+// (rho[q + 256 i], rho[q + 256 (15 - i)]) / mean of thread t, q = (t >> 4) + 16 (t & 15).  gain = mean rho / F.
+bool save_tables (const std::vector<float>& fir, uint32_t F, std::vector<float>& tab, float& gain, int& rows)
+{
+	const size_t Lg = fir.size () / 2;
+	if (F != 4096 || Lg % 512 != 0 || Lg < 512 || Lg > 2048) {
+		return false;
+	}
+	std::vector<double> re (F, 0.0), im (F, 0.0);
+	for (size_t s = 0; s < Lg; ++s) {
+		if (fir[2 * s + 1] != -fir[2 * (Lg - 1 - s) + 1] || fir[2 * s] != 0.f) {
+			return false;
+		}
+		re[s] = fir[2 * s + 1];
+	}
+	fft_f64 (re, im);
+	std::vector<double> rho (F);
+	for (uint32_t k = 0; k < F; ++k) {
+		// conj of P[k] = -i e^{-2 pi i (Lg/2) k / F} e^{+2 pi i k / (2F)}
+		const double a  = 2.0 * M_PI * ((double)(Lg / 2) * k / F - (double)k / (2.0 * F));
+		const double pr = -std::sin (a), pi = -std::cos (a); // P = -i e^{-ia} = (-sin a, -cos a)
+		const double br = re[k] * pr + im[k] * pi, bi = im[k] * pr - re[k] * pi; // H conj(P)
+		if (std::fabs (bi) > 1e-9) {
+			return false;
+		}
+		rho[k] = -br;
+	}
+	for (rows = 1; rows <= 2; ++rows) {
+		double mean = 0;
+		const uint32_t k0 = 256 * rows, k1 = F - 256 * rows;
+		for (uint32_t k = k0; k < k1; ++k) {
+			mean += rho[k];
+		}
+		mean /= (double)(k1 - k0);
+		double dev = 0;
+		for (uint32_t k = k0; k < k1; ++k) {
+			dev = std::max (dev, std::fabs (rho[k] / mean - 1.0));
+		}
+		if (dev > 1.5e-7) {
+			continue;
+		}
+		gain = (float)(mean / F);
+		tab.assign (2 * (size_t)(13 + rows) * 256, 0.f);
+		auto put = [&] (size_t idx, double ang) {
+			tab[2 * idx]     = (float)std::cos (ang);
+			tab[2 * idx + 1] = (float)std::sin (ang);
+		};
+		for (int t = 0; t < 256; ++t) {
+			for (int i = 1; i <= 3; ++i) {
+				put ((size_t)(i - 1) * 256 + t, -2.0 * M_PI * (t - 0.5) * i / F);
+				put ((size_t)(3 + i - 1) * 256 + t, -2.0 * M_PI * (t - 0.5) * 4 * i / F);
+				put ((size_t)(6 + i - 1) * 256 + t, -2.0 * M_PI * (double)t * i / F);
+				put ((size_t)(9 + i - 1) * 256 + t, -2.0 * M_PI * (double)t * 4 * i / F);
+			}
+			put ((size_t)12 * 256 + t, -2.0 * M_PI * ((t & 15) - 0.5) * (t >> 4) / 256.0);
+			const int q = (t >> 4) + 16 * (t & 15);
+			for (int i = 0; i < rows; ++i) {
+				tab[2 * ((size_t)(13 + i) * 256 + t)]     = (float)(rho[q + 256 * i] / mean);
+				tab[2 * ((size_t)(13 + i) * 256 + t) + 1] = (float)(rho[q + 256 * (15 - i)] / mean);
+			}
+		}
+		return true;
+	}
+	return false;
+}
+
 template <typename T>
 struct DevBuf {
 	T*     p   = nullptr;
@@ -249,6 +320,12 @@ struct prot_engine {
 	DevBuf<float2> d_Hp;          // 4096-tap engines (direct form): spectrum of the 2048 odd taps -- short LV2 launches, fp16 path
 
 	DevBuf<float2> d_H, d_tw;
+	// overlap-save, table-free form of the one-partition polyphase engines (prot_olasave.hip): four workgroups per CU
+	bool           use_save = false;
+	DevBuf<float>  d_sv;
+	float          sv_gain = 0.f;
+	int            sv_rows = 0;
+	int            sv_flags = 0; // 1 (PROT_SV_NOASM at creation, tests): every block through the C++ form of olasave_kernel
 	DevBuf<float>  d_lut, d_rot, d_hist[2], d_peaks, d_in, d_out, d_u, d_inter, d_rot_s;
 	// whole-file calls: two sets of staging buffers, a copy stream and events, so that chunk k+1 is uploaded and
 	// de-interleaved while chunk k is swept (cli/phase-rotate.cc:565-587 reads and analyses block by block)
@@ -510,6 +587,18 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 		// of longer FIRs lose 6 % with it and keep equal runs)
 		if (e->info.partitions == np) {
 			rank_runs (p, (int64_t)e->info.run_align, n_chn, n_out, e->wg_slots, e->cus, false);
+		}
+		if (e->use_save) { // one partition of an antisymmetric g: overlap-save, no spectrum table, four workgroups per CU
+			p.sv         = e->d_sv.p;
+			p.sv_gain    = e->sv_gain;
+			p.sv_flags   = e->sv_flags;
+			p.conv_delay = (int)e->info.conv_delay;
+			p.accumulate = 0;
+			hipError_t err = prot::launch_ola_save (p, e->hopseg / 2, e->sv_rows, n_chn, s);
+			if (err != hipSuccess) {
+				return hip_fail (err, "overlap-save ola kernel launch");
+			}
+			return finish ();
 		}
 		for (uint32_t l = 0; l < e->info.partitions / np; ++l) {
 			p.H          = e->d_H.p + (size_t)(np * l) * e->info.fftlen;
@@ -883,6 +972,15 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 		}
 	};
 	std::vector<float2> H_h, tw_h (F);
+	std::vector<float>  sv_h;
+	if (use_poly && n_part == 1 && !(cfg->flags & PROT_CFG_OVERLAP_ADD) && getenv ("PROT_NO_SAVE") == nullptr &&
+	    2 * (inf.dry_delay - inf.conv_delay) == 256 * (32 - (uint32_t)hopseg) && inf.dry_delay % 2 == 0) {
+		e->sv_flags = getenv ("PROT_SV_NOASM") != nullptr ? 1 : 0;
+		e->use_save = hopseg <= 24 && save_tables (fir_taps, F, sv_h, e->sv_gain, e->sv_rows) && e->sv_rows == 1;
+		if (e->use_save && e->cus > 0 && getenv ("PROT_WG_PER_CU") == nullptr) {
+			e->wg_slots = e->cus * 4; // 128 VGPRs, 38 KiB of LDS
+		}
+	}
 	if (use_poly) {
 		std::vector<float> g (inf.firlen / 2);
 		for (size_t i = 0; i < g.size (); ++i) {
@@ -922,8 +1020,11 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	    (use_poly && n_part <= 2 && ((rc = e->d_hist16[0].ensure (hn)) || (rc = e->d_hist16[1].ensure (hn)))) ||
 	    (rc = e->d_hist[1].ensure (hn)) || (rc = e->d_peaks.ensure ((size_t)PROT_MAXSAMPLE * inf.n_chn)) ||
 	    (rc = e->d_angles.ensure (PROT_MAXSAMPLE + 8)) || (rc = e->d_thr.ensure (4 * (size_t)inf.n_chn)) ||
-	    (rc = e->d_stats.ensure (2))) {
+	    (rc = e->d_stats.ensure (2)) || (e->use_save && (rc = e->d_sv.ensure (sv_h.size ())))) {
 		return fail (rc);
+	}
+	if (e->use_save && hipMemcpy (e->d_sv.p, sv_h.data (), sv_h.size () * sizeof (float), hipMemcpyHostToDevice) != hipSuccess) {
+		return fail (PROT_EHIP);
 	}
 	if ((!Hp_h.empty () && hipMemcpy (e->d_Hp.p, Hp_h.data (), Hp_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess) ||
 	    hipMemcpy (e->d_H.p, H_h.data (), H_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess ||
@@ -968,6 +1069,7 @@ void prot_engine_destroy (prot_engine* e)
 		(void)hipStreamSynchronize (e->stream);
 	}
 	e->d_H.release ();
+	e->d_sv.release ();
 	e->d_Hp.release ();
 	e->d_tw.release ();
 	e->d_lut.release ();

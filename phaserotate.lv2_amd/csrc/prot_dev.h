@@ -1,0 +1,121 @@
+// prot_dev.h -- device helpers shared by the OLA kernels (prot_kernels.hip, prot_olasave.hip): the virtual input stream
+// [history | input | silence], SGPR-pinned stream pointers, the fused history write, the LDS exchange geometry.
+#pragma once
+#include "prot_fft.h"
+#include "prot_kernels.h"
+
+namespace prot {
+
+enum { MODE_ROT = 0, MODE_RAMP = 1, MODE_HILBERT = 2 };
+
+// ------------------------------------------------------------------ helpers
+// virtual stream [hist | in | silence] at index i (i may be negative)
+template <class S>
+PROT_DEV float ldv (const S* __restrict__ in, int64_t n_in, const S* __restrict__ hist, int hist_len, int64_t i)
+{
+	if (i >= 0) {
+		return i < n_in ? (float)in[i] : 0.f;
+	}
+	const int64_t h = i + hist_len;
+	return (hist != nullptr && h >= 0) ? (float)hist[h] : 0.f;
+}
+
+// pin a wave-uniform pointer in an SGPR pair: the loads/stores that use it take the
+// "saddr + 32-bit lane offset + immediate" form (half the address traffic of 64-bit per-lane
+// addresses and no VALU pointer arithmetic); opaque to loop strength reduction, which would
+// otherwise turn the bases back into per-lane pointer induction variables
+#define PROT_GLOBAL __attribute__ ((address_space (1)))
+template <class P>
+PROT_DEV PROT_GLOBAL P* uniform_ptr (P* q)
+{
+	const uint64_t b  = reinterpret_cast<uint64_t> (q);
+	const uint32_t lo = __builtin_amdgcn_readfirstlane ((uint32_t)b);
+	const uint32_t hi = __builtin_amdgcn_readfirstlane ((uint32_t)(b >> 32));
+	return (PROT_GLOBAL P*)(((uint64_t)hi << 32) | lo);
+}
+
+// the same for a plain (generic address space) pointer: an SGPR pair for inline-asm "s" operands
+template <class P>
+PROT_DEV P* uniform_ptr_generic (P* q)
+{
+	const uint64_t b  = reinterpret_cast<uint64_t> (q);
+	const uint32_t lo = __builtin_amdgcn_readfirstlane ((uint32_t)b);
+	const uint32_t hi = __builtin_amdgcn_readfirstlane ((uint32_t)(b >> 32));
+	return (P*)(((uint64_t)hi << 32) | lo);
+}
+
+// Fused history advance: workgroup b of a channel copies slice b of the next call's history (the last
+// hist_len frames of [hist | in | silence]) -- saves the separate history kernel and its launch gap on
+// small stateful launches (LV2 run(), batched buffers).  Called by every workgroup exactly once: on its early
+// return, or at the very END of the kernel (after the main loop, when the loop's registers are dead -- called
+// up front it perturbed the allocation of kernels that sit at the 256-VGPR limit into spilling inside the loop).
+template <class S>
+PROT_DEV void hist_write_slice (const OlaParamsT<S>& p, int c, int t)
+{
+	if (p.hist_out == nullptr) {
+		return;
+	}
+	const int per = (p.hist_len + (int)gridDim.x - 1) / (int)gridDim.x;
+	const int i0  = (int)blockIdx.x * per;
+	const int i1  = i0 + per < p.hist_len ? i0 + per : p.hist_len;
+	const S* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
+	const S* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
+	S* __restrict__ ho         = p.hist_out + (int64_t)c * p.hist_len;
+	for (int i = i0 + t; i < i1; i += 256) {
+		ho[i] = (S)ldv (in, p.n_in, hist, p.hist_len, p.n_in - p.hist_len + i);
+	}
+}
+
+// The run [r0, r0 + rlen) of output frames this workgroup emits.  One-round launches (every workgroup resident at once,
+// p.rank_cu > 0) give the runs unequal lengths by DISPATCH RANK: the hardware arbitrates oldest-first, so of the workgroups
+// of a CU the one dispatched first runs ahead and the last one finishes alone; workgroups are dealt out in id order, one
+// per CU per round, so id / CUs is the rank (if a dispatcher ever does it differently the lengths are merely not ideal --
+// the runs still tile the stream).  Which run: workgroups are dealt round-robin over the 8 XCDs, so XCD k would own the
+// runs k, k + 8, ... -- rotating the position inside each group of eight consecutive runs by the group's number gives every
+// XCD all eight residues in turn (-2 %, measured on olapoly_kernel).
+template <class S>
+PROT_DEV void run_of_workgroup (const OlaParamsT<S>& p, int64_t& r0, int64_t& rlen)
+{
+	int bx = (int)blockIdx.x;
+	if ((bx | 7) < (int)gridDim.x) {
+		bx = (bx & ~7) | ((bx + (bx >> 3)) & 7);
+	}
+	rlen = p.run_frames;
+	if (p.rank_cu > 0) {
+		const int id = (int)blockIdx.y * (int)gridDim.x + bx, id0 = (int)blockIdx.y * (int)gridDim.x;
+		r0           = 0;
+		const int last = p.n_rank - 1;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { // runs of rank k in front of this one, within the channel
+			const int lo = k * p.rank_cu > id0 ? k * p.rank_cu : id0;
+			const int hi = (k >= last || (k + 1) * p.rank_cu > id) ? id : (k + 1) * p.rank_cu;
+			r0 += (k <= last && hi > lo) ? (int64_t)(hi - lo) * p.rank_frames[k] : 0;
+		}
+		const int rk = id / p.rank_cu > last ? last : id / p.rank_cu;
+		rlen         = p.rank_frames[rk];
+	} else {
+		r0 = (int64_t)bx * p.run_frames;
+	}
+}
+
+// ------------------------------------------------------------ LDS exchange geometry of the 4096-point transform
+// 16 x 16 x 16: thread t keeps 16 complex values; the exchange between pass 1 and 2 (and its inverse mirror) goes through
+// slots k * kL1 + t (workgroup-wide, one barrier), the one between pass 2 and 3 is a 16 x 16 transposition inside each
+// 16-lane group, in the group's own chunk [th * kL1, th * kL1 + 272) with row stride kG (wave-local: DS instructions of one
+// wave execute in order, no s_barrier).  Strides chosen conflict-free for ds_write_b64 / ds_read_b64.
+constexpr int kL1 = 272;
+constexpr int kG  = 17;
+constexpr int kLdsExchange = 16 * kL1; // complex slots
+
+// exchange accesses are volatile, address-space-3 pointers: the backend keeps one ds_read_b64 / ds_write_b64 per element in
+// source order instead of fusing neighbours into ds_read2_b64 / ds_write2_b64 (8 and 13 LDS cycles against 2 x 2 and 2 x 6)
+#define PROT_LDS_PTR(T) volatile __attribute__ ((address_space (3))) typename T::cplx
+
+PROT_DEV void wave_sync ()
+{
+	__builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier ();
+	__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "wavefront");
+}
+
+} // namespace prot

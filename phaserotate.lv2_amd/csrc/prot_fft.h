@@ -146,6 +146,8 @@ typedef _Float16 h2 __attribute__ ((ext_vector_type (2)));
 	struct NAME {                                                                                            \
 		typedef C cplx;                                                                                      \
 		PROT_DEV C mk (float x, float y) { return C{ (E)x, (E)y }; }                                         \
+		/* a * r (real): a plain product, which the compiler may contract into a following add */           \
+		PROT_DEV C scale (C a, float r) { return a * C{ (E)r, (E)r }; }                                      \
 		/* a + (-j) b = (a.x + b.y, a.y - b.x) */                                                            \
 		PROT_DEV C add_mj (C a, C b)                                                                         \
 		{                                                                                                    \
@@ -218,6 +220,17 @@ PROT_PK_OPS (pk32, f2, float, "f32");
 PROT_PK_OPS (pk16, h2, _Float16, "f16");
 #undef PROT_PK_OPS
 
+// pk32 with every product spelled out as an instruction of its own: olasave_kernel's C++ blocks must round exactly like
+// its generated loop (tools/gen/gen_olasave.py), so nothing may be contracted into a neighbouring add
+struct pk32a : pk32 {
+	PROT_DEV f2 scale (f2 a, float r)
+	{
+		f2 d;
+		asm ("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "s"(f2{ r, r }));
+		return d;
+	}
+};
+
 // 4-point DFT on packed values; CROT: operand c arrives un-rotated and still
 // has to be multiplied by -j (DIR > 0) / +j (DIR < 0) -- the W16^4 twiddle
 // folded into the butterfly.
@@ -255,9 +268,9 @@ PROT_DEV typename O::cplx pkt_mul_w16 (typename O::cplx a)
 	constexpr int   m  = M & 15;
 	static_assert (m == 1 || m == 2 || m == 3 || m == 6 || m == 9, "twiddle not used by fft16");
 	if (m == 2) { // R(1 -+ j) a
-		return (DIR > 0 ? O::add_mj (a, a) : O::sub_mj (a, a)) * O::mk (R, R);
+		return O::scale (DIR > 0 ? O::add_mj (a, a) : O::sub_mj (a, a), R);
 	} else if (m == 6) { // R(-1 -+ j) a
-		return (DIR > 0 ? O::sub_mj (a, a) : O::add_mj (a, a)) * O::mk (-R, -R);
+		return O::scale (DIR > 0 ? O::sub_mj (a, a) : O::add_mj (a, a), -R);
 	} else {
 		constexpr float cw = (m == 1) ? C1 : (m == 3) ? S1 : /* 9 */ -C1;
 		constexpr float sw = (m == 1) ? S1 : (m == 3) ? C1 : /* 9 */ -S1;

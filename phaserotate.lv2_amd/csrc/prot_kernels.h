@@ -41,6 +41,13 @@ struct OlaParamsT {
 	// steady rotation by value ({ca, sa} of channels 0..15, read when rot == NULL): two floats per channel ride in the
 	// kernel arguments instead of a host-to-device copy in front of every launch (4 us on a 20 us launch)
 	float         rot_v[2 * kRotInline];
+	// olasave_kernel: per-engine constants (prot_engine_create): f2[12][256] split outer twiddles of thread t (forward at
+	// the half-shifted index: W^{(t-1/2) i}, W^{(t-1/2) 4i}; inverse: W^{t i}, W^{4 t i}; i = 1..3), f2[256] the
+	// half-shifted W256 table W256^{(c-1/2) k2} at [16 k2 + c], f2[2][256] the |B| factors of the rows next to DC
+	// ((rho[q + 256 i], rho[q + 256 (15 - i)]) of thread t, q = (t >> 4) + 16 (t & 15)); sv_gain = mean |B| / 4096
+	const float*  sv;
+	float         sv_gain;
+	int32_t       sv_flags;   // 1: every block through the C++ form (cross-check of the generated loop)
 };
 typedef OlaParamsT<float>    OlaParams;
 typedef OlaParamsT<_Float16> OlaParamsH; // fp16 sample path (BASELINE config 5)
@@ -60,6 +67,10 @@ hipError_t launch_ola4096_p2 (const OlaParams& p, int n_chn, hipStream_t s);
 hipError_t launch_ola_poly (const OlaParams& p, int n_part, int hop_rows, int n_chn, hipStream_t s);
 // the same on fp16 samples (no accumulating launches: FIRs of up to 8192 taps): BASELINE config 5
 hipError_t launch_ola_poly_f16 (const OlaParamsH& p, int n_part, int hop_rows, int n_chn, hipStream_t s);
+
+// overlap-save, table-free form of launch_ola_poly for one partition of an antisymmetric g (prot_olasave.hip): four
+// workgroups per CU; hop_rows in {8, 10, 12}, n_rho_rows = 1; p.sv / p.sv_gain set; dry_delay even
+hipError_t launch_ola_save (const OlaParams& p, int hop_rows, int n_rho_rows, int n_chn, hipStream_t s);
 
 // fp16 sample path (BASELINE config 5): half samples in HBM, packed-half butterflies,
 // fp32 overlap-add + rotation.  Stateless, steady rotation.

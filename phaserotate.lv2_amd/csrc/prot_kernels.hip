@@ -40,6 +40,7 @@
 //   running maxima in 6 VGPRs per wave, unsigned atomicMax at the end.
 #include "prot_fft.h"
 #include "prot_kernels.h"
+#include "prot_dev.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -82,63 +83,14 @@ struct Stamps {
 };
 #endif
 
-// ------------------------------------------------------------------ helpers
-// virtual stream [hist | in | silence] at index i (i may be negative)
-template <class S>
-PROT_DEV float ldv (const S* __restrict__ in, int64_t n_in, const S* __restrict__ hist, int hist_len, int64_t i)
-{
-	if (i >= 0) {
-		return i < n_in ? (float)in[i] : 0.f;
-	}
-	const int64_t h = i + hist_len;
-	return (hist != nullptr && h >= 0) ? (float)hist[h] : 0.f;
-}
-
-// pin a wave-uniform pointer in an SGPR pair: the loads/stores that use it take the
-// "saddr + 32-bit lane offset + immediate" form (half the address traffic of 64-bit per-lane
-// addresses and no VALU pointer arithmetic); opaque to loop strength reduction, which would
-// otherwise turn the bases back into per-lane pointer induction variables
-#define PROT_GLOBAL __attribute__ ((address_space (1)))
-template <class P>
-PROT_DEV PROT_GLOBAL P* uniform_ptr (P* q)
-{
-	const uint64_t b  = reinterpret_cast<uint64_t> (q);
-	const uint32_t lo = __builtin_amdgcn_readfirstlane ((uint32_t)b);
-	const uint32_t hi = __builtin_amdgcn_readfirstlane ((uint32_t)(b >> 32));
-	return (PROT_GLOBAL P*)(((uint64_t)hi << 32) | lo);
-}
-
-// Fused history advance: workgroup b of a channel copies slice b of the next call's history (the last
-// hist_len frames of [hist | in | silence]) -- saves the separate history kernel and its launch gap on
-// small stateful launches (LV2 run(), batched buffers).  Called by every workgroup exactly once: on its early
-// return, or at the very END of the kernel (after the main loop, when the loop's registers are dead -- called
-// up front it perturbed the allocation of kernels that sit at the 256-VGPR limit into spilling inside the loop).
-template <class S>
-PROT_DEV void hist_write_slice (const OlaParamsT<S>& p, int c, int t)
-{
-	if (p.hist_out == nullptr) {
-		return;
-	}
-	const int per = (p.hist_len + (int)gridDim.x - 1) / (int)gridDim.x;
-	const int i0  = (int)blockIdx.x * per;
-	const int i1  = i0 + per < p.hist_len ? i0 + per : p.hist_len;
-	const S* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
-	const S* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
-	S* __restrict__ ho         = p.hist_out + (int64_t)c * p.hist_len;
-	for (int i = i0 + t; i < i1; i += 256) {
-		ho[i] = (S)ldv (in, p.n_in, hist, p.hist_len, p.n_in - p.hist_len + i);
-	}
-}
-
 // ------------------------------------------------------------ OLA, FFT-4096
-constexpr int kL1 = 272; // exchange between pass 1 and 2 (and inverse mirror)
+// (kL1 = 272, the exchange stride between pass 1 and 2, and the MODE_* enum live in prot_dev.h)
 constexpr int kL2 = 258; // forward exchange 2 and inverse exchange A share slots (n0*kL2 + t):
                          // conflict-free b64 reads on the inverse side, 2-way on the forward
                          // side stores (8 vs 6 cycles) -- cheaper than the barrier it removes
 constexpr int kL3 = kL2;
 constexpr int kLdsRegion = 16 * kL1;
 
-enum { MODE_ROT = 0, MODE_RAMP = 1, MODE_HILBERT = 2 };
 
 // the 2*HOPSEG frames thread t contributes to the hop pair whose block A reads in[iA ...]
 template <int HOPSEG>
@@ -594,14 +546,7 @@ struct T16 {
 //    to its multiply and every one of them stalls for the full LDS latency;
 //  * every value goes to the exchange as soon as its twiddle multiply is done, so the
 //    VGPR->LDS transfers (6 cycles each) run under the remaining multiplies.
-constexpr int kG = 17;
-
-PROT_DEV void wave_sync ()
-{
-	__builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier ();
-	__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "wavefront");
-}
+// (kG = 17, wave_sync and PROT_LDS_PTR live in prot_dev.h)
 
 // slot of bin i (0..2048) in the digit-swapped spectrum table
 PROT_DEV int swap_lo_digits (int i)
@@ -609,7 +554,6 @@ PROT_DEV int swap_lo_digits (int i)
 	return (i & ~255) | ((i & 15) << 4) | ((i >> 4) & 15);
 }
 
-#define PROT_LDS_PTR(T) PROT_LDSQ __attribute__ ((address_space (3))) typename T::cplx
 
 // issue the reads of W256^{k tl}, k = 1..15 (twm[16 k + tl]: neighbouring lanes, conflict-free)
 template <class T>

@@ -840,3 +840,80 @@ def test_rank_weighted_runs_ragged_sizes(pkg, kind, param, chn, n):
         d = (y1[c * stride:c * stride + n] - y2[c * stride:c * stride + n]).abs()
         assert d.max().item() < TOL, (c, int(d.argmax()))
     e.close()
+
+
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("chn", [3, 4, 6])
+def test_rank_weighted_runs_three_and_more_channels(pkg, chn, half):
+    """rank_runs with three or more channels: a channel may consist of lower-rank workgroups only, and the covering loop
+    used to lengthen the LAST rank for ever (round-2 advisor finding: the host call never returned).  One-shot launches at
+    sizes that take the rank-weighted path (>= 12 blocks per run at one round of resident workgroups) against the same
+    streams pushed through in stateful chunks; fp32 and fp16 samples."""
+    import torch
+    dev = torch.device("cuda:0")
+    e = pkg.Engine(1, 48000, chn)
+    slots = 256 * (4 if half else 3)
+    n = (slots // chn + 1) * 13 * 5120 + 777
+    stride = n + 6
+    g = torch.Generator(device=dev).manual_seed(99 + chn)
+    x = torch.rand(chn * stride, generator=g, device=dev) - 0.5
+    ang = np.linspace(0.3, 2.7, chn)
+    rot = np.stack([np.cos(ang), np.sin(ang)], 1).astype(np.float32).ravel()
+    if half:
+        x = x.half()
+        y1, y2 = torch.zeros_like(x), torch.zeros_like(x)
+        esz, one, tol = 2, e.apply_dev_f16, 4e-3
+    else:
+        y1, y2 = torch.zeros_like(x), torch.zeros_like(x)
+        esz, one, tol = 4, e.apply_dev, TOL
+    torch.cuda.synchronize()
+    if half:
+        one(x.data_ptr(), stride, n, y1.data_ptr(), stride, n, rot, flags=pkg.F_STATELESS)
+    else:
+        one(x.data_ptr(), stride, n, y1.data_ptr(), stride, n, rot, pkg.F_STATELESS)
+    pos, k = 0, 0
+    while pos < n:
+        m = min(n - pos, 900_001 + 7919 * (k % 5))
+        if half:
+            one(x.data_ptr() + esz * pos, stride, m, y2.data_ptr() + esz * pos, stride, m, rot, flags=0)
+        else:
+            one(x.data_ptr() + esz * pos, stride, m, y2.data_ptr() + esz * pos, stride, m, rot, 0)
+        pos += m
+        k += 1
+    e.sync()
+    for c in range(chn):
+        d = (y1[c * stride:c * stride + n].float() - y2[c * stride:c * stride + n].float()).abs()
+        assert d.max().item() < tol, (c, int(d.argmax()), d.max().item())
+    e.close()
+
+
+@pytest.mark.parametrize("kind,param", [(1, 48000), (1, 96000), (0, 2048)])
+def test_generated_loop_and_cpp_blocks_give_the_same_bits(pkg, kind, param):
+    """olasave_kernel runs whole in-range blocks through its generated assembly loop and every other block through C++
+    code with the same packed instructions in the same order: the two must agree BIT FOR BIT (sharded and chunked sweeps
+    rely on it: where a chunk ends decides which path a block takes).  One stream through an engine created with
+    PROT_SV_NOASM (every block the C++ way) and through a default engine; also the Hilbert-only form the sweep uses."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 3_000_017
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.rand(n, generator=g, device=dev) - 0.5
+    rot = np.array([0.28, -0.96], np.float32)
+    outs = []
+    for noasm in (False, True):
+        if noasm:
+            os.environ["PROT_SV_NOASM"] = "1"
+        try:
+            e = pkg.Engine(kind, param, 1)
+        finally:
+            os.environ.pop("PROT_SV_NOASM", None)
+        y, u = torch.zeros_like(x), torch.zeros_like(x)
+        torch.cuda.synchronize()
+        e.apply_dev(x.data_ptr(), n, n, y.data_ptr(), n, n, rot, pkg.F_STATELESS)
+        e.hilbert_dev(x.data_ptr(), n, n, u.data_ptr(), n, n, pkg.F_STATELESS)
+        e.sync()
+        outs.append((y, u))
+        e.close()
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][0].abs().max()) > 0.1

@@ -55,8 +55,14 @@ res = {t: [] for t in tags}
 for r in range(rounds):
     for t in tags:
         env = dict(os.environ)
-        if t != "main":
-            env["PROT_LIB_PATH"] = os.path.join(ROOT, "phaserotate.lv2_amd", "lib", "variants", "libprot_hip_%s.so" % t)
+        lib_tag = t
+        if "@" in t:  # "<lib tag>@NAME=VAL[,NAME=VAL]": environment switches of one library (e.g. main@PROT_NO_SAVE=1)
+            lib_tag, _, ev = t.partition("@")
+            for kv in ev.split(","):
+                k, _, v = kv.partition("=")
+                env[k] = v
+        if lib_tag != "main":
+            env["PROT_LIB_PATH"] = os.path.join(ROOT, "phaserotate.lv2_amd", "lib", "variants", "libprot_hip_%s.so" % lib_tag)
         p = subprocess.run([sys.executable, "-c", CHILD, cases], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")]
         if not line:

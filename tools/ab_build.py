@@ -18,5 +18,6 @@ for arg in sys.argv[1:]:
             "-amdgpu-mfma-vgpr-form"] + extra + ["-c", os.path.join(b.CSRC, "prot_kernels.hip"), "-o", o])
     lib = os.path.join(vdir, "libprot_hip_%s.so" % tag)
     b._run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, o,
-            os.path.join(b.OBJDIR, "prot_kernels_f16.o"), os.path.join(b.OBJDIR, "prot_capi.o"), "-lpthread"])
+            os.path.join(b.OBJDIR, "prot_kernels_f16.o"), os.path.join(b.OBJDIR, "prot_olasave.o"),
+            os.path.join(b.OBJDIR, "prot_capi.o"), "-lpthread"])
     print("built", lib)

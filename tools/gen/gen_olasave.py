@@ -1,0 +1,639 @@
+#!/usr/bin/env python3
+"""Generator of the steady-state loop of olasave_kernel (phaserotate.lv2_amd/csrc/prot_olasave.hip) as gfx950 assembly with
+hand-allocated registers: hipcc needs ~150 VGPRs for this loop (52..140 B/lane of scratch at the 128 that four workgroups
+per CU allow, and a spilled build is slower than the three-per-CU kernel), the loop itself needs 120.
+
+    python3 tools/gen/gen_olasave.py            -> csrc/prot_olasave_asm.inc  (+ a self-test of every variant in the emulator)
+    python3 tools/gen/gen_olasave.py --check    -> self-test only
+
+One asm block = a RUN of n >= 1 consecutive "fast" blocks of one channel-stream (every frame the blocks read lies inside the
+input array, 8-byte aligned streams, whole blocks): prologue (addresses, twiddle registers, the first block's 16 rows), then
+per block: build (p, q) -> forward transform at the half-shifted index -> constants -> inverse -> mix with the dry rows ->
+store, with the next block's new rows prefetched behind the first barrier.  The maths, pass by pass, is tools/model/
+olasave_model.py; the C++ kernel around the block handles everything else (history, edges, per-frame rotation) with the
+same packed instructions in the same order, so the two paths give the same bits.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "model"))
+from isa import Prog, Emu, V, VP, S, SP, Lit  # noqa: E402
+
+KL1, KG = 272, 17                 # LDS exchange strides (prot_dev.h)
+LDS_TWM, LDS_TWF = 34816, 36864   # byte offsets of the W256 tables behind the exchange area
+MODE_ROT, MODE_HILBERT = 0, 2
+
+# ---- SGPR plan (the asm block clobbers s34..s99; s32 and s100.. are reserved by the compiler) ----
+S_IN, S_OUT = SP(34), SP(36)      # frame (row 0, thread 0).q of the current block; first output frame of the current block
+S_NBLK, S_LDS = S(38), S(39)
+S_SV = SP(40)
+S_ROT = SP(42)                    # (ca, sa * gain): one pair, the half picked by op_sel
+S_C32 = {k: SP(44 + 2 * (k - 1)) for k in range(1, 16)}            # s44..s73
+S_RR, S_W1, S_W3, S_W9 = SP(74), SP(76), SP(78), SP(80)            # (R, -R), (C1, -S1), (S1, -C1), (-C1, S1)
+S_TWI = [SP(82 + 2 * i) for i in range(6)]                         # s82..s93: W8192^{1,2,3}, W2048^{1,2,3}
+S_T = [S(94), S(95), S(96), S(97)]                                 # readlane temporaries
+S_A0 = SP(98)                                                      # address temporary
+SGPR_CLOBBER = range(34, 100)
+
+C1, S1, RR = 0.92387953251128675613, 0.38268343236508977173, 0.70710678118654752440
+
+
+class Gen:
+    def __init__(self, HS, MODE, NA=1):
+        self.HS, self.MODE, self.NA = HS, MODE, NA
+        self.NT = 16 - HS
+        self.R0 = self.NT // 2
+        self.BLK = 512 * HS
+        P = self.P = Prog()
+        n = 0
+        self.D = [VP(2 * k) for k in range(16)]
+        n = 32
+        self.K = {}
+        for r in range(self.R0, 16):
+            self.K[r] = VP(n)
+            n += 2
+        self.N = []
+        for i in range(HS):
+            self.N.append(VP(n))
+            n += 2
+        self.TW = [None] + [VP(n + 2 * i) for i in range(3)] + [None] + [VP(n + 6 + 2 * i) for i in range(3)]  # A[1..3] at [1..3], B[1..3] at [5..7]
+        n += 12
+        self.RHO = [VP(n + 2 * i) for i in range(NA)]
+        n += 2 * NA
+        self.G_CAR, self.G_NX = V(n), V(n + 1)
+        self.A_W1, self.A_R1, self.A_X2, self.A_TL, self.VOFF, self.VG = V(n + 2), V(n + 3), V(n + 4), V(n + 5), V(n + 6), V(n + 7)
+        n += 8
+        self.TMP = []
+        cap = 119   # the compiler keeps its own live values (and SGPR spill lanes) in what is left of 128
+        while n + 1 <= cap:
+            self.TMP.append(VP(n))
+            n += 2
+        self.n_vgpr = n
+        assert len(self.TMP) >= 6, "temporaries"
+        # roles of the temporaries
+        self.TB = self.TMP[:4]                 # twiddle batch (also: derived inverse twiddle, epilogue products)
+        self.TR = self.TMP[4:5]                # complex-multiply scratch
+        self.TT = self.TMP[5:9] if len(self.TMP) >= 9 else self.TMP[5:6] * 4  # radix-4 scratch (one per butterfly in flight)
+        self.nbf = len(set(t.n for t in self.TT))
+
+    # ------------------------------------------------------------ packed helpers (prot_fft.h's pk32 ops)
+    def add(self, d, a, b): self.P.pk("add", d, [a, b])
+    def sub(self, d, a, b): self.P.pk("add", d, [a, b], neg_lo=[0, 1], neg_hi=[0, 1])
+    def add_mj(self, d, a, b): self.P.pk("add", d, [a, b], op_sel=[0, 1], op_sel_hi=[1, 0], neg_hi=[0, 1])
+    def sub_mj(self, d, a, b): self.P.pk("add", d, [a, b], op_sel=[0, 1], op_sel_hi=[1, 0], neg_lo=[0, 1])
+
+    def cmul_ops(self, d, a, w, DIR, r):
+        """d = a * w (DIR > 0) or a * conj(w) (DIR < 0); r = scratch pair; returns two thunks"""
+        P = self.P
+        if DIR > 0:
+            return [lambda: P.pk("mul", r, [a, w], op_sel=[0, 0], op_sel_hi=[0, 1]),
+                    lambda: P.pk("fma", d, [a, w, r], op_sel=[1, 1, 0], op_sel_hi=[1, 0, 1], neg_lo=[0, 1, 0])]
+        return [lambda: P.pk("mul", r, [a, w], op_sel=[0, 0], op_sel_hi=[0, 1], neg_hi=[0, 1]),
+                lambda: P.pk("fma", d, [a, w, r], op_sel=[1, 1, 0], op_sel_hi=[1, 0, 1])]
+
+    def cmul(self, d, a, w, DIR, r):
+        for f in self.cmul_ops(d, a, w, DIR, r):
+            f()
+
+    def radix4_ops(self, a, b, c, d, DIR, crot, T):
+        """pkt_radix4 in place with one scratch pair (same operations and operand order)"""
+        ops = []
+        if not crot:
+            ops.append(lambda: self.add(T, a, c))
+            ops.append(lambda: self.sub(a, a, c))
+        elif DIR > 0:
+            ops.append(lambda: self.add_mj(T, a, c))
+            ops.append(lambda: self.sub_mj(a, a, c))
+        else:
+            ops.append(lambda: self.sub_mj(T, a, c))
+            ops.append(lambda: self.add_mj(a, a, c))
+        ops.append(lambda: self.add(c, b, d))      # t2
+        ops.append(lambda: self.sub(d, b, d))      # t3
+        if DIR > 0:
+            ops.append(lambda: self.add_mj(b, a, d))
+            ops.append(lambda: self.sub_mj(d, a, d))
+        else:
+            ops.append(lambda: self.sub_mj(b, a, d))
+            ops.append(lambda: self.add_mj(d, a, d))
+        ops.append(lambda: self.add(a, T, c))
+        ops.append(lambda: self.sub(c, T, c))
+        return ops
+
+    @staticmethod
+    def interleave(lists):
+        out, i = [], 0
+        lists = [list(l) for l in lists]
+        while any(lists):
+            for l in lists:
+                if l:
+                    out.append(l.pop(0))
+        return out
+
+    def run_ops(self, ops):
+        for f in ops:
+            f()
+
+    def mul_w16_ops(self, x, DIR, m, r):
+        """pkt_mul_w16: x *= W16^m (conjugate for DIR < 0), m in {1, 2, 3, 6, 9}"""
+        P = self.P
+        if m == 2:
+            return [lambda: (self.add_mj if DIR > 0 else self.sub_mj)(r, x, x), lambda: P.pk("mul", x, [r, S_RR], op_sel=[0, 0], op_sel_hi=[1, 0])]
+        if m == 6:
+            return [lambda: (self.sub_mj if DIR > 0 else self.add_mj)(r, x, x), lambda: P.pk("mul", x, [r, S_RR], op_sel=[0, 1], op_sel_hi=[1, 1])]
+        w = {1: S_W1, 3: S_W3, 9: S_W9}[m]
+        return self.cmul_ops(x, x, w, DIR, r)
+
+    def stage1_twiddle_ops(self, v, DIR, rs):
+        """pkt_stage1_twiddles; rs = scratch pairs to rotate through"""
+        spec = [(5, 1), (6, 2), (7, 3), (9, 2), (11, 6), (13, 3), (14, 6), (15, 9)]
+        lists = []
+        for i, (k, m) in enumerate(spec):
+            lists.append(self.mul_w16_ops(v[k], DIR, m, rs[i % len(rs)]))
+        # group so that scratch pairs are not reused while live: interleave in groups of len(rs)
+        out = []
+        for g in range(0, len(lists), len(rs)):
+            out += self.interleave(lists[g:g + len(rs)])
+        return out
+
+    def stage1(self, v, DIR):
+        bf = [self.radix4_ops(v[be], v[4 + be], v[8 + be], v[12 + be], DIR, False, self.TT[be % 4]) for be in range(4)]
+        if self.nbf >= 4:
+            self.run_ops(self.interleave(bf))
+        else:
+            for l in bf:
+                self.run_ops(l)
+
+    def stage2_lists(self, v, DIR):
+        return [self.radix4_ops(v[4 * ka], v[4 * ka + 1], v[4 * ka + 2], v[4 * ka + 3], DIR, ka == 2, self.TT[ka % 4]) for ka in range(4)]
+
+    def scratch_pairs(self):
+        return self.TR + self.TB
+
+    # ------------------------------------------------------------ phases
+    def prologue(self):
+        P, HS, NT = self.P, self.HS, self.NT
+        P.comment("---- prologue: addresses")
+        t = self.TMP[0].lo   # holds t (copied from the input operand by the wrapper text)
+        tl, th, tmp = self.TMP[0].hi, self.TMP[1].lo, self.TMP[1].hi
+        P.v_and(tl, Lit(15), t)
+        P.v_lshr(th, Lit(4), t)
+        P.v_lshl(self.VOFF, Lit(3), t)                          # 8 t
+        P.v_add_u32(self.A_W1, S_LDS, self.VOFF)
+        P.v_mul_u24(tmp, Lit(KL1 * 8), th)
+        P.v_add_u32(tmp, S_LDS, tmp)                            # lds + 8 * 272 th
+        P.v_lshl(self.A_TL, Lit(3), tl)                         # 8 tl
+        P.v_add_u32(self.A_R1, tmp, self.A_TL)
+        P.v_mul_u24(self.A_X2, Lit(KG * 8), tl)
+        P.v_add_u32(self.A_X2, tmp, self.A_X2)
+        P.v_add_u32(self.A_TL, S_LDS, self.A_TL)
+        # gather offsets: lane l of a wave fetches the frame in front of row (l)'s first sample of this wave
+        lane, wv = self.TMP[2].lo, self.TMP[2].hi
+        P.v_and(lane, Lit(63), t)
+        P.v_lshr(wv, Lit(6), t)
+        P.v_lshl(wv, Lit(9), wv)                                # 512 B per wave
+        # VG = 2048 * (lane < HS ? lane : 0) + 512 wave        (steady state: lanes 0..HS-1 <-> new rows NT..15)
+        # lane < HS  <=>  select by arithmetic: min(lane, HS) then zero if == HS ... done with a small table of moves instead:
+        # v_cmp is avoided (VCC): rows = lane clamped by repeated and/shift is awkward -> use v_mul_u24 with a 0/1 mask from (HS-1-lane) >> 31
+        m = self.TMP[3].lo
+        P.v_add_u32(m, Lit(-(HS)), lane)                        # lane - HS  (negative if lane < HS)
+        P.v_lshr(m, Lit(31), m)                                 # 1 if lane < HS
+        P.v_mul_u24(m, m, lane)                                 # lane or 0
+        P.v_lshl(m, Lit(11), m)
+        P.v_add_u32(self.VG, m, wv)
+        # first block: rows 0..NT-1 come with gathers in lanes HS-NT .. HS-1 (where the steady state leaves the carried ones)
+        vg0 = self.TMP[3].hi
+        m2, m3 = self.TMP[4].lo, self.TMP[4].hi
+        P.v_add_u32(m2, Lit(-(HS - NT)), lane)                  # lane - (HS - NT)
+        P.v_add_u32(m3, Lit(-(HS)), lane)
+        P.v_lshr(m3, Lit(31), m3)                               # lane < HS
+        P.v_lshr(m, Lit(31), m2)                                # lane < HS-NT  -> invalid
+        P.v_add_u32(m, Lit(-1), m)                              # 0 if invalid else 0xffffffff ... (m was 1 -> 0, 0 -> -1)
+        P.v_and(m2, m, m2)                                      # lane - (HS-NT) or 0
+        P.v_mul_u24(m2, m3, m2)
+        P.v_lshl(m2, Lit(11), m2)
+        P.v_add_u32(vg0, m2, wv)
+        P.comment("---- prologue: twiddle registers, |B| factors")
+        for j in range(3):
+            P.s_add_u32(S_A0.lo, S_SV.lo, Lit(4096 * j))
+            P.s_addc_u32(S_A0.hi, S_SV.hi, Lit(0))
+            for e in range(2):
+                i = 2 * j + e                                   # table rows 0..5: A[1..3], B[1..3]
+                dst = self.TW[1 + i] if i < 3 else self.TW[5 + i - 3]
+                P.global_load_dwordx2(dst, self.VOFF, S_A0, 2048 * e)
+        for i in range(self.NA):
+            off = (13 + i) * 2048
+            P.s_add_u32(S_A0.lo, S_SV.lo, Lit(off))
+            P.s_addc_u32(S_A0.hi, S_SV.hi, Lit(0))
+            P.global_load_dwordx2(self.RHO[i], self.VOFF, S_A0, 0)
+        P.comment("---- prologue: the first block's rows")
+        # rows 0..NT-1 -> K[HS .. 15] (the registers the steady state carries them in); gathers -> G_CAR lanes HS-NT..
+        for mpair in range(NT // 2):
+            P.s_add_u32(S_A0.lo, S_IN.lo, Lit(4096 * mpair))
+            P.s_addc_u32(S_A0.hi, S_IN.hi, Lit(0))
+            for e in range(2):
+                P.global_load_dwordx2(self.K[HS + 2 * mpair + e], self.VOFF, S_A0, 2048 * e)
+        P.global_load_dword(self.G_CAR, vg0, S_IN, -4)
+        self.load_new_rows(0)
+        P.comment("---- prologue done")
+
+    def load_new_rows(self, blk_ahead):
+        """rows NT..15 of the block `blk_ahead` blocks after the current one -> N, their gathers -> G_NX"""
+        P, HS, NT = self.P, self.HS, self.NT
+        base = 4 * self.BLK * blk_ahead + 2048 * NT
+        for mpair in range(HS // 2):
+            P.s_add_u32(S_A0.lo, S_IN.lo, Lit(base + 4096 * mpair))
+            P.s_addc_u32(S_A0.hi, S_IN.hi, Lit(0))
+            for e in range(2):
+                P.global_load_dwordx2(self.N[2 * mpair + e], self.VOFF, S_A0, 2048 * e)
+        P.s_add_u32(S_A0.lo, S_IN.lo, Lit(base))
+        P.s_addc_u32(S_A0.hi, S_IN.hi, Lit(0))
+        P.global_load_dword(self.G_NX, self.VG, S_A0, -4)
+
+    def build_pq(self):
+        """D[k] = (p, q) of block row k: q = own pair's .x, p = the .y of lane t-1 (lane 0 of a wave: the gathered frame);
+        then the (q, c) pairs move to where the block keeps them"""
+        P, HS, NT, R0 = self.P, self.HS, self.NT, self.R0
+        src = lambda k: self.K[HS + k] if k < NT else self.N[k - NT]
+        for g in range(0, 16, 4):
+            for k in range(g, g + 4):
+                gl = (self.G_CAR, HS - NT + k) if k < NT else (self.G_NX, k - NT)
+                P.v_readlane(S_T[k - g], gl[0], gl[1])
+            for k in range(g, g + 4):
+                P.v_mov(self.D[k].lo, S_T[k - g])
+            for k in range(g, g + 4):
+                P.v_mov(self.D[k].hi, src(k).lo)
+            for k in range(g, g + 4):   # (two wait states after the VALU write of D[k].lo: the other moves are in between)
+                P.v_mov_dpp_shr1(self.D[k].lo, src(k).hi)
+        for r in range(R0, NT):         # context rows that are also dry rows of this block
+            P.v_mov(self.K[r].lo, self.K[HS + r].lo)
+            P.v_mov(self.K[r].hi, self.K[HS + r].hi)
+        for i in range(HS):
+            P.v_mov(self.K[NT + i].lo, self.N[i].lo)
+            P.v_mov(self.K[NT + i].hi, self.N[i].hi)
+        P.v_mov(self.G_CAR, self.G_NX)
+
+    def fwd_pass1(self):
+        """pkt_fft16_fwd_pruned_twout<16> on rows, outputs straight into the first exchange"""
+        P = self.P
+        v = self.D
+        A, B = self.TW[0:4], self.TW[4:8]
+        self.stage1(v, 1)
+        self.run_ops(self.stage1_twiddle_ops(v, 1, self.scratch_pairs()))
+        sc = self.scratch_pairs()
+        lists = []
+        for ka in range(1, 4):
+            for be in range(4):
+                lists.append(self.cmul_ops(v[4 * ka + be], v[4 * ka + be], A[ka], 1, sc[len(lists) % len(sc)]))
+        for g in range(0, len(lists), len(sc)):
+            self.run_ops(self.interleave(lists[g:g + len(sc)]))
+        # stage 2, then B on the outputs X[ka + 4 la] (at v[4 ka + la]) and the store of logical k = ka + 4 la
+        bfl = self.stage2_lists(v, 1)
+        if self.nbf >= 4:
+            self.run_ops(self.interleave(bfl))
+        else:
+            for l in bfl:
+                self.run_ops(l)
+        n = 0
+        for ka in range(4):
+            P.ds_write_b64(self.A_W1, v[4 * ka], (ka) * KL1 * 8)
+        for la in range(1, 4):
+            for ka in range(4):
+                x = v[4 * ka + la]
+                self.cmul(x, x, B[la], 1, sc[n % len(sc)])
+                n += 1
+                P.ds_write_b64(self.A_W1, x, (ka + 4 * la) * KL1 * 8)
+
+    def fft16_plain(self, v, DIR, before_stage2=None):
+        """pkt_fft16 on the logical list v; returns the logical list of the outputs (a renaming)"""
+        self.stage1(v, DIR)
+        self.run_ops(self.stage1_twiddle_ops(v, DIR, self.scratch_pairs()))
+        if before_stage2:
+            before_stage2()
+        return v
+
+    def fwd_pass2(self):
+        P = self.P
+        v = self.D
+        order = [0, 4, 8, 12, 1, 5, 9, 13, 2, 6, 10, 14, 3, 7, 11, 15]
+        for k in order:
+            P.ds_read_b64(v[k], self.A_R1, 128 * k)
+        return v
+
+    def twiddled_exchange(self, v, DIR, tw_base, waddr, wstride, raddr, rstride):
+        """second half of a middle pass: stage 2 one DFT-4 at a time, outputs X[ka + 4 la] times the W256 table entry, stored
+        to the wave-local exchange; then the transposed read back into D"""
+        P = self.P
+        tb = self.TB
+        def fetch(ka):
+            for la in range(4):
+                k = ka + 4 * la
+                if k:
+                    P.ds_read_b64(tb[la], self.A_TL, tw_base + 128 * k)
+        bfl = self.stage2_lists(v, DIR)
+        r = self.TR[0]
+        fetch(0)
+        for ka in range(4):
+            self.run_ops(bfl[ka])
+            for la in range(4):
+                k = ka + 4 * la
+                x = v[4 * ka + la]
+                if k:
+                    self.cmul(x, x, tb[la], DIR, r)
+                P.ds_write_b64(waddr, x, wstride * k)
+            if ka < 3:
+                fetch(ka + 1)
+        order = [0, 4, 8, 12, 1, 5, 9, 13, 2, 6, 10, 14, 3, 7, 11, 15]
+        for k in order:
+            P.ds_read_b64(self.D[k], raddr, rstride * k)
+
+    def pointwise(self, v):
+        """v = logical outputs k3 of the last forward pass: times i W32^{-k3}, and the |B| factors of the rows next to DC"""
+        P = self.P
+        sc = self.scratch_pairs()
+        # k3 = 0: (i rho0) v
+        P.pk("mul", v[0], [v[0], self.RHO[0]], op_sel=[1, 0], op_sel_hi=[0, 0], neg_lo=[1, 0])
+        lists = []
+        for k in range(1, 16):
+            if k == 8:
+                lists.append([lambda x=v[8]: P.pk("mul", x, [x, S_C32[8]])])
+            else:
+                lists.append(self.cmul_ops(v[k], v[k], S_C32[k], 1, sc[len(lists) % len(sc)]))
+        for g in range(0, len(lists), len(sc)):
+            self.run_ops(self.interleave(lists[g:g + len(sc)]))
+        P.pk("mul", v[15], [v[15], self.RHO[0]], op_sel=[0, 1], op_sel_hi=[1, 1])
+        if self.NA == 2:
+            P.pk("mul", v[1], [v[1], self.RHO[1]], op_sel=[0, 0], op_sel_hi=[1, 0])
+            P.pk("mul", v[14], [v[14], self.RHO[1]], op_sel=[0, 1], op_sel_hi=[1, 1])
+
+    def natural(self, v):
+        """logical outputs of pkt_fft16: X[ka + 4 la] sits in v[4 ka + la]"""
+        return [v[4 * (k % 4) + k // 4] for k in range(16)]
+
+    def inv_pass3(self):
+        """pkt_fft16_inv_twin with the plain twiddles derived from the half-shifted ones, one at a time"""
+        P = self.P
+        v = self.D
+        A, B = self.TW[0:4], self.TW[4:8]
+        w, r = self.TB[0], self.TR[0]
+        sc = self.TB[1:] + self.TT[:1]
+        for al in range(1, 4):      # inputs n = 4 al + be: conj(W^{4 t al})
+            self.cmul(w, B[al], S_TWI[3 + al - 1], 1, r)
+            ls = [self.cmul_ops(v[4 * al + be], v[4 * al + be], w, -1, sc[be % len(sc)]) for be in range(4)]
+            self.run_ops(self.interleave(ls) if len(set(x.n for x in sc)) >= 4 else sum(ls, []))
+        self.stage1(v, -1)
+        self.run_ops(self.stage1_twiddle_ops(v, -1, self.scratch_pairs()[1:] if False else [self.TR[0]] + self.TB[1:]))
+        for be in range(1, 4):      # y[be][ka] sits in v[4 ka + be]: conj(W^{t be})
+            self.cmul(w, A[be], S_TWI[be - 1], 1, r)
+            ls = [self.cmul_ops(v[4 * ka + be], v[4 * ka + be], w, -1, sc[ka % len(sc)]) for ka in range(4)]
+            self.run_ops(self.interleave(ls) if len(set(x.n for x in sc)) >= 4 else sum(ls, []))
+        bfl = self.stage2_lists(v, -1)
+        if self.nbf >= 4:
+            self.run_ops(self.interleave(bfl))
+        else:
+            for l in bfl:
+                self.run_ops(l)
+        return self.natural(v)
+
+    def epilogue(self, u):
+        """rows R0 .. R0 + HS - 1: out = ca dry + sa u (or sa u), stored as aligned pairs"""
+        P, HS, R0 = self.P, self.HS, self.R0
+        for m in range(HS // 2):
+            P.s_add_u32(S_A0.lo, S_OUT.lo, Lit(4096 * m))
+            P.s_addc_u32(S_A0.hi, S_OUT.hi, Lit(0))
+            for e in range(2):
+                k = 2 * m + e
+                x = u[R0 + k]
+                if self.MODE == MODE_ROT:
+                    tq = self.TB[k % len(self.TB)]
+                    P.pk("mul", tq, [self.K[R0 + k], S_ROT], op_sel=[0, 0], op_sel_hi=[1, 0])
+                    P.pk("fma", x, [x, S_ROT, tq], op_sel=[0, 1, 0], op_sel_hi=[1, 1, 1])
+                else:
+                    P.pk("mul", x, [x, S_ROT], op_sel=[0, 1], op_sel_hi=[1, 1])
+                P.global_store_dwordx2(self.VOFF, x, S_A0, 2048 * e)
+
+    def loop(self):
+        P, HS = self.P, self.HS
+        P.s_waitcnt(vmcnt=0)
+        P.label("L_top")
+        # whichever way the top is reached, what may still be in flight: the previous block's HS stores (younger than its
+        # prefetch, which the wait below therefore completes)
+        P.s_waitcnt(vmcnt=HS, lgkmcnt=0)
+        P.reset_queues(vm_stores=HS)
+        P.comment("---- (p, q) pairs")
+        self.build_pq()
+        P.comment("---- forward pass 1 + exchange 1")
+        self.fwd_pass1()
+        P.s_waitcnt(lgkmcnt=0)
+        P.s_barrier()
+        P.comment("---- forward pass 2")
+        v = self.fwd_pass2()
+        # the next block's new rows go out right behind the first barrier
+        P.s_cmp_eq_u32(S_NBLK, Lit(1))
+        P.s_cbranch_scc1("L_nopf")
+        self.load_new_rows(1)
+        P.label("L_nopf")
+        self.stage1(v, 1)
+        self.run_ops(self.stage1_twiddle_ops(v, 1, self.scratch_pairs()))
+        self.twiddled_exchange(v, 1, LDS_TWF, self.A_X2, 8, self.A_R1, KG * 8)
+        P.comment("---- forward pass 3")
+        v = self.D
+        self.stage1(v, 1)
+        self.run_ops(self.stage1_twiddle_ops(v, 1, self.scratch_pairs()))
+        bfl = self.stage2_lists(v, 1)
+        self.run_ops(self.interleave(bfl) if self.nbf >= 4 else sum(bfl, []))
+        v = self.natural(v)
+        P.comment("---- constants")
+        self.pointwise(v)
+        P.comment("---- inverse pass 1")
+        self.stage1(v, -1)
+        self.run_ops(self.stage1_twiddle_ops(v, -1, self.scratch_pairs()))
+        self.twiddled_exchange(v, -1, LDS_TWM, self.A_R1, KG * 8, self.A_X2, 8)
+        P.comment("---- inverse pass 2 + exchange 4")
+        v = self.D
+        self.stage1(v, -1)
+        self.run_ops(self.stage1_twiddle_ops(v, -1, self.scratch_pairs()))
+        bfl = self.stage2_lists(v, -1)
+        for ka in range(4):
+            self.run_ops(bfl[ka])
+            for la in range(4):
+                P.ds_write_b64(self.A_R1, v[4 * ka + la], 128 * (ka + 4 * la))
+        P.s_waitcnt(lgkmcnt=0)
+        P.s_barrier()
+        order = [4, 8, 12, 0, 5, 9, 13, 1, 6, 10, 14, 2, 7, 11, 15, 3]   # rows 4 al + be with al >= 1 get their twiddle first
+        for k in order:
+            P.ds_read_b64(self.D[k], self.A_W1, KL1 * 8 * k)
+        P.comment("---- inverse pass 3")
+        u = self.inv_pass3()
+        P.comment("---- mix and store")
+        self.epilogue(u)
+        P.s_add_u32(S_IN.lo, S_IN.lo, Lit(4 * self.BLK))
+        P.s_addc_u32(S_IN.hi, S_IN.hi, Lit(0))
+        P.s_add_u32(S_OUT.lo, S_OUT.lo, Lit(4 * self.BLK))
+        P.s_addc_u32(S_OUT.hi, S_OUT.hi, Lit(0))
+        P.s_sub_u32(S_NBLK, S_NBLK, Lit(1))
+        P.s_cmp_lg_u32(S_NBLK, Lit(0))
+        P.s_cbranch_scc1("L_top")
+
+    def constants(self):
+        """SGPR constants (set by the wrapper from literals)"""
+        c = {}
+        for k in range(1, 16):
+            th = math.pi / 2 + math.pi * k / 16
+            c[S_C32[k].n] = (math.cos(th), math.sin(th)) if k != 8 else (-1.0, -1.0)
+        c[S_RR.n] = (RR, -RR)
+        c[S_W1.n] = (C1, -S1)
+        c[S_W3.n] = (S1, -C1)
+        c[S_W9.n] = (-C1, S1)
+        for i in range(1, 4):
+            c[S_TWI[i - 1].n] = (math.cos(2 * math.pi * i / 8192), -math.sin(2 * math.pi * i / 8192))
+            c[S_TWI[3 + i - 1].n] = (math.cos(2 * math.pi * 2 * i / 4096), -math.sin(2 * math.pi * 2 * i / 4096))
+        return c
+
+    def build(self):
+        self.prologue()
+        self.loop()
+        return self.P
+
+
+# ---------------------------------------------------------------------------------------------------- self-test
+def self_test(HS, MODE, NA=1, nblk=3, seed=1, verbose=True):
+    import olasave_model as M
+    g = Gen(HS, MODE, NA)
+    P = g.build()
+    NT, R0, BLK = g.NT, g.R0, g.BLK
+    firlen = 512 * NT
+    fir = M.hilbert_fir(firlen)
+    gt = fir[1::2]
+    B = M.tables(gt)
+    rho = -B
+    mean = rho[256 * NA:4096 - 256 * NA].mean()
+    # device table (prot_capi.hip save_tables)
+    tab = np.zeros(2 * (13 + NA) * 256, np.float32)
+    def put(idx, ang):
+        tab[2 * idx], tab[2 * idx + 1] = math.cos(ang), math.sin(ang)
+    for t in range(256):
+        for i in range(1, 4):
+            put((i - 1) * 256 + t, -2 * math.pi * (t - 0.5) * i / 4096)
+            put((3 + i - 1) * 256 + t, -2 * math.pi * (t - 0.5) * 4 * i / 4096)
+        q = (t >> 4) + 16 * (t & 15)
+        for i in range(NA):
+            tab[2 * ((13 + i) * 256 + t)] = rho[q + 256 * i] / mean
+            tab[2 * ((13 + i) * 256 + t) + 1] = rho[q + 256 * (15 - i)] / mean
+    gain = np.float32(mean / 4096)
+    rng = np.random.default_rng(seed)
+    n_frames = 8192 + BLK * nblk + 64
+    x = (rng.random(n_frames, dtype=np.float32) - 0.5)
+    # frame index of (row 0, thread 0).q of the first block
+    a0 = 2
+    out = np.zeros(BLK * nblk + 16, np.float32)
+    emu = Emu(lds_bytes=40960)
+    IN_BASE, OUT_BASE, SV_BASE = 0x10000000, 0x20000000, 0x30000000
+    emu.map(IN_BASE, x.view(np.uint32))
+    emu.map(OUT_BASE, out.view(np.uint32))
+    emu.map(SV_BASE, tab.view(np.uint32))
+    # LDS tables (the C++ kernel sets them up)
+    ldsf = emu.lds.view(np.float32)
+    for t in range(256):
+        a = -2 * math.pi * (((t & 15) * (t >> 4)) & 255) / 256
+        ldsf[LDS_TWM // 4 + 2 * t], ldsf[LDS_TWM // 4 + 2 * t + 1] = math.cos(a), math.sin(a)
+        a = -2 * math.pi * ((t & 15) - 0.5) * (t >> 4) / 256
+        ldsf[LDS_TWF // 4 + 2 * t], ldsf[LDS_TWF // 4 + 2 * t + 1] = math.cos(a), math.sin(a)
+    ca, sa = 0.6, -0.8
+    def sset(sp, lo, hi):
+        emu.s[:, sp.n] = np.float32(lo).view(np.uint32)
+        emu.s[:, sp.n + 1] = np.float32(hi).view(np.uint32)
+    for n, (lo, hi) in g.constants().items():
+        sset(SP(n), lo, hi)
+    sset(S_ROT, ca, np.float32(sa) * gain)
+    addr = IN_BASE + 4 * a0
+    emu.s[:, S_IN.n], emu.s[:, S_IN.n + 1] = addr & 0xffffffff, addr >> 32
+    emu.s[:, S_OUT.n], emu.s[:, S_OUT.n + 1] = OUT_BASE & 0xffffffff, OUT_BASE >> 32
+    emu.s[:, S_SV.n], emu.s[:, S_SV.n + 1] = SV_BASE & 0xffffffff, SV_BASE >> 32
+    emu.s[:, S_NBLK.n] = nblk
+    emu.s[:, S_LDS.n] = 0
+    emu.v[g.TMP[0].n] = np.arange(256, dtype=np.uint32)
+    steps = emu.run(P)
+    # reference: direct convolution in float64.  z[j] = x[a0 + 2j - 1] + i x[a0 + 2j]; block b's local sample n is
+    # stream sample j = b * 256 HS + n; output row R0 + k of block b <-> frames b BLK + 512 k + 2 t (+1)
+    xd = x.astype(np.float64)
+    nz = (n_frames - a0) // 2 - 1
+    z = xd[a0 - 1:a0 - 1 + 2 * nz:2] + 1j * xd[a0:a0 + 2 * nz:2]
+    full = np.convolve(z, gt)               # full[m] = sum g[s] z[m - s]
+    Lg = len(gt)
+    want = np.zeros(BLK * nblk)
+    for b in range(nblk):
+        for k in range(HS):
+            j = b * 256 * HS + 256 * (R0 + k) + np.arange(256)          # stream complex index of the output samples
+            y = full[j + Lg // 2]
+            dq = xd[a0 + 2 * j]
+            dc = xd[a0 + 2 * j + 1]
+            pos = b * BLK + 512 * k + 2 * np.arange(256)
+            if MODE == MODE_ROT:
+                want[pos] = ca * dq + sa * y.real
+                want[pos + 1] = ca * dc + sa * y.imag
+            else:
+                want[pos] = sa * y.real
+                want[pos + 1] = sa * y.imag
+    err = np.abs(out[:BLK * nblk] - want).max()
+    st = P.stats()
+    npk = sum(v for k, v in st.items() if k.startswith("pk_"))
+    nval = sum(v for k, v in st.items() if k.startswith("v_"))
+    if verbose:
+        print("HS %2d mode %d NA %d: max err %.2e over %d blocks; VGPRs %d (temporaries %d pairs); loop+prologue: %d packed, %d other VALU, "
+              "%d ds, %d vmem, %d waits" % (HS, MODE, NA, err, nblk, g.n_vgpr, len(g.TMP), npk, nval, st.get("ds_read_b64", 0) + st.get("ds_write_b64", 0),
+                                            st.get("gload2", 0) + st.get("gload1", 0) + st.get("gstore2", 0), st.get("s_waitcnt", 0)))
+    assert err < 1e-6, err
+    return g, P
+
+
+# (HS = 14, the 512 odd taps of CLI blksiz 1024, needs 124 VGPRs before any temporary: that engine keeps olapoly_kernel)
+VARIANTS = [(hs, mode, 1) for hs in (8, 10, 12) for mode in (MODE_ROT, MODE_HILBERT)]
+
+
+def emit(path):
+    """csrc/prot_olasave_asm.inc: one macro per variant = the asm text of a run of blocks, its inputs taken from the inline-asm
+    operands %0..%7 (in, out: 64-bit SGPR pairs; nblk, lds byte offset: SGPRs; sv: pair; ca, sa * gain: SGPRs; t: VGPR)"""
+    out = ["// GENERATED by tools/gen/gen_olasave.py -- do not edit.  The steady-state loop of olasave_kernel as gfx950 assembly",
+           "// with hand-allocated registers (see the generator for the register plan and the schedule); the emulator",
+           "// (tools/gen/isa.py) has run every variant against the float64 convolution (tests/test_gen_olasave.py).",
+           "// operands: %0 in (frame (row 0, thread 0).q of the first block), %1 out (first output frame), %2 blocks, %3 LDS byte",
+           "// offset of the exchange area, %4 constants table, %5 ca, %6 sa * gain, %7 thread id",
+           "#pragma once", ""]
+    for HS, MODE, NA in VARIANTS:
+        g = Gen(HS, MODE, NA)
+        P = g.build()
+        head = ["s_mov_b64 %r, %%0" % S_IN, "s_mov_b64 %r, %%1" % S_OUT, "s_mov_b32 %r, %%2" % S_NBLK, "s_mov_b32 %r, %%3" % S_LDS,
+                "s_mov_b64 %r, %%4" % S_SV, "s_mov_b32 %r, %%5" % S_ROT.lo, "s_mov_b32 %r, %%6" % S_ROT.hi, "v_mov_b32 %r, %%7" % g.TMP[0].lo,
+                "s_waitcnt vmcnt(0) lgkmcnt(0)"]   # (whatever the compiler's code left in flight into registers this block uses)
+        for n, (lo, hi) in sorted(g.constants().items()):
+            head.append("s_mov_b32 s%d, %r" % (n, Lit(float(lo))))
+            head.append("s_mov_b32 s%d, %r" % (n + 1, Lit(float(hi))))
+        lines = head + P.text(label_suffix="%=")
+        st = P.stats()
+        out.append("// HS %d, mode %d, NA %d: %d VGPRs, %d instructions" % (HS, MODE, NA, g.n_vgpr, sum(v for k, v in st.items() if k not in ("comment", "label"))))
+        out.append("#define PROT_SV_ASM_%d_%d_%d \\" % (HS, MODE, NA))
+        for l in lines:
+            if l.startswith(";"):
+                continue
+            out.append('\t"%s\\n\t" \\' % l)
+        out.append('\t""')
+        out.append("")
+    for HS in (8, 10, 12):
+        nv = max(Gen(HS, m, na).n_vgpr for (h, m, na) in VARIANTS if h == HS)
+        clob = ['"memory"', '"vcc"', '"scc"'] + ['"s%d"' % i for i in SGPR_CLOBBER] + ['"v%d"' % i for i in range(0, nv)]
+        out.append("#define PROT_SV_ASM_CLOBBERS_%d " % HS + ", ".join(clob))
+    out.append("")
+    open(path, "w").write("\n".join(out))
+
+
+if __name__ == "__main__":
+    for HS, MODE, NA in VARIANTS:
+        self_test(HS, MODE, NA, nblk=2 if "--quick" in sys.argv else 3)
+    if "--check" not in sys.argv:
+        dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "phaserotate.lv2_amd", "csrc", "prot_olasave_asm.inc")
+        emit(dst)
+        print("wrote", os.path.normpath(dst))
