@@ -30,250 +30,72 @@
 namespace prot {
 
 typedef volatile __attribute__ ((address_space (3))) f2 LdsC;
-typedef pk32a O; // (every product an instruction of its own: the C++ blocks round like the generated loop)
+typedef volatile __attribute__ ((address_space (3))) float LdsF;
 
-// a * w for a wave-uniform constant w (SGPR pair: the 14 constants of the last forward pass cost no VGPR)
-PROT_DEV f2 cmul_sconst (f2 a, f2 w)
-{
-	f2 r, d;
-	asm ("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "s"(w));
-	asm ("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "s"(w), "v"(r));
-	return d;
-}
-// a * (i rho.x): (-a.y rho.x, a.x rho.x)
-PROT_DEV f2 mul_i_lo (f2 a, f2 rho)
-{
-	f2 d;
-	asm ("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[1,0]" : "=v"(d) : "v"(a), "v"(rho));
-	return d;
-}
-// a * rho.x / a * rho.y (real)
-PROT_DEV f2 mul_lo (f2 a, f2 rho)
-{
-	f2 d;
-	asm ("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(rho));
-	return d;
-}
-PROT_DEV f2 mul_hi (f2 a, f2 rho)
-{
-	f2 d;
-	asm ("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(rho));
-	return d;
-}
-
-// v[k] *= w[k] (k = 1..15, conj(w) for DIR < 0) with the W256 twiddles fetched from LDS four at a time, one batch ahead of
-// its multiplies, every value stored to dst[k * STRIDE] as soon as it is done (the VGPR -> LDS transfers run under the
-// remaining multiplies).  `r` = &table[tl]; q0 = batch 0 (k = 1..3), fetched by the caller ahead of the butterfly.
-template <int DIR, int STRIDE>
-PROT_DEV void sv_twiddle_store (f2 (&v)[16], const LdsC* r, const f2 (&q0)[4], LdsC* dst)
-{
-	f2 q[2][4];
-#pragma unroll
-	for (int i = 1; i < 4; ++i) {
-		q[0][i] = q0[i];
-	}
-#pragma unroll
-	for (int j = 0; j < 4; ++j) {
-		if (j < 3) {
-#pragma unroll
-			for (int i = 0; i < 4; ++i) {
-				q[(j + 1) & 1][i] = r[16 * (4 * (j + 1) + i)];
-			}
-		}
-		if (j == 0) {
-			dst[0] = v[0];
-			v[1]   = O::template cmul<DIR> (v[1], q[0][1]);
-			dst[STRIDE] = v[1];
-			O::template cmul2<DIR> (v[2], q[0][2], v[3], q[0][3]);
-			dst[2 * STRIDE] = v[2];
-			dst[3 * STRIDE] = v[3];
-		} else {
-#pragma unroll
-			for (int i = 0; i < 4; i += 2) {
-				const int k = 4 * j + i;
-				O::template cmul2<DIR> (v[k], q[j & 1][i], v[k + 1], q[j & 1][i + 1]);
-				dst[k * STRIDE]       = v[k];
-				dst[(k + 1) * STRIDE] = v[k + 1];
-			}
-		}
-	}
-}
-
-// forward transform at the half-shifted time index, up to (not including) the last radix-16 pass.
-// tw[0..3] = A (W^{(t-1/2) i}), tw[4..7] = B (W^{(t-1/2) 4 i}); twf = W256^{(c-1/2) k2} table in LDS
-template <class G>
-PROT_DEV void sv_forward (f2 (&v)[16], f2* lds, const f2* twf, const f2 (&A)[4], const f2 (&B)[4], int t, int tl, int th, G&& after_barrier)
-{
-	// own slots (k * kL1 + t): read by this thread at the end of the previous inverse -- no barrier in front
-	pkt_fft16_fwd_pruned_twout<O, 16> (v, A, B);
-	{
-		LdsC* w = (LdsC*)&lds[t];
-#pragma unroll
-		for (int k = 0; k < 16; ++k) {
-			w[k * kL1] = v[k];
-		}
-	}
-	__syncthreads ();
-	{
-		const LdsC* r = (const LdsC*)&lds[th * kL1 + tl];
-#pragma unroll
-		for (int k = 0; k < 16; ++k) {
-			v[k] = r[16 * k];
-		}
-	}
-	after_barrier ();
-	{
-		const LdsC* rq = (const LdsC*)&twf[tl];
-		f2          q0[4];
-#pragma unroll
-		for (int i = 1; i < 4; ++i) {
-			q0[i] = rq[16 * i];
-		}
-		pkt_fft16<O, 1> (v);
-		sv_twiddle_store<1, 1> (v, rq, q0, (LdsC*)&lds[th * kL1 + tl * kG]);
-	}
-	wave_sync ();
-	{
-		const LdsC* r = (const LdsC*)&lds[th * kL1 + tl];
-#pragma unroll
-		for (int k = 0; k < 16; ++k) {
-			v[k] = r[k * kG];
-		}
-	}
-	pkt_fft16<O, 1> (v);
-}
-
-// inverse radix-16 of the last pass with the conjugated split outer twiddles on its inputs, and only the output rows
-// [R0, 16 - R0) computed (the other rows of an overlap-save block are circular wrap-around)
-template <int R0>
-PROT_DEV void sv_fft16_inv_twin_pruned (f2 (&v)[16], const f2 (&A)[4], const f2 (&B)[4])
-{
-#pragma unroll
-	for (int al = 1; al < 4; ++al) { // input n = 4 al + be
-		O::template cmul2<-1> (v[4 * al], B[al], v[4 * al + 1], B[al]);
-		O::template cmul2<-1> (v[4 * al + 2], B[al], v[4 * al + 3], B[al]);
-	}
-	pkt_radix4<O, -1> (v[0], v[4], v[8], v[12]);
-	pkt_radix4<O, -1> (v[1], v[5], v[9], v[13]);
-	pkt_radix4<O, -1> (v[2], v[6], v[10], v[14]);
-	pkt_radix4<O, -1> (v[3], v[7], v[11], v[15]);
-	pkt_stage1_twiddles<O, -1> (v);
-#pragma unroll
-	for (int be = 1; be < 4; ++be) { // y[be][ka] sits in v[4 ka + be]
-		O::template cmul2<-1> (v[be], A[be], v[4 + be], A[be]);
-		O::template cmul2<-1> (v[8 + be], A[be], v[12 + be], A[be]);
-	}
-	pkt_fft16_stage2<O, -1> (v); // (the unused outputs' adds are dead code: the compiler drops them)
-}
-
-PROT_DEV void sv_inverse (f2 (&v)[16], f2* lds, const f2* twm, const f2 (&A)[4], const f2 (&B)[4], int t, int tl, int th)
-{
-	{
-		const LdsC* rq = (const LdsC*)&twm[tl];
-		f2          q0[4];
-#pragma unroll
-		for (int i = 1; i < 4; ++i) {
-			q0[i] = rq[16 * i];
-		}
-		pkt_fft16<O, -1> (v);
-		sv_twiddle_store<-1, kG> (v, rq, q0, (LdsC*)&lds[th * kL1 + tl]);
-	}
-	wave_sync ();
-	{
-		const LdsC* r = (const LdsC*)&lds[th * kL1 + tl * kG];
-#pragma unroll
-		for (int k = 0; k < 16; ++k) {
-			v[k] = r[k];
-		}
-	}
-	pkt_fft16<O, -1> (v);
-	{
-		// the group's chunk again, in the pass-1 layout: nobody else touches it before the barrier
-		wave_sync ();
-		LdsC* w = (LdsC*)&lds[th * kL1 + tl];
-#pragma unroll
-		for (int k = 0; k < 16; ++k) {
-			w[16 * k] = v[k];
-		}
-		__syncthreads ();
-		const LdsC* r = (const LdsC*)&lds[t];
-#pragma unroll
-		for (int k = 0; k < 16; ++k) {
-			v[k] = r[k * kL1];
-		}
-	}
-	// the plain twiddles from the half-shifted ones: W^{t i} = W^{(t-1/2) i} W^{i/2}, W^{4 t i} = W^{(t-1/2) 4 i} W^{2 i}
-	f2 Ai[4], Bi[4];
-	Ai[1] = cmul_sconst (A[1], mkf2 (0.99999970586288223f, -0.00076699031874270453f));
-	Ai[2] = cmul_sconst (A[2], mkf2 (0.99999882345170188f, -0.0015339801862847656f));
-	Ai[3] = cmul_sconst (A[3], mkf2 (0.99999735276697821f, -0.0023009691514258073f));
-	Bi[1] = cmul_sconst (B[1], mkf2 (0.99999529380957619f, -0.0030679567629659763f));
-	Bi[2] = cmul_sconst (B[2], mkf2 (0.99998117528260111f, -0.0061358846491544753f));
-	Bi[3] = cmul_sconst (B[3], mkf2 (0.9999576445519639f, -0.0092037547820598194f));
-	pkt_fft16_inv_twin<O> (v, Ai, Bi);
-}
-
-// the 14 constants i W32^{-k3} = e^{i (pi/2 + pi k3 / 16)}, k3 = 1..15 (k3 = 8: -1)
-PROT_DEV f2 sv_c32 (int k)
-{
-	constexpr float C[16] = { 0.f, -0.19509032201612825f, -0.38268343236508977f, -0.55557023301960222f, -0.70710678118654752f,
-		                      -0.83146961230254524f, -0.92387953251128676f, -0.98078528040323045f, -1.f, -0.98078528040323045f,
-		                      -0.92387953251128676f, -0.83146961230254524f, -0.70710678118654752f, -0.55557023301960222f,
-		                      -0.38268343236508977f, -0.19509032201612825f };
-	constexpr float S[16] = { 1.f, 0.98078528040323045f, 0.92387953251128676f, 0.83146961230254524f, 0.70710678118654752f,
-		                      0.55557023301960222f, 0.38268343236508977f, 0.19509032201612825f, 0.f, -0.19509032201612825f,
-		                      -0.38268343236508977f, -0.55557023301960222f, -0.70710678118654752f, -0.83146961230254524f,
-		                      -0.92387953251128676f, -0.98078528040323045f };
-	return mkf2 (C[k], S[k]);
-}
-
-// out = a * x + y (packed, a wave-uniform): the mix of the dry and the Hilbert branch, spelled out so that the C++ blocks
-// and the generated loop round alike
-PROT_DEV f2 pk_mul_s (f2 x, f2 a)
-{
-	f2 d;
-	asm ("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(x), "s"(a));
-	return d;
-}
-PROT_DEV f2 pk_fma_s (f2 x, f2 a, f2 y)
-{
-	f2 d;
-	asm ("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "s"(a), "v"(y));
-	return d;
-}
-
+#ifdef PROT_SV_INC // (tuning builds: a variant of the generated code, tools/ab_build.py sv:...)
+#include PROT_SV_INC
+#else
 #include "prot_olasave_asm.inc"
-#define PROT_SV_CAT_(a, b, c) PROT_SV_ASM_##a##_##b##_##c
+#endif
+#ifdef PROT_SV_CLOCK // diagnostic build (tools/ab_build.py sv:clk:-DPROT_SV_CLOCK): shader cycles and 100 MHz ticks spent in the generated loop
+__device__ unsigned long long g_sv_clock[4];
+__device__ unsigned long long g_sv_wg[4096 * 4]; // per workgroup: kernel entry, first generated-loop entry, last exit, kernel exit (100 MHz ticks)
+extern "C" int prot_debug_sv_clock (unsigned long long* out)
+{
+	return hipMemcpyFromSymbol (out, HIP_SYMBOL (g_sv_clock), sizeof (g_sv_clock)) == hipSuccess ? 0 : -1;
+}
+extern "C" int prot_debug_sv_wg (unsigned long long* out, int n_wg)
+{
+	return hipMemcpyFromSymbol (out, HIP_SYMBOL (g_sv_wg), sizeof (unsigned long long) * 4 * (size_t)(n_wg < 4096 ? n_wg : 4096)) == hipSuccess ? 0 : -1;
+}
+#endif
+#define PROT_SV_CAT_(k, a, b, c) PROT_SV_##k##_##a##_##b##_##c
 #define PROT_SV_CLOB_(a) PROT_SV_ASM_CLOBBERS_##a
-#define PROT_SV_RUN(HS_, MODE_, NA_)                                                                                                  \
-	if (HS == HS_ && MODE == MODE_ && NA == NA_) {                                                                                    \
-		asm volatile (PROT_SV_CAT_ (HS_, MODE_, NA_)                                                                                  \
-		              :                                                                                                               \
-		              : "s"(a_in), "s"(a_out), "s"(nf), "s"(lds_off), "s"(a_sv), "s"(ca), "s"(sa), "v"(t0)                               \
-		              : PROT_SV_CLOB_ (HS_));                                                                                        \
+// one generated block of code: KIND_ = ASM (a run of nf whole blocks streamed from / to global memory) or CORE (one block staged
+// in LDS); the transform's mode AM_ (0 mix with the dry rows, 2 Hilbert branch only)
+#define PROT_SV_CALL(KIND_, HS_, AM_, in_, out_, nf_, ca_, sa_)                                                                        \
+	if (HS == HS_ && AM == AM_) {                                                                                                       \
+		asm volatile (PROT_SV_CAT_ (KIND_, HS_, AM_, 1)                                                                                 \
+		              :                                                                                                                 \
+		              : "s"(in_), "s"(out_), "s"(nf_), "s"(lds_off), "s"(a_sv), "s"(ca_), "s"(sa_), "v"(t0)                                \
+		              : PROT_SV_CLOB_ (HS_));                                                                                           \
 	}
+#define PROT_SV_ALL(KIND_, in_, out_, nf_, ca_, sa_)                                                                                   \
+	PROT_SV_CALL (KIND_, 8, 0, in_, out_, nf_, ca_, sa_)                                                                                \
+	PROT_SV_CALL (KIND_, 8, 2, in_, out_, nf_, ca_, sa_)                                                                                \
+	PROT_SV_CALL (KIND_, 10, 0, in_, out_, nf_, ca_, sa_)                                                                               \
+	PROT_SV_CALL (KIND_, 10, 2, in_, out_, nf_, ca_, sa_)                                                                               \
+	PROT_SV_CALL (KIND_, 12, 0, in_, out_, nf_, ca_, sa_)                                                                               \
+	PROT_SV_CALL (KIND_, 12, 2, in_, out_, nf_, ca_, sa_)
 
-// HS new rows (512 HS frames) per block; MODE_ROT / MODE_RAMP / MODE_HILBERT; NA = rows next to DC (on either side) whose
-// |B| needs its own factor (1: FIRs of 1024 odd taps and more; 2: the 512 odd taps of CLI blksiz 1024).
-// A workgroup walks its run block by block: consecutive blocks that lie wholly inside the input array (aligned streams,
-// steady rotation) go to the generated loop (prot_olasave_asm.inc: 126 hand-allocated VGPRs, the next block's rows
-// prefetched, the context rows carried in registers); every other block -- history or silence in reach, a partial last
-// block, odd alignment, per-frame rotation -- is done here, self-contained, with the same instructions in the same order.
-template <int HS, int MODE, int NA>
+// HS new rows (512 HS frames) per block; MODE_ROT / MODE_RAMP / MODE_HILBERT.
+// ALL arithmetic of the block is generated code (prot_olasave_asm.inc, tools/gen/gen_olasave.py: 120 hand-allocated VGPRs);
+// this function moves data.  A workgroup walks its run block by block:
+//  * consecutive blocks that lie wholly inside the input array (8-byte aligned streams, steady rotation) are one call of the
+//    generated LOOP: the next block's rows prefetched, the context rows carried in registers, stores straight from registers;
+//  * every other block -- history or silence in reach, a partial last block, odd alignment, per-frame rotation -- is staged
+//    here into the LDS exchange area (16 rows of (q, c) pairs + the frames in front of each wave's first pair), transformed by
+//    the generated CORE (the same instructions on the same values: the two paths agree bit for bit, and a sharded or chunked
+//    sweep does not depend on where its chunks end), and stored from LDS with bounds.
+template <int HS, int MODE>
 __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 {
 	constexpr int BLK = 512 * HS; // output frames per block
 	constexpr int NT  = 16 - HS;  // context rows
 	constexpr int R0  = NT / 2;   // first valid output row = first dry row
-	static_assert ((HS == 8 || HS == 10 || HS == 12) && NA == 1, "rows per block (HS = 14 needs 124 VGPRs before any temporary: olapoly_kernel)");
+	constexpr int AM  = MODE == MODE_ROT ? 0 : 2; // the generated code's mode (per-frame rotation: Hilbert branch, mixed here)
+	static_assert (HS == 8 || HS == 10 || HS == 12, "rows per block (HS = 14 needs 124 VGPRs before any temporary: olapoly_kernel)");
 
 	__shared__ f2 smem[kLdsExchange + 512];
-	f2* const lds = smem;
 	f2* const twm = smem + kLdsExchange;
 	f2* const twf = smem + kLdsExchange + 256;
 
 	const int t0 = threadIdx.x;
 	const int c  = blockIdx.y;
+#ifdef PROT_SV_CLOCK
+	const uint64_t wg_t0 = __builtin_amdgcn_s_memrealtime ();
+	uint64_t       wg_a0 = 0, wg_a1 = 0;
+#endif
 	int64_t   r0, rlen;
 	run_of_workgroup (p, r0, rlen);
 	if (r0 >= p.n_out) {
@@ -305,6 +127,7 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 	ca = __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (ca)));
 	sa = __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (sa)));
 	const unsigned lds_off = (unsigned)(uintptr_t)(__attribute__ ((address_space (3))) f2*)smem;
+	const float*   a_sv    = uniform_ptr_generic (p.sv);
 	__syncthreads ();
 
 	for (int64_t s = r0; s < r1;) {
@@ -315,109 +138,88 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 			const int64_t n2 = n_in - 8192 - a0 >= 0 ? (n_in - 8192 - a0) / BLK + 1 : 0;
 			int           nf = (int)(n1 < n2 ? n1 : n2);
 			if (nf > 0) {
-				nf                    = __builtin_amdgcn_readfirstlane (nf);
+				nf                 = __builtin_amdgcn_readfirstlane (nf);
 				const float* a_in  = uniform_ptr_generic (in + a0);
 				float*       a_out = uniform_ptr_generic (out + s);
-				const float* a_sv  = uniform_ptr_generic (p.sv);
-				PROT_SV_RUN (8, 0, 1)
-				PROT_SV_RUN (8, 2, 1)
-				PROT_SV_RUN (10, 0, 1)
-				PROT_SV_RUN (10, 2, 1)
-				PROT_SV_RUN (12, 0, 1)
-				PROT_SV_RUN (12, 2, 1)
+#ifdef PROT_SV_CLOCK
+				const uint64_t c0 = __builtin_readcyclecounter (), q0 = __builtin_amdgcn_s_memrealtime ();
+#endif
+				PROT_SV_ALL (ASM, a_in, a_out, nf, ca, sa)
+#ifdef PROT_SV_CLOCK
+				if (t0 == 0) {
+					atomicAdd (&g_sv_clock[0], (unsigned long long)(__builtin_readcyclecounter () - c0));
+					atomicAdd (&g_sv_clock[1], (unsigned long long)(__builtin_amdgcn_s_memrealtime () - q0));
+					atomicAdd (&g_sv_clock[2], (unsigned long long)nf);
+					atomicAdd (&g_sv_clock[3], 1ull);
+				}
+				wg_a0 = wg_a0 ? wg_a0 : q0;
+				wg_a1 = __builtin_amdgcn_s_memrealtime ();
+#endif
 				s += (int64_t)nf * BLK;
 				continue;
 			}
 		}
-		// ---- one block, self-contained
+		// ---- one block through LDS
 		int t = t0;
 		asm volatile ("" : "+v"(t)); // (opaque per block: per-lane address terms are otherwise hoisted out of the loop)
 		t &= 255;
-		const int tl = t & 15, th = t >> 4;
-		f2    inr[16]; // (q, c) pairs (x[a], x[a+1]), a = a0 + 512 row + 2 t
-		float g = 0.f; // lane r of every wave: the frame in front of row r's first pair of this wave
+		LdsC* const st   = (LdsC*)smem;               // rows: slot 256 row + t
+		LdsF* const gcar = (LdsF*)(smem + 4096);      // gathered frames in the generated code's lane layout:
+		LdsF* const gnx  = (LdsF*)(smem + 4096 + 128); //   lanes HS-NT..HS-1 <-> rows 0..NT-1, lanes 0..HS-1 <-> rows NT..15
+		__syncthreads (); // (every wave has left the generated loop, if that is where it comes from)
 		{
-			const bool     fast = (a0 - 1 >= 0) && (a0 + 8192 <= n_in);
-			const unsigned l    = (unsigned)t & 63u;
-			const unsigned grow = l < 16u ? l : 0u;
-			if (fast && in_al8) {
+			const bool fast = (a0 - 1 >= 0) && (a0 + 8192 <= n_in) && in_al8;
+			if (fast) {
 #pragma unroll
 				for (int m = 0; m < 8; ++m) {
 					const PROT_GLOBAL float* __restrict__ b = uniform_ptr (in + a0 + 1024 * m);
 #pragma unroll
 					for (int e = 0; e < 2; ++e) {
-						inr[2 * m + e] = reinterpret_cast<const PROT_GLOBAL f2*> (b)[(unsigned)t + 256u * e];
+						st[256 * (2 * m + e) + t] = reinterpret_cast<const PROT_GLOBAL f2*> (b)[(unsigned)t + 256u * e];
 					}
 				}
-				const PROT_GLOBAL float* __restrict__ b = uniform_ptr (in + a0 - 1);
-				g = b[((unsigned)t & ~63u) * 2u + 512u * grow];
 			} else {
-#pragma unroll
+#pragma unroll 4
 				for (int k = 0; k < 16; ++k) {
 					const int64_t a = a0 + 2 * (int64_t)(t + 256 * k);
-					inr[k]          = mkf2 (ldv (in, n_in, hist, p.hist_len, a), ldv (in, n_in, hist, p.hist_len, a + 1));
+					st[256 * k + t] = mkf2 (ldv (in, n_in, hist, p.hist_len, a), ldv (in, n_in, hist, p.hist_len, a + 1));
 				}
-				g = ldv (in, n_in, hist, p.hist_len, a0 + 2 * (int64_t)(((unsigned)t & ~63u) + 256u * grow) - 1);
 			}
+			const int l = t & 63, w = t >> 6;
+			const int rc = l - (HS - NT), rn = NT + l; // the row this lane gathers for, as a carried / as a new row
+			gcar[t] = (rc >= 0 && rc < NT) ? ldv (in, n_in, hist, p.hist_len, a0 + 512 * (int64_t)rc + 128 * w - 1) : 0.f;
+			gnx[t]  = (l < HS) ? ldv (in, n_in, hist, p.hist_len, a0 + 512 * (int64_t)rn + 128 * w - 1) : 0.f;
 		}
-		f2 twr[8]; // [1..3] A = W^{(t-1/2) i}, [5..7] B = W^{(t-1/2) 4 i}
-		f2 rho[NA];
+		__syncthreads ();
 		{
-			const f2* __restrict__ sv = reinterpret_cast<const f2*> (p.sv);
-#pragma unroll
-			for (int i = 0; i < 6; ++i) {
-				twr[(i / 3) * 4 + 1 + i % 3] = sv[i * 256 + t];
-			}
-#pragma unroll
-			for (int i = 0; i < NA; ++i) {
-				rho[i] = sv[(13 + i) * 256 + t]; // (rho[q + 256 i], rho[q + 256 (15 - i)])
-			}
+			const float  cca = MODE == MODE_RAMP ? 0.f : ca, csa = MODE == MODE_RAMP ? __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (p.sv_gain))) : sa;
+			const float* a_in  = a_sv; // (unused by the core)
+			float*       a_out = nullptr;
+			const int    one   = 1;
+			PROT_SV_ALL (CORE, a_in, a_out, one, cca, csa)
 		}
-		f2 v[16];
-#pragma unroll
-		for (int k = 0; k < 16; ++k) {
-			// wave_shr:1 -- lane i reads lane i-1, lane 0 keeps `old` = the gathered frame of this row
-			const unsigned first = (unsigned)__builtin_amdgcn_readlane ((int)__float_as_uint (g), k);
-			const float    pk_   = __uint_as_float (__builtin_amdgcn_update_dpp (first, __float_as_uint (inr[k].y), 0x138, 0xf, 0xf, false));
-			v[k] = mkf2 (pk_, inr[k].x);
-		}
-		sv_forward (v, lds, twf, reinterpret_cast<const f2 (&)[4]> (twr[0]), reinterpret_cast<const f2 (&)[4]> (twr[4]), t, tl, th, [] () {});
-
-		// Y[k] = Z'[k] (-i B[k]) W^{-(Lg/2) k}: the constant i W32^{-k3} per row, the |B| factors next to DC
-		v[0] = mul_i_lo (v[0], rho[0]);
-#pragma unroll
-		for (int k = 1; k < 16; ++k) {
-			v[k] = k == 8 ? pk_mul_s (v[k], mkf2 (-1.f, -1.f)) : cmul_sconst (v[k], sv_c32 (k));
-		}
-		v[15] = mul_hi (v[15], rho[0]);
-		if (NA == 2) {
-			v[1]  = mul_lo (v[1], rho[NA - 1]);
-			v[14] = mul_hi (v[14], rho[NA - 1]);
-		}
-		sv_inverse (v, lds, twm, reinterpret_cast<const f2 (&)[4]> (twr[0]), reinterpret_cast<const f2 (&)[4]> (twr[4]), t, tl, th);
-
-		const f2 ca2 = mkf2 (ca, ca), sa2 = mkf2 (sa, sa);
+		__syncthreads ();
+		// rows 0..HS-1 of the exchange area now hold the output pairs of frames s + 512 k + 2 t (+1)
 		if (MODE != MODE_RAMP && s + BLK <= r1 && out_al8) {
 #pragma unroll
 			for (int m = 0; m < HS / 2; ++m) {
 				PROT_GLOBAL f2* __restrict__ ob = reinterpret_cast<PROT_GLOBAL f2*> (uniform_ptr (out + s + 1024 * m));
 #pragma unroll
 				for (int e = 0; e < 2; ++e) {
-					const int k = R0 + 2 * m + e;
-					ob[(unsigned)t + 256u * e] = MODE == MODE_ROT ? pk_fma_s (v[k], sa2, pk_mul_s (inr[k], ca2)) : pk_mul_s (v[k], sa2);
+					ob[(unsigned)t + 256u * e] = st[256 * (2 * m + e) + t];
 				}
 			}
 		} else {
-#pragma unroll
+#pragma unroll 2
 			for (int k = 0; k < HS; ++k) {
-				f2 o = MODE == MODE_ROT ? pk_fma_s (v[R0 + k], sa2, pk_mul_s (inr[R0 + k], ca2)) : pk_mul_s (v[R0 + k], sa2);
+				const f2 o = st[256 * k + t];
 #pragma unroll
 				for (int h = 0; h < 2; ++h) {
 					const int64_t pos = s + 2 * (int64_t)(t + 256 * k) + h;
 					if (pos < r1) {
 						if (MODE == MODE_RAMP) {
 							const f2 cs = reinterpret_cast<const f2*> (p.rot_s)[(int64_t)c * p.n_out + pos];
-							out[pos]    = cs.x * (h ? inr[R0 + k].y : inr[R0 + k].x) + (cs.y * p.sv_gain) * (h ? v[R0 + k].y : v[R0 + k].x);
+							out[pos]    = cs.x * ldv (in, n_in, hist, p.hist_len, pos - Dd) + cs.y * (h ? o.y : o.x);
 						} else {
 							out[pos] = h ? o.y : o.x;
 						}
@@ -425,21 +227,30 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 				}
 			}
 		}
+		__syncthreads (); // (the output rows have been read: the exchange area is free for whatever comes next)
 		s += BLK;
 	}
+#ifdef PROT_SV_CLOCK
+	if (t0 == 0 && blockIdx.x < 4096) {
+		g_sv_wg[4 * blockIdx.x]     = wg_t0;
+		g_sv_wg[4 * blockIdx.x + 1] = wg_a0;
+		g_sv_wg[4 * blockIdx.x + 2] = wg_a1;
+		g_sv_wg[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime ();
+	}
+#endif
 	hist_write_slice (p, blockIdx.y, threadIdx.x);
 }
 
-template <int HS, int NA>
+template <int HS>
 static hipError_t launch_sv_m (const OlaParams& p, dim3 grid, hipStream_t s)
 {
 	const dim3 block (256);
 	if (p.hilbert_only) {
-		hipLaunchKernelGGL ((olasave_kernel<HS, MODE_HILBERT, NA>), grid, block, 0, s, p);
+		hipLaunchKernelGGL ((olasave_kernel<HS, MODE_HILBERT>), grid, block, 0, s, p);
 	} else if (p.rot_s != nullptr) {
-		hipLaunchKernelGGL ((olasave_kernel<HS, MODE_RAMP, NA>), grid, block, 0, s, p);
+		hipLaunchKernelGGL ((olasave_kernel<HS, MODE_RAMP>), grid, block, 0, s, p);
 	} else {
-		hipLaunchKernelGGL ((olasave_kernel<HS, MODE_ROT, NA>), grid, block, 0, s, p);
+		hipLaunchKernelGGL ((olasave_kernel<HS, MODE_ROT>), grid, block, 0, s, p);
 	}
 	return hipGetLastError ();
 }
@@ -456,9 +267,9 @@ hipError_t launch_ola_save (const OlaParams& p, int hop_rows, int n_rho_rows, in
 	const int64_t runs = (p.n_out + p.run_frames - 1) / p.run_frames;
 	dim3          grid ((unsigned)runs, (unsigned)n_chn);
 	switch (hop_rows * 4 + n_rho_rows) {
-		case 8 * 4 + 1: return launch_sv_m<8, 1> (p, grid, s);
-		case 10 * 4 + 1: return launch_sv_m<10, 1> (p, grid, s);
-		case 12 * 4 + 1: return launch_sv_m<12, 1> (p, grid, s);
+		case 8 * 4 + 1: return launch_sv_m<8> (p, grid, s);
+		case 10 * 4 + 1: return launch_sv_m<10> (p, grid, s);
+		case 12 * 4 + 1: return launch_sv_m<12> (p, grid, s);
 		default: return hipErrorInvalidValue;
 	}
 }

@@ -10,6 +10,28 @@ b.build_lib()
 vdir = os.path.join(b.LIBDIR, "variants"); os.makedirs(vdir, exist_ok=True)
 hipcc = b._hipcc()
 for arg in sys.argv[1:]:
+    if arg.startswith("sv:"):
+        # "sv:<tag>[:flag,flag]": a variant of prot_olasave.hip only (the generated loop csrc/variants/prot_olasave_asm_<tag>.inc
+        # if it exists: python3 tools/gen/gen_olasave.py --variant <tag> --opts ...), linked with the shipped objects
+        _, tag, fl = (arg.split(":") + [""])[:3]
+        extra = [f for f in fl.split(",") if f]
+        inc_tag = tag
+        for f in list(extra):
+            if f.startswith("INC="):   # the generated loop of another variant under this tag's flags
+                inc_tag = f[4:]
+                extra.remove(f)
+        inc = os.path.join(b.CSRC, "variants", "prot_olasave_asm_%s.inc" % inc_tag)
+        if os.path.exists(inc):
+            extra.append('-DPROT_SV_INC="%s"' % inc)
+        o = os.path.join(b.OBJDIR, "prot_olasave_%s.o" % tag)
+        b._run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-function",
+                "-I" + os.path.join(ROOT, "include"), "-ffast-math", "-fno-slp-vectorize"] + extra +
+               ["-c", os.path.join(b.CSRC, "prot_olasave.hip"), "-o", o])
+        lib = os.path.join(vdir, "libprot_hip_%s.so" % tag)
+        b._run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, o, os.path.join(b.OBJDIR, "prot_kernels.o"),
+                os.path.join(b.OBJDIR, "prot_kernels_f16.o"), os.path.join(b.OBJDIR, "prot_capi.o"), "-lpthread"])
+        print("built", lib)
+        continue
     tag, _, fl = arg.partition(":")
     extra = [f for f in fl.split(",") if f]
     o = os.path.join(b.OBJDIR, "prot_kernels_%s.o" % tag)

@@ -25,6 +25,7 @@ from isa import Prog, Emu, V, VP, S, SP, Lit  # noqa: E402
 
 KL1, KG = 272, 17                 # LDS exchange strides (prot_dev.h)
 LDS_TWM, LDS_TWF = 34816, 36864   # byte offsets of the W256 tables behind the exchange area
+LDS_GCAR, LDS_GNX = 32768, 33792  # core blocks: the gathered frames, one float per thread in lane layout, behind the 16 staged rows
 MODE_ROT, MODE_HILBERT = 0, 2
 
 # ---- SGPR plan (the asm block clobbers s34..s99; s32 and s100.. are reserved by the compiler) ----
@@ -43,12 +44,26 @@ C1, S1, RR = 0.92387953251128675613, 0.38268343236508977173, 0.70710678118654752
 
 
 class Gen:
-    def __init__(self, HS, MODE, NA=1):
+    def __init__(self, HS, MODE, NA=1, opts=(), kind="run"):
+        """opts: timing experiments only (results wrong): "nolds" no LDS traffic and no barriers, "nomem" no stream loads / stores,
+        "novalu" no packed arithmetic; "tw2" two twiddle batches in flight; "burstld" the prefetch loads in one burst behind the
+        barrier instead of woven into the butterflies; "spreadst" stores issued per DFT-4 of the last stage; "nt" non-temporal
+        stream accesses; "prio1" / "prio2" raised priority in front of the first barrier / behind the second"""
         self.HS, self.MODE, self.NA = HS, MODE, NA
+        self.opts = set(opts)
+        # "run": n >= 1 blocks streamed from / to global memory; "core": ONE block whose 16 rows (and gathered frames) the
+        # C++ code has staged in the LDS exchange area, outputs back into it (edge blocks: history, silence, partial stores)
+        self.kind = kind
         self.NT = 16 - HS
         self.R0 = self.NT // 2
         self.BLK = 512 * HS
         P = self.P = Prog()
+        if "nolds" in self.opts:
+            P.ds_write_b64 = lambda *a, **k: None
+            P.ds_read_b64 = lambda *a, **k: None
+            P.s_barrier = lambda *a, **k: None
+        if "novalu" in self.opts:
+            P.pk = lambda *a, **k: None
         n = 0
         self.D = [VP(2 * k) for k in range(16)]
         n = 32
@@ -136,6 +151,20 @@ class Gen:
     def run_ops(self, ops):
         for f in ops:
             f()
+
+    @staticmethod
+    def weave(main, extra, every):
+        """`extra` thunks spread through `main`, one after every `every` of them (the rest at the end)"""
+        out, extra = [], list(extra)
+        for i, f in enumerate(main):
+            out.append(f)
+            if extra and (i + 1) % every == 0:
+                out.append(extra.pop(0))
+        return out + extra
+
+    def stage1_ops(self, v, DIR):
+        bf = [self.radix4_ops(v[be], v[4 + be], v[8 + be], v[12 + be], DIR, False, self.TT[be % 4]) for be in range(4)]
+        return self.interleave(bf) if self.nbf >= 4 else sum(bf, [])
 
     def mul_w16_ops(self, x, DIR, m, r):
         """pkt_mul_w16: x *= W16^m (conjugate for DIR < 0), m in {1, 2, 3, 6, 9}"""
@@ -230,6 +259,21 @@ class Gen:
             P.s_addc_u32(S_A0.hi, S_SV.hi, Lit(0))
             P.global_load_dwordx2(self.RHO[i], self.VOFF, S_A0, 0)
         P.comment("---- prologue: the first block's rows")
+        if self.kind == "core":
+            # staged by the C++ code: row r's (q, c) pair of thread t at slot r * 256 + t, the gathered frames in lane layout
+            for r in range(NT):
+                P.ds_read_b64(self.K[HS + r], self.A_W1, 2048 * r)
+            for i in range(HS):
+                P.ds_read_b64(self.N[i], self.A_W1, 2048 * (NT + i))
+            a4 = self.TMP[2].lo
+            P.v_lshl(a4, Lit(2), t)
+            P.v_add_u32(a4, S_LDS, a4)
+            P.ds_read_b32(self.G_CAR, a4, LDS_GCAR)
+            P.ds_read_b32(self.G_NX, a4, LDS_GNX)
+            P.s_waitcnt(vmcnt=0, lgkmcnt=0)
+            P.s_barrier()   # every wave has its rows: the exchange area may be written
+            P.comment("---- prologue done")
+            return
         # rows 0..NT-1 -> K[HS .. 15] (the registers the steady state carries them in); gathers -> G_CAR lanes HS-NT..
         for mpair in range(NT // 2):
             P.s_add_u32(S_A0.lo, S_IN.lo, Lit(4096 * mpair))
@@ -240,18 +284,43 @@ class Gen:
         self.load_new_rows(0)
         P.comment("---- prologue done")
 
-    def load_new_rows(self, blk_ahead):
-        """rows NT..15 of the block `blk_ahead` blocks after the current one -> N, their gathers -> G_NX"""
+    def load_new_rows(self, blk_ahead, thunks=False, soff=None):
+        """rows NT..15 of the block `blk_ahead` blocks after the current one -> N, their gathers -> G_NX.
+        thunks: return the instructions as a list of closures (to be woven into arithmetic); soff: an SGPR holding the byte
+        offset of that block instead of a constant"""
         P, HS, NT = self.P, self.HS, self.NT
-        base = 4 * self.BLK * blk_ahead + 2048 * NT
+        if "nomem" in self.opts and blk_ahead:
+            return []
+        nt = "nt" in self.opts or "ntld" in self.opts
+        base = (0 if soff is not None else 4 * self.BLK * blk_ahead) + 2048 * NT
+        ops = []
+        def setbase(extra):
+            def f():
+                if soff is not None:
+                    P.s_add_u32(S_A0.lo, S_IN.lo, soff)
+                    P.s_addc_u32(S_A0.hi, S_IN.hi, Lit(0))
+                    P.s_add_u32(S_A0.lo, S_A0.lo, Lit(base + extra))
+                    P.s_addc_u32(S_A0.hi, S_A0.hi, Lit(0))
+                else:
+                    P.s_add_u32(S_A0.lo, S_IN.lo, Lit(base + extra))
+                    P.s_addc_u32(S_A0.hi, S_IN.hi, Lit(0))
+            return f
         for mpair in range(HS // 2):
-            P.s_add_u32(S_A0.lo, S_IN.lo, Lit(base + 4096 * mpair))
-            P.s_addc_u32(S_A0.hi, S_IN.hi, Lit(0))
             for e in range(2):
-                P.global_load_dwordx2(self.N[2 * mpair + e], self.VOFF, S_A0, 2048 * e)
-        P.s_add_u32(S_A0.lo, S_IN.lo, Lit(base))
-        P.s_addc_u32(S_A0.hi, S_IN.hi, Lit(0))
-        P.global_load_dword(self.G_NX, self.VG, S_A0, -4)
+                def f(mpair=mpair, e=e):
+                    if e == 0:
+                        setbase(4096 * mpair)()
+                    P.global_load_dwordx2(self.N[2 * mpair + e], self.VOFF, S_A0, 2048 * e, nt=nt)
+                ops.append(f)
+        def g():
+            setbase(0)()
+            P.global_load_dword(self.G_NX, self.VG, S_A0, -4, nt=nt)
+        ops.append(g)
+        if thunks:
+            return ops
+        for f in ops:
+            f()
+        return []
 
     def build_pq(self):
         """D[k] = (p, q) of block row k: q = own pair's .x, p = the .y of lane t-1 (lane 0 of a wave: the gathered frame);
@@ -327,16 +396,21 @@ class Gen:
         """second half of a middle pass: stage 2 one DFT-4 at a time, outputs X[ka + 4 la] times the W256 table entry, stored
         to the wave-local exchange; then the transposed read back into D"""
         P = self.P
-        tb = self.TB
+        two = "tw2" in self.opts and len(self.TMP) >= 10
+        sets = [self.TB, self.TT[1:4] + [self.TMP[9]]] if two else [self.TB]
         def fetch(ka):
+            tb = sets[ka % len(sets)]
             for la in range(4):
                 k = ka + 4 * la
                 if k:
                     P.ds_read_b64(tb[la], self.A_TL, tw_base + 128 * k)
-        bfl = self.stage2_lists(v, DIR)
+        bfl = [self.radix4_ops(v[4 * ka], v[4 * ka + 1], v[4 * ka + 2], v[4 * ka + 3], DIR, ka == 2, self.TT[0]) for ka in range(4)]
         r = self.TR[0]
         fetch(0)
+        if two:
+            fetch(1)
         for ka in range(4):
+            tb = sets[ka % len(sets)]
             self.run_ops(bfl[ka])
             for la in range(4):
                 k = ka + 4 * la
@@ -344,8 +418,8 @@ class Gen:
                 if k:
                     self.cmul(x, x, tb[la], DIR, r)
                 P.ds_write_b64(waddr, x, wstride * k)
-            if ka < 3:
-                fetch(ka + 1)
+            if ka + len(sets) < 4:
+                fetch(ka + len(sets))
         order = [0, 4, 8, 12, 1, 5, 9, 13, 2, 6, 10, 14, 3, 7, 11, 15]
         for k in order:
             P.ds_read_b64(self.D[k], raddr, rstride * k)
@@ -391,6 +465,17 @@ class Gen:
             ls = [self.cmul_ops(v[4 * ka + be], v[4 * ka + be], w, -1, sc[ka % len(sc)]) for ka in range(4)]
             self.run_ops(self.interleave(ls) if len(set(x.n for x in sc)) >= 4 else sum(ls, []))
         bfl = self.stage2_lists(v, -1)
+        if "spreadst" in self.opts and self.kind != "core":
+            # each DFT-4 of the last stage yields rows ka, ka + 4, ka + 8, ka + 12: mixed and stored while the next one computes
+            u = self.natural(v)
+            for ka in range(4):
+                self.run_ops(bfl[ka])
+                for la in range(4):
+                    row = ka + 4 * la
+                    if self.R0 <= row < self.R0 + self.HS:
+                        self.epilogue_row(u, row - self.R0)
+            self.stored = True
+            return u
         if self.nbf >= 4:
             self.run_ops(self.interleave(bfl))
         else:
@@ -398,46 +483,70 @@ class Gen:
                 self.run_ops(l)
         return self.natural(v)
 
-    def epilogue(self, u):
-        """rows R0 .. R0 + HS - 1: out = ca dry + sa u (or sa u), stored as aligned pairs"""
-        P, HS, R0 = self.P, self.HS, self.R0
-        for m in range(HS // 2):
+    def epilogue_row(self, u, k):
+        """output row R0 + k: out = ca dry + sa u (or sa u), stored as aligned pairs"""
+        P, R0 = self.P, self.R0
+        nt = "nt" in self.opts or "ntst" in self.opts
+        m, e = k // 2, k % 2
+        x = u[R0 + k]
+        if self.MODE == MODE_ROT:
+            tq = self.TB[k % len(self.TB)]
+            P.pk("mul", tq, [self.K[R0 + k], S_ROT], op_sel=[0, 0], op_sel_hi=[1, 0])
+            P.pk("fma", x, [x, S_ROT, tq], op_sel=[0, 1, 0], op_sel_hi=[1, 1, 1])
+        else:
+            P.pk("mul", x, [x, S_ROT], op_sel=[0, 1], op_sel_hi=[1, 1])
+        if self.kind == "core":
+            P.ds_write_b64(self.A_W1, x, 2048 * k)
+        elif "nomem" not in self.opts:
             P.s_add_u32(S_A0.lo, S_OUT.lo, Lit(4096 * m))
             P.s_addc_u32(S_A0.hi, S_OUT.hi, Lit(0))
-            for e in range(2):
-                k = 2 * m + e
-                x = u[R0 + k]
-                if self.MODE == MODE_ROT:
-                    tq = self.TB[k % len(self.TB)]
-                    P.pk("mul", tq, [self.K[R0 + k], S_ROT], op_sel=[0, 0], op_sel_hi=[1, 0])
-                    P.pk("fma", x, [x, S_ROT, tq], op_sel=[0, 1, 0], op_sel_hi=[1, 1, 1])
-                else:
-                    P.pk("mul", x, [x, S_ROT], op_sel=[0, 1], op_sel_hi=[1, 1])
-                P.global_store_dwordx2(self.VOFF, x, S_A0, 2048 * e)
+            P.global_store_dwordx2(self.VOFF, x, S_A0, 2048 * e, nt=nt)
+
+    def epilogue(self, u):
+        for k in range(self.HS):
+            self.epilogue_row(u, k)
 
     def loop(self):
         P, HS = self.P, self.HS
-        P.s_waitcnt(vmcnt=0)
-        P.label("L_top")
-        # whichever way the top is reached, what may still be in flight: the previous block's HS stores (younger than its
-        # prefetch, which the wait below therefore completes)
-        P.s_waitcnt(vmcnt=HS, lgkmcnt=0)
-        P.reset_queues(vm_stores=HS)
+        core = self.kind == "core"
+        if not core:
+            P.s_waitcnt(vmcnt=0)
+            P.label("L_top")
+            # whichever way the top is reached, what may still be in flight: the previous block's HS stores (younger than its
+            # prefetch, which the wait below therefore completes)
+            P.s_waitcnt(vmcnt=HS, lgkmcnt=0)
+            P.reset_queues(vm_stores=HS)
         P.comment("---- (p, q) pairs")
+        if "prio1" in self.opts:
+            P.s_setprio(3)
         self.build_pq()
         P.comment("---- forward pass 1 + exchange 1")
         self.fwd_pass1()
         P.s_waitcnt(lgkmcnt=0)
+        if "prio1" in self.opts:
+            P.s_setprio(0)
         P.s_barrier()
         P.comment("---- forward pass 2")
         v = self.fwd_pass2()
         # the next block's new rows go out right behind the first barrier
-        P.s_cmp_eq_u32(S_NBLK, Lit(1))
-        P.s_cbranch_scc1("L_nopf")
-        self.load_new_rows(1)
-        P.label("L_nopf")
-        self.stage1(v, 1)
-        self.run_ops(self.stage1_twiddle_ops(v, 1, self.scratch_pairs()))
+        if core:
+            self.stage1(v, 1)
+            self.run_ops(self.stage1_twiddle_ops(v, 1, self.scratch_pairs()))
+        elif "burstld" not in self.opts:
+            # ... woven into the butterflies, one load every few instructions; the last block of a run re-reads its own rows
+            # (in range by definition) instead of branching around the loads
+            P.s_cmp_eq_u32(S_NBLK, Lit(1))
+            P.s_cselect(S_T[3], Lit(0), Lit(4 * self.BLK))
+            lds_ = self.load_new_rows(1, thunks=True, soff=S_T[3])
+            main = self.stage1_ops(v, 1) + self.stage1_twiddle_ops(v, 1, self.scratch_pairs())
+            self.run_ops(self.weave(main, lds_, max(1, len(main) // (len(lds_) + 1)) if lds_ else 1))
+        else:
+            P.s_cmp_eq_u32(S_NBLK, Lit(1))
+            P.s_cbranch_scc1("L_nopf")
+            self.load_new_rows(1)
+            P.label("L_nopf")
+            self.stage1(v, 1)
+            self.run_ops(self.stage1_twiddle_ops(v, 1, self.scratch_pairs()))
         self.twiddled_exchange(v, 1, LDS_TWF, self.A_X2, 8, self.A_R1, KG * 8)
         P.comment("---- forward pass 3")
         v = self.D
@@ -467,9 +576,20 @@ class Gen:
         for k in order:
             P.ds_read_b64(self.D[k], self.A_W1, KL1 * 8 * k)
         P.comment("---- inverse pass 3")
+        self.stored = False
+        if "prio2" in self.opts:
+            P.s_setprio(3)
         u = self.inv_pass3()
         P.comment("---- mix and store")
-        self.epilogue(u)
+        if core:
+            P.s_barrier()   # every wave has read its share of the last exchange: the area takes the output rows
+            self.epilogue(u)
+            P.s_waitcnt(lgkmcnt=0)
+            return
+        if not self.stored:
+            self.epilogue(u)
+        if "prio2" in self.opts:
+            P.s_setprio(0)
         P.s_add_u32(S_IN.lo, S_IN.lo, Lit(4 * self.BLK))
         P.s_addc_u32(S_IN.hi, S_IN.hi, Lit(0))
         P.s_add_u32(S_OUT.lo, S_OUT.lo, Lit(4 * self.BLK))
@@ -500,9 +620,11 @@ class Gen:
 
 
 # ---------------------------------------------------------------------------------------------------- self-test
-def self_test(HS, MODE, NA=1, nblk=3, seed=1, verbose=True):
+def self_test(HS, MODE, NA=1, nblk=3, seed=1, verbose=True, opts=(), kind="run"):
     import olasave_model as M
-    g = Gen(HS, MODE, NA)
+    g = Gen(HS, MODE, NA, opts, kind)
+    if kind == "core":
+        nblk = 1
     P = g.build()
     NT, R0, BLK = g.NT, g.R0, g.BLK
     firlen = 512 * NT
@@ -556,7 +678,23 @@ def self_test(HS, MODE, NA=1, nblk=3, seed=1, verbose=True):
     emu.s[:, S_NBLK.n] = nblk
     emu.s[:, S_LDS.n] = 0
     emu.v[g.TMP[0].n] = np.arange(256, dtype=np.uint32)
+    if kind == "core":   # what the C++ code stages: rows as (q, c) pairs, the gathered frames in lane layout
+        tt = np.arange(256)
+        for r in range(16):
+            a = a0 + 512 * r + 2 * tt
+            ldsf[(r * 256 + tt) * 2], ldsf[(r * 256 + tt) * 2 + 1] = x[a], x[a + 1]
+        l, w = tt & 63, tt >> 6
+        for arr, off, lo in ((LDS_GCAR, HS - NT, 0), (LDS_GNX, 0, NT)):
+            n_rows = NT if arr == LDS_GCAR else HS
+            ok = (l >= off) & (l < off + n_rows)
+            row = np.where(ok, lo + l - off, 0)
+            val = np.where(ok, x[a0 + 512 * row + 2 * 64 * w - 1], 0)
+            ldsf[arr // 4 + tt] = val
     steps = emu.run(P)
+    if kind == "core":
+        tt = np.arange(256)
+        for k in range(HS):
+            out[512 * k + 2 * tt], out[512 * k + 2 * tt + 1] = ldsf[(k * 256 + tt) * 2], ldsf[(k * 256 + tt) * 2 + 1]
     # reference: direct convolution in float64.  z[j] = x[a0 + 2j - 1] + i x[a0 + 2j]; block b's local sample n is
     # stream sample j = b * 256 HS + n; output row R0 + k of block b <-> frames b BLK + 512 k + 2 t (+1)
     xd = x.astype(np.float64)
@@ -583,8 +721,8 @@ def self_test(HS, MODE, NA=1, nblk=3, seed=1, verbose=True):
     npk = sum(v for k, v in st.items() if k.startswith("pk_"))
     nval = sum(v for k, v in st.items() if k.startswith("v_"))
     if verbose:
-        print("HS %2d mode %d NA %d: max err %.2e over %d blocks; VGPRs %d (temporaries %d pairs); loop+prologue: %d packed, %d other VALU, "
-              "%d ds, %d vmem, %d waits" % (HS, MODE, NA, err, nblk, g.n_vgpr, len(g.TMP), npk, nval, st.get("ds_read_b64", 0) + st.get("ds_write_b64", 0),
+        print("%s HS %2d mode %d NA %d: max err %.2e over %d blocks; VGPRs %d (temporaries %d pairs); loop+prologue: %d packed, %d other VALU, "
+              "%d ds, %d vmem, %d waits" % (kind, HS, MODE, NA, err, nblk, g.n_vgpr, len(g.TMP), npk, nval, st.get("ds_read_b64", 0) + st.get("ds_write_b64", 0) + st.get("ds_read_b32", 0),
                                             st.get("gload2", 0) + st.get("gload1", 0) + st.get("gstore2", 0), st.get("s_waitcnt", 0)))
     assert err < 1e-6, err
     return g, P
@@ -594,7 +732,7 @@ def self_test(HS, MODE, NA=1, nblk=3, seed=1, verbose=True):
 VARIANTS = [(hs, mode, 1) for hs in (8, 10, 12) for mode in (MODE_ROT, MODE_HILBERT)]
 
 
-def emit(path):
+def emit(path, opts=()):
     """csrc/prot_olasave_asm.inc: one macro per variant = the asm text of a run of blocks, its inputs taken from the inline-asm
     operands %0..%7 (in, out: 64-bit SGPR pairs; nblk, lds byte offset: SGPRs; sv: pair; ca, sa * gain: SGPRs; t: VGPR)"""
     out = ["// GENERATED by tools/gen/gen_olasave.py -- do not edit.  The steady-state loop of olasave_kernel as gfx950 assembly",
@@ -603,8 +741,8 @@ def emit(path):
            "// operands: %0 in (frame (row 0, thread 0).q of the first block), %1 out (first output frame), %2 blocks, %3 LDS byte",
            "// offset of the exchange area, %4 constants table, %5 ca, %6 sa * gain, %7 thread id",
            "#pragma once", ""]
-    for HS, MODE, NA in VARIANTS:
-        g = Gen(HS, MODE, NA)
+    for HS, MODE, NA, kind in [(h, m, n, k) for k in ("run", "core") for (h, m, n) in VARIANTS]:
+        g = Gen(HS, MODE, NA, opts if kind == "run" else [o for o in opts if o in ("nolds", "novalu")], kind)
         P = g.build()
         head = ["s_mov_b64 %r, %%0" % S_IN, "s_mov_b64 %r, %%1" % S_OUT, "s_mov_b32 %r, %%2" % S_NBLK, "s_mov_b32 %r, %%3" % S_LDS,
                 "s_mov_b64 %r, %%4" % S_SV, "s_mov_b32 %r, %%5" % S_ROT.lo, "s_mov_b32 %r, %%6" % S_ROT.hi, "v_mov_b32 %r, %%7" % g.TMP[0].lo,
@@ -614,8 +752,8 @@ def emit(path):
             head.append("s_mov_b32 s%d, %r" % (n + 1, Lit(float(hi))))
         lines = head + P.text(label_suffix="%=")
         st = P.stats()
-        out.append("// HS %d, mode %d, NA %d: %d VGPRs, %d instructions" % (HS, MODE, NA, g.n_vgpr, sum(v for k, v in st.items() if k not in ("comment", "label"))))
-        out.append("#define PROT_SV_ASM_%d_%d_%d \\" % (HS, MODE, NA))
+        out.append("// %s, HS %d, mode %d, NA %d: %d VGPRs, %d instructions" % (kind, HS, MODE, NA, g.n_vgpr, sum(v for k, v in st.items() if k not in ("comment", "label"))))
+        out.append("#define PROT_SV_%s_%d_%d_%d \\" % ("ASM" if kind == "run" else "CORE", HS, MODE, NA))
         for l in lines:
             if l.startswith(";"):
                 continue
@@ -623,7 +761,7 @@ def emit(path):
         out.append('\t""')
         out.append("")
     for HS in (8, 10, 12):
-        nv = max(Gen(HS, m, na).n_vgpr for (h, m, na) in VARIANTS if h == HS)
+        nv = max(Gen(HS, m, na, opts, k).n_vgpr for (h, m, na) in VARIANTS if h == HS for k in ("run", "core"))
         clob = ['"memory"', '"vcc"', '"scc"'] + ['"s%d"' % i for i in SGPR_CLOBBER] + ['"v%d"' % i for i in range(0, nv)]
         out.append("#define PROT_SV_ASM_CLOBBERS_%d " % HS + ", ".join(clob))
     out.append("")
@@ -631,9 +769,24 @@ def emit(path):
 
 
 if __name__ == "__main__":
+    here = os.path.dirname(os.path.abspath(__file__))
+    csrc = os.path.join(here, "..", "..", "phaserotate.lv2_amd", "csrc")
+    if "--variant" in sys.argv:   # timing experiments: python3 gen_olasave.py --variant NAME --opts a,b  -> csrc/variants/
+        name = sys.argv[sys.argv.index("--variant") + 1]
+        opts = [o for o in sys.argv[sys.argv.index("--opts") + 1].split(",") if o] if "--opts" in sys.argv else []
+        wrong = {"nolds", "nomem", "novalu"} & set(opts)
+        if not wrong:
+            for HS, MODE, NA in VARIANTS:
+                self_test(HS, MODE, NA, nblk=2, opts=opts, verbose=False)
+        os.makedirs(os.path.join(csrc, "variants"), exist_ok=True)
+        dst = os.path.join(csrc, "variants", "prot_olasave_asm_%s.inc" % name)
+        emit(dst, opts)
+        print("wrote", os.path.normpath(dst), "(results WRONG by design)" if wrong else "(self-test passed)")
+        sys.exit(0)
     for HS, MODE, NA in VARIANTS:
         self_test(HS, MODE, NA, nblk=2 if "--quick" in sys.argv else 3)
+        self_test(HS, MODE, NA, kind="core")
     if "--check" not in sys.argv:
-        dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "phaserotate.lv2_amd", "csrc", "prot_olasave_asm.inc")
+        dst = os.path.join(csrc, "prot_olasave_asm.inc")
         emit(dst)
         print("wrote", os.path.normpath(dst))

@@ -120,7 +120,7 @@ class Prog:
                 self.vmq.append(self._regs(i.d))
             elif i.op == "gstore2":
                 self.vmq.append(set())
-            elif i.op == "ds_read_b64":
+            elif i.op in ("ds_read_b64", "ds_read_b32"):
                 if len(self.lgq) >= 15:   # the counter has 4 bits: the 16th operation in flight would stall the wave anyway
                     pass
                 self.lgq.append(self._regs(i.d))
@@ -158,6 +158,9 @@ class Prog:
     def ds_write_b64(self, addr, data, off=0):
         assert 0 <= off < 65536
         return self.add(Ins("ds_write_b64", "ds_write_b64 %r, %r%s" % (addr, data, " offset:%d" % off if off else ""), addr=addr, data=data, off=off))
+    def ds_read_b32(self, d, addr, off=0):
+        assert 0 <= off < 65536
+        return self.add(Ins("ds_read_b32", "ds_read_b32 %r, %r%s" % (d, addr, " offset:%d" % off if off else ""), d=d, addr=addr, off=off))
     def ds_read_b64(self, d, addr, off=0):
         assert 0 <= off < 65536
         return self.add(Ins("ds_read_b64", "ds_read_b64 %r, %r%s" % (d, addr, " offset:%d" % off if off else ""), d=d, addr=addr, off=off))
@@ -166,12 +169,12 @@ class Prog:
     def _goff(self, off):
         assert -4096 <= off <= 4095, off
         return " offset:%d" % off if off else ""
-    def global_load_dwordx2(self, d, voff, sbase, off=0):
-        return self.add(Ins("gload2", "global_load_dwordx2 %r, %r, %r%s" % (d, voff, sbase, self._goff(off)), d=d, voff=voff, sbase=sbase, off=off))
-    def global_load_dword(self, d, voff, sbase, off=0):
-        return self.add(Ins("gload1", "global_load_dword %r, %r, %r%s" % (d, voff, sbase, self._goff(off)), d=d, voff=voff, sbase=sbase, off=off))
-    def global_store_dwordx2(self, voff, data, sbase, off=0):
-        return self.add(Ins("gstore2", "global_store_dwordx2 %r, %r, %r%s" % (voff, data, sbase, self._goff(off)), voff=voff, data=data, sbase=sbase, off=off))
+    def global_load_dwordx2(self, d, voff, sbase, off=0, nt=False):
+        return self.add(Ins("gload2", "global_load_dwordx2 %r, %r, %r%s%s" % (d, voff, sbase, self._goff(off), " nt" if nt else ""), d=d, voff=voff, sbase=sbase, off=off))
+    def global_load_dword(self, d, voff, sbase, off=0, nt=False):
+        return self.add(Ins("gload1", "global_load_dword %r, %r, %r%s%s" % (d, voff, sbase, self._goff(off), " nt" if nt else ""), d=d, voff=voff, sbase=sbase, off=off))
+    def global_store_dwordx2(self, voff, data, sbase, off=0, nt=False):
+        return self.add(Ins("gstore2", "global_store_dwordx2 %r, %r, %r%s%s" % (voff, data, sbase, self._goff(off), " nt" if nt else ""), voff=voff, data=data, sbase=sbase, off=off))
 
     # ---- SALU / control ----
     def s_mov(self, d, a): return self.add(Ins("s_mov", "s_mov_b32 %r, %r" % (d, a), d=d, a=a))
@@ -179,6 +182,7 @@ class Prog:
     def s_add_u32(self, d, a, b): return self.add(Ins("s_add_u32", "s_add_u32 %r, %r, %r" % (d, a, b), d=d, a=a, b=b))
     def s_addc_u32(self, d, a, b): return self.add(Ins("s_addc_u32", "s_addc_u32 %r, %r, %r" % (d, a, b), d=d, a=a, b=b))
     def s_sub_u32(self, d, a, b): return self.add(Ins("s_sub_u32", "s_sub_u32 %r, %r, %r" % (d, a, b), d=d, a=a, b=b))
+    def s_cselect(self, d, a, b): return self.add(Ins("s_cselect", "s_cselect_b32 %r, %r, %r" % (d, a, b), d=d, a=a, b=b))
     def s_cmp_lg_u32(self, a, b): return self.add(Ins("s_cmp_lg", "s_cmp_lg_u32 %r, %r" % (a, b), a=a, b=b))
     def s_cmp_eq_u32(self, a, b): return self.add(Ins("s_cmp_eq", "s_cmp_eq_u32 %r, %r" % (a, b), a=a, b=b))
     def s_cbranch_scc1(self, label): return self.add(Ins("s_cbranch_scc1", "s_cbranch_scc1 %s" % label, label=label))
@@ -373,6 +377,12 @@ class Emu:
                 w = a // 4
                 self.v[i.d.n], self.v[i.d.n + 1] = self.lds[w], self.lds[w + 1]
                 self.lgkm_q.append(("dsread", self._regs(i.d)))
+            elif op == "ds_read_b32":
+                self._touch(self._regs(i.addr), self._regs(i.d), i.text)
+                a = (self._rd32(i.addr).astype(np.int64) + i.off)
+                assert np.all(a % 4 == 0) and a.max() + 4 <= self.lds.size * 4, "LDS address"
+                self.v[i.d.n] = self.lds[a // 4]
+                self.lgkm_q.append(("dsread", self._regs(i.d)))
             elif op in ("gload2", "gload1", "gstore2"):
                 base = (self._srd(i.sbase.lo).astype(np.uint64) | (self._srd(i.sbase.hi).astype(np.uint64) << 32))
                 addr = np.repeat(base, 64).astype(np.int64) + self._rd32(i.voff).astype(np.int64) + i.off
@@ -412,6 +422,8 @@ class Emu:
                 else:
                     self.scc = int(r[0] >> 32) & 1
                 self.s[:, i.d.n] = (r & 0xffffffff).astype(np.uint32)
+            elif op == "s_cselect":
+                self.s[:, i.d.n] = self._srd(i.a) if self.scc else self._srd(i.b)
             elif op in ("s_cmp_lg", "s_cmp_eq"):
                 a, b = self._srd(i.a), self._srd(i.b)
                 self.scc = int((a[0] != b[0]) if op == "s_cmp_lg" else (a[0] == b[0]))

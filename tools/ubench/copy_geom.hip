@@ -75,6 +75,69 @@ __global__ __launch_bounds__(256) void copy_blocks(const float* __restrict__ in,
   if (WHAT == 1 && acc.x == 12345.678f) out[t] = acc.y;
 }
 
+// E: contiguous runs, row by row: the load of row r + D goes out, then the store of row r (a steady 1:1 mix of loads and
+// stores instead of bursts of ROWS loads and ROWS stores); D rows of 256 x 8 B in flight per workgroup
+template <int D>
+__global__ __launch_bounds__(256) void copy_rowpipe(const float* __restrict__ in, float* __restrict__ out, long rows_per_wg) {
+  extern __shared__ char dyn[];
+  const int t = threadIdx.x;
+  const f2* s = (const f2*)in + (long)blockIdx.x * rows_per_wg * 256;
+  f2* d = (f2*)out + (long)blockIdx.x * rows_per_wg * 256;
+  f2 ring[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) ring[i] = s[t + 256 * i];
+  long r = 0;
+  for (; r + D <= rows_per_wg - D; r += D) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      f2 cur = ring[i];
+      ring[i] = s[t + 256 * (r + D + i)];
+      d[t + 256 * (r + i)] = cur;
+    }
+  }
+  for (; r < rows_per_wg; ++r) {
+    f2 cur = s[t + 256 * r];
+    d[t + 256 * r] = cur;
+  }
+}
+
+// F: does it matter WHICH XCD touches an address?  The one-shot copy deals 4 KiB chunks round-robin over the 8 XCDs (workgroup
+// i -> XCD i % 8), i.e. XCD k only ever touches chunks = k (mod 8).  Persistent workgroups, workgroup g on XCD g % 8 (observed
+// round-robin placement), each copying chunks of CS bytes whose index is = (g + shift) (mod 8): shift 0 reproduces the one-shot
+// copy's address -> XCD map, shift 4 its opposite; "mix": chunk index = anything (plain block-cyclic).  float4 per lane,
+// DEPTH chunks in flight.
+template <int CSV, int DEPTH>   // CSV float4 per thread per chunk: chunk = CSV * 4 KiB
+__global__ __launch_bounds__(256) void copy_xcd(const f4* __restrict__ in, f4* __restrict__ out, long nchunks, int shift, int mix) {
+  extern __shared__ char dyn[];
+  const int t = threadIdx.x, g = blockIdx.x, G = gridDim.x;
+  auto chunk_of = [&](long i) -> long {
+    long c = mix ? (i * G + g) : ((i * (G / 8) + g / 8) * 8 + ((g + shift) & 7));
+    return c < nchunks ? c : -1;
+  };
+  f4 ring[DEPTH][CSV];
+#pragma unroll
+  for (int a = 0; a < DEPTH; ++a) { long c = chunk_of(a); if (c >= 0) {
+#pragma unroll
+    for (int k = 0; k < CSV; ++k) ring[a][k] = in[(c * CSV + k) * 256 + t]; } }
+  for (long i = 0;; i += DEPTH) {
+#pragma unroll
+    for (int a = 0; a < DEPTH; ++a) {
+      long c = chunk_of(i + a);
+      if (c < 0) return;
+      f4 cur[CSV];
+#pragma unroll
+      for (int k = 0; k < CSV; ++k) cur[k] = ring[a][k];
+      long cn = chunk_of(i + a + DEPTH);
+      if (cn >= 0) {
+#pragma unroll
+        for (int k = 0; k < CSV; ++k) ring[a][k] = in[(cn * CSV + k) * 256 + t];
+      }
+#pragma unroll
+      for (int k = 0; k < CSV; ++k) out[(c * CSV + k) * 256 + t] = cur[k];
+    }
+  }
+}
+
 static float time_it(std::function<void()> f) {
   float best = 1e9;
   for (int rep = 0; rep < 5; ++rep) {
@@ -135,6 +198,25 @@ int main() {
     run_cfg<10, false, 1, 1>(in, out, n, wgs, 2, 1, "C read");
     run_cfg<10, false, 2, 1>(in, out, n, wgs, 1, 1, "B write");
     run_cfg<10, false, 2, 1>(in, out, n, wgs, 2, 1, "C write");
+  }
+  for (int wgs = 2; wgs <= 8; wgs *= 2) {
+    const unsigned lds = wgs >= 8 ? 0 : ((160 * 1024 / wgs) & ~1023u);
+    const int grid = 256 * wgs;
+    const long rows = (n / 512) / grid;
+#define ROWPIPE(D_) { auto kern = copy_rowpipe<D_>; hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      float ms = time_it([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, in, out, rows); }); \
+      printf("E rowpipe D %2d wg/CU %d: %.4f ms  %.2f TB/s\n", D_, wgs, ms, 8.0 * rows * 512 * grid / ms * 1e-9); fflush(stdout); }
+    ROWPIPE(4) ROWPIPE(8) ROWPIPE(10) ROWPIPE(16) ROWPIPE(24)
+  }
+#define XCDRUN(CSV_, DEPTH_, wgs, shift, mix) { auto kern = copy_xcd<CSV_, DEPTH_>; hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      const unsigned lds = wgs >= 8 ? 0 : ((160 * 1024 / wgs) & ~1023u); const long nch = n * 4 / (CSV_ * 4096); \
+      float ms = time_it([&] { hipLaunchKernelGGL(kern, dim3(256 * wgs), dim3(256), lds, 0, (const f4*)in, (f4*)out, nch, shift, mix); }); \
+      printf("F xcd chunk %2d KiB depth %d wg/CU %d shift %d mix %d: %.4f ms  %.2f TB/s\n", 4 * CSV_, DEPTH_, wgs, shift, mix, ms, 8.0 * n / ms * 1e-9); fflush(stdout); }
+  for (int wgs = 4; wgs <= 8; wgs += 4) {
+    XCDRUN(1, 4, wgs, 0, 0) XCDRUN(1, 4, wgs, 4, 0) XCDRUN(1, 4, wgs, 1, 0) XCDRUN(1, 4, wgs, 0, 1)
+    XCDRUN(1, 8, wgs, 0, 0) XCDRUN(1, 8, wgs, 4, 0)
+    XCDRUN(2, 4, wgs, 0, 0) XCDRUN(2, 4, wgs, 4, 0) XCDRUN(2, 4, wgs, 0, 1)
+    XCDRUN(4, 2, wgs, 0, 0) XCDRUN(4, 2, wgs, 4, 0)
   }
   printf("status %s\n", hipGetErrorString(hipDeviceSynchronize()));
   return 0;
