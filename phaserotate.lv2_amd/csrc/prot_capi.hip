@@ -154,7 +154,7 @@ bool save_tables (const std::vector<float>& fir, uint32_t F, std::vector<float>&
 			continue;
 		}
 		gain = (float)(mean / F);
-		tab.assign (2 * (size_t)(13 + rows) * 256, 0.f);
+		tab.assign (2 * (size_t)15 * 256, 0.f); // rows 0..11 twiddles, 12 W256 half-shifted, 13 rho, 14 W256 plain
 		auto put = [&] (size_t idx, double ang) {
 			tab[2 * idx]     = (float)std::cos (ang);
 			tab[2 * idx + 1] = (float)std::sin (ang);
@@ -167,8 +167,9 @@ bool save_tables (const std::vector<float>& fir, uint32_t F, std::vector<float>&
 				put ((size_t)(9 + i - 1) * 256 + t, -2.0 * M_PI * (double)t * 4 * i / F);
 			}
 			put ((size_t)12 * 256 + t, -2.0 * M_PI * ((t & 15) - 0.5) * (t >> 4) / 256.0);
+			put ((size_t)14 * 256 + t, -2.0 * M_PI * (double)(((t & 15) * (t >> 4)) & 255) / 256.0);
 			const int q = (t >> 4) + 16 * (t & 15);
-			for (int i = 0; i < rows; ++i) {
+			for (int i = 0; i < 1; ++i) { // (rows == 2 engines keep olapoly_kernel)
 				tab[2 * ((size_t)(13 + i) * 256 + t)]     = (float)(rho[q + 256 * i] / mean);
 				tab[2 * ((size_t)(13 + i) * 256 + t) + 1] = (float)(rho[q + 256 * (15 - i)] / mean);
 			}

@@ -43,8 +43,8 @@ struct OlaParamsT {
 	float         rot_v[2 * kRotInline];
 	// olasave_kernel: per-engine constants (prot_engine_create): f2[12][256] split outer twiddles of thread t (forward at
 	// the half-shifted index: W^{(t-1/2) i}, W^{(t-1/2) 4i}; inverse: W^{t i}, W^{4 t i}; i = 1..3), f2[256] the
-	// half-shifted W256 table W256^{(c-1/2) k2} at [16 k2 + c], f2[2][256] the |B| factors of the rows next to DC
-	// ((rho[q + 256 i], rho[q + 256 (15 - i)]) of thread t, q = (t >> 4) + 16 (t & 15)); sv_gain = mean |B| / 4096
+	// half-shifted W256 table W256^{(c-1/2) k2} at [16 k2 + c], f2[256] the |B| factors of the rows next to DC
+	// ((rho[q], rho[q + 3840]) of thread t, q = (t >> 4) + 16 (t & 15)), f2[256] the plain W256 table; sv_gain = mean |B| / 4096
 	const float*  sv;
 	float         sv_gain;
 	int32_t       sv_flags;   // 1: every block through the C++ form (cross-check of the generated loop)

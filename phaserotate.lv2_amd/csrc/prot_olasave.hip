@@ -86,9 +86,7 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 	constexpr int AM  = MODE == MODE_ROT ? 0 : 2; // the generated code's mode (per-frame rotation: Hilbert branch, mixed here)
 	static_assert (HS == 8 || HS == 10 || HS == 12, "rows per block (HS = 14 needs 124 VGPRs before any temporary: olapoly_kernel)");
 
-	__shared__ f2 smem[kLdsExchange + 512];
-	f2* const twm = smem + kLdsExchange;
-	f2* const twf = smem + kLdsExchange + 256;
+	__shared__ f2 smem[kLdsExchange + 512]; // the exchange area + the two W256 tables (written by the generated prologue)
 
 	const int t0 = threadIdx.x;
 	const int c  = blockIdx.y;
@@ -112,13 +110,6 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 	const bool in_al8  = (reinterpret_cast<uintptr_t> (in) & 7) == 0;
 	const bool out_al8 = (reinterpret_cast<uintptr_t> (out) & 7) == 0;
 
-	// W256 tables in LDS: plain (inverse) and at the half-shifted index (forward)
-	{
-		const f2* __restrict__ sv  = reinterpret_cast<const f2*> (p.sv);
-		const f2* __restrict__ twp = reinterpret_cast<const f2*> (p.tw);
-		twf[t0] = sv[12 * 256 + t0];
-		twm[t0] = twp[16 * (((t0 & 15) * (t0 >> 4)) & 255)];
-	}
 	float ca = 0.f, sa = p.sv_gain;
 	if (MODE == MODE_ROT) {
 		ca = p.rot ? p.rot[2 * c] : p.rot_v[2 * c];
@@ -128,7 +119,21 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 	sa = __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (sa)));
 	const unsigned lds_off = (unsigned)(uintptr_t)(__attribute__ ((address_space (3))) f2*)smem;
 	const float*   a_sv    = uniform_ptr_generic (p.sv);
-	__syncthreads ();
+
+	// the (x[a], x[a+1]) pair of thread t in the 512-frame row that starts at frame ar (a = ar + 2 t): a row lies wholly in the
+	// input array or wholly in the history (both start on row boundaries) -- aligned 8-byte loads; anything else (silence in
+	// reach, odd alignment) frame by frame through the virtual stream [history | input | silence]
+	const bool hist_al8 = hist != nullptr && (reinterpret_cast<uintptr_t> (hist) & 7) == 0 && (p.hist_len & 1) == 0;
+	auto row_pair = [&] (int64_t ar, int t) -> f2 {
+		if (in_al8 && ar >= 0 && ar + 512 <= n_in) {
+			return reinterpret_cast<const f2*> (in + ar)[t];
+		}
+		if (hist_al8 && ar + 512 <= 0 && ar + p.hist_len >= 0) {
+			return reinterpret_cast<const f2*> (hist + (ar + p.hist_len))[t];
+		}
+		const int64_t a = ar + 2 * (int64_t)t;
+		return mkf2 (ldv (in, n_in, hist, p.hist_len, a), ldv (in, n_in, hist, p.hist_len, a + 1));
+	};
 
 	for (int64_t s = r0; s < r1;) {
 		const int64_t a0 = s - Dd - 512 * R0; // frame of (row 0, thread 0).q: the dry frame of output row r is input row r
@@ -168,22 +173,9 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 		LdsF* const gnx  = (LdsF*)(smem + 4096 + 128); //   lanes HS-NT..HS-1 <-> rows 0..NT-1, lanes 0..HS-1 <-> rows NT..15
 		__syncthreads (); // (every wave has left the generated loop, if that is where it comes from)
 		{
-			const bool fast = (a0 - 1 >= 0) && (a0 + 8192 <= n_in) && in_al8;
-			if (fast) {
-#pragma unroll
-				for (int m = 0; m < 8; ++m) {
-					const PROT_GLOBAL float* __restrict__ b = uniform_ptr (in + a0 + 1024 * m);
-#pragma unroll
-					for (int e = 0; e < 2; ++e) {
-						st[256 * (2 * m + e) + t] = reinterpret_cast<const PROT_GLOBAL f2*> (b)[(unsigned)t + 256u * e];
-					}
-				}
-			} else {
-#pragma unroll 4
-				for (int k = 0; k < 16; ++k) {
-					const int64_t a = a0 + 2 * (int64_t)(t + 256 * k);
-					st[256 * k + t] = mkf2 (ldv (in, n_in, hist, p.hist_len, a), ldv (in, n_in, hist, p.hist_len, a + 1));
-				}
+#pragma unroll 2
+			for (int k = 0; k < 16; ++k) {
+				st[256 * k + t] = row_pair (a0 + 512 * (int64_t)k, t);
 			}
 			const int l = t & 63, w = t >> 6;
 			const int rc = l - (HS - NT), rn = NT + l; // the row this lane gathers for, as a carried / as a new row
@@ -199,6 +191,13 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 			PROT_SV_ALL (CORE, a_in, a_out, one, cca, csa)
 		}
 		__syncthreads ();
+		// The thread id opaque AGAIN: nothing per-lane may be kept alive across the generated code (which owns v0..v119) except
+		// the thread id itself -- the compiler otherwise carries hoisted per-lane addresses across it through scratch, and a
+		// spill placed inside one of the divergent branches above comes back with the inactive lanes' slots stale
+		// (seen: the per-frame rotation of lanes >= 2 read at index 0)
+		t = t0;
+		asm volatile ("" : "+v"(t));
+		t &= 255;
 		// rows 0..HS-1 of the exchange area now hold the output pairs of frames s + 512 k + 2 t (+1)
 		if (MODE != MODE_RAMP && s + BLK <= r1 && out_al8) {
 #pragma unroll
@@ -212,18 +211,20 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 		} else {
 #pragma unroll 2
 			for (int k = 0; k < HS; ++k) {
-				const f2 o = st[256 * k + t];
-#pragma unroll
-				for (int h = 0; h < 2; ++h) {
-					const int64_t pos = s + 2 * (int64_t)(t + 256 * k) + h;
-					if (pos < r1) {
-						if (MODE == MODE_RAMP) {
-							const f2 cs = reinterpret_cast<const f2*> (p.rot_s)[(int64_t)c * p.n_out + pos];
-							out[pos]    = cs.x * ldv (in, n_in, hist, p.hist_len, pos - Dd) + cs.y * (h ? o.y : o.x);
-						} else {
-							out[pos] = h ? o.y : o.x;
-						}
-					}
+				f2            o    = st[256 * k + t];
+				const int64_t pos0 = s + 512 * (int64_t)k + 2 * (int64_t)t;
+				if (MODE == MODE_RAMP && pos0 < r1) {
+					// per-frame rotation: the dry pair of output row k is the (q, c) pair of input row R0 + k
+					const f2 d   = row_pair (pos0 - 2 * (int64_t)t - Dd, t);
+					const f2 cs0 = reinterpret_cast<const f2*> (p.rot_s)[(int64_t)c * p.n_out + pos0];
+					const f2 cs1 = pos0 + 1 < r1 ? reinterpret_cast<const f2*> (p.rot_s)[(int64_t)c * p.n_out + pos0 + 1] : mkf2 (0.f, 0.f);
+					o            = mkf2 (cs0.x * d.x + cs0.y * o.x, cs1.x * d.y + cs1.y * o.y);
+				}
+				if (pos0 < r1) {
+					out[pos0] = o.x;
+				}
+				if (pos0 + 1 < r1) {
+					out[pos0 + 1] = o.y;
 				}
 			}
 		}

@@ -167,14 +167,55 @@ class Gen:
         return self.interleave(bf) if self.nbf >= 4 else sum(bf, [])
 
     def mul_w16_ops(self, x, DIR, m, r):
-        """pkt_mul_w16: x *= W16^m (conjugate for DIR < 0), m in {1, 2, 3, 6, 9}"""
-        P = self.P
+        """pkt_mul_w16: x *= W16^m (conjugate for DIR < 0), m in {1, 2, 3, 6, 9}.  For m = 2 and 6 only the rotation part
+        x -+ j x is done here (in place); the real factor +-R rides in the butterfly that consumes x (stage2_ops: one fma
+        instead of a multiply and an add)"""
         if m == 2:
-            return [lambda: (self.add_mj if DIR > 0 else self.sub_mj)(r, x, x), lambda: P.pk("mul", x, [r, S_RR], op_sel=[0, 0], op_sel_hi=[1, 0])]
+            return [lambda: (self.add_mj if DIR > 0 else self.sub_mj)(x, x, x)]
         if m == 6:
-            return [lambda: (self.sub_mj if DIR > 0 else self.add_mj)(r, x, x), lambda: P.pk("mul", x, [r, S_RR], op_sel=[0, 1], op_sel_hi=[1, 1])]
+            return [lambda: (self.sub_mj if DIR > 0 else self.add_mj)(x, x, x)]
         w = {1: S_W1, 3: S_W3, 9: S_W9}[m]
         return self.cmul_ops(x, x, w, DIR, r)
+
+    def stage2_ops(self, v, ka, DIR, T, need=(0, 1, 2, 3)):
+        """DFT-4 number ka of the second stage on (v[4 ka], .., v[4 ka + 3]) -> X[ka + 4 la] in v[4 ka + la], with the pending
+        real factors of stage1_twiddle_ops folded in (v[6]: +R, v[9]: +R, v[11]: -R, v[14]: -R; v[10] carries W16^4 = -+j);
+        need = the outputs la that are wanted (the others' instructions are left out)"""
+        P = self.P
+        a, b, c, d = v[4 * ka], v[4 * ka + 1], v[4 * ka + 2], v[4 * ka + 3]
+        n02, n13 = (0 in need or 2 in need), (1 in need or 3 in need)
+        ops = []
+        fma_c = lambda dst, sel: (lambda: P.pk("fma", dst, [c, S_RR, a], op_sel=[0, sel, 0], op_sel_hi=[1, sel, 1]))
+        if ka == 1 or ka == 3:           # c = R' r with R' = +R (ka 1) / -R (ka 3): t0 = a + R' r, t1 = a - R' r
+            sel = 0 if ka == 1 else 1
+            if n02: ops.append(fma_c(T, sel))
+            if n13: ops.append(fma_c(a, 1 - sel))
+        elif ka == 2:                    # c carries -+j
+            if DIR > 0:
+                if n02: ops.append(lambda: self.add_mj(T, a, c))
+                if n13: ops.append(lambda: self.sub_mj(a, a, c))
+            else:
+                if n02: ops.append(lambda: self.sub_mj(T, a, c))
+                if n13: ops.append(lambda: self.add_mj(a, a, c))
+        else:
+            if n02: ops.append(lambda: self.add(T, a, c))
+            if n13: ops.append(lambda: self.sub(a, a, c))
+        if ka == 2:                      # b = R rb, d = -R rd: d' = -R rd; t2 = R rb + d'; t3 = R rb - d'
+            ops.append(lambda: P.pk("mul", d, [d, S_RR], op_sel=[0, 1], op_sel_hi=[1, 1]))
+            if n02: ops.append(lambda: P.pk("fma", c, [b, S_RR, d], op_sel=[0, 0, 0], op_sel_hi=[1, 0, 1]))
+            if n13: ops.append(lambda: P.pk("fma", d, [b, S_RR, d], op_sel=[0, 0, 0], op_sel_hi=[1, 0, 1], neg_lo=[0, 0, 1], neg_hi=[0, 0, 1]))
+        else:
+            if n02: ops.append(lambda: self.add(c, b, d))      # t2
+            if n13: ops.append(lambda: self.sub(d, b, d))      # t3
+        if DIR > 0:
+            if 1 in need: ops.append(lambda: self.add_mj(b, a, d))
+            if 3 in need: ops.append(lambda: self.sub_mj(d, a, d))
+        else:
+            if 1 in need: ops.append(lambda: self.sub_mj(b, a, d))
+            if 3 in need: ops.append(lambda: self.add_mj(d, a, d))
+        if 0 in need: ops.append(lambda: self.add(a, T, c))
+        if 2 in need: ops.append(lambda: self.sub(c, T, c))
+        return ops
 
     def stage1_twiddle_ops(self, v, DIR, rs):
         """pkt_stage1_twiddles; rs = scratch pairs to rotate through"""
@@ -196,8 +237,8 @@ class Gen:
             for l in bf:
                 self.run_ops(l)
 
-    def stage2_lists(self, v, DIR):
-        return [self.radix4_ops(v[4 * ka], v[4 * ka + 1], v[4 * ka + 2], v[4 * ka + 3], DIR, ka == 2, self.TT[ka % 4]) for ka in range(4)]
+    def stage2_lists(self, v, DIR, need=None):
+        return [self.stage2_ops(v, ka, DIR, self.TT[ka % 4], need[ka] if need else (0, 1, 2, 3)) for ka in range(4)]
 
     def scratch_pairs(self):
         return self.TR + self.TB
@@ -258,6 +299,18 @@ class Gen:
             P.s_add_u32(S_A0.lo, S_SV.lo, Lit(off))
             P.s_addc_u32(S_A0.hi, S_SV.hi, Lit(0))
             P.global_load_dwordx2(self.RHO[i], self.VOFF, S_A0, 0)
+        # the W256 tables of the middle passes go to LDS behind the exchange area: half-shifted (forward, table row 12) and plain
+        # (inverse, row 14); every wave stores its own 64 entries, the first workgroup barrier of the block orders them
+        P.s_add_u32(S_A0.lo, S_SV.lo, Lit(12 * 2048))
+        P.s_addc_u32(S_A0.hi, S_SV.hi, Lit(0))
+        P.global_load_dwordx2(self.TMP[6], self.VOFF, S_A0, 0)
+        P.s_add_u32(S_A0.lo, S_SV.lo, Lit(14 * 2048))
+        P.s_addc_u32(S_A0.hi, S_SV.hi, Lit(0))
+        P.global_load_dwordx2(self.TMP[7] if len(self.TMP) > 7 else self.TMP[1], self.VOFF, S_A0, 0)
+        self.tab_regs = (self.TMP[6], self.TMP[7] if len(self.TMP) > 7 else self.TMP[1])
+        self.scale_constants()
+        P.ds_write_b64(self.A_W1, self.tab_regs[0], LDS_TWF)
+        P.ds_write_b64(self.A_W1, self.tab_regs[1], LDS_TWM)
         P.comment("---- prologue: the first block's rows")
         if self.kind == "core":
             # staged by the C++ code: row r's (q, c) pair of thread t at slot r * 256 + t, the gathered frames in lane layout
@@ -283,6 +336,25 @@ class Gen:
         P.global_load_dword(self.G_CAR, vg0, S_IN, -4)
         self.load_new_rows(0)
         P.comment("---- prologue done")
+
+    def scale_constants(self):
+        """sa * gain (S_ROT.hi) into the 15 constants i W32^{-k3} and into the |B| factor of row 0 -- every value of the block
+        passes through exactly one of them, so the mix at the end is one fma per pair (Hilbert-only blocks: none)"""
+        P = self.P
+        # through VGPRs, all reads of the constants first, all v_readfirstlane last: on gfx950 a VALU instruction that reads an
+        # SGPR right behind a VALU write of an SGPR (v_readfirstlane s44; v_mul_f32 .., s45, ..) gets the wrong value (measured:
+        # tools/gen/isa.py checks for it); the D registers are free here
+        sa = self.TMP[5].lo
+        regs = [(S_C32[k].lo, self.D[k].lo) for k in range(1, 16)] + [(S_C32[k].hi, self.D[k].hi) for k in range(1, 16)]
+        P.v_mov(sa, S_ROT.hi)
+        for sreg, v in regs:
+            P.v_mov(v, sreg)
+        for sreg, v in regs:
+            P.v_mul_f32(v, v, sa)
+        P.v_mul_f32(self.RHO[0].lo, sa, self.RHO[0].lo)
+        for sreg, v in regs:
+            P.v_readfirstlane(sreg, v)
+        P.s_nop(4)
 
     def load_new_rows(self, blk_ahead, thunks=False, soff=None):
         """rows NT..15 of the block `blk_ahead` blocks after the current one -> N, their gathers -> G_NX.
@@ -328,11 +400,12 @@ class Gen:
         P, HS, NT, R0 = self.P, self.HS, self.NT, self.R0
         src = lambda k: self.K[HS + k] if k < NT else self.N[k - NT]
         for g in range(0, 16, 4):
-            for k in range(g, g + 4):
-                gl = (self.G_CAR, HS - NT + k) if k < NT else (self.G_NX, k - NT)
-                P.v_readlane(S_T[k - g], gl[0], gl[1])
-            for k in range(g, g + 4):
-                P.v_mov(self.D[k].lo, S_T[k - g])
+            for k in range(g, g + 4):   # lane 0 <- the gathered frame of row k (lanes 1..3: junk, overwritten below)
+                gv, lane = (self.G_CAR, HS - NT + k) if k < NT else (self.G_NX, k - NT)
+                if lane == 0:
+                    P.v_mov(self.D[k].lo, gv)
+                else:
+                    P.v_mov_dpp_rowshl(self.D[k].lo, gv, lane)
             for k in range(g, g + 4):
                 P.v_mov(self.D[k].hi, src(k).lo)
             for k in range(g, g + 4):   # (two wait states after the VALU write of D[k].lo: the other moves are in between)
@@ -404,7 +477,7 @@ class Gen:
                 k = ka + 4 * la
                 if k:
                     P.ds_read_b64(tb[la], self.A_TL, tw_base + 128 * k)
-        bfl = [self.radix4_ops(v[4 * ka], v[4 * ka + 1], v[4 * ka + 2], v[4 * ka + 3], DIR, ka == 2, self.TT[0]) for ka in range(4)]
+        bfl = [self.stage2_ops(v, ka, DIR, self.TT[0]) for ka in range(4)]
         r = self.TR[0]
         fetch(0)
         if two:
@@ -464,7 +537,8 @@ class Gen:
             self.cmul(w, A[be], S_TWI[be - 1], 1, r)
             ls = [self.cmul_ops(v[4 * ka + be], v[4 * ka + be], w, -1, sc[ka % len(sc)]) for ka in range(4)]
             self.run_ops(self.interleave(ls) if len(set(x.n for x in sc)) >= 4 else sum(ls, []))
-        bfl = self.stage2_lists(v, -1)
+        rows = range(self.R0, self.R0 + self.HS)   # only these output rows exist (the others are circular wrap-around)
+        bfl = self.stage2_lists(v, -1, need=[[la for la in range(4) if ka + 4 * la in rows] for ka in range(4)])
         if "spreadst" in self.opts and self.kind != "core":
             # each DFT-4 of the last stage yields rows ka, ka + 4, ka + 8, ka + 12: mixed and stored while the next one computes
             u = self.natural(v)
@@ -489,12 +563,8 @@ class Gen:
         nt = "nt" in self.opts or "ntst" in self.opts
         m, e = k // 2, k % 2
         x = u[R0 + k]
-        if self.MODE == MODE_ROT:
-            tq = self.TB[k % len(self.TB)]
-            P.pk("mul", tq, [self.K[R0 + k], S_ROT], op_sel=[0, 0], op_sel_hi=[1, 0])
-            P.pk("fma", x, [x, S_ROT, tq], op_sel=[0, 1, 0], op_sel_hi=[1, 1, 1])
-        else:
-            P.pk("mul", x, [x, S_ROT], op_sel=[0, 1], op_sel_hi=[1, 1])
+        if self.MODE == MODE_ROT:   # (sa * gain rides in the constants of the pointwise stage: scale_constants)
+            P.pk("fma", x, [self.K[R0 + k], S_ROT, x], op_sel=[0, 0, 0], op_sel_hi=[1, 0, 1])
         if self.kind == "core":
             P.ds_write_b64(self.A_W1, x, 2048 * k)
         elif "nomem" not in self.opts:
@@ -634,7 +704,7 @@ def self_test(HS, MODE, NA=1, nblk=3, seed=1, verbose=True, opts=(), kind="run")
     rho = -B
     mean = rho[256 * NA:4096 - 256 * NA].mean()
     # device table (prot_capi.hip save_tables)
-    tab = np.zeros(2 * (13 + NA) * 256, np.float32)
+    tab = np.zeros(2 * 15 * 256, np.float32)
     def put(idx, ang):
         tab[2 * idx], tab[2 * idx + 1] = math.cos(ang), math.sin(ang)
     for t in range(256):
@@ -657,13 +727,10 @@ def self_test(HS, MODE, NA=1, nblk=3, seed=1, verbose=True, opts=(), kind="run")
     emu.map(IN_BASE, x.view(np.uint32))
     emu.map(OUT_BASE, out.view(np.uint32))
     emu.map(SV_BASE, tab.view(np.uint32))
-    # LDS tables (the C++ kernel sets them up)
     ldsf = emu.lds.view(np.float32)
-    for t in range(256):
-        a = -2 * math.pi * (((t & 15) * (t >> 4)) & 255) / 256
-        ldsf[LDS_TWM // 4 + 2 * t], ldsf[LDS_TWM // 4 + 2 * t + 1] = math.cos(a), math.sin(a)
-        a = -2 * math.pi * ((t & 15) - 0.5) * (t >> 4) / 256
-        ldsf[LDS_TWF // 4 + 2 * t], ldsf[LDS_TWF // 4 + 2 * t + 1] = math.cos(a), math.sin(a)
+    for t in range(256):   # table rows 12 (W256 at the half-shifted index) and 14 (plain W256)
+        put(12 * 256 + t, -2 * math.pi * ((t & 15) - 0.5) * (t >> 4) / 256)
+        put(14 * 256 + t, -2 * math.pi * (((t & 15) * (t >> 4)) & 255) / 256)
     ca, sa = 0.6, -0.8
     def sset(sp, lo, hi):
         emu.s[:, sp.n] = np.float32(lo).view(np.uint32)

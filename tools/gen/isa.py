@@ -147,6 +147,12 @@ class Prog:
     def v_mov(self, d, a): return self.add(Ins("v_mov", "v_mov_b32 %r, %r" % (d, a), d=d, a=a))
     def v_mov_dpp_shr1(self, d, a):
         return self.add(Ins("v_mov_dpp_shr1", "v_mov_b32_dpp %r, %r wave_shr:1 row_mask:0xf bank_mask:0xf" % (d, a), d=d, a=a))
+    def v_mov_dpp_rowshl(self, d, a, k):
+        """lanes 0..3 of every wave: d[lane] = a[lane + k] (row 0, bank 0 only; the other lanes keep d)"""
+        assert 1 <= k <= 15
+        return self.add(Ins("v_mov_dpp_rowshl", "v_mov_b32_dpp %r, %r row_shl:%d row_mask:0x1 bank_mask:0x1" % (d, a, k), d=d, a=a, k=k))
+    def v_mul_f32(self, d, a, b): return self.add(Ins("v_mul_f32", "v_mul_f32 %r, %r, %r" % (d, a, b), d=d, a=a, b=b))
+    def v_readfirstlane(self, sd, v): return self.add(Ins("v_readfirstlane", "v_readfirstlane_b32 %r, %r" % (sd, v), d=sd, a=v))
     def v_readlane(self, sd, v, lane): return self.add(Ins("v_readlane", "v_readlane_b32 %r, %r, %d" % (sd, v, lane), d=sd, a=v, lane=lane))
     def v_and(self, d, a, b): return self.add(Ins("v_and", "v_and_b32 %r, %r, %r" % (d, a, b), d=d, a=a, b=b))
     def v_lshl(self, d, sh, a): return self.add(Ins("v_lshl", "v_lshlrev_b32 %r, %r, %r" % (d, sh, a), d=d, a=a, sh=sh))
@@ -299,6 +305,7 @@ class Emu:
         pc, steps = 0, 0
         ins = prog.ins
         recent = []   # VGPRs written by the last two VALU instructions (DPP hazard: 2 wait states)
+        sgpr_wr = 99  # instructions since a VALU wrote an SGPR (v_readlane / v_readfirstlane)
         f32 = lambda u: u.view(np.float32)
         while pc < len(ins):
             i = ins[pc]
@@ -311,14 +318,21 @@ class Emu:
                 continue
             if op == "s_nop":
                 recent = (recent + [set()])[-2:]
+                sgpr_wr += 5
                 continue
-            if op == "v_mov_dpp_shr1":
+            # measured on gfx950: a VALU instruction reading an SGPR directly behind a VALU write of an SGPR reads garbage
+            if op.startswith("pk_") or (op.startswith("v_") and op not in ("v_readlane", "v_readfirstlane")):
+                srcs = list(getattr(i, "srcs", [])) + [getattr(i, k) for k in ("a", "b", "sh") if hasattr(i, k)]
+                if sgpr_wr < 3 and any(isinstance(x, (S, SP)) for x in srcs):
+                    raise RuntimeError("SGPR hazard: %s reads an SGPR %d instruction(s) after a VALU wrote one" % (i.text, sgpr_wr + 1))
+            sgpr_wr = 0 if op in ("v_readlane", "v_readfirstlane") else sgpr_wr + (5 if op == "s_nop" else 1)
+            if op in ("v_mov_dpp_shr1", "v_mov_dpp_rowshl"):
                 used = set(self._regs(i.a) + self._regs(i.d))
                 for w in recent:
                     if w & used:
                         raise RuntimeError("DPP hazard: %s within 2 wait states of a VALU write of its register" % i.text)
             if op.startswith("pk_") or op.startswith("v_"):
-                recent = (recent + [set(self._regs(i.d)) if op != "v_readlane" else set()])[-2:]
+                recent = (recent + [set(self._regs(i.d)) if op not in ("v_readlane", "v_readfirstlane") else set()])[-2:]
             else:
                 recent = (recent + [set()])[-2:]
             if op.startswith("pk_"):
@@ -348,6 +362,21 @@ class Emu:
                 dst = self.v[i.d.n].reshape(4, 64).copy()
                 dst[:, 1:] = src[:, :-1]
                 self.v[i.d.n] = dst.reshape(-1)
+            elif op == "v_mov_dpp_rowshl":
+                self._touch(self._regs(i.a) + self._regs(i.d), self._regs(i.d), i.text)
+                src = self.v[i.a.n].reshape(4, 64)
+                dst = self.v[i.d.n].reshape(4, 64).copy()
+                for lane in range(4):
+                    if lane + i.k <= 15:
+                        dst[:, lane] = src[:, lane + i.k]
+                self.v[i.d.n] = dst.reshape(-1)
+            elif op == "v_mul_f32":
+                self._touch(self._regs(i.a) + self._regs(i.b), self._regs(i.d), i.text)
+                a, b = self._rd32(i.a).view(np.float32), self._rd32(i.b).view(np.float32)
+                self.v[i.d.n] = (a * b).astype(np.float32).view(np.uint32)
+            elif op == "v_readfirstlane":
+                self._touch(self._regs(i.a), [], i.text)
+                self.s[:, i.d.n] = self.v[i.a.n].reshape(4, 64)[:, 0]
             elif op == "v_readlane":
                 self._touch(self._regs(i.a), [], i.text)
                 self.s[:, i.d.n] = self.v[i.a.n].reshape(4, 64)[:, i.lane]
