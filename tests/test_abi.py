@@ -28,9 +28,9 @@ def test_library_exports_every_declared_symbol(pkg):
     out = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
     exported = set(re.findall(r" T (prot_[a-z0-9_]+)", out))
     assert set(declared_symbols()) <= exported
-    # library and header agree on the ABI revision (2: prot_info.run_align, prot_sweep_stats, PROT_CFG_* flags)
+    # library and header agree on the ABI revision (2: prot_info.run_align, prot_sweep_stats, PROT_CFG_* flags; 4: PROT_CFG_OVERLAP_ADD)
     declared = int(re.search(r"#define\s+PROT_ABI_VERSION\s+(\d+)", open(HDR).read()).group(1))
-    assert lib.prot_abi_version() == declared == 3
+    assert lib.prot_abi_version() == declared == 4
 
 
 def test_header_is_plain_c():

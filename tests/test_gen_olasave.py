@@ -1,0 +1,43 @@
+"""The generated loop of olasave_kernel (tools/gen/gen_olasave.py -> csrc/prot_olasave_asm.inc) on the CPU: every variant runs
+in the instruction emulator (tools/gen/isa.py: packed-fp32 semantics, LDS, the s_waitcnt discipline, the DPP and SGPR hazards
+found on the hardware) against the float64 convolution of the stream with the reference's odd taps, and the committed include
+file is what the generator writes today."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools", "gen"))
+sys.path.insert(0, os.path.join(ROOT, "tools", "model"))
+
+
+@pytest.mark.parametrize("hs", [8, 10, 12])
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("kind", ["run", "core"])
+def test_generated_block_matches_float64_convolution(hs, mode, kind):
+    import gen_olasave as G
+    G.self_test(hs, mode, 1, nblk=2, kind=kind, verbose=False)  # asserts max error < 1e-6 and a clean wait / hazard record
+
+
+def test_model_of_the_table_free_form():
+    """tools/model/olasave_model.py: the half-shifted transform pair with |B| = 1 outside the bins next to DC reproduces the
+    convolution with g to 1e-7 for every FIR the engines use"""
+    import numpy as np
+    import olasave_model as M
+    rng = np.random.default_rng(1)
+    for n_taps, hs in [(3072, 10), (4096, 8), (2048, 12)]:
+        g = M.hilbert_fir(n_taps)[1::2]
+        B = M.tables(g)
+        z = 0.3 * (rng.standard_normal(M.N) + 1j * rng.standard_normal(M.N))
+        want = np.convolve(z, g)[len(g) // 2:len(g) // 2 + M.N]
+        lo, hi = 256 * (16 - hs) // 2, M.N - 256 * (16 - hs) // 2
+        assert np.abs(M.block(z, B, len(g), False, 1) - want)[lo:hi].max() < 1e-7
+
+
+def test_committed_include_is_current(tmp_path):
+    import gen_olasave as G
+    dst = tmp_path / "asm.inc"
+    G.emit(str(dst))
+    cur = open(os.path.join(ROOT, "phaserotate.lv2_amd", "csrc", "prot_olasave_asm.inc")).read()
+    assert open(dst).read() == cur, "run python3 tools/gen/gen_olasave.py"
