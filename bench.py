@@ -229,15 +229,33 @@ def main():
     value = world * n * args.steps / wall
     bytes_per_launch = 8.0 * n  # 4 B read + 4 B written per frame
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            # PMC traffic is per kernel: never attach another kernel's bytes to this line
-            traffic = tj.get("hbm_bytes_per_launch") if (args.frames_log2 == 27 and "olapoly_kernel<prot::T32, 1, 10, 0, 3, false, 3>" in tj.get("kernel", "")) else None
-        except Exception:
-            traffic = None
+    rows = int(eng.info.hop) // 512
+    if int(eng.info.form) == pkg.FORM_POLY_SAVE:
+        kname = "olasave_kernel<%d, 0>" % rows
+        klabel = ("prot::%s (polyphase form, overlap-save: one partition of the odd taps applied centred and table-free -- forward transform at "
+                  "the half-shifted index --, %d new sample rows of 16 per block, steady rotation as kernel arguments, dry path from the kept "
+                  "input rows; the block loop is generated gfx950 assembly, 120 hand-allocated VGPRs, %d workgroups per CU)"
+                  % (kname, rows, int(eng.info.wg_per_cu)))
+    else:
+        kname = "olapoly_kernel<prot::T32, 1, %d, 0, 3, false, 3>" % rows
+        klabel = ("prot::%s (polyphase form, overlap-add: one partition of the odd taps, %d new sample rows per block, steady rotation, dry "
+                  "path from registers, packed-fp32 butterflies, %d workgroups per CU)" % (kname, rows, int(eng.info.wg_per_cu)))
+    # HBM bytes and SQ counters come from separate rocprofv3 --pmc passes (tools/profile_round.sh, builder-side run on another box of
+    # the pool; summaries committed under profiles/): attached only when they are of THIS kernel, and labelled as not of this run
+    traffic, pmc = None, {}
+    for fn, dst in (("traffic_latest.json", "traffic"), ("pmc_latest.json", "pmc")):
+        fp = os.path.join(ROOT, "profiles", fn)
+        if os.path.exists(fp) and args.frames_log2 == 27:
+            try:
+                tj = json.load(open(fp))
+                if kname in tj.get("kernel", ""):
+                    if dst == "traffic":
+                        traffic = tj.get("hbm_bytes_per_launch")
+                    else:
+                        pmc = {k: tj[k] for k in ("valu_busy", "lds_busy", "active_fraction", "clock_ghz_under_profile") if k in tj}
+            except Exception:
+                pass
+    ACHIEVABLE_GBS = 6290.0  # MI355X_MICROARCH.md: 6.29 TB/s measured float4 copy (this pool: 6.14-6.18, tools/ubench/copy_geom.hip)
     out = {
         "metric": "mono-sample frames/s through 4096-pt OLA phase-rotate",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -251,11 +269,16 @@ def main():
                    "fftlen": int(eng.info.fftlen), "hop": int(eng.info.hop), "firlen": int(eng.info.firlen),
                    "latency": int(eng.info.latency), "frames_per_gpu": n, "streams_per_gpu": 1,
                    "parallelism": "independent streams x%d" % world},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "prot::olapoly_kernel<prot::T32, 1, 10, 0, 3, false, 3> (one partition of the odd taps, 10 new sample rows per "
-                               "block, steady rotation, dry path from registers, packed-fp32 butterflies, 3 workgroups per CU)", "kernel_ms": kern_ms,
-                     "algorithmic_bytes_per_launch": bytes_per_launch},
+        "roofline": dict({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": achieved / HBM_PEAK_GBS, "frac_of_achievable": achieved / ACHIEVABLE_GBS,
+                          "achievable": ACHIEVABLE_GBS, "traffic": traffic,
+                          "source": "achieved / frac: HIP events of this run; traffic, valu_busy, lds_busy, active_fraction: profiles/"
+                                    "traffic_latest.json and profiles/pmc_latest.json (rocprofv3 --pmc passes of the same command, "
+                                    "builder-side run, NOT this run)",
+                          "kernel": klabel, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                          "binding_resource": "packed-fp32 VALU issue (4 cycles per v_pk_*_f32, tools/ubench/pk_rate.hip) at the clock the "
+                                              "chip holds under this load (1.7 GHz in-kernel, tools/sv_clock.py), with LDS at about half of "
+                                              "its cycles: DESIGN.md section 5"}, **pmc),
         "oracle_check": head_check,
     }
     eng.close()
@@ -375,8 +398,8 @@ def bench_cfg3(args, pkg, torch, np, dev, ts, st, local_rank, barrier, world):
                      "roofline_frac": 8.0 * n_chn * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
         del x, y
     r0 = rows[0]
-    return {"workload": "LV2 stereo, 96 kHz filter (4096 taps: one partition of the 2048 odd taps, one halo block per run), "
-                        "256 x 1024-frame buffers per channel per launch, stateful back-to-back launches",
+    return {"workload": "LV2 stereo, 96 kHz filter (4096 taps: one partition of the 2048 odd taps, overlap-save: one transform pair per "
+                        "4096-frame block, no halo), 256 x 1024-frame buffers per channel per launch, stateful back-to-back launches",
             "value": r0["value"], "unit": "channel-frames/s", "ms_per_launch": r0["ms_per_launch"],
             "roofline_frac": r0["roofline_frac"], "by_buffers_per_launch": rows}
 
@@ -459,6 +482,14 @@ def _sweep_signal(torch, np, dev, n_chn, f0, n, seed, kind):
 
 
 def bench_sweep(args, pkg, torch, dist, dev, st, world, rank, local_rank, barrier):
+    """BASELINE config 4 at -f 2048 (the block size of the headline engine) and at the reference's default block size for
+    96 kHz material, 16384 (cli/phase-rotate.cc:749-755: samplerate / 8 rounded up to a power of two)."""
+    main_line = _bench_sweep_at(2048, True, args, pkg, torch, dist, dev, st, world, rank, local_rank, barrier)
+    main_line["blksiz_16384"] = _bench_sweep_at(16384, False, args, pkg, torch, dist, dev, st, world, rank, local_rank, barrier)
+    return main_line
+
+
+def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local_rank, barrier):
     """BASELINE config 4: 360-angle (-s 1) min-peak sweep of stereo 96 kHz audio, blksiz 2048 (-f 2048, 4096-pt),
     frame-blocks sharded across the ranks with a history halo, one RCCL MAX all-reduce of the [2][360] peak table.
     Strong scaling: the total amount of audio is fixed.  `value` = resident pass on the harmonic material; the noise
@@ -466,7 +497,7 @@ def bench_sweep(args, pkg, torch, dist, dev, st, world, rank, local_rank, barrie
     the timed region, double-buffered against the sweep: SURVEY 8d's multi-GPU wall) are reported beside it."""
     import numpy as np
     from phaserotate_lv2_amd import sweep_dist
-    P, n_chn = 2048, 2
+    n_chn = 2
     total = int(args.sweep_seconds * 96000) // P * P
     eng = pkg.Engine(pkg.KIND_CLI, P, n_chn, device=local_rank)
     # shard starts on whole device transform blocks: the merged table is bit-identical to a single pass
@@ -485,7 +516,7 @@ def bench_sweep(args, pkg, torch, dist, dev, st, world, rank, local_rank, barrie
             return float(t.item())
         return v
 
-    for kind in ("harmonic", "noise"):
+    for kind in (("harmonic", "noise") if full else ("harmonic",)):
         x = _sweep_signal(torch, np, dev, n_chn, f0, n, 1234, kind) if n > 0 else torch.zeros((n_chn, 0), device=dev)
         # (the halo only primes the history in front of the shard; for this timing any material will do)
         halo = _sweep_signal(torch, np, dev, n_chn, f0 - H, H, 4321, kind).contiguous() if rank > 0 else None
@@ -528,7 +559,37 @@ def bench_sweep(args, pkg, torch, dist, dev, st, world, rank, local_rank, barrie
                      "evaluated_fraction": ev / max(seen, 1), "table_identical_unpruned": same,
                      "per_rank_device_ms": per_rank,
                      "min_angle_index": [int(pk[c].argmin()) for c in range(n_chn)]}
-        if kind == "harmonic":
+        if world == 1:
+            # What eight GPUs would do, predicted on one: the eight frame-block shards of the same material (plan_shards: whole
+            # device transform blocks, history primed in front of each) timed one after the other on this device.  The pruning
+            # makes the sweep's time depend on the material, so the shards are not equal; predicted_speedup = single pass /
+            # slowest shard.  A PREDICTION (no collective, no host link, one device's clocks), never `value`.
+            plan8 = sweep_dist.plan_shards(total, P, 8, align=eng.shard_align_blocks())
+            shard_ms = []
+            for r8, (c0, c1) in enumerate(plan8):
+                xs8 = x[:, c0 * P:c1 * P]
+                halo8 = _sweep_signal(torch, np, dev, n_chn, c0 * P - H, H, 4321, kind).contiguous() if r8 > 0 else None
+                fl8 = (pkg.F_STREAM_START if r8 == 0 else 0) | (pkg.F_STREAM_END if r8 == 7 else 0)
+
+                def shard_pass():
+                    eng.reset()
+                    peaks.zero_()
+                    if r8 > 0:
+                        sweep_dist.prime_history(eng, halo8, st)
+                    eng.sweep_dev(xs8.data_ptr(), x.shape[1], xs8.shape[1], 0, 360, 1, -1, peaks.data_ptr(), fl8, st)
+                shard_pass()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream())
+                for _ in range(3):
+                    shard_pass()
+                e1.record(torch.cuda.current_stream())
+                torch.cuda.synchronize()
+                shard_ms.append(e0.elapsed_time(e1) / 3)
+            res[kind]["predicted_8gpu"] = {"per_shard_ms": shard_ms, "single_pass_ms": dev_ms,
+                                           "predicted_speedup": dev_ms / max(shard_ms),
+                                           "note": "PREDICTED from eight same-device shard passes; no N > 1 run exists"}
+        if kind == "harmonic" and full:
             # host-inclusive pass: the shard comes from pinned host memory inside the timed region, in chunks whose
             # upload overlaps the sweep of the chunk before (two device buffers, a copy stream)
             chunk = eng.shard_align_blocks() * P * 1024
@@ -605,12 +666,21 @@ def bench_sweep(args, pkg, torch, dist, dev, st, world, rank, local_rank, barrie
         e2.close()
     eng.close()
     h = res["harmonic"]
+    if not full:
+        return {"metric": "channel-frames/s through the 360-angle min-peak sweep (cli -s 1, default block size at 96 kHz: %d)" % P,
+                "value": h["value"], "unit": "channel-frames/s", "ms": h["ms"], "unpruned_ms": h["unpruned_ms"],
+                "evaluated_fraction": h["evaluated_fraction"], "table_identical_unpruned": h["table_identical_unpruned"],
+                "min_angle_index": h["min_angle_index"], "per_rank_device_ms": h["per_rank_device_ms"],
+                "predicted_8gpu": h.get("predicted_8gpu"), "oracle_check_10s": check,
+                "engine": "16384-tap FIR = four 2048-tap partitions of the odd taps: two accumulating launches of two partitions each "
+                          "for the Hilbert branch (olapoly_kernel<T32, 2, 8, ...>), then the MFMA sweep"}
     return {"metric": "channel-frames/s through the 360-angle min-peak sweep (cli -s 1 -f 2048)",
             "signal": "32-harmonic asymmetric stack (110 / 137.5 Hz) under a slow swell + 2 % noise, generated on the device; resident in HBM",
             "value": h["value"], "unit": "channel-frames/s", "ms": h["ms"], "unpruned_ms": h["unpruned_ms"],
             "evaluated_fraction": h["evaluated_fraction"], "table_identical_unpruned": h["table_identical_unpruned"],
             "min_angle_index": h["min_angle_index"], "per_rank_device_ms": h["per_rank_device_ms"],
             "oracle_check_10s": check,
+            "predicted_8gpu": h.get("predicted_8gpu"),
             "noise_worst_case": res["noise"], "host_inclusive": res.get("host_inclusive"),
             "seconds_of_audio": total / 96000.0, "channels": n_chn, "rate": 96000, "scaling": "strong", "n_gpus": world,
             "collective": "all_reduce(MAX) float[2][360] over RCCL" if world > 1 else None}

@@ -86,7 +86,12 @@ typedef struct {
 	uint32_t run_align;   /* frames: a stream cut at multiples of this (CLI: of lcm(run_align, blksiz)) and fed to
 	                       * separate engines / launches reproduces the single-pass arithmetic BIT FOR BIT -- it is
 	                       * the span of one device transform block (pair); shard and chunk boundaries use it */
+	uint32_t form;        /* which device kernel convolves: PROT_FORM_* (reporting only) */
+	uint32_t wg_per_cu;   /* resident workgroups per CU that kernel is sized for (run lengths are planned with it) */
 } prot_info;
+#define PROT_FORM_DIRECT 0u        /* partitions of the FIR itself, hop pairs as re/im (ola4096_kernel, ola4096p2_kernel) */
+#define PROT_FORM_POLY_OLA 1u      /* polyphase, overlap-add, spectrum table (olapoly_kernel) */
+#define PROT_FORM_POLY_SAVE 2u     /* polyphase, overlap-save, table-free, generated loop (olasave_kernel) */
 
 typedef struct prot_engine prot_engine;
 

@@ -27,6 +27,7 @@ CFG_SINGLE_FFT_PER_HOP = 1
 CFG_DIRECT_FORM = 2
 CFG_POLYPHASE = 4
 CFG_OVERLAP_ADD = 8
+FORM_DIRECT, FORM_POLY_OLA, FORM_POLY_SAVE = 0, 1, 2
 
 # every symbol include/prot_hip.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = (
@@ -53,7 +54,8 @@ class Info(C.Structure):
     _fields_ = [("kind", C.c_int32), ("n_chn", C.c_uint32), ("fftlen", C.c_uint32),
                 ("hop", C.c_uint32), ("firlen", C.c_uint32), ("latency", C.c_uint32),
                 ("dry_delay", C.c_uint32), ("conv_delay", C.c_uint32), ("history", C.c_uint32),
-                ("blksiz", C.c_uint32), ("partitions", C.c_uint32), ("run_align", C.c_uint32)]
+                ("blksiz", C.c_uint32), ("partitions", C.c_uint32), ("run_align", C.c_uint32),
+                ("form", C.c_uint32), ("wg_per_cu", C.c_uint32)]
 
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")

@@ -1027,6 +1027,8 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	if (e->use_save && hipMemcpy (e->d_sv.p, sv_h.data (), sv_h.size () * sizeof (float), hipMemcpyHostToDevice) != hipSuccess) {
 		return fail (PROT_EHIP);
 	}
+	e->info.form      = e->use_save ? PROT_FORM_POLY_SAVE : use_poly ? PROT_FORM_POLY_OLA : PROT_FORM_DIRECT;
+	e->info.wg_per_cu = e->cus > 0 ? (uint32_t)(e->wg_slots / e->cus) : 0;
 	if ((!Hp_h.empty () && hipMemcpy (e->d_Hp.p, Hp_h.data (), Hp_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess) ||
 	    hipMemcpy (e->d_H.p, H_h.data (), H_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMemcpy (e->d_tw.p, tw_h.data (), F * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess ||
