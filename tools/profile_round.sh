@@ -3,7 +3,7 @@
 # rocprofv3 kernel stats of the default bench command, then separate --pmc passes (never combined with traces) for HBM
 # traffic and the SQ counters of the headline kernel and of the sweep; raw output under gpurun_out/prof_<tag>/, the
 # summaries that are meant to be judged are written to profiles/ by tools/summarize_round.py (run it there, copy back).
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

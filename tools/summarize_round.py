@@ -10,7 +10,7 @@ import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
 tag, out = sys.argv[1], sys.argv[2]
-HEAD, SWEEP = "olapoly_kernel<prot::T32, 1, 10, 0, 3, false, 3>", "sweep_mfma_kernel<3"
+HEAD, SWEEP = "olasave_kernel<10, 0>", "sweep_mfma_kernel<3"
 
 
 def counters(d):
@@ -79,6 +79,21 @@ for d in ("sw1", "sw2"):
 if h:
     if "SQ_ACTIVE_INST_ANY" in h and "SQ_WAVE_CYCLES" in h:
         h["active_fraction = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES"] = h["SQ_ACTIVE_INST_ANY"]["mean"] / h["SQ_WAVE_CYCLES"]["mean"]
+    # busy fractions of the launch (bench.py attaches them to roofline as builder-side figures): GRBM_GUI_ACTIVE is summed over
+    # the 8 XCDs -> cycles of the launch; SQ_ACTIVE_INST_VALU counts one quad-cycle per VALU instruction, i.e. 4 cycles each
+    # (packed fp32: measured 4, tools/ubench/pk_rate.hip; unpacked: 2 -- a slight over-statement) on 1024 SIMDs;
+    # SQ_LDS_IDX_ACTIVE counts LDS-array cycles on 256 CUs
+    need = ("GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES")
+    if all(k in h for k in need):
+        cyc = h["GRBM_GUI_ACTIVE"]["mean"] / 8.0
+        lat = {"kernel": h["_kernel"], "launch_cycles": cyc,
+               "valu_busy": 4.0 * h["SQ_ACTIVE_INST_VALU"]["mean"] / (1024.0 * cyc),
+               "lds_busy": h["SQ_LDS_IDX_ACTIVE"]["mean"] / (256.0 * cyc),
+               "active_fraction": h["SQ_ACTIVE_INST_ANY"]["mean"] / h["SQ_WAVE_CYCLES"]["mean"],
+               "source": tag + "_pmc_sq.json (rocprofv3 --pmc passes of python3 bench.py --no-extra ..., builder-side run; counters "
+                               "perturb the clock: compare ratios, not times)"}
+        json.dump(lat, open(os.path.join(PROF, "pmc_latest.json"), "w"), indent=1)
+        print(json.dumps(lat))
     sq["headline"] = h
 if s:
     sq["sweep"] = s
