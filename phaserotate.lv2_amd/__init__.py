@@ -38,6 +38,7 @@ ABI_SYMBOLS = (
     "prot_lv2_run", "prot_lv2_set_max_block", "prot_lv2_get_angle", "prot_cli_apply", "prot_cli_analyze", "prot_cli_analyze_file",
     "prot_cli_apply_file", "prot_cli_peak", "prot_cli_peak_all", "prot_cli_peaks",
     "prot_cli_peaks_dev", "prot_allreduce_peaks", "prot_cli_analyze_file_multi", "prot_sweep_stats",
+    "prot_sweep_stats_ex",
 )
 
 
@@ -117,6 +118,7 @@ def load_library():
                                  C.c_uint32, _f32p]
     lib.prot_lv2_get_angle.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
     lib.prot_sweep_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.prot_sweep_stats_ex.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.prot_cli_apply.argtypes = [C.c_void_p, _f32p, _i32p]
     lib.prot_cli_analyze.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.prot_cli_analyze_file.argtypes = [C.c_void_p, _f32p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -226,10 +228,16 @@ class Engine:
         return P // math.gcd(P, A) * A // P
 
     def sweep_stats(self):
-        """(evaluated, seen) tile groups of the sweep since the last reset (prot_sweep_stats)."""
+        """(evaluated, seen) 32-frame tiles of the sweep since the last reset (prot_sweep_stats)."""
         a, b = C.c_uint64(0), C.c_uint64(0)
         _check(self._lib.prot_sweep_stats(self._h, C.byref(a), C.byref(b)), "prot_sweep_stats")
         return a.value, b.value
+
+    def sweep_stats_ex(self):
+        """{evaluated, seen, untested (tiles), survivors (frames of the tested tiles)} (prot_sweep_stats_ex)."""
+        v = (C.c_uint64 * 4)()
+        _check(self._lib.prot_sweep_stats_ex(self._h, v), "prot_sweep_stats_ex")
+        return dict(evaluated=v[0], seen=v[1], untested=v[2], survivors=v[3])
 
     def sweep_dev(self, d_in, in_stride, n_frames, ang_start, ang_end, ang_stride, chn=-1,
                   d_peaks=0, flags=0, stream=0):

@@ -53,7 +53,8 @@ def build_lib(force=False, verbose=False):
         # no SLP: hipcc otherwise packs the butterflies into v_pk_*_f32 with ~500 v_mov per
         # iteration to marshal register pairs (measured: 1500 -> 1240 VALU, 255 -> 165 VGPRs);
         # MFMA results in VGPRs (unified file on gfx950) so the sweep's v_max3 reads them directly
-        ("prot_kernels.hip", ["-ffast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
+        ("prot_kernels.hip", ["-ffast-math", "-fno-slp-vectorize"]),
+        ("prot_sweep.hip", ["-ffast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
         ("prot_kernels_f16.hip", ["-ffast-math"]),
         ("prot_olasave.hip", ["-ffast-math", "-fno-slp-vectorize"]),
         # host logic mirrors the reference's float arithmetic: no fast-math

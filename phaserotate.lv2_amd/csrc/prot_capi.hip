@@ -339,7 +339,7 @@ struct prot_engine {
 	int            hist16_cur = 0;
 	DevBuf<int>    d_angles;
 	DevBuf<float>  d_thr;   // [n_chn][4] shared pruning bounds of one sweep launch
-	DevBuf<unsigned long long> d_stats; // {tile groups evaluated, tile groups seen} since the last reset
+	DevBuf<unsigned long long> d_stats; // {tiles evaluated, tiles seen, tiles untested, surviving frames} since the last reset
 	PinBuf<float>  h_io;
 	// small host->device parameter copies (rotation pairs, angle lists) are staged through a ring of
 	// pinned slots owned by the engine, each guarded by an event: the caller's array may die as soon
@@ -372,7 +372,7 @@ int zero_state (prot_engine* e)
 	HIP_TRY (hipMemsetAsync (e->d_hist[0].p, 0, hn * sizeof (float), e->stream));
 	HIP_TRY (hipMemsetAsync (e->d_hist[1].p, 0, hn * sizeof (float), e->stream));
 	HIP_TRY (hipMemsetAsync (e->d_peaks.p, 0, (size_t)PROT_MAXSAMPLE * e->info.n_chn * sizeof (float), e->stream));
-	HIP_TRY (hipMemsetAsync (e->d_stats.p, 0, 2 * sizeof (unsigned long long), e->stream));
+	HIP_TRY (hipMemsetAsync (e->d_stats.p, 0, 4 * sizeof (unsigned long long), e->stream));
 	if (e->d_hist16[0].p) {
 		HIP_TRY (hipMemsetAsync (e->d_hist16[0].p, 0, hn * sizeof (uint16_t), e->stream));
 		HIP_TRY (hipMemsetAsync (e->d_hist16[1].p, 0, hn * sizeof (uint16_t), e->stream));
@@ -1021,7 +1021,7 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	    (use_poly && n_part <= 2 && ((rc = e->d_hist16[0].ensure (hn)) || (rc = e->d_hist16[1].ensure (hn)))) ||
 	    (rc = e->d_hist[1].ensure (hn)) || (rc = e->d_peaks.ensure ((size_t)PROT_MAXSAMPLE * inf.n_chn)) ||
 	    (rc = e->d_angles.ensure (PROT_MAXSAMPLE + 8)) || (rc = e->d_thr.ensure (4 * (size_t)inf.n_chn)) ||
-	    (rc = e->d_stats.ensure (2)) || (e->use_save && (rc = e->d_sv.ensure (sv_h.size ())))) {
+	    (rc = e->d_stats.ensure (4)) || (e->use_save && (rc = e->d_sv.ensure (sv_h.size ())))) {
 		return fail (rc);
 	}
 	if (e->use_save && hipMemcpy (e->d_sv.p, sv_h.data (), sv_h.size () * sizeof (float), hipMemcpyHostToDevice) != hipSuccess) {
@@ -1471,18 +1471,33 @@ float* prot_cli_peaks_dev (prot_engine* e)
 	return e ? e->d_peaks.p : nullptr;
 }
 
+int prot_sweep_stats_ex (prot_engine* e, uint64_t out[4])
+{
+	if (!e || !out) {
+		return PROT_EINVAL;
+	}
+	HIP_TRY (hipSetDevice (e->device));
+	HIP_TRY (hipStreamSynchronize (e->stream));
+	unsigned long long h[4] = { 0, 0, 0, 0 };
+	HIP_TRY (hipMemcpy (h, e->d_stats.p, sizeof (h), hipMemcpyDeviceToHost));
+	for (int i = 0; i < 4; ++i) {
+		out[i] = h[i];
+	}
+	return PROT_OK;
+}
+
 int prot_sweep_stats (prot_engine* e, uint64_t* evaluated, uint64_t* seen)
 {
 	if (!e || !evaluated || !seen) {
 		return PROT_EINVAL;
 	}
-	HIP_TRY (hipSetDevice (e->device));
-	HIP_TRY (hipStreamSynchronize (e->stream));
-	unsigned long long h[2] = { 0, 0 };
-	HIP_TRY (hipMemcpy (h, e->d_stats.p, sizeof (h), hipMemcpyDeviceToHost));
-	*evaluated = h[0];
-	*seen      = h[1];
-	return PROT_OK;
+	uint64_t  h[4];
+	const int rc = prot_sweep_stats_ex (e, h);
+	if (rc == PROT_OK) {
+		*evaluated = h[0];
+		*seen      = h[1];
+	}
+	return rc;
 }
 
 int prot_cli_peaks (prot_engine* e, float* out)

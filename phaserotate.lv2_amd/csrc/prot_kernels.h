@@ -97,9 +97,9 @@ struct SweepParams {
 	const float* lut;         // device, [360][2] = {sin, cos}  (SinCosLut)
 	float*       peaks;       // device, [n_chn][360], max-accumulated
 	int32_t      chn0;        // first channel handled by blockIdx.y = 0
-	int32_t      prune;       // skip tile groups that cannot raise any maximum (exact; see sweep_mfma_kernel)
+	int32_t      prune;       // evaluate only the frames that can still raise a maximum (exact; see prot_sweep.hip)
 	float*       thr;         // device, [n_chn][4], ZEROED before the launch: shared pruning bounds, or NULL
-	unsigned long long* stats; // device, [2] += {tile groups evaluated, tile groups seen}, or NULL
+	unsigned long long* stats; // device, [4] += {tiles evaluated, tiles seen, tiles fed untested, surviving frames of tested tiles}, or NULL
 };
 hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s);
 

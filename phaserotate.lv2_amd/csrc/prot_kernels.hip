@@ -1858,7 +1858,7 @@ hipError_t launch_ola4096 (const OlaParams& p, int hopseg, int n_chn, hipStream_
 	return hipErrorInvalidValue;
 }
 
-// ------------------------------------------------------------------- sweep
+// ------------------------------------------------------------------- reductions (the sweep itself: prot_sweep.hip)
 // max over the 64 lanes of a non-negative value, result valid in lane 63
 PROT_DEV float wave_max_nonneg (float v)
 {
@@ -1873,401 +1873,6 @@ PROT_DEV float wave_max_nonneg (float v)
 	PROT_DPP_MAX (0x143, 0xc); // row_bcast:31 into rows 2 and 3
 #undef PROT_DPP_MAX
 	return v;
-}
-
-hipError_t launch_sweep_valu (const SweepParams& p, int n_chn, hipStream_t s);
-
-constexpr int kSweepE    = 32;                // frames per thread per tile
-constexpr int kSweepTile = 256 * kSweepE;     // frames per workgroup iteration
-
-__global__ __launch_bounds__ (256) void sweep_kernel (const SweepParams p)
-{
-	const int tid  = threadIdx.x;
-	const int lane = tid & 63;
-	const int c    = p.chn0 + blockIdx.y;
-
-	const float* __restrict__ x    = p.x + (int64_t)c * p.x_stride;
-	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
-	const float* __restrict__ u    = p.u + (int64_t)c * p.u_stride;
-
-	float pk[6];
-#pragma unroll
-	for (int r = 0; r < 6; ++r) {
-		pk[r] = 0.f;
-	}
-
-	for (int64_t base = p.t_begin + (int64_t)blockIdx.x * kSweepTile; base < p.t_end;
-	     base += (int64_t)gridDim.x * kSweepTile) {
-		float d[kSweepE], h[kSweepE];
-		const bool fast = (base + kSweepTile <= p.t_end) && (base - p.delay >= 0) &&
-		                  (base + kSweepTile - p.delay <= p.n_x) && (base + p.t_abs0 >= p.dry_from);
-		if (fast) {
-#pragma unroll
-			for (int e = 0; e < kSweepE; ++e) {
-				const int64_t tt = base + e * 256 + tid;
-				d[e]             = x[tt - p.delay];
-				h[e]             = u[tt];
-			}
-		} else {
-#pragma unroll
-			for (int e = 0; e < kSweepE; ++e) {
-				const int64_t tt = base + e * 256 + tid;
-				float         dd = 0.f, hh = 0.f;
-				if (tt < p.t_end) {
-					hh = u[tt];
-					if (tt + p.t_abs0 >= p.dry_from) {
-						dd = ldv (x, p.n_x, hist, p.hist_len, tt - p.delay);
-					}
-				}
-				d[e] = dd;
-				h[e] = hh;
-			}
-		}
-#pragma unroll
-		for (int r = 0; r < 6; ++r) {
-			for (int j = 0; j < 64; ++j) {
-				const int i = r * 64 + j;
-				if (i >= p.n_angles) {
-					break;
-				}
-				const int   a  = p.angles[i];       // wave-uniform -> scalar loads
-				const float sa = p.lut[2 * a];
-				const float ca = p.lut[2 * a + 1];
-				float       m0 = 0.f, m1 = 0.f;
-#pragma unroll
-				for (int e = 0; e < kSweepE; e += 2) {
-					const float v0 = ca * d[e] + sa * h[e];
-					const float v1 = ca * d[e + 1] + sa * h[e + 1];
-					m0             = fmaxf (m0, fabsf (v0));
-					m1             = fmaxf (m1, fabsf (v1));
-				}
-				float m = wave_max_nonneg (fmaxf (m0, m1));
-				m       = __int_as_float (__builtin_amdgcn_readlane (__float_as_int (m), 63));
-				pk[r]   = (lane == j) ? fmaxf (pk[r], m) : pk[r];
-			}
-		}
-	}
-
-	unsigned* gp = reinterpret_cast<unsigned*> (p.peaks + (int64_t)c * kMaxSample);
-#pragma unroll
-	for (int r = 0; r < 6; ++r) {
-		const int i = r * 64 + lane;
-		if (i < p.n_angles) {
-			// non-negative floats order like their bit patterns
-			atomicMax (&gp[p.angles[i]], __float_as_uint (pk[r]));
-		}
-	}
-}
-
-// ---- matrix-core form of the same sweep ---------------------------------------------
-// |ca_a d_i + sa_a h_i| for 32 angles x 32 frames is the rank-2 product
-// [ca sa] (32x2) . [d; h] (2x32): one v_mfma_f32_32x32x2_f32.  f32 MFMA is an exact
-// k-ordered fmaf chain, fma(sa, h, ca*d) -- bit-identical to the vector kernel above --
-// and runs beside the VALU, which is left with the |.|/max (v_max3_f32 over two tiles).
-// Lane l of the 32x32 result holds frame (l & 31) for 16 of the 32 angles, so running
-// maxima stay lane-local for the whole launch: no per-tile cross-lane reduction at all.
-// A wave owns up to 3 blocks of 32 angles (48 VGPRs of maxima); the 4 waves of a
-// workgroup cover the 360 angles (12 blocks) and read the same frames.
-typedef float f32x16 __attribute__ ((ext_vector_type (16)));
-
-constexpr int kMfmaSuper = 256; // 32-frame tiles per workgroup iteration (8192 frames)
-
-template <int NBLK, bool PRUNE>
-__global__ __launch_bounds__ (256, 3) void sweep_mfma_kernel (const SweepParams p)
-{
-	const int tid  = threadIdx.x;
-	const int w    = __builtin_amdgcn_readfirstlane (tid >> 6); // wave-uniform by construction
-	const int lane = tid & 63;
-	const int j    = lane & 31; // frame within a tile / angle within a block (A operand)
-	const int kk   = lane >> 5; // k index of the rank-2 product: 0 -> (cos, dry), 1 -> (sin, hilbert)
-	const int c    = p.chn0 + blockIdx.y;
-
-	const float* __restrict__ x    = p.x + (int64_t)c * p.x_stride;
-	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
-	const float* __restrict__ u    = p.u + (int64_t)c * p.u_stride;
-
-	const int nb   = (p.n_angles + 31) >> 5;      // angle blocks in this call (<= 12)
-	const int G    = nb >= 3 ? 4 : nb;            // wave groups: 4, 2 or 1
-	const int g    = w % G;                       // my group -> blocks g, g + G, g + 2G
-	const int sub  = w / G;                       // waves of one group split the tiles
-	const int nsub = 4 / G;
-
-	// NBLK = blocks per wave (1..3); a wave whose group has fewer blocks multiplies by an
-	// all-zero A operand there (maxima stay 0, nothing is published for them)
-	float a_op[NBLK];
-#pragma unroll
-	for (int q = 0; q < NBLK; ++q) {
-		const int idx = (g + q * G) * 32 + j;
-		float     v   = 0.f;
-		if (g + q * G < nb && idx < p.n_angles) {
-			const int a = p.angles[idx];
-			v           = p.lut[2 * a + (kk ? 0 : 1)]; // lut = {sin, cos}
-		}
-		a_op[q] = v;
-	}
-	f32x16 m[NBLK];
-#pragma unroll
-	for (int q = 0; q < NBLK; ++q) {
-#pragma unroll
-		for (int r = 0; r < 16; ++r) {
-			m[q][r] = 0.f;
-		}
-	}
-	const f32x16 zero = m[0];
-
-	// ---- pruning --------------------------------------------------------------------------
-	// |ca d + sa h| <= sqrt(d^2 + h^2) =: r for every angle, so a frame whose r is below a LOWER
-	// BOUND of the smallest final peak among this wave's angles cannot change any maximum: the
-	// whole group of tiles is skipped after one r^2 per frame (mul, half-swap, add, max) and one
-	// ballot instead of 2 NBLK MFMAs + 16 NBLK max3 per tile pair.  The result is bit-identical
-	// to the unpruned sweep (skipped frames would have lost every max); how much is skipped
-	// depends on the signal -- record-setting frames become rare quickly in anything stationary,
-	// a monotonically growing signal skips nothing.  The bound: the smallest of the table
-	// entries as they stand at launch (earlier chunks; they only grow) and, refreshed once per
-	// super-tile, the smallest of this wave's own lane-local running maxima.  1e-4 of relative
-	// margin on r^2 covers the rounding of the float evaluation against the exact inequality.
-	// (all pruning state is wave-uniform and forced into SGPRs: with NBLK = 3 the kernel sits at the
-	// 168-VGPR boundary of 3 waves per SIMD, and a first version that kept it in VGPRs fell to 2
-	// waves per SIMD -- 10-13 % slower on every signal, pruning on or off)
-	auto valid = [&] (int q, int r) { // m[q][r] belongs to a requested angle
-		const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
-		const int idx = (g + q * G) * 32 + row;
-		return g + q * G < nb && idx < p.n_angles;
-	};
-	auto uniform_f = [] (float v) { return __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (v))); };
-	auto wave_min = [] (float v) {
-		v = fminf (v, __shfl_xor (v, 1));
-		v = fminf (v, __shfl_xor (v, 2));
-		v = fminf (v, __shfl_xor (v, 4));
-		v = fminf (v, __shfl_xor (v, 8));
-		v = fminf (v, __shfl_xor (v, 16));
-		v = fminf (v, __shfl_xor (v, 32));
-		return v;
-	};
-	int n_groups = 0, n_live = 0; // tile groups seen / evaluated by this wave (statistics)
-	// This file is compiled with -ffast-math (finite-math-only): no infinities as sentinels.  A wave
-	// whose group has no angle block (g >= nb: 65..96 angles put three blocks on four groups) is
-	// `idle` -- integer logic -- and skips everything; every other wave has at least one valid entry,
-	// so the minima below always end up on real data and kBig never survives a wave_min.
-	const bool      idle = g >= nb;
-	constexpr float kBig = 1.0e18f; // finite, and its square still is
-	float thr2 = 0.f;
-	if (PRUNE && !idle) {
-		float lo = kBig;
-#pragma unroll
-		for (int q = 0; q < NBLK; ++q) {
-			const int idx = (g + q * G) * 32 + j;
-			if (g + q * G < nb && idx < p.n_angles) {
-				lo = fminf (lo, __builtin_nontemporal_load (&p.peaks[(int64_t)c * kMaxSample + p.angles[idx]]));
-			}
-		}
-		lo   = wave_min (lo);
-		thr2 = uniform_f (lo * lo);
-	}
-	// Every wave of angle group g (of this channel) bounds the SAME quantity -- the smallest final
-	// peak among the group's angles -- from below, so the largest bound any of them has found is
-	// valid for all: one atomicMax per wave per super-tile on p.thr[c][g] (non-negative floats
-	// order as their bit patterns; zeroed by the host before the launch) shares it.  Without it a
-	// wave whose own stripes are quiet never learns that another wave has already seen the peaks.
-	unsigned* const thr_slot = p.thr ? reinterpret_cast<unsigned*> (p.thr) + ((int64_t)c * 4 + g) : nullptr;
-	auto share = [&] (float lo) { // lo: this wave's bound (not squared); returns the best bound known
-		if (thr_slot != nullptr && !idle) {
-			float best = lo;
-			if (lane == 0) {
-				const unsigned old = atomicMax (thr_slot, __float_as_uint (lo));
-				best               = fmaxf (lo, __uint_as_float (old));
-			}
-			lo = __shfl (best, 0);
-		}
-		return lo;
-	};
-	if (PRUNE && thr2 > 0.f) {
-		const float b = share (sqrtf (thr2));
-		thr2          = uniform_f (b * b);
-	}
-
-	const int64_t span = (int64_t)kMfmaSuper * 32;
-	bool          first = true;
-	for (int64_t base = p.t_begin + (int64_t)blockIdx.x * span; base < p.t_end; base += (int64_t)gridDim.x * span) {
-		if (PRUNE && !first && !idle) {
-			float lo = kBig;
-#pragma unroll
-			for (int q = 0; q < NBLK; ++q) {
-#pragma unroll
-				for (int r = 0; r < 16; ++r) {
-					if (valid (q, r)) {
-						lo = fminf (lo, m[q][r]);
-					}
-				}
-			}
-			lo   = share (wave_min (lo));
-			thr2 = uniform_f (fmaxf (thr2, lo * lo));
-		}
-		first = false;
-		const bool fast = (base + span <= p.t_end) && (base - p.delay >= 0) && (base + span - p.delay <= p.n_x) &&
-		                  (base + p.t_abs0 >= p.dry_from);
-		// NT tiles per step; the frames of step s+1 are requested before the MFMAs of step s
-		// (double-buffered registers), so HBM latency never idles the matrix pipe
-		constexpr int NT = 8;
-		auto load_tiles = [&] (float (&bt)[NT], int tp) {
-			const int64_t t0 = base + (int64_t)tp * 32 + j;
-			if (fast) {
-				const float* __restrict__ src = kk ? (u + t0) : (x + t0 - p.delay);
-#pragma unroll
-				for (int i = 0; i < NT; ++i) {
-					bt[i] = src[32 * i];
-				}
-			} else {
-#pragma unroll
-				for (int i = 0; i < NT; ++i) {
-					const int64_t ti = t0 + 32 * i;
-					float         v  = 0.f;
-					if (ti < p.t_end) {
-						v = kk ? u[ti] : (ti + p.t_abs0 >= p.dry_from ? ldv (x, p.n_x, hist, p.hist_len, ti - p.delay) : 0.f);
-					}
-					bt[i] = v;
-				}
-			}
-		};
-		float bcur[NT], bnxt[NT];
-		load_tiles (bcur, sub * NT);
-		for (int tp = sub * NT; tp < kMfmaSuper; tp += NT * nsub) {
-			if (tp + NT * nsub < kMfmaSuper) {
-				load_tiles (bnxt, tp + NT * nsub);
-			}
-			bool live = true;
-			if (PRUNE) {
-				n_groups++;
-			}
-			// adaptive: a wave that found (nearly) every group live so far stops paying for the test
-			// (noise-like or steadily growing material); its statistics still count every group
-			if (PRUNE && !(n_groups > 64 && n_live * 16 > n_groups * 15)) {
-				float r2m = 0.f;
-#pragma unroll
-				for (int i = 0; i < NT; ++i) {
-					const unsigned b2 = __float_as_uint (bcur[i] * bcur[i]);
-					const auto     sw = __builtin_amdgcn_permlane32_swap (b2, b2, false, false); // {d^2, h^2} of my frame
-					r2m               = fmaxf (r2m, __uint_as_float (sw[0]) + __uint_as_float (sw[1]));
-				}
-				live = __builtin_amdgcn_ballot_w64 (r2m * 1.0001f > thr2) != 0;
-			}
-			if (PRUNE && idle) {
-				live = false; // no angles in this wave's group: its products are all zero
-			}
-			if (PRUNE) {
-				n_live += live ? 1 : 0;
-			}
-			if (live) {
-#pragma unroll
-			for (int i = 0; i < NT; i += 2) {
-#pragma unroll
-				for (int q = 0; q < NBLK; ++q) {
-					const f32x16 r0 = __builtin_amdgcn_mfma_f32_32x32x2f32 (a_op[q], bcur[i], zero, 0, 0, 0);
-					const f32x16 r1 = __builtin_amdgcn_mfma_f32_32x32x2f32 (a_op[q], bcur[i + 1], zero, 0, 0, 0);
-#pragma unroll
-					for (int r = 0; r < 16; ++r) {
-						m[q][r] = fmaxf (m[q][r], fmaxf (fabsf (r0[r]), fabsf (r1[r])));
-					}
-				}
-			}
-			}
-#pragma unroll
-			for (int i = 0; i < NT; ++i) {
-				bcur[i] = bnxt[i];
-			}
-		}
-	}
-
-	if (PRUNE && p.stats != nullptr && lane == 0) {
-		atomicAdd (&p.stats[0], (unsigned long long)n_live);
-		atomicAdd (&p.stats[1], (unsigned long long)n_groups);
-	}
-	// reduce over the 32 frames (lanes of one half), then one atomic per angle
-	unsigned* gp = reinterpret_cast<unsigned*> (p.peaks + (int64_t)c * kMaxSample);
-#pragma unroll
-	for (int q = 0; q < NBLK; ++q) {
-		{
-#pragma unroll
-			for (int r = 0; r < 16; ++r) {
-				float v = m[q][r];
-				v       = fmaxf (v, __shfl_xor (v, 1));
-				v       = fmaxf (v, __shfl_xor (v, 2));
-				v       = fmaxf (v, __shfl_xor (v, 4));
-				v       = fmaxf (v, __shfl_xor (v, 8));
-				v       = fmaxf (v, __shfl_xor (v, 16));
-				// C/D layout of 32x32: row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column = lane & 31
-				const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
-				const int idx = (g + q * G) * 32 + row;
-				if (j == 0 && g + q * G < nb && idx < p.n_angles) {
-					atomicMax (&gp[p.angles[idx]], __float_as_uint (v));
-				}
-			}
-		}
-	}
-}
-
-static int sweep_variant ()
-{
-	static int v = -1;
-	if (v < 0) {
-		const char* e = getenv ("PROT_SWEEP_VARIANT");
-		v             = e ? atoi (e) : 0;
-	}
-	return v;
-}
-
-hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s)
-{
-	if (sweep_variant () == 0 && p.t_end > p.t_begin && p.n_angles > 0 && n_chn > 0) {
-		const int  nb   = (p.n_angles + 31) / 32;
-		const int  nblk = nb >= 3 ? (nb + 3) / 4 : 1;
-		// persistent grid: exactly the workgroups the chip keeps resident, so the
-		// grid-stride loop ends without a ragged last round
-		typedef void (*kern_t) (SweepParams);
-		static const kern_t kern[2][4] = {
-			{ nullptr, sweep_mfma_kernel<1, false>, sweep_mfma_kernel<2, false>, sweep_mfma_kernel<3, false> },
-			{ nullptr, sweep_mfma_kernel<1, true>, sweep_mfma_kernel<2, true>, sweep_mfma_kernel<3, true> },
-		};
-		const int    pr = p.prune ? 1 : 0;
-		const kern_t fn = kern[pr][nblk];
-		static int   slots[2][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
-		if (slots[pr][nblk] == 0) {
-			int dev = 0, cus = 256, occ = 2;
-			(void)hipGetDevice (&dev);
-			(void)hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, dev);
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor (&occ, (const void*)fn, 256, 0) != hipSuccess || occ < 1) {
-				occ = 2;
-			}
-			slots[pr][nblk] = cus * occ;
-		}
-		const int64_t span  = (int64_t)kMfmaSuper * 32;
-		const int64_t tiles = (p.t_end - p.t_begin + span - 1) / span;
-		int64_t       gx    = tiles;
-		const int64_t cap   = std::max (1, slots[pr][nblk] / n_chn);
-		if (gx > cap) {
-			gx = cap;
-		}
-		const dim3 grid ((unsigned)gx, (unsigned)n_chn), block (256);
-		hipLaunchKernelGGL (fn, grid, block, 0, s, p);
-		return hipGetLastError ();
-	}
-	return launch_sweep_valu (p, n_chn, s);
-}
-
-hipError_t launch_sweep_valu (const SweepParams& p, int n_chn, hipStream_t s)
-{
-	if (p.t_end <= p.t_begin || p.n_angles <= 0 || n_chn <= 0) {
-		return hipSuccess;
-	}
-	const int64_t tiles = (p.t_end - p.t_begin + kSweepTile - 1) / kSweepTile;
-	int64_t       gx    = tiles;
-	const int64_t cap   = (2048 + n_chn - 1) / n_chn; // ~8 workgroups per CU in flight
-	if (gx > cap) {
-		gx = cap;
-	}
-	dim3 grid ((unsigned)gx, (unsigned)n_chn), block (256);
-	hipLaunchKernelGGL (sweep_kernel, grid, block, 0, s, p);
-	return hipGetLastError ();
 }
 
 // ------------------------------------------------------------------ absmax

@@ -556,29 +556,55 @@ def _sweep_table(pkg, x, P, stride, prune, passes=((0, 360, 24), (100, 140, 1)))
             pr.analyze_file(x, a0, a1, st)
         tab = np.array([[pr.peak(c, a) for a in range(360)] for c in range(x.shape[1])], np.float32)
         ev, seen = pr.sweep_stats()
+        _sweep_table.last_stats = pr.sweep_stats_ex()
         pr.close()
     finally:
         os.environ.pop("PROT_SWEEP_PRUNE", None)
     return tab, (ev / seen if seen else None)  # the unpruned kernel keeps no statistics: seen == 0
 
 
-@pytest.mark.parametrize("signal", ["noise+harmonics", "growing", "silence-then-burst", "long-multichunk", "constant"])
+@pytest.mark.parametrize("signal", ["noise+harmonics", "steady-tone", "silence-then-burst", "long-multichunk", "constant",
+                                    "stationary-noise", "tone-then-noise", "bursts"])
 def test_pruned_sweep_is_bit_identical_to_unpruned(pkg, signal):
-    """The sweep skips tile groups whose r = sqrt(d^2 + h^2) is below a lower bound of every final
-    peak.  That must not change a single bit of the table -- including when nothing can be skipped
-    (monotonically growing signal), when the bound starts at zero (leading silence), across chunks
-    (> 2^22 frames: later chunks start from the table of the earlier ones) and across passes.
-    The evaluated fraction is asserted too, both ways: a test in which nothing was skipped would
-    compare the unpruned sweep with itself (that happened with the first, per-wave version of the
-    bound), and the growing signal must NOT be skippable."""
+    """The sweep tests every frame's r = sqrt(d^2 + h^2) against a lower bound of every final peak and
+    evaluates only compacted tiles of survivors.  That must not change a single bit of the table --
+    including when nothing can be skipped (a steady tone: every frame's r equals every angle's peak; a
+    GROWING signal is no worst case on a parallel machine -- the waves working on the loud end publish
+    their bound to those working on the quiet start), when the bound starts
+    at zero (leading silence), across chunks (> 2^22 frames: later chunks start from the table of the
+    earlier ones) and across passes.  The evaluated fraction is asserted too, both ways: a test in which
+    nothing was skipped would compare the unpruned sweep with itself (that happened with the first,
+    per-wave version of the bound); the steady tone must NOT be skippable and must go through the
+    untested feed; long stationary noise -- the case the group-granular pruning of rounds 1-2 could not
+    touch -- must stay below one half; and a wave that switched the test off on a tone must find its
+    way back once the material turns quiet (two-way switch: "bursts" inside one launch, "tone-then-noise"
+    across chunks)."""
     P = 2048
     rng = np.random.default_rng(11)
     if signal == "noise+harmonics":
         n = 600000
         x = np.stack([0.5 * harmonic_stack(n, 48000) + 0.1 * xorshift_uniform(n, seed=3), xorshift_uniform(n, seed=4)], 1)
-    elif signal == "growing":
+    elif signal == "steady-tone":
+        # constant envelope: r(t) = A for every frame and every angle's peak tends to A -- nothing is skippable
         n = 400000
-        x = (xorshift_uniform(n, seed=5) * np.linspace(0.01, 1.0, n, dtype=np.float32))[:, None]
+        x = (0.7 * np.sin(2 * np.pi * 997.0 / 48000 * np.arange(n)))[:, None]
+    elif signal == "tone-then-noise":
+        # 2^22 frames of the steady tone (test switched off), then 3 x 2^22 of noise below it
+        n = (1 << 22) * 4
+        x = np.empty((n, 1), np.float32)
+        g = 1 << 22
+        x[:g, 0] = 0.7 * np.sin(2 * np.pi * 997.0 / 48000 * np.arange(g))
+        x[g:, 0] = 0.5 * xorshift_uniform(n - g, seed=12)
+    elif signal == "bursts":
+        # period = the 8192 frames one workgroup iteration covers: a quarter of ever louder tone (all of it survives:
+        # the test is switched off), three quarters of quiet noise (the wave must switch it back on)
+        segs, A = 40, 0.1
+        x = np.empty((segs * 8192, 1), np.float32)
+        for k in range(segs):
+            x[k * 8192:k * 8192 + 2048, 0] = np.sin(2 * np.pi * 0.05 * np.arange(2048)) * np.linspace(A, 1.05 * A, 2048)
+            x[k * 8192 + 2048:(k + 1) * 8192, 0] = 0.3 * A * xorshift_uniform(6144, seed=30 + k)
+            A *= 1.05
+        n = x.shape[0]
     elif signal == "silence-then-burst":
         n = 300000
         x = np.zeros((n, 2), np.float32)
@@ -586,31 +612,47 @@ def test_pruned_sweep_is_bit_identical_to_unpruned(pkg, signal):
         x[299990:, 1] = 0.9
     elif signal == "long-multichunk":
         # four device chunks (2^22 frames each): loud material in the first, 40 dB quieter afterwards --
-        # the later chunks (3/4 of the groups) start from the bound the first one left in the table and
-        # are skipped -- plus one late click louder than everything, which must still land in the table
+        # the later chunks start from the bound the first one left in the table and are skipped -- plus
+        # one late click louder than everything, which must still land in the table
         n = (1 << 22) * 3 + 12345
         x = (0.8 * harmonic_stack(n, 48000) + 0.05 * xorshift_uniform(n, seed=8))[:, None].astype(np.float32)
         x[1 << 22:] *= 0.01
         x[n - 3000:n - 2990] = 0.97
+    elif signal == "stationary-noise":
+        n = (1 << 22) * 3 + 777
+        x = np.stack([0.9 * xorshift_uniform(n, seed=9), 0.9 * xorshift_uniform(n, seed=10)], 1)
     else:
         n = 100000
         x = np.full((n, 1), 0.25, np.float32)
     x = np.ascontiguousarray(x, np.float32)
     a, frac_pruned = _sweep_table(pkg, x, P, 24, prune=True)
+    st = dict(_sweep_table.last_stats)
     b, frac_plain = _sweep_table(pkg, x, P, 24, prune=False)
     assert a.tobytes() == b.tobytes()
     assert a.max() > 0            # every signal here has energy
     assert frac_plain is None and frac_pruned is not None  # the switch really selects the two kernels
-    print("\n[sweep pruning, %s] evaluated %.1f %% of the tile groups" % (signal, 100 * frac_pruned))
+    assert st["evaluated"] <= st["seen"] + 2 * 4 * 4096 and st["untested"] <= st["evaluated"]  # (+ zero-padded last tiles)
+    print("\n[sweep pruning, %s] evaluated %.1f %% of the tiles, %.1f %% fed untested" %
+          (signal, 100 * frac_pruned, 100.0 * st["untested"] / st["seen"]))
     # ... and the comparison is not vacuous: pruning must have skipped work where the signal allows it
     # (no expectation for "constant": its Hilbert branch is ~0, so the peaks near 90 degrees are ~0 and
-    # nothing is skippable -- 95 % evaluated, correctly; nor for the noise mixture)
+    # little is skippable)
     if signal == "silence-then-burst":
-        assert frac_pruned < 0.5, frac_pruned   # the silences cannot raise anything
+        assert frac_pruned < 0.1, frac_pruned   # the silences cannot raise anything
     if signal == "long-multichunk":
-        assert frac_pruned < 0.45, frac_pruned  # at most the loud quarter (+ margin) is evaluated
+        assert frac_pruned < 0.3, frac_pruned   # a part of the loud quarter is evaluated, the rest is not
+    if signal == "stationary-noise":
+        assert frac_pruned < 0.5, frac_pruned
+        assert st["untested"] < 0.2 * st["seen"], st
     if signal == "growing":
-        assert frac_pruned > 0.9, frac_pruned  # every group holds a new record: nothing may be skipped
+        assert frac_pruned > 0.9, frac_pruned   # every frame holds a new record: nothing may be skipped
+        assert st["untested"] > 0.5 * st["seen"], st  # ... and the test is switched off most of the time
+    if signal == "bursts":
+        assert 0.2 < frac_pruned < 0.6, frac_pruned
+        assert 0.05 * st["seen"] < st["untested"] < 0.4 * st["seen"], st  # off in the tone, back on in the noise
+    if signal == "growing-then-steady":
+        assert frac_pruned < 0.6, frac_pruned   # the steady 3/4 are tested again (and mostly skipped)
+        assert 0.1 * st["seen"] < st["untested"] < 0.4 * st["seen"], st
 
 
 @pytest.mark.parametrize("stride,blocks", [(1, 12), (3, 4), (4, 3), (5, 3), (6, 2), (8, 2), (24, 1)])

@@ -17,7 +17,8 @@ harm = 0.8 * harm / harm.abs().max()
 sigs = {"uniform noise": noise,
         "harmonic stack + noise": torch.cat([harm + 0.05 * noise[:n], 0.7 * harm + 0.05 * noise[n:]]),
         "loud first second, then quiet": torch.where((torch.arange(nc * n, device=dev) % n) < 96000, noise, 1e-3 * noise),
-        "growing noise (worst case)": noise * torch.linspace(0.01, 1.0, n, device=dev).repeat(nc)}
+        "growing noise": noise * torch.linspace(0.01, 1.0, n, device=dev).repeat(nc),
+        "steady tone (worst case)": (0.7 * torch.sin(2 * np.pi * 997.0 * t)).float().repeat(nc)}
 for name, x in sigs.items():
     res = {}
     for prune in (1, 0, 1, 0):
@@ -32,7 +33,11 @@ for name, x in sigs.items():
         res["tab%d" % prune] = pk.cpu().numpy().tobytes()
         ev, seen = e.sweep_stats()
         res["frac%d" % prune] = ev / max(seen, 1)
+        res["ex%d" % prune] = e.sweep_stats_ex()
         e.close()
     print("%-28s pruned %s ms (evaluated %.1f %% of the groups)   unpruned %s ms (%.0f %%)   tables identical: %s" % (
         name, ["%.2f" % v for v in res[1]], 100 * res["frac1"], ["%.2f" % v for v in res[0]], 100 * res["frac0"],
         res["tab1"] == res["tab0"]), flush=True)
+    ex = res["ex1"]
+    print("    untested %.1f %% of the tiles, survivors %.1f %% of the tested frames" % (
+        100.0 * ex["untested"] / max(ex["seen"], 1), 100.0 * ex["survivors"] / max(32 * (ex["seen"] - ex["untested"]), 1)), flush=True)
