@@ -34,23 +34,24 @@ namespace prot {
 
 typedef float f32x16 __attribute__ ((ext_vector_type (16)));
 
-constexpr int kSuper = 256;  // 32-frame tiles per workgroup iteration (8192 frames)
-constexpr int kNL    = 4;    // 64-frame groups per step; the frames of step s + 1 are requested before the work of step s
-constexpr int kSteps = kSuper * 32 / (64 * kNL); // steps per workgroup iteration
-constexpr int kRing  = 512;  // (d, h) entries of one wave's survivor ring: < 64 left over + the 64 kNL frames of one step
-static_assert (kRing >= 64 + 64 * kNL && (kRing & (kRing - 1)) == 0, "ring too small");
-constexpr int kWin   = 16;   // tiles per decision window of the switch-off (a workgroup sees only 256..512 tiles per launch)
-constexpr int kPause0 = 4, kPauseMax = 1024; // steps (of 2 kNL tiles) fed untested after a failed window: first, cap
+constexpr int kStage  = 1024;             // frames per step: loaded ONCE per workgroup, shared through LDS
+constexpr int kSteps  = 8;                // steps between two looks at the shared bound
+constexpr int kBatch  = 256;              // frames a wave tests between two looks at its ring (4 groups = 8 tiles)
+constexpr int kRing   = 512;              // (d, h) entries of one wave's survivor ring: < 64 left over + one batch
+static_assert (kRing >= 64 + kBatch && (kRing & (kRing - 1)) == 0, "ring too small");
+constexpr int kWin    = 16;               // tiles per decision window of the switch-off (two batches)
+constexpr int kPause0 = 4, kPauseMax = 1024; // batches fed untested after a failed window: first, cap
 
 template <int NBLK, bool PRUNE>
-__global__ __launch_bounds__ (256, 3) void sweep_kernel (const SweepParams p)
+__global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const SweepParams p)
 {
+	__shared__ float stage_s[2 * 2 * kStage]; // [buffer][d | h][frame]: planar, so that a loaded dwordx4 is parked as it is
 	__shared__ float2 ring_s[PRUNE ? 4 * kRing : 1];
 
 	const int tid  = threadIdx.x;
 	const int w    = __builtin_amdgcn_readfirstlane (tid >> 6); // wave-uniform by construction
 	const int lane = tid & 63;
-	const int j    = lane & 31; // frame within a tile / angle within a block (A operand)
+	const int j    = lane & 31; // column within a tile / angle within a block (A operand)
 	const int kk   = lane >> 5; // k index of the rank-2 product: 0 -> (cos, dry), 1 -> (sin, hilbert)
 	const int c    = p.chn0 + blockIdx.y;
 
@@ -60,12 +61,13 @@ __global__ __launch_bounds__ (256, 3) void sweep_kernel (const SweepParams p)
 
 	const int nb   = (p.n_angles + 31) >> 5;      // angle blocks in this call (<= 12)
 	const int G    = nb >= 3 ? 4 : nb;            // wave groups: 4, 2 or 1
-	const int g    = w % G;                       // my group -> blocks g, g + G, g + 2G
-	const int sub  = w / G;                       // waves of one group split the tiles
+	// which group a wave serves rotates with the workgroup: wave w of every resident workgroup sits on SIMD w, and the
+	// groups' survivor counts differ (the group that holds the smallest peak evaluates several times more tiles)
+	const int wr_  = (w + (int)blockIdx.x) & 3;
+	const int g    = wr_ % G;                     // my group -> blocks g, g + G, g + 2G
+	const int sub  = wr_ / G;                     // waves of one group split the batches
 	const int nsub = 4 / G;
-	if (g >= nb) {
-		return; // 65..96 angles put three blocks on four groups: nothing to do (no workgroup barrier anywhere below)
-	}
+	const bool idle = g >= nb; // 65..96 angles put three blocks on four groups: this wave only helps loading
 
 	// NBLK = blocks per wave (1..3); a wave whose group has fewer blocks multiplies by an
 	// all-zero A operand there (maxima stay 0, nothing is published for them)
@@ -79,6 +81,12 @@ __global__ __launch_bounds__ (256, 3) void sweep_kernel (const SweepParams p)
 			v           = p.lut[2 * a + (kk ? 0 : 1)]; // lut = {sin, cos}
 		}
 		a_op[q] = v;
+	}
+#pragma unroll
+	for (int q = 0; q < NBLK; ++q) {
+		// the A operands are in their registers from here on: without this use the first s_waitcnt that covers their loads
+		// lands INSIDE the main loop, in front of the first MFMA, as vmcnt(0) -- and drains the prefetch of every step
+		asm volatile ("" : "+v"(a_op[q]));
 	}
 	f32x16 m[NBLK];
 #pragma unroll
@@ -119,12 +127,11 @@ __global__ __launch_bounds__ (256, 3) void sweep_kernel (const SweepParams p)
 		}
 	};
 
-	// ---- pruning state: wave-uniform, kept in SGPRs (with NBLK = 3 the kernel sits at the 168-VGPR boundary of
-	// 3 waves per SIMD).  This file is compiled with -ffast-math (finite-math-only): no infinities as sentinels; every
-	// wave that gets here has at least one valid entry, so kBig never survives a wave_min.
+	// ---- pruning state: wave-uniform.  This file is compiled with -ffast-math (finite-math-only): no infinities as
+	// sentinels; every wave that is not idle has at least one valid entry, so kBig never survives its wave_min.
 	constexpr float kBig = 1.0e18f; // finite, and its square still is
 	float thr2 = 0.f;               // frames with r^2 <= thr2 cannot matter (margin included)
-	if (PRUNE) {
+	if (PRUNE && !idle) {
 		float lo = kBig;
 #pragma unroll
 		for (int q = 0; q < NBLK; ++q) {
@@ -143,12 +150,18 @@ __global__ __launch_bounds__ (256, 3) void sweep_kernel (const SweepParams p)
 	unsigned* const thr_slot = p.thr ? reinterpret_cast<unsigned*> (p.thr) + ((int64_t)c * 4 + g) : nullptr;
 	auto share = [&] (float lo) { // lo: this wave's bound (not squared); returns the best bound known
 		if (thr_slot != nullptr) {
+			// read first, write only a bound that improves on what is published: every wave of the launch aims at the
+			// same cache line (n_chn x 4 floats), and same-line atomics are served one at a time by one L2 channel --
+			// with an unconditional atomicMax per wave and iteration that queue, not the stream, set the kernel's time
 			float best = lo;
 			if (lane == 0) {
-				const unsigned old = atomicMax (thr_slot, __float_as_uint (lo));
-				best               = fmaxf (lo, __uint_as_float (old));
+				float cur = __uint_as_float (__hip_atomic_load (thr_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+				if (lo > cur) {
+					cur = __uint_as_float (atomicMax (thr_slot, __float_as_uint (lo)));
+				}
+				best = fmaxf (lo, cur);
 			}
-			lo = __shfl (best, 0);
+			lo = uniform_f (best);
 		}
 		return lo;
 	};
@@ -166,7 +179,7 @@ __global__ __launch_bounds__ (256, 3) void sweep_kernel (const SweepParams p)
 		lo   = share (wave_min (lo));
 		thr2 = uniform_f (fmaxf (thr2, lo * lo * 0.9999f));
 	};
-	if (PRUNE && thr2 > 0.f) {
+	if (PRUNE && !idle && thr2 > 0.f) {
 		const float b = share (sqrtf (thr2));
 		thr2          = uniform_f (fmaxf (thr2, b * b * 0.9999f));
 	}
@@ -178,136 +191,197 @@ __global__ __launch_bounds__ (256, 3) void sweep_kernel (const SweepParams p)
 	int          win_tiles = 0, win_surv = 0;
 	unsigned     n_seen = 0, n_eval = 0, n_untested = 0, n_surv = 0; // tiles, tiles, tiles, frames
 
-	// A lane owns one frame of each 64-frame group: d from the dry stream, h from the Hilbert branch, both in its own
-	// registers -- the test needs no cross-lane traffic, and one v_permlane32_swap turns a group into the B operands of
-	// its two 32-frame tiles ([d_0..31 | h_0..31] and [d_32..63 | h_32..63]) for the untested feed.
-	const int64_t span  = (int64_t)kSuper * 32;
-	bool          first = true;
-	for (int64_t base = p.t_begin + (int64_t)blockIdx.x * span; base < p.t_end; base += (int64_t)gridDim.x * span) {
-		if (PRUNE && !first) {
-			refresh ();
-		}
-		first = false;
-		const bool fast = (base + span <= p.t_end) && (base - p.delay >= 0) && (base + span - p.delay <= p.n_x) &&
-		                  (base + p.t_abs0 >= p.dry_from);
-		auto load_groups = [&] (float (&dt)[kNL], float (&ht)[kNL], int sp) {
-			const int64_t t0 = base + (int64_t)sp * (64 * kNL) + lane;
-			if (fast) {
-				const float* __restrict__ xs = x + t0 - p.delay;
-				const float* __restrict__ us = u + t0;
+	// ---- the stream: steps of 1024 frames, grid-strided -- at any moment the workgroups of a channel read ONE dense
+	// window of the stream (grid x 4 KB per stream), which is what keeps DRAM pages open; with 8192-frame iterations cut
+	// into steps the same loads were spread over an 8 x wider window, one 4 KB piece in eight live at a time, and the
+	// bare stream (loads, stage, barrier, no work) ran at 2.4 TB/s.  A step's frames are loaded once per workgroup and
+	// parked in LDS, where all four waves test them; with every wave loading every frame itself (rounds 1-2) the loads
+	// in flight per CU were 4 x redundant.
+	const int64_t first_base = p.t_begin + (int64_t)blockIdx.x * kStage;
+	const int64_t stride     = (int64_t)gridDim.x * kStage;
+	const int     n_step     = first_base < p.t_end ? (int)((p.t_end - first_base + stride - 1) / stride) : 0;
+
+	// Loading is split by step parity: waves 0-1 bring in the odd steps, waves 2-3 the even ones, each wave half a step
+	// (512 frames: a lane four consecutive frames of each stream, twice -- dwordx4 loads).  At the start of step s the
+	// waves whose turn it is park the frames of step s + 1 (requested two steps ago) in the stage and request step s + 3:
+	// two steps are in flight per workgroup at any time, with one set of registers per wave and one instance of the code
+	// (one step in flight, 4 x 8 KB per CU, streamed at 2.4 TB/s with nothing else to do; two register sets and the loop
+	// unrolled by two ran the wave-uniform state out of SGPRs).
+	const int ld_par  = w >> 1;        // parity of the steps s at whose start this wave parks / requests
+	const int ld_half = (w & 1) * 512; // my half of a step
+	float4    dv[2], hv[2];
+	auto locate = [&] (int s, int64_t& t0) { // first frame of my lane in step s; true: the whole step is plain stream
+		const int64_t base = first_base + (int64_t)s * stride;
+		t0                 = base + ld_half + 4 * lane;
+		return (base + kStage <= p.t_end) && (base - p.delay >= 0) && (base + kStage - p.delay <= p.n_x) &&
+		       (base + p.t_abs0 >= p.dry_from);
+	};
+	auto request = [&] (int s) { // frames of step s -> dv, hv (plain stream only; the edges are fetched when they are parked)
+		int64_t t0;
+		if (locate (s, t0)) {
+			typedef float f4u __attribute__ ((ext_vector_type (4), aligned (4)));
 #pragma unroll
-				for (int i = 0; i < kNL; ++i) {
-					dt[i] = xs[64 * i];
-					ht[i] = us[64 * i];
-				}
-			} else {
-				// edges of the stream (history, silence, the dry-less first half block): the same loads, branch-free -- an
-				// element outside everything reads a frame that certainly exists (u[t_begin]) and is replaced by 0; no
-				// control flow between the loads, so the s_waitcnt before the work counts loads instead of draining
-				const float* const safe = u + p.t_begin;
-#pragma unroll
-				for (int i = 0; i < kNL; ++i) {
-					const int64_t ti  = t0 + 64 * i;
-					const int64_t ix  = ti - p.delay, ih = ix + p.hist_len;
-					const bool    in  = ti < p.t_end;
-					const bool    okx = ix >= 0 && ix < p.n_x, okh = ix < 0 && ih >= 0 && hist != nullptr;
-					const bool    okd = in && (okx || okh) && ti + p.t_abs0 >= p.dry_from;
-					const float*  qd  = okx ? x + ix : (okh ? hist + ih : safe);
-					const float*  qh  = in ? u + ti : safe;
-					const float   vd = *qd, vh = *qh;
-					dt[i]             = okd ? vd : 0.f;
-					ht[i]             = in ? vh : 0.f;
-				}
-			}
-		};
-		float dcur[kNL], hcur[kNL], dnxt[kNL], hnxt[kNL];
-		load_groups (dcur, hcur, sub);
-		for (int sp = sub; sp < kSteps; sp += nsub) {
-			if (sp + nsub < kSteps) {
-				load_groups (dnxt, hnxt, sp + nsub);
-			}
-			if (!PRUNE) {
-#pragma unroll
-				for (int i = 0; i < kNL; ++i) {
-					const auto sw = __builtin_amdgcn_permlane32_swap (__float_as_uint (dcur[i]), __float_as_uint (hcur[i]), false, false);
-					evaluate (__uint_as_float (sw[0]), __uint_as_float (sw[1]));
-				}
-			} else {
-				// one instance of the evaluation serves both feeds (an unrolled register feed next to the ring loop pushed
-				// the three-block kernel over 168 VGPRs, i.e. down to two waves per SIMD)
-				int direct = 0; // groups still to be fed straight from dcur / hcur
-				if (testing) {
-					int surv = 0;
-#pragma unroll
-					for (int i = 0; i < kNL; ++i) {
-						const float    d = dcur[i], h = hcur[i];
-						const bool     live = d * d + h * h > thr2;
-						const uint64_t mask = __builtin_amdgcn_ballot_w64 (live);
-						if (live) {
-							const unsigned at = (wr + __builtin_amdgcn_mbcnt_hi ((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned)mask, 0u))) & (kRing - 1);
-							*reinterpret_cast<float2*> (ring + 2 * at) = make_float2 (d, h);
-						}
-						const int nl = __builtin_popcountll (mask);
-						wr += (unsigned)nl;
-						surv += nl;
-					}
-					n_surv += (unsigned)surv;
-					win_tiles += 2 * kNL;
-					win_surv += surv;
-				} else {
-					direct = kNL;
-					n_untested += 2 * kNL;
-					n_eval += 2 * kNL;
-				}
-				n_seen += 2 * kNL;
-				__builtin_amdgcn_wave_barrier ();
-				for (;;) {
-					float b0, b1;
-					if (direct > 0) {
-						const auto sw = __builtin_amdgcn_permlane32_swap (__float_as_uint (dcur[0]), __float_as_uint (hcur[0]), false, false);
-						b0 = __uint_as_float (sw[0]);
-						b1 = __uint_as_float (sw[1]);
-#pragma unroll
-						for (int i = 0; i + 1 < kNL; ++i) {
-							dcur[i] = dcur[i + 1];
-							hcur[i] = hcur[i + 1];
-						}
-						--direct;
-					} else if (wr - rd >= 64u) {
-						b0 = ring[2 * ((rd + j) & (kRing - 1)) + kk];
-						b1 = ring[2 * ((rd + 32 + j) & (kRing - 1)) + kk];
-						rd += 64u;
-						n_eval += 2;
-					} else {
-						break;
-					}
-					evaluate (b0, b1);
-				}
-				__builtin_amdgcn_wave_barrier ();
-				if (!testing) {
-					if (--pause_left <= 0) {
-						testing = true;
-						refresh ();
-					}
-				} else if (win_tiles >= kWin) {
-					if (win_surv * 8 > win_tiles * 32 * 7) {
-						testing    = false;
-						pause_left = pause;
-						pause      = pause * 2 < kPauseMax ? pause * 2 : kPauseMax;
-					} else {
-						pause = kPause0;
-					}
-					win_tiles = win_surv = 0;
-				}
-			}
-#pragma unroll
-			for (int i = 0; i < kNL; ++i) {
-				dcur[i] = dnxt[i];
-				hcur[i] = hnxt[i];
+			for (int i = 0; i < 2; ++i) {
+				const f4u d4 = *reinterpret_cast<const f4u*> (x + t0 + 256 * i - p.delay);
+				const f4u h4 = *reinterpret_cast<const f4u*> (u + t0 + 256 * i);
+				dv[i]        = make_float4 (d4[0], d4[1], d4[2], d4[3]);
+				hv[i]        = make_float4 (h4[0], h4[1], h4[2], h4[3]);
 			}
 		}
+	};
+	auto park = [&] (int buf, int s) { // frames of step s: dv, hv -> (d, h) pairs of the stage
+		int64_t t0;
+		if (locate (s, t0)) {
+#pragma unroll
+			for (int i = 0; i < 2; ++i) {
+				float* const q                            = stage_s + buf * 2 * kStage + ld_half + 256 * i + 4 * lane;
+				*reinterpret_cast<float4*> (q)            = dv[i];
+				*reinterpret_cast<float4*> (q + kStage)   = hv[i];
+			}
+		} else {
+			// edges of the stream (history, silence, the dry-less first half block): fetched here, frame by frame, latency
+			// exposed -- a few iterations per launch; kept out of request() so that its loads land in registers no other
+			// path writes (a merge of two producers costs copies, and a copy of a register in flight is a wait)
+#pragma unroll
+			for (int i = 0; i < 2; ++i) {
+#pragma unroll
+				for (int e = 0; e < 4; ++e) {
+					const int64_t ti  = t0 + 256 * i + e;
+					const int64_t ix  = ti - p.delay;
+					float         d = 0.f, h = 0.f;
+					if (ti < p.t_end) {
+						h = u[ti];
+						d = ti + p.t_abs0 >= p.dry_from ? ldv (x, p.n_x, hist, p.hist_len, ix) : 0.f;
+					}
+					float* const q = stage_s + buf * 2 * kStage + ld_half + 256 * i + 4 * lane + e;
+					q[0]           = d;
+					q[kStage]      = h;
+				}
+			}
+		}
+	};
+	// prologue: waves 2-3 fetch step 0 and park it (the only exposed latency), then request step 2; waves 0-1 request step 1
+	if (ld_par == 1) {
+		if (n_step > 0) {
+			request (0);
+			park (0, 0);
+		}
+		if (n_step > 2) {
+			request (2);
+		}
+	} else if (n_step > 1) {
+		request (1);
 	}
-	if (PRUNE) {
+	__syncthreads ();
+	for (int s = 0; s < n_step; ++s) {
+		const int buf = s & 1;
+		if ((s & 1) == ld_par) {
+			if (s + 1 < n_step) {
+				park (buf ^ 1, s + 1); // everybody finished reading that half of the stage before the barrier that ended step s - 1
+			}
+			if (s + 3 < n_step) {
+				request (s + 3);
+			}
+		}
+		if (!idle) {
+			if (PRUNE && s > 0 && s % kSteps == 0) {
+				refresh ();
+			}
+			const float* const st = stage_s + buf * 2 * kStage; // d at st[f], h at st[kStage + f]
+			// the four (d, h) of a lane in batch bi: requested one batch ahead, in front of the ring writes of the batch
+			// before (the backend will not move an LDS read across an LDS write that may alias: left inside the test loop
+			// each read waited out its full latency, one after the other -- 120 cycles per 64 frames and wave)
+			float2 cur[kBatch / 64], nxt[kBatch / 64];
+			auto fetch = [&] (float2 (&v)[kBatch / 64], int bi) {
+#pragma unroll
+				for (int i = 0; i < kBatch / 64; ++i) {
+					v[i] = make_float2 (st[bi * kBatch + i * 64 + lane], st[kStage + bi * kBatch + i * 64 + lane]);
+				}
+			};
+			if (PRUNE) {
+				fetch (cur, sub);
+			}
+			for (int bi = sub; bi < kStage / kBatch; bi += nsub) {
+				if (PRUNE && bi + nsub < kStage / kBatch) {
+					fetch (nxt, bi + nsub); // (also while the test is off: it may come back on at the end of this batch)
+				}
+				if (!PRUNE) {
+#pragma unroll
+					for (int tt = 0; tt < kBatch / 32; tt += 2) {
+						evaluate (st[kk * kStage + bi * kBatch + tt * 32 + j], st[kk * kStage + bi * kBatch + tt * 32 + 32 + j]);
+					}
+				} else {
+					// one instance of the evaluation serves both feeds (an unrolled direct feed next to the ring loop pushed
+					// the three-block kernel over 168 VGPRs, i.e. down to two waves per SIMD)
+					int direct = 0; // tile pairs of this batch still to be fed untested, straight from the stage
+					if (testing) {
+						int surv = 0;
+#pragma unroll
+						for (int i = 0; i < kBatch / 64; ++i) {
+							const float2   v    = cur[i];
+							const bool     live = v.x * v.x + v.y * v.y > thr2;
+							const uint64_t mask = __builtin_amdgcn_ballot_w64 (live);
+							if (live) {
+								const unsigned at = (wr + __builtin_amdgcn_mbcnt_hi ((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned)mask, 0u))) & (kRing - 1);
+								*reinterpret_cast<float2*> (ring + 2 * at) = v;
+							}
+							const int nl = __builtin_popcountll (mask);
+							wr += (unsigned)nl;
+							surv += nl;
+						}
+						n_surv += (unsigned)surv;
+						win_tiles += kBatch / 32;
+						win_surv += surv;
+					} else {
+						direct = kBatch / 64;
+						n_untested += kBatch / 32;
+						n_eval += kBatch / 32;
+					}
+					n_seen += kBatch / 32;
+					__builtin_amdgcn_wave_barrier ();
+					for (;;) {
+						float b0, b1;
+						if (direct > 0) {
+							const int tt = 2 * (kBatch / 64 - direct);
+							b0           = st[kk * kStage + bi * kBatch + tt * 32 + j];
+							b1           = st[kk * kStage + bi * kBatch + tt * 32 + 32 + j];
+							--direct;
+						} else if (wr - rd >= 64u) {
+							b0 = ring[2 * ((rd + j) & (kRing - 1)) + kk];
+							b1 = ring[2 * ((rd + 32 + j) & (kRing - 1)) + kk];
+							rd += 64u;
+							n_eval += 2;
+						} else {
+							break;
+						}
+						evaluate (b0, b1);
+					}
+					__builtin_amdgcn_wave_barrier ();
+					if (!testing) {
+						if (--pause_left <= 0) {
+							testing = true;
+							refresh ();
+						}
+					} else if (win_tiles >= kWin) {
+						if (win_surv * 8 > win_tiles * 32 * 7) {
+							testing    = false;
+							pause_left = pause;
+							pause      = pause * 2 < kPauseMax ? pause * 2 : kPauseMax;
+						} else {
+							pause = kPause0;
+						}
+						win_tiles = win_surv = 0;
+					}
+#pragma unroll
+					for (int i = 0; i < kBatch / 64; ++i) {
+						cur[i] = nxt[i];
+					}
+				}
+			}
+		}
+		__syncthreads ();
+	}
+	if (PRUNE && !idle) {
 		const unsigned left = wr - rd; // < 64
 		if (left > 0u) {
 			float b0 = ring[2 * ((rd + j) & (kRing - 1)) + kk];
@@ -317,12 +391,27 @@ __global__ __launch_bounds__ (256, 3) void sweep_kernel (const SweepParams p)
 			evaluate (b0, b1);
 			n_eval += left > 32u ? 2 : 1;
 		}
-		if (p.stats != nullptr && lane == 0) {
-			atomicAdd (&p.stats[0], (unsigned long long)n_eval);
-			atomicAdd (&p.stats[1], (unsigned long long)n_seen);
-			atomicAdd (&p.stats[2], (unsigned long long)n_untested);
-			atomicAdd (&p.stats[3], (unsigned long long)n_surv);
+	}
+	// statistics: one set of atomics per workgroup, not per wave (every atomic of the launch lands on the same cache line)
+	if (PRUNE && p.stats != nullptr) {
+		unsigned* const acc = reinterpret_cast<unsigned*> (stage_s); // the stage is free: everybody passed the last barrier
+		if (tid < 4) {
+			acc[tid] = 0u;
 		}
+		__syncthreads ();
+		if (lane == 0 && !idle) {
+			atomicAdd (&acc[0], n_eval);
+			atomicAdd (&acc[1], n_seen);
+			atomicAdd (&acc[2], n_untested);
+			atomicAdd (&acc[3], n_surv);
+		}
+		__syncthreads ();
+		if (tid < 4) {
+			atomicAdd (&p.stats[tid], (unsigned long long)acc[tid]);
+		}
+	}
+	if (idle) {
+		return;
 	}
 	// reduce over the 32 columns (lanes of one half), then one atomic per angle
 	unsigned* gp = reinterpret_cast<unsigned*> (p.peaks + (int64_t)c * kMaxSample);
@@ -339,7 +428,12 @@ __global__ __launch_bounds__ (256, 3) void sweep_kernel (const SweepParams p)
 			const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
 			const int idx = (g + q * G) * 32 + row;
 			if (j == 0 && g + q * G < nb && idx < p.n_angles) {
-				atomicMax (&gp[p.angles[idx]], __float_as_uint (v));
+				// look first: of the thousands of waves that hold a maximum for this angle only a few hold one that raises
+				// the table, and the table's few cache lines serve their atomics one at a time
+				unsigned* const slot = &gp[p.angles[idx]];
+				if (__float_as_uint (v) > __hip_atomic_load (slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+					atomicMax (slot, __float_as_uint (v));
+				}
 			}
 		}
 	}
@@ -371,7 +465,7 @@ hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s)
 		}
 		slots[pr][nblk] = cus * occ;
 	}
-	const int64_t span  = (int64_t)kSuper * 32;
+	const int64_t span  = kStage;
 	const int64_t tiles = (p.t_end - p.t_begin + span - 1) / span;
 	const int64_t gx    = std::min<int64_t> (tiles, std::max (1, slots[pr][nblk] / n_chn));
 	const dim3    grid ((unsigned)gx, (unsigned)n_chn), block (256);

@@ -596,15 +596,13 @@ def test_pruned_sweep_is_bit_identical_to_unpruned(pkg, signal):
         x[:g, 0] = 0.7 * np.sin(2 * np.pi * 997.0 / 48000 * np.arange(g))
         x[g:, 0] = 0.5 * xorshift_uniform(n - g, seed=12)
     elif signal == "bursts":
-        # period = the 8192 frames one workgroup iteration covers: a quarter of ever louder tone (all of it survives:
-        # the test is switched off), three quarters of quiet noise (the wave must switch it back on)
-        segs, A = 40, 0.1
-        x = np.empty((segs * 8192, 1), np.float32)
-        for k in range(segs):
-            x[k * 8192:k * 8192 + 2048, 0] = np.sin(2 * np.pi * 0.05 * np.arange(2048)) * np.linspace(A, 1.05 * A, 2048)
-            x[k * 8192 + 2048:(k + 1) * 8192, 0] = 0.3 * A * xorshift_uniform(6144, seed=30 + k)
-            A *= 1.05
-        n = x.shape[0]
+        # ONE launch (a device chunk holds 2^22 frames; a workgroup walks it in steps of 1024 frames, grid-strided, so it
+        # meets the material in file order): a quarter of steady tone -- all of it survives, the test goes off --, then
+        # three quarters of quiet noise, where the wave must switch the test back on
+        n, g = 1 << 22, 1 << 20
+        x = np.empty((n, 1), np.float32)
+        x[:g, 0] = 0.7 * np.sin(2 * np.pi * 997.0 / 48000 * np.arange(g))
+        x[g:, 0] = 0.2 * xorshift_uniform(n - g, seed=30)
     elif signal == "silence-then-burst":
         n = 300000
         x = np.zeros((n, 2), np.float32)
@@ -648,8 +646,8 @@ def test_pruned_sweep_is_bit_identical_to_unpruned(pkg, signal):
         assert frac_pruned > 0.9, frac_pruned   # every frame holds a new record: nothing may be skipped
         assert st["untested"] > 0.5 * st["seen"], st  # ... and the test is switched off most of the time
     if signal == "bursts":
-        assert 0.2 < frac_pruned < 0.6, frac_pruned
-        assert 0.05 * st["seen"] < st["untested"] < 0.4 * st["seen"], st  # off in the tone, back on in the noise
+        assert 0.2 < frac_pruned < 0.85, frac_pruned  # (the tone quarter + the pauses that reach into the noise)
+        assert 0.05 * st["seen"] < st["untested"] < 0.6 * st["seen"], st  # off in the tone, back on in the noise
     if signal == "growing-then-steady":
         assert frac_pruned < 0.6, frac_pruned   # the steady 3/4 are tested again (and mostly skipped)
         assert 0.1 * st["seen"] < st["untested"] < 0.4 * st["seen"], st
