@@ -1,18 +1,21 @@
-// prot_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the phase-rotation
-// hot path.  wave64 throughout; no hipFFT/rocFFT; MFMA only in the sweep (the OLA
-// path is a butterfly network, not a contraction).
+// prot_kernels.hip -- gfx950 (MI355X, CDNA4) overlap-add kernels of the phase-rotation hot path, and the small
+// movers around them.  wave64 throughout; no hipFFT/rocFFT (the OLA path is a butterfly network, not a contraction).
 //
-// Three OLA kernels share the 4096-point transform pair (fwd4096w / inv4096w or the
-// inline version of ola4096_kernel), the register-resident overlap-add tail and dry path,
-// the halo scheme and the fused history write:
-//   olapoly_kernel   -- polyphase form (odd taps on the stream read as complex samples,
-//                       512 HS new frames per block): default except at 4096 taps, the
-//                       headline kernel; described at its definition
-//   ola4096p2_kernel -- direct form, two 2048-tap partitions sharing a forward transform:
-//                       default at 4096 taps (LV2 96 kHz, CLI blksiz 4096), fp16 path
-//   ola4096_kernel   -- direct form, one partition (<= 3072 taps), described here:
-// sweep_mfma_kernel  -- K7, the per-angle abs-max as rank-2 MFMA products, with exact
-//                       pruning of frame groups that cannot raise a maximum
+// The kernels of the path, by file:
+//   prot_olasave.hip  olasave_kernel   -- polyphase OVERLAP-SAVE, one partition of the odd taps, no spectrum table,
+//                                         generated gfx950 assembly, four workgroups per CU: the default for every
+//                                         Hilbert FIR of 1024..6144 taps (LV2 48 / 96 kHz, CLI blksiz 1024..4096) --
+//                                         the headline kernel
+//   here              olapoly_kernel   -- polyphase overlap-add with a spectrum table: FIRs of 8192 taps and more
+//                                         (two partitions of the odd taps per launch, accumulating launches beyond),
+//                                         7168-frame blocks (CLI blksiz 1024: HS = 14), PROT_CFG_OVERLAP_ADD, fp16
+//   here              ola4096p2_kernel -- direct form, two 2048-tap partitions sharing a forward transform:
+//                                         PROT_CFG_DIRECT_FORM (cross-check of the polyphase forms), fp16 at 4096 taps
+//   here              ola4096_kernel   -- direct form, one partition: FIRs below 1024 taps (CLI blksiz 64..512),
+//                                         PROT_CFG_SINGLE_FFT_PER_HOP; described below
+//   prot_sweep.hip    sweep_kernel     -- K7, the per-angle abs-max on the matrix core over compacted survivors
+// They share the 4096-point transform pair (fwd4096w / inv4096w, or the inline version of ola4096_kernel), the
+// register-resident overlap-add tail and dry path, the halo scheme and the fused history write (prot_dev.h).
 //
 // ola4096_kernel -- overlap-add Hilbert convolution + rotation, one
 //   workgroup (256 threads = 4 waves) per run of consecutive hops of one
@@ -34,54 +37,16 @@
 //       nothing but the FFT exchange;
 //     * a run starts (fftlen/hop) halo blocks early to rebuild the tail from
 //       input history, so workgroups never exchange data.
-// sweep_kernel  -- K7: per-angle max |ca*d + sa*h| (cli/phase-rotate.cc:98-121,
-//   :409-428, cli/dsp_peak_calc.h): lanes own frames, the angle loop is
-//   scalar (sin/cos in SGPRs), one DPP wave-reduction per angle per tile,
-//   running maxima in 6 VGPRs per wave, unsigned atomicMax at the end.
 #include "prot_fft.h"
 #include "prot_kernels.h"
 #include "prot_dev.h"
+#include "prot_ablate.h"
 
 #include <algorithm>
 #include <cstdlib>
 
-// ABL (ablation, timing experiments only -- results are wrong): 1 no LDS exchange, 2 no barriers,
-// 4 no H loads, 8 no stream loads
-#define PROT_SYNC() do { if (!(ABL & 2)) __syncthreads (); } while (0)
 
 namespace prot {
-
-// PROT_STAMPS (diagnostic build only, tools/phase_stamps.py): per-phase shader-cycle sums of the polyphase kernel's
-// main loop, accumulated per wave in SGPRs and added to g_stamps at the end.  Each stamp is an s_memtime, which
-// drains lgkmcnt: the stamped build runs ~10 % slower and nothing of it exists in the shipped library.
-#ifdef PROT_STAMPS
-__device__ unsigned long long g_stamps[32];
-__device__ unsigned long long g_wg_t[4 * 4096]; // per workgroup: entry, loop start, end (s_memrealtime, 100 MHz), HW_ID
-struct Stamps {
-	uint64_t last, acc[16];
-	__device__ __forceinline__ void start ()
-	{
-#pragma unroll
-		for (int i = 0; i < 16; ++i) {
-			acc[i] = 0;
-		}
-		last = __builtin_readcyclecounter ();
-	}
-	__device__ __forceinline__ void tick (int i)
-	{
-#if PROT_STAMPS == 1 // (2: the per-workgroup timeline only -- the per-phase stamps slow the kernel by a third)
-		const uint64_t now = __builtin_readcyclecounter ();
-		acc[i] += now - last;
-		last = now;
-#endif
-	}
-};
-#else
-struct Stamps {
-	__device__ __forceinline__ void start () {}
-	__device__ __forceinline__ void tick (int) {}
-};
-#endif
 
 // ------------------------------------------------------------ OLA, FFT-4096
 // (kL1 = 272, the exchange stride between pass 1 and 2, and the MODE_* enum live in prot_dev.h)
@@ -113,7 +78,7 @@ PROT_DEV void load_pair (float (&nx)[2 * HOPSEG], const float* __restrict__ in, 
 	}
 }
 
-template <int HOPSEG, int NREG, int WAVES, int MODE, int ABL = 0, bool ACC = false, int DH = 0, bool PK = true>
+template <int HOPSEG, int NREG, int WAVES, int MODE, bool ACC = false, int DH = 0, bool PK = true>
 __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p)
 {
 	constexpr int HOP  = HOPSEG * 256;
@@ -175,7 +140,7 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 	// in its inverse transform, so HBM latency hides behind a whole half-iteration
 	float nx[2 * HOPSEG];
 	load_pair<HOPSEG> (nx, in, n_in, hist, p.hist_len, sA - Dc, t);
-	PROT_SYNC ();
+	__syncthreads ();
 
 	// DH > 0: the dry path (x delayed by dry_delay) is served from registers: its
 	// frames are the FFT input of this pair (cur) and the last DH 256-frame segments of
@@ -231,13 +196,13 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 			f2* w = &lds[NREG - 1][t];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
-				if (!(ABL & 1)) w[k * kL1] = v[k];
+				w[k * kL1] = v[k];
 			}
-			PROT_SYNC ();
+			__syncthreads ();
 			const f2* r = &lds[NREG - 1][th * kL1 + tl];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
-				if (!(ABL & 1)) v[k] = r[16 * k];
+				v[k] = r[16 * k];
 			}
 		}
 		// ---- forward pass 2 (over n1), twiddle W256^{n0 k1} -----------------
@@ -251,19 +216,19 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 			v[k] = PK ? pk_cmul<1> (v[k], twm[k * 16 + tl]) : cmulw<1> (v[k], twm[k * 16 + tl]);
 		}
 		if (NREG == 1) {
-			PROT_SYNC ();
+			__syncthreads ();
 		}
 		{
 			f2* w = &lds[0][tl * kL2 + th];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
-				if (!(ABL & 1)) w[16 * k] = v[k];
+				w[16 * k] = v[k];
 			}
-			PROT_SYNC ();
+			__syncthreads ();
 			const f2* r = &lds[0][t];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
-				if (!(ABL & 1)) v[k] = r[k * kL2];
+				v[k] = r[k * kL2];
 			}
 		}
 		// ---- forward pass 3 (over n0): v[k2] = X[t + 256 k2] ----------------
@@ -276,16 +241,16 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 		// ---- x H: Hilbert FIR spectrum, 1/fftlen folded in -------------------
 #pragma unroll
 		for (int k = 0; k < 8; ++k) {
-			v[k] = PK ? pk_cmul<1> (v[k], (ABL & 4) ? mkf2 (0.5f + k, 0.25f) : Hs[t + 256 * k]) : cmulw<1> (v[k], (ABL & 4) ? mkf2 (0.5f + k, 0.25f) : Hs[t + 256 * k]);
+			v[k] = PK ? pk_cmul<1> (v[k], Hs[t + 256 * k]) : cmulw<1> (v[k], Hs[t + 256 * k]);
 		}
 #pragma unroll
 		for (int k = 8; k < 16; ++k) { // bins >= 2048: conjugate of the mirrored bin
-			v[k] = PK ? pk_cmul<-1> (v[k], (ABL & 4) ? mkf2 (0.5f + k, 0.25f) : Hs[256 * (16 - k) - t]) : cmulw<-1> (v[k], (ABL & 4) ? mkf2 (0.5f + k, 0.25f) : Hs[256 * (16 - k) - t]);
+			v[k] = PK ? pk_cmul<-1> (v[k], Hs[256 * (16 - k) - t]) : cmulw<-1> (v[k], Hs[256 * (16 - k) - t]);
 		}
 
 		// ---- request the next pair's frames (after the H loads: vmcnt retires in order)
 		__builtin_amdgcn_sched_barrier (0);
-		if (it + 1 < n_pairs && !(ABL & 8)) {
+		if (it + 1 < n_pairs) {
 			load_pair<HOPSEG> (nx, in, n_in, hist, p.hist_len, sA + 2 * HOP - Dc, t);
 		}
 		// ... and the delayed dry frames of this pair (L2 hits: read as FFT input earlier)
@@ -306,7 +271,7 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 				const float* __restrict__ dq = in + (sA - Dd) + t;
 #pragma unroll
 				for (int k = 0; k < 2 * HOPSEG; ++k) {
-					dry[k] = (ABL & 8) ? 0.25f * k : dq[256 * k];
+					dry[k] = dq[256 * k];
 				}
 			} else {
 #pragma unroll
@@ -332,13 +297,13 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 			f2* w = &lds[0][t];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
-				if (!(ABL & 1)) w[k * kL3] = v[k];
+				w[k * kL3] = v[k];
 			}
-			PROT_SYNC ();
+			__syncthreads ();
 			const f2* r = &lds[0][tl * kL3 + th];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
-				if (!(ABL & 1)) v[k] = r[16 * k];
+				v[k] = r[16 * k];
 			}
 		}
 		// ---- inverse pass 2 (over k1) ----------------------------------------
@@ -348,19 +313,19 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 			fft16<-1> (v);
 		}
 		if (NREG == 1) {
-			PROT_SYNC ();
+			__syncthreads ();
 		}
 		{
 			f2* w = &lds[NREG - 1][th * kL1 + tl];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
-				if (!(ABL & 1)) w[16 * k] = v[k];
+				w[16 * k] = v[k];
 			}
-			PROT_SYNC ();
+			__syncthreads ();
 			const f2* r = &lds[NREG - 1][t];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
-				if (!(ABL & 1)) v[k] = r[k * kL1];
+				v[k] = r[k * kL1];
 			}
 		}
 		// ---- twiddle conj W^{t k0}, inverse pass 3 (over k0) -----------------
@@ -449,17 +414,9 @@ __global__ __launch_bounds__ (256, WAVES) void ola4096_kernel (const OlaParams p
 // The re/im packing pairs block b of two SUB-RUNS of the workgroup's run (first and second
 // half), so the delayed spectrum X_{b-1} of the pair is simply last iteration's registers.
 // --------------------------------------------------------------------------------------
-// PROT_LDS_VOLATILE: exchange accesses as volatile so the backend keeps one ds_read_b64 /
-// ds_write_b64 per element instead of fusing neighbours into ds_read2_b64 / ds_write2_b64
-// (8 and 13 LDS cycles against 2 x 2 and 2 x 6, and mod-32 banking)
-#ifndef PROT_LDS_VOLATILE
-#define PROT_LDS_VOLATILE 1
-#endif
-#if PROT_LDS_VOLATILE
+// exchange accesses are volatile so the backend keeps one ds_read_b64 / ds_write_b64 per element instead of fusing
+// neighbours into ds_read2_b64 / ds_write2_b64 (8 and 13 LDS cycles against 2 x 2 and 2 x 6, and mod-32 banking)
 #define PROT_LDSQ volatile
-#else
-#define PROT_LDSQ
-#endif
 // precision traits: fp32 (aligned VGPR pair per complex) and fp16 (one VGPR per complex)
 struct T32 {
 	typedef pk32  ops;
@@ -473,59 +430,6 @@ struct T16 {
 	typedef _Float16 samp;
 	static constexpr int kWaves = 3;
 };
-
-// PROT_ABL2 (timing experiments only, results are wrong): 1 no LDS exchange, 2 no workgroup barriers,
-// 4 no radix-16 butterflies, 8 no twiddle multiplies, 16 no spectrum multiply, 32 no stream loads,
-// 64 no stores, 128 the stream does not advance (each run re-reads and re-writes its first block: the same instructions,
-// served by the caches instead of HBM)
-#ifndef PROT_ABL2
-#define PROT_ABL2 0
-#endif
-// where the next block's stream loads are issued: 0 = top of the iteration, 1 = after the spectrum multiply
-#ifndef PROT_LEAN_PIN
-#define PROT_LEAN_PIN 0
-#endif
-#ifndef PROT_XCD_ROTATE
-#define PROT_XCD_ROTATE 1
-#endif
-#ifndef PROT_PREFETCH_EARLY
-#define PROT_PREFETCH_EARLY 1
-#endif
-#ifndef PROT_TABLES_LATE
-#define PROT_TABLES_LATE 1
-#endif
-// 1: the exchanges' LDS stores are issued per DFT-4 of the second butterfly stage (pkt_fft16_stage2_each), pinned with
-// scheduling barriers, so that they run under the wave's own remaining butterflies.  Measured (interleaved A/B, four
-// engines): no difference to the compiler's own order (all stores behind the butterflies) -- with three workgroups per
-// CU the other waves already fill those cycles.  Off; kept as the record of the experiment.
-#ifndef PROT_PIPE_STORES
-#define PROT_PIPE_STORES 0
-#endif
-#ifndef PROT_NT_STORE
-#define PROT_NT_STORE 0
-#endif
-#ifndef PROT_NT_LOAD
-#define PROT_NT_LOAD 0
-#endif
-#ifndef PROT_PROBE4
-#define PROT_PROBE4 0
-#endif
-#ifndef PROT_T_MASK
-#define PROT_T_MASK 1
-#endif
-// 1: on the last iteration (nothing to prefetch) the carried registers are "defined" by an empty asm instead of keeping
-// their values, which saves 2 HS register copies in front of the prefetch branch -- NOT USED: together with the
-// wait-before-stores asm below, hipcc 7.2 turned copies of the carried registers into KILLs at the loop top (rows 10, 11
-// of the 12-row kernels read garbage; smoke() and the CLI tests caught it).  Kept as a switch for the record only.
-#ifndef PROT_PREFETCH_ELSE
-#define PROT_PREFETCH_ELSE 0
-#endif
-#ifndef PROT_WAIT_BEFORE_STORES
-#define PROT_WAIT_BEFORE_STORES 1
-#endif
-#ifndef PROT_PREFETCH_AT
-#define PROT_PREFETCH_AT 1
-#endif
 
 // ---- FFT-4096 with wave-local inner exchanges (2 workgroup barriers per transform pair) ----
 // Pass-2 threads are (n1 = tl, k1 = th), so the 16 threads of one `th` hold a full n1 x k2 tile:
@@ -606,9 +510,6 @@ PROT_DEV void twiddle_store_lean (typename T::cplx (&v)[16], const PROT_LDS_PTR 
 				if (!(PROT_ABL2 & 8)) q[(j + 1) & 1][i] = r[16 * (4 * (j + 1) + i)];
 			}
 		}
-#if PROT_LEAN_PIN
-		__builtin_amdgcn_sched_barrier (0);
-#endif
 		if (j == 0) {
 			if (!(PROT_ABL2 & 1)) dst[0] = v[0];
 			if (!(PROT_ABL2 & 8)) v[1] = O::template cmul<DIR> (v[1], q[0][1]);
@@ -679,25 +580,11 @@ PROT_DEV void fwd4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 		const C (&A)[4] = reinterpret_cast<const C (&)[4]> (tw1[0]);
 		const C (&B)[4] = reinterpret_cast<const C (&)[4]> (tw1[4]);
 		VC* w = (VC*)&lds[t];
-#if PROT_PIPE_STORES && PROT_ABL2 == 0
-		pkt_fft16_fwd_pruned_twout_stage1<O, NNZ> (v, A);
-		pkt_fft16_stage2_each<O, 1> (v, [&] (auto ic, C& x0, C& x1, C& x2, C& x3) { // B on the outputs, stored as they come
-			constexpr int i = decltype (ic)::value;
-			O::template cmul2<1> (x1, B[1], x2, B[2]);
-			x3             = O::template cmul<1> (x3, B[3]);
-			w[i * kL1]        = x0;
-			w[(i + 4) * kL1]  = x1;
-			w[(i + 8) * kL1]  = x2;
-			w[(i + 12) * kL1] = x3;
-			__builtin_amdgcn_sched_barrier (0);
-		});
-#else
 		if (!(PROT_ABL2 & 4)) pkt_fft16_fwd_pruned_twout<O, NNZ> (v, A, B);
 #pragma unroll
 		for (int k = 0; k < 16; ++k) {
 			if (!(PROT_ABL2 & 1)) w[k * kL1] = v[k];
 		}
-#endif
 	} else {
 		if (!(PROT_ABL2 & 4)) pkt_fft16_fwd_pruned<O, NNZ> (v);
 		twiddle_store<T, 1, kL1> (v, tw1, (VC*)&lds[t]);
@@ -715,9 +602,6 @@ PROT_DEV void fwd4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 	after_barrier ();
 	if (LEAN) {
 		const VC* rq = (const VC*)&twm[tl];
-#if PROT_PIPE_STORES && PROT_ABL2 == 0
-		fft16_twiddle_store_each<T, 1, 1> (v, rq, (VC*)&lds[th * kL1 + tl * kG]);
-#else
 		C q0[4];
 #pragma unroll
 		for (int i = 1; i < 4; ++i) {
@@ -725,7 +609,6 @@ PROT_DEV void fwd4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 		}
 		if (!(PROT_ABL2 & 4)) pkt_fft16<O, 1> (v);
 		twiddle_store_lean<T, 1, 1> (v, rq, q0, (VC*)&lds[th * kL1 + tl * kG]);
-#endif
 	} else {
 		C q[16];
 		twm_fetch<T> (q, twm, tl);
@@ -766,9 +649,6 @@ PROT_DEV void inv4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 	typedef typename T::ops  O;
 	if (LEAN) {
 		const VC* rq = (const VC*)&twm[tl];
-#if PROT_PIPE_STORES && PROT_ABL2 == 0
-		fft16_twiddle_store_each<T, -1, kG> (v, rq, (VC*)&lds[th * kL1 + tl]);
-#else
 		C q0[4];
 #pragma unroll
 		for (int i = 1; i < 4; ++i) {
@@ -776,7 +656,6 @@ PROT_DEV void inv4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 		}
 		if (!(PROT_ABL2 & 4)) pkt_fft16<O, -1> (v);
 		twiddle_store_lean<T, -1, kG> (v, rq, q0, (VC*)&lds[th * kL1 + tl]);
-#endif
 	} else {
 		C q[16];
 		twm_fetch<T> (q, twm, tl); // W256^{k2 n1}: the table is symmetric, so lanes read neighbours here too
@@ -792,21 +671,6 @@ PROT_DEV void inv4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 			if (!(PROT_ABL2 & 1)) v[k] = r[k];
 		}
 	}
-#if PROT_PIPE_STORES && PROT_ABL2 == 0
-	if (LEAN) {
-		pkt_fft16_stage1<O, -1> (v);
-		wave_sync ();
-		VC* w = (VC*)&lds[th * kL1 + tl];
-		pkt_fft16_stage2_each<O, -1> (v, [&] (auto ic, C& x0, C& x1, C& x2, C& x3) {
-			constexpr int i = decltype (ic)::value;
-			w[16 * i]        = x0;
-			w[16 * (i + 4)]  = x1;
-			w[16 * (i + 8)]  = x2;
-			w[16 * (i + 12)] = x3;
-			__builtin_amdgcn_sched_barrier (0);
-		});
-	} else
-#endif
 	if (!(PROT_ABL2 & 4)) pkt_fft16<O, -1> (v);
 	{
 		// the group's chunk again, in the pass-1 layout: nobody else touches it before the barrier
@@ -814,7 +678,7 @@ PROT_DEV void inv4096w (typename T::cplx (&v)[16], typename T::cplx* lds, const 
 		VC* w = (VC*)&lds[th * kL1 + tl];
 #pragma unroll
 		for (int k = 0; k < 16; ++k) {
-			if (!(PROT_ABL2 & 1) && !(PROT_PIPE_STORES && PROT_ABL2 == 0 && LEAN)) w[16 * k] = v[k];
+			if (!(PROT_ABL2 & 1)) w[16 * k] = v[k];
 		}
 		st.tick (7);
 		if (!(PROT_ABL2 & 2)) __syncthreads ();
@@ -876,9 +740,6 @@ __global__ __launch_bounds__ (256, (T::kWaves == 3 && DH > 0 && MODE != MODE_HIL
 		hist_write_slice (p, blockIdx.y, threadIdx.x);
 		return;
 	}
-#ifdef PROT_CLOCKDBG
-	const uint64_t dbg_c0 = __builtin_readcyclecounter (), dbg_r0 = __builtin_amdgcn_s_memrealtime ();
-#endif
 	const int64_t r1 = (r0 + p.run_frames < p.n_out) ? r0 + p.run_frames : p.n_out;
 	const int64_t Lh = p.run_frames / 2;                      // sub-run length (multiple of HOP)
 	const int64_t eP = (r0 + Lh < r1) ? r0 + Lh : r1;         // sub-run P = [r0, eP), Q = [r0 + Lh, r1)
@@ -981,13 +842,6 @@ __global__ __launch_bounds__ (256, (T::kWaves == 3 && DH > 0 && MODE != MODE_HIL
 			v[k]     = O::mk (cur[k], cur[8 + k]);
 			v[8 + k] = O::mk (0.f, 0.f);
 		}
-#if PROT_PREFETCH_AT == 0
-		// next block's frames: requested a whole iteration ahead of their use
-		if (it + 1 < n_it) {
-			load_blocks (sP + HOP - Dc, sQ + HOP - Dc);
-		}
-		__builtin_amdgcn_sched_barrier (0);
-#endif
 		// spectrum tables, 4 bins (8 reads) per batch, one batch in flight ahead of the multiplies
 		typedef PROT_LDS_PTR (T) VC;
 		C    hb[2][8];
@@ -1023,13 +877,11 @@ __global__ __launch_bounds__ (256, (T::kWaves == 3 && DH > 0 && MODE != MODE_HIL
 			__builtin_amdgcn_sched_barrier (0);
 		}
 
-#if PROT_PREFETCH_AT != 0
 		__builtin_amdgcn_sched_barrier (0);
 		if (it + 1 < n_it) {
 			load_blocks (sP + HOP - Dc, sQ + HOP - Dc);
 		}
 		__builtin_amdgcn_sched_barrier (0);
-#endif
 
 		// dry path: from registers ((dry_delay - conv_delay) = 256 * DH frames back) or, for
 		// larger delays, re-read from the stream (L2/MALL)
@@ -1113,34 +965,9 @@ __global__ __launch_bounds__ (256, (T::kWaves == 3 && DH > 0 && MODE != MODE_HIL
 			}
 		}
 	}
-#ifdef PROT_CLOCKDBG
-	if (t == 0) { // debug build only: per-workgroup timeline into the first output frames (4 words each)
-		const uint64_t dc = __builtin_readcyclecounter () - dbg_c0, r1t = __builtin_amdgcn_s_memrealtime ();
-		uint32_t* d = reinterpret_cast<uint32_t*> (p.out) + 4 * blockIdx.x;
-		d[0] = (uint32_t)dc;
-		d[1] = (uint32_t)dbg_r0;
-		d[2] = (uint32_t)r1t;
-		d[3] = __builtin_amdgcn_s_getreg ((31 << 11) | 4) | (__builtin_amdgcn_s_getreg ((3 << 11) | 20) << 28); // HW_ID, XCC_ID
-	}
-#endif
 	hist_write_slice (p, blockIdx.y, threadIdx.x);
 }
 
-// PROT_TUNING builds only (tools/ab_build.py): PROT_DBG_DYNLDS = bytes of dynamic LDS added to every OLA launch, to
-// take resident workgroups away from a CU without touching the code
-static unsigned dbg_dyn_lds ()
-{
-#ifdef PROT_TUNING
-	static int v = -1;
-	if (v < 0) {
-		const char* e = getenv ("PROT_DBG_DYNLDS");
-		v             = e ? atoi (e) : 0;
-	}
-	return (unsigned)v;
-#else
-	return 0;
-#endif
-}
 
 template <class T, int MODE>
 static hipError_t launch_p2_m (const OlaParamsT<typename T::samp>& p, dim3 grid, hipStream_t s)
@@ -1236,11 +1063,7 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 
 	__shared__ C lds[kLdsRegion];
 	__shared__ C twm[256];
-#if PROT_PROBE4 // timing probe only (wrong results): the spectrum table shrunk so that four workgroups fit a CU
-	__shared__ C Hs[NP][64];
-#else
 	__shared__ C Hs[NP][2049];
-#endif
 
 	const int     t  = threadIdx.x;
 	const int     c  = blockIdx.y;
@@ -1259,11 +1082,9 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 	// version of this comment quoted came from a stamped diagnostic build whose end-of-kernel atomics queued on one
 	// cache line; the timeline-only build shows the XCDs within +-3 %, tools/xcd_timeline.py.)
 	int bx = (int)blockIdx.x;
-#if PROT_XCD_ROTATE
 	if ((bx | 7) < (int)gridDim.x) {
 		bx = (bx & ~7) | ((bx + (bx >> 3)) & 7);
 	}
-#endif
 	int64_t r0, rlen = p.run_frames;
 	if (p.rank_cu > 0) {
 		const int id = (int)blockIdx.y * (int)gridDim.x + bx, id0 = (int)blockIdx.y * (int)gridDim.x;
@@ -1318,13 +1139,10 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 #pragma unroll
 		for (int pp = 0; pp < NP; ++pp) {
 			const f2 hv = reinterpret_cast<const f2*> (p.H)[pp * 4096 + i];
-			Hs[pp][PROT_PROBE4 ? (j & 63) : j] = O::mk (hv.x, hv.y);
+			Hs[pp][j] = O::mk (hv.x, hv.y);
 		}
 	}
 	};
-#if !PROT_TABLES_LATE
-	setup_tables ();
-#endif
 	float ca = 0.f, sa = 1.f;
 	if (MODE == MODE_ROT) {
 		ca = p.rot ? p.rot[2 * c] : p.rot_v[2 * c];
@@ -1380,11 +1198,7 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 				const PROT_GLOBAL S* __restrict__ b = uniform_ptr (in + a0 + 1024 * m);
 #pragma unroll
 				for (int e = 0; e < 2; ++e) {
-#if PROT_NT_LOAD
-					nxqc[2 * m + e] = to_f2 (__builtin_nontemporal_load (&reinterpret_cast<const PROT_GLOBAL C*> (b)[(unsigned)t + 256u * e]));
-#else
 					nxqc[2 * m + e] = to_f2 (reinterpret_cast<const PROT_GLOBAL C*> (b)[(unsigned)t + 256u * e]);
-#endif
 				}
 			}
 			const PROT_GLOBAL S* __restrict__ b = uniform_ptr (in + a0 - 1);
@@ -1410,9 +1224,7 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 		}
 	};
 	load_block (s - Dc, t);
-#if PROT_TABLES_LATE
 	setup_tables ();
-#endif
 	__syncthreads ();
 	Stamps st;
 	st.start ();
@@ -1427,9 +1239,7 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 		// for the whole run; recomputed in place they fold into immediate offsets or stay inside their rare branch
 		int t = t0;
 		asm volatile ("" : "+v"(t));
-#if PROT_T_MASK
 		t &= 255; // known range again: stream addresses become SGPR base + 32-bit lane offset + immediate (no 64-bit lane arithmetic)
-#endif
 		const int tl = t & 15, th = t >> 4;
 		C  v[16];
 		f2 cur[HS];
@@ -1456,31 +1266,15 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 				const int idx = k < 8 ? t + 256 * k : 256 * (15 - k) + mq;
 #pragma unroll
 				for (int pp = 0; pp < NP; ++pp) {
-					hb[j & 1][pp * HB + i] = ((const VC*)Hs[pp])[PROT_PROBE4 ? (idx & 63) : idx];
+					hb[j & 1][pp * HB + i] = ((const VC*)Hs[pp])[idx];
 				}
 			}
 		};
-#if PROT_PREFETCH_EARLY == 2
-		if (LEAN && it + 1 < n_it) {
-			load_block (((PROT_ABL2 & 128) ? r0 : s + BLK) - Dc, t);
-		}
-#endif
 		st.tick (0);
 		fwd4096w<T, HS, LEAN> (v, lds, twm, tw1, t, tl, th, [&] () { if (!(PROT_ABL2 & 16)) h_fetch (0); }, st, [&] () {
-#if PROT_PREFETCH_EARLY == 1
 			if (LEAN && it + 1 < n_it) { // the next block's frames go out right behind the first barrier: three quarters of an iteration ahead
 				load_block (((PROT_ABL2 & 128) ? r0 : s + BLK) - Dc, t);
 			}
-#if PROT_PREFETCH_ELSE
-			else if (LEAN) { // nothing carried over from the block just consumed: no copies in front of the branch
-#pragma unroll
-				for (int k = 0; k < HS; ++k) {
-					asm volatile ("" : "=v"(nxqc[k].x), "=v"(nxqc[k].y)); // "some value": no instruction
-				}
-				asm volatile ("" : "=v"(nxg));
-			}
-#endif
-#endif
 		});
 
 		// Y = Z G0 (+ Z_prev G1); bins >= 2048 use the conjugate of the mirrored bin
@@ -1518,19 +1312,10 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 
 		st.tick (5);
 		__builtin_amdgcn_sched_barrier (0);
-		if (!(LEAN && PROT_PREFETCH_EARLY)) {
+		if (!LEAN) {
 			if (it + 1 < n_it) {
 				load_block (((PROT_ABL2 & 128) ? r0 : s + BLK) - Dc, t);
 			}
-#if PROT_PREFETCH_ELSE
-			else {
-#pragma unroll
-				for (int k = 0; k < HS; ++k) {
-					asm volatile ("" : "=v"(nxqc[k].x), "=v"(nxqc[k].y));
-				}
-				asm volatile ("" : "=v"(nxg));
-			}
-#endif
 		}
 		__builtin_amdgcn_sched_barrier (0);
 
@@ -1584,12 +1369,11 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 			acc[k] = to_f2 (v[HS + k]);
 		}
 
-#if PROT_WAIT_BEFORE_STORES
 		// The prefetched block (issued three quarters of an iteration ago: long here) is waited for IN FRONT of the stores.
 		// vmcnt retires in order, so a wait for those loads placed behind the stores -- where the next iteration first
 		// reads them -- is a wait for the stores too (s_waitcnt vmcnt(0) at the loop end: every iteration then ends with a
 		// full write round trip).  Waited for here, the stores drain under the next block's forward transform.
-		if (!ACC || (LEAN && PROT_PREFETCH_EARLY)) {
+		if (!ACC || LEAN) {
 #pragma unroll
 			for (int k = 0; k < HS; ++k) {
 				asm volatile ("" : "+v"(nxqc[k].x), "+v"(nxqc[k].y));
@@ -1597,7 +1381,6 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 			asm volatile ("" : "+v"(nxg));
 			__builtin_amdgcn_sched_barrier (0);
 		}
-#endif
 		if (it >= NP) {
 			const bool full = s + BLK <= r1;
 			if (MODE == MODE_ROT && !ACC && full && out_al8 && !(PROT_ABL2 & 64)) {
@@ -1607,11 +1390,7 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 					PROT_GLOBAL C* __restrict__ ob = reinterpret_cast<PROT_GLOBAL C*> (uniform_ptr (out + ((PROT_ABL2 & 128) ? r0 : s) + 1024 * m));
 #pragma unroll
 					for (int e = 0; e < 2; ++e) {
-#if PROT_NT_STORE
-						__builtin_nontemporal_store (to_sp (ca2 * dry[2 * m + e] + sa2 * u[2 * m + e]), &ob[(unsigned)t + 256u * e]);
-#else
 						ob[(unsigned)t + 256u * e] = to_sp (ca2 * dry[2 * m + e] + sa2 * u[2 * m + e]);
-#endif
 					}
 				}
 			} else if (MODE == MODE_ROT && ACC && full && out_al8 && !(PROT_ABL2 & 64)) {
@@ -1711,16 +1490,16 @@ static hipError_t launch_poly_m (const OlaParamsT<typename T::samp>& p, dim3 gri
 	// partitions) -- the launch bounds say the same, so that a register count beyond that budget is a compile-time spill
 	// report (tools/kernel_resources.py) instead of a silently two-round launch
 	constexpr int WPS = sizeof (typename T::samp) == 2 ? (NP == 1 ? 4 : 3)
-	                  : (NP == 1 && !(MODE == MODE_RAMP && HS >= 12)) ? (PROT_PROBE4 ? 4 : 3) : 2;
+	                  : (NP == 1 && !(MODE == MODE_RAMP && HS >= 12)) ? 3 : 2;
 	const dim3 block (256);
 	if (p.accumulate) {
-		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, 0, true, WPS>), grid, block, dbg_dyn_lds (), s, p);
+		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, 0, true, WPS>), grid, block, 0, s, p);
 	} else if (MODE != MODE_HILBERT && dd == DHS) {
-		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, DHS, false, WPS>), grid, block, dbg_dyn_lds (), s, p);
+		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, DHS, false, WPS>), grid, block, 0, s, p);
 	} else {
 		// (dry frames re-read from the stream: with 10 or more rows per block that form does not fit 168 VGPRs)
 		constexpr int WPS0 = (HS >= 10 && MODE != MODE_HILBERT) ? 2 : WPS;
-		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, 0, false, WPS0>), grid, block, dbg_dyn_lds (), s, p);
+		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, 0, false, WPS0>), grid, block, 0, s, p);
 	}
 	return hipGetLastError ();
 }
@@ -1778,56 +1557,25 @@ hipError_t launch_ola_poly_f16 (const OlaParamsH& p, int n_part, int hop_rows, i
 	}
 }
 
-// PROT_ABLATIONS builds only (tools/ab_build.py ...:-DPROT_ABLATIONS=1): PROT_OLA_VARIANT selects timing variants of
-// ola4096_kernel that leave out parts of the work -- their results are WRONG by design, and none of them exists in
-// the shipped library
-#ifdef PROT_ABLATIONS
-static int ola_variant ()
-{
-	static int v = -1;
-	if (v < 0) {
-		const char* e = getenv ("PROT_OLA_VARIANT");
-		v             = e ? atoi (e) : 0;
-	}
-	return v;
-}
-#endif
-
 template <int HOPSEG, int MODE>
 static hipError_t launch_ola4096_m (const OlaParams& p, dim3 grid, hipStream_t s)
 {
 	dim3 block (256);
 	if (p.accumulate) {
-		hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, true>), grid, block, dbg_dyn_lds (), s, p);
+		hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, true>), grid, block, 0, s, p);
 		return hipGetLastError ();
 	}
-#ifdef PROT_ABLATIONS
-	switch (ola_variant ()) {
-		case 0: break;
-		case 1: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE>), grid, block, 0, s, p); return hipGetLastError (); // global dry loads
-		case 3: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, false, 0, false>), grid, block, 0, s, p); return hipGetLastError (); // scalar butterflies
-		case 11: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 1>), grid, block, 0, s, p); return hipGetLastError ();
-		case 12: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 2>), grid, block, 0, s, p); return hipGetLastError ();
-		case 13: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 3>), grid, block, 0, s, p); return hipGetLastError ();
-		case 18: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 8>), grid, block, 0, s, p); return hipGetLastError ();
-		case 19: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 9>), grid, block, 0, s, p); return hipGetLastError ();
-		case 20: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 10>), grid, block, 0, s, p); return hipGetLastError ();
-		case 21: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 11>), grid, block, 0, s, p); return hipGetLastError ();
-		case 25: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 15>), grid, block, 0, s, p); return hipGetLastError ();
-		default: break;
-	}
-#endif
 	// dry path from registers when the delay difference is a small multiple of 256 frames
 	const int dd = p.dry_delay - p.conv_delay;
 	if (MODE != MODE_HILBERT && dd > 0 && dd % 256 == 0) {
 		switch (dd / 256) {
-			case 2: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, false, 2>), grid, block, dbg_dyn_lds (), s, p); return hipGetLastError ();
-			case 4: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, false, 4>), grid, block, dbg_dyn_lds (), s, p); return hipGetLastError ();
-			case 6: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, 0, false, 6>), grid, block, dbg_dyn_lds (), s, p); return hipGetLastError ();
+			case 2: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, false, 2>), grid, block, 0, s, p); return hipGetLastError ();
+			case 4: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, false, 4>), grid, block, 0, s, p); return hipGetLastError ();
+			case 6: hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE, false, 6>), grid, block, 0, s, p); return hipGetLastError ();
 			default: break;
 		}
 	}
-	hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE>), grid, block, dbg_dyn_lds (), s, p);
+	hipLaunchKernelGGL ((ola4096_kernel<HOPSEG, 1, 3, MODE>), grid, block, 0, s, p);
 	return hipGetLastError ();
 }
 
