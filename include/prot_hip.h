@@ -69,6 +69,14 @@ typedef struct {
  * spectrum table (olapoly_kernel, three workgroups per CU) instead of the overlap-SAVE, table-free form
  * (olasave_kernel, four per CU).  Same filter; kept for cross-checks. */
 #define PROT_CFG_OVERLAP_ADD 8u
+/* Pipelined stateful launches (overlap-save engines only; ignored by the others): consecutive prot_apply_dev calls with
+ * stream == NULL, steady rotation and history rotate over three streams of the engine and overlap on the device --
+ * launch k + 1 needs nothing of launch k but the history, which the kernel hands over on the device.  For callers that
+ * issue many short launches back to back (BASELINE config 3: 256 x 1024-frame buffers per launch).  Same results bit for
+ * bit.  Outputs are complete after prot_engine_sync (or any later call on the engine, which is ordered behind them);
+ * the caller must not reuse an input or output buffer of a launch before that.  PROT_PIPELINE=1 / =0 in the
+ * environment forces it on / off. */
+#define PROT_CFG_PIPELINE 16u
 
 typedef struct {
 	int32_t  kind;

@@ -27,6 +27,7 @@ CFG_SINGLE_FFT_PER_HOP = 1
 CFG_DIRECT_FORM = 2
 CFG_POLYPHASE = 4
 CFG_OVERLAP_ADD = 8
+CFG_PIPELINE = 16
 FORM_DIRECT, FORM_POLY_OLA, FORM_POLY_SAVE = 0, 1, 2
 
 # every symbol include/prot_hip.h declares (tests check the .so exports them all)

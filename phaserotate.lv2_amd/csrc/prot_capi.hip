@@ -327,7 +327,8 @@ struct prot_engine {
 	float          sv_gain = 0.f;
 	int            sv_rows = 0;
 	int            sv_flags = 0; // 1 (PROT_SV_NOASM at creation, tests): every block through the C++ form of olasave_kernel
-	DevBuf<float>  d_lut, d_rot, d_hist[2], d_peaks, d_in, d_out, d_u, d_inter, d_rot_s;
+	static constexpr int kPipe = 3, kHist = kPipe + 1; // pipelined launches in flight; history ring (one more)
+	DevBuf<float>  d_lut, d_rot, d_hist[kHist], d_peaks, d_in, d_out, d_u, d_inter, d_rot_s;
 	// whole-file calls: two sets of staging buffers, a copy stream and events, so that chunk k+1 is uploaded and
 	// de-interleaved while chunk k is swept (cli/phase-rotate.cc:565-587 reads and analyses block by block)
 	DevBuf<float>  d_inter_b, d_in_b;
@@ -348,7 +349,16 @@ struct prot_engine {
 	PinBuf<char>   h_slots;
 	hipEvent_t     slot_ev[kSlots] = {};
 	int            slot_next = 0;
-	int            hist_cur = 0;
+	int            hist_cur = 0; // ring: a call reads [cur] and writes [(cur + 1) % kHist]
+	// PROT_CFG_PIPELINE: stateful prot_apply_dev calls on the engine's own streams rotate over kPipe of them and hand
+	// the history over on the device (prot_olasave.hip); everything else joins them first (join_pipe)
+	bool           pipeline   = false;
+	hipStream_t    pipe_stream[kPipe] = {};
+	hipEvent_t     pipe_ev[kPipe + 1] = {};
+	DevBuf<uint32_t> d_pipe;      // [0..7] generation g's history is complete when slot g & 7 holds g; [8..11] slice counters
+	uint32_t       pipe_gen   = 0;    // pipelined launches so far (= the value the last one publishes)
+	uint32_t       pipe_q     = 0;    // ... since the last join (stream and counter of the next one)
+	bool           pipe_dirty = false; // work may be in flight on the pipe streams
 	uint64_t       pos      = 0; // frames consumed since reset (CLI stream position)
 	int            pairs_per_run_override = 0;
 	int            wg_slots = 768; // resident OLA workgroups on the device (CUs x 3)
@@ -369,8 +379,9 @@ namespace {
 int zero_state (prot_engine* e)
 {
 	const size_t hn = (size_t)e->info.history * e->info.n_chn;
-	HIP_TRY (hipMemsetAsync (e->d_hist[0].p, 0, hn * sizeof (float), e->stream));
-	HIP_TRY (hipMemsetAsync (e->d_hist[1].p, 0, hn * sizeof (float), e->stream));
+	for (int i = 0; i < prot_engine::kHist; ++i) {
+		HIP_TRY (hipMemsetAsync (e->d_hist[i].p, 0, hn * sizeof (float), e->stream));
+	}
 	HIP_TRY (hipMemsetAsync (e->d_peaks.p, 0, (size_t)PROT_MAXSAMPLE * e->info.n_chn * sizeof (float), e->stream));
 	HIP_TRY (hipMemsetAsync (e->d_stats.p, 0, 4 * sizeof (unsigned long long), e->stream));
 	if (e->d_hist16[0].p) {
@@ -532,9 +543,15 @@ void rank_runs (P& p, int64_t blk, int n_chn, uint64_t n_out, int slots, int cus
 int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_in, float* d_out,
                 int64_t out_stride, uint64_t n_out, const float* d_rot, const float* d_rot_s,
                 bool hilbert_only, bool stateless, int chn0, int n_chn, hipStream_t s, bool advance_hist = false,
-                const float* h_rot = nullptr)
+                const float* h_rot = nullptr, const uint32_t* pipe_wait_post = nullptr)
 {
 	prot::OlaParams p {};
+	if (pipe_wait_post) { // pipelined stateful launch (prot_apply_dev): history handed over on the device
+		p.hs_flag = e->d_pipe.p;
+		p.hs_cnt  = e->d_pipe.p + 8 + (pipe_wait_post[1] & 3u);
+		p.hs_wait = pipe_wait_post[0];
+		p.hs_post = pipe_wait_post[1];
+	}
 	if (h_rot) { // steady rotation of up to kRotInline channels: by value in the kernel arguments (d_rot == nullptr)
 		memcpy (p.rot_v, h_rot + 2 * chn0, 2 * sizeof (float) * (size_t)std::min (n_chn, prot::kRotInline));
 	}
@@ -546,7 +563,7 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 	// all channels, something to launch: the first OLA launch also writes the next call's history
 	// (other buffer of the pair) and the separate history kernel is skipped
 	const bool fuse_hist = advance_hist && !stateless && n_out > 0 && chn0 == 0 && n_chn == (int)e->info.n_chn;
-	p.hist_out     = fuse_hist ? e->d_hist[1 - e->hist_cur].p : nullptr;
+	p.hist_out     = fuse_hist ? e->d_hist[(e->hist_cur + 1) % prot_engine::kHist].p : nullptr;
 	p.out          = d_out + (int64_t)chn0 * out_stride;
 	p.out_stride   = out_stride;
 	p.n_out        = (int64_t)n_out;
@@ -562,7 +579,7 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 			return PROT_OK;
 		}
 		if (fuse_hist) {
-			e->hist_cur = 1 - e->hist_cur;
+			e->hist_cur = (e->hist_cur + 1) % prot_engine::kHist;
 			return PROT_OK;
 		}
 		return hist_advance (e, d_in, in_stride, n_in, chn0, n_chn, s);
@@ -646,7 +663,7 @@ int hist_advance (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t
 	const int    H   = (int)e->info.history;
 	const int    cur = e->hist_cur;
 	const float* hin = e->d_hist[cur].p;
-	float*       hout = e->d_hist[1 - cur].p;
+	float*       hout = e->d_hist[(cur + 1) % prot_engine::kHist].p;
 	if (n_chn != (int)e->info.n_chn) {
 		// untouched channels keep their history: carry it over to the other buffer
 		HIP_TRY (hipMemcpyAsync (hout, hin, (size_t)H * e->info.n_chn * sizeof (float),
@@ -657,7 +674,7 @@ int hist_advance (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t
 	if (err != hipSuccess) {
 		return hip_fail (err, "hist update launch");
 	}
-	e->hist_cur = 1 - cur;
+	e->hist_cur = (cur + 1) % prot_engine::kHist;
 	return PROT_OK;
 }
 
@@ -699,9 +716,30 @@ int lv2_reserve (prot_engine* e, uint32_t frames)
 	return PROT_OK;
 }
 
+// pipelined launches in flight: everything that follows on stream s is ordered behind them
+int join_pipe (prot_engine* e, hipStream_t s)
+{
+	if (e->pipe_dirty) {
+		for (int i = 0; i < prot_engine::kPipe; ++i) {
+			HIP_TRY (hipEventRecord (e->pipe_ev[i], e->pipe_stream[i]));
+			if (s != e->pipe_stream[i]) {
+				HIP_TRY (hipStreamWaitEvent (s, e->pipe_ev[i], 0));
+			}
+			if (s != e->stream && e->stream != e->pipe_stream[i]) {
+				HIP_TRY (hipStreamWaitEvent (e->stream, e->pipe_ev[i], 0));
+			}
+		}
+		e->pipe_dirty = false;
+		e->pipe_q     = 0;
+	}
+	return PROT_OK;
+}
+
 hipStream_t pick_stream (prot_engine* e, void* stream)
 {
-	return stream ? (hipStream_t)stream : e->stream;
+	hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+	(void)join_pipe (e, s);
+	return s;
 }
 
 // copy a small host array to device memory in stream order without keeping a reference to `src`
@@ -982,6 +1020,24 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 			e->wg_slots = e->cus * 4; // 128 VGPRs, 38 KiB of LDS
 		}
 	}
+	const char* pipe_env = getenv ("PROT_PIPELINE");
+	if (e->use_save && ((cfg->flags & PROT_CFG_PIPELINE) || (pipe_env && atoi (pipe_env) != 0)) && !(pipe_env && atoi (pipe_env) == 0)) {
+		// consecutive stateful prot_apply_dev calls on the engine's own streams overlap
+		bool ok = e->d_pipe.ensure (12) == PROT_OK && hipMemset (e->d_pipe.p, 0, 12 * sizeof (uint32_t)) == hipSuccess;
+		// (the engine's main stream is one of the three: the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware
+		// queues, 4 by default, and two pipe streams that share a queue do not overlap -- 10 us per launch instead of 5.5)
+		e->pipe_stream[0] = e->stream;
+		for (int i = 1; ok && i < prot_engine::kPipe; ++i) {
+			ok = hipStreamCreateWithFlags (&e->pipe_stream[i], hipStreamNonBlocking) == hipSuccess;
+		}
+		for (int i = 0; ok && i <= prot_engine::kPipe; ++i) {
+			ok = hipEventCreateWithFlags (&e->pipe_ev[i], hipEventDisableTiming) == hipSuccess;
+		}
+		if (!ok) {
+			return fail (PROT_EHIP);
+		}
+		e->pipeline = true;
+	}
 	if (use_poly) {
 		std::vector<float> g (inf.firlen / 2);
 		for (size_t i = 0; i < g.size (); ++i) {
@@ -1002,7 +1058,7 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	for (uint32_t i = 0; poly_taps_ok && i < inf.firlen; i += 2) {
 		poly_taps_ok = fir_taps[i] == 0.f;
 	}
-	if (use_p2 && !use_poly && inf.firlen == F && poly_taps_ok && cfg->flags == 0 && getenv ("PROT_NO_POLY") == nullptr) {
+	if (use_p2 && !use_poly && inf.firlen == F && poly_taps_ok && (cfg->flags & ~PROT_CFG_PIPELINE) == 0 && getenv ("PROT_NO_POLY") == nullptr) {
 		std::vector<float> g (inf.firlen / 2);
 		for (size_t i = 0; i < g.size (); ++i) {
 			g[i] = fir_taps[2 * i + 1];
@@ -1017,7 +1073,7 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	int rc;
 	if ((rc = e->d_H.ensure ((size_t)F * n_part)) ||
 	    (!Hp_h.empty () && (rc = e->d_Hp.ensure (Hp_h.size ()))) || (rc = e->d_tw.ensure (F)) || (rc = e->d_lut.ensure (PROT_MAXSAMPLE * 2)) ||
-	    (rc = e->d_rot.ensure (2 * (size_t)inf.n_chn)) || (rc = e->d_hist[0].ensure (hn)) ||
+	    (rc = e->d_rot.ensure (2 * (size_t)inf.n_chn)) || (rc = e->d_hist[0].ensure (hn)) || (rc = e->d_hist[2].ensure (hn)) || (rc = e->d_hist[3].ensure (hn)) ||
 	    (use_poly && n_part <= 2 && ((rc = e->d_hist16[0].ensure (hn)) || (rc = e->d_hist16[1].ensure (hn)))) ||
 	    (rc = e->d_hist[1].ensure (hn)) || (rc = e->d_peaks.ensure ((size_t)PROT_MAXSAMPLE * inf.n_chn)) ||
 	    (rc = e->d_angles.ensure (PROT_MAXSAMPLE + 8)) || (rc = e->d_thr.ensure (4 * (size_t)inf.n_chn)) ||
@@ -1068,6 +1124,11 @@ void prot_engine_destroy (prot_engine* e)
 		return;
 	}
 	(void)hipSetDevice (e->device);
+	for (int i = 0; i < prot_engine::kPipe; ++i) {
+		if (e->pipe_stream[i]) {
+			(void)hipStreamSynchronize (e->pipe_stream[i]);
+		}
+	}
 	if (e->stream) {
 		(void)hipStreamSynchronize (e->stream);
 	}
@@ -1079,6 +1140,8 @@ void prot_engine_destroy (prot_engine* e)
 	e->d_rot.release ();
 	e->d_hist[0].release ();
 	e->d_hist[1].release ();
+	e->d_hist[2].release ();
+	e->d_hist[3].release ();
 	e->d_hist16[0].release ();
 	e->d_hist16[1].release ();
 	e->d_peaks.release ();
@@ -1110,6 +1173,17 @@ void prot_engine_destroy (prot_engine* e)
 			(void)hipEventDestroy (e->slot_ev[i]);
 		}
 	}
+	for (int i = 1; i < prot_engine::kPipe; ++i) { // ([0] is the main stream)
+		if (e->pipe_stream[i]) {
+			(void)hipStreamDestroy (e->pipe_stream[i]);
+		}
+	}
+	for (int i = 0; i <= prot_engine::kPipe; ++i) {
+		if (e->pipe_ev[i]) {
+			(void)hipEventDestroy (e->pipe_ev[i]);
+		}
+	}
+	e->d_pipe.release ();
 	if (e->stream) {
 		(void)hipStreamDestroy (e->stream);
 	}
@@ -1128,6 +1202,7 @@ int prot_engine_reset (prot_engine* e)
 		return PROT_EINVAL;
 	}
 	HIP_TRY (hipSetDevice (e->device));
+	(void)join_pipe (e, e->stream);
 	int rc = zero_state (e);
 	if (rc) {
 		return rc;
@@ -1135,6 +1210,7 @@ int prot_engine_reset (prot_engine* e)
 	for (auto& c : e->lv2) { // channel_reset: offset = 0, buf_out = 0 (angle state kept, Q10)
 		c.offset = 0;
 	}
+	(void)join_pipe (e, e->stream);
 	HIP_TRY (hipStreamSynchronize (e->stream));
 	return PROT_OK;
 }
@@ -1163,6 +1239,7 @@ int prot_engine_sync (prot_engine* e)
 		return PROT_EINVAL;
 	}
 	HIP_TRY (hipSetDevice (e->device));
+	(void)join_pipe (e, e->stream);
 	HIP_TRY (hipStreamSynchronize (e->stream));
 	return PROT_OK;
 }
@@ -1179,9 +1256,38 @@ int prot_apply_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		return PROT_EINVAL;
 	}
 	HIP_TRY (hipSetDevice (e->device));
-	hipStream_t s = pick_stream (e, stream);
 	const int   nc = (int)e->info.n_chn;
 	const bool inl = rot && nc <= prot::kRotInline; // {ca, sa} per channel as kernel arguments: no copy in front of the launch
+	// Pipelined route (PROT_CFG_PIPELINE engines, the engine's own streams): a stateful launch needs nothing of the launch
+	// before it but the history, i.e. the tail of that launch's INPUT -- so consecutive launches rotate over three
+	// streams and the kernel hands the history over on the device (prot_olasave.hip).  Only launches that are small against
+	// the device (a waiting workgroup must never hold a slot the launch it waits for needs) and long enough that the new
+	// history is a plain copy of input frames; everything else joins the two streams first (pick_stream).
+	if (e->pipeline && stream == nullptr && inl && !(flags & (PROT_F_STATELESS | PROT_F_HILBERT)) && n_out > 0 && n_out <= n_in &&
+	    n_in >= e->info.history &&
+	    ((int64_t)n_out + e->info.run_align - 1) / (int64_t)e->info.run_align * nc <= e->wg_slots / (2 * prot_engine::kPipe)) {
+		hipStream_t ps = e->pipe_stream[e->pipe_q % prot_engine::kPipe];
+		uint32_t    wp[2];
+		if (!e->pipe_dirty) { // first of a series: behind whatever the engine's stream holds; its history came by stream order
+			HIP_TRY (hipEventRecord (e->pipe_ev[prot_engine::kPipe], e->stream));
+			for (int i = 1; i < prot_engine::kPipe; ++i) {
+				HIP_TRY (hipStreamWaitEvent (e->pipe_stream[i], e->pipe_ev[prot_engine::kPipe], 0));
+			}
+			wp[0] = 0;
+		} else {
+			wp[0] = e->pipe_gen; // what the launch before this one publishes
+		}
+		wp[1]         = ++e->pipe_gen;
+		e->pipe_dirty = true;
+		e->pipe_q++;
+		int rc = ola_launch (e, d_in, in_stride, n_in, d_out, out_stride, n_out, nullptr, nullptr, false, false, 0, nc, ps,
+		                     /*advance_hist*/ true, rot, wp);
+		if (rc == PROT_OK) {
+			e->pos += n_in;
+		}
+		return rc;
+	}
+	hipStream_t s = pick_stream (e, stream);
 	if (rot && !inl) {
 		int rcs = stage_small (e, e->d_rot.p, rot, 2 * (size_t)nc * sizeof (float), s);
 		if (rcs) {
@@ -1383,7 +1489,7 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 	if (rc) {
 		return rc;
 	}
-	const float* hist_old = e->d_hist[e->hist_cur].p; // stays intact: history is double-buffered
+	const float* hist_old = e->d_hist[e->hist_cur].p; // stays intact: the launch writes the next buffer of the ring
 	rc = ola_launch (e, d_in, in_stride, n_frames, e->d_u.p, (int64_t)ustride, n_out, nullptr, nullptr, true,
 	                 false, c0, nc, s);
 	if (rc) {
@@ -1448,7 +1554,7 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		const int    H    = (int)e->info.history;
 		const int    cur  = e->hist_cur;
 		const float* hin  = e->d_hist[cur].p;
-		float*       hout = e->d_hist[1 - cur].p;
+		float*       hout = e->d_hist[(cur + 1) % prot_engine::kHist].p;
 		if (nc != (int)e->info.n_chn) {
 			HIP_TRY (hipMemcpyAsync (hout, hin, (size_t)H * e->info.n_chn * sizeof (float), hipMemcpyDeviceToDevice, s));
 		}
@@ -1460,7 +1566,7 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 			}
 			HIP_TRY (hipMemsetAsync (hout + (size_t)c * H + keep, 0, ((size_t)H - keep) * sizeof (float), s));
 		}
-		e->hist_cur = 1 - cur;
+		e->hist_cur = (cur + 1) % prot_engine::kHist;
 	}
 	e->pos += n_out;
 	return PROT_OK;
@@ -1477,6 +1583,7 @@ int prot_sweep_stats_ex (prot_engine* e, uint64_t out[4])
 		return PROT_EINVAL;
 	}
 	HIP_TRY (hipSetDevice (e->device));
+	(void)join_pipe (e, e->stream);
 	HIP_TRY (hipStreamSynchronize (e->stream));
 	unsigned long long h[4] = { 0, 0, 0, 0 };
 	HIP_TRY (hipMemcpy (h, e->d_stats.p, sizeof (h), hipMemcpyDeviceToHost));
@@ -1506,6 +1613,7 @@ int prot_cli_peaks (prot_engine* e, float* out)
 		return PROT_EINVAL;
 	}
 	HIP_TRY (hipSetDevice (e->device));
+	(void)join_pipe (e, e->stream);
 	HIP_TRY (hipStreamSynchronize (e->stream));
 	HIP_TRY (hipMemcpy (out, e->d_peaks.p, (size_t)PROT_MAXSAMPLE * e->info.n_chn * sizeof (float), hipMemcpyDeviceToHost));
 	return PROT_OK;
@@ -1563,6 +1671,7 @@ int prot_lv2_set_max_block (prot_engine* e, uint32_t frames)
 		return PROT_EINVAL;
 	}
 	HIP_TRY (hipSetDevice (e->device));
+	(void)join_pipe (e, e->stream);
 	HIP_TRY (hipStreamSynchronize (e->stream));
 	return lv2_reserve (e, frames);
 }
@@ -1574,7 +1683,7 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 	const uint32_t nc = e->info.n_chn;
 	const uint32_t P  = e->info.blksiz;
 	const size_t   n  = n_samples;
-	hipStream_t    s  = e->stream;
+	hipStream_t    s  = pick_stream (e, nullptr);
 
 	int rc;
 	// Zero-copy (default): the kernels read the input, the per-frame rotation and write the output
@@ -1750,7 +1859,7 @@ int prot_cli_apply (prot_engine* e, float* buf, const int* angles)
 	HIP_TRY (hipSetDevice (e->device));
 	const uint32_t nc = e->info.n_chn;
 	const size_t   P  = e->info.blksiz;
-	hipStream_t    s  = e->stream;
+	hipStream_t    s  = pick_stream (e, nullptr);
 	int rc;
 	if ((rc = e->d_inter.ensure (P * nc)) || (rc = e->d_in.ensure (P * nc)) || (rc = e->d_out.ensure (P * nc))) {
 		return rc;
@@ -1788,7 +1897,7 @@ int prot_cli_analyze (prot_engine* e, const float* buf, int ang_start, int ang_e
 	HIP_TRY (hipSetDevice (e->device));
 	const uint32_t nc = e->info.n_chn;
 	const size_t   P  = e->info.blksiz;
-	hipStream_t    s  = e->stream;
+	hipStream_t    s  = pick_stream (e, nullptr);
 	int rc;
 	if ((rc = e->d_inter.ensure (P * nc)) || (rc = e->d_in.ensure (P * nc))) {
 		return rc;
@@ -1816,7 +1925,7 @@ int prot_cli_analyze_file (prot_engine* e, const float* data, uint64_t n_frames,
 	HIP_TRY (hipSetDevice (e->device));
 	const uint32_t nc = e->info.n_chn;
 	const uint64_t P  = e->info.blksiz;
-	hipStream_t    s  = e->stream;
+	hipStream_t    s  = pick_stream (e, nullptr);
 	(void)nc;
 	(void)P;
 	(void)s;
@@ -1851,7 +1960,7 @@ static int analyze_range_impl (prot_engine* e, const float* data, uint64_t f0, u
 {
 	HIP_TRY (hipSetDevice (e->device));
 	const uint32_t nc = e->info.n_chn;
-	hipStream_t    s  = e->stream;
+	hipStream_t    s  = pick_stream (e, nullptr);
 	const uint64_t chunk = file_chunk_frames (e);
 	const uint64_t H     = e->info.history;
 	const uint64_t cap   = std::max<uint64_t> (std::min<uint64_t> (chunk, std::max<uint64_t> (nf, 1)), H);
@@ -2077,7 +2186,7 @@ int prot_cli_apply_file (prot_engine* e, const float* data, uint64_t n_frames, c
 	const uint32_t nc  = e->info.n_chn;
 	const uint64_t P   = e->info.blksiz;
 	const uint64_t lat = P / 2; // cli/phase-rotate.cc:963
-	hipStream_t    s   = e->stream;
+	hipStream_t    s   = pick_stream (e, nullptr);
 	const uint64_t chunk = file_chunk_frames (e);
 	const uint64_t cap   = std::min<uint64_t> (chunk, n_frames) + lat;
 	int rc;

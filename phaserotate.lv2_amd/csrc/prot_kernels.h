@@ -48,6 +48,17 @@ struct OlaParamsT {
 	const float*  sv;
 	float         sv_gain;
 	int32_t       sv_flags;   // 1: every block through the C++ form (cross-check of the generated loop)
+	// olasave_kernel, pipelined stateful launches (PROT_CFG_PIPELINE): consecutive launches run on different streams and hand
+	// the history over on the device.  hs_flag != NULL: every workgroup writes its history slice FIRST and counts it in
+	// *hs_cnt; the last one stores hs_post (this launch's generation) into hs_flag[hs_post & 7].  Workgroups that read
+	// history wait until hs_flag[hs_wait & 7] holds hs_wait (0: nothing to wait for -- the history they read was ordered
+	// by the stream).  One slot per generation, NOT one running maximum: with three streams launch g + 1 may publish before
+	// launch g - 1 has (its history write waits for nothing), and a reader of generation g - 1 must not mistake that for it;
+	// a slot is reused by generation g + 8, which cannot start before g is complete (stream order, and every launch's
+	// readers wait for the launch before it: the lead is 5 at most).
+	uint32_t*     hs_flag;
+	uint32_t*     hs_cnt;
+	uint32_t      hs_wait, hs_post;
 };
 typedef OlaParamsT<float>    OlaParams;
 typedef OlaParamsT<_Float16> OlaParamsH; // fp16 sample path (BASELINE config 5)

@@ -94,13 +94,57 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 	const uint64_t wg_t0 = __builtin_amdgcn_s_memrealtime ();
 	uint64_t       wg_a0 = 0, wg_a1 = 0;
 #endif
+	// Pipelined stateful launches: the next launch (on the engine's other stream, possibly running already) needs nothing
+	// of this one but the history, i.e. the tail of this launch's INPUT -- written first, counted, and published by the
+	// last workgroup to get there.  (The host takes this route only when n_in >= hist_len: the slice is then a plain copy
+	// of input frames and does not read the previous history.)
+	const bool piped = p.hs_flag != nullptr;
+	if (piped) {
+		// my slice of the next history: device-scope (write-through) stores, so that publishing it needs no release FENCE --
+		// at device scope that is a write-back of the XCD's whole L2, and with one per workgroup two overlapping launches
+		// took 28 us each instead of 11.7 (measured).  The stores are awaited (s_waitcnt: a write-through store is
+		// acknowledged by the memory side), then counted with a device-scope atomic; the last workgroup to count publishes.
+		{
+			const int per = (p.hist_len + (int)gridDim.x - 1) / (int)gridDim.x;
+			const int i0  = (int)blockIdx.x * per;
+			const int i1  = i0 + per < p.hist_len ? i0 + per : p.hist_len;
+			const float* __restrict__ src = p.in + (int64_t)blockIdx.y * p.in_stride + (p.n_in - p.hist_len);
+			float* __restrict__ ho        = p.hist_out + (int64_t)blockIdx.y * p.hist_len;
+			for (int i = i0 + t0; i < i1; i += 256) {
+				__hip_atomic_store (&ho[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+		// (a workgroup-scope release is no wait at all when the waves of a workgroup share their CU's cache: the count
+		// below would overtake the stores of the other waves)
+		asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads ();
+		if (t0 == 0) {
+			const unsigned total = gridDim.x * gridDim.y;
+			if (__hip_atomic_fetch_add (p.hs_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1u) {
+				__hip_atomic_store (p.hs_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store (p.hs_flag + (p.hs_post & 7u), p.hs_post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+	}
 	int64_t   r0, rlen;
 	run_of_workgroup (p, r0, rlen);
 	if (r0 >= p.n_out) {
-		hist_write_slice (p, blockIdx.y, threadIdx.x);
+		if (!piped) {
+			hist_write_slice (p, blockIdx.y, threadIdx.x);
+		}
 		return;
 	}
 	const int64_t r1 = (r0 + rlen < p.n_out) ? r0 + rlen : p.n_out;
+	if (piped && p.hs_wait != 0u && r0 - p.dry_delay - 512 * R0 < 1) {
+		// this run starts inside the history the previous launch is writing (or has written) on the other stream
+		if (t0 == 0) {
+			while (__hip_atomic_load (p.hs_flag + (p.hs_wait & 7u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.hs_wait) {
+				__builtin_amdgcn_s_sleep (8);
+			}
+		}
+		__syncthreads ();
+		__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");
+	}
 
 	const float* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
 	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
@@ -123,7 +167,20 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 	// the (x[a], x[a+1]) pair of thread t in the 512-frame row that starts at frame ar (a = ar + 2 t): a row lies wholly in the
 	// input array or wholly in the history (both start on row boundaries) -- aligned 8-byte loads; anything else (silence in
 	// reach, odd alignment) frame by frame through the virtual stream [history | input | silence]
-	const bool hist_al8 = hist != nullptr && (reinterpret_cast<uintptr_t> (hist) & 7) == 0 && (p.hist_len & 1) == 0;
+	// (a pipelined launch reads a history that another launch, possibly on another XCD, wrote while this one was already
+	// running: frame by frame with device-scope loads -- the aligned 8-byte route could hit a stale line of this XCD's L2,
+	// found as launch 5 of a series reading what launch 1 had read from the same buffer of the ring)
+	const bool hist_al8 = !piped && hist != nullptr && (reinterpret_cast<uintptr_t> (hist) & 7) == 0 && (p.hist_len & 1) == 0;
+	auto ldv = [&] (const float* in_, int64_t n_in_, const float* hist_, int hist_len_, int64_t i) -> float {
+		if (i >= 0) {
+			return i < n_in_ ? in_[i] : 0.f;
+		}
+		const int64_t h = i + hist_len_;
+		if (hist_ == nullptr || h < 0) {
+			return 0.f;
+		}
+		return piped ? __hip_atomic_load (const_cast<float*> (hist_) + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : hist_[h];
+	};
 	auto row_pair = [&] (int64_t ar, int t) -> f2 {
 		if (in_al8 && ar >= 0 && ar + 512 <= n_in) {
 			return reinterpret_cast<const f2*> (in + ar)[t];
@@ -239,7 +296,9 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 		g_sv_wg[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime ();
 	}
 #endif
-	hist_write_slice (p, blockIdx.y, threadIdx.x);
+	if (!piped) {
+		hist_write_slice (p, blockIdx.y, threadIdx.x);
+	}
 }
 
 template <int HS>

@@ -850,6 +850,49 @@ def test_cfg3_shape_against_oracle(pkg):
     e.close()
 
 
+@pytest.mark.parametrize("rate,per,n_launch", [(96000, 256 * 1024, 24), (48000, 64 * 1024, 40), (96000, 20480, 33)])
+def test_pipelined_launches_equal_sequential_ones(pkg, rate, per, n_launch):
+    """PROT_CFG_PIPELINE: stateful launches on the engine's own streams alternate between two streams and
+    hand the history over on the device.  N pipelined launches must equal N sequential ones bit for bit -- outputs AND the
+    state they leave (one more, sequential, call on both engines) --, also when other calls (a ramp call, a sync, a call on
+    a caller's stream) interrupt the series and force a join, and for launches too short to qualify (n_in < history)."""
+    import torch
+    dev = torch.device("cuda:0")
+    n_chn = 2
+    n = (n_launch + 3) * per
+    x = torch.from_numpy(xorshift_uniform(n_chn * n, seed=77).reshape(n_chn, n)).to(dev)
+    rot = np.array([0.6, 0.8, -0.28, 0.96], np.float32)
+    outs = []
+    for flags in (0, pkg.CFG_PIPELINE):
+        e = pkg.Engine(pkg.KIND_LV2, rate, n_chn, flags=flags)
+        assert e.info.form == pkg.FORM_POLY_SAVE
+        y = torch.zeros_like(x)
+        ts = torch.cuda.Stream()
+        for k in range(n_launch):
+            xin, yout = x[:, k * per:(k + 1) * per], y[:, k * per:(k + 1) * per]
+            if k == 9:      # a call on a caller's stream in the middle of the series: ordered behind it, and the series after it
+                e.apply_dev(xin.data_ptr(), n, per, yout.data_ptr(), n, per, rot, 0, ts.cuda_stream)
+                ts.synchronize()
+            elif k == 17:   # a short call (less input than the history is long) cannot take the pipelined route
+                h = per // 2 if per // 2 < e.info.history else 1000
+                e.apply_dev(xin.data_ptr(), n, h, yout.data_ptr(), n, h, rot, 0)
+                e.apply_dev(xin.data_ptr() + 4 * h, n, per - h, yout.data_ptr() + 4 * h, n, per - h, rot, 0)
+            else:
+                e.apply_dev(xin.data_ptr(), n, per, yout.data_ptr(), n, per, rot, 0)
+            if k == 5:
+                e.sync()
+        # the state the series leaves: one more call, per-frame rotation (never pipelined)
+        k = n_launch
+        rs = torch.from_numpy(np.tile(rot, (per, 1)).reshape(per, n_chn, 2).transpose(1, 0, 2).copy()).to(dev)
+        e.apply_dev_ramp(x[:, k * per:].data_ptr(), n, per, y[:, k * per:].data_ptr(), n, per, rs.data_ptr(), 0)
+        e.sync()
+        torch.cuda.synchronize()
+        outs.append(y.cpu().numpy())
+        e.close()
+    assert np.abs(outs[0][:, :(n_launch + 1) * per]).max() > 0.05
+    assert outs[0].tobytes() == outs[1].tobytes()
+
+
 @pytest.mark.parametrize("kind,param,chn,n", [(1, 48000, 1, 50_000_017), (1, 48000, 2, 33_333_333), (0, 2048, 1, (1 << 27) - 3),
                                               (0, 1024, 2, 40_000_001), (0, 8192, 1, 70_000_001), (1, 192000, 2, 40_000_003),
                                               (0, 16384, 1, 60_000_001)])
