@@ -243,14 +243,14 @@ float* prot_cli_peaks_dev (prot_engine* e);
 /* How much of the sweep the engine had to evaluate since the last reset.  The per-angle abs-max
  * (calc_rotated_peak, cli/phase-rotate.cc:98-121) is bounded by r = sqrt(dry^2 + hilbert^2) for
  * every angle, so a frame whose r stays below a lower bound of every final peak cannot change the
- * table: every frame is tested, the survivors are compacted and only full 32-frame tiles of
+ * table: every frame is tested (once per workgroup, against the smallest bound of its four angle
+ * groups), the survivors are compacted and only full 32-frame tiles of
  * survivors go through the per-angle evaluation -- the table is bit-identical to evaluating
  * everything.  Units are (wave, 32-frame tile) pairs: `seen` offered, `evaluated` run through the
  * per-angle evaluation (tiles of survivors + tiles fed untested); the ratio is signal-dependent
  * (stationary material: the share of frames near the peaks; a signal that keeps growing: 1).
- * A wave on which > 7/8 of a 16-tile window survives stops testing for a while (4 steps of 8 tiles,
- * doubling while re-probes keep failing, back to 4 after one that succeeds); those tiles are
- * `untested`.  Launches with the pruning switched off (PROT_SWEEP_PRUNE=0) run the plain kernel
+ * When more than 7/8 of a 1024-frame step survive, the workgroup stops testing for a while (2 steps, doubling while
+ * re-probes keep failing, back to 2 after one that succeeds); those tiles are `untested`.  Launches with the pruning switched off (PROT_SWEEP_PRUNE=0) run the plain kernel
  * and count nothing.  Work on the engine's own stream is awaited first; launches on a caller's
  * stream are the caller's to await.
  *   prot_sweep_stats_ex: out = { evaluated, seen, untested, surviving frames of the tested tiles } */

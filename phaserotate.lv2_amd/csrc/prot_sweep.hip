@@ -10,21 +10,23 @@
 //   cover the 360 angles (12 blocks) and read the same frames.
 //
 //   Pruning (exact): |ca d + sa h| <= sqrt(d^2 + h^2) =: r for every angle, so a frame whose r is below a LOWER BOUND
-//   of the smallest final peak among this wave's angles cannot change any maximum.  Every frame is tested (a lane
-//   holds d and h of its own frame: r^2, one compare); the survivors of 64 frames are COMPACTED -- ballot, v_mbcnt,
-//   one ds_write_b64 of (d, h) per survivor into the wave's own LDS ring -- and the matrix core only ever sees full
-//   tiles of survivors (two at a time, so v_max3 folds both).  What is left in the ring at the end is
-//   padded with zeros (|0| never raises a maximum >= 0).  The table is bit-identical to evaluating everything: max is
-//   exact, order-free, and skipped frames would have lost every comparison; 1e-4 of relative margin on r^2 covers the
-//   rounding of the float evaluation against the exact inequality.
-//   The bound: the smallest of the table entries as they stand at launch (earlier chunks; they only grow), the
-//   smallest of this wave's own lane-local running maxima, refreshed once per super-tile, and the largest bound any
-//   wave of the same angle group has published (one atomicMax per refresh).
-//   Material on which nearly everything survives (a signal that keeps growing; the first tiles of the first chunk,
-//   when no bound exists yet) would pay for the test and the LDS round trip on top of the full evaluation: a wave
-//   that saw more than 7/8 of a 16-tile window survive feeds tiles straight from registers for a while, then refreshes
-//   its bound and probes one window again -- the pause doubles while probes keep failing and resets when one
-//   succeeds.  Tiles that went through untested are counted separately (prot_sweep_stats_ex).
+//   of the smallest final peak among the workgroup's angles cannot change any maximum.  Every frame is tested ONCE per
+//   workgroup (wave w its quarter of a step: a lane holds d and h of its own frame: r^2, one compare); the survivors of
+//   64 frames are COMPACTED -- ballot, v_mbcnt, one ds_write_b64 of (d, h) per survivor into the wave's own LDS ring --
+//   and after a barrier every wave runs the full tiles of all four rings through the matrix core with its own angles (two
+//   tiles at a time, so v_max3 folds both).  What is left in the rings at the end is padded with zeros (|0| never raises
+//   a maximum >= 0).  The table is bit-identical to evaluating everything: max is exact, order-free, and skipped frames
+//   would have lost every comparison; 1e-4 of relative margin on r^2 covers the rounding of the float evaluation against
+//   the exact inequality.
+//   The bound: per wave the smallest of the table entries of its angles as they stand at launch (earlier chunks; they
+//   only grow), the smallest of its own lane-local running maxima, and the largest bound any wave of the same angle
+//   group has published (read first, atomicMax only when it improves), refreshed every 8 steps; the test compares
+//   with the smallest of the four waves' bounds.
+//   Material on which nearly everything survives (a steady tone; the first steps of the first chunk, when no bound
+//   exists yet) would pay for the test and the LDS round trip on top of the full evaluation: when more than 7/8 of a
+//   step's frames survive the workgroup feeds the next steps straight from the stage, untested, then refreshes its
+//   bounds and tests one step again -- the pause doubles while that keeps failing and resets when it succeeds.  Tiles
+//   that went through untested are counted separately (prot_sweep_stats_ex).
 #include "prot_dev.h"
 #include "prot_kernels.h"
 
@@ -36,11 +38,10 @@ typedef float f32x16 __attribute__ ((ext_vector_type (16)));
 
 constexpr int kStage  = 1024;             // frames per step: loaded ONCE per workgroup, shared through LDS
 constexpr int kSteps  = 8;                // steps between two looks at the shared bound
-constexpr int kBatch  = 256;              // frames a wave tests between two looks at its ring (4 groups = 8 tiles)
+constexpr int kBatch  = kStage / 4;       // frames of a step each wave tests (4 groups of 64 = 8 tiles)
 constexpr int kRing   = 512;              // (d, h) entries of one wave's survivor ring: < 64 left over + one batch
 static_assert (kRing >= 64 + kBatch && (kRing & (kRing - 1)) == 0, "ring too small");
-constexpr int kWin    = 16;               // tiles per decision window of the switch-off (two batches)
-constexpr int kPause0 = 4, kPauseMax = 1024; // batches fed untested after a failed window: first, cap
+constexpr int kPause0 = 2, kPauseMax = 256; // steps fed untested after a step on which > 7/8 of the frames survived: first, cap
 
 template <int NBLK, bool PRUNE>
 __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const SweepParams p)
@@ -184,12 +185,30 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 		thr2          = uniform_f (fmaxf (thr2, b * b * 0.9999f));
 	}
 
+	// ---- survivors: wave w tests ITS quarter of a step's frames -- once per workgroup, against the smallest of the four
+	// groups' bounds -- and compacts them into its own ring; after a barrier every wave evaluates the full tiles of all four
+	// rings with its own angles (waves of one group split them).  (Every wave testing every frame against its own bound,
+	// the first compacting version, spent 0.40 of its 0.50 ms per 115 M channel-frames in the test.)
 	float* const ring = reinterpret_cast<float*> (ring_s + (PRUNE ? w * kRing : 0));
-	unsigned     rd = 0, wr = 0;                    // ring cursors (entries, free-running)
-	bool         testing   = true;
-	int          pause     = kPause0, pause_left = 0;
-	int          win_tiles = 0, win_surv = 0;
-	unsigned     n_seen = 0, n_eval = 0, n_untested = 0, n_surv = 0; // tiles, tiles, tiles, frames
+	__shared__ unsigned sh_wr[2][4];   // ring write cursors (entries, free-running) after the step of that parity
+	__shared__ unsigned sh_surv[4];    // survivors each wave found in the current step
+	__shared__ float    sh_thr[4];     // each wave's own bound (squared, margin included; idle waves: huge)
+	unsigned            wr = 0;
+	bool                testing = true;
+	int                 pause = kPause0, pause_left = 0;
+	unsigned            pair_no = 0;   // tile pairs drained so far (same in every wave): pair_no % nsub == sub are mine
+	unsigned            n_seen = 0, n_eval = 0, n_untested = 0, n_surv = 0; // tiles, tiles, tiles, frames
+	float               thr_min = 0.f; // what the test compares with: the smallest of the four waves' bounds
+	if (PRUNE) {
+		if (lane == 0) {
+			sh_wr[0][w] = 0u;
+			sh_wr[1][w] = 0u;
+			sh_surv[w]  = 0u;
+			sh_thr[w]   = idle ? kBig : thr2;
+		}
+		__syncthreads ();
+		thr_min = fminf (fminf (sh_thr[0], sh_thr[1]), fminf (sh_thr[2], sh_thr[3]));
+	}
 
 	// ---- the stream: steps of 1024 frames, grid-strided -- at any moment the workgroups of a channel read ONE dense
 	// window of the stream (grid x 4 KB per stream), which is what keeps DRAM pages open; with 8192-frame iterations cut
@@ -283,113 +302,132 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 				request (s + 3);
 			}
 		}
-		if (!idle) {
-			if (PRUNE && s > 0 && s % kSteps == 0) {
-				refresh ();
-			}
-			const float* const st = stage_s + buf * 2 * kStage; // d at st[f], h at st[kStage + f]
-			// the four (d, h) of a lane in batch bi: requested one batch ahead, in front of the ring writes of the batch
-			// before (the backend will not move an LDS read across an LDS write that may alias: left inside the test loop
-			// each read waited out its full latency, one after the other -- 120 cycles per 64 frames and wave)
-			float2 cur[kBatch / 64], nxt[kBatch / 64];
-			auto fetch = [&] (float2 (&v)[kBatch / 64], int bi) {
-#pragma unroll
-				for (int i = 0; i < kBatch / 64; ++i) {
-					v[i] = make_float2 (st[bi * kBatch + i * 64 + lane], st[kStage + bi * kBatch + i * 64 + lane]);
-				}
-			};
-			if (PRUNE) {
-				fetch (cur, sub);
-			}
-			for (int bi = sub; bi < kStage / kBatch; bi += nsub) {
-				if (PRUNE && bi + nsub < kStage / kBatch) {
-					fetch (nxt, bi + nsub); // (also while the test is off: it may come back on at the end of this batch)
-				}
-				if (!PRUNE) {
+		const float* const st = stage_s + buf * 2 * kStage; // d at st[f], h at st[kStage + f]
+		if (!PRUNE) {
+			if (!idle) {
+				for (int bi = sub; bi < kStage / kBatch; bi += nsub) {
 #pragma unroll
 					for (int tt = 0; tt < kBatch / 32; tt += 2) {
 						evaluate (st[kk * kStage + bi * kBatch + tt * 32 + j], st[kk * kStage + bi * kBatch + tt * 32 + 32 + j]);
 					}
-				} else {
-					// one instance of the evaluation serves both feeds (an unrolled direct feed next to the ring loop pushed
-					// the three-block kernel over 168 VGPRs, i.e. down to two waves per SIMD)
-					int direct = 0; // tile pairs of this batch still to be fed untested, straight from the stage
-					if (testing) {
-						int surv = 0;
-#pragma unroll
-						for (int i = 0; i < kBatch / 64; ++i) {
-							const float2   v    = cur[i];
-							const bool     live = v.x * v.x + v.y * v.y > thr2;
-							const uint64_t mask = __builtin_amdgcn_ballot_w64 (live);
-							if (live) {
-								const unsigned at = (wr + __builtin_amdgcn_mbcnt_hi ((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned)mask, 0u))) & (kRing - 1);
-								*reinterpret_cast<float2*> (ring + 2 * at) = v;
-							}
-							const int nl = __builtin_popcountll (mask);
-							wr += (unsigned)nl;
-							surv += nl;
-						}
-						n_surv += (unsigned)surv;
-						win_tiles += kBatch / 32;
-						win_surv += surv;
-					} else {
-						direct = kBatch / 64;
-						n_untested += kBatch / 32;
-						n_eval += kBatch / 32;
-					}
-					n_seen += kBatch / 32;
-					__builtin_amdgcn_wave_barrier ();
-					for (;;) {
-						float b0, b1;
-						if (direct > 0) {
-							const int tt = 2 * (kBatch / 64 - direct);
-							b0           = st[kk * kStage + bi * kBatch + tt * 32 + j];
-							b1           = st[kk * kStage + bi * kBatch + tt * 32 + 32 + j];
-							--direct;
-						} else if (wr - rd >= 64u) {
-							b0 = ring[2 * ((rd + j) & (kRing - 1)) + kk];
-							b1 = ring[2 * ((rd + 32 + j) & (kRing - 1)) + kk];
-							rd += 64u;
-							n_eval += 2;
-						} else {
-							break;
-						}
-						evaluate (b0, b1);
-					}
-					__builtin_amdgcn_wave_barrier ();
-					if (!testing) {
-						if (--pause_left <= 0) {
-							testing = true;
-							refresh ();
-						}
-					} else if (win_tiles >= kWin) {
-						if (win_surv * 8 > win_tiles * 32 * 7) {
-							testing    = false;
-							pause_left = pause;
-							pause      = pause * 2 < kPauseMax ? pause * 2 : kPauseMax;
-						} else {
-							pause = kPause0;
-						}
-						win_tiles = win_surv = 0;
-					}
-#pragma unroll
-					for (int i = 0; i < kBatch / 64; ++i) {
-						cur[i] = nxt[i];
-					}
 				}
 			}
+			__syncthreads ();
+			continue;
 		}
-		__syncthreads ();
+		// ---- test my quarter (all four waves, idle or not: an idle wave has no angles, but frames to test)
+		if (testing) {
+			float2 v[kBatch / 64];
+#pragma unroll
+			for (int i = 0; i < kBatch / 64; ++i) { // all reads in front of the ring writes (the backend keeps that order)
+				v[i] = make_float2 (st[w * kBatch + i * 64 + lane], st[kStage + w * kBatch + i * 64 + lane]);
+			}
+			unsigned surv = 0;
+#pragma unroll
+			for (int i = 0; i < kBatch / 64; ++i) {
+				const bool     live = v[i].x * v[i].x + v[i].y * v[i].y > thr_min;
+				const uint64_t mask = __builtin_amdgcn_ballot_w64 (live);
+				if (live) {
+					const unsigned at = (wr + __builtin_amdgcn_mbcnt_hi ((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned)mask, 0u))) & (kRing - 1);
+					*reinterpret_cast<float2*> (ring + 2 * at) = v[i];
+				}
+				const unsigned nl = (unsigned)__builtin_popcountll (mask);
+				wr += nl;
+				surv += nl;
+			}
+			n_surv += surv;
+			if (lane == 0) {
+				sh_surv[w] = surv;
+			}
+		}
+		if (lane == 0) {
+			sh_wr[buf][w] = wr;
+		}
+		__syncthreads (); // the rings and their cursors are complete for this step
+		// ---- evaluate: the full tiles of the four rings, or -- test switched off -- all 32 tiles of the step from the stage
+		{
+			unsigned r0v[4], cnt[4], total = 0; // first entry and number of tile pairs to take from each ring (wave-uniform)
+#pragma unroll
+			for (int v4 = 0; v4 < 4; ++v4) {
+				const unsigned c1 = sh_wr[buf][v4], c0 = sh_wr[buf ^ 1][v4] & ~63u; // drained up to a multiple of 64 last time
+				r0v[v4]           = c0;
+				cnt[v4]           = testing ? (c1 - c0) >> 6 : 0u;
+				total += cnt[v4];
+			}
+			if (!testing) {
+				total = kStage / 64;
+			}
+			const unsigned b1 = cnt[0], b2 = b1 + cnt[1], b3 = b2 + cnt[2];
+			const float* const rings = reinterpret_cast<const float*> (ring_s);
+			for (unsigned it = 0; it < total; ++it) {
+				const bool mine = !idle && (pair_no + it) % (unsigned)nsub == (unsigned)sub;
+				if (mine) {
+					float b0, b1v;
+					if (testing) {
+						const unsigned v4 = (it >= b1) + (it >= b2) + (it >= b3);
+						const unsigned lo = v4 == 0 ? 0u : v4 == 1 ? b1 : v4 == 2 ? b2 : b3;
+						const unsigned e0 = (v4 == 0 ? r0v[0] : v4 == 1 ? r0v[1] : v4 == 2 ? r0v[2] : r0v[3]) + 64u * (it - lo);
+						const float* const rg = rings + 2 * kRing * v4;
+						b0  = rg[2 * ((e0 + j) & (kRing - 1)) + kk];
+						b1v = rg[2 * ((e0 + 32 + j) & (kRing - 1)) + kk];
+					} else {
+						b0  = st[kk * kStage + it * 64 + j];
+						b1v = st[kk * kStage + it * 64 + 32 + j];
+					}
+					evaluate (b0, b1v);
+					n_eval += 2;
+				}
+			}
+			pair_no += total;
+			if (!idle) {
+				// (statistics in the units of the unpruned kernel: tiles this wave's share of the step would have cost)
+				n_seen += (kStage / 32) / nsub;
+				n_untested += testing ? 0 : (kStage / 32) / nsub;
+			}
+		}
+		// ---- the switch (workgroup-uniform: every wave sees the same counts), and the bound
+		bool look = (s + 1) % kSteps == 0; // time to look at the bounds again
+		if (testing) {
+			const unsigned sv = sh_surv[0] + sh_surv[1] + sh_surv[2] + sh_surv[3];
+			if (sv * 8 > (unsigned)kStage * 7) {
+				testing    = false;
+				pause_left = pause;
+				pause      = pause * 2 < kPauseMax ? pause * 2 : kPauseMax;
+			} else {
+				pause = kPause0;
+			}
+		} else if (--pause_left <= 0) {
+			testing = true;
+			look    = true;
+		}
+		if (look) {
+			if (!idle) {
+				refresh ();
+			}
+			if (lane == 0) {
+				sh_thr[w] = idle ? kBig : thr2;
+			}
+		}
+		__syncthreads (); // everybody is done with this half of the stage and with the rings' drained entries
+		if (look) {
+			thr_min = fminf (fminf (sh_thr[0], sh_thr[1]), fminf (sh_thr[2], sh_thr[3]));
+		}
 	}
 	if (PRUNE && !idle) {
-		const unsigned left = wr - rd; // < 64
-		if (left > 0u) {
-			float b0 = ring[2 * ((rd + j) & (kRing - 1)) + kk];
-			float b1 = ring[2 * ((rd + 32 + j) & (kRing - 1)) + kk];
-			b0       = (unsigned)j < left ? b0 : 0.f;
-			b1       = (unsigned)j + 32u < left ? b1 : 0.f;
-			evaluate (b0, b1);
-			n_eval += left > 32u ? 2 : 1;
+		// what is left in the four rings (< 64 entries each), padded with zeros
+		const int last = (n_step - 1) & 1;
+		const float* const rings = reinterpret_cast<const float*> (ring_s);
+		for (unsigned v4 = 0; v4 < 4u; ++v4) {
+			const unsigned c1 = n_step > 0 ? sh_wr[last][v4] : 0u, e0 = c1 & ~63u, left = c1 - e0;
+			if (left > 0u && (pair_no + v4) % (unsigned)nsub == (unsigned)sub) {
+				const float* const rg = rings + 2 * kRing * v4;
+				float b0 = rg[2 * ((e0 + j) & (kRing - 1)) + kk];
+				float b1 = rg[2 * ((e0 + 32 + j) & (kRing - 1)) + kk];
+				b0       = (unsigned)j < left ? b0 : 0.f;
+				b1       = (unsigned)j + 32u < left ? b1 : 0.f;
+				evaluate (b0, b1);
+				n_eval += left > 32u ? 2 : 1;
+			}
 		}
 	}
 	// statistics: one set of atomics per workgroup, not per wave (every atomic of the launch lands on the same cache line)
