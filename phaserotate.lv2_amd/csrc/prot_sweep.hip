@@ -190,10 +190,10 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 	// rings with its own angles (waves of one group split them).  (Every wave testing every frame against its own bound,
 	// the first compacting version, spent 0.40 of its 0.50 ms per 115 M channel-frames in the test.)
 	float* const ring = reinterpret_cast<float*> (ring_s + (PRUNE ? w * kRing : 0));
-	__shared__ unsigned sh_wr[2][4];   // ring write cursors (entries, free-running) after the step of that parity
-	__shared__ unsigned sh_surv[4];    // survivors each wave found in the current step
+	__shared__ unsigned sh_surv[4];    // survivors each wave found in the current step (every wave keeps all four ring cursors itself)
 	__shared__ float    sh_thr[4];     // each wave's own bound (squared, margin included; idle waves: huge)
-	unsigned            wr = 0;
+	unsigned            wr = 0;                 // my ring's write cursor (entries, free-running)
+	unsigned            cw[4] = { 0u, 0u, 0u, 0u }; // all four rings' cursors as of the last barrier (same in every wave)
 	bool                testing = true;
 	int                 pause = kPause0, pause_left = 0;
 	unsigned            pair_no = 0;   // tile pairs drained so far (same in every wave): pair_no % nsub == sub are mine
@@ -201,8 +201,6 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 	float               thr_min = 0.f; // what the test compares with: the smallest of the four waves' bounds
 	if (PRUNE) {
 		if (lane == 0) {
-			sh_wr[0][w] = 0u;
-			sh_wr[1][w] = 0u;
 			sh_surv[w]  = 0u;
 			sh_thr[w]   = idle ? kBig : thr2;
 		}
@@ -340,19 +338,20 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 				sh_surv[w] = surv;
 			}
 		}
-		if (lane == 0) {
-			sh_wr[buf][w] = wr;
-		}
-		__syncthreads (); // the rings and their cursors are complete for this step
+		__syncthreads (); // the rings and the survivor counts are complete for this step
 		// ---- evaluate: the full tiles of the four rings, or -- test switched off -- all 32 tiles of the step from the stage
+		unsigned sv_step = 0;
 		{
-			unsigned r0v[4], cnt[4], total = 0; // first entry and number of tile pairs to take from each ring (wave-uniform)
+			unsigned r0v[4], cnt[4], total = 0, sv = 0; // first entry and number of tile pairs to take from each ring (wave-uniform)
 #pragma unroll
 			for (int v4 = 0; v4 < 4; ++v4) {
-				const unsigned c1 = sh_wr[buf][v4], c0 = sh_wr[buf ^ 1][v4] & ~63u; // drained up to a multiple of 64 last time
-				r0v[v4]           = c0;
-				cnt[v4]           = testing ? (c1 - c0) >> 6 : 0u;
+				const unsigned add = testing ? (unsigned)__builtin_amdgcn_readfirstlane ((int)sh_surv[v4]) : 0u;
+				r0v[v4]            = cw[v4] & ~63u; // drained up to a multiple of 64 last time
+				cw[v4] += add;
+				cnt[v4] = (cw[v4] - r0v[v4]) >> 6;
+				cnt[v4] = testing ? cnt[v4] : 0u;
 				total += cnt[v4];
+				sv += add;
 			}
 			if (!testing) {
 				total = kStage / 64;
@@ -379,6 +378,7 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 				}
 			}
 			pair_no += total;
+			sv_step = sv;
 			if (!idle) {
 				// (statistics in the units of the unpruned kernel: tiles this wave's share of the step would have cost)
 				n_seen += (kStage / 32) / nsub;
@@ -388,8 +388,7 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 		// ---- the switch (workgroup-uniform: every wave sees the same counts), and the bound
 		bool look = (s + 1) % kSteps == 0; // time to look at the bounds again
 		if (testing) {
-			const unsigned sv = sh_surv[0] + sh_surv[1] + sh_surv[2] + sh_surv[3];
-			if (sv * 8 > (unsigned)kStage * 7) {
+			if (sv_step * 8 > (unsigned)kStage * 7) {
 				testing    = false;
 				pause_left = pause;
 				pause      = pause * 2 < kPauseMax ? pause * 2 : kPauseMax;
@@ -415,10 +414,9 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 	}
 	if (PRUNE && !idle) {
 		// what is left in the four rings (< 64 entries each), padded with zeros
-		const int last = (n_step - 1) & 1;
 		const float* const rings = reinterpret_cast<const float*> (ring_s);
 		for (unsigned v4 = 0; v4 < 4u; ++v4) {
-			const unsigned c1 = n_step > 0 ? sh_wr[last][v4] : 0u, e0 = c1 & ~63u, left = c1 - e0;
+			const unsigned c1 = v4 == 0 ? cw[0] : v4 == 1 ? cw[1] : v4 == 2 ? cw[2] : cw[3], e0 = c1 & ~63u, left = c1 - e0;
 			if (left > 0u && (pair_no + v4) % (unsigned)nsub == (unsigned)sub) {
 				const float* const rg = rings + 2 * kRing * v4;
 				float b0 = rg[2 * ((e0 + j) & (kRing - 1)) + kk];
