@@ -434,7 +434,8 @@ def bench_cfg3(args, pkg, torch, np, dev, ts, st, local_rank, barrier, world):
             # process with GPU_MAX_HW_QUEUES=8 (the setting a deployment that uses the flag would make; it costs the long
             # launches of the headline ~1 %, which is why this process does not set it)
             row["pipelined_ms_per_launch_this_process"] = cfg3_pipelined(pkg, torch, np, local_rank)
-            if world == 1:
+            profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+            if world == 1 and not profiled:  # (no child processes under a profiler)
                 import subprocess
                 try:
                     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cfg3-pipelined-child"], capture_output=True,
@@ -614,8 +615,17 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
             t[rank] = dev_ms
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             per_rank = [float(v) for v in t.cpu()]
+        exs = eng.sweep_stats_ex() if hasattr(eng, "sweep_stats_ex") else {}
+        n_ang = 359  # (angle 0 is the plain abs-max of the input, Q4)
         res[kind] = {"ms": wall * 1e3, "value": total * n_chn / wall, "unpruned_ms": wall_np * 1e3,
                      "evaluated_fraction": ev / max(seen, 1), "table_identical_unpruned": same,
+                     "untested_fraction": exs.get("untested", 0) / max(seen, 1),
+                     # SURVEY 8d, "for completeness": the sweep reads 4 B per channel-frame (its Hilbert branch is written and
+                     # re-read on the device: 8 B more) and the UNPRUNED evaluation is 359 angles x (mul + fma) on the matrix
+                     # core: fraction of the 157 TFLOP/s fp32 matrix peak the unpruned pass reaches, and the HBM fraction of
+                     # the pruned pass at its algorithmic 4 B per channel-frame
+                     "hbm_frac_algorithmic": total * n_chn * 4.0 / wall / 1e9 / HBM_PEAK_GBS,
+                     "unpruned_frac_of_fp32_matrix_peak": total * n_chn * n_ang * 4.0 / wall_np / 157.3e12,
                      "per_rank_device_ms": per_rank,
                      "min_angle_index": [int(pk[c].argmin()) for c in range(n_chn)]}
         if world == 1:

@@ -10,7 +10,7 @@ import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
 tag, out = sys.argv[1], sys.argv[2]
-HEAD, SWEEP = "olasave_kernel<10, 0>", "sweep_mfma_kernel<3"
+HEAD, SWEEP = "olasave_kernel<10, 0>", "sweep_kernel<3"
 
 
 def counters(d):
