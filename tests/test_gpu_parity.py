@@ -252,7 +252,8 @@ def _signal(n, n_chn, seed):
 
 
 @pytest.mark.parametrize("blksiz,n_chn,nblk_frac", [(2048, 1, 10.0), (2048, 2, 7.37), (1024, 1, 9.5),
-                                                    (8192, 2, 4.2), (16384, 1, 3.5)])
+                                                    (8192, 2, 4.2), (16384, 1, 3.5), (16384, 2, 30.3), (32768, 1, 6.5),
+                                                    (4096, 2, 41.7)])
 def test_sweep_full_table(pkg, blksiz, n_chn, nblk_frac):
     n = int(blksiz * nblk_frac)
     data = _signal(n, n_chn, seed=11)
