@@ -33,6 +33,17 @@ def test_library_exports_every_declared_symbol(pkg):
     assert lib.prot_abi_version() == declared == 4
 
 
+def test_header_constants_and_python_mirror_agree(pkg):
+    """Every PROT_CFG_* / PROT_F_* / PROT_FORM_* / PROT_KIND_* constant of the header has the same value in the ctypes mirror."""
+    code = re.sub(r"/\*.*?\*/", "", open(HDR).read(), flags=re.S)
+    defs = dict((n, int(v.rstrip("uU"), 0)) for n, v in re.findall(r"#define\s+(PROT_(?:CFG|F|FORM|KIND)_[A-Z0-9_]+)\s+(\d+[uU]?|0x[0-9a-fA-F]+[uU]?)", code))
+    assert {"PROT_CFG_PIPELINE", "PROT_CFG_OVERLAP_ADD", "PROT_F_STATELESS"} <= set(defs)
+    for name, val in defs.items():
+        py = name[len("PROT_"):]
+        assert hasattr(pkg, py), "phaserotate_lv2_amd lacks %s" % py
+        assert getattr(pkg, py) == val, name
+
+
 def test_header_is_plain_c():
     """No torch/HIP/C++ types in the signatures: the header compiles as C99 on its own."""
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", HDR],
