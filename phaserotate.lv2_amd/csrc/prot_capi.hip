@@ -340,6 +340,7 @@ struct prot_engine {
 	int            hist16_cur = 0;
 	DevBuf<int>    d_angles;
 	DevBuf<float>  d_thr;   // [n_chn][4] shared pruning bounds of one sweep launch
+	DevBuf<float>  d_part;  // per-workgroup maxima of one sweep launch (prot_sweep.hip), allocated by the first sweep
 	DevBuf<unsigned long long> d_stats; // {tiles evaluated, tiles seen, tiles untested, surviving frames} since the last reset
 	PinBuf<float>  h_io;
 	// small host->device parameter copies (rotation pairs, angle lists) are staged through a ring of
@@ -1165,6 +1166,7 @@ void prot_engine_destroy (prot_engine* e)
 	e->d_rot_s.release ();
 	e->d_angles.release ();
 	e->d_thr.release ();
+	e->d_part.release ();
 	e->d_stats.release ();
 	e->h_io.release ();
 	e->h_slots.release ();
@@ -1528,6 +1530,11 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		sp.prune       = (pe && atoi (pe) == 0) ? 0 : 1; // exact either way; 0 = the unpruned sweep, for timing and tests
 		sp.thr         = e->d_thr.p;
 		sp.stats       = e->d_stats.p;
+		if ((rc = e->d_part.ensure (prot::sweep_scratch_floats ())) != PROT_OK) {
+			return rc;
+		}
+		sp.part        = e->d_part.p;
+		sp.part_floats = prot::sweep_scratch_floats ();
 		// bounds are per launch: they refer to THIS call's angle set
 		HIP_TRY (hipMemsetAsync (e->d_thr.p, 0, 4 * (size_t)e->info.n_chn * sizeof (float), s));
 		hipError_t err = prot::launch_sweep (sp, nc, s);

@@ -110,9 +110,12 @@ struct SweepParams {
 	int32_t      chn0;        // first channel handled by blockIdx.y = 0
 	int32_t      prune;       // evaluate only the frames that can still raise a maximum (exact; see prot_sweep.hip)
 	float*       thr;         // device, [n_chn][4], ZEROED before the launch: shared pruning bounds, or NULL
+	float*       part;        // device scratch, >= sweep_scratch_floats () floats: per-workgroup maxima of one launch (merged into peaks)
+	size_t       part_floats;
 	unsigned long long* stats; // device, [4] += {tiles evaluated, tiles seen, tiles fed untested, surviving frames of tested tiles}, or NULL
 };
 hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s);
+size_t     sweep_scratch_floats ();
 
 // peaks[c][slot] = max(peaks[c][slot], max_{t in [0,n)} |x[c][t]|)   (angle 0, Q4)
 hipError_t launch_absmax (const float* x, int64_t x_stride, int64_t n, float* peaks, int slot,

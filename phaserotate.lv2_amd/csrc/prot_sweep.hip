@@ -449,8 +449,12 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 	if (idle) {
 		return;
 	}
-	// reduce over the 32 columns (lanes of one half), then one atomic per angle
-	unsigned* gp = reinterpret_cast<unsigned*> (p.peaks + (int64_t)c * kMaxSample);
+	// reduce over the 32 columns (lanes of one half); one value per angle and wave goes to the launch's scratch table
+	// [channel][workgroup][wave's place g + G sub][angle slot] with a plain store (a wave fills the slots of its own angle
+	// blocks only), and sweep_merge_kernel folds that into the peak table.  (One
+	// atomicMax per wave and angle on the table itself -- 196 K atomics on 45 cache lines at the end of a full launch --
+	// cost 100-200 us per launch however short; looking first made each wave walk 48 dependent L2 round trips instead.)
+	float* const part = p.part + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wr_) * p.n_angles;
 #pragma unroll
 	for (int q = 0; q < NBLK; ++q) {
 #pragma unroll
@@ -464,14 +468,32 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 			const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
 			const int idx = (g + q * G) * 32 + row;
 			if (j == 0 && g + q * G < nb && idx < p.n_angles) {
-				// look first: of the thousands of waves that hold a maximum for this angle only a few hold one that raises
-				// the table, and the table's few cache lines serve their atomics one at a time
-				unsigned* const slot = &gp[p.angles[idx]];
-				if (__float_as_uint (v) > __hip_atomic_load (slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-					atomicMax (slot, __float_as_uint (v));
-				}
+				part[idx] = v;
 			}
 		}
+	}
+}
+
+// peaks[c][angle] = max (peaks[c][angle], max over the launch's workgroups and the waves that served the angle's block):
+// one thread per (angle slot, slice of workgroups), 16 slices -> at most 16 atomics per table entry
+__global__ __launch_bounds__ (64) void sweep_merge_kernel (const float* __restrict__ part, int n_wg, int n_angles, const int* __restrict__ angles,
+                                                             float* peaks, int chn0)
+{
+	const int idx = blockIdx.x * 64 + threadIdx.x;
+	if (idx >= n_angles) {
+		return;
+	}
+	const int nb = (n_angles + 31) >> 5, G = nb >= 3 ? 4 : nb, nsub = 4 / G, g = (idx >> 5) % G;
+	const float* const q = part + (int64_t)blockIdx.y * n_wg * 4 * n_angles + idx;
+	float              v = 0.f;
+	for (int b = blockIdx.z; b < n_wg; b += gridDim.z) {
+		for (int sub = 0; sub < nsub; ++sub) {
+			v = fmaxf (v, q[((int64_t)b * 4 + g + G * sub) * n_angles]);
+		}
+	}
+	unsigned* const slot = reinterpret_cast<unsigned*> (peaks + (int64_t)(chn0 + blockIdx.y) * kMaxSample + angles[idx]);
+	if (__float_as_uint (v) > *slot) {
+		atomicMax (slot, __float_as_uint (v));
 	}
 }
 
@@ -504,9 +526,27 @@ hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s)
 	const int64_t span  = kStage;
 	const int64_t tiles = (p.t_end - p.t_begin + span - 1) / span;
 	const int64_t gx    = std::min<int64_t> (tiles, std::max (1, slots[pr][nblk] / n_chn));
-	const dim3    grid ((unsigned)gx, (unsigned)n_chn), block (256);
+	if (p.part == nullptr || p.part_floats < (size_t)gx * n_chn * 4 * p.n_angles) {
+		return hipErrorInvalidValue; // the host sizes the scratch table with sweep_scratch_floats ()
+	}
+	const dim3 grid ((unsigned)gx, (unsigned)n_chn), block (256);
 	hipLaunchKernelGGL (fn, grid, block, 0, s, p);
+	hipError_t err = hipGetLastError ();
+	if (err != hipSuccess) {
+		return err;
+	}
+	const dim3 mgrid ((unsigned)((p.n_angles + 63) / 64), (unsigned)n_chn, 16);
+	hipLaunchKernelGGL (sweep_merge_kernel, mgrid, dim3 (64), 0, s, p.part, (int)gx, p.n_angles, p.angles, p.peaks, p.chn0);
 	return hipGetLastError ();
+}
+
+// floats of scratch a sweep launch may need on this device (every resident-workgroup slot x 4 waves x 360 angles)
+size_t sweep_scratch_floats ()
+{
+	int dev = 0, cus = 256;
+	(void)hipGetDevice (&dev);
+	(void)hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, dev);
+	return (size_t)cus * 8 * 4 * kMaxSample;
 }
 
 } // namespace prot
