@@ -1535,6 +1535,7 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		}
 		sp.part        = e->d_part.p;
 		sp.part_floats = prot::sweep_scratch_floats ();
+		sp.raw_slot    = raw0 ? 0 : -1; // the raw peak rides along with the sweep (no pass of its own over the input)
 		// bounds are per launch: they refer to THIS call's angle set
 		HIP_TRY (hipMemsetAsync (e->d_thr.p, 0, 4 * (size_t)e->info.n_chn * sizeof (float), s));
 		hipError_t err = prot::launch_sweep (sp, nc, s);
@@ -1542,8 +1543,8 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 			return hip_fail (err, "sweep kernel launch");
 		}
 	}
-	// 3. angle 0: raw peak of the (un-delayed) blocks
-	if (raw0) {
+	// 3. angle 0: raw peak of the (un-delayed) blocks -- on its own only when no other angle was asked for
+	if (raw0 && n_ang == 0) {
 		hipError_t err = prot::launch_absmax (d_in, in_stride, (int64_t)n_frames, pk, 0, c0, nc, s);
 		if (err != hipSuccess) {
 			return hip_fail (err, "absmax kernel launch");

@@ -110,6 +110,7 @@ struct SweepParams {
 	int32_t      chn0;        // first channel handled by blockIdx.y = 0
 	int32_t      prune;       // evaluate only the frames that can still raise a maximum (exact; see prot_sweep.hip)
 	float*       thr;         // device, [n_chn][4], ZEROED before the launch: shared pruning bounds, or NULL
+	int32_t      raw_slot;    // >= 0: also max |x| over the frames the launch reads -> peaks[c][raw_slot] (angle 0, Q4); -1: no
 	float*       part;        // device scratch, >= sweep_scratch_floats () floats: per-workgroup maxima of one launch (merged into peaks)
 	size_t       part_floats;
 	unsigned long long* stats; // device, [4] += {tiles evaluated, tiles seen, tiles fed untested, surviving frames of tested tiles}, or NULL

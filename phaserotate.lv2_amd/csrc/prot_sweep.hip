@@ -227,6 +227,12 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 	const int ld_par  = w >> 1;        // parity of the steps s at whose start this wave parks / requests
 	const int ld_half = (w & 1) * 512; // my half of a step
 	float4    dv[2], hv[2];
+	// the raw peak (angle 0, Q4: abs-max of the un-rotated input, cli/phase-rotate.cc:413-414) rides along: every input frame
+	// passes through exactly one wave's registers on its way to the stage (a separate pass over the input was 0.49 ms of
+	// cfg4's 3.7).  What the loaders see is x[t - delay] for t in [t_begin, t_end): every frame of the call's input from its
+	// first on -- at a stream start t_begin - delay = 0; the last `delay` frames of a chunk that is not the last are seen
+	// by the next chunk as history, frames before a shard (primed history) belong to the same file -- beyond it zeros
+	float amax = 0.f;
 	auto locate = [&] (int s, int64_t& t0) { // first frame of my lane in step s; true: the whole step is plain stream
 		const int64_t base = first_base + (int64_t)s * stride;
 		t0                 = base + ld_half + 4 * lane;
@@ -254,6 +260,7 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 				float* const q                            = stage_s + buf * 2 * kStage + ld_half + 256 * i + 4 * lane;
 				*reinterpret_cast<float4*> (q)            = dv[i];
 				*reinterpret_cast<float4*> (q + kStage)   = hv[i];
+				amax = fmaxf (fmaxf (amax, fabsf (dv[i].x)), fmaxf (fabsf (dv[i].y), fmaxf (fabsf (dv[i].z), fabsf (dv[i].w))));
 			}
 		} else {
 			// edges of the stream (history, silence, the dry-less first half block): fetched here, frame by frame, latency
@@ -267,8 +274,10 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 					const int64_t ix  = ti - p.delay;
 					float         d = 0.f, h = 0.f;
 					if (ti < p.t_end) {
-						h = u[ti];
-						d = ti + p.t_abs0 >= p.dry_from ? ldv (x, p.n_x, hist, p.hist_len, ix) : 0.f;
+						h               = u[ti];
+						const float raw = ldv (x, p.n_x, hist, p.hist_len, ix);
+						amax            = fmaxf (amax, fabsf (raw)); // (the raw peak sees the frames the first block's dry term skips)
+						d               = ti + p.t_abs0 >= p.dry_from ? raw : 0.f;
 					}
 					float* const q = stage_s + buf * 2 * kStage + ld_half + 256 * i + 4 * lane + e;
 					q[0]           = d;
@@ -446,15 +455,27 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 			atomicAdd (&p.stats[tid], (unsigned long long)acc[tid]);
 		}
 	}
+	// reduce over the 32 columns (lanes of one half); one value per angle and wave goes to the launch's scratch table
+	// [channel][workgroup][wave's place g + G sub][angle slot | raw] with a plain store (a wave fills the slots of its own
+	// angle blocks, and the raw slot), and sweep_merge_kernel folds that into the peak table.  (One atomicMax per wave and
+	// angle on the table itself -- 196 K atomics on 45 cache lines at the end of a full launch -- cost 100-200 us per
+	// launch however short; looking first made each wave walk 48 dependent L2 round trips instead.)
+	float* const part = p.part + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wr_) * (p.n_angles + 1);
+	{
+		float v = amax;
+		v       = fmaxf (v, __shfl_xor (v, 1));
+		v       = fmaxf (v, __shfl_xor (v, 2));
+		v       = fmaxf (v, __shfl_xor (v, 4));
+		v       = fmaxf (v, __shfl_xor (v, 8));
+		v       = fmaxf (v, __shfl_xor (v, 16));
+		v       = fmaxf (v, __shfl_xor (v, 32));
+		if (lane == 0) {
+			part[p.n_angles] = v;
+		}
+	}
 	if (idle) {
 		return;
 	}
-	// reduce over the 32 columns (lanes of one half); one value per angle and wave goes to the launch's scratch table
-	// [channel][workgroup][wave's place g + G sub][angle slot] with a plain store (a wave fills the slots of its own angle
-	// blocks only), and sweep_merge_kernel folds that into the peak table.  (One
-	// atomicMax per wave and angle on the table itself -- 196 K atomics on 45 cache lines at the end of a full launch --
-	// cost 100-200 us per launch however short; looking first made each wave walk 48 dependent L2 round trips instead.)
-	float* const part = p.part + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wr_) * p.n_angles;
 #pragma unroll
 	for (int q = 0; q < NBLK; ++q) {
 #pragma unroll
@@ -477,21 +498,29 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 // peaks[c][angle] = max (peaks[c][angle], max over the launch's workgroups and the waves that served the angle's block):
 // one thread per (angle slot, slice of workgroups), 16 slices -> at most 16 atomics per table entry
 __global__ __launch_bounds__ (64) void sweep_merge_kernel (const float* __restrict__ part, int n_wg, int n_angles, const int* __restrict__ angles,
-                                                             float* peaks, int chn0)
+                                                             float* peaks, int chn0, int raw_slot)
 {
 	const int idx = blockIdx.x * 64 + threadIdx.x;
-	if (idx >= n_angles) {
+	if (idx > n_angles || (idx == n_angles && raw_slot < 0)) {
 		return;
 	}
 	const int nb = (n_angles + 31) >> 5, G = nb >= 3 ? 4 : nb, nsub = 4 / G, g = (idx >> 5) % G;
-	const float* const q = part + (int64_t)blockIdx.y * n_wg * 4 * n_angles + idx;
+	const float* const q = part + (int64_t)blockIdx.y * n_wg * 4 * (n_angles + 1) + idx;
 	float              v = 0.f;
-	for (int b = blockIdx.z; b < n_wg; b += gridDim.z) {
-		for (int sub = 0; sub < nsub; ++sub) {
-			v = fmaxf (v, q[((int64_t)b * 4 + g + G * sub) * n_angles]);
+	if (idx == n_angles) { // the raw peak: every wave of every workgroup has seen some of the frames
+		for (int b = blockIdx.z; b < n_wg; b += gridDim.z) {
+			for (int wv = 0; wv < 4; ++wv) {
+				v = fmaxf (v, q[((int64_t)b * 4 + wv) * (n_angles + 1)]);
+			}
+		}
+	} else {
+		for (int b = blockIdx.z; b < n_wg; b += gridDim.z) {
+			for (int sub = 0; sub < nsub; ++sub) {
+				v = fmaxf (v, q[((int64_t)b * 4 + g + G * sub) * (n_angles + 1)]);
+			}
 		}
 	}
-	unsigned* const slot = reinterpret_cast<unsigned*> (peaks + (int64_t)(chn0 + blockIdx.y) * kMaxSample + angles[idx]);
+	unsigned* const slot = reinterpret_cast<unsigned*> (peaks + (int64_t)(chn0 + blockIdx.y) * kMaxSample + (idx == n_angles ? raw_slot : angles[idx]));
 	if (__float_as_uint (v) > *slot) {
 		atomicMax (slot, __float_as_uint (v));
 	}
@@ -526,7 +555,7 @@ hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s)
 	const int64_t span  = kStage;
 	const int64_t tiles = (p.t_end - p.t_begin + span - 1) / span;
 	const int64_t gx    = std::min<int64_t> (tiles, std::max (1, slots[pr][nblk] / n_chn));
-	if (p.part == nullptr || p.part_floats < (size_t)gx * n_chn * 4 * p.n_angles) {
+	if (p.part == nullptr || p.part_floats < (size_t)gx * n_chn * 4 * (p.n_angles + 1)) {
 		return hipErrorInvalidValue; // the host sizes the scratch table with sweep_scratch_floats ()
 	}
 	const dim3 grid ((unsigned)gx, (unsigned)n_chn), block (256);
@@ -535,8 +564,8 @@ hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s)
 	if (err != hipSuccess) {
 		return err;
 	}
-	const dim3 mgrid ((unsigned)((p.n_angles + 63) / 64), (unsigned)n_chn, 16);
-	hipLaunchKernelGGL (sweep_merge_kernel, mgrid, dim3 (64), 0, s, p.part, (int)gx, p.n_angles, p.angles, p.peaks, p.chn0);
+	const dim3 mgrid ((unsigned)((p.n_angles + 1 + 63) / 64), (unsigned)n_chn, 16);
+	hipLaunchKernelGGL (sweep_merge_kernel, mgrid, dim3 (64), 0, s, p.part, (int)gx, p.n_angles, p.angles, p.peaks, p.chn0, p.raw_slot);
 	return hipGetLastError ();
 }
 
@@ -546,7 +575,7 @@ size_t sweep_scratch_floats ()
 	int dev = 0, cus = 256;
 	(void)hipGetDevice (&dev);
 	(void)hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, dev);
-	return (size_t)cus * 8 * 4 * kMaxSample;
+	return (size_t)cus * 8 * 4 * (kMaxSample + 1);
 }
 
 } // namespace prot
