@@ -1409,6 +1409,23 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 						ob[(unsigned)t + 256u * e] = to_sp (prev[e] + sa2 * u[2 * m + e]);
 					}
 				}
+			} else if (MODE == MODE_HILBERT && ACC && full && out_al8 && !(PROT_ABL2 & 64)) {
+				// ... and of the sweep's Hilbert branch (CLI blksiz 16384 / 32768: the second and later launches): the same
+				// aligned-pair load-add-store (through the per-frame path below this launch took 3.8 ms of cfg4's 7.5 at
+				// blksiz 16384, against 2.0 for the launch that only stores)
+#pragma unroll
+				for (int m = 0; m < HS / 2; ++m) {
+					PROT_GLOBAL C* __restrict__ ob = reinterpret_cast<PROT_GLOBAL C*> (uniform_ptr (out + s + 1024 * m));
+					f2                          prev[2];
+#pragma unroll
+					for (int e = 0; e < 2; ++e) {
+						prev[e] = to_f2 (ob[(unsigned)t + 256u * e]);
+					}
+#pragma unroll
+					for (int e = 0; e < 2; ++e) {
+						ob[(unsigned)t + 256u * e] = to_sp (prev[e] + u[2 * m + e]);
+					}
+				}
 			} else if (MODE == MODE_HILBERT && !ACC && full && out_al8 && !(PROT_ABL2 & 64)) {
 				// the Hilbert pass of the sweep: whole blocks as aligned pairs too
 #pragma unroll
