@@ -308,6 +308,19 @@ class Gen:
         P.s_addc_u32(S_A0.hi, S_SV.hi, Lit(0))
         P.global_load_dwordx2(self.TMP[7] if len(self.TMP) > 7 else self.TMP[1], self.VOFF, S_A0, 0)
         self.tab_regs = (self.TMP[6], self.TMP[7] if len(self.TMP) > 7 else self.TMP[1])
+        if self.kind != "core":
+            # the first block's rows are requested right behind the tables, in front of everything that waits for a table:
+            # vector memory retires in order, so the waits below are for the (older) table loads only and the two round
+            # trips of a launch's start overlap (one-block launches -- BASELINE config 3 -- are little else)
+            P.comment("---- prologue: the first block's rows (requested early)")
+            # rows 0..NT-1 -> K[HS .. 15] (the registers the steady state carries them in); gathers -> G_CAR lanes HS-NT..
+            for mpair in range(NT // 2):
+                P.s_add_u32(S_A0.lo, S_IN.lo, Lit(4096 * mpair))
+                P.s_addc_u32(S_A0.hi, S_IN.hi, Lit(0))
+                for e in range(2):
+                    P.global_load_dwordx2(self.K[HS + 2 * mpair + e], self.VOFF, S_A0, 2048 * e)
+            P.global_load_dword(self.G_CAR, vg0, S_IN, -4)
+            self.load_new_rows(0)
         self.scale_constants()
         P.ds_write_b64(self.A_W1, self.tab_regs[0], LDS_TWF)
         P.ds_write_b64(self.A_W1, self.tab_regs[1], LDS_TWM)
@@ -327,14 +340,6 @@ class Gen:
             P.s_barrier()   # every wave has its rows: the exchange area may be written
             P.comment("---- prologue done")
             return
-        # rows 0..NT-1 -> K[HS .. 15] (the registers the steady state carries them in); gathers -> G_CAR lanes HS-NT..
-        for mpair in range(NT // 2):
-            P.s_add_u32(S_A0.lo, S_IN.lo, Lit(4096 * mpair))
-            P.s_addc_u32(S_A0.hi, S_IN.hi, Lit(0))
-            for e in range(2):
-                P.global_load_dwordx2(self.K[HS + 2 * mpair + e], self.VOFF, S_A0, 2048 * e)
-        P.global_load_dword(self.G_CAR, vg0, S_IN, -4)
-        self.load_new_rows(0)
         P.comment("---- prologue done")
 
     def scale_constants(self):
