@@ -679,6 +679,48 @@ def test_pruned_sweep_every_angle_block_layout(pkg, stride, blocks):
     assert d_db.max() < 1e-3, d_db.max()
 
 
+@pytest.mark.parametrize("n_chn,n,passes", [
+    (3, 100000, ((0, 360, 24),)),                 # three channels: the scratch table's channel stride, 15 angles (one block)
+    (1, 700, ((0, 360, 1),)),                     # less than one 1024-frame step, all angles
+    (4, 5000, ((0, 1, 24),)),                     # angle 0 only: no sweep launch, the stand-alone abs-max kernel
+    (2, 2048 * 3 + 1, ((0, 360, 8), (200, 236, 1))),  # a ragged last block, a second pass over a few angles without angle 0
+    (5, 40000, ((1, 360, 7),)),                   # five channels, angle 0 NOT asked for (slot 0 must stay untouched)
+])
+def test_sweep_table_small_and_many_channel_calls(pkg, n_chn, n, passes):
+    """The sweep's per-launch scratch table and merge kernel (one value per angle, workgroup and wave; the raw peak of angle 0
+    riding along in the loaders) at shapes the long-file tests do not reach: more channels than two, inputs shorter than
+    one step, calls that ask for angle 0 alone or not at all.  Against the oracle (1e-3 dB, angle 0 exact)."""
+    P = 2048
+    x = np.ascontiguousarray(np.stack([0.5 * harmonic_stack(n, 48000) * (0.4 + 0.1 * c) + 0.02 * xorshift_uniform(n, seed=40 + c)
+                                       for c in range(n_chn)], 1), np.float32)
+    g = pkg.PhaseRotate(P, n_chn)
+    o = orc.CliEngine(P, n_chn)
+    asked = set()
+    for a0, a1, st in passes:
+        g.analyze_file(x, a0, a1, st)
+        o.analyze_file(x, a0, a1, st)
+        a = a0
+        while a <= a1:           # the loop bounds of cli/phase-rotate.cc:409-428
+            asked.add(((a % 360) + 360) % 360)
+            a += st
+            if a >= a1:
+                break
+    tab = np.array([[g.peak(c, a) for a in range(360)] for c in range(n_chn)], np.float32)
+    ref = o.peaks()
+    g.close()
+    for a in range(360):
+        if a not in asked:
+            assert (tab[:, a] == 0).all(), a            # untouched slots stay untouched
+    swept = sorted(a for a in asked if a != 0)
+    if 0 in asked:
+        assert tab[:, 0].tobytes() == ref[:, 0].astype(np.float32).tobytes()  # the raw peak: exact
+        assert (tab[:, 0] > 0).all()
+    if swept:
+        assert (tab[:, swept] > 0).all()
+        d_db = np.abs(20 * np.log10(tab[:, swept] / ref[:, swept]))
+        assert d_db.max() < 1e-3, d_db.max()
+
+
 @pytest.mark.parametrize("stride", [70004, 70003])
 @pytest.mark.parametrize("kind,param", [(1, 48000), (1, 96000), (0, 1024), (0, 8192)])
 def test_many_channels_equal_independent_mono_streams(pkg, kind, param, stride):
