@@ -1286,6 +1286,8 @@ int prot_apply_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		                     /*advance_hist*/ true, rot, wp);
 		if (rc == PROT_OK) {
 			e->pos += n_in;
+		} else {
+			e->pipe_gen--; // nothing was launched: the generation must not be waited for by the next launch
 		}
 		return rc;
 	}
