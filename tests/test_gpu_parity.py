@@ -721,6 +721,61 @@ def test_sweep_table_small_and_many_channel_calls(pkg, n_chn, n, passes):
         assert d_db.max() < 1e-3, d_db.max()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_sweep_random_shapes_against_oracle_and_unpruned(pkg, seed):
+    """Randomised: block size, channel count, length (1 frame ... 150 000), angle range and stride, signal shape per channel
+    (noise, tone, growing tone, bursts in silence, level steps, DC), one or two passes.  The pruned table must equal the
+    unpruned one bit for bit and the oracle's within 1e-3 dB, the raw peak (angle 0) exactly.  (tools/sweep_fuzz.py is the
+    long-running pruned-vs-unpruned version of this.)"""
+    rng = np.random.default_rng(seed)
+
+    def signal(n, nc):
+        t = np.arange(n)
+        x = np.zeros((n, nc), np.float32)
+        for c in range(nc):
+            kind, amp = rng.integers(0, 6), rng.uniform(0.05, 0.9)
+            if kind == 0:
+                x[:, c] = amp * (rng.random(n) - 0.5)
+            elif kind == 1:
+                x[:, c] = amp * np.sin(2 * np.pi * rng.uniform(0.001, 0.2) * t)
+            elif kind == 2:
+                x[:, c] = amp * np.sin(2 * np.pi * rng.uniform(0.001, 0.05) * t) * np.linspace(0.1, 1, n)
+            elif kind == 3:
+                for _ in range(rng.integers(1, 6)):
+                    a = rng.integers(0, n)
+                    b = min(n, a + rng.integers(1, 5000))
+                    x[a:b, c] = amp * (rng.random(b - a) - 0.5)
+            elif kind == 4:
+                lev = rng.uniform(0.01, 1.0, 8)
+                x[:, c] = lev[np.minimum(t * 8 // max(n, 1), 7)] * 0.5 * np.sign(np.sin(2 * np.pi * 0.01 * t) + 1e-9) + 0.01 * (rng.random(n) - 0.5)
+            else:
+                x[:, c] = amp * 0.25
+        return np.ascontiguousarray(x)
+
+    for k in range(14):
+        P = int(rng.choice([1024, 2048, 2048, 4096, 8192]))
+        nc = int(rng.choice([1, 2, 2, 3]))
+        n = int(rng.choice([rng.integers(1, 3000), rng.integers(3000, 150000)]))
+        st = int(rng.choice([1, 2, 3, 5, 8, 24]))
+        a0 = int(rng.choice([0, 0, 1, rng.integers(0, 300)]))
+        a1 = int(min(360, a0 + rng.choice([1, 40, 100, 360])))
+        x = signal(n, nc)
+        passes = ((a0, a1, st),) if k % 3 else ((a0, a1, st), (max(0, a0 - 7), min(360, a1 + 9), 1))
+        a, _ = _sweep_table(pkg, x, P, st, prune=True, passes=passes)
+        b, _ = _sweep_table(pkg, x, P, st, prune=False, passes=passes)
+        assert a.tobytes() == b.tobytes(), (seed, k, P, nc, n, passes)
+        o = orc.CliEngine(P, nc)
+        for q0, q1, qs in passes:
+            o.analyze_file(x, q0, q1, qs)
+        ref = o.peaks().astype(np.float32)
+        assert a[:, 0].tobytes() == ref[:, 0].tobytes(), (seed, k, "raw peak")
+        nz = ref[:, 1:] > 1e-12
+        assert ((a[:, 1:] > 0) == (ref[:, 1:] > 0)).all(), (seed, k, "touched slots")
+        if nz.any():
+            d_db = np.abs(20 * np.log10(a[:, 1:][nz] / ref[:, 1:][nz]))
+            assert d_db.max() < 1e-3, (seed, k, P, nc, n, passes, float(d_db.max()))
+
+
 @pytest.mark.parametrize("stride", [70004, 70003])
 @pytest.mark.parametrize("kind,param", [(1, 48000), (1, 96000), (0, 1024), (0, 8192)])
 def test_many_channels_equal_independent_mono_streams(pkg, kind, param, stride):
