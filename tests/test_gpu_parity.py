@@ -721,6 +721,47 @@ def test_sweep_table_small_and_many_channel_calls(pkg, n_chn, n, passes):
         assert d_db.max() < 1e-3, d_db.max()
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_overlap_save_equals_overlap_add_on_random_chunkings(pkg, seed):
+    """Two independent kernels for the same filter -- the generated overlap-save loop (default) and the overlap-add kernel
+    with its spectrum table (PROT_CFG_OVERLAP_ADD) -- fed the same stream in random stateful chunks (1 frame ... 300 000),
+    random channel counts, odd and even row strides (the aligned and the frame-by-frame paths), steady rotation and the
+    Hilbert-only mode: the two must agree to 2e-6 everywhere, and each must equal its own one-shot stateless pass bit for
+    bit where the chunk boundaries allow the same block cuts (checked as <= 2e-6 as well: cuts differ)."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(seed)
+    kind, param = [(pkg.KIND_LV2, 48000), (pkg.KIND_LV2, 96000), (pkg.KIND_CLI, 2048), (pkg.KIND_CLI, 4096)][seed % 4]
+    nc = int(rng.integers(1, 4))
+    n = int(rng.integers(200_000, 900_000))
+    stride = n + int(rng.integers(0, 9))
+    x = torch.from_numpy(xorshift_uniform(nc * stride + 1, seed=seed)).to(dev)[1 if seed % 2 else 0:][:nc * stride]
+    rot = np.array([[np.cos(0.7 * c + 0.1), np.sin(0.7 * c + 0.1)] for c in range(nc)], np.float32).reshape(-1)
+    hil = (pkg.F_HILBERT if seed % 3 == 0 else 0)
+    cuts = [0]
+    while cuts[-1] < n:
+        cuts.append(min(n, cuts[-1] + int(rng.choice([1, 2, 63, 1024, 4096, 5121, 70001, 300000]))))
+    outs = []
+    for flags in (0, pkg.CFG_OVERLAP_ADD):
+        e = pkg.Engine(kind, param, nc, flags=flags)
+        assert e.info.form == (pkg.FORM_POLY_SAVE if flags == 0 else pkg.FORM_POLY_OLA)
+        y = torch.zeros(nc * stride, device=dev)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            e.apply_dev(x.data_ptr() + 4 * a, stride, b - a, y.data_ptr() + 4 * a, stride, b - a, rot, hil)
+        e.sync()
+        y1 = torch.zeros(nc * stride, device=dev)
+        e.reset()
+        e.apply_dev(x.data_ptr(), stride, n, y1.data_ptr(), stride, n, rot, hil | pkg.F_STATELESS)
+        e.sync()
+        torch.cuda.synchronize()
+        yy = y.cpu().numpy().reshape(nc, stride)[:, :n]
+        assert np.abs(yy - y1.cpu().numpy().reshape(nc, stride)[:, :n]).max() < 2e-6
+        outs.append(yy)
+        e.close()
+    assert np.abs(outs[0]).max() > 0.05
+    assert np.abs(outs[0] - outs[1]).max() < 2e-6, (kind, param, nc, n, stride, len(cuts))
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_sweep_random_shapes_against_oracle_and_unpruned(pkg, seed):
     """Randomised: block size, channel count, length (1 frame ... 150 000), angle range and stride, signal shape per channel
