@@ -221,7 +221,14 @@ int prot_cli_analyze (prot_engine* e, const float* buf, int ang_start, int ang_e
                       int ang_stride, int chn, int start);
 
 /* analyze_file (cli/phase-rotate.cc:565-587) on an in-memory interleaved
- * float file: whole-file device pass (upload, de-interleave, sweep). */
+ * float file: whole-file device pass (upload, de-interleave, sweep).
+ *
+ * prot_cli_file_resident (e, 1): the engine keeps the de-interleaved file in device memory after the first
+ * prot_cli_analyze_file of a (data, n_frames) pair, and later calls with the same pair sweep the resident copy without
+ * touching the host link (the reference re-reads the file for every pass of its search, cli/phase-rotate.cc:815-929;
+ * the upload is 10-40 x the sweep).  The caller promises not to change the file's samples in between; (e, 0) drops the
+ * copy and the promise.  Files that do not fit (> 1/4 of the device's memory) stream as before. */
+int prot_cli_file_resident (prot_engine* e, int on);
 int prot_cli_analyze_file (prot_engine* e, const float* data, uint64_t n_frames,
                            int ang_start, int ang_end, int ang_stride, int chn);
 

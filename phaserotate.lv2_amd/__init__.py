@@ -39,7 +39,7 @@ ABI_SYMBOLS = (
     "prot_lv2_run", "prot_lv2_set_max_block", "prot_lv2_get_angle", "prot_cli_apply", "prot_cli_analyze", "prot_cli_analyze_file",
     "prot_cli_apply_file", "prot_cli_peak", "prot_cli_peak_all", "prot_cli_peaks",
     "prot_cli_peaks_dev", "prot_allreduce_peaks", "prot_cli_analyze_file_multi", "prot_sweep_stats",
-    "prot_sweep_stats_ex",
+    "prot_sweep_stats_ex", "prot_cli_file_resident",
 )
 
 
@@ -120,6 +120,7 @@ def load_library():
     lib.prot_lv2_get_angle.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
     lib.prot_sweep_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.prot_sweep_stats_ex.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.prot_cli_file_resident.argtypes = [C.c_void_p, C.c_int]
     lib.prot_cli_apply.argtypes = [C.c_void_p, _f32p, _i32p]
     lib.prot_cli_analyze.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.prot_cli_analyze_file.argtypes = [C.c_void_p, _f32p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -298,6 +299,10 @@ class PhaseRotate(Engine):
         data = np.ascontiguousarray(data, np.float32).reshape(-1)
         _check(self._lib.prot_cli_analyze_file(self._h, data, data.size // self.n_chn, ang_start,
                                                ang_end, ang_stride, chn), "prot_cli_analyze_file")
+
+    def file_resident(self, on=True):
+        """prot_cli_file_resident: keep the de-interleaved file of analyze_file on the device between passes."""
+        _check(self._lib.prot_cli_file_resident(self._h, 1 if on else 0), "prot_cli_file_resident")
 
     def apply_file(self, data, angles, out=None):
         data = np.ascontiguousarray(data, np.float32).reshape(-1)

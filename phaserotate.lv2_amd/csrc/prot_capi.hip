@@ -332,6 +332,11 @@ struct prot_engine {
 	// whole-file calls: two sets of staging buffers, a copy stream and events, so that chunk k+1 is uploaded and
 	// de-interleaved while chunk k is swept (cli/phase-rotate.cc:565-587 reads and analyses block by block)
 	DevBuf<float>  d_inter_b, d_in_b;
+	// prot_cli_file_resident: the de-interleaved file of the last prot_cli_analyze_file, [n_chn][file_n] planar
+	bool           file_resident = false;
+	DevBuf<float>  d_file;
+	const float*   file_key = nullptr;
+	uint64_t       file_n   = 0, file_stride = 0; // (rows 256-byte aligned: the same aligned paths as the staged chunks)
 	hipStream_t    copy_stream = nullptr;
 	hipEvent_t     ev_copied[2] = {}, ev_free[2] = {};
 	std::vector<int> angles_last;          // what d_angles holds, uploaded on angles_stream
@@ -1151,6 +1156,7 @@ void prot_engine_destroy (prot_engine* e)
 	e->d_u.release ();
 	e->d_inter.release ();
 	e->d_inter_b.release ();
+	e->d_file.release ();
 	e->d_in_b.release ();
 	for (int i = 0; i < 2; ++i) {
 		if (e->ev_copied[i]) {
@@ -1936,10 +1942,57 @@ int prot_cli_analyze_file (prot_engine* e, const float* data, uint64_t n_frames,
 	const uint32_t nc = e->info.n_chn;
 	const uint64_t P  = e->info.blksiz;
 	hipStream_t    s  = pick_stream (e, nullptr);
-	(void)nc;
 	(void)P;
-	(void)s;
+	if (e->file_resident && n_frames > 0) {
+		size_t free_b = 0, total_b = 0;
+		const size_t need = (size_t)n_frames * nc * sizeof (float);
+		const bool   have = e->file_key == data && e->file_n == n_frames && e->d_file.p != nullptr;
+		if (have || (hipMemGetInfo (&free_b, &total_b) == hipSuccess && need <= total_b / 4 && 3 * need <= free_b)) {
+			if (!have) {
+				// upload once: chunks through the interleaved staging buffer, de-interleaved straight into the planar copy
+				const uint64_t chunk = file_chunk_frames (e);
+				e->file_stride       = (n_frames + 63) & ~(uint64_t)63;
+				int            rc    = e->d_file.ensure ((size_t)e->file_stride * nc);
+				if (rc == PROT_OK) {
+					rc = e->d_inter.ensure (std::min<uint64_t> (chunk, n_frames) * nc);
+				}
+				if (rc) {
+					return rc;
+				}
+				e->file_key = nullptr;
+				for (uint64_t pos = 0; pos < n_frames; pos += chunk) {
+					const uint64_t n = std::min (chunk, n_frames - pos);
+					HIP_TRY (hipMemcpyAsync (e->d_inter.p, data + pos * nc, n * nc * sizeof (float), hipMemcpyHostToDevice, s));
+					hipError_t err = prot::launch_deinterleave (e->d_inter.p, e->d_file.p + pos, (int64_t)e->file_stride, (int64_t)n, (int)nc, s);
+					if (err != hipSuccess) {
+						return hip_fail (err, "deinterleave launch");
+					}
+				}
+				e->file_key = data;
+				e->file_n   = n_frames;
+			}
+			return prot_sweep_dev (e, e->d_file.p, (int64_t)e->file_stride, n_frames, ang_start, ang_end, ang_stride, chn, nullptr,
+			                       PROT_F_STREAM_START | PROT_F_STREAM_END, s);
+		}
+	}
 	return analyze_range (e, data, 0, n_frames, true, true, ang_start, ang_end, ang_stride, chn);
+}
+
+int prot_cli_file_resident (prot_engine* e, int on)
+{
+	if (!e || e->info.kind != PROT_KIND_CLI) {
+		return PROT_EINVAL;
+	}
+	HIP_TRY (hipSetDevice (e->device));
+	e->file_resident = on != 0;
+	if (!on) {
+		(void)join_pipe (e, e->stream);
+		HIP_TRY (hipStreamSynchronize (e->stream));
+		e->d_file.release ();
+		e->file_key = nullptr;
+		e->file_n   = 0;
+	}
+	return PROT_OK;
 }
 
 // ------------------------------------------------------------------ several GPUs
@@ -2209,17 +2262,23 @@ int prot_cli_apply_file (prot_engine* e, const float* data, uint64_t n_frames, c
 		rot[2 * c]     = g_lut[2 * a + 1];
 		rot[2 * c + 1] = g_lut[2 * a];
 	}
-	uint64_t pos = 0;
+	const bool resident = e->file_resident && e->file_key == data && e->file_n == n_frames && e->d_file.p != nullptr;
+	uint64_t   pos      = 0;
 	while (pos < n_frames) {
 		const uint64_t n     = std::min (chunk, n_frames - pos);
 		const bool     last  = pos + n >= n_frames;
 		const uint64_t n_out = n + (last ? lat : 0); // flush: latency frames of silence in (:993-1001)
-		HIP_TRY (hipMemcpyAsync (e->d_inter.p, data + pos * nc, n * nc * sizeof (float), hipMemcpyHostToDevice, s));
-		hipError_t err = prot::launch_deinterleave (e->d_inter.p, e->d_in.p, (int64_t)cap, (int64_t)n, (int)nc, s);
-		if (err != hipSuccess) {
-			return hip_fail (err, "deinterleave launch");
+		hipError_t err = hipSuccess;
+		if (resident) { // the de-interleaved file is on the device already (prot_cli_file_resident): no upload
+			rc = prot_apply_dev (e, e->d_file.p + pos, (int64_t)e->file_stride, n, e->d_out.p, (int64_t)cap, n_out, rot.data (), 0, s);
+		} else {
+			HIP_TRY (hipMemcpyAsync (e->d_inter.p, data + pos * nc, n * nc * sizeof (float), hipMemcpyHostToDevice, s));
+			err = prot::launch_deinterleave (e->d_inter.p, e->d_in.p, (int64_t)cap, (int64_t)n, (int)nc, s);
+			if (err != hipSuccess) {
+				return hip_fail (err, "deinterleave launch");
+			}
+			rc = prot_apply_dev (e, e->d_in.p, (int64_t)cap, n, e->d_out.p, (int64_t)cap, n_out, rot.data (), 0, s);
 		}
-		rc = prot_apply_dev (e, e->d_in.p, (int64_t)cap, n, e->d_out.p, (int64_t)cap, n_out, rot.data (), 0, s);
 		if (rc) {
 			return rc;
 		}

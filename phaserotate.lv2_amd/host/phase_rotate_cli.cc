@@ -482,7 +482,15 @@ int main (int argc, char** argv)
 		if (opt.verbose > 1) {
 			fprintf (vfd, "Analyzing using %d process threads, stride = %d\n", n_chn, opt.stride);
 		}
+		if (gpus.size () == 1 && getenv ("PROT_CLI_NO_RESIDENT") == nullptr) {
+			// the search re-analyses the whole file once per candidate (cli/phase-rotate.cc:815-929); the samples do not
+			// change in between: the engine keeps its de-interleaved copy on the device and only the first pass uploads
+			gpu_call (prot_cli_file_resident (pr, 1), "resident file");
+		}
 		const Result res = find_minimum (gpus, file, n_frames, n_chn, opt, vfd);
+		if (gpus.size () == 1 && !opt.out_path) {
+			gpu_call (prot_cli_file_resident (pr, 0), "resident file");
+		}
 		angles           = res.angle;
 		if (!opt.out_path || opt.verbose) {
 			print_result (res, n_chn, vfd);

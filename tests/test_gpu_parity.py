@@ -721,6 +721,37 @@ def test_sweep_table_small_and_many_channel_calls(pkg, n_chn, n, passes):
         assert d_db.max() < 1e-3, d_db.max()
 
 
+@pytest.mark.parametrize("blksiz,n_chn,n", [(2048, 2, 1 << 23), (8192, 1, 5_000_003), (1024, 3, 777), (2048, 3, 600_001)])
+def test_resident_file_passes_equal_streamed_ones(pkg, blksiz, n_chn, n):
+    """prot_cli_file_resident: after the first analyze_file of a file the engine sweeps its de-interleaved device copy; a
+    coarse pass, a fine pass and a pass over another file (new pointer: uploaded afresh) must leave the same table, bit for
+    bit, as an engine that streams the file from the host every time (two device chunks at the first shape)."""
+    x = np.ascontiguousarray(np.stack([0.5 * harmonic_stack(n, 48000) * (0.5 + 0.2 * c) + 0.03 * xorshift_uniform(n, seed=60 + c)
+                                       for c in range(n_chn)], 1), np.float32)
+    y = np.ascontiguousarray(x[::-1] * 0.9)
+    tabs = []
+    for resident in (False, True):
+        g = pkg.PhaseRotate(blksiz, n_chn)
+        if resident:
+            g.file_resident(True)
+        out = []
+        for data, (a0, a1, st) in ((x, (0, 360, 24)), (x, (100, 140, 1)), (y, (0, 360, 8)), (x, (0, 360, 3))):
+            g.reset()
+            g.analyze_file(data, a0, a1, st)
+            out.append(np.array([[g.peak(c, a) for a in range(360)] for c in range(n_chn)], np.float32))
+        g.reset()
+        out.append(g.apply_file(x, [37 + 5 * c for c in range(n_chn)]).copy())  # (resident: the input is not uploaded again)
+        if resident:
+            g.file_resident(False)
+            g.reset()
+            g.analyze_file(x, 0, 360, 24)   # streams again
+            assert np.array([[g.peak(c, a) for a in range(360)] for c in range(n_chn)], np.float32).tobytes() == out[0].tobytes()
+        g.close()
+        tabs.append(out)
+    for a, b in zip(*tabs):
+        assert a.max() > 0 and a.tobytes() == b.tobytes()
+
+
 @pytest.mark.parametrize("seed", [11, 12, 13, 14])
 def test_overlap_save_equals_overlap_add_on_random_chunkings(pkg, seed):
     """Two independent kernels for the same filter -- the generated overlap-save loop (default) and the overlap-add kernel

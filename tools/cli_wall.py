@@ -28,8 +28,15 @@ bps = bits // 8
 hdr = b"RIFF" + struct.pack("<I", 36 + len(raw)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, tag, chn, rate, rate * bps * chn, bps * chn, bits) + b"data" + struct.pack("<I", len(raw))
 open(path, "wb").write(hdr + raw)
 print("file: %.1f min stereo 96 kHz %s, %.0f MB" % (minutes, kind, (len(raw) + 44) / 1e6))
-env = dict(os.environ, PROT_CLI_TIMING="1")
-for args, what in (([CLI, "-s", "1", path], "analysis only (-s 1)"), ([CLI, "-s", "1", path, out], "analysis + apply + write")):
+env0 = dict(os.environ, PROT_CLI_TIMING="1")
+runs = [([CLI, "-s", "1", path], "analysis only (-s 1)", {}),
+        ([CLI, path], "analysis only, default stride (coarse pass + fine passes: the file is re-analysed per candidate)", {}),
+        ([CLI, path], "same, file streamed from the host for every pass (PROT_CLI_NO_RESIDENT=1)", {"PROT_CLI_NO_RESIDENT": "1"}),
+        ([CLI, "-s", "1", path, out], "analysis + apply + write", {}),
+        ([CLI, "-s", "1", path, out], "analysis + apply + write, file streamed from the host (PROT_CLI_NO_RESIDENT=1)", {"PROT_CLI_NO_RESIDENT": "1"}),
+        ([CLI, "-s", "1", path, out], "analysis + apply + write (again)", {})]
+for args, what, extra in runs:
+    env = dict(env0, **extra)
     t0 = time.perf_counter()
     r = subprocess.run(args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     w = time.perf_counter() - t0
