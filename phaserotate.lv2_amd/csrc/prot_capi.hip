@@ -1500,8 +1500,11 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		return rc;
 	}
 	const float* hist_old = e->d_hist[e->hist_cur].p; // stays intact: the launch writes the next buffer of the ring
+	// (the launch also advances the input history -- fused into the kernel when all channels are swept, a small launch behind
+	// it otherwise: state step 4 of the reference, the reference has consumed the data blocks; the sweep below still reads
+	// the buffer of the ring that was current on entry)
 	rc = ola_launch (e, d_in, in_stride, n_frames, e->d_u.p, (int64_t)ustride, n_out, nullptr, nullptr, true,
-	                 false, c0, nc, s);
+	                 false, c0, nc, s, /*advance_hist*/ true);
 	if (rc) {
 		return rc;
 	}
@@ -1558,11 +1561,8 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 			return hip_fail (err, "absmax kernel launch");
 		}
 	}
-	// 4. state: the reference has consumed nb blocks (zero padding included)
-	rc = hist_advance (e, d_in, in_stride, n_frames, c0, nc, s);
-	if (rc) {
-		return rc;
-	}
+	// 4. state: the reference has consumed nb blocks (zero padding included): the data frames went into the history with
+	// the Hilbert launch above
 	if (n_out > n_frames) {
 		// padding/flush frames are silence that also entered the history
 		const uint64_t extra = n_out - n_frames;
