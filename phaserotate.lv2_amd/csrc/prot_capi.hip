@@ -384,15 +384,21 @@ namespace {
 
 int zero_state (prot_engine* e)
 {
+	// one launch: the history buffer that becomes current (the others of the ring are written in full before they are
+	// read), the peak table, the sweep statistics, the half-precision history that becomes current
 	const size_t hn = (size_t)e->info.history * e->info.n_chn;
-	for (int i = 0; i < prot_engine::kHist; ++i) {
-		HIP_TRY (hipMemsetAsync (e->d_hist[i].p, 0, hn * sizeof (float), e->stream));
-	}
-	HIP_TRY (hipMemsetAsync (e->d_peaks.p, 0, (size_t)PROT_MAXSAMPLE * e->info.n_chn * sizeof (float), e->stream));
-	HIP_TRY (hipMemsetAsync (e->d_stats.p, 0, 4 * sizeof (unsigned long long), e->stream));
-	if (e->d_hist16[0].p) {
-		HIP_TRY (hipMemsetAsync (e->d_hist16[0].p, 0, hn * sizeof (uint16_t), e->stream));
-		HIP_TRY (hipMemsetAsync (e->d_hist16[1].p, 0, hn * sizeof (uint16_t), e->stream));
+	prot::ZeroRegions z {};
+	z.p[0] = reinterpret_cast<uint32_t*> (e->d_hist[0].p);
+	z.n[0] = hn;
+	z.p[1] = reinterpret_cast<uint32_t*> (e->d_peaks.p);
+	z.n[1] = (size_t)PROT_MAXSAMPLE * e->info.n_chn;
+	z.p[2] = reinterpret_cast<uint32_t*> (e->d_stats.p);
+	z.n[2] = 4 * sizeof (unsigned long long) / sizeof (uint32_t);
+	z.p[3] = reinterpret_cast<uint32_t*> (e->d_hist16[0].p);
+	z.n[3] = e->d_hist16[0].p ? (hn + 1) / 2 : 0;
+	hipError_t err = prot::launch_zero_regions (z, e->stream);
+	if (err != hipSuccess) {
+		return hip_fail (err, "state reset launch");
 	}
 	e->hist16_cur    = 0;
 	e->hist_cur      = 0;

@@ -130,6 +130,13 @@ hipError_t launch_hist_update_f16 (const _Float16* in, int64_t in_stride, int64_
                                    const _Float16* hist_in, _Float16* hist_out, int hist_len,
                                    int n_chn, hipStream_t s);
 
+// up to four regions of 32-bit words zeroed by ONE launch (prot_engine_reset: the separate memsets were 8 launches, ~60 us)
+struct ZeroRegions {
+	uint32_t* p[4];
+	uint64_t  n[4]; // words
+};
+hipError_t launch_zero_regions (const ZeroRegions& z, hipStream_t s);
+
 // interleaved [n][n_chn] <-> planar [n_chn][stride]
 hipError_t launch_deinterleave (const float* inter, float* planar, int64_t stride, int64_t n,
                                 int n_chn, hipStream_t s);

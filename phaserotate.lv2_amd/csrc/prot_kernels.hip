@@ -1700,6 +1700,29 @@ hipError_t launch_absmax (const float* x, int64_t x_stride, int64_t n, float* pe
 }
 
 // ------------------------------------------------------------ small movers
+__global__ __launch_bounds__ (256) void zero_regions_kernel (const ZeroRegions z)
+{
+	uint32_t* const q = z.p[blockIdx.y];
+	const uint64_t  n = z.n[blockIdx.y];
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+		q[i] = 0u;
+	}
+}
+
+hipError_t launch_zero_regions (const ZeroRegions& z, hipStream_t s)
+{
+	uint64_t most = 0;
+	for (int i = 0; i < 4; ++i) {
+		most = std::max (most, z.p[i] ? z.n[i] : 0);
+	}
+	if (most == 0) {
+		return hipSuccess;
+	}
+	const dim3 grid ((unsigned)std::min<uint64_t> ((most + 255) / 256, 512), 4), block (256);
+	hipLaunchKernelGGL (zero_regions_kernel, grid, block, 0, s, z);
+	return hipGetLastError ();
+}
+
 template <class S>
 __global__ void hist_update_kernel (const S* __restrict__ in, int64_t in_stride, int64_t n_in,
                                     const S* __restrict__ hist_in, S* __restrict__ hist_out,
