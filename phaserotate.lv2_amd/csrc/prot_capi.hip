@@ -1103,7 +1103,8 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	    hipMemcpy (e->d_lut.p, g_lut, sizeof (g_lut), hipMemcpyHostToDevice) != hipSuccess) {
 		return fail (PROT_EHIP);
 	}
-	if (zero_state (e) != PROT_OK || hipStreamSynchronize (e->stream) != hipSuccess) {
+	if (hipMemset (e->d_thr.p, 0, 4 * (size_t)inf.n_chn * sizeof (float)) != hipSuccess || zero_state (e) != PROT_OK ||
+	    hipStreamSynchronize (e->stream) != hipSuccess) {
 		return fail (PROT_EHIP);
 	}
 
@@ -1554,7 +1555,7 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		sp.part_floats = prot::sweep_scratch_floats ();
 		sp.raw_slot    = raw0 ? 0 : -1; // the raw peak rides along with the sweep (no pass of its own over the input)
 		// bounds are per launch: they refer to THIS call's angle set
-		HIP_TRY (hipMemsetAsync (e->d_thr.p, 0, 4 * (size_t)e->info.n_chn * sizeof (float), s));
+		// (p.thr is all zeros here: zeroed once when the engine was created, and again by every launch's merge kernel)
 		hipError_t err = prot::launch_sweep (sp, nc, s);
 		if (err != hipSuccess) {
 			return hip_fail (err, "sweep kernel launch");
@@ -1580,13 +1581,11 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		if (nc != (int)e->info.n_chn) {
 			HIP_TRY (hipMemcpyAsync (hout, hin, (size_t)H * e->info.n_chn * sizeof (float), hipMemcpyDeviceToDevice, s));
 		}
-		for (int c = c0; c < c0 + nc; ++c) {
-			const uint64_t keep = extra >= (uint64_t)H ? 0 : (uint64_t)H - extra;
-			if (keep) {
-				HIP_TRY (hipMemcpyAsync (hout + (size_t)c * H, hin + (size_t)c * H + (H - keep), keep * sizeof (float),
-				                         hipMemcpyDeviceToDevice, s));
-			}
-			HIP_TRY (hipMemsetAsync (hout + (size_t)c * H + keep, 0, ((size_t)H - keep) * sizeof (float), s));
+		// (one small launch: hout[c][i] = [hin | silence](extra + i), the input being empty)
+		hipError_t herr = prot::launch_hist_update (hin + (size_t)c0 * H, (int64_t)H, 0, hin + (size_t)c0 * H, hout + (size_t)c0 * H, H, nc, s,
+		                                            (int64_t)std::min<uint64_t> (extra, (uint64_t)H));
+		if (herr != hipSuccess) {
+			return hip_fail (herr, "history shift launch");
 		}
 		e->hist_cur = (cur + 1) % prot_engine::kHist;
 	}

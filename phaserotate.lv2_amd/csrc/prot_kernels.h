@@ -109,7 +109,7 @@ struct SweepParams {
 	float*       peaks;       // device, [n_chn][360], max-accumulated
 	int32_t      chn0;        // first channel handled by blockIdx.y = 0
 	int32_t      prune;       // evaluate only the frames that can still raise a maximum (exact; see prot_sweep.hip)
-	float*       thr;         // device, [n_chn][4], ZEROED before the launch: shared pruning bounds, or NULL
+	float*       thr;         // device, [n_chn][4], all zeros at launch (the merge kernel of every launch leaves it so): shared pruning bounds, or NULL
 	int32_t      raw_slot;    // >= 0: also max |x| over the frames the launch reads -> peaks[c][raw_slot] (angle 0, Q4); -1: no
 	float*       part;        // device scratch, >= sweep_scratch_floats () floats: per-workgroup maxima of one launch (merged into peaks)
 	size_t       part_floats;
@@ -122,10 +122,11 @@ size_t     sweep_scratch_floats ();
 hipError_t launch_absmax (const float* x, int64_t x_stride, int64_t n, float* peaks, int slot,
                           int chn0, int n_chn, hipStream_t s);
 
-// hist_out[c][i] = virtual(n_in - hist_len + i), virtual = [hist_in | in | silence]
+// hist_out[c][i] = virtual(n_in + shift - hist_len + i), virtual = [hist_in | in | silence]  (shift: frames of silence that
+// followed the input, e.g. the zero padding and the flush block of a file's last chunk)
 hipError_t launch_hist_update (const float* in, int64_t in_stride, int64_t n_in,
                                const float* hist_in, float* hist_out, int hist_len,
-                               int n_chn, hipStream_t s);
+                               int n_chn, hipStream_t s, int64_t shift = 0);
 hipError_t launch_hist_update_f16 (const _Float16* in, int64_t in_stride, int64_t n_in,
                                    const _Float16* hist_in, _Float16* hist_out, int hist_len,
                                    int n_chn, hipStream_t s);

@@ -1726,22 +1726,22 @@ hipError_t launch_zero_regions (const ZeroRegions& z, hipStream_t s)
 template <class S>
 __global__ void hist_update_kernel (const S* __restrict__ in, int64_t in_stride, int64_t n_in,
                                     const S* __restrict__ hist_in, S* __restrict__ hist_out,
-                                    int hist_len)
+                                    int hist_len, int64_t shift)
 {
 	const int c = blockIdx.y;
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < hist_len) {
 		hist_out[(int64_t)c * hist_len + i] =
 		    (S)ldv (in + (int64_t)c * in_stride, n_in, hist_in + (int64_t)c * hist_len, hist_len,
-		            n_in - hist_len + i);
+		            n_in + shift - hist_len + i);
 	}
 }
 
 hipError_t launch_hist_update (const float* in, int64_t in_stride, int64_t n_in, const float* hist_in,
-                               float* hist_out, int hist_len, int n_chn, hipStream_t s)
+                               float* hist_out, int hist_len, int n_chn, hipStream_t s, int64_t shift)
 {
 	dim3 grid ((unsigned)((hist_len + 255) / 256), (unsigned)n_chn), block (256);
-	hipLaunchKernelGGL (hist_update_kernel<float>, grid, block, 0, s, in, in_stride, n_in, hist_in, hist_out, hist_len);
+	hipLaunchKernelGGL (hist_update_kernel<float>, grid, block, 0, s, in, in_stride, n_in, hist_in, hist_out, hist_len, shift);
 	return hipGetLastError ();
 }
 
@@ -1749,7 +1749,7 @@ hipError_t launch_hist_update_f16 (const _Float16* in, int64_t in_stride, int64_
                                    _Float16* hist_out, int hist_len, int n_chn, hipStream_t s)
 {
 	dim3 grid ((unsigned)((hist_len + 255) / 256), (unsigned)n_chn), block (256);
-	hipLaunchKernelGGL (hist_update_kernel<_Float16>, grid, block, 0, s, in, in_stride, n_in, hist_in, hist_out, hist_len);
+	hipLaunchKernelGGL (hist_update_kernel<_Float16>, grid, block, 0, s, in, in_stride, n_in, hist_in, hist_out, hist_len, (int64_t)0);
 	return hipGetLastError ();
 }
 

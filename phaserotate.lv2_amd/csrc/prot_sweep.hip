@@ -498,8 +498,11 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 // peaks[c][angle] = max (peaks[c][angle], max over the launch's workgroups and the waves that served the angle's block):
 // one thread per (angle slot, slice of workgroups), up to 64 slices -> at most 64 atomics per table entry
 __global__ __launch_bounds__ (64) void sweep_merge_kernel (const float* __restrict__ part, int n_wg, int n_angles, const int* __restrict__ angles,
-                                                             float* peaks, int chn0, int raw_slot)
+                                                             float* peaks, int chn0, int raw_slot, float* thr)
 {
+	if (thr != nullptr && blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x < 4) {
+		thr[(chn0 + blockIdx.y) * 4 + threadIdx.x] = 0.f; // the shared bounds of the launch that just ended: zero for the next one
+	}
 	const int idx = blockIdx.x * 64 + threadIdx.x;
 	if (idx > n_angles || (idx == n_angles && raw_slot < 0)) {
 		return;
@@ -565,7 +568,7 @@ hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s)
 		return err;
 	}
 	const dim3 mgrid ((unsigned)((p.n_angles + 1 + 63) / 64), (unsigned)n_chn, (unsigned)std::min<int64_t> (64, gx)); // (slices of workgroups)
-	hipLaunchKernelGGL (sweep_merge_kernel, mgrid, dim3 (64), 0, s, p.part, (int)gx, p.n_angles, p.angles, p.peaks, p.chn0, p.raw_slot);
+	hipLaunchKernelGGL (sweep_merge_kernel, mgrid, dim3 (64), 0, s, p.part, (int)gx, p.n_angles, p.angles, p.peaks, p.chn0, p.raw_slot, p.prune ? p.thr : nullptr);
 	return hipGetLastError ();
 }
 
