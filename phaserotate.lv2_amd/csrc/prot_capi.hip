@@ -345,6 +345,7 @@ struct prot_engine {
 	int            hist16_cur = 0;
 	DevBuf<int>    d_angles;
 	DevBuf<float>  d_thr;   // [n_chn][4] shared pruning bounds of one sweep launch
+	DevBuf<unsigned> d_ctr; // [n_chn][32][32] step counters of a sweep launch (zero between launches)
 	DevBuf<float>  d_part;  // per-workgroup maxima of one sweep launch (prot_sweep.hip), allocated by the first sweep
 	DevBuf<unsigned long long> d_stats; // {tiles evaluated, tiles seen, tiles untested, surviving frames} since the last reset
 	PinBuf<float>  h_io;
@@ -1088,7 +1089,7 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	    (rc = e->d_rot.ensure (2 * (size_t)inf.n_chn)) || (rc = e->d_hist[0].ensure (hn)) || (rc = e->d_hist[2].ensure (hn)) || (rc = e->d_hist[3].ensure (hn)) ||
 	    (use_poly && n_part <= 2 && ((rc = e->d_hist16[0].ensure (hn)) || (rc = e->d_hist16[1].ensure (hn)))) ||
 	    (rc = e->d_hist[1].ensure (hn)) || (rc = e->d_peaks.ensure ((size_t)PROT_MAXSAMPLE * inf.n_chn)) ||
-	    (rc = e->d_angles.ensure (PROT_MAXSAMPLE + 8)) || (rc = e->d_thr.ensure (4 * (size_t)inf.n_chn)) ||
+	    (rc = e->d_angles.ensure (PROT_MAXSAMPLE + 8)) || (rc = e->d_thr.ensure (4 * (size_t)inf.n_chn)) || (rc = e->d_ctr.ensure ((size_t)inf.n_chn * 32 * 32)) ||
 	    (rc = e->d_stats.ensure (4)) || (e->use_save && (rc = e->d_sv.ensure (sv_h.size ())))) {
 		return fail (rc);
 	}
@@ -1103,7 +1104,8 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	    hipMemcpy (e->d_lut.p, g_lut, sizeof (g_lut), hipMemcpyHostToDevice) != hipSuccess) {
 		return fail (PROT_EHIP);
 	}
-	if (hipMemset (e->d_thr.p, 0, 4 * (size_t)inf.n_chn * sizeof (float)) != hipSuccess || zero_state (e) != PROT_OK ||
+	if (hipMemset (e->d_thr.p, 0, 4 * (size_t)inf.n_chn * sizeof (float)) != hipSuccess ||
+	    hipMemset (e->d_ctr.p, 0, (size_t)inf.n_chn * 32 * 32 * sizeof (unsigned)) != hipSuccess || zero_state (e) != PROT_OK ||
 	    hipStreamSynchronize (e->stream) != hipSuccess) {
 		return fail (PROT_EHIP);
 	}
@@ -1179,6 +1181,7 @@ void prot_engine_destroy (prot_engine* e)
 	e->d_rot_s.release ();
 	e->d_angles.release ();
 	e->d_thr.release ();
+	e->d_ctr.release ();
 	e->d_part.release ();
 	e->d_stats.release ();
 	e->h_io.release ();
@@ -1551,6 +1554,7 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		if ((rc = e->d_part.ensure (prot::sweep_scratch_floats ())) != PROT_OK) {
 			return rc;
 		}
+		sp.ctr         = e->d_ctr.p;
 		sp.part        = e->d_part.p;
 		sp.part_floats = prot::sweep_scratch_floats ();
 		sp.raw_slot    = raw0 ? 0 : -1; // the raw peak rides along with the sweep (no pass of its own over the input)

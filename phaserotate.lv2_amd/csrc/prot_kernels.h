@@ -110,6 +110,8 @@ struct SweepParams {
 	int32_t      chn0;        // first channel handled by blockIdx.y = 0
 	int32_t      prune;       // evaluate only the frames that can still raise a maximum (exact; see prot_sweep.hip)
 	float*       thr;         // device, [n_chn][4], all zeros at launch (the merge kernel of every launch leaves it so): shared pruning bounds, or NULL
+	unsigned*    ctr;         // device, [n_chn][32][32] (32 counters per channel, one cache line each), all zeros at launch (the merge
+	                          // kernel leaves them so): the next step to hand out
 	int32_t      raw_slot;    // >= 0: also max |x| over the frames the launch reads -> peaks[c][raw_slot] (angle 0, Q4); -1: no
 	float*       part;        // device scratch, >= sweep_scratch_floats () floats: per-workgroup maxima of one launch (merged into peaks)
 	size_t       part_floats;

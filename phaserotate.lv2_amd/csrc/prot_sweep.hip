@@ -41,6 +41,7 @@ constexpr int kSteps  = 8;                // steps between two looks at the shar
 constexpr int kBatch  = kStage / 4;       // frames of a step each wave tests (4 groups of 64 = 8 tiles)
 constexpr int kRing   = 512;              // (d, h) entries of one wave's survivor ring: < 64 left over + one batch
 static_assert (kRing >= 64 + kBatch && (kRing & (kRing - 1)) == 0, "ring too small");
+constexpr unsigned kCtr = 32;             // step counters per channel (a cache line each): workgroup b draws from counter b mod kCtr
 constexpr int kPause0 = 2, kPauseMax = 256; // steps fed untested after a step on which > 7/8 of the frames survived: first, cap
 
 template <int NBLK, bool PRUNE>
@@ -208,15 +209,31 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 		thr_min = fminf (fminf (sh_thr[0], sh_thr[1]), fminf (sh_thr[2], sh_thr[3]));
 	}
 
-	// ---- the stream: steps of 1024 frames, grid-strided -- at any moment the workgroups of a channel read ONE dense
-	// window of the stream (grid x 4 KB per stream), which is what keeps DRAM pages open; with 8192-frame iterations cut
-	// into steps the same loads were spread over an 8 x wider window, one 4 KB piece in eight live at a time, and the
-	// bare stream (loads, stage, barrier, no work) ran at 2.4 TB/s.  A step's frames are loaded once per workgroup and
-	// parked in LDS, where all four waves test them; with every wave loading every frame itself (rounds 1-2) the loads
-	// in flight per CU were 4 x redundant.
-	const int64_t first_base = p.t_begin + (int64_t)blockIdx.x * kStage;
-	const int64_t stride     = (int64_t)gridDim.x * kStage;
-	const int     n_step     = first_base < p.t_end ? (int)((p.t_end - first_base + stride - 1) / stride) : 0;
+	// ---- the stream: steps of 1024 frames, handed out by a counter -- at any moment the workgroups of a channel read ONE
+	// dense window of the stream (what keeps DRAM pages open: with 8192-frame iterations cut into steps the same loads were
+	// spread over an 8 x wider window and the bare stream ran at 2.4 TB/s instead of 4.4), and no workgroup is left with
+	// steps to do when the others are done: the hardware serves the oldest wave first, so of the four workgroups of a CU
+	// the first dispatched runs ahead, and with a fixed share per workgroup (grid-stride) the CUs spent the last third of
+	// a launch with fewer and fewer workgroups to overlap.  seq (s) = the step this workgroup does as its s-th: fetched
+	// four steps ahead (the loads of step s + 3 go out during step s) by a wave that is not loading in that step, passed
+	// on through LDS; the counters are p.ctr[channel][kCtr], zero at launch (the merge kernel of every launch leaves it so).
+	// A step's frames are loaded once per workgroup and parked in LDS, where all four waves test them; with every wave
+	// loading every frame itself (rounds 1-2) the loads in flight per CU were 4 x redundant.
+	__shared__ unsigned sh_seq[8];
+	const unsigned  n_total = p.t_end > p.t_begin ? (unsigned)((p.t_end - p.t_begin + kStage - 1) / kStage) : 0u;
+	// (kCtr counters per channel, each on a cache line of its own, each handing out every kCtr-th step to the workgroups
+	// with that blockIdx.x mod kCtr: ONE counter serves its atomics one at a time -- 675 K of them made cfg4 9 ms instead of 3)
+	const unsigned  grp = blockIdx.x & (kCtr - 1);
+	unsigned* const ctr = p.ctr + ((size_t)c * kCtr + grp) * 32;
+	if (tid == 0) {
+		const unsigned b0 = atomicAdd (ctr, 4u);
+		sh_seq[0]         = kCtr * b0 + grp;
+		sh_seq[1]         = kCtr * (b0 + 1u) + grp;
+		sh_seq[2]         = kCtr * (b0 + 2u) + grp;
+		sh_seq[3]         = kCtr * (b0 + 3u) + grp;
+	}
+	__syncthreads ();
+	auto seq = [&] (int s) { return (unsigned)__builtin_amdgcn_readfirstlane ((int)sh_seq[s & 7]); };
 
 	// Loading is split by step parity: waves 0-1 bring in the odd steps, waves 2-3 the even ones, each wave half a step
 	// (512 frames: a lane four consecutive frames of each stream, twice -- dwordx4 loads).  At the start of step s the
@@ -233,13 +250,13 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 	// first on -- at a stream start t_begin - delay = 0; the last `delay` frames of a chunk that is not the last are seen
 	// by the next chunk as history, frames before a shard (primed history) belong to the same file -- beyond it zeros
 	float amax = 0.f;
-	auto locate = [&] (int s, int64_t& t0) { // first frame of my lane in step s; true: the whole step is plain stream
-		const int64_t base = first_base + (int64_t)s * stride;
+	auto locate = [&] (unsigned gs, int64_t& t0) { // gs: the step's number in the stream (seq of the local step) // first frame of my lane in step s; true: the whole step is plain stream
+		const int64_t base = p.t_begin + (int64_t)gs * kStage;
 		t0                 = base + ld_half + 4 * lane;
 		return (base + kStage <= p.t_end) && (base - p.delay >= 0) && (base + kStage - p.delay <= p.n_x) &&
 		       (base + p.t_abs0 >= p.dry_from);
 	};
-	auto request = [&] (int s) { // frames of step s -> dv, hv (plain stream only; the edges are fetched when they are parked)
+	auto request = [&] (unsigned s) { // frames of step s -> dv, hv (plain stream only; the edges are fetched when they are parked)
 		int64_t t0;
 		if (locate (s, t0)) {
 			typedef float f4u __attribute__ ((ext_vector_type (4), aligned (4)));
@@ -252,7 +269,7 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 			}
 		}
 	};
-	auto park = [&] (int buf, int s) { // frames of step s: dv, hv -> (d, h) pairs of the stage
+	auto park = [&] (int buf, unsigned s) { // frames of step s: dv, hv -> (d, h) pairs of the stage
 		int64_t t0;
 		if (locate (s, t0)) {
 #pragma unroll
@@ -287,37 +304,53 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 		}
 	};
 	// prologue: waves 2-3 fetch step 0 and park it (the only exposed latency), then request step 2; waves 0-1 request step 1
-	if (ld_par == 1) {
-		if (n_step > 0) {
-			request (0);
-			park (0, 0);
+	{
+		const unsigned g0 = seq (0), g1 = seq (1), g2 = seq (2);
+		if (ld_par == 1) {
+			if (g0 < n_total) {
+				request (g0);
+				park (0, g0);
+			}
+			if (g2 < n_total) {
+				request (g2);
+			}
+		} else if (g1 < n_total) {
+			request (g1);
 		}
-		if (n_step > 2) {
-			request (2);
-		}
-	} else if (n_step > 1) {
-		request (1);
 	}
 	__syncthreads ();
-	for (int s = 0; s < n_step; ++s) {
+	for (int s = 0;; ++s) {
+		const unsigned gs0 = seq (s), gs1 = seq (s + 1), gs3 = seq (s + 3); // this step, the one to park, the one to request
+		if (gs0 >= n_total) {
+			break;
+		}
 		const int buf = s & 1;
+		// the step after the ones that are known (s + 4): asked for by the first wave of the pair that does not load now
+		const bool asks = tid == ((s & 1) << 7 ^ 128);
+		unsigned   got  = 0u;
+		if (asks) {
+			got = kCtr * atomicAdd (ctr, 1u) + grp;
+		}
 		if ((s & 1) == ld_par) {
-			if (s + 1 < n_step) {
-				park (buf ^ 1, s + 1); // everybody finished reading that half of the stage before the barrier that ended step s - 1
+			if (gs1 < n_total) {
+				park (buf ^ 1, gs1); // everybody finished reading that half of the stage before the barrier that ended step s - 1
 			}
-			if (s + 3 < n_step) {
-				request (s + 3);
+			if (gs3 < n_total) {
+				request (gs3);
 			}
 		}
 		const float* const st = stage_s + buf * 2 * kStage; // d at st[f], h at st[kStage + f]
 		if (!PRUNE) {
 			if (!idle) {
-				for (int bi = sub; bi < kStage / kBatch; bi += nsub) {
-#pragma unroll
-					for (int tt = 0; tt < kBatch / 32; tt += 2) {
-						evaluate (st[kk * kStage + bi * kBatch + tt * 32 + j], st[kk * kStage + bi * kBatch + tt * 32 + 32 + j]);
-					}
+				// (one instance of the evaluation in a plain loop, like the pruned kernel's untested feed: unrolled it needs
+				// ~160 VGPRs, three waves per SIMD; at four the other waves cover the matrix core's latency just as well)
+#pragma unroll 1
+				for (int it = sub; it < kStage / 64; it += nsub) {
+					evaluate (st[kk * kStage + it * 64 + j], st[kk * kStage + it * 64 + 32 + j]);
 				}
+			}
+			if (asks) {
+				sh_seq[(s + 4) & 7] = got;
 			}
 			__syncthreads ();
 			continue;
@@ -416,6 +449,9 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 				sh_thr[w] = idle ? kBig : thr2;
 			}
 		}
+		if (asks) {
+			sh_seq[(s + 4) & 7] = got; // (not one of the three slots this step reads: s, s + 1, s + 3)
+		}
 		__syncthreads (); // everybody is done with this half of the stage and with the rings' drained entries
 		if (look) {
 			thr_min = fminf (fminf (sh_thr[0], sh_thr[1]), fminf (sh_thr[2], sh_thr[3]));
@@ -476,6 +512,10 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 	if (idle) {
 		return;
 	}
+	// (the lane's coordinates made opaque: the compiler otherwise carries what the prologue derived from them through the
+	// whole kernel for this one use -- seven VGPRs spilled at the 128 of four waves per SIMD)
+	int kk_e = kk, j_e = j;
+	asm volatile ("" : "+v"(kk_e), "+v"(j_e));
 #pragma unroll
 	for (int q = 0; q < NBLK; ++q) {
 #pragma unroll
@@ -486,9 +526,9 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 			v       = fmaxf (v, __shfl_xor (v, 4));
 			v       = fmaxf (v, __shfl_xor (v, 8));
 			v       = fmaxf (v, __shfl_xor (v, 16));
-			const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+			const int row = (r & 3) + 8 * (r >> 2) + 4 * kk_e;
 			const int idx = (g + q * G) * 32 + row;
-			if (j == 0 && g + q * G < nb && idx < p.n_angles) {
+			if (j_e == 0 && g + q * G < nb && idx < p.n_angles) {
 				part[idx] = v;
 			}
 		}
@@ -498,10 +538,15 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 // peaks[c][angle] = max (peaks[c][angle], max over the launch's workgroups and the waves that served the angle's block):
 // one thread per (angle slot, slice of workgroups), up to 64 slices -> at most 64 atomics per table entry
 __global__ __launch_bounds__ (64) void sweep_merge_kernel (const float* __restrict__ part, int n_wg, int n_angles, const int* __restrict__ angles,
-                                                             float* peaks, int chn0, int raw_slot, float* thr)
+                                                             float* peaks, int chn0, int raw_slot, float* thr, unsigned* ctr)
 {
-	if (thr != nullptr && blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x < 4) {
-		thr[(chn0 + blockIdx.y) * 4 + threadIdx.x] = 0.f; // the shared bounds of the launch that just ended: zero for the next one
+	if (blockIdx.x == 0 && blockIdx.z == 0) { // what the launch that just ended shared: zero for the next one
+		if (thr != nullptr && threadIdx.x < 4) {
+			thr[(chn0 + blockIdx.y) * 4 + threadIdx.x] = 0.f;
+		}
+		if (threadIdx.x < kCtr) {
+			ctr[((size_t)(chn0 + blockIdx.y) * kCtr + threadIdx.x) * 32] = 0u;
+		}
 	}
 	const int idx = blockIdx.x * 64 + threadIdx.x;
 	if (idx > n_angles || (idx == n_angles && raw_slot < 0)) {
@@ -568,7 +613,7 @@ hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s)
 		return err;
 	}
 	const dim3 mgrid ((unsigned)((p.n_angles + 1 + 63) / 64), (unsigned)n_chn, (unsigned)std::min<int64_t> (64, gx)); // (slices of workgroups)
-	hipLaunchKernelGGL (sweep_merge_kernel, mgrid, dim3 (64), 0, s, p.part, (int)gx, p.n_angles, p.angles, p.peaks, p.chn0, p.raw_slot, p.prune ? p.thr : nullptr);
+	hipLaunchKernelGGL (sweep_merge_kernel, mgrid, dim3 (64), 0, s, p.part, (int)gx, p.n_angles, p.angles, p.peaks, p.chn0, p.raw_slot, p.prune ? p.thr : nullptr, p.ctr);
 	return hipGetLastError ();
 }
 
