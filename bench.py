@@ -255,6 +255,28 @@ def main():
         return res
 
     eng = pkg.Engine(pkg.KIND_LV2, 48000, 1, device=local_rank)
+
+    def cold_figures(engine, steps):
+        """What a caller sees without this file's pre-roll, measured FIRST in the process: the very first
+        launch (code object load, first-touch of the output pages), then `steps` launches timed by HIP events with nothing in
+        front of them but that one call.  Reported beside the headline; never `value`."""
+        def step():
+            engine.apply_dev(x.data_ptr(), n, n, y.data_ptr(), n, n, rot, pkg.F_STATELESS, st)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        first = (time.perf_counter() - t0) * 1e3
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record(ts)
+        for _ in range(steps):
+            step()
+        ev1.record(ts)
+        torch.cuda.synchronize()
+        return first, ev0.elapsed_time(ev1) / steps
+
+    first_call_ms, cold_ms = cold_figures(eng, args.steps)
     wall, kern_ms = timed(eng, args.steps, args.warmup, n)
     head_check = oracle_check() if rank == 0 else None
     value = world * n * args.steps / wall
@@ -291,6 +313,11 @@ def main():
         "metric": "mono-sample frames/s through 4096-pt OLA phase-rotate",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3, "preroll_steps": args.preroll,
+        "cold_ms_per_step": cold_ms, "cold_roofline_frac": 8.0 * n / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "first_call_ms": first_call_ms,
+        "cold_note": "cold_ms_per_step: the first %d launches after the process's very first one, no pre-roll (HIP events); "
+                     "first_call_ms: that very first launch, wall clock; `value` is the steady state after preroll_steps + warmup "
+                     "untimed launches (clocks settle over ~150 launches: DESIGN.md section 5)" % args.steps,
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "LV2 mono 48 kHz: 3072-tap Hilbert FIR (latency 1792), 4096-pt OLA in polyphase form (1536 odd taps "
@@ -605,9 +632,9 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
         wall, dev_ms = timed_passes()
         pk = peaks.cpu().numpy()
         ev, seen = eng.sweep_stats()
-        os.environ["PROT_SWEEP_PRUNE"] = "0"
+        pkg.set_test_option(pkg.TEST_SWEEP_UNPRUNED, 1)
         wall_np, _ = timed_passes()
-        os.environ.pop("PROT_SWEEP_PRUNE", None)
+        pkg.set_test_option(pkg.TEST_SWEEP_UNPRUNED, 0)
         same = bool((peaks.cpu().numpy() == pk).all())
         per_rank = [dev_ms]
         if world > 1:

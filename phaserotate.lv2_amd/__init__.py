@@ -139,6 +139,18 @@ def load_library():
     return lib
 
 
+# csrc/prot_internal.h: process-wide switches for tests and bench.py (NOT part of the drop-in boundary)
+TEST_SWEEP_UNPRUNED, TEST_EDGE_PATH_ONLY, TEST_LV2_STAGED, TEST_ALLREDUCE = 0, 1, 2, 3
+
+
+def set_test_option(option, value):
+    """prot_internal_set_test_option: the shipped library reads no environment variables; what tests and the bench
+    switch (unpruned sweep, every block through the staged path, ...) goes through this hook."""
+    lib = load_library()
+    lib.prot_internal_set_test_option.argtypes = [C.c_int, C.c_int]
+    _check(lib.prot_internal_set_test_option(int(option), int(value)), "prot_internal_set_test_option")
+
+
 def _check(rc, what):
     if rc != 0:
         lib = load_library()

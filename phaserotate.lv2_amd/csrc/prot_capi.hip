@@ -5,11 +5,13 @@
 // No CPU fallback lives here: without a usable HIP device every entry point
 // fails (PROT_ENODEV / NULL), loudly.
 #include "../../include/prot_hip.h"
+#include "prot_internal.h"
 #include "prot_kernels.h"
 
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <dlfcn.h>
 #include <thread>
 #include <climits>
@@ -28,6 +30,16 @@
 #endif
 
 namespace {
+
+// The shipped library (the one LV2 hosts load) never reads its environment.  Tuning switches -- run geometry, forced
+// kernel forms -- exist only in PROT_TUNING builds (tools/ab_build.py); what the test-suite and bench.py need to switch
+// (the unpruned sweep, every block through the staged path, the all-reduce route) goes through prot_internal_set_test_option.
+#ifdef PROT_TUNING
+inline const char* tuning_env (const char* name) { return getenv (name); }
+#else
+inline const char* tuning_env (const char*) { return nullptr; }
+#endif
+std::atomic<int> g_test_opt[PROT_TEST_OPTIONS];
 
 thread_local char g_err[256] = "";
 
@@ -362,7 +374,9 @@ struct prot_engine {
 	bool           pipeline   = false;
 	hipStream_t    pipe_stream[kPipe] = {};
 	hipEvent_t     pipe_ev[kPipe + 1] = {};
-	DevBuf<uint32_t> d_pipe;      // [0..7] generation g's history is complete when slot g & 7 holds g; [8..11] slice counters
+	DevBuf<uint32_t> d_pipe;      // [0..7] generation g's history is complete when slot g & 7 holds g; [8..11] slice counters;
+	                              // [12] status: the generation a kernel gave up waiting for (0: none) -- checked by prot_engine_sync
+	bool           pipe_used  = false; // pipelined launches since the status word was last looked at
 	uint32_t       pipe_gen   = 0;    // pipelined launches so far (= the value the last one publishes)
 	uint32_t       pipe_q     = 0;    // ... since the last join (stream and counter of the next one)
 	bool           pipe_dirty = false; // work may be in flight on the pipe streams
@@ -397,6 +411,12 @@ int zero_state (prot_engine* e)
 	z.n[2] = 4 * sizeof (unsigned long long) / sizeof (uint32_t);
 	z.p[3] = reinterpret_cast<uint32_t*> (e->d_hist16[0].p);
 	z.n[3] = e->d_hist16[0].p ? (hn + 1) / 2 : 0;
+	// what a sweep launch shares (bounds, step counters): its merge kernel leaves them zero, a launch that failed or was
+	// aborted between the two does not -- a reset restores the known-good state
+	z.p[4] = reinterpret_cast<uint32_t*> (e->d_thr.p);
+	z.n[4] = e->d_thr.p ? 4 * (size_t)e->info.n_chn : 0;
+	z.p[5] = reinterpret_cast<uint32_t*> (e->d_ctr.p);
+	z.n[5] = e->d_ctr.p ? (size_t)e->info.n_chn * 32 * 32 : 0;
 	hipError_t err = prot::launch_zero_regions (z, e->stream);
 	if (err != hipSuccess) {
 		return hip_fail (err, "state reset launch");
@@ -490,7 +510,7 @@ void rank_runs (P& p, int64_t blk, int n_chn, uint64_t n_out, int slots, int cus
 		w[0] = 1.4, w[1] = 1.1, w[2] = 0.9, w[3] = 0.6; // fp16 headline / CLI 2048, ms per 2^27 frames: equal runs 0.247 / 0.238; 1.5:1.1:0.8:0.6 0.230 / 0.228;
 		                                                 // 1.4:1.1:0.9:0.6 0.229 / 0.226; 1.6:1.1:0.8:0.5 0.227 / 0.235; 1.3:1.1:0.9:0.7 0.234 / 0.229 (PROT_RANK_W16)
 	}
-	const char* we = getenv (half ? "PROT_RANK_W16" : "PROT_RANK_W"); // tuning: "w0,w1,w2[,w3]" ("1,1,1": equal runs)
+	const char* we = tuning_env (half ? "PROT_RANK_W16" : "PROT_RANK_W"); // tuning: "w0,w1,w2[,w3]" ("1,1,1": equal runs)
 	if (we) {
 		double v[4] = { 0, 0, 0, 0 };
 		if (sscanf (we, "%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3]) >= R) {
@@ -877,7 +897,7 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	// FIRs longer than one 2048-tap partition: partitions are convolved in PAIRS that share a
 	// forward transform (ola4096p2_kernel); pair s covers taps [4096 s, 4096 s + 4096) and is
 	// delayed by 4096 s frames; pairs after the first accumulate into the output.
-	const bool no_p2  = getenv ("PROT_NO_P2") != nullptr || (cfg->flags & PROT_CFG_SINGLE_FFT_PER_HOP);
+	const bool no_p2  = tuning_env ("PROT_NO_P2") != nullptr || (cfg->flags & PROT_CFG_SINGLE_FFT_PER_HOP);
 	bool       use_p2 = !no_p2 && inf.firlen > F / 2 + 1;
 	// ... and, the Hilbert FIR being zero at every even tap (checked below on the designed taps),
 	// in POLYPHASE form: the stream read as complex samples x[2j-1] + i x[2j] is convolved with
@@ -896,7 +916,7 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	// (round 2: with three workgroups per CU the polyphase kernel also wins at 4096 taps, 0.33 against 0.43 ms for the
 	// two-partition direct form at LV2 96 kHz -- it is the default for every Hilbert FIR now)
 	const bool poly_wanted = true;
-	bool use_poly = (use_p2 || long_hop || (cfg->flags & PROT_CFG_POLYPHASE)) && poly_wanted && getenv ("PROT_NO_POLY") == nullptr &&
+	bool use_poly = (use_p2 || long_hop || (cfg->flags & PROT_CFG_POLYPHASE)) && poly_wanted && tuning_env ("PROT_NO_POLY") == nullptr &&
 	                !(cfg->flags & (PROT_CFG_DIRECT_FORM | PROT_CFG_SINGLE_FFT_PER_HOP)) && inf.firlen % 4 == 0 &&
 	                inf.firlen >= 1024 && inf.conv_delay % 2 == 0;
 	for (uint32_t i = 0; use_poly && i < inf.firlen; i += 2) {
@@ -977,13 +997,13 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 			e->cus      = cus;
 		}
 	}
-	if (const char* o = getenv ("PROT_WG_PER_CU")) { // tuning
+	if (const char* o = tuning_env ("PROT_WG_PER_CU")) { // tuning
 		int cus = 256;
 		(void)hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, cfg->device);
 		e->wg_slots = cus * atoi (o);
 		e->cus      = cus;
 	}
-	if (const char* o = getenv ("PROT_PAIRS_PER_RUN")) {
+	if (const char* o = tuning_env ("PROT_PAIRS_PER_RUN")) {
 		e->pairs_per_run_override = atoi (o);
 	}
 
@@ -1025,18 +1045,18 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	};
 	std::vector<float2> H_h, tw_h (F);
 	std::vector<float>  sv_h;
-	if (use_poly && n_part == 1 && !(cfg->flags & PROT_CFG_OVERLAP_ADD) && getenv ("PROT_NO_SAVE") == nullptr &&
+	if (use_poly && n_part == 1 && !(cfg->flags & PROT_CFG_OVERLAP_ADD) && tuning_env ("PROT_NO_SAVE") == nullptr &&
 	    2 * (inf.dry_delay - inf.conv_delay) == 256 * (32 - (uint32_t)hopseg) && inf.dry_delay % 2 == 0) {
-		e->sv_flags = getenv ("PROT_SV_NOASM") != nullptr ? 1 : 0;
+		e->sv_flags = g_test_opt[PROT_TEST_EDGE_PATH_ONLY].load () ? 1 : 0; // (test hook: every block through the staged path)
 		e->use_save = hopseg <= 24 && save_tables (fir_taps, F, sv_h, e->sv_gain, e->sv_rows) && e->sv_rows == 1;
-		if (e->use_save && e->cus > 0 && getenv ("PROT_WG_PER_CU") == nullptr) {
+		if (e->use_save && e->cus > 0 && tuning_env ("PROT_WG_PER_CU") == nullptr) {
 			e->wg_slots = e->cus * 4; // 128 VGPRs, 38 KiB of LDS
 		}
 	}
-	const char* pipe_env = getenv ("PROT_PIPELINE");
+	const char* pipe_env = tuning_env ("PROT_PIPELINE");
 	if (e->use_save && ((cfg->flags & PROT_CFG_PIPELINE) || (pipe_env && atoi (pipe_env) != 0)) && !(pipe_env && atoi (pipe_env) == 0)) {
 		// consecutive stateful prot_apply_dev calls on the engine's own streams overlap
-		bool ok = e->d_pipe.ensure (12) == PROT_OK && hipMemset (e->d_pipe.p, 0, 12 * sizeof (uint32_t)) == hipSuccess;
+		bool ok = e->d_pipe.ensure (16) == PROT_OK && hipMemset (e->d_pipe.p, 0, 16 * sizeof (uint32_t)) == hipSuccess;
 		// (the engine's main stream is one of the three: the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware
 		// queues, 4 by default, and two pipe streams that share a queue do not overlap -- 10 us per launch instead of 5.5)
 		e->pipe_stream[0] = e->stream;
@@ -1071,7 +1091,7 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	for (uint32_t i = 0; poly_taps_ok && i < inf.firlen; i += 2) {
 		poly_taps_ok = fir_taps[i] == 0.f;
 	}
-	if (use_p2 && !use_poly && inf.firlen == F && poly_taps_ok && (cfg->flags & ~PROT_CFG_PIPELINE) == 0 && getenv ("PROT_NO_POLY") == nullptr) {
+	if (use_p2 && !use_poly && inf.firlen == F && poly_taps_ok && (cfg->flags & ~PROT_CFG_PIPELINE) == 0 && tuning_env ("PROT_NO_POLY") == nullptr) {
 		std::vector<float> g (inf.firlen / 2);
 		for (size_t i = 0; i < g.size (); ++i) {
 			g[i] = fir_taps[2 * i + 1];
@@ -1259,6 +1279,17 @@ int prot_engine_sync (prot_engine* e)
 	HIP_TRY (hipSetDevice (e->device));
 	(void)join_pipe (e, e->stream);
 	HIP_TRY (hipStreamSynchronize (e->stream));
+	if (e->pipe_used && e->d_pipe.p) {
+		// did a pipelined launch give up waiting for the history of the one before it (prot_olasave.hip: bounded wait)?
+		uint32_t st = 0;
+		HIP_TRY (hipMemcpy (&st, e->d_pipe.p + prot::kPipeStatusWord, sizeof (st), hipMemcpyDeviceToHost));
+		e->pipe_used = false;
+		if (st != 0u) {
+			(void)hipMemset (e->d_pipe.p + prot::kPipeStatusWord, 0, sizeof (st));
+			snprintf (g_err, sizeof (g_err), "pipelined launch: the history of generation %u never arrived (outputs since then are invalid)", st);
+			return PROT_EHIP;
+		}
+	}
 	return PROT_OK;
 }
 
@@ -1295,15 +1326,20 @@ int prot_apply_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		} else {
 			wp[0] = e->pipe_gen; // what the launch before this one publishes
 		}
-		wp[1]         = ++e->pipe_gen;
+		const uint32_t gen_before = e->pipe_gen;
+		if (++e->pipe_gen == 0u) {
+			++e->pipe_gen; // 0 means "first of a series, wait for nobody" (hs_wait): never a generation's number
+		}
+		wp[1]         = e->pipe_gen;
 		e->pipe_dirty = true;
+		e->pipe_used  = true;
 		e->pipe_q++;
 		int rc = ola_launch (e, d_in, in_stride, n_in, d_out, out_stride, n_out, nullptr, nullptr, false, false, 0, nc, ps,
 		                     /*advance_hist*/ true, rot, wp);
 		if (rc == PROT_OK) {
 			e->pos += n_in;
 		} else {
-			e->pipe_gen--; // nothing was launched: the generation must not be waited for by the next launch
+			e->pipe_gen = gen_before; // nothing was launched: the generation must not be waited for by the next launch
 		}
 		return rc;
 	}
@@ -1418,7 +1454,7 @@ static int apply_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint6
 	p.rot_s      = d_rot_s;
 	// fp16 samples, one partition: 104-128 VGPRs and 26 KiB of LDS per workgroup -- FOUR per CU (measured 0.269 -> 0.252 ms
 	// at the headline shape with equal runs; the fp32 kernel cannot: 158 VGPRs, 53 KiB)
-	static const bool slots_forced = getenv ("PROT_WG_PER_CU") != nullptr; // tuning
+	static const bool slots_forced = tuning_env ("PROT_WG_PER_CU") != nullptr; // tuning
 	// (two partitions per launch: 128-158 VGPRs, 34 KiB -- three per CU where the fp32 kernel has two; 0.367 -> 0.336 ms)
 	const int slots16 = (!f16_poly || slots_forced) ? e->wg_slots : e->cus * (e->info.partitions == 1 ? 4 : 3);
 	p.run_frames = pick_run_frames (e, n_out, nc, 0, slots16); // the engine's own transform block: the fp16 kernels share its form
@@ -1547,8 +1583,7 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		sp.lut      = e->d_lut.p;
 		sp.peaks    = pk;
 		sp.chn0     = c0;
-		const char* pe = getenv ("PROT_SWEEP_PRUNE"); // read per call: tests flip it inside one process
-		sp.prune       = (pe && atoi (pe) == 0) ? 0 : 1; // exact either way; 0 = the unpruned sweep, for timing and tests
+		sp.prune       = g_test_opt[PROT_TEST_SWEEP_UNPRUNED].load () ? 0 : 1; // exact either way; the unpruned sweep is for timing and tests (prot_internal.h)
 		sp.thr         = e->d_thr.p;
 		sp.stats       = e->d_stats.p;
 		if ((rc = e->d_part.ensure (prot::sweep_scratch_floats ())) != PROT_OK) {
@@ -1558,10 +1593,15 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		sp.part        = e->d_part.p;
 		sp.part_floats = prot::sweep_scratch_floats ();
 		sp.raw_slot    = raw0 ? 0 : -1; // the raw peak rides along with the sweep (no pass of its own over the input)
+		sp.raw_tail    = (raw0 && !end) ? 1 : 0; // ... and is complete for this call's frames when the call returns
 		// bounds are per launch: they refer to THIS call's angle set
 		// (p.thr is all zeros here: zeroed once when the engine was created, and again by every launch's merge kernel)
 		hipError_t err = prot::launch_sweep (sp, nc, s);
 		if (err != hipSuccess) {
+			// the launch may have died between the sweep and its merge kernel: the shared bounds and step counters are
+			// not known to be zero any more
+			(void)hipMemsetAsync (e->d_thr.p, 0, 4 * (size_t)e->info.n_chn * sizeof (float), s);
+			(void)hipMemsetAsync (e->d_ctr.p, 0, (size_t)e->info.n_chn * 32 * 32 * sizeof (unsigned), s);
 			return hip_fail (err, "sweep kernel launch");
 		}
 	}
@@ -1717,7 +1757,7 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 	// (H2D copies -> device buffers -> D2H copy) for comparison.
 	// Measured (tools/run_latency.py): 64..1024-frame buffers 37..42 us zero-copy vs 46..47 us staged; at 8192 frames the
 	// DMA copies win (70 vs 76 us: 64 KiB over the host link from inside a latency-bound kernel) -- staged above 4096 samples.
-	static const bool force_staged = getenv ("PROT_LV2_STAGED") != nullptr;
+	const bool force_staged = g_test_opt[PROT_TEST_LV2_STAGED].load () != 0;
 	const bool        staged       = force_staged || n * nc > 4096;
 	// (buffers: lv2_reserve -- nothing is allocated on this path)
 	float* h_in  = e->h_io.p;
@@ -2135,9 +2175,9 @@ int prot_allreduce_peaks (prot_engine* const* engines, int n)
 	}
 	// PROT_ALLREDUCE=host: merge through the host even on distinct devices; =rccl: take the collective even when the
 	// engines share a device (only meaningful with a stand-in library: real RCCL wants one rank per device)
-	const char* mode      = getenv ("PROT_ALLREDUCE");
-	const bool  want_host = mode && !strcmp (mode, "host");
-	const bool  force     = mode && !strcmp (mode, "rccl");
+	const int   mode      = g_test_opt[PROT_TEST_ALLREDUCE].load (); // (prot_internal.h: 1 = through the host, 2 = the collective even on one device)
+	const bool  want_host = mode == 1;
+	const bool  force     = mode == 2;
 	std::lock_guard<std::mutex> lk (g_rccl_lock);
 	if ((distinct || force) && !want_host && g_rccl.load ()) {
 		std::vector<int> devs (n);
@@ -2313,6 +2353,15 @@ int prot_cli_apply_file (prot_engine* e, const float* data, uint64_t n_frames, c
 // TEST HOOK, not part of include/prot_hip.h (declared in csrc/prot_internal.h): the library that Rccl::load() opens in
 // place of the system's RCCL -- an explicit call of the test process, never the environment (the library is also
 // loaded into LV2 hosts).  Only before the first all-reduce; NULL / "" restores the default.
+int prot_internal_set_test_option (int option, int value)
+{
+	if (option < 0 || option >= PROT_TEST_OPTIONS) {
+		return PROT_EINVAL;
+	}
+	g_test_opt[option].store (value);
+	return PROT_OK;
+}
+
 int prot_internal_set_rccl_library (const char* path)
 {
 	std::lock_guard<std::mutex> lk (g_rccl_lock);

@@ -7,6 +7,15 @@ extern "C" {
 // the shared library dlopen()ed in place of the system's RCCL by prot_allreduce_peaks (tests: a counting stand-in);
 // only before the first all-reduce of the process, NULL or "" = the default search.  0 or PROT_EINVAL.
 int prot_internal_set_rccl_library (const char* path);
+// process-wide switches of the test-suite and bench.py (the shipped library reads no environment variables):
+enum {
+	PROT_TEST_SWEEP_UNPRUNED = 0, // != 0: prot_sweep_dev launches the unpruned sweep kernel (bit-identical tables; timing and tests)
+	PROT_TEST_EDGE_PATH_ONLY = 1, // != 0: engines created from now on run every overlap-save block through the staged (edge) path
+	PROT_TEST_LV2_STAGED     = 2, // != 0: prot_lv2_run copies its buffers through staging memory whatever their size
+	PROT_TEST_ALLREDUCE      = 3, // 0 automatic; 1 merge through the host; 2 the RCCL collective even when engines share a device
+	PROT_TEST_OPTIONS        = 4
+};
+int prot_internal_set_test_option (int option, int value); // 0 or PROT_EINVAL
 #ifdef __cplusplus
 }
 #endif

@@ -56,7 +56,7 @@ struct OlaParamsT {
 	// launch g - 1 has (its history write waits for nothing), and a reader of generation g - 1 must not mistake that for it;
 	// a slot is reused by generation g + 8, which cannot start before g is complete (stream order, and every launch's
 	// readers wait for the launch before it: the lead is 5 at most).
-	uint32_t*     hs_flag;
+	uint32_t*     hs_flag;      // (word kPipeStatusWord of the same array: generation whose wait timed out, 0 = none)
 	uint32_t*     hs_cnt;
 	uint32_t      hs_wait, hs_post;
 };
@@ -91,6 +91,9 @@ hipError_t launch_ola4096_p2_f16 (const OlaParamsH& p, int n_chn, hipStream_t s)
 // Rotated abs-max sweep over t in [t_begin, t_end) of one chunk:
 //   v = ca[a] * (t_abs >= dry_from ? x[t - delay] : 0) + sa[a] * u[t]
 //   peaks[c][a] = max(peaks[c][a], |v|)
+constexpr unsigned kPipeStatusWord = 12;       // of prot_engine::d_pipe
+constexpr unsigned kPipeSpinMax    = 1u << 21; // ~1 us per look: about two seconds
+
 struct SweepParams {
 	const float* x;           // device planar input (dry), channel stride x_stride
 	int64_t      x_stride;
@@ -113,6 +116,8 @@ struct SweepParams {
 	unsigned*    ctr;         // device, [n_chn][32][32] (32 counters per channel, one cache line each), all zeros at launch (the merge
 	                          // kernel leaves them so): the next step to hand out
 	int32_t      raw_slot;    // >= 0: also max |x| over the frames the launch reads -> peaks[c][raw_slot] (angle 0, Q4); -1: no
+	int32_t      raw_tail;    // with raw_slot: the last `delay` frames of x too (a chunk that is not the stream's last: the loaders see them
+	                          // only as the next chunk's history, and calc_peak, cli/phase-rotate.cc:413-414, takes the whole new block)
 	float*       part;        // device scratch, >= sweep_scratch_floats () floats: per-workgroup maxima of one launch (merged into peaks)
 	size_t       part_floats;
 	unsigned long long* stats; // device, [4] += {tiles evaluated, tiles seen, tiles fed untested, surviving frames of tested tiles}, or NULL
@@ -133,10 +138,11 @@ hipError_t launch_hist_update_f16 (const _Float16* in, int64_t in_stride, int64_
                                    const _Float16* hist_in, _Float16* hist_out, int hist_len,
                                    int n_chn, hipStream_t s);
 
-// up to four regions of 32-bit words zeroed by ONE launch (prot_engine_reset: the separate memsets were 8 launches, ~60 us)
+// up to six regions of 32-bit words zeroed by ONE launch (prot_engine_reset: the separate memsets were 8 launches, ~60 us)
+constexpr int kZeroRegions = 6;
 struct ZeroRegions {
-	uint32_t* p[4];
-	uint64_t  n[4]; // words
+	uint32_t* p[kZeroRegions];
+	uint64_t  n[kZeroRegions]; // words
 };
 hipError_t launch_zero_regions (const ZeroRegions& z, hipStream_t s);
 

@@ -1712,13 +1712,13 @@ __global__ __launch_bounds__ (256) void zero_regions_kernel (const ZeroRegions z
 hipError_t launch_zero_regions (const ZeroRegions& z, hipStream_t s)
 {
 	uint64_t most = 0;
-	for (int i = 0; i < 4; ++i) {
+	for (int i = 0; i < kZeroRegions; ++i) {
 		most = std::max (most, z.p[i] ? z.n[i] : 0);
 	}
 	if (most == 0) {
 		return hipSuccess;
 	}
-	const dim3 grid ((unsigned)std::min<uint64_t> ((most + 255) / 256, 512), 4), block (256);
+	const dim3 grid ((unsigned)std::min<uint64_t> ((most + 255) / 256, 512), kZeroRegions), block (256);
 	hipLaunchKernelGGL (zero_regions_kernel, grid, block, 0, s, z);
 	return hipGetLastError ();
 }

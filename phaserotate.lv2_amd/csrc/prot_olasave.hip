@@ -138,8 +138,17 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 	if (piped && p.hs_wait != 0u && r0 - p.dry_delay - 512 * R0 < 1) {
 		// this run starts inside the history the previous launch is writing (or has written) on the other stream
 		if (t0 == 0) {
+			// bounded: the launch waited for cannot be behind this one in a queue (host rule: pipelined launches take at most
+			// 1/6 of the resident-workgroup slots), so the wait ends within a launch's duration -- if it ever does not (a
+			// runtime that serialises the streams differently, a lost launch) the kernel gives up after ~2 s instead of
+			// hanging the device, and says so in the status word the host checks at the next synchronisation (PROT_EHIP)
+			unsigned spins = 0;
 			while (__hip_atomic_load (p.hs_flag + (p.hs_wait & 7u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.hs_wait) {
 				__builtin_amdgcn_s_sleep (8);
+				if (++spins > kPipeSpinMax) {
+					__hip_atomic_store (p.hs_flag + kPipeStatusWord, p.hs_wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					break;
+				}
 			}
 		}
 		__syncthreads ();

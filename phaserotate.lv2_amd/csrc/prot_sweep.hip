@@ -223,14 +223,17 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 	const unsigned  n_total = p.t_end > p.t_begin ? (unsigned)((p.t_end - p.t_begin + kStage - 1) / kStage) : 0u;
 	// (kCtr counters per channel, each on a cache line of its own, each handing out every kCtr-th step to the workgroups
 	// with that blockIdx.x mod kCtr: ONE counter serves its atomics one at a time -- 675 K of them made cfg4 9 ms instead of 3)
-	const unsigned  grp = blockIdx.x & (kCtr - 1);
-	unsigned* const ctr = p.ctr + ((size_t)c * kCtr + grp) * 32;
+	// (a launch of fewer than kCtr workgroups per channel -- many channels, a small device -- uses as many counters as it has
+	// workgroups: a counter nobody draws from would leave its steps undone)
+	const unsigned  ngrp = gridDim.x < kCtr ? gridDim.x : kCtr;
+	const unsigned  grp  = blockIdx.x % ngrp;
+	unsigned* const ctr  = p.ctr + ((size_t)c * kCtr + grp) * 32;
 	if (tid == 0) {
 		const unsigned b0 = atomicAdd (ctr, 4u);
-		sh_seq[0]         = kCtr * b0 + grp;
-		sh_seq[1]         = kCtr * (b0 + 1u) + grp;
-		sh_seq[2]         = kCtr * (b0 + 2u) + grp;
-		sh_seq[3]         = kCtr * (b0 + 3u) + grp;
+		sh_seq[0]         = ngrp * b0 + grp;
+		sh_seq[1]         = ngrp * (b0 + 1u) + grp;
+		sh_seq[2]         = ngrp * (b0 + 2u) + grp;
+		sh_seq[3]         = ngrp * (b0 + 3u) + grp;
 	}
 	__syncthreads ();
 	auto seq = [&] (int s) { return (unsigned)__builtin_amdgcn_readfirstlane ((int)sh_seq[s & 7]); };
@@ -303,6 +306,13 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 			}
 		}
 	};
+	if (p.raw_slot >= 0 && p.raw_tail && blockIdx.x == 0) {
+		// the call's last `delay` input frames: the loaders reach them only as the next chunk's history (x[t - delay], t < t_end),
+		// the reference's calc_peak has them in this block -- folded here so that peaks[c][0] is complete when the call returns
+		for (int64_t i = p.n_x - p.delay + tid; i < p.n_x; i += 256) {
+			amax = fmaxf (amax, fabsf (ldv (x, p.n_x, hist, p.hist_len, i)));
+		}
+	}
 	// prologue: waves 2-3 fetch step 0 and park it (the only exposed latency), then request step 2; waves 0-1 request step 1
 	{
 		const unsigned g0 = seq (0), g1 = seq (1), g2 = seq (2);
@@ -329,7 +339,7 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 		const bool asks = tid == ((s & 1) << 7 ^ 128);
 		unsigned   got  = 0u;
 		if (asks) {
-			got = kCtr * atomicAdd (ctr, 1u) + grp;
+			got = ngrp * atomicAdd (ctr, 1u) + grp;
 		}
 		if ((s & 1) == ld_par) {
 			if (gs1 < n_total) {
@@ -602,19 +612,35 @@ hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s)
 	}
 	const int64_t span  = kStage;
 	const int64_t tiles = (p.t_end - p.t_begin + span - 1) / span;
-	const int64_t gx    = std::min<int64_t> (tiles, std::max (1, slots[pr][nblk] / n_chn));
-	if (p.part == nullptr || p.part_floats < (size_t)gx * n_chn * 4 * (p.n_angles + 1)) {
-		return hipErrorInvalidValue; // the host sizes the scratch table with sweep_scratch_floats ()
+	if (p.part == nullptr) {
+		return hipErrorInvalidValue;
 	}
-	const dim3 grid ((unsigned)gx, (unsigned)n_chn), block (256);
-	hipLaunchKernelGGL (fn, grid, block, 0, s, p);
-	hipError_t err = hipGetLastError ();
-	if (err != hipSuccess) {
-		return err;
+	// channels beyond what the scratch table holds at one workgroup each go in further launches (the table is sized for
+	// every resident-workgroup slot: sweep_scratch_floats ())
+	const int64_t per_wg   = 4 * ((int64_t)p.n_angles + 1);
+	const int64_t chn_most = std::min<int64_t> ((int64_t)(p.part_floats / (size_t)per_wg), 65535);
+	if (chn_most < 1) {
+		return hipErrorInvalidValue;
 	}
-	const dim3 mgrid ((unsigned)((p.n_angles + 1 + 63) / 64), (unsigned)n_chn, (unsigned)std::min<int64_t> (64, gx)); // (slices of workgroups)
-	hipLaunchKernelGGL (sweep_merge_kernel, mgrid, dim3 (64), 0, s, p.part, (int)gx, p.n_angles, p.angles, p.peaks, p.chn0, p.raw_slot, p.prune ? p.thr : nullptr, p.ctr);
-	return hipGetLastError ();
+	for (int c0 = 0; c0 < n_chn; c0 += (int)chn_most) {
+		const int     nc = (int)std::min<int64_t> (chn_most, n_chn - c0);
+		const int64_t gx = std::min<int64_t> (std::min<int64_t> (tiles, std::max (1, slots[pr][nblk] / nc)), chn_most / nc);
+		SweepParams   q  = p;
+		q.chn0           = p.chn0 + c0;
+		const dim3 grid ((unsigned)gx, (unsigned)nc), block (256);
+		hipLaunchKernelGGL (fn, grid, block, 0, s, q);
+		hipError_t err = hipGetLastError ();
+		if (err != hipSuccess) {
+			return err;
+		}
+		const dim3 mgrid ((unsigned)((p.n_angles + 1 + 63) / 64), (unsigned)nc, (unsigned)std::min<int64_t> (64, gx)); // (slices of workgroups)
+		hipLaunchKernelGGL (sweep_merge_kernel, mgrid, dim3 (64), 0, s, q.part, (int)gx, q.n_angles, q.angles, q.peaks, q.chn0, q.raw_slot, q.prune ? q.thr : nullptr, q.ctr);
+		err = hipGetLastError ();
+		if (err != hipSuccess) {
+			return err;
+		}
+	}
+	return hipSuccess;
 }
 
 // floats of scratch a sweep launch may need on this device (every resident-workgroup slot x 4 waves x 360 angles)

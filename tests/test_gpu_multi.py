@@ -92,6 +92,7 @@ def counts():
 lib = pkg.load_library()
 lib.prot_internal_set_rccl_library.argtypes = [ctypes.c_char_p]
 assert lib.prot_internal_set_rccl_library(os.environ["TEST_RCCL_STUB"].encode()) == 0
+pkg.set_test_option(pkg.TEST_ALLREDUCE, 2)  # the collective although both engines sit on one device
 a, b = pkg.Engine(pkg.KIND_CLI, 2048, 2), pkg.Engine(pkg.KIND_CLI, 2048, 2)
 arr = (ctypes.c_void_p * 2)(a._h, b._h)
 for _ in range(25):
@@ -115,7 +116,7 @@ def test_allreduce_keeps_its_communicators(tmp_path):
     src.write_text(STUB)
     so = str(tmp_path / "librccl_stub.so")
     subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-o", so, str(src)], check=True)
-    env = dict(os.environ, TEST_RCCL_STUB=so, PROT_ALLREDUCE="rccl")
+    env = dict(os.environ, TEST_RCCL_STUB=so)
     r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("COUNTS")]
     assert r.returncode == 0 and line, r.stdout[-3000:]

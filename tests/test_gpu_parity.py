@@ -293,6 +293,33 @@ def test_sweep_block_by_block_matches_oracle(pkg):
     g.close()
 
 
+def test_sweep_mid_stream_raw_peak_is_complete_call_by_call(pkg):
+    """Angle 0 (the raw peak, calc_peak over the whole new block: cli/phase-rotate.cc:413-414) rides along in the sweep's
+    loaders, which see x[t - P/2]: the last P/2 frames of a call that is not the stream's last must still be in
+    peaks[c][0] when the call returns -- the loudest frame of every block sits in its second half here."""
+    P, n_chn, nblk = 2048, 2, 5
+    data = (0.05 * _signal(P * nblk, n_chn, seed=23)).reshape(nblk, P, n_chn).copy()
+    for b in range(nblk):
+        data[b, P - 3 - b, b % n_chn] = 0.1 + 0.15 * b      # in the last P/2 frames of block b
+    g = pkg.PhaseRotate(P, n_chn)
+    o = orc.CliEngine(P, n_chn)
+    for b in range(nblk):
+        g.analyze(data[b].reshape(-1), 0, 360, 24, -1, b == 0)
+        o.analyze(data[b].reshape(-1), 0, 360, 24, -1, b == 0)
+        pg, po = g.peaks(), o.peaks()
+        assert pg[:, 0].tobytes() == po[:, 0].astype(np.float32).tobytes(), b
+        assert pg[b % n_chn, 0] == np.float32(0.1 + 0.15 * b)
+    # ... and the same through the angle-0-only route and a mixed sequence of the two
+    g.reset()
+    o.reset()
+    for b in range(nblk):
+        a1, st = (1, 24) if b % 2 else (360, 24)
+        g.analyze(data[b].reshape(-1), 0, a1, st, -1, b == 0)
+        o.analyze(data[b].reshape(-1), 0, a1, st, -1, b == 0)
+        assert g.peaks()[:, 0].tobytes() == o.peaks()[:, 0].astype(np.float32).tobytes(), b
+    g.close()
+
+
 def test_sweep_first_block_quirk_q1(pkg):
     """An early impulse: dry contributions of t < blksiz/2 never enter a rotated peak."""
     P = 2048
@@ -550,7 +577,7 @@ def test_lv2_random_buffer_sizes_and_angle_moves(pkg):
 def _sweep_table(pkg, x, P, stride, prune, passes=((0, 360, 24), (100, 140, 1))):
     """Peak table [n_chn][360] after a coarse and a fine pass over the interleaved file x, and the
     fraction of tile groups the sweep actually evaluated."""
-    os.environ["PROT_SWEEP_PRUNE"] = "1" if prune else "0"
+    pkg.set_test_option(pkg.TEST_SWEEP_UNPRUNED, 0 if prune else 1)
     try:
         pr = pkg.PhaseRotate(P, x.shape[1])
         for a0, a1, st in passes:
@@ -560,7 +587,7 @@ def _sweep_table(pkg, x, P, stride, prune, passes=((0, 360, 24), (100, 140, 1)))
         _sweep_table.last_stats = pr.sweep_stats_ex()
         pr.close()
     finally:
-        os.environ.pop("PROT_SWEEP_PRUNE", None)
+        pkg.set_test_option(pkg.TEST_SWEEP_UNPRUNED, 0)
     return tab, (ev / seen if seen else None)  # the unpruned kernel keeps no statistics: seen == 0
 
 
@@ -685,6 +712,9 @@ def test_pruned_sweep_every_angle_block_layout(pkg, stride, blocks):
     (4, 5000, ((0, 1, 24),)),                     # angle 0 only: no sweep launch, the stand-alone abs-max kernel
     (2, 2048 * 3 + 1, ((0, 360, 8), (200, 236, 1))),  # a ragged last block, a second pass over a few angles without angle 0
     (5, 40000, ((1, 360, 7),)),                   # five channels, angle 0 NOT asked for (slot 0 must stay untouched)
+    (33, 9000, ((0, 360, 1),)),                   # more channels than step counters per workgroup slot: fewer than 32 workgroups
+    (64, 7000, ((0, 360, 3),)),                   #   per channel draw from as many counters as there are workgroups
+    (1100, 2500, ((0, 360, 24),)),                # more channels than resident-workgroup slots: the scratch table in several launches
 ])
 def test_sweep_table_small_and_many_channel_calls(pkg, n_chn, n, passes):
     """The sweep's per-launch scratch table and merge kernel (one value per angle, workgroup and wave; the raw peak of angle 0
@@ -1145,7 +1175,7 @@ def test_generated_loop_and_cpp_blocks_give_the_same_bits(pkg, kind, param):
     """olasave_kernel runs whole in-range blocks through its generated assembly loop and every other block through C++
     code with the same packed instructions in the same order: the two must agree BIT FOR BIT (sharded and chunked sweeps
     rely on it: where a chunk ends decides which path a block takes).  One stream through an engine created with
-    PROT_SV_NOASM (every block the C++ way) and through a default engine; also the Hilbert-only form the sweep uses."""
+    the test option EDGE_PATH_ONLY (every block the staged way) and through a default engine; also the Hilbert-only form the sweep uses."""
     import torch
     dev = torch.device("cuda:0")
     n = 3_000_017
@@ -1154,12 +1184,11 @@ def test_generated_loop_and_cpp_blocks_give_the_same_bits(pkg, kind, param):
     rot = np.array([0.28, -0.96], np.float32)
     outs = []
     for noasm in (False, True):
-        if noasm:
-            os.environ["PROT_SV_NOASM"] = "1"
+        pkg.set_test_option(pkg.TEST_EDGE_PATH_ONLY, 1 if noasm else 0)
         try:
             e = pkg.Engine(kind, param, 1)
         finally:
-            os.environ.pop("PROT_SV_NOASM", None)
+            pkg.set_test_option(pkg.TEST_EDGE_PATH_ONLY, 0)
         y, u = torch.zeros_like(x), torch.zeros_like(x)
         torch.cuda.synchronize()
         e.apply_dev(x.data_ptr(), n, n, y.data_ptr(), n, n, rot, pkg.F_STATELESS)

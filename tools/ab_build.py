@@ -9,6 +9,11 @@ b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
 b.build_lib()
 vdir = os.path.join(b.LIBDIR, "variants"); os.makedirs(vdir, exist_ok=True)
 hipcc = b._hipcc()
+# variant libraries read the tuning switches of prot_capi.hip from the environment (-DPROT_TUNING); the shipped library never does
+CAPI_T = os.path.join(b.OBJDIR, "prot_capi_tuning.o")
+if b._newer(CAPI_T, [os.path.join(b.CSRC, "prot_capi.hip"), os.path.join(b.CSRC, "prot_kernels.h")]):
+    b._run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-function", "-DPROT_TUNING",
+            "-I" + os.path.join(ROOT, "include"), "-c", os.path.join(b.CSRC, "prot_capi.hip"), "-o", CAPI_T])
 for arg in sys.argv[1:]:
     if arg.startswith("sv:"):
         # "sv:<tag>[:flag,flag]": a variant of prot_olasave.hip only (the generated loop csrc/variants/prot_olasave_asm_<tag>.inc
@@ -29,7 +34,7 @@ for arg in sys.argv[1:]:
                ["-c", os.path.join(b.CSRC, "prot_olasave.hip"), "-o", o])
         lib = os.path.join(vdir, "libprot_hip_%s.so" % tag)
         b._run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, o, os.path.join(b.OBJDIR, "prot_kernels.o"),
-                os.path.join(b.OBJDIR, "prot_kernels_f16.o"), os.path.join(b.OBJDIR, "prot_capi.o"), "-lpthread"])
+                os.path.join(b.OBJDIR, "prot_sweep.o"), os.path.join(b.OBJDIR, "prot_kernels_f16.o"), CAPI_T, "-lpthread"])
         print("built", lib)
         continue
     tag, _, fl = arg.partition(":")
@@ -40,6 +45,6 @@ for arg in sys.argv[1:]:
             "-amdgpu-mfma-vgpr-form"] + extra + ["-c", os.path.join(b.CSRC, "prot_kernels.hip"), "-o", o])
     lib = os.path.join(vdir, "libprot_hip_%s.so" % tag)
     b._run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, o,
-            os.path.join(b.OBJDIR, "prot_kernels_f16.o"), os.path.join(b.OBJDIR, "prot_olasave.o"),
-            os.path.join(b.OBJDIR, "prot_capi.o"), "-lpthread"])
+            os.path.join(b.OBJDIR, "prot_sweep.o"), os.path.join(b.OBJDIR, "prot_kernels_f16.o"), os.path.join(b.OBJDIR, "prot_olasave.o"),
+            CAPI_T, "-lpthread"])
     print("built", lib)

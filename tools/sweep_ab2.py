@@ -9,6 +9,7 @@ sys.path.insert(0, %r)
 import numpy as np, torch
 from __graft_entry__ import load_package
 pkg = load_package()
+pkg.set_test_option(pkg.TEST_SWEEP_UNPRUNED, int(os.environ.get("SWEEP_AB_UNPRUNED", "0")))
 dev = torch.device("cuda:0")
 P, nc = 2048, 2
 n = int(600 * 96000) // P * P
@@ -43,7 +44,7 @@ for a in args:
     if "=" in a:
         tag, lib = a.split("=", 1)
         variants.append((tag, {} if lib == "main" else {"PROT_LIB_PATH": os.path.abspath(lib)}))
-variants.append(("unpruned(main)", {"PROT_SWEEP_PRUNE": "0"}))
+variants.append(("unpruned(main)", {"SWEEP_AB_UNPRUNED": "1"}))
 res = {v[0]: {} for v in variants}
 for r in range(R):
     for name, env in variants[r % len(variants):] + variants[:r % len(variants)]:

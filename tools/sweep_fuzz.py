@@ -44,7 +44,7 @@ for k in range(cases):
     x = signal(n, nc)
     tabs = []
     for prune in (1, 0):
-        os.environ["PROT_SWEEP_PRUNE"] = str(prune)
+        pkg.set_test_option(pkg.TEST_SWEEP_UNPRUNED, 1 - prune)
         g = pkg.PhaseRotate(P, nc)
         if rng.random() < 0.5 or prune == 0 and False:
             pass
@@ -58,5 +58,5 @@ for k in range(cases):
         bad += 1
         d = np.argwhere(tabs[0] != tabs[1])
         print("MISMATCH case %d: P %d nc %d n %d angles %d..%d step %d: %d entries differ, first %s" % (k, P, nc, n, a0, a1, st, len(d), d[:3].tolist()), flush=True)
-os.environ.pop("PROT_SWEEP_PRUNE", None)
+pkg.set_test_option(pkg.TEST_SWEEP_UNPRUNED, 0)
 print("%d cases, %d mismatches" % (cases, bad))

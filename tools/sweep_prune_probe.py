@@ -22,7 +22,7 @@ sigs = {"uniform noise": noise,
 for name, x in sigs.items():
     res = {}
     for prune in (1, 0, 1, 0):
-        os.environ["PROT_SWEEP_PRUNE"] = str(prune)
+        pkg.set_test_option(pkg.TEST_SWEEP_UNPRUNED, 1 - prune)
         e = pkg.Engine(pkg.KIND_CLI, P, nc)
         pk = torch.zeros(nc * 360, device=dev)
         torch.cuda.synchronize()
