@@ -108,7 +108,7 @@ class Prog:
                 del q[:len(q) - left]
 
     def add(self, i):
-        if self.auto and i.op not in ("comment", "label", "s_waitcnt"):
+        if self.auto and i.op not in ("comment", "label", "s_waitcnt", "probe"):
             regs = set()
             for k in ("d", "a", "b", "sh", "addr", "data", "voff"):
                 if hasattr(i, k):
@@ -159,6 +159,9 @@ class Prog:
     def v_lshr(self, d, sh, a): return self.add(Ins("v_lshr", "v_lshrrev_b32 %r, %r, %r" % (d, sh, a), d=d, a=a, sh=sh))
     def v_add_u32(self, d, a, b): return self.add(Ins("v_add_u32", "v_add_u32 %r, %r, %r" % (d, a, b), d=d, a=a, b=b))
     def v_mul_u24(self, d, a, b): return self.add(Ins("v_mul_u24", "v_mul_u32_u24 %r, %r, %r" % (d, a, b), d=d, a=a, b=b))
+    def v_cmp_eq_u32(self, a, b): return self.add(Ins("v_cmp_eq", "v_cmp_eq_u32 vcc, %r, %r" % (a, b), a=a, b=b))      # (a: constant or SGPR, b: VGPR)
+    def v_cmp_lt_u32(self, a, b): return self.add(Ins("v_cmp_lt", "v_cmp_lt_u32 vcc, %r, %r" % (a, b), a=a, b=b))      # vcc = a < b
+    def v_cndmask(self, d, a, b): return self.add(Ins("v_cndmask", "v_cndmask_b32 %r, %r, %r, vcc" % (d, a, b), d=d, a=a, b=b))  # d = vcc ? b : a
 
     # ---- LDS ----
     def ds_write_b64(self, addr, data, off=0):
@@ -188,6 +191,7 @@ class Prog:
     def s_add_u32(self, d, a, b): return self.add(Ins("s_add_u32", "s_add_u32 %r, %r, %r" % (d, a, b), d=d, a=a, b=b))
     def s_addc_u32(self, d, a, b): return self.add(Ins("s_addc_u32", "s_addc_u32 %r, %r, %r" % (d, a, b), d=d, a=a, b=b))
     def s_sub_u32(self, d, a, b): return self.add(Ins("s_sub_u32", "s_sub_u32 %r, %r, %r" % (d, a, b), d=d, a=a, b=b))
+    def s_subb_u32(self, d, a, b): return self.add(Ins("s_subb_u32", "s_subb_u32 %r, %r, %r" % (d, a, b), d=d, a=a, b=b))
     def s_cselect(self, d, a, b): return self.add(Ins("s_cselect", "s_cselect_b32 %r, %r, %r" % (d, a, b), d=d, a=a, b=b))
     def s_cmp_lg_u32(self, a, b): return self.add(Ins("s_cmp_lg", "s_cmp_lg_u32 %r, %r" % (a, b), a=a, b=b))
     def s_cmp_eq_u32(self, a, b): return self.add(Ins("s_cmp_eq", "s_cmp_eq_u32 %r, %r" % (a, b), a=a, b=b))
@@ -210,13 +214,42 @@ class Prog:
     def s_nop(self, n=0): return self.add(Ins("s_nop", "s_nop %d" % n))
     def s_setprio(self, n): return self.add(Ins("s_nop", "s_setprio %d" % n))
     def comment(self, txt): return self.add(Ins("comment", "; " + txt))
+    def probe(self, name, regs):   # emulator only: snapshot of registers (debugging a generator)
+        return self.add(Ins("probe", "; probe " + name, name=name, regs=list(regs)))
     def raw(self, txt):  # text the emulator ignores (input copies in the C++ wrapper's dialect)
         return self.add(Ins("comment", txt))
+
+    # ---- wave-uniform branches: the wait bookkeeping of two alternative instruction sequences
+    def settle(self, regs):
+        """nothing in flight may still write these registers from here on (call in front of a region some waves skip: a wait
+        inserted INSIDE it would be skipped with it)"""
+        r = set()
+        for x in regs:
+            r |= self._regs(x)
+        self._need(r)
+
+    def fork(self):
+        return ([set(x) for x in self.vmq], [set(x) for x in self.lgq], sum(1 for i in self.ins if i.op == "s_waitcnt"))
+
+    def restore(self, st):
+        self.vmq, self.lgq = [set(x) for x in st[0]], [set(x) for x in st[1]]
+
+    def join(self, other):
+        """merge the bookkeeping of the alternative that was emitted last with `other` (the state at the end of the one before):
+        both must have put the same number of operations in flight; a register either of them loads counts as loading"""
+        assert len(self.vmq) == len(other[0]) and len(self.lgq) == len(other[1]), "alternatives differ in what they leave in flight"
+        self.vmq = [a | b for a, b in zip(self.vmq, other[0])]
+        self.lgq = [a | b for a, b in zip(self.lgq, other[1])]
+
+    def assert_no_waits_since(self, st):
+        assert sum(1 for i in self.ins if i.op == "s_waitcnt") == st[2], "a wait was inserted inside a region that some waves skip"
 
     def text(self, label_suffix=""):
         out = []
         for i in self.ins:
             t = i.text
+            if i.op == "probe":
+                continue
             if i.op == "label":
                 t = "%s%s:" % (i.name, label_suffix)
             elif hasattr(i, "label"):
@@ -232,18 +265,41 @@ class Prog:
 
 
 # ------------------------------------------------------------------------------------------------ emulator
-class Emu:
-    NT = 256
-
-    def __init__(self, lds_bytes=65536, check_waits=True):
-        self.v = np.zeros((256, self.NT), np.uint32)
-        self.s = np.zeros((4, 128), np.uint32)          # per wave
+class _Wave:
+    def __init__(self):
+        self.v = np.zeros((256, 64), np.uint32)
+        self.s = np.zeros(128, np.uint32)
         self.scc = 0
+        self.vcc = np.zeros(64, bool)
+        self.pc = 0
+        self.vm_q, self.lgkm_q = [], []     # in-flight ops: (kind, regs)
+        self.recent = []                    # VGPRs written by the last two VALU instructions (DPP hazard: 2 wait states)
+        self.sgpr_wr = 99                   # instructions since a VALU wrote an SGPR (v_readlane / v_readfirstlane)
+        self.done = False
+
+
+class Emu:
+    """One workgroup of NT threads (NT / 64 waves).  Every wave has its own program counter, registers, SCC and wait
+    queues; the waves run ONE AFTER THE OTHER from barrier to barrier (a legal interleaving of a race-free program), so
+    wave-uniform branches may diverge between waves.  That the program IS race-free in LDS is checked: a slot written by
+    one wave and touched by another between the same two barriers is an error (the exchanges that skip the workgroup
+    barrier must stay inside one wave).  The old interface (emu.v[reg][thread], emu.s[wave, reg]) is kept as views."""
+    def __init__(self, lds_bytes=65536, check_waits=True, n_threads=256):
+        assert n_threads % 64 == 0
+        self.NT = n_threads
+        self.NW = n_threads // 64
+        self.waves = [_Wave() for _ in range(self.NW)]
         self.lds = np.zeros(lds_bytes // 4, np.uint32)
         self.mem = {}                                   # base address -> (np.uint32 array)
         self.check = check_waits
-        self.vm_q, self.lgkm_q = [], []                 # in-flight ops: (kind, regs)
-        self.v[255, :] = 0
+        self.epoch = 0
+        self.probes = {}
+        self.lds_w_epoch = np.full(lds_bytes // 4, -1, np.int64)   # last write: barrier epoch, wave
+        self.lds_w_wave = np.zeros(lds_bytes // 4, np.int64)
+        self.lds_r_epoch = np.full(lds_bytes // 4, -1, np.int64)   # reads in the current epoch: epoch, bit mask of waves
+        self.lds_r_mask = np.zeros(lds_bytes // 4, np.int64)
+        self.v = _VView(self)
+        self.s = _SView(self)
 
     # memory regions
     def map(self, base, arr_u32):
@@ -255,26 +311,24 @@ class Emu:
                 return b, a
         raise RuntimeError("unmapped address 0x%x" % addr)
 
-    # waits discipline
-    def _busy_regs(self):
-        busy = {}
-        for kind, regs in self.vm_q + self.lgkm_q:
-            if kind in ("store", "dswrite"):   # data is read when the instruction issues
-                continue
-            for r in regs:
-                busy[r] = kind
-        return busy
+    # LDS race discipline
+    def _lds_write(self, w, words, what):
+        E = self.epoch
+        other_w = (self.lds_w_epoch[words] == E) & (self.lds_w_wave[words] != w)
+        other_r = (self.lds_r_epoch[words] == E) & ((self.lds_r_mask[words] & ~(1 << w)) != 0)
+        if other_w.any() or other_r.any():
+            raise RuntimeError("LDS race: wave %d %s a slot another wave %s since the last barrier" % (w, what, "wrote" if other_w.any() else "read"))
+        self.lds_w_epoch[words] = E
+        self.lds_w_wave[words] = w
 
-    def _touch(self, reads, writes, what):
-        if not self.check:
-            return
-        busy = self._busy_regs()
-        for r in reads:
-            if r in busy and busy[r] in ("load", "dsread"):
-                raise RuntimeError("%s reads v%d while a %s into it is in flight" % (what, r, busy[r]))
-        for r in writes:
-            if r in busy:
-                raise RuntimeError("%s writes v%d while a %s on it is in flight" % (what, r, busy[r]))
+    def _lds_read(self, w, words, what):
+        E = self.epoch
+        other_w = (self.lds_w_epoch[words] == E) & (self.lds_w_wave[words] != w)
+        if other_w.any():
+            raise RuntimeError("LDS race: wave %d %s a slot another wave wrote since the last barrier" % (w, what))
+        stale = self.lds_r_epoch[words] != E
+        self.lds_r_mask[words] = np.where(stale, 0, self.lds_r_mask[words]) | (1 << w)
+        self.lds_r_epoch[words] = E
 
     @staticmethod
     def _regs(x):
@@ -282,63 +336,111 @@ class Emu:
         if isinstance(x, VP): return [x.n, x.n + 1]
         return []
 
-    # operand access
-    def _rd32(self, x):
-        if isinstance(x, V): return self.v[x.n].copy()
-        if isinstance(x, S): return np.repeat(self.s[:, x.n], 64)
-        if isinstance(x, Lit): return np.full(self.NT, x.bits(), np.uint32)
-        if isinstance(x, (int, np.integer)): return np.full(self.NT, np.uint32(x & 0xffffffff), np.uint32)
-        raise TypeError(x)
+    def run(self, prog, max_steps=20_000_000):
+        steps = 0
+        for wv in self.waves:
+            wv.pc, wv.done = 0, False
+        while not all(wv.done for wv in self.waves):
+            at_barrier = 0
+            for w, wv in enumerate(self.waves):
+                if wv.done:
+                    continue
+                n, hit = self._run_wave(prog, w, wv, max_steps - steps)
+                steps += n
+                at_barrier += hit
+            live = sum(not wv.done for wv in self.waves)
+            if at_barrier not in (0, self.NW) and live != at_barrier:
+                raise RuntimeError("some waves ended while others wait at a barrier")
+            if at_barrier and at_barrier != self.NW:
+                raise RuntimeError("barrier reached by %d of %d waves" % (at_barrier, self.NW))
+            self.epoch += 1
+        return steps
 
-    def _rd64(self, x):
-        if isinstance(x, VP): return self.v[x.n].copy(), self.v[x.n + 1].copy()
-        if isinstance(x, SP): return np.repeat(self.s[:, x.n], 64), np.repeat(self.s[:, x.n + 1], 64)
-        raise TypeError(x)
-
-    def _srd(self, x):  # scalar read, per wave [4]
-        if isinstance(x, S): return self.s[:, x.n].copy()
-        if isinstance(x, Lit): return np.full(4, x.bits(), np.uint32)
-        if isinstance(x, (int, np.integer)): return np.full(4, np.uint32(x & 0xffffffff), np.uint32)
-        raise TypeError(x)
-
-    def run(self, prog, max_steps=10_000_000):
-        pc, steps = 0, 0
+    def _run_wave(self, prog, w, W_, budget):
+        """runs wave w until its next s_barrier (returns (steps, 1)) or the end of the program (steps, 0)"""
         ins = prog.ins
-        recent = []   # VGPRs written by the last two VALU instructions (DPP hazard: 2 wait states)
-        sgpr_wr = 99  # instructions since a VALU wrote an SGPR (v_readlane / v_readfirstlane)
         f32 = lambda u: u.view(np.float32)
-        while pc < len(ins):
-            i = ins[pc]
-            pc += 1
+        v, s = W_.v, W_.s
+        steps = 0
+
+        def busy_regs():
+            busy = {}
+            for kind, regs in W_.vm_q + W_.lgkm_q:
+                if kind in ("store", "dswrite"):   # data is read when the instruction issues
+                    continue
+                for r in regs:
+                    busy[r] = kind
+            return busy
+
+        def touch(reads, writes, what):
+            if not self.check:
+                return
+            busy = busy_regs()
+            for r in reads:
+                if r in busy and busy[r] in ("load", "dsread"):
+                    raise RuntimeError("%s reads v%d while a %s into it is in flight" % (what, r, busy[r]))
+            for r in writes:
+                if r in busy:
+                    raise RuntimeError("%s writes v%d while a %s on it is in flight" % (what, r, busy[r]))
+
+        def rd32(x):
+            if isinstance(x, V): return v[x.n].copy()
+            if isinstance(x, S): return np.full(64, s[x.n], np.uint32)
+            if isinstance(x, Lit): return np.full(64, x.bits(), np.uint32)
+            if isinstance(x, (int, np.integer)): return np.full(64, np.uint32(x & 0xffffffff), np.uint32)
+            raise TypeError(x)
+
+        def rd64(x):
+            if isinstance(x, VP): return v[x.n].copy(), v[x.n + 1].copy()
+            if isinstance(x, SP): return np.full(64, s[x.n], np.uint32), np.full(64, s[x.n + 1], np.uint32)
+            raise TypeError(x)
+
+        def srd(x):
+            if isinstance(x, S): return int(s[x.n])
+            if isinstance(x, Lit): return int(x.bits())
+            if isinstance(x, (int, np.integer)): return int(x) & 0xffffffff
+            raise TypeError(x)
+
+        regs_of = self._regs
+        while W_.pc < len(ins):
+            i = ins[W_.pc]
+            W_.pc += 1
             steps += 1
-            if steps > max_steps:
+            if steps > budget:
                 raise RuntimeError("emulation did not terminate")
             op = i.op
-            if op in ("comment", "label", "s_barrier"):
+            if op in ("comment", "label"):
                 continue
+            if op == "probe":
+                snap = self.probes.setdefault(i.name, {})
+                if w not in snap:   # (first visit)
+                    snap[w] = {r.n: (v[r.n].copy(), v[r.n + 1].copy()) if isinstance(r, VP) else v[r.n].copy() for r in i.regs}
+                continue
+            if op == "s_barrier":
+                return steps, 1
             if op == "s_nop":
-                recent = (recent + [set()])[-2:]
-                sgpr_wr += 5
+                W_.recent = (W_.recent + [set()])[-2:]
+                W_.sgpr_wr += 5
                 continue
             # measured on gfx950: a VALU instruction reading an SGPR directly behind a VALU write of an SGPR reads garbage
             if op.startswith("pk_") or (op.startswith("v_") and op not in ("v_readlane", "v_readfirstlane")):
                 srcs = list(getattr(i, "srcs", [])) + [getattr(i, k) for k in ("a", "b", "sh") if hasattr(i, k)]
-                if sgpr_wr < 3 and any(isinstance(x, (S, SP)) for x in srcs):
-                    raise RuntimeError("SGPR hazard: %s reads an SGPR %d instruction(s) after a VALU wrote one" % (i.text, sgpr_wr + 1))
-            sgpr_wr = 0 if op in ("v_readlane", "v_readfirstlane") else sgpr_wr + (5 if op == "s_nop" else 1)
+                if W_.sgpr_wr < 3 and any(isinstance(x, (S, SP)) for x in srcs):
+                    raise RuntimeError("SGPR hazard: %s reads an SGPR %d instruction(s) after a VALU wrote one" % (i.text, W_.sgpr_wr + 1))
+            W_.sgpr_wr = 0 if op in ("v_readlane", "v_readfirstlane") else W_.sgpr_wr + 1
             if op in ("v_mov_dpp_shr1", "v_mov_dpp_rowshl"):
-                used = set(self._regs(i.a) + self._regs(i.d))
-                for w in recent:
-                    if w & used:
+                used = set(regs_of(i.a) + regs_of(i.d))
+                for wr in W_.recent:
+                    if wr & used:
                         raise RuntimeError("DPP hazard: %s within 2 wait states of a VALU write of its register" % i.text)
             if op.startswith("pk_") or op.startswith("v_"):
-                recent = (recent + [set(self._regs(i.d)) if op not in ("v_readlane", "v_readfirstlane") else set()])[-2:]
+                W_.recent = (W_.recent + [set(regs_of(i.d)) if op not in ("v_readlane", "v_readfirstlane", "v_cmp_eq", "v_cmp_lt") else set()])[-2:]
             else:
-                recent = (recent + [set()])[-2:]
+                W_.recent = (W_.recent + [set()])[-2:]
             if op.startswith("pk_"):
-                reads = sum((self._regs(x) for x in i.srcs), [])
-                self._touch(reads, self._regs(i.d), i.text)
-                vals = [self._rd64(x) for x in i.srcs]
+                reads = sum((regs_of(x) for x in i.srcs), [])
+                touch(reads, regs_of(i.d), i.text)
+                vals = [rd64(x) for x in i.srcs]
                 def pick(k, sel, neg):
                     lo, hi = vals[k]
                     x = f32(hi if sel else lo).astype(np.float64)
@@ -352,114 +454,144 @@ class Emu:
                     elif op == "pk_fma": r = (a * b + pick(2, sels[2], negs[2]))
                     else: raise RuntimeError(op)
                     res.append(r.astype(np.float32).view(np.uint32))
-                self.v[i.d.n], self.v[i.d.n + 1] = res[0], res[1]
+                v[i.d.n], v[i.d.n + 1] = res[0], res[1]
             elif op == "v_mov":
-                self._touch(self._regs(i.a), self._regs(i.d), i.text)
-                self.v[i.d.n] = self._rd32(i.a)
+                touch(regs_of(i.a), regs_of(i.d), i.text)
+                v[i.d.n] = rd32(i.a)
             elif op == "v_mov_dpp_shr1":
-                self._touch(self._regs(i.a) + self._regs(i.d), self._regs(i.d), i.text)
-                src = self.v[i.a.n].reshape(4, 64)
-                dst = self.v[i.d.n].reshape(4, 64).copy()
-                dst[:, 1:] = src[:, :-1]
-                self.v[i.d.n] = dst.reshape(-1)
+                touch(regs_of(i.a) + regs_of(i.d), regs_of(i.d), i.text)
+                src = v[i.a.n].copy()
+                v[i.d.n][1:] = src[:-1]
             elif op == "v_mov_dpp_rowshl":
-                self._touch(self._regs(i.a) + self._regs(i.d), self._regs(i.d), i.text)
-                src = self.v[i.a.n].reshape(4, 64)
-                dst = self.v[i.d.n].reshape(4, 64).copy()
+                touch(regs_of(i.a) + regs_of(i.d), regs_of(i.d), i.text)
+                src = v[i.a.n].copy()
                 for lane in range(4):
                     if lane + i.k <= 15:
-                        dst[:, lane] = src[:, lane + i.k]
-                self.v[i.d.n] = dst.reshape(-1)
+                        v[i.d.n][lane] = src[lane + i.k]
             elif op == "v_mul_f32":
-                self._touch(self._regs(i.a) + self._regs(i.b), self._regs(i.d), i.text)
-                a, b = self._rd32(i.a).view(np.float32), self._rd32(i.b).view(np.float32)
-                self.v[i.d.n] = (a * b).astype(np.float32).view(np.uint32)
+                touch(regs_of(i.a) + regs_of(i.b), regs_of(i.d), i.text)
+                a, b = rd32(i.a).view(np.float32), rd32(i.b).view(np.float32)
+                v[i.d.n] = (a * b).astype(np.float32).view(np.uint32)
             elif op == "v_readfirstlane":
-                self._touch(self._regs(i.a), [], i.text)
-                self.s[:, i.d.n] = self.v[i.a.n].reshape(4, 64)[:, 0]
+                touch(regs_of(i.a), [], i.text)
+                s[i.d.n] = v[i.a.n][0]
             elif op == "v_readlane":
-                self._touch(self._regs(i.a), [], i.text)
-                self.s[:, i.d.n] = self.v[i.a.n].reshape(4, 64)[:, i.lane]
+                touch(regs_of(i.a), [], i.text)
+                s[i.d.n] = v[i.a.n][i.lane]
             elif op in ("v_and", "v_add_u32", "v_mul_u24"):
-                self._touch(self._regs(i.a) + self._regs(i.b), self._regs(i.d), i.text)
-                a, b = self._rd32(i.a).astype(np.uint64), self._rd32(i.b).astype(np.uint64)
+                touch(regs_of(i.a) + regs_of(i.b), regs_of(i.d), i.text)
+                a, b = rd32(i.a).astype(np.uint64), rd32(i.b).astype(np.uint64)
                 r = (a & b) if op == "v_and" else (a + b) if op == "v_add_u32" else ((a & 0xffffff) * (b & 0xffffff))
-                self.v[i.d.n] = (r & 0xffffffff).astype(np.uint32)
+                v[i.d.n] = (r & 0xffffffff).astype(np.uint32)
+            elif op in ("v_cmp_eq", "v_cmp_lt"):
+                touch(regs_of(i.a) + regs_of(i.b), [], i.text)
+                a, b = rd32(i.a), rd32(i.b)
+                W_.vcc = (a == b) if op == "v_cmp_eq" else (a < b)
+            elif op == "v_cndmask":
+                touch(regs_of(i.a) + regs_of(i.b), regs_of(i.d), i.text)
+                v[i.d.n] = np.where(W_.vcc, rd32(i.b), rd32(i.a))
             elif op in ("v_lshl", "v_lshr"):
-                self._touch(self._regs(i.a), self._regs(i.d), i.text)
-                a, sh = self._rd32(i.a).astype(np.uint64), self._rd32(i.sh).astype(np.uint64) & 31
+                touch(regs_of(i.a), regs_of(i.d), i.text)
+                a, sh = rd32(i.a).astype(np.uint64), rd32(i.sh).astype(np.uint64) & 31
                 r = (a << sh) if op == "v_lshl" else (a >> sh)
-                self.v[i.d.n] = (r & 0xffffffff).astype(np.uint32)
+                v[i.d.n] = (r & 0xffffffff).astype(np.uint32)
             elif op == "ds_write_b64":
-                self._touch(self._regs(i.addr) + self._regs(i.data), [], i.text)
-                a = (self._rd32(i.addr).astype(np.int64) + i.off)
+                touch(regs_of(i.addr) + regs_of(i.data), [], i.text)
+                a = (rd32(i.addr).astype(np.int64) + i.off)
                 assert np.all(a % 8 == 0) and a.max() + 8 <= self.lds.size * 4, "LDS address"
-                w = a // 4
-                assert len(set(w.tolist())) == self.NT, "two lanes store to one LDS slot"
-                lo, hi = self._rd64(i.data)
-                self.lds[w], self.lds[w + 1] = lo, hi
-                self.lgkm_q.append(("dswrite", self._regs(i.data)))
+                wd = a // 4
+                assert len(set(wd.tolist())) == 64, "two lanes store to one LDS slot"
+                self._lds_write(w, np.concatenate([wd, wd + 1]), "writes")
+                lo, hi = rd64(i.data)
+                self.lds[wd], self.lds[wd + 1] = lo, hi
+                W_.lgkm_q.append(("dswrite", regs_of(i.data)))
             elif op == "ds_read_b64":
-                self._touch(self._regs(i.addr), self._regs(i.d), i.text)
-                a = (self._rd32(i.addr).astype(np.int64) + i.off)
+                touch(regs_of(i.addr), regs_of(i.d), i.text)
+                a = (rd32(i.addr).astype(np.int64) + i.off)
                 assert np.all(a % 8 == 0) and a.max() + 8 <= self.lds.size * 4, "LDS address"
-                w = a // 4
-                self.v[i.d.n], self.v[i.d.n + 1] = self.lds[w], self.lds[w + 1]
-                self.lgkm_q.append(("dsread", self._regs(i.d)))
+                wd = a // 4
+                self._lds_read(w, np.concatenate([wd, wd + 1]), "reads")
+                v[i.d.n], v[i.d.n + 1] = self.lds[wd], self.lds[wd + 1]
+                W_.lgkm_q.append(("dsread", regs_of(i.d)))
             elif op == "ds_read_b32":
-                self._touch(self._regs(i.addr), self._regs(i.d), i.text)
-                a = (self._rd32(i.addr).astype(np.int64) + i.off)
+                touch(regs_of(i.addr), regs_of(i.d), i.text)
+                a = (rd32(i.addr).astype(np.int64) + i.off)
                 assert np.all(a % 4 == 0) and a.max() + 4 <= self.lds.size * 4, "LDS address"
-                self.v[i.d.n] = self.lds[a // 4]
-                self.lgkm_q.append(("dsread", self._regs(i.d)))
+                self._lds_read(w, a // 4, "reads")
+                v[i.d.n] = self.lds[a // 4]
+                W_.lgkm_q.append(("dsread", regs_of(i.d)))
             elif op in ("gload2", "gload1", "gstore2"):
-                base = (self._srd(i.sbase.lo).astype(np.uint64) | (self._srd(i.sbase.hi).astype(np.uint64) << 32))
-                addr = np.repeat(base, 64).astype(np.int64) + self._rd32(i.voff).astype(np.int64) + i.off
+                base = srd(i.sbase.lo) | (srd(i.sbase.hi) << 32)
+                addr = base + rd32(i.voff).astype(np.int64) + i.off
                 b0, arr = self._region(int(addr.min()))
                 assert int(addr.max()) + (4 if op == "gload1" else 8) <= b0 + arr.size * 4, "global access out of its buffer"
                 assert np.all(addr % 4 == 0)
-                w = ((addr - b0) // 4).astype(np.int64)
+                wd = ((addr - b0) // 4).astype(np.int64)
                 if op == "gload2":
-                    self._touch(self._regs(i.voff), self._regs(i.d), i.text)
-                    self.v[i.d.n], self.v[i.d.n + 1] = arr[w], arr[w + 1]
-                    self.vm_q.append(("load", self._regs(i.d)))
+                    touch(regs_of(i.voff), regs_of(i.d), i.text)
+                    v[i.d.n], v[i.d.n + 1] = arr[wd], arr[wd + 1]
+                    W_.vm_q.append(("load", regs_of(i.d)))
                 elif op == "gload1":
-                    self._touch(self._regs(i.voff), self._regs(i.d), i.text)
-                    self.v[i.d.n] = arr[w]
-                    self.vm_q.append(("load", self._regs(i.d)))
+                    touch(regs_of(i.voff), regs_of(i.d), i.text)
+                    v[i.d.n] = arr[wd]
+                    W_.vm_q.append(("load", regs_of(i.d)))
                 else:
-                    self._touch(self._regs(i.voff) + self._regs(i.data), [], i.text)
-                    lo, hi = self._rd64(i.data)
-                    arr[w], arr[w + 1] = lo, hi
-                    self.vm_q.append(("store", self._regs(i.data)))
+                    touch(regs_of(i.voff) + regs_of(i.data), [], i.text)
+                    lo, hi = rd64(i.data)
+                    arr[wd], arr[wd + 1] = lo, hi
+                    W_.vm_q.append(("store", regs_of(i.data)))
             elif op == "s_waitcnt":
                 if i.vmcnt is not None:
-                    while len(self.vm_q) > i.vmcnt: self.vm_q.pop(0)
+                    while len(W_.vm_q) > i.vmcnt: W_.vm_q.pop(0)
                 if i.lgkmcnt is not None:
-                    while len(self.lgkm_q) > i.lgkmcnt: self.lgkm_q.pop(0)
+                    while len(W_.lgkm_q) > i.lgkmcnt: W_.lgkm_q.pop(0)
             elif op == "s_mov":
-                self.s[:, i.d.n] = self._srd(i.a)
+                s[i.d.n] = srd(i.a)
             elif op == "s_mov64":
-                self.s[:, i.d.n], self.s[:, i.d.n + 1] = self._srd(i.a.lo), self._srd(i.a.hi)
-            elif op in ("s_add_u32", "s_addc_u32", "s_sub_u32"):
-                a, b = self._srd(i.a).astype(np.uint64), self._srd(i.b).astype(np.uint64)
+                s[i.d.n], s[i.d.n + 1] = srd(i.a.lo), srd(i.a.hi)
+            elif op in ("s_add_u32", "s_addc_u32", "s_sub_u32", "s_subb_u32"):
+                a, b = srd(i.a), srd(i.b)
                 if op == "s_add_u32": r = a + b
-                elif op == "s_addc_u32": r = a + b + np.uint64(self.scc)
-                else: r = (a + (np.uint64(1 << 32) - b))
-                if op == "s_sub_u32":
-                    self.scc = int(b[0] > a[0])
-                else:
-                    self.scc = int(r[0] >> 32) & 1
-                self.s[:, i.d.n] = (r & 0xffffffff).astype(np.uint32)
+                elif op == "s_addc_u32": r = a + b + W_.scc
+                elif op == "s_sub_u32": r = a + ((1 << 32) - b)
+                else: r = a + ((1 << 32) - b - W_.scc) if (b + W_.scc) else a + (1 << 32)
+                if op == "s_sub_u32": W_.scc = int(b > a)
+                elif op == "s_subb_u32": W_.scc = int(b + W_.scc > a)
+                else: W_.scc = (r >> 32) & 1
+                s[i.d.n] = r & 0xffffffff
             elif op == "s_cselect":
-                self.s[:, i.d.n] = self._srd(i.a) if self.scc else self._srd(i.b)
+                s[i.d.n] = srd(i.a) if W_.scc else srd(i.b)
             elif op in ("s_cmp_lg", "s_cmp_eq"):
-                a, b = self._srd(i.a), self._srd(i.b)
-                self.scc = int((a[0] != b[0]) if op == "s_cmp_lg" else (a[0] == b[0]))
+                a, b = srd(i.a), srd(i.b)
+                W_.scc = int((a != b) if op == "s_cmp_lg" else (a == b))
             elif op in ("s_cbranch_scc1", "s_cbranch_scc0", "s_branch"):
-                take = True if op == "s_branch" else (self.scc == 1) if op == "s_cbranch_scc1" else (self.scc == 0)
+                take = True if op == "s_branch" else (W_.scc == 1) if op == "s_cbranch_scc1" else (W_.scc == 0)
                 if take:
-                    pc = prog.labels[i.label]
+                    W_.pc = prog.labels[i.label]
             else:
                 raise RuntimeError("emulator: unknown op " + op)
-        return steps
+        W_.done = True
+        return steps, 0
+
+
+class _VView:   # emu.v[reg] -> all threads' values of one VGPR, as the pre-round-4 emulator exposed them (read / assign)
+    def __init__(self, emu): self.e = emu
+    def __getitem__(self, n): return np.concatenate([w.v[n] for w in self.e.waves])
+    def __setitem__(self, n, val):
+        val = np.broadcast_to(np.asarray(val, np.uint32), (self.e.NT,))
+        for k, w in enumerate(self.e.waves):
+            w.v[n] = val[64 * k:64 * k + 64]
+
+
+class _SView:   # emu.s[:, n] / emu.s[wave, n]
+    def __init__(self, emu): self.e = emu
+    def __setitem__(self, key, val):
+        wsel, n = key
+        ws = range(self.e.NW) if isinstance(wsel, slice) else [wsel]
+        for w in ws:
+            self.e.waves[w].s[n] = np.uint32(int(val) & 0xffffffff)
+    def __getitem__(self, key):
+        wsel, n = key
+        if isinstance(wsel, slice):
+            return np.array([w.s[n] for w in self.e.waves], np.uint32)
+        return self.e.waves[wsel].s[n]

@@ -1,0 +1,112 @@
+"""numpy model of the 8192-point overlap-save block (round 4; olasave8k_kernel): 512 threads, 16 points per thread, three
+radix-16 passes over the digits (a, b, c) / (k1, k2, k3) plus ONE radix-2 layer over the top bit e of the thread index
+(T = 256 e + 16 b + c; k = k1 + 16 ke + 32 k2 + 512 k3), the forward transform again evaluated at the half-shifted index
+p - 1/2 so that the odd-tap polyphase filter g needs no spectrum table (see olasave_model.py for the 4096-point form).
+
+A block holds 16 rows of 512 complex samples; NT = len(g) / 512 rows are context.  For odd NT the valid outputs would
+straddle row boundaries, so the block is loaded circularly rotated by half a row: position p holds local sample
+n = (p + 256) mod 8192 -- circular convolution commutes with the rotation, nothing else changes, and the valid outputs
+are the whole rows R0 = NT // 2 ... R0 + HS - 1 (HS = 16 - NT).  Checked here against the direct convolution."""
+import numpy as np
+
+N = 8192
+
+
+def W(num, den):
+    return np.exp(-2j * np.pi * np.asarray(num, np.float64) / den)
+
+
+def hilbert_fir(n_taps):
+    n = np.arange(n_taps); m = n - n_taps // 2
+    fir = np.zeros(n_taps)
+    odd = (m % 2 != 0)
+    fir[odd] = -(2 / n_taps) / np.tan(np.pi * m[odd] / n_taps) * 0.5 * (1 - np.cos(2 * np.pi * n[odd] / n_taps))
+    return fir.astype(np.float32).astype(np.float64)
+
+
+def tables(g):
+    Lg = len(g)
+    assert Lg % 256 == 0 and np.all(g == -g[::-1])
+    H = np.fft.fft(np.concatenate([g, np.zeros(N - Lg)]))
+    k = np.arange(N)
+    B = (H / (W((Lg // 2) * k, N) * W(-k, 2 * N)) / (-1j))
+    assert np.abs(B.imag).max() < 1e-10
+    return B.real
+
+
+F16 = W(np.outer(np.arange(16), np.arange(16)), 16)   # DFT-16 kernel [out][in]
+
+
+def fwd_shifted(w):
+    """w[512 a + T] -> Z'[k] = sum_p w[p] W^{(p - 1/2) k}, k = k1 + 16 ke + 32 k2 + 512 k3; returns [k1][ke][k2][k3]"""
+    x = w.reshape(16, 512)                                   # [a][T]
+    u = np.einsum('ka,at->kt', F16, x)                       # pass 1: [k1][T]
+    T = np.arange(512)
+    u = u * W((T[None, :] - 0.5) * np.arange(16)[:, None], N)            # twiddle 1: W_N^{(T - 1/2) k1}
+    u = u.reshape(16, 2, 16, 16)                             # [k1][e][b][c]
+    v = np.stack([u[:, 0] + u[:, 1], u[:, 0] - u[:, 1]], 1)  # radix 2 over e -> ke: [k1][ke][b][c]
+    v = v * W(np.arange(16)[None, None, :, None] * np.arange(2)[None, :, None, None], 32)   # W32^{b ke}
+    y2 = np.einsum('jb,kebc->kejc', F16, v)                  # pass 2: [k1][ke][k2][c]
+    cc = np.arange(16)[None, None, None, :] - 0.5
+    y2 = y2 * W(cc * np.arange(2)[None, :, None, None], 512) * W(cc * np.arange(16)[None, None, :, None], 256)
+    y3 = np.einsum('lc,kejc->kejl', F16, y2)                 # pass 3: [k1][ke][k2][k3]
+    return y3 * W(-np.arange(16), 32)[None, None, None, :]   # W32^{-k3}
+
+
+def inv_plain(Y):
+    """Y[k1][ke][k2][k3] -> y[512 a + T] = sum_k Y[k] W^{-pk} (unnormalised)"""
+    Fi = np.conj(F16)
+    r = np.einsum('cl,kejl->kejc', Fi, Y)                    # over k3 -> c
+    cc = np.arange(16)[None, None, None, :]
+    r = r * np.conj(W(cc * np.arange(2)[None, :, None, None], 512) * W(cc * np.arange(16)[None, None, :, None], 256))
+    s = np.einsum('bj,kejc->kebc', Fi, r)                    # over k2 -> b
+    s = s * np.conj(W(np.arange(16)[None, None, :, None] * np.arange(2)[None, :, None, None], 32))
+    t = np.stack([s[:, 0] + s[:, 1], s[:, 0] - s[:, 1]], 1)  # over ke -> e: [k1][e][b][c]
+    t = t.reshape(16, 512)
+    T = np.arange(512)
+    t = t * np.conj(W(T[None, :] * np.arange(16)[:, None], N))
+    return np.einsum('ak,kt->at', Fi, t).reshape(N)          # over k1 -> a
+
+
+def kindex():
+    return (np.arange(16)[:, None, None, None] + 16 * np.arange(2)[None, :, None, None] +
+            32 * np.arange(16)[None, None, :, None] + 512 * np.arange(16)[None, None, None, :])
+
+
+def block(w, B, exact_B=False):
+    """one block at positions p (already rotated); valid outputs are the whole rows R0 .. R0 + HS - 1"""
+    Zp = fwd_shifted(w)
+    k = kindex()
+    Bk = B[k]
+    if not exact_B:                                          # |B| = 1 outside the rows next to DC: k3 = 0 and k3 = 15
+        keep = (k < 512) | (k >= N - 512)
+        Bk = np.where(keep, Bk, np.sign(Bk))
+    return inv_plain(Zp * (-1j) * Bk) / N
+
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(1)
+    # direct check of the transform pair against numpy's FFT
+    w = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    Z = np.fft.fft(w) * W(-np.arange(N), 2 * N)
+    assert np.abs(fwd_shifted(w) - Z[kindex()]).max() < 1e-9
+    assert np.abs(inv_plain(Z[kindex()] / W(-np.arange(N), 2 * N)[kindex()]) / N - w).max() < 1e-9
+    for n_taps, hs in [(3072, 13), (4096, 12), (2048, 14), (8192, 8), (1024, 15)]:
+        fir = hilbert_fir(n_taps)
+        g = fir[1::2]
+        Lg = len(g); NT = 16 - hs
+        assert Lg == 512 * NT
+        rot = 256 if NT % 2 else 0
+        R0 = NT // 2
+        B = tables(g)
+        dev = np.abs(np.abs(B) - 1)
+        rows = [float(dev[512 * r:512 * (r + 1)].max()) for r in range(3)]
+        z = 0.3 * (rng.standard_normal(N) + 1j * rng.standard_normal(N))
+        ref = np.convolve(z, g)                  # ref[n] = sum g[s] z[n - s]; block output local n <-> ref[n + Lg/2]
+        want = ref[Lg // 2:Lg // 2 + N]
+        wrot = np.roll(z, -rot)                  # w[p] = z[(p + rot) mod N]
+        lo, hi = 512 * R0, 512 * (R0 + hs)
+        e_exact = np.abs(block(wrot, B, True) - np.roll(want, -rot))[lo:hi].max()
+        e1 = np.abs(block(wrot, B, False) - np.roll(want, -rot))[lo:hi].max()
+        print("taps %5d HS %2d NT %2d rot %3d: |B|-1 by 512-bin row %s  err exact %.2e  table-free %.2e  sign(B) %s" % (
+            n_taps, hs, NT, rot, ["%.1e" % r for r in rows], e_exact, e1, set(np.sign(B[512:N - 512]).tolist())))
