@@ -77,6 +77,12 @@ typedef struct {
  * the caller must not reuse an input or output buffer of a launch before that.  PROT_PIPELINE=1 / =0 in the
  * environment forces it on / off. */
 #define PROT_CFG_PIPELINE 16u
+/* Overlap-save LV2 engines run LONG launches (>= 2^24 channel-frames) on 8192-point blocks (olasave8k_kernel: 512-thread
+ * workgroups, two per CU, 12 or 13 of 16 rows of a block new) and everything shorter on 4096-point blocks (olasave_kernel).
+ * This flag keeps the 4096-point kernel for every launch.  Same filter, results equal to a rounding error (~1e-7);
+ * for cross-checks and timing comparisons.  CLI engines always use ONE block size (sharded sweeps are bit-identical
+ * whatever the shard sizes because of it). */
+#define PROT_CFG_BLOCK4096 32u
 
 typedef struct {
 	int32_t  kind;
@@ -100,6 +106,7 @@ typedef struct {
 #define PROT_FORM_DIRECT 0u        /* partitions of the FIR itself, hop pairs as re/im (ola4096_kernel, ola4096p2_kernel) */
 #define PROT_FORM_POLY_OLA 1u      /* polyphase, overlap-add, spectrum table (olapoly_kernel) */
 #define PROT_FORM_POLY_SAVE 2u     /* polyphase, overlap-save, table-free, generated loop (olasave_kernel) */
+#define PROT_FORM_POLY_SAVE8K 3u   /* the same on 8192-point blocks for long launches (olasave8k_kernel), olasave_kernel for short ones */
 
 typedef struct prot_engine prot_engine;
 

@@ -28,7 +28,8 @@ CFG_DIRECT_FORM = 2
 CFG_POLYPHASE = 4
 CFG_OVERLAP_ADD = 8
 CFG_PIPELINE = 16
-FORM_DIRECT, FORM_POLY_OLA, FORM_POLY_SAVE = 0, 1, 2
+CFG_BLOCK4096 = 32
+FORM_DIRECT, FORM_POLY_OLA, FORM_POLY_SAVE, FORM_POLY_SAVE8K = 0, 1, 2, 3
 
 # every symbol include/prot_hip.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = (

@@ -191,6 +191,64 @@ bool save_tables (const std::vector<float>& fir, uint32_t F, std::vector<float>&
 	return false;
 }
 
+// The same for the 8192-point block (prot_olasave8k.hip; tools/gen/gen_olasave8k.py device_table): five rows of 512 float2 --
+// W_N^{(T - 1/2)}, W_N^{4 (T - 1/2)} (N = 8192), the half-shifted and the plain table of the middle passes ([ke][k2][c] and
+// its transpose: W512^{(c - 1/2) ke} W256^{(c - 1/2) k2}, W512^{c ke} W256^{c k2}), the |B| factors of the 512 bins either side
+// of DC per thread -- and gain = mean |B| / 8192.  firlen = 1024 NT, NT in {3, 4}.
+bool save_tables8k (const std::vector<float>& fir, std::vector<float>& tab, float& gain)
+{
+	const uint32_t F  = 8192;
+	const size_t   Lg = fir.size () / 2;
+	if (Lg % 512 != 0 || (Lg != 1536 && Lg != 2048)) {
+		return false;
+	}
+	std::vector<double> re (F, 0.0), im (F, 0.0);
+	for (size_t s = 0; s < Lg; ++s) {
+		if (fir[2 * s + 1] != -fir[2 * (Lg - 1 - s) + 1] || fir[2 * s] != 0.f) {
+			return false;
+		}
+		re[s] = fir[2 * s + 1];
+	}
+	fft_f64 (re, im);
+	std::vector<double> rho (F);
+	for (uint32_t k = 0; k < F; ++k) {
+		const double a  = 2.0 * M_PI * ((double)(Lg / 2) * k / F - (double)k / (2.0 * F));
+		const double pr = -std::sin (a), pi = -std::cos (a);
+		const double br = re[k] * pr + im[k] * pi, bi = im[k] * pr - re[k] * pi;
+		if (std::fabs (bi) > 1e-9) {
+			return false;
+		}
+		rho[k] = -br;
+	}
+	double mean = 0;
+	for (uint32_t k = 512; k < F - 512; ++k) {
+		mean += rho[k];
+	}
+	mean /= (double)(F - 1024);
+	for (uint32_t k = 512; k < F - 512; ++k) {
+		if (std::fabs (rho[k] / mean - 1.0) > 1.5e-7) {
+			return false;
+		}
+	}
+	gain = (float)(mean / F);
+	tab.assign (2 * (size_t)5 * 512, 0.f);
+	auto put = [&] (size_t idx, double ang) {
+		tab[2 * idx]     = (float)std::cos (ang);
+		tab[2 * idx + 1] = (float)std::sin (ang);
+	};
+	for (int T = 0; T < 512; ++T) {
+		put ((size_t)T, -2.0 * M_PI * (T - 0.5) / F);
+		put ((size_t)512 + T, -2.0 * M_PI * (T - 0.5) * 4.0 / F);
+		const int ke = T >> 8, hi = (T >> 4) & 15, lo = T & 15;
+		put ((size_t)2 * 512 + T, -2.0 * M_PI * ((lo - 0.5) * ke / 512.0 + (lo - 0.5) * hi / 256.0)); // [ke][k2 = hi][c = lo]
+		put ((size_t)3 * 512 + T, -2.0 * M_PI * ((double)hi * ke / 512.0 + (double)(hi * lo) / 256.0)); // [ke][c = hi][k2 = lo]
+		const int q = hi + 16 * ke + 32 * lo; // pass-3 layout: k1 = hi, k2 = lo
+		tab[2 * ((size_t)4 * 512 + T)]     = (float)(rho[q] / mean);
+		tab[2 * ((size_t)4 * 512 + T) + 1] = (float)(rho[q + 7680] / mean);
+	}
+	return true;
+}
+
 template <typename T>
 struct DevBuf {
 	T*     p   = nullptr;
@@ -335,6 +393,11 @@ struct prot_engine {
 	DevBuf<float2> d_H, d_tw;
 	// overlap-save, table-free form of the one-partition polyphase engines (prot_olasave.hip): four workgroups per CU
 	bool           use_save = false;
+	// long launches of overlap-save LV2 engines: 8192-point blocks (prot_olasave8k.hip)
+	bool           use_save8 = false;
+	int            sv8_rows  = 0;     // new rows per 8192-point block (12 or 13)
+	float          sv8_gain  = 0.f;
+	DevBuf<float>  d_sv8;
 	DevBuf<float>  d_sv;
 	float          sv_gain = 0.f;
 	int            sv_rows = 0;
@@ -638,6 +701,23 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 		// of longer FIRs lose 6 % with it and keep equal runs)
 		if (e->info.partitions == np) {
 			rank_runs (p, (int64_t)e->info.run_align, n_chn, n_out, e->wg_slots, e->cus, false);
+		}
+		if (e->use_save8 && pipe_wait_post == nullptr && (uint64_t)n_out * (uint64_t)n_chn >= ((uint64_t)1 << 24)) {
+			// a long launch: 8192-point blocks, 512-thread workgroups, two per CU (run lengths 1.2 : 0.8 by dispatch rank)
+			const int blk8 = 1024 * e->sv8_rows, slots8 = e->cus * 2;
+			p.run_frames   = pick_run_frames (e, n_out, n_chn, blk8, slots8);
+			p.rank_cu      = 0;
+			rank_runs (p, (int64_t)blk8, n_chn, n_out, slots8, e->cus, false);
+			p.sv         = e->d_sv8.p;
+			p.sv_gain    = e->sv8_gain;
+			p.sv_flags   = e->sv_flags;
+			p.conv_delay = (int)e->info.conv_delay;
+			p.accumulate = 0;
+			hipError_t err = prot::launch_ola_save8k (p, e->sv8_rows, n_chn, s);
+			if (err != hipSuccess) {
+				return hip_fail (err, "overlap-save (8192-point) ola kernel launch");
+			}
+			return finish ();
 		}
 		if (e->use_save) { // one partition of an antisymmetric g: overlap-save, no spectrum table, four workgroups per CU
 			p.sv         = e->d_sv.p;
@@ -1053,6 +1133,12 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 			e->wg_slots = e->cus * 4; // 128 VGPRs, 38 KiB of LDS
 		}
 	}
+	std::vector<float> sv8_h;
+	if (e->use_save && inf.kind == PROT_KIND_LV2 && !(cfg->flags & PROT_CFG_BLOCK4096) && (inf.firlen == 3072 || inf.firlen == 4096) &&
+	    tuning_env ("PROT_NO_SAVE8K") == nullptr) {
+		e->use_save8 = save_tables8k (fir_taps, sv8_h, e->sv8_gain);
+		e->sv8_rows  = 16 - (int)(inf.firlen / 1024);
+	}
 	const char* pipe_env = tuning_env ("PROT_PIPELINE");
 	if (e->use_save && ((cfg->flags & PROT_CFG_PIPELINE) || (pipe_env && atoi (pipe_env) != 0)) && !(pipe_env && atoi (pipe_env) == 0)) {
 		// consecutive stateful prot_apply_dev calls on the engine's own streams overlap
@@ -1110,13 +1196,17 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	    (use_poly && n_part <= 2 && ((rc = e->d_hist16[0].ensure (hn)) || (rc = e->d_hist16[1].ensure (hn)))) ||
 	    (rc = e->d_hist[1].ensure (hn)) || (rc = e->d_peaks.ensure ((size_t)PROT_MAXSAMPLE * inf.n_chn)) ||
 	    (rc = e->d_angles.ensure (PROT_MAXSAMPLE + 8)) || (rc = e->d_thr.ensure (4 * (size_t)inf.n_chn)) || (rc = e->d_ctr.ensure ((size_t)inf.n_chn * 32 * 32)) ||
-	    (rc = e->d_stats.ensure (4)) || (e->use_save && (rc = e->d_sv.ensure (sv_h.size ())))) {
+	    (rc = e->d_stats.ensure (4)) || (e->use_save && (rc = e->d_sv.ensure (sv_h.size ()))) ||
+	    (e->use_save8 && (rc = e->d_sv8.ensure (sv8_h.size ())))) {
 		return fail (rc);
+	}
+	if (e->use_save8 && hipMemcpy (e->d_sv8.p, sv8_h.data (), sv8_h.size () * sizeof (float), hipMemcpyHostToDevice) != hipSuccess) {
+		return fail (PROT_EHIP);
 	}
 	if (e->use_save && hipMemcpy (e->d_sv.p, sv_h.data (), sv_h.size () * sizeof (float), hipMemcpyHostToDevice) != hipSuccess) {
 		return fail (PROT_EHIP);
 	}
-	e->info.form      = e->use_save ? PROT_FORM_POLY_SAVE : use_poly ? PROT_FORM_POLY_OLA : PROT_FORM_DIRECT;
+	e->info.form      = e->use_save8 ? PROT_FORM_POLY_SAVE8K : e->use_save ? PROT_FORM_POLY_SAVE : use_poly ? PROT_FORM_POLY_OLA : PROT_FORM_DIRECT;
 	e->info.wg_per_cu = e->cus > 0 ? (uint32_t)(e->wg_slots / e->cus) : 0;
 	if ((!Hp_h.empty () && hipMemcpy (e->d_Hp.p, Hp_h.data (), Hp_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess) ||
 	    hipMemcpy (e->d_H.p, H_h.data (), H_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess ||
@@ -1169,6 +1259,7 @@ void prot_engine_destroy (prot_engine* e)
 	}
 	e->d_H.release ();
 	e->d_sv.release ();
+	e->d_sv8.release ();
 	e->d_Hp.release ();
 	e->d_tw.release ();
 	e->d_lut.release ();

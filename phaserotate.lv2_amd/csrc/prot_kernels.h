@@ -82,6 +82,9 @@ hipError_t launch_ola_poly_f16 (const OlaParamsH& p, int n_part, int hop_rows, i
 // overlap-save, table-free form of launch_ola_poly for one partition of an antisymmetric g (prot_olasave.hip): four
 // workgroups per CU; hop_rows in {8, 10, 12}, n_rho_rows = 1; p.sv / p.sv_gain set; dry_delay even
 hipError_t launch_ola_save (const OlaParams& p, int hop_rows, int n_rho_rows, int n_chn, hipStream_t s);
+// the same on 8192-point blocks (prot_olasave8k.hip): 512-thread workgroups, two per CU; hop_rows in {12, 13} (x 1024 new
+// frames per block: firlen = 1024 (16 - hop_rows)); p.sv = the five-row table of save_tables8k; no pipelined launches
+hipError_t launch_ola_save8k (const OlaParams& p, int hop_rows, int n_chn, hipStream_t s);
 
 // fp16 sample path (BASELINE config 5): half samples in HBM, packed-half butterflies,
 // fp32 overlap-add + rotation.  Stateless, steady rotation.

@@ -1,0 +1,237 @@
+// prot_olasave8k.hip -- olasave8k_kernel: the overlap-save, table-free polyphase block of prot_olasave.hip on an 8192-POINT
+// transform pair (round 4).  512 threads (8 waves) per workgroup, 16 points per thread, two workgroups per CU (<= 128
+// VGPRs, 78 KiB of LDS): the same 16 waves per CU as the 4096-point kernel, but a block is 16 rows of 512 complex samples
+// of which NT = firlen / 1024 are context -- 13 of 16 rows new for the LV2 48 kHz filter (10 of 16 on 4096 points), 12 of
+// 16 at 96 kHz (8 of 16), 14 of 16 for CLI blksiz 2048 (12 of 16): fewer VALU issue cycles and LDS instructions per frame,
+// the resource that bounds this path.
+//
+// What it replaces: the block body of process_channel (src/phaserotate.c:629-720) and PhaseRotateProc::hilbert / rotate
+// (cli/phase-rotate.cc:181-232), exactly as olasave_kernel does.  The transform is 16 x 2 x 16 x 16: the radix-2 layer over
+// the top bit of the thread index is taken by the READER of the first LDS exchange (forward) and of the last one (inverse);
+// tools/model/olasave_model8k.py is the numpy model, tools/gen/gen_olasave8k.py the generator of ALL the arithmetic
+// (prot_olasave8k_asm.inc: a streamed run of blocks, and one LDS-staged block for edges); this file moves data.
+//
+// Blocks with an odd number of context rows (LV2 48 kHz: 3) are kept circularly rotated by half a row, so that the valid
+// outputs are whole rows for every thread: position p of the block holds local sample (p + 256) mod 8192.
+#include "prot_dev.h"
+
+namespace prot {
+
+typedef volatile __attribute__ ((address_space (3))) f2 LdsC8;
+typedef volatile __attribute__ ((address_space (3))) float LdsF8;
+
+#ifdef PROT_SV8_INC // (tuning builds: a variant of the generated code, tools/ab_build.py sv8:...)
+#include PROT_SV8_INC
+#else
+#include "prot_olasave8k_asm.inc"
+#endif
+
+constexpr int kSv8LdsBytes = 16 * 560 * 8 + 8192; // exchange area (16 rows of 560 slots) + the two 512-entry twiddle tables
+
+#define PROT_SV8_CAT_(k, a, b) PROT_SV8_##k##_##a##_##b
+#define PROT_SV8_CLOB_(a) PROT_SV8_ASM_CLOBBERS_##a
+#define PROT_SV8_CALL(KIND_, HS_, AM_, in_, out_, nf_, ca_, sa_)                                                                       \
+	if (HS == HS_ && AM == AM_) {                                                                                                       \
+		asm volatile (PROT_SV8_CAT_ (KIND_, HS_, AM_)                                                                                   \
+		              :                                                                                                                 \
+		              : "s"(in_), "s"(out_), "s"(nf_), "s"(lds_off), "s"(a_sv), "s"(ca_), "s"(sa_), "v"(t0)                                \
+		              : PROT_SV8_CLOB_ (HS_));                                                                                          \
+	}
+#define PROT_SV8_ALL(KIND_, in_, out_, nf_, ca_, sa_)                                                                                  \
+	PROT_SV8_CALL (KIND_, 12, 0, in_, out_, nf_, ca_, sa_)                                                                              \
+	PROT_SV8_CALL (KIND_, 12, 2, in_, out_, nf_, ca_, sa_)                                                                              \
+	PROT_SV8_CALL (KIND_, 13, 0, in_, out_, nf_, ca_, sa_)                                                                              \
+	PROT_SV8_CALL (KIND_, 13, 2, in_, out_, nf_, ca_, sa_)
+
+// HS new rows (1024 HS frames) per block; MODE_ROT / MODE_RAMP / MODE_HILBERT.  Same division of labour as olasave_kernel:
+// consecutive whole in-range blocks are ONE call of the generated loop; every other block is staged here, position by
+// position, into the LDS exchange area, transformed by the generated CORE (the same instructions on the same values: the
+// two paths agree bit for bit) and stored from LDS with bounds.
+template <int HS, int MODE>
+__global__ __launch_bounds__ (512, 4) void olasave8k_kernel (const OlaParams p)
+{
+	constexpr int BLK = 1024 * HS;           // output frames per block
+	constexpr int NT  = 16 - HS;             // context rows (of 512 complex samples = 1024 frames)
+	constexpr int R0  = NT / 2;              // first valid output row = first dry row
+	constexpr int ROT = (NT & 1) ? 256 : 0;  // complex samples the block is rotated by
+	constexpr int AM  = MODE == MODE_ROT ? 0 : 2;
+	static_assert (HS == 12 || HS == 13, "rows per block");
+
+	extern __shared__ f2 smem8[]; // kSv8LdsBytes: the exchange area + the two tables (written by the generated prologue)
+
+	const int t0 = threadIdx.x;
+	const int c  = blockIdx.y;
+	int64_t   r0, rlen;
+	run_of_workgroup (p, r0, rlen);
+	if (r0 >= p.n_out) {
+		if (t0 < 256) {
+			hist_write_slice (p, blockIdx.y, t0);
+		}
+		return;
+	}
+	const int64_t r1 = (r0 + rlen < p.n_out) ? r0 + rlen : p.n_out;
+
+	const float* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
+	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
+	float* __restrict__ out        = p.out + (int64_t)c * p.out_stride;
+	const int64_t n_in = p.n_in;
+	const int     Dd   = p.dry_delay; // even (host guarantees)
+	const bool in_al8  = (reinterpret_cast<uintptr_t> (in) & 7) == 0;
+	const bool out_al8 = (reinterpret_cast<uintptr_t> (out) & 7) == 0;
+
+	float ca = 0.f, sa = p.sv_gain;
+	if (MODE == MODE_ROT) {
+		ca = p.rot ? p.rot[2 * c] : p.rot_v[2 * c];
+		sa = (p.rot ? p.rot[2 * c + 1] : p.rot_v[2 * c + 1]) * p.sv_gain;
+	}
+	ca = __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (ca)));
+	sa = __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (sa)));
+	const unsigned lds_off = (unsigned)(uintptr_t)(__attribute__ ((address_space (3))) f2*)smem8;
+	const float*   a_sv    = uniform_ptr_generic (p.sv);
+
+	const bool hist_al8 = hist != nullptr && (reinterpret_cast<uintptr_t> (hist) & 7) == 0 && (p.hist_len & 1) == 0;
+	// the (x[a], x[a+1]) pair of lane t (0..255) in the 512-frame half row that starts at frame ar: a half row lies wholly in
+	// the input array or wholly in the history (both start on half-row boundaries) -- aligned 8-byte loads; anything else
+	// (silence in reach, odd alignment) frame by frame through the virtual stream [history | input | silence]
+	auto half_pair = [&] (int64_t ar, int t) -> f2 {
+		if (in_al8 && ar >= 0 && ar + 512 <= n_in) {
+			return reinterpret_cast<const f2*> (in + ar)[t];
+		}
+		if (hist_al8 && ar + 512 <= 0 && ar + p.hist_len >= 0) {
+			return reinterpret_cast<const f2*> (hist + (ar + p.hist_len))[t];
+		}
+		const int64_t a = ar + 2 * (int64_t)t;
+		return mkf2 (ldv (in, n_in, hist, p.hist_len, a), ldv (in, n_in, hist, p.hist_len, a + 1));
+	};
+
+	for (int64_t s = r0; s < r1;) {
+		// frame of local sample 0's aligned pair: the dry frame of output position p is input position p, and output row R0
+		// starts at local sample 512 R0 + ROT
+		const int64_t a0 = s - Dd - 1024 * R0 - 2 * ROT;
+		if (MODE != MODE_RAMP && in_al8 && out_al8 && a0 >= 1 && !(p.sv_flags & 1)) {
+			// blocks from here on that read only frames inside the array (local samples 0..8191 and the frame in front) and
+			// are emitted whole
+			const int64_t n1 = (r1 - s) / BLK;
+			const int64_t n2 = n_in - 16384 - a0 >= 0 ? (n_in - 16384 - a0) / BLK + 1 : 0;
+			int           nf = (int)(n1 < n2 ? n1 : n2);
+			if (nf > 0) {
+				nf                 = __builtin_amdgcn_readfirstlane (nf);
+				const float* a_in  = uniform_ptr_generic (in + a0);
+				float*       a_out = uniform_ptr_generic (out + s);
+				PROT_SV8_ALL (ASM, a_in, a_out, nf, ca, sa)
+				s += (int64_t)nf * BLK;
+				continue;
+			}
+		}
+		// ---- one block through LDS
+		int t = t0;
+		asm volatile ("" : "+v"(t)); // (opaque per block: per-lane address terms are otherwise hoisted out of the loop)
+		t &= 511;
+		LdsC8* const st = (LdsC8*)smem8;            // positions: slot 512 row + T
+		LdsF8* const gc = (LdsF8*)(smem8 + 8192);   // byte 65536: the frame in front of each wave's first sample of row (lane), lanes 0..15
+		__syncthreads (); // (every wave has left the generated loop, if that is where it comes from)
+		{
+			const int h = t >> 8, tl = t & 255;
+#pragma unroll 2
+			for (int k = 0; k < 16; ++k) {
+				const int nloc = (512 * k + 256 * h + ROT) & 8191; // first local sample of this half row
+				st[512 * k + t] = half_pair (a0 + 2 * (int64_t)nloc, tl);
+			}
+			const int l = t & 63, w = t >> 6;
+			const int nl = (512 * (l & 15) + 64 * w + ROT) & 8191;
+			gc[t]        = l < 16 ? ldv (in, n_in, hist, p.hist_len, a0 + 2 * (int64_t)nl - 1) : 0.f;
+		}
+		__syncthreads ();
+		{
+			const float  cca = MODE == MODE_RAMP ? 0.f : ca, csa = MODE == MODE_RAMP ? __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (p.sv_gain))) : sa;
+			const float* a_in  = a_sv; // (unused by the core)
+			float*       a_out = nullptr;
+			const int    one   = 1;
+			PROT_SV8_ALL (CORE, a_in, a_out, one, cca, csa)
+		}
+		__syncthreads ();
+		// (the thread id opaque again: nothing per-lane may live across the generated code, see prot_olasave.hip)
+		t = t0;
+		asm volatile ("" : "+v"(t));
+		t &= 511;
+		// rows 0..HS-1 of the staging area now hold the output pairs of frames s + 1024 k + 2 t (+1)
+		if (MODE != MODE_RAMP && s + BLK <= r1 && out_al8) {
+#pragma unroll
+			for (int k = 0; k < HS; ++k) {
+				PROT_GLOBAL f2* __restrict__ ob = reinterpret_cast<PROT_GLOBAL f2*> (uniform_ptr (out + s + 1024 * k));
+				ob[(unsigned)t]                 = st[512 * k + t];
+			}
+		} else {
+#pragma unroll 2
+			for (int k = 0; k < HS; ++k) {
+				f2            o    = st[512 * k + t];
+				const int64_t pos0 = s + 1024 * (int64_t)k + 2 * (int64_t)t;
+				if (MODE == MODE_RAMP && pos0 < r1) {
+					// per-frame rotation: the dry pair of an output pair is the input pair Dd frames earlier
+					const f2 d   = half_pair (pos0 - 2 * (int64_t)(t & 255) - Dd, t & 255);
+					const f2 cs0 = reinterpret_cast<const f2*> (p.rot_s)[(int64_t)c * p.n_out + pos0];
+					const f2 cs1 = pos0 + 1 < r1 ? reinterpret_cast<const f2*> (p.rot_s)[(int64_t)c * p.n_out + pos0 + 1] : mkf2 (0.f, 0.f);
+					o            = mkf2 (cs0.x * d.x + cs0.y * o.x, cs1.x * d.y + cs1.y * o.y);
+				}
+				if (pos0 < r1) {
+					out[pos0] = o.x;
+				}
+				if (pos0 + 1 < r1) {
+					out[pos0 + 1] = o.y;
+				}
+			}
+		}
+		__syncthreads (); // (the output rows have been read: the exchange area is free for whatever comes next)
+		s += BLK;
+	}
+	if (t0 < 256) {
+		hist_write_slice (p, blockIdx.y, t0);
+	}
+}
+
+template <int HS>
+static hipError_t launch_sv8_m (const OlaParams& p, dim3 grid, hipStream_t s)
+{
+	const dim3 block (512);
+	typedef void (*kern_t) (OlaParams);
+	const kern_t fn = p.hilbert_only ? olasave8k_kernel<HS, MODE_HILBERT> : p.rot_s != nullptr ? olasave8k_kernel<HS, MODE_RAMP> : olasave8k_kernel<HS, MODE_ROT>;
+	// (more than 64 KiB of LDS per workgroup has to be asked for, once per kernel and device)
+	static bool asked[3][8] = {};
+	int         dev = 0;
+	(void)hipGetDevice (&dev);
+	const int mi = p.hilbert_only ? 2 : p.rot_s != nullptr ? 1 : 0;
+	if (dev >= 0 && dev < 8 && !asked[mi][dev]) {
+		hipError_t err = hipFuncSetAttribute ((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, kSv8LdsBytes);
+		if (err != hipSuccess) {
+			return err;
+		}
+		asked[mi][dev] = true;
+	} else if (dev >= 8) {
+		hipError_t err = hipFuncSetAttribute ((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, kSv8LdsBytes);
+		if (err != hipSuccess) {
+			return err;
+		}
+	}
+	hipLaunchKernelGGL (fn, grid, block, kSv8LdsBytes, s, p);
+	return hipGetLastError ();
+}
+
+hipError_t launch_ola_save8k (const OlaParams& p, int hop_rows, int n_chn, hipStream_t s)
+{
+	if ((p.dry_delay & 1) || (p.run_frames % (1024 * hop_rows)) != 0 || p.accumulate || p.sv == nullptr || p.hs_flag != nullptr ||
+	    2 * (p.dry_delay - p.conv_delay) != 1024 * (16 - hop_rows)) {
+		return hipErrorInvalidValue;
+	}
+	if (p.n_out <= 0) {
+		return hipSuccess;
+	}
+	const int64_t runs = (p.n_out + p.run_frames - 1) / p.run_frames;
+	dim3          grid ((unsigned)runs, (unsigned)n_chn);
+	switch (hop_rows) {
+		case 12: return launch_sv8_m<12> (p, grid, s);
+		case 13: return launch_sv8_m<13> (p, grid, s);
+		default: return hipErrorInvalidValue;
+	}
+}
+
+} // namespace prot

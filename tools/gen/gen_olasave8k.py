@@ -161,7 +161,8 @@ class Gen8k(Gen):
         P.s_cselect(S_SIG.lo, Lit(-1.0), Lit(1.0))
         P.s_cselect(S_SIG.hi, Lit(-1.0), Lit(1.0))
         if self.ODD:
-            P.s_cselect(S_MIX, Lit(4096 * (NT - 1)), Lit(4096 * 15))
+            P.s_mov(S_MIX, Lit(4096 * 15))                         # (one literal per scalar instruction)
+            P.s_cselect(S_MIX, Lit(4096 * (NT - 1)), S_MIX)
         # passes 2 and 3: thread (k1, ke, c), k1 = (T >> 4) & 15, c = T & 15
         P.v_lshr(b, Lit(4), t)
         P.v_and(b, Lit(15), b)                                  # k1
@@ -233,7 +234,8 @@ class Gen8k(Gen):
             # lower waves: lane 0 <-> row NT - 1; upper waves: lane HS - NT <-> row 15, wrapped (the block's first half row)
             P.s_cmp_eq_u32(S_HI, Lit(1))
             P.s_cselect(S_T[0], Lit(HS - NT), Lit(0))
-            P.s_cselect(S_T[1], Lit(4096 * 15 - 65536 + 4096), Lit(4096 * (NT - 1) + 4096))
+            P.s_mov(S_T[1], Lit(4096 * (NT - 1) + 4096))
+            P.s_cselect(S_T[1], Lit(4096 * 15 - 65536 + 4096), S_T[1])
             P.v_mov(y, S_T[1])
             P.v_cmp_eq_u32(S_T[0], lane)
             P.v_cndmask(x, x, y)
@@ -468,7 +470,7 @@ class Gen8k(Gen):
         P = self.P
         v = self.D
         order = [0, 4, 8, 12, 1, 5, 9, 13, 2, 6, 10, 14, 3, 7, 11, 15]
-        sets = [self.TMP[:4], self.TMP[4:8] if len(self.TMP) >= 8 else self.TMP[4:7] + self.TMP[:1]]
+        sets = [self.TMP[:4], self.TMP[4:8] if len(self.TMP) >= 8 else []]
         nset = len(sets[1])
         def issue(j):
             for i, k in enumerate(order[4 * j:4 * j + 4]):
@@ -623,7 +625,7 @@ class Gen8k(Gen):
         P.s_barrier()
         # the reader's half of the inverse layer: thread T takes Y0 + sigma Y1 of its column (rows 4 al + be with al >= 1 first)
         order = [4, 8, 12, 0, 5, 9, 13, 1, 6, 10, 14, 2, 7, 11, 15, 3]
-        sets = [self.TMP[:4], self.TMP[4:8] if len(self.TMP) >= 8 else self.TMP[4:7] + self.TMP[:1]]
+        sets = [self.TMP[:4], self.TMP[4:8] if len(self.TMP) >= 8 else []]
         def issue(j):
             for i, k in enumerate(order[4 * j:4 * j + 4]):
                 base, imm = self.row_slot(k)
@@ -793,11 +795,68 @@ def self_test(HS, MODE, nblk=3, seed=1, verbose=True, opts=(), kind="run"):
     return g, P
 
 
+# (HS = 14, CLI blksiz 2048, and HS = 8, CLI blksiz 8192 as ONE partition, pass the self-test too: `gen_olasave8k.py 14 8`;
+# neither gains on the kernel that serves it today -- DESIGN.md -- so they are not emitted)
 VARIANTS = [(hs, mode) for hs in (12, 13) for mode in (MODE_ROT, MODE_HILBERT)]
 
+
+def emit(path, opts=()):
+    """csrc/prot_olasave8k_asm.inc: one macro per variant = the asm text of a run of blocks (ASM) or of one staged block (CORE),
+    inputs from the inline-asm operands %0..%7 as in prot_olasave_asm.inc"""
+    out = ["// GENERATED by tools/gen/gen_olasave8k.py -- do not edit.  The steady-state loop of olasave8k_kernel (8192-point blocks, 512",
+           "// threads) as gfx950 assembly with hand-allocated registers; the emulator (tools/gen/isa.py) has run every variant",
+           "// against the float64 convolution (tests/test_gen_olasave.py).",
+           "// operands: %0 in (aligned pair of local sample 0 of the first block), %1 out (first output frame), %2 blocks, %3 LDS byte",
+           "// offset of the exchange area, %4 constants table, %5 ca, %6 sa * gain, %7 thread id",
+           "#pragma once", ""]
+    nv = {}
+    for kind in ("run", "core"):
+        for HS, MODE in VARIANTS:
+            g = Gen8k(HS, MODE, opts if kind == "run" else [o for o in opts if o in ("nolds", "novalu")], kind)
+            P = g.build()
+            nv[HS] = max(nv.get(HS, 0), g.n_vgpr)
+            head = ["s_mov_b64 %r, %%0" % S_IN, "s_mov_b64 %r, %%1" % S_OUT, "s_mov_b32 %r, %%2" % S_NBLK, "s_mov_b32 %r, %%3" % S_LDS,
+                    "s_mov_b64 %r, %%4" % S_SV, "s_mov_b32 %r, %%5" % S_ROT.lo, "s_mov_b32 %r, %%6" % S_ROT.hi, "v_mov_b32 %r, %%7" % g.TMP[0].lo,
+                    "s_waitcnt vmcnt(0) lgkmcnt(0)"]
+            for n, (lo, hi) in sorted(g.constants().items()):
+                head.append("s_mov_b32 s%d, %r" % (n, Lit(float(lo))))
+                head.append("s_mov_b32 s%d, %r" % (n + 1, Lit(float(hi))))
+            lines = head + P.text(label_suffix="%=")
+            st = P.stats()
+            out.append("// %s, HS %d, mode %d: %d VGPRs, %d instructions" % (kind, HS, MODE, g.n_vgpr, sum(v for k, v in st.items() if k not in ("comment", "label", "probe"))))
+            out.append("#define PROT_SV8_%s_%d_%d \\" % ("ASM" if kind == "run" else "CORE", HS, MODE))
+            for l in lines:
+                if l.startswith(";"):
+                    continue
+                out.append('\t"%s\\n\t" \\' % l)
+            out.append('\t""')
+            out.append("")
+    for HS in sorted(nv):
+        clob = ['"memory"', '"vcc"', '"scc"'] + ['"s%d"' % i for i in SGPR_CLOBBER] + ['"v%d"' % i for i in range(0, nv[HS])]
+        out.append("#define PROT_SV8_ASM_CLOBBERS_%d " % HS + ", ".join(clob))
+    out.append("")
+    open(path, "w").write("\n".join(out))
+
+
 if __name__ == "__main__":
-    hs_list = [int(a) for a in sys.argv[1:] if a.isdigit()] or [12, 13]
-    for HS in hs_list:
-        for MODE in (MODE_ROT, MODE_HILBERT):
-            self_test(HS, MODE, nblk=2 if "--quick" in sys.argv else 3)
-            self_test(HS, MODE, kind="core")
+    here = os.path.dirname(os.path.abspath(__file__))
+    csrc = os.path.join(here, "..", "..", "phaserotate.lv2_amd", "csrc")
+    if "--variant" in sys.argv:   # timing experiments: python3 gen_olasave8k.py --variant NAME --opts a,b  -> csrc/variants/
+        name = sys.argv[sys.argv.index("--variant") + 1]
+        opts = [o for o in sys.argv[sys.argv.index("--opts") + 1].split(",") if o] if "--opts" in sys.argv else []
+        wrong = {"nolds", "nomem", "novalu"} & set(opts)
+        if not wrong:
+            for HS, MODE in VARIANTS:
+                self_test(HS, MODE, nblk=2, opts=opts, verbose=False)
+        os.makedirs(os.path.join(csrc, "variants"), exist_ok=True)
+        dst = os.path.join(csrc, "variants", "prot_olasave8k_asm_%s.inc" % name)
+        emit(dst, opts)
+        print("wrote", os.path.normpath(dst), "(results WRONG by design)" if wrong else "(self-test passed)")
+        sys.exit(0)
+    for HS, MODE in VARIANTS:
+        self_test(HS, MODE, nblk=2 if "--quick" in sys.argv else 3)
+        self_test(HS, MODE, kind="core")
+    if "--check" not in sys.argv:
+        dst = os.path.join(csrc, "prot_olasave8k_asm.inc")
+        emit(dst)
+        print("wrote", os.path.normpath(dst))

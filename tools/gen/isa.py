@@ -48,6 +48,8 @@ class Lit:  # 32-bit literal / inline constant (float or int)
     def __init__(self, v): self.v = v
     def __repr__(self):
         if isinstance(self.v, float):
+            if self.v in (0.5, -0.5, 1.0, -1.0, 2.0, -2.0, 4.0, -4.0):   # inline constants (no literal slot taken)
+                return repr(self.v)
             return "0x%08x" % np.float32(self.v).view(np.uint32)
         return str(self.v)
     def bits(self):
