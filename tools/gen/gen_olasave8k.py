@@ -98,6 +98,22 @@ class Gen8k(Gen):
         self.nbf = len(set(t.n for t in self.TT))
         self.lab = 0
 
+    def tap(self, name, regs):
+        """debugging: opts "probe" = snapshot in the emulator; "dump:<name>" = the 16 pairs to global memory (row k of the output
+        buffer <- regs[k]) and out: tools/sv8_core_test.py compares the hardware with the emulator stage by stage"""
+        P = self.P
+        regs = list(regs)
+        if "probe" in self.opts:
+            P.probe(name, regs)
+        if "dump:" + name in self.opts:
+            P.s_waitcnt(vmcnt=0, lgkmcnt=0)
+            for k, r in enumerate(regs):
+                P.s_add_u32(S_A0.lo, S_OUT.lo, Lit(4096 * k))
+                P.s_addc_u32(S_A0.hi, S_OUT.hi, Lit(0))
+                P.global_store_dwordx2(self.VOFF, r, S_A0, 0)
+            P.s_waitcnt(vmcnt=0)
+            P.s_branch("L_end")
+
     def label(self, stem):
         self.lab += 1
         return "%s_%d" % (stem, self.lab)
@@ -150,12 +166,12 @@ class Gen8k(Gen):
         t, a, b, c, d, lane, wv, m, z, vg0 = T_[0].lo, T_[0].hi, T_[1].lo, T_[1].hi, T_[2].lo, T_[2].hi, T_[3].lo, T_[3].hi, T_[4].lo, T_[4].hi
         tabs = (T_[5], T_[6])
         P.v_lshr(a, Lit(8), t)                                  # e = ke = T >> 8: wave-uniform
-        P.v_readfirstlane(S_HI, a)
         P.v_and(b, Lit(255), t)
         P.v_lshl(self.VOFF, Lit(3), t)                          # 8 T
         P.v_lshl(b, Lit(3), b)
         P.v_add_u32(self.A_RZ, S_LDS, b)                        # lds + 8 (T & 255): half 0 of a column
         P.v_add_u32(self.A_RZH, Lit(8 * ROWS * HI_ROW), self.A_RZ)
+        P.v_readfirstlane(S_HI, a)                              # (well behind the write of its source: isa.py's lane-read hazard)
         P.s_nop(4)
         P.s_cmp_eq_u32(S_HI, Lit(1))
         P.s_cselect(S_SIG.lo, Lit(-1.0), Lit(1.0))
@@ -464,6 +480,11 @@ class Gen8k(Gen):
                 P.s_branch(done)
         P.label(done)
         P.join(st1)
+        if "probe" in self.opts or "dump:p1out" in self.opts:
+            # (debugging) what pass 1 handed to the exchange, and the wave-uniform state as the registers see it
+            P.v_mov(self.TMP[0].lo, S_SIG.lo)
+            P.v_mov(self.TMP[0].hi, S_HI)
+            self.tap("p1out", self.natural(v)[:15] + [self.TMP[0]])
 
     def fwd_pass2_reads(self):
         """the reader's half of the radix-2 layer: D[b] = u0[b] + sigma u1[b], then W32^{b ke}"""
@@ -574,14 +595,14 @@ class Gen8k(Gen):
             P.reset_queues(vm_stores=HS)
         P.comment("---- (p, q) pairs")
         self.build_pq()
-        if "probe" in self.opts: P.probe("pq", self.D)
+        self.tap("pq", self.D)
         P.comment("---- forward pass 1 + exchange 1")
         self.fwd_pass1()
         P.s_waitcnt(lgkmcnt=0)
         P.s_barrier()
         P.comment("---- forward pass 2 (the radix-2 layer first)")
         v = self.fwd_pass2_reads()
-        if "probe" in self.opts: P.probe("p2in", self.D)
+        self.tap("p2in", self.D)
         if core:
             self.stage1(v, 1)
             self.run_ops(self.stage1_twiddle_ops(v, 1, self.scratch_pairs()))
@@ -594,31 +615,31 @@ class Gen8k(Gen):
         self.twiddled_exchange8(v, 1, 0, self.A_X2, 8, self.A_CH, KG * 8)
         P.comment("---- forward pass 3")
         v = self.D
-        if "probe" in self.opts: P.probe("p3in", self.D)
+        self.tap("p3in", self.D)
         self.stage1(v, 1)
         self.run_ops(self.stage1_twiddle_ops(v, 1, self.scratch_pairs()))
         bfl = self.stage2_lists(v, 1)
         self.run_ops(self.interleave(bfl) if self.nbf >= 4 else sum(bfl, []))
         v = self.natural(v)
-        if "probe" in self.opts: P.probe("p3out", v)
+        self.tap("p3out", v)
         P.comment("---- constants")
         self.pointwise(v)
-        if "probe" in self.opts: P.probe("pw", v)
+        self.tap("pw", v)
         P.comment("---- inverse pass 1")
         self.stage1(v, -1)
         self.run_ops(self.stage1_twiddle_ops(v, -1, self.scratch_pairs()))
         self.twiddled_exchange8(v, -1, LDS_TWI - LDS_TWF, self.A_CH, KG * 8, self.A_X2, 8)
         P.comment("---- inverse pass 2, the radix-2 layer's twiddle, exchange 4")
         v = self.D
-        if "probe" in self.opts: P.probe("ip2in", self.D)
+        self.tap("ip2in", self.D)
         self.stage1(v, -1)
         self.run_ops(self.stage1_twiddle_ops(v, -1, self.scratch_pairs()))
         bfl = self.stage2_lists(v, -1)
         self.run_ops(self.interleave(bfl) if self.nbf >= 4 else sum(bfl, []))
         u = self.natural(v)          # u[b] = output b of the pass
-        if "probe" in self.opts: P.probe("ip2out", u)
+        self.tap("ip2out", u)
         self.ke_twiddle(u, True)
-        if "probe" in self.opts: P.probe("ip2tw", u)
+        self.tap("ip2tw", u)
         for b in range(16):
             P.ds_write_b64(self.A_CH, u[b], 128 * b)   # into the group's own chunk: wave-local, no barrier in front
         P.s_waitcnt(lgkmcnt=0)
@@ -647,10 +668,10 @@ class Gen8k(Gen):
                 issue(j)
                 fold(j - 1)
             fold(3)
-        if "probe" in self.opts: P.probe("ip3in", self.D)
+        self.tap("ip3in", self.D)
         P.comment("---- inverse pass 3")
         u = self.inv_pass3()
-        if "probe" in self.opts: P.probe("ip3out", u)
+        self.tap("ip3out", u)
         P.comment("---- mix and store")
         if core:
             P.s_barrier()   # every wave has read its share of the last exchange: the area takes the output rows
@@ -687,6 +708,8 @@ class Gen8k(Gen):
         tabs, t, vg0 = self.prologue()
         self.prologue_rows(tabs, t, vg0)
         self.loop()
+        if any(o.startswith("dump:") for o in self.opts):
+            self.P.label("L_end")
         return self.P
 
 
