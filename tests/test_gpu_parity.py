@@ -1199,3 +1199,77 @@ def test_generated_loop_and_cpp_blocks_give_the_same_bits(pkg, kind, param):
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1])
     assert float(outs[0][0].abs().max()) > 0.1
+
+
+# ------------------------------------------------- 8192-point blocks (round 4) ---
+@pytest.mark.parametrize("rate,chn,n,odd", [(48000, 1, (1 << 24) + 12345, 0), (96000, 1, (1 << 24) + 777, 0), (48000, 2, (1 << 23) + 4099, 0),
+                                             (96000, 2, 9_000_001, 1)])
+def test_block8192_kernel_against_oracle_and_block4096(pkg, rate, chn, n, odd):
+    """Long launches of the overlap-save LV2 engines run on 8192-point blocks (olasave8k_kernel: 512-thread workgroups, the radix-2
+    layer taken by the readers of the LDS exchanges, half-row rotation at 48 kHz).  The whole stream against the 4096-point
+    kernel (PROT_CFG_BLOCK4096: two different fp32 transforms of the same filter, 2e-6), windows of it against the CPU oracle's
+    run(), and -- every block through the LDS-staged path -- bit for bit against the generated loop.  Ragged length, stereo with
+    different rotations, an odd channel stride (4-byte aligned streams: every block staged)."""
+    import torch
+    dev = torch.device("cuda:0")
+    stride = n + 2 + odd
+    g = torch.Generator(device=dev).manual_seed(31 + chn)
+    x = torch.rand(chn * stride, generator=g, device=dev) - 0.5
+    rot = np.array([0.28, -0.96, -0.6, 0.8][:2 * chn], np.float32)
+    outs = {}
+    for tag, flags, edge in (("8k", 0, 0), ("4k", pkg.CFG_BLOCK4096, 0), ("8k-staged", 0, 1)):
+        pkg.set_test_option(pkg.TEST_EDGE_PATH_ONLY, edge)
+        try:
+            e = pkg.Engine(pkg.KIND_LV2, rate, chn, flags=flags)
+        finally:
+            pkg.set_test_option(pkg.TEST_EDGE_PATH_ONLY, 0)
+        assert int(e.info.form) == (pkg.FORM_POLY_SAVE8K if flags == 0 else pkg.FORM_POLY_SAVE)
+        y = torch.zeros_like(x)
+        e.apply_dev(x.data_ptr(), stride, n, y.data_ptr(), stride, n, rot, pkg.F_STATELESS)
+        e.sync()
+        outs[tag] = y
+        e.close()
+    assert float((outs["8k"] - outs["4k"]).abs().max()) < TOL
+    assert torch.equal(outs["8k"], outs["8k-staged"])
+    for c in range(chn):    # nothing written beyond the requested frames
+        assert float(outs["8k"][c * stride + n:(c + 1) * stride].abs().max()) == 0.0
+    # windows against the oracle: the start of the stream (history = silence), two inside, the ragged end
+    W = 8192
+    rng = np.random.default_rng(5)
+    lat = {48000: 1792, 96000: 2560}[rate]
+    for t0 in [0, n - W] + [int(v) for v in rng.integers(1 << 16, n - (1 << 16), size=2)]:
+        lo = max(0, t0 - 20000)
+        for c in range(chn):
+            xs = x[c * stride + lo:c * stride + t0 + W].cpu().numpy()[None, :]
+            o = orc.Lv2Engine(rate, 1)
+            o.activate()
+            ang = np.degrees(np.arctan2(-rot[2 * c + 1], rot[2 * c]))   # rot = {cos, sin}(-2 pi angle / 360)
+            yo = o.run_stream(xs, float(ang), 1024)[0]
+            skip = 2 * lat + 4096 if lo == 0 else 0                      # (Q10: the oracle instance ramps from 0 degrees on its first blocks)
+            got = outs["8k"][c * stride + t0 + skip:c * stride + t0 + W].cpu().numpy()
+            assert np.abs(got - yo[t0 - lo + skip:]).max() < TOL, (t0, c)
+
+
+def test_block8192_hilbert_branch_and_history(pkg):
+    """The same kernel in its Hilbert-only mode and with the engine's history in front of the stream: two stateful calls of
+    2^24 frames against one stateless call over both (the second call's first blocks read the history buffer the first one
+    wrote: the staged path's job), to rounding -- the blocks of the second call start on its own first frame."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 1 << 24
+    g = torch.Generator(device=dev).manual_seed(9)
+    x = torch.rand(2 * n, generator=g, device=dev) - 0.5
+    rot = np.array([0.0, -1.0], np.float32)
+    e = pkg.Engine(pkg.KIND_LV2, 48000, 1)
+    y1, y2, u1 = torch.zeros_like(x), torch.zeros_like(x), torch.zeros_like(x)
+    e.apply_dev(x.data_ptr(), 2 * n, 2 * n, y1.data_ptr(), 2 * n, 2 * n, rot, pkg.F_STATELESS)
+    e.hilbert_dev(x.data_ptr(), 2 * n, 2 * n, u1.data_ptr(), 2 * n, 2 * n, pkg.F_STATELESS)
+    e.reset()
+    for k in range(2):
+        e.apply_dev(x.data_ptr() + 4 * k * n, n, n, y2.data_ptr() + 4 * k * n, n, n, rot, 0)
+    e.sync()
+    assert float((y1 - y2).abs().max()) < TOL
+    # angle 90 degrees: cos = 0 to rounding, sin = -1: the rotated output is the negated Hilbert branch (to the rounding of cos)
+    assert float((y1 + u1).abs().max()) < 1e-6
+    assert float(u1.abs().max()) > 0.3
+    e.close()

@@ -9,7 +9,7 @@ import numpy as np, torch
 from __graft_entry__ import load_package
 pkg = load_package()
 dev = torch.device("cuda:0")
-cases = {"hop1024": (pkg.KIND_LV2, 48000, 1), "p2": (pkg.KIND_LV2, 48000, 2), "p2_96k": (pkg.KIND_LV2, 96000, 2),
+cases = {"b4k": (pkg.KIND_LV2, 48000, 32), "b4k_96k": (pkg.KIND_LV2, 96000, 32), "hop1024": (pkg.KIND_LV2, 48000, 1), "p2": (pkg.KIND_LV2, 48000, 2), "p2_96k": (pkg.KIND_LV2, 96000, 2),
          "poly": (pkg.KIND_LV2, 48000, 0), "poly_96k": (pkg.KIND_LV2, 96000, 0), "poly_192k": (pkg.KIND_LV2, 192000, 0),
          "polyf_48k": (pkg.KIND_LV2, 48000, 4), "polyf_96k": (pkg.KIND_LV2, 96000, 4), "polyf_cli2048": (pkg.KIND_CLI, 2048, 4),
          "cli": (pkg.KIND_CLI, 2048, 0), "cli1024": (pkg.KIND_CLI, 1024, 0), "cli_direct": (pkg.KIND_CLI, 2048, 2), "cli4096": (pkg.KIND_CLI, 4096, 0), "cli8192": (pkg.KIND_CLI, 8192, 0),

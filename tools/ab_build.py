@@ -15,6 +15,23 @@ if b._newer(CAPI_T, [os.path.join(b.CSRC, "prot_capi.hip"), os.path.join(b.CSRC,
     b._run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-function", "-DPROT_TUNING",
             "-I" + os.path.join(ROOT, "include"), "-c", os.path.join(b.CSRC, "prot_capi.hip"), "-o", CAPI_T])
 for arg in sys.argv[1:]:
+    if arg.startswith("sv8:"):
+        # "sv8:<tag>[:flag,flag]": a variant of prot_olasave8k.hip (the generated loop csrc/variants/prot_olasave8k_asm_<tag>.inc
+        # if it exists: python3 tools/gen/gen_olasave8k.py --variant <tag> --opts ...), linked with the shipped objects
+        _, tag, fl = (arg.split(":") + [""])[:3]
+        extra = [f for f in fl.split(",") if f]
+        inc = os.path.join(b.CSRC, "variants", "prot_olasave8k_asm_%s.inc" % tag)
+        if os.path.exists(inc):
+            extra.append('-DPROT_SV8_INC="%s"' % inc)
+        o = os.path.join(b.OBJDIR, "prot_olasave8k_%s.o" % tag)
+        b._run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-function",
+                "-I" + os.path.join(ROOT, "include"), "-ffast-math", "-fno-slp-vectorize"] + extra +
+               ["-c", os.path.join(b.CSRC, "prot_olasave8k.hip"), "-o", o])
+        lib = os.path.join(vdir, "libprot_hip_%s.so" % tag)
+        b._run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, o, os.path.join(b.OBJDIR, "prot_kernels.o"), os.path.join(b.OBJDIR, "prot_olasave.o"),
+                os.path.join(b.OBJDIR, "prot_sweep.o"), os.path.join(b.OBJDIR, "prot_kernels_f16.o"), CAPI_T, "-lpthread"])
+        print("built", lib)
+        continue
     if arg.startswith("sv:"):
         # "sv:<tag>[:flag,flag]": a variant of prot_olasave.hip only (the generated loop csrc/variants/prot_olasave_asm_<tag>.inc
         # if it exists: python3 tools/gen/gen_olasave.py --variant <tag> --opts ...), linked with the shipped objects
@@ -33,7 +50,7 @@ for arg in sys.argv[1:]:
                 "-I" + os.path.join(ROOT, "include"), "-ffast-math", "-fno-slp-vectorize"] + extra +
                ["-c", os.path.join(b.CSRC, "prot_olasave.hip"), "-o", o])
         lib = os.path.join(vdir, "libprot_hip_%s.so" % tag)
-        b._run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, o, os.path.join(b.OBJDIR, "prot_kernels.o"),
+        b._run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, o, os.path.join(b.OBJDIR, "prot_kernels.o"), os.path.join(b.OBJDIR, "prot_olasave8k.o"),
                 os.path.join(b.OBJDIR, "prot_sweep.o"), os.path.join(b.OBJDIR, "prot_kernels_f16.o"), CAPI_T, "-lpthread"])
         print("built", lib)
         continue
@@ -45,6 +62,6 @@ for arg in sys.argv[1:]:
             "-amdgpu-mfma-vgpr-form"] + extra + ["-c", os.path.join(b.CSRC, "prot_kernels.hip"), "-o", o])
     lib = os.path.join(vdir, "libprot_hip_%s.so" % tag)
     b._run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, o,
-            os.path.join(b.OBJDIR, "prot_sweep.o"), os.path.join(b.OBJDIR, "prot_kernels_f16.o"), os.path.join(b.OBJDIR, "prot_olasave.o"),
+            os.path.join(b.OBJDIR, "prot_sweep.o"), os.path.join(b.OBJDIR, "prot_kernels_f16.o"), os.path.join(b.OBJDIR, "prot_olasave.o"), os.path.join(b.OBJDIR, "prot_olasave8k.o"),
             CAPI_T, "-lpthread"])
     print("built", lib)
