@@ -283,7 +283,13 @@ def main():
     bytes_per_launch = 8.0 * n  # 4 B read + 4 B written per frame
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
     rows = int(eng.info.hop) // 512
-    if int(eng.info.form) == pkg.FORM_POLY_SAVE:
+    if int(eng.info.form) == pkg.FORM_POLY_SAVE8K:
+        rows8 = 16 - int(eng.info.firlen) // 1024
+        kname = "olasave8k_kernel<%d, 0>" % rows8
+        klabel = ("prot::%s (polyphase form, overlap-save on 8192-POINT blocks: 512-thread workgroups, two per CU, %d of 16 sample rows new per block, "
+                  "table-free centred filter, the radix-2 layer taken by the readers of the LDS exchanges; generated gfx950 assembly, 120 "
+                  "hand-allocated VGPRs; launches shorter than 2^24 channel-frames run olasave_kernel on 4096-point blocks)" % (kname, rows8))
+    elif int(eng.info.form) == pkg.FORM_POLY_SAVE:
         kname = "olasave_kernel<%d, 0>" % rows
         klabel = ("prot::%s (polyphase form, overlap-save: one partition of the odd taps applied centred and table-free -- forward transform at "
                   "the half-shifted index --, %d new sample rows of 16 per block, steady rotation as kernel arguments, dry path from the kept "
