@@ -1234,7 +1234,7 @@ def test_block8192_kernel_against_oracle_and_block4096(pkg, rate, chn, n, odd):
     for c in range(chn):    # nothing written beyond the requested frames
         assert float(outs["8k"][c * stride + n:(c + 1) * stride].abs().max()) == 0.0
     # windows against the oracle: the start of the stream (history = silence), two inside, the ragged end
-    W = 8192
+    W = 16384
     rng = np.random.default_rng(5)
     lat = {48000: 1792, 96000: 2560}[rate]
     for t0 in [0, n - W] + [int(v) for v in rng.integers(1 << 16, n - (1 << 16), size=2)]:

@@ -26,7 +26,7 @@ from isa import Prog, Emu, V, VP, S, SP, Lit  # noqa: E402
 KL1, KG = 272, 17                 # LDS exchange strides (prot_dev.h)
 LDS_TWM, LDS_TWF = 34816, 36864   # byte offsets of the W256 tables behind the exchange area
 LDS_GCAR, LDS_GNX = 32768, 33792  # core blocks: the gathered frames, one float per thread in lane layout, behind the 16 staged rows
-MODE_ROT, MODE_HILBERT = 0, 2
+MODE_ROT, MODE_HILBERT, MODE_SWEEP = 0, 2, 3   # (SWEEP: the Hilbert branch tested against a bound and its survivors compacted, round 4)
 
 # ---- SGPR plan (the asm block clobbers s34..s99; s32 and s100.. are reserved by the compiler) ----
 S_IN, S_OUT = SP(34), SP(36)      # frame (row 0, thread 0).q of the current block; first output frame of the current block
@@ -88,6 +88,8 @@ class Gen:
             self.TMP.append(VP(n))
             n += 2
         self.n_vgpr = n
+        if MODE == MODE_SWEEP:    # the running max |x| of the frames that pass through (angle 0, the raw peak) lives across blocks
+            self.V_RAW = V(120)   # (one register beyond the plan: the sweep instantiation is checked to stay without scratch)
         assert len(self.TMP) >= 6, "temporaries"
         # roles of the temporaries
         self.TB = self.TMP[:4]                 # twiddle batch (also: derived inverse twiddle, epilogue products)
@@ -568,6 +570,9 @@ class Gen:
         nt = "nt" in self.opts or "ntst" in self.opts
         m, e = k // 2, k % 2
         x = u[R0 + k]
+        if self.MODE == MODE_SWEEP:
+            self.sweep_row(self.K[R0 + k], x)
+            return
         if self.MODE == MODE_ROT:   # (sa * gain rides in the constants of the pointwise stage: scale_constants)
             P.pk("fma", x, [self.K[R0 + k], S_ROT, x], op_sel=[0, 0, 0], op_sel_hi=[1, 0, 1])
         if self.kind == "core":
@@ -576,6 +581,30 @@ class Gen:
             P.s_add_u32(S_A0.lo, S_OUT.lo, Lit(4096 * m))
             P.s_addc_u32(S_A0.hi, S_OUT.hi, Lit(0))
             P.global_store_dwordx2(self.VOFF, x, S_A0, 2048 * e, nt=nt)
+
+    def sweep_row(self, d, h):
+        """MODE_SWEEP: one output row is not stored -- d (dry pair) and h (Hilbert pair) of a frame go to the survivor list of this
+        wave (a plain append at the SGPR cursor S_OUT: lanes compacted by ballot + mbcnt) if d^2 + h^2 exceeds the bound in
+        S_ROT.lo: |ca d + sa h| <= sqrt(d^2 + h^2) for every angle, so the other frames cannot raise any maximum that has reached the
+        bound (prot_sweep.hip evaluates the list).  max |d| rides along (the raw peak)."""
+        P = self.P
+        r2, pr, idx = self.TMP[0], self.TMP[1], self.TMP[2].lo
+        P.pk("mul", r2, [d, d])
+        P.pk("fma", r2, [h, h, r2])
+        P.v_max3_abs(self.V_RAW, d.lo, d.hi)
+        for half in ("lo", "hi"):
+            P.v_cmp_lt_f32(S_ROT.lo, getattr(r2, half))
+            P.v_mov(pr.lo, getattr(d, half))
+            P.v_mov(pr.hi, getattr(h, half))
+            P.v_mbcnt(idx)
+            P.s_bcnt1_vcc(S_T[0])
+            P.v_lshl(idx, Lit(3), idx)
+            P.exec_from_vcc()
+            P.global_store_dwordx2(idx, pr, S_OUT, 0)
+            P.exec_all()
+            P.s_lshl_b32(S_T[0], S_T[0], Lit(3))
+            P.s_add_u32(S_OUT.lo, S_OUT.lo, S_T[0])
+            P.s_addc_u32(S_OUT.hi, S_OUT.hi, Lit(0))
 
     def epilogue(self, u):
         for k in range(self.HS):
@@ -589,8 +618,9 @@ class Gen:
             P.label("L_top")
             # whichever way the top is reached, what may still be in flight: the previous block's HS stores (younger than its
             # prefetch, which the wait below therefore completes)
-            P.s_waitcnt(vmcnt=HS, lgkmcnt=0)
-            P.reset_queues(vm_stores=HS)
+            n_st = 2 * HS if self.MODE == MODE_SWEEP else HS   # (two appends per row instead of one store)
+            P.s_waitcnt(vmcnt=n_st, lgkmcnt=0)
+            P.reset_queues(vm_stores=n_st)
         P.comment("---- (p, q) pairs")
         if "prio1" in self.opts:
             P.s_setprio(3)
@@ -667,8 +697,9 @@ class Gen:
             P.s_setprio(0)
         P.s_add_u32(S_IN.lo, S_IN.lo, Lit(4 * self.BLK))
         P.s_addc_u32(S_IN.hi, S_IN.hi, Lit(0))
-        P.s_add_u32(S_OUT.lo, S_OUT.lo, Lit(4 * self.BLK))
-        P.s_addc_u32(S_OUT.hi, S_OUT.hi, Lit(0))
+        if self.MODE != MODE_SWEEP:    # (SWEEP: S_OUT is the survivor cursor, advanced by what was appended)
+            P.s_add_u32(S_OUT.lo, S_OUT.lo, Lit(4 * self.BLK))
+            P.s_addc_u32(S_OUT.hi, S_OUT.hi, Lit(0))
         P.s_sub_u32(S_NBLK, S_NBLK, Lit(1))
         P.s_cmp_lg_u32(S_NBLK, Lit(0))
         P.s_cbranch_scc1("L_top")
@@ -737,6 +768,12 @@ def self_test(HS, MODE, NA=1, nblk=3, seed=1, verbose=True, opts=(), kind="run")
         put(12 * 256 + t, -2 * math.pi * ((t & 15) - 0.5) * (t >> 4) / 256)
         put(14 * 256 + t, -2 * math.pi * (((t & 15) * (t >> 4)) & 255) / 256)
     ca, sa = 0.6, -0.8
+    thr2 = 0.30
+    if MODE == MODE_SWEEP:   # S_ROT.lo is the bound, the Hilbert branch is unscaled, every wave appends to a list of its own
+        ca, sa = thr2, 1.0
+        SURV_BASE, CAP = 0x40000000, 2 * BLK * nblk
+        surv = np.zeros(4 * CAP, np.float32)
+        emu.map(SURV_BASE, surv.view(np.uint32))
     def sset(sp, lo, hi):
         emu.s[:, sp.n] = np.float32(lo).view(np.uint32)
         emu.s[:, sp.n + 1] = np.float32(hi).view(np.uint32)
@@ -750,6 +787,11 @@ def self_test(HS, MODE, NA=1, nblk=3, seed=1, verbose=True, opts=(), kind="run")
     emu.s[:, S_NBLK.n] = nblk
     emu.s[:, S_LDS.n] = 0
     emu.v[g.TMP[0].n] = np.arange(256, dtype=np.uint32)
+    if MODE == MODE_SWEEP:
+        for w in range(4):
+            a_ = SURV_BASE + 4 * CAP * w
+            emu.s[w, S_OUT.n], emu.s[w, S_OUT.n + 1] = a_ & 0xffffffff, a_ >> 32
+        emu.v[g.V_RAW.n] = np.zeros(256, np.float32).view(np.uint32)
     if kind == "core":   # what the C++ code stages: rows as (q, c) pairs, the gathered frames in lane layout
         tt = np.arange(256)
         for r in range(16):
@@ -782,13 +824,53 @@ def self_test(HS, MODE, NA=1, nblk=3, seed=1, verbose=True, opts=(), kind="run")
             dq = xd[a0 + 2 * j]
             dc = xd[a0 + 2 * j + 1]
             pos = b * BLK + 512 * k + 2 * np.arange(256)
-            if MODE == MODE_ROT:
+            if MODE == MODE_SWEEP:     # keep (d, h) per frame for the survivor check below
+                want[pos], want[pos + 1] = y.real, y.imag
+                if b == 0 and k == 0:
+                    dry = np.zeros(BLK * nblk)
+                dry[pos], dry[pos + 1] = dq, dc
+            elif MODE == MODE_ROT:
                 want[pos] = ca * dq + sa * y.real
                 want[pos + 1] = ca * dc + sa * y.imag
             else:
                 want[pos] = sa * y.real
                 want[pos + 1] = sa * y.imag
-    err = np.abs(out[:BLK * nblk] - want).max()
+    if MODE == MODE_SWEEP:
+        # every wave's list: frames in the order (block, row, first / second frame of the pairs, lane); exact d, h to rounding,
+        # membership by d^2 + h^2 > bound (frames within rounding of the bound may go either way)
+        err = 0.0
+        for w in range(4):
+            end = (int(emu.s[w, S_OUT.n]) | (int(emu.s[w, S_OUT.n + 1]) << 32)) - (SURV_BASE + 4 * CAP * w)
+            got = surv[CAP * w:CAP * w + end // 4].reshape(-1, 2)
+            exp = []
+            for b in range(nblk):
+                for k in range(HS):
+                    for half in range(2):
+                        pos = b * BLK + 512 * k + 2 * (64 * w + np.arange(64)) + half
+                        exp += [(dry[p_], want[p_]) for p_ in pos]
+            exp = np.array(exp)
+            r2 = exp[:, 0] ** 2 + exp[:, 1] ** 2
+            sure, maybe = r2 > thr2 + 1e-5, np.abs(r2 - thr2) <= 1e-5
+            gi = 0
+            for j in range(len(exp)):
+                hit = gi < len(got) and got[gi, 0] == np.float32(exp[j, 0]) and abs(got[gi, 1] - exp[j, 1]) < 1e-6
+                if sure[j] or (maybe[j] and hit):
+                    assert hit, ("survivor list of wave %d differs at entry %d" % (w, gi))
+                    err = max(err, abs(got[gi, 1] - exp[j, 1]))
+                    gi += 1
+            assert gi == len(got), "wave %d appended %d entries, expected %d" % (w, len(got), gi)
+            raw = emu.v[g.V_RAW.n].view(np.float32)[64 * w:64 * w + 64]
+            lanes = 64 * w + np.arange(64)
+            rexp = np.zeros(64)
+            for b in range(nblk):
+                for k in range(HS):
+                    pos = b * BLK + 512 * k + 2 * lanes
+                    rexp = np.maximum(rexp, np.maximum(np.abs(dry[pos]), np.abs(dry[pos + 1])))
+            assert np.array_equal(raw, rexp.astype(np.float32)), "running max |x|"
+        frac = sum(((int(emu.s[w, S_OUT.n]) | (int(emu.s[w, S_OUT.n + 1]) << 32)) - (SURV_BASE + 4 * CAP * w)) // 8 for w in range(4)) / (BLK * nblk)
+        kind = kind + " sweep (%.0f %% of the frames survive)" % (100 * frac)
+    else:
+        err = np.abs(out[:BLK * nblk] - want).max()
     st = P.stats()
     npk = sum(v for k, v in st.items() if k.startswith("pk_"))
     nval = sum(v for k, v in st.items() if k.startswith("v_"))
@@ -832,10 +914,33 @@ def emit(path, opts=()):
             out.append('\t"%s\\n\t" \\' % l)
         out.append('\t""')
         out.append("")
+    # MODE_SWEEP (run kind only; edge blocks take the Hilbert core and are tested by the C++ code): operands %0 survivor cursor
+    # (in / out), %1 running max |x| (in / out), %2 in, %3 blocks, %4 LDS byte offset, %5 constants table, %6 bound, %7 gain, %8 thread id
+    for HS in (8, 12):
+        g = Gen(HS, MODE_SWEEP, 1, opts, "run")
+        P = g.build()
+        head = ["s_mov_b64 %r, %%2" % S_IN, "s_mov_b64 %r, %%0" % S_OUT, "s_mov_b32 %r, %%3" % S_NBLK, "s_mov_b32 %r, %%4" % S_LDS,
+                "s_mov_b64 %r, %%5" % S_SV, "s_mov_b32 %r, %%6" % S_ROT.lo, "s_mov_b32 %r, %%7" % S_ROT.hi, "v_mov_b32 %r, %%8" % g.TMP[0].lo,
+                "v_mov_b32 %r, %%1" % g.V_RAW, "s_waitcnt vmcnt(0) lgkmcnt(0)"]
+        for n, (lo, hi) in sorted(g.constants().items()):
+            head.append("s_mov_b32 s%d, %r" % (n, Lit(float(lo))))
+            head.append("s_mov_b32 s%d, %r" % (n + 1, Lit(float(hi))))
+        tail = ["s_mov_b64 %%0, %r" % S_OUT, "v_mov_b32 %%1, %r" % g.V_RAW]
+        lines = head + P.text(label_suffix="%=") + tail
+        st = P.stats()
+        out.append("// sweep, HS %d: %d VGPRs, %d instructions" % (HS, g.n_vgpr, sum(v for k, v in st.items() if k not in ("comment", "label", "probe"))))
+        out.append("#define PROT_SV_SWEEP_%d \\" % HS)
+        for l in lines:
+            if l.startswith(";"):
+                continue
+            out.append('\t"%s\\n\t" \\' % l)
+        out.append('\t""')
+        out.append("")
     for HS in (8, 10, 12):
         nv = max(Gen(HS, m, na, opts, k).n_vgpr for (h, m, na) in VARIANTS if h == HS for k in ("run", "core"))
         clob = ['"memory"', '"vcc"', '"scc"'] + ['"s%d"' % i for i in SGPR_CLOBBER] + ['"v%d"' % i for i in range(0, nv)]
         out.append("#define PROT_SV_ASM_CLOBBERS_%d " % HS + ", ".join(clob))
+        out.append("#define PROT_SV_SWEEP_CLOBBERS_%d PROT_SV_ASM_CLOBBERS_%d, \"v120\"" % (HS, HS))
     out.append("")
     open(path, "w").write("\n".join(out))
 
@@ -858,6 +963,8 @@ if __name__ == "__main__":
     for HS, MODE, NA in VARIANTS:
         self_test(HS, MODE, NA, nblk=2 if "--quick" in sys.argv else 3)
         self_test(HS, MODE, NA, kind="core")
+    for HS in (8, 12):
+        self_test(HS, MODE_SWEEP, 1, nblk=2)
     if "--check" not in sys.argv:
         dst = os.path.join(csrc, "prot_olasave_asm.inc")
         emit(dst)

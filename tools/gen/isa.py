@@ -163,6 +163,17 @@ class Prog:
     def v_mul_u24(self, d, a, b): return self.add(Ins("v_mul_u24", "v_mul_u32_u24 %r, %r, %r" % (d, a, b), d=d, a=a, b=b))
     def v_cmp_eq_u32(self, a, b): return self.add(Ins("v_cmp_eq", "v_cmp_eq_u32 vcc, %r, %r" % (a, b), a=a, b=b))      # (a: constant or SGPR, b: VGPR)
     def v_cmp_lt_u32(self, a, b): return self.add(Ins("v_cmp_lt", "v_cmp_lt_u32 vcc, %r, %r" % (a, b), a=a, b=b))      # vcc = a < b
+    def v_cmp_lt_f32(self, a, b): return self.add(Ins("v_cmp_lt_f32", "v_cmp_lt_f32 vcc, %r, %r" % (a, b), a=a, b=b))    # vcc = a < b (floats)
+    def v_mbcnt(self, d):
+        """d = number of set VCC bits below this lane (both halves of the wave)"""
+        self.add(Ins("v_mbcnt_lo", "v_mbcnt_lo_u32_b32 %r, vcc_lo, 0" % d, d=d))
+        return self.add(Ins("v_mbcnt_hi", "v_mbcnt_hi_u32_b32 %r, vcc_hi, %r" % (d, d), d=d, a=d))
+    def v_max3_abs(self, d, a, b):   # d = max(|a|, |b|, d)
+        return self.add(Ins("v_max3_abs", "v_max3_f32 %r, |%r|, |%r|, %r" % (d, a, b, d), d=d, a=a, b=b))
+    def s_bcnt1_vcc(self, d): return self.add(Ins("s_bcnt1_vcc", "s_bcnt1_i32_b64 %r, vcc" % d, d=d))
+    def s_lshl_b32(self, d, a, sh): return self.add(Ins("s_lshl", "s_lshl_b32 %r, %r, %r" % (d, a, sh), d=d, a=a, sh=sh))
+    def exec_from_vcc(self): return self.add(Ins("exec_vcc", "s_mov_b64 exec, vcc"))
+    def exec_all(self): return self.add(Ins("exec_all", "s_mov_b64 exec, -1"))
     def v_cndmask(self, d, a, b): return self.add(Ins("v_cndmask", "v_cndmask_b32 %r, %r, %r, vcc" % (d, a, b), d=d, a=a, b=b))  # d = vcc ? b : a
 
     # ---- LDS ----
@@ -273,6 +284,7 @@ class _Wave:
         self.s = np.zeros(128, np.uint32)
         self.scc = 0
         self.vcc = np.zeros(64, bool)
+        self.exec = np.ones(64, bool)
         self.pc = 0
         self.vm_q, self.lgkm_q = [], []     # in-flight ops: (kind, regs)
         self.recent = []                    # VGPRs written by the last two VALU instructions (DPP hazard: 2 wait states)
@@ -442,7 +454,7 @@ class Emu:
                     if wr & used:
                         raise RuntimeError("DPP hazard: %s within 2 wait states of a VALU write of its register" % i.text)
             if op.startswith("pk_") or op.startswith("v_"):
-                W_.recent = (W_.recent + [set(regs_of(i.d)) if op not in ("v_readlane", "v_readfirstlane", "v_cmp_eq", "v_cmp_lt") else set()])[-2:]
+                W_.recent = (W_.recent + [set(regs_of(i.d)) if op not in ("v_readlane", "v_readfirstlane", "v_cmp_eq", "v_cmp_lt", "v_cmp_lt_f32") else set()])[-2:]
             else:
                 W_.recent = (W_.recent + [set()])[-2:]
             if op.startswith("pk_"):
@@ -495,6 +507,32 @@ class Emu:
                 touch(regs_of(i.a) + regs_of(i.b), [], i.text)
                 a, b = rd32(i.a), rd32(i.b)
                 W_.vcc = (a == b) if op == "v_cmp_eq" else (a < b)
+            elif op == "v_cmp_lt_f32":
+                touch(regs_of(i.a) + regs_of(i.b), [], i.text)
+                W_.vcc = rd32(i.a).view(np.float32) < rd32(i.b).view(np.float32)
+            elif op == "v_mbcnt_lo":
+                touch([], regs_of(i.d), i.text)
+                c = np.concatenate([[0], np.cumsum(W_.vcc[:32])[:-1]]).astype(np.uint32)
+                v[i.d.n] = np.concatenate([c, np.full(32, int(W_.vcc[:32].sum()), np.uint32)])
+            elif op == "v_mbcnt_hi":
+                touch(regs_of(i.a), regs_of(i.d), i.text)
+                c = np.concatenate([[0], np.cumsum(W_.vcc[32:])[:-1]]).astype(np.uint32)
+                v[i.d.n] = rd32(i.a) + np.concatenate([np.zeros(32, np.uint32), c])
+            elif op == "v_max3_abs":
+                touch(regs_of(i.a) + regs_of(i.b) + regs_of(i.d), regs_of(i.d), i.text)
+                m = np.maximum(np.maximum(np.abs(rd32(i.a).view(np.float32)), np.abs(rd32(i.b).view(np.float32))), rd32(i.d).view(np.float32))
+                v[i.d.n] = m.astype(np.float32).view(np.uint32)
+            elif op == "s_bcnt1_vcc":
+                s[i.d.n] = int(W_.vcc.sum())
+                W_.scc = int(W_.vcc.any())
+            elif op == "s_lshl":
+                r = (srd(i.a) << (srd(i.sh) & 31)) & 0xffffffff
+                s[i.d.n] = r
+                W_.scc = int(r != 0)
+            elif op == "exec_vcc":
+                W_.exec = W_.vcc.copy()
+            elif op == "exec_all":
+                W_.exec = np.ones(64, bool)
             elif op == "v_cndmask":
                 touch(regs_of(i.a) + regs_of(i.b), regs_of(i.d), i.text)
                 v[i.d.n] = np.where(W_.vcc, rd32(i.b), rd32(i.a))
@@ -531,8 +569,13 @@ class Emu:
             elif op in ("gload2", "gload1", "gstore2"):
                 base = srd(i.sbase.lo) | (srd(i.sbase.hi) << 32)
                 addr = base + rd32(i.voff).astype(np.int64) + i.off
-                b0, arr = self._region(int(addr.min()))
-                assert int(addr.max()) + (4 if op == "gload1" else 8) <= b0 + arr.size * 4, "global access out of its buffer"
+                act = addr[W_.exec] if op == "gstore2" else addr
+                if act.size == 0:
+                    W_.vm_q.append(("store", regs_of(i.data)))
+                    continue
+                b0, arr = self._region(int(act.min()))
+                assert int(act.max()) + (4 if op == "gload1" else 8) <= b0 + arr.size * 4, "global access out of its buffer"
+                addr = np.where(W_.exec, addr, b0) if op == "gstore2" else addr
                 assert np.all(addr % 4 == 0)
                 wd = ((addr - b0) // 4).astype(np.int64)
                 if op == "gload2":
@@ -546,7 +589,8 @@ class Emu:
                 else:
                     touch(regs_of(i.voff) + regs_of(i.data), [], i.text)
                     lo, hi = rd64(i.data)
-                    arr[wd], arr[wd + 1] = lo, hi
+                    m = W_.exec
+                    arr[wd[m]], arr[wd[m] + 1] = lo[m], hi[m]
                     W_.vm_q.append(("store", regs_of(i.data)))
             elif op == "s_waitcnt":
                 if i.vmcnt is not None:
