@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define PROT_ABI_VERSION 4
+#define PROT_ABI_VERSION 5
 #define PROT_SUBSAMPLE 2                      /* cli/phase-rotate.cc:38 */
 #define PROT_MAXSAMPLE (180 * PROT_SUBSAMPLE) /* cli/phase-rotate.cc:39 */
 
@@ -264,12 +264,18 @@ float* prot_cli_peaks_dev (prot_engine* e);
  * per-angle evaluation (tiles of survivors + tiles fed untested); the ratio is signal-dependent
  * (stationary material: the share of frames near the peaks; a signal that keeps growing: 1).
  * When more than 7/8 of a 1024-frame step survive, the workgroup stops testing for a while (2 steps, doubling while
- * re-probes keep failing, back to 2 after one that succeeds); those tiles are `untested`.  Launches with the pruning switched off (PROT_SWEEP_PRUNE=0) run the plain kernel
- * and count nothing.  Work on the engine's own stream is awaited first; launches on a caller's
+ * re-probes keep failing, back to 2 after one that succeeds); those tiles are `untested`.  Launches with the pruning switched off
+ * (a test hook) run the plain kernel and count nothing.  Work on the engine's own stream is awaited first; launches on a caller's
  * stream are the caller's to await.
  *   prot_sweep_stats_ex: out = { evaluated, seen, untested, surviving frames of the tested tiles } */
 int prot_sweep_stats (prot_engine* e, uint64_t* evaluated, uint64_t* seen);
 int prot_sweep_stats_ex (prot_engine* e, uint64_t out[4]);
+/* ABI 5.  Long sweeps of the engines whose Hilbert pass is the overlap-save kernel (blksiz 2048, 4096) FUSE a first test into that
+ * pass: the Hilbert branch is never written, only the (dry, hilbert) pairs of the frames whose r exceeds the bound of the whole
+ * call -- the table as it stands at launch, seeded by a pass over every 64th block when the call opens a stream or brings new
+ * angles -- go to lists which the matrix-core kernel then evaluates as above (its statistics then count tiles of LISTED frames).
+ * out = { channel-frames the fused pass has tested since the last reset, channel-frames it listed }.  Same tables, bit for bit. */
+int prot_sweep_stats_fused (prot_engine* e, uint64_t out[2]);
 
 /* ---- several GPUs of one node, single process --------------------------- */
 /* MAX all-reduce of the engines' OWN peak tables (prot_cli_peaks_dev) across

@@ -40,7 +40,7 @@ ABI_SYMBOLS = (
     "prot_lv2_run", "prot_lv2_set_max_block", "prot_lv2_get_angle", "prot_cli_apply", "prot_cli_analyze", "prot_cli_analyze_file",
     "prot_cli_apply_file", "prot_cli_peak", "prot_cli_peak_all", "prot_cli_peaks",
     "prot_cli_peaks_dev", "prot_allreduce_peaks", "prot_cli_analyze_file_multi", "prot_sweep_stats",
-    "prot_sweep_stats_ex", "prot_cli_file_resident",
+    "prot_sweep_stats_ex", "prot_sweep_stats_fused", "prot_cli_file_resident",
 )
 
 
@@ -121,6 +121,7 @@ def load_library():
     lib.prot_lv2_get_angle.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
     lib.prot_sweep_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.prot_sweep_stats_ex.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.prot_sweep_stats_fused.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.prot_cli_file_resident.argtypes = [C.c_void_p, C.c_int]
     lib.prot_cli_apply.argtypes = [C.c_void_p, _f32p, _i32p]
     lib.prot_cli_analyze.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -141,7 +142,7 @@ def load_library():
 
 
 # csrc/prot_internal.h: process-wide switches for tests and bench.py (NOT part of the drop-in boundary)
-TEST_SWEEP_UNPRUNED, TEST_EDGE_PATH_ONLY, TEST_LV2_STAGED, TEST_ALLREDUCE = 0, 1, 2, 3
+TEST_SWEEP_UNPRUNED, TEST_EDGE_PATH_ONLY, TEST_LV2_STAGED, TEST_ALLREDUCE, TEST_SWEEP_UNFUSED = 0, 1, 2, 3, 4
 
 
 def set_test_option(option, value):
@@ -253,6 +254,12 @@ class Engine:
         v = (C.c_uint64 * 4)()
         _check(self._lib.prot_sweep_stats_ex(self._h, v), "prot_sweep_stats_ex")
         return dict(evaluated=v[0], seen=v[1], untested=v[2], survivors=v[3])
+
+    def sweep_stats_fused(self):
+        """{tested, listed}: channel-frames the fused Hilbert + test pass has seen / kept since the last reset (prot_sweep_stats_fused)."""
+        v = (C.c_uint64 * 2)()
+        _check(self._lib.prot_sweep_stats_fused(self._h, v), "prot_sweep_stats_fused")
+        return dict(tested=v[0], listed=v[1])
 
     def sweep_dev(self, d_in, in_stride, n_frames, ang_start, ang_end, ang_stride, chn=-1,
                   d_peaks=0, flags=0, stream=0):

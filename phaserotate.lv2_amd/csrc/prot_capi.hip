@@ -423,6 +423,13 @@ struct prot_engine {
 	DevBuf<unsigned> d_ctr; // [n_chn][32][32] step counters of a sweep launch (zero between launches)
 	DevBuf<float>  d_part;  // per-workgroup maxima of one sweep launch (prot_sweep.hip), allocated by the first sweep
 	DevBuf<unsigned long long> d_stats; // {tiles evaluated, tiles seen, tiles untested, surviving frames} since the last reset
+	// fused sweep (olasave_kernel MODE_SWEEP + sweep_kernel COMPACT): the survivor lists of one pass, their lengths, the step table
+	DevBuf<float2>   d_surv;
+	DevBuf<unsigned> d_surv_cnt, d_nsteps;
+	DevBuf<uint2>    d_desc;
+	uint64_t         fused_frames = 0;          // channel-frames the fused pass has tested since the last reset
+	DevBuf<unsigned long long> d_fused_surv;    // ... and how many of them it kept (device counter)
+	bool             sweep_seeded = false;      // the table holds a bound for the angle list of angles_last
 	PinBuf<float>  h_io;
 	// small host->device parameter copies (rotation pairs, angle lists) are staged through a ring of
 	// pinned slots owned by the engine, each guarded by an event: the caller's array may die as soon
@@ -484,6 +491,11 @@ int zero_state (prot_engine* e)
 	if (err != hipSuccess) {
 		return hip_fail (err, "state reset launch");
 	}
+	if (e->d_fused_surv.p) {
+		(void)hipMemsetAsync (e->d_fused_surv.p, 0, sizeof (unsigned long long), e->stream);
+	}
+	e->fused_frames  = 0;
+	e->sweep_seeded  = false;
 	e->hist16_cur    = 0;
 	e->hist_cur      = 0;
 	e->pos           = 0;
@@ -636,10 +648,23 @@ void rank_runs (P& p, int64_t blk, int n_chn, uint64_t n_out, int slots, int cus
 }
 
 // core of prot_apply_dev / the Hilbert pass of the sweep
+// what the fused Hilbert pass of a sweep adds to an overlap-save launch (OlaParams::surv ...)
+struct FusedSweep {
+	float*     peaks;      // table [n_chn][360] (bound, raw peak)
+	const int* angles;
+	int        n_angles, raw_slot, raw_tail;
+	bool       sample;     // the seeding pass: every `stride_blocks`-th block, no bound, nothing of the engine's state moves
+	int        stride_blocks;
+	int64_t    t_begin, dry_from;
+	// out: the geometry of the lists
+	int        n_lists;
+	int64_t    cap;
+};
+
 int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_in, float* d_out,
                 int64_t out_stride, uint64_t n_out, const float* d_rot, const float* d_rot_s,
                 bool hilbert_only, bool stateless, int chn0, int n_chn, hipStream_t s, bool advance_hist = false,
-                const float* h_rot = nullptr, const uint32_t* pipe_wait_post = nullptr)
+                const float* h_rot = nullptr, const uint32_t* pipe_wait_post = nullptr, FusedSweep* fs = nullptr)
 {
 	prot::OlaParams p {};
 	if (pipe_wait_post) { // pipelined stateful launch (prot_apply_dev): history handed over on the device
@@ -725,6 +750,40 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 			p.sv_flags   = e->sv_flags;
 			p.conv_delay = (int)e->info.conv_delay;
 			p.accumulate = 0;
+			if (fs) {
+				// the sweep's test rides in the Hilbert pass: one list per wave (4 per workgroup), long enough for every frame of
+				// the workgroup's run to survive
+				const int64_t blk = (int64_t)e->info.run_align;
+				if (fs->sample) {
+					p.run_frames = (int)blk;
+					p.run_stride = (int)(blk * fs->stride_blocks);
+					p.rank_cu    = 0;
+				}
+				const int64_t unit   = p.run_stride > 0 ? p.run_stride : p.run_frames;
+				const int64_t runs   = ((int64_t)n_out + unit - 1) / unit;
+				int64_t       longest = p.run_frames;
+				for (int k = 0; k < p.n_rank && p.rank_cu > 0; ++k) {
+					longest = std::max<int64_t> (longest, p.rank_frames[k]);
+				}
+				fs->n_lists = (int)runs * 4;
+				fs->cap     = ((longest / 4 + 3) & ~(int64_t)3) + 4; // a wave's share of its workgroup's longest run
+				int rc2;
+				if ((rc2 = e->d_surv.ensure ((size_t)fs->n_lists * fs->cap * n_chn + 2048)) || (rc2 = e->d_surv_cnt.ensure ((size_t)fs->n_lists * n_chn)) ||
+				    (rc2 = e->d_desc.ensure (((size_t)fs->n_lists + (size_t)(n_out / 1024) + 8) * n_chn)) || (rc2 = e->d_nsteps.ensure ((size_t)n_chn))) {
+					return rc2;
+				}
+				p.surv        = e->d_surv.p;
+				p.surv_cap    = fs->cap;
+				p.surv_cnt    = e->d_surv_cnt.p;
+				p.sw_peaks    = fs->peaks + (size_t)chn0 * PROT_MAXSAMPLE;
+				p.sw_angles   = fs->angles;
+				p.sw_n_angles = fs->n_angles;
+				p.sw_raw_slot = fs->raw_slot;
+				p.sw_raw_tail = fs->raw_tail;
+				p.sw_thr_zero = fs->sample ? 1 : 0;
+				p.sw_t_begin  = fs->t_begin;
+				p.sw_dry_from = fs->dry_from;
+			}
 			hipError_t err = prot::launch_ola_save (p, e->hopseg / 2, e->sv_rows, n_chn, s);
 			if (err != hipSuccess) {
 				return hip_fail (err, "overlap-save ola kernel launch");
@@ -1260,6 +1319,11 @@ void prot_engine_destroy (prot_engine* e)
 	e->d_H.release ();
 	e->d_sv.release ();
 	e->d_sv8.release ();
+	e->d_surv.release ();
+	e->d_surv_cnt.release ();
+	e->d_nsteps.release ();
+	e->d_desc.release ();
+	e->d_fused_surv.release ();
 	e->d_Hp.release ();
 	e->d_tw.release ();
 	e->d_lut.release ();
@@ -1630,9 +1694,95 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		}
 	}
 
+	// the angle list of a file analysis is the same for every chunk: uploaded when it changes (or the stream does)
+	const bool new_angles = n_ang > 0 && (e->angles_stream != s || e->angles_last.size () != (size_t)n_ang || memcmp (e->angles_last.data (), lut_idx, n_ang * sizeof (int)));
+	int rc = PROT_OK;
+	if (new_angles) {
+		rc = stage_small (e, e->d_angles.p, lut_idx, n_ang * sizeof (int), s);
+		if (rc) {
+			return rc;
+		}
+		e->angles_last.assign (lut_idx, lut_idx + n_ang);
+		e->angles_stream = s;
+		e->sweep_seeded  = false;
+	}
+	const bool unpruned = g_test_opt[PROT_TEST_SWEEP_UNPRUNED].load () != 0;
+	// FUSED (round 4): the sweep's test rides in the Hilbert pass (olasave_kernel MODE_SWEEP: nothing but the surviving (d, h)
+	// pairs -- a few percent of the frames -- is written), the matrix-core kernel evaluates the lists.  For the engines whose
+	// Hilbert pass is the overlap-save kernel (blksiz 2048, 4096), pruned sweeps, calls long enough to carry five more launches;
+	// the tables are bit-identical to the separate passes' (same blocks, same arithmetic per frame, max is order-free).
+	const bool fused = e->use_save && (e->hopseg == 16 || e->hopseg == 24) && n_ang > 0 && !unpruned && !(e->sv_flags & 1) &&
+	                   n_out >= ((uint64_t)1 << 20) && !g_test_opt[PROT_TEST_SWEEP_UNFUSED].load ();
+	if (fused) {
+		const float* hist_old = e->d_hist[e->hist_cur].p; (void)hist_old;
+		if (e->pos == 0) {
+			e->sweep_seeded = false;
+		}
+		int rc2;
+		const bool first_fused = e->d_fused_surv.p == nullptr;
+		if ((rc2 = e->d_part.ensure (prot::sweep_scratch_floats ())) || (rc2 = e->d_fused_surv.ensure (1))) {
+			return rc2;
+		}
+		if (first_fused) {
+			HIP_TRY (hipMemsetAsync (e->d_fused_surv.p, 0, sizeof (unsigned long long), s));
+		}
+		for (int pass = e->sweep_seeded ? 1 : 0; pass < 2; ++pass) {
+			FusedSweep fs {};
+			fs.peaks         = pk;
+			fs.angles        = e->d_angles.p;
+			fs.n_angles      = n_ang;
+			fs.raw_slot      = raw0 ? 0 : -1;
+			fs.raw_tail      = (raw0 && !end && pass == 1) ? 1 : 0;
+			fs.sample        = pass == 0;
+			fs.stride_blocks = 64;
+			fs.t_begin       = beg ? P / 2 : 0; // :418-419
+			fs.dry_from      = beg ? P : 0;     // (local frames: the first block's dry term is the silent previous block, Q1)
+			if (pass == 0 && n_out < (uint64_t)fs.stride_blocks * e->info.run_align * 8) {
+				continue; // too short for a sample worth its launches: the main pass starts from the table as it is
+			}
+			rc = ola_launch (e, d_in, in_stride, n_frames, const_cast<float*> (d_in), in_stride, n_out, nullptr, nullptr, true, false, c0, nc, s,
+			                 /*advance_hist*/ pass == 1, nullptr, nullptr, &fs);
+			if (rc) {
+				return rc;
+			}
+			const int64_t desc_stride = (int64_t)fs.n_lists + (int64_t)(n_out / 1024) + 8;
+			hipError_t    err = prot::launch_sweep_plan (e->d_surv_cnt.p, fs.n_lists, fs.cap, e->d_desc.p, desc_stride, e->d_nsteps.p, nc,
+			                                             pass == 1 ? e->d_fused_surv.p : nullptr, s);
+			if (err != hipSuccess) {
+				return hip_fail (err, "sweep plan launch");
+			}
+			prot::SweepParams sp {};
+			sp.surv        = e->d_surv.p;
+			sp.desc        = e->d_desc.p;
+			sp.desc_stride = desc_stride;
+			sp.n_steps     = e->d_nsteps.p;
+			sp.t_begin     = 0;
+			sp.t_end       = pass == 0 ? (int64_t)((n_out / ((uint64_t)fs.stride_blocks * e->info.run_align) + 1) * e->info.run_align) : (int64_t)n_out;
+			sp.angles      = e->d_angles.p;
+			sp.n_angles    = n_ang;
+			sp.lut         = e->d_lut.p;
+			sp.peaks       = pk;
+			sp.chn0        = c0;
+			sp.prune       = 1;
+			sp.thr         = e->d_thr.p;
+			sp.stats       = e->d_stats.p;
+			sp.ctr         = e->d_ctr.p;
+			sp.part        = e->d_part.p;
+			sp.part_floats = prot::sweep_scratch_floats ();
+			sp.raw_slot    = -1; // (the raw peak went into the table from the fused pass)
+			err            = prot::launch_sweep (sp, nc, s);
+			if (err != hipSuccess) {
+				(void)hipMemsetAsync (e->d_thr.p, 0, 4 * (size_t)e->info.n_chn * sizeof (float), s);
+				(void)hipMemsetAsync (e->d_ctr.p, 0, (size_t)e->info.n_chn * 32 * 32 * sizeof (unsigned), s);
+				return hip_fail (err, "sweep kernel launch (lists)");
+			}
+		}
+		e->sweep_seeded = true;
+		e->fused_frames += n_out * (uint64_t)nc;
+	} else {
 	// 1. Hilbert branch u[t], t in [0, n_out)
 	const size_t ustride = (size_t)((n_out + 255) & ~(uint64_t)255);
-	int rc = e->d_u.ensure (ustride * e->info.n_chn);
+	rc = e->d_u.ensure (ustride * e->info.n_chn);
 	if (rc) {
 		return rc;
 	}
@@ -1647,15 +1797,6 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 	}
 	// 2. rotated peaks
 	if (n_ang > 0) {
-		// the angle list of a file analysis is the same for every chunk: uploaded when it changes (or the stream does)
-		if (e->angles_stream != s || e->angles_last.size () != (size_t)n_ang || memcmp (e->angles_last.data (), lut_idx, n_ang * sizeof (int))) {
-			rc = stage_small (e, e->d_angles.p, lut_idx, n_ang * sizeof (int), s);
-			if (rc) {
-				return rc;
-			}
-			e->angles_last.assign (lut_idx, lut_idx + n_ang);
-			e->angles_stream = s;
-		}
 		prot::SweepParams sp {};
 		sp.x        = d_in;
 		sp.x_stride = in_stride;
@@ -1674,7 +1815,7 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		sp.lut      = e->d_lut.p;
 		sp.peaks    = pk;
 		sp.chn0     = c0;
-		sp.prune       = g_test_opt[PROT_TEST_SWEEP_UNPRUNED].load () ? 0 : 1; // exact either way; the unpruned sweep is for timing and tests (prot_internal.h)
+		sp.prune       = unpruned ? 0 : 1; // exact either way; the unpruned sweep is for timing and tests (prot_internal.h)
 		sp.thr         = e->d_thr.p;
 		sp.stats       = e->d_stats.p;
 		if ((rc = e->d_part.ensure (prot::sweep_scratch_floats ())) != PROT_OK) {
@@ -1702,6 +1843,7 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		if (err != hipSuccess) {
 			return hip_fail (err, "absmax kernel launch");
 		}
+	}
 	}
 	// 4. state: the reference has consumed nb blocks (zero padding included): the data frames went into the history with
 	// the Hilbert launch above
@@ -1746,6 +1888,23 @@ int prot_sweep_stats_ex (prot_engine* e, uint64_t out[4])
 	for (int i = 0; i < 4; ++i) {
 		out[i] = h[i];
 	}
+	return PROT_OK;
+}
+
+int prot_sweep_stats_fused (prot_engine* e, uint64_t out[2])
+{
+	if (!e || !out) {
+		return PROT_EINVAL;
+	}
+	HIP_TRY (hipSetDevice (e->device));
+	(void)join_pipe (e, e->stream);
+	HIP_TRY (hipStreamSynchronize (e->stream));
+	unsigned long long kept = 0;
+	if (e->d_fused_surv.p) {
+		HIP_TRY (hipMemcpy (&kept, e->d_fused_surv.p, sizeof (kept), hipMemcpyDeviceToHost));
+	}
+	out[0] = e->fused_frames;
+	out[1] = kept;
 	return PROT_OK;
 }
 

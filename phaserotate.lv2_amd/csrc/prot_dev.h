@@ -6,7 +6,7 @@
 
 namespace prot {
 
-enum { MODE_ROT = 0, MODE_RAMP = 1, MODE_HILBERT = 2 };
+enum { MODE_ROT = 0, MODE_RAMP = 1, MODE_HILBERT = 2, MODE_SWEEP = 3 };
 
 // ------------------------------------------------------------------ helpers
 // virtual stream [hist | in | silence] at index i (i may be negative)
@@ -81,6 +81,10 @@ PROT_DEV void run_of_workgroup (const OlaParamsT<S>& p, int64_t& r0, int64_t& rl
 		bx = (bx & ~7) | ((bx + (bx >> 3)) & 7);
 	}
 	rlen = p.run_frames;
+	if (p.run_stride > 0) { // a sparse sample of the stream (the sweep's bound-seeding pass): run g starts at g * run_stride
+		r0 = (int64_t)blockIdx.x * p.run_stride;
+		return;
+	}
 	if (p.rank_cu > 0) {
 		const int id = (int)blockIdx.y * (int)gridDim.x + bx, id0 = (int)blockIdx.y * (int)gridDim.x;
 		r0           = 0;

@@ -13,7 +13,8 @@ enum {
 	PROT_TEST_EDGE_PATH_ONLY = 1, // != 0: engines created from now on run every overlap-save block through the staged (edge) path
 	PROT_TEST_LV2_STAGED     = 2, // != 0: prot_lv2_run copies its buffers through staging memory whatever their size
 	PROT_TEST_ALLREDUCE      = 3, // 0 automatic; 1 merge through the host; 2 the RCCL collective even when engines share a device
-	PROT_TEST_OPTIONS        = 4
+	PROT_TEST_SWEEP_UNFUSED  = 4, // != 0: prot_sweep_dev keeps the separate Hilbert and sweep passes where it would fuse them (bit-identical tables)
+	PROT_TEST_OPTIONS        = 5
 };
 int prot_internal_set_test_option (int option, int value); // 0 or PROT_EINVAL
 #ifdef __cplusplus

@@ -59,6 +59,25 @@ struct OlaParamsT {
 	uint32_t*     hs_flag;      // (word kPipeStatusWord of the same array: generation whose wait timed out, 0 = none)
 	uint32_t*     hs_cnt;
 	uint32_t      hs_wait, hs_post;
+	// olasave_kernel, MODE_SWEEP (surv != NULL): the Hilbert pass of the CLI sweep with the sweep's test fused into it -- nothing is
+	// written to `out`; for every frame t in [sw_t_begin, n_out) the pair d = x[t - dry_delay] (0 while t < sw_dry_from, Q1),
+	// h = hilbert[t] is appended to the list of the wave that computed it if d^2 + h^2 exceeds the bound: the smallest entry of
+	// sw_peaks[c][sw_angles[..]] as it stands at launch, squared, less the margin of prot_sweep.hip (sw_thr_zero: no bound --
+	// the seeding pass over a sparse sample of the blocks, run_stride).  List of wave w of workgroup g of channel c: surv +
+	// ((c * gridDim.x + g) * 4 + w) * surv_cap, its length in surv_cnt at the same index.  max |x| over the frames that pass
+	// through goes to sw_peaks[c][sw_raw_slot] (>= 0; sw_raw_tail: the call's last dry_delay input frames too).
+	float2*       surv;
+	int64_t       surv_cap;
+	uint32_t*     surv_cnt;
+	float*        sw_peaks;
+	const int*    sw_angles;
+	int32_t       sw_n_angles;
+	int32_t       sw_raw_slot;
+	int32_t       sw_raw_tail;
+	int32_t       sw_thr_zero;
+	int64_t       sw_t_begin;
+	int64_t       sw_dry_from;
+	int32_t       run_stride; // > 0: workgroup g's run starts at frame g * run_stride (instead of g * run_frames)
 };
 typedef OlaParamsT<float>    OlaParams;
 typedef OlaParamsT<_Float16> OlaParamsH; // fp16 sample path (BASELINE config 5)
@@ -124,7 +143,19 @@ struct SweepParams {
 	float*       part;        // device scratch, >= sweep_scratch_floats () floats: per-workgroup maxima of one launch (merged into peaks)
 	size_t       part_floats;
 	unsigned long long* stats; // device, [4] += {tiles evaluated, tiles seen, tiles fed untested, surviving frames of tested tiles}, or NULL
+	// COMPACT source (surv != NULL; round 4): the frames come as (d, h) pairs from the lists the fused Hilbert pass left
+	// (olasave_kernel MODE_SWEEP) instead of from x, hist and u: step gs of channel c is desc[c * desc_stride + gs] = {first entry
+	// (index into surv), entries (1..1024)}, n_steps[c] steps in all (sweep_plan_kernel); x, u, t_begin .. delay are unused
+	const float2*   surv;
+	const uint2*    desc;
+	int64_t         desc_stride;
+	const unsigned* n_steps;
 };
+// the step table of a COMPACT sweep from the list lengths: cnt[c][n_lists] -> desc, n_steps; list l of channel c starts at entry
+// (c * n_lists + l) * cap
+// (total, optional: += the number of entries of all lists)
+hipError_t launch_sweep_plan (const unsigned* cnt, int n_lists, int64_t cap, uint2* desc, int64_t desc_stride, unsigned* n_steps, int n_chn,
+                              unsigned long long* total, hipStream_t s);
 hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s);
 size_t     sweep_scratch_floats ();
 

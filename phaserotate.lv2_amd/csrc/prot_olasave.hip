@@ -60,6 +60,15 @@ extern "C" int prot_debug_sv_wg (unsigned long long* out, int n_wg)
 		              : "s"(in_), "s"(out_), "s"(nf_), "s"(lds_off), "s"(a_sv), "s"(ca_), "s"(sa_), "v"(t0)                                \
 		              : PROT_SV_CLOB_ (HS_));                                                                                           \
 	}
+// MODE_SWEEP: the generated loop with the sweep's test in its epilogue (no output rows: survivors appended at cursor_, the
+// running max |x| in raw_); cursor_ and raw_ are read and written
+#define PROT_SV_SWEEP_CALL(HS_, in_, cursor_, raw_, nf_, thr_, gain_)                                                                  \
+	if (HS == HS_) {                                                                                                                    \
+		asm volatile (PROT_SV_SWEEP_##HS_                                                                                               \
+		              : "=s"(cursor_), "=v"(raw_)                                                                                       \
+		              : "s"(in_), "s"(nf_), "s"(lds_off), "s"(a_sv), "s"(thr_), "s"(gain_), "v"(t0), "s"(cursor_), "v"(raw_)             \
+		              : PROT_SV_SWEEP_CLOBBERS_##HS_);                                                                                  \
+	}
 #define PROT_SV_ALL(KIND_, in_, out_, nf_, ca_, sa_)                                                                                   \
 	PROT_SV_CALL (KIND_, 8, 0, in_, out_, nf_, ca_, sa_)                                                                                \
 	PROT_SV_CALL (KIND_, 8, 2, in_, out_, nf_, ca_, sa_)                                                                                \
@@ -83,8 +92,9 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 	constexpr int BLK = 512 * HS; // output frames per block
 	constexpr int NT  = 16 - HS;  // context rows
 	constexpr int R0  = NT / 2;   // first valid output row = first dry row
-	constexpr int AM  = MODE == MODE_ROT ? 0 : 2; // the generated code's mode (per-frame rotation: Hilbert branch, mixed here)
+	constexpr int AM  = MODE == MODE_ROT ? 0 : 2; // the generated code's mode (per-frame rotation, sweep: Hilbert branch, mixed / tested here)
 	static_assert (HS == 8 || HS == 10 || HS == 12, "rows per block (HS = 14 needs 124 VGPRs before any temporary: olapoly_kernel)");
+	static_assert (MODE != MODE_SWEEP || HS != 10, "the fused sweep exists for the CLI engines (blksiz 2048, 4096)");
 
 	__shared__ f2 smem[kLdsExchange + 512]; // the exchange area + the two W256 tables (written by the generated prologue)
 
@@ -98,7 +108,51 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 	// of this one but the history, i.e. the tail of this launch's INPUT -- written first, counted, and published by the
 	// last workgroup to get there.  (The host takes this route only when n_in >= hist_len: the slice is then a plain copy
 	// of input frames and does not read the previous history.)
-	const bool piped = p.hs_flag != nullptr;
+	const bool piped = MODE != MODE_SWEEP && p.hs_flag != nullptr;
+	// MODE_SWEEP: the bound of this launch -- the smallest of the table's entries for the call's angles as they stand now (they only
+	// grow: a lower bound of every final peak), squared, less prot_sweep.hip's margin; every wave appends to a list of its own
+	__shared__ float sw_lo_s[4];
+	float            sw_raw = 0.f;
+	// (the bound is re-read from LDS where it is used: a register copy would live across the generated code)
+	auto sw_thr = [&] () -> float { return __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (((volatile float*)sw_lo_s)[0]))); };
+	unsigned         sw_cnt  = 0u; // entries this wave has appended (wave-uniform; the list's address is recomputed where it is needed:
+	                               // nothing but this count, the bound and the running maximum lives across the generated code)
+	// (wave reductions with the lane id made opaque at each use: with __shfl_xor the compiler keeps the six permutation indices of
+	// the reduction at the top of the kernel alive for the one at its end -- across the generated code, i.e. in scratch)
+	auto sw_wave_reduce = [] (float v, bool take_max) -> float {
+		int lane;
+		asm volatile ("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+		for (int m = 1; m < 64; m <<= 1) {
+			const float o = __int_as_float (__builtin_amdgcn_ds_bpermute ((lane ^ m) << 2, __float_as_int (v)));
+			v             = take_max ? fmaxf (v, o) : fminf (v, o);
+		}
+		return v;
+	};
+	auto sw_list = [&] () -> float2* {
+		const int w = __builtin_amdgcn_readfirstlane (threadIdx.x >> 6);
+		return uniform_ptr_generic (p.surv + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) * p.surv_cap);
+	};
+	if (MODE == MODE_SWEEP) {
+		float lo = 1.0e18f;
+		if (!p.sw_thr_zero) {
+			for (int i = t0; i < p.sw_n_angles; i += 256) {
+				lo = fminf (lo, __builtin_nontemporal_load (&p.sw_peaks[(int64_t)c * kMaxSample + p.sw_angles[i]]));
+			}
+		} else {
+			lo = 0.f;
+		}
+		lo = sw_wave_reduce (lo, false);
+		if ((t0 & 63) == 0) {
+			sw_lo_s[t0 >> 6] = lo;
+		}
+		__syncthreads ();
+		lo = fminf (fminf (sw_lo_s[0], sw_lo_s[1]), fminf (sw_lo_s[2], sw_lo_s[3]));
+		__syncthreads ();
+		if (t0 == 0) {
+			sw_lo_s[0] = lo * lo * 0.9999f;
+		}
+		__syncthreads ();
+	}
 	if (piped) {
 		// my slice of the next history: device-scope (write-through) stores, so that publishing it needs no release FENCE --
 		// at device scope that is a write-back of the XCD's whole L2, and with one per workgroup two overlapping launches
@@ -132,6 +186,9 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 		if (!piped) {
 			hist_write_slice (p, blockIdx.y, threadIdx.x);
 		}
+		if (MODE == MODE_SWEEP && (t0 & 63) == 0) {
+			p.surv_cnt[((int64_t)c * gridDim.x + blockIdx.x) * 4 + (t0 >> 6)] = 0u;
+		}
 		return;
 	}
 	const int64_t r1 = (r0 + rlen < p.n_out) ? r0 + rlen : p.n_out;
@@ -163,6 +220,13 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 	const bool in_al8  = (reinterpret_cast<uintptr_t> (in) & 7) == 0;
 	const bool out_al8 = (reinterpret_cast<uintptr_t> (out) & 7) == 0;
 
+	if (MODE == MODE_SWEEP && p.sw_raw_slot >= 0 && p.sw_raw_tail && blockIdx.x == 0) {
+		// the call's last dry_delay input frames: the rows reach them only as the next chunk's history (see prot_sweep.hip)
+		const float* xin = p.in + (int64_t)c * p.in_stride;
+		for (int64_t i = p.n_in - p.dry_delay + t0; i < p.n_in; i += 256) {
+			sw_raw = fmaxf (sw_raw, i >= 0 ? fabsf (xin[i]) : 0.f);
+		}
+	}
 	float ca = 0.f, sa = p.sv_gain;
 	if (MODE == MODE_ROT) {
 		ca = p.rot ? p.rot[2 * c] : p.rot_v[2 * c];
@@ -203,7 +267,8 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 
 	for (int64_t s = r0; s < r1;) {
 		const int64_t a0 = s - Dd - 512 * R0; // frame of (row 0, thread 0).q: the dry frame of output row r is input row r
-		if (MODE != MODE_RAMP && in_al8 && out_al8 && a0 >= 1 && !(p.sv_flags & 1)) {
+		if (MODE != MODE_RAMP && in_al8 && (out_al8 || MODE == MODE_SWEEP) && a0 >= 1 && !(p.sv_flags & 1) &&
+		    (MODE != MODE_SWEEP || (s >= p.sw_t_begin && s >= p.sw_dry_from))) {
 			// blocks from here on that read only frames inside the array and are emitted whole
 			const int64_t n1 = (r1 - s) / BLK;
 			const int64_t n2 = n_in - 8192 - a0 >= 0 ? (n_in - 8192 - a0) / BLK + 1 : 0;
@@ -215,7 +280,16 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 #ifdef PROT_SV_CLOCK
 				const uint64_t c0 = __builtin_readcyclecounter (), q0 = __builtin_amdgcn_s_memrealtime ();
 #endif
-				PROT_SV_ALL (ASM, a_in, a_out, nf, ca, sa)
+				if constexpr (MODE == MODE_SWEEP) {
+					float2* const base  = sw_list ();
+					float2*       cur   = uniform_ptr_generic (base + sw_cnt);
+					const float   thr_u = sw_thr ();
+					PROT_SV_SWEEP_CALL (8, a_in, cur, sw_raw, nf, thr_u, sa)
+					PROT_SV_SWEEP_CALL (12, a_in, cur, sw_raw, nf, thr_u, sa)
+					sw_cnt = (unsigned)__builtin_amdgcn_readfirstlane ((int)(cur - sw_list ()));
+				} else {
+					PROT_SV_ALL (ASM, a_in, a_out, nf, ca, sa)
+				}
 #ifdef PROT_SV_CLOCK
 				if (t0 == 0) {
 					atomicAdd (&g_sv_clock[0], (unsigned long long)(__builtin_readcyclecounter () - c0));
@@ -250,7 +324,7 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 		}
 		__syncthreads ();
 		{
-			const float  cca = MODE == MODE_RAMP ? 0.f : ca, csa = MODE == MODE_RAMP ? __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (p.sv_gain))) : sa;
+			const float  cca = (MODE == MODE_RAMP || MODE == MODE_SWEEP) ? 0.f : ca, csa = MODE == MODE_RAMP ? __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (p.sv_gain))) : sa;
 			const float* a_in  = a_sv; // (unused by the core)
 			float*       a_out = nullptr;
 			const int    one   = 1;
@@ -265,7 +339,34 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 		asm volatile ("" : "+v"(t));
 		t &= 255;
 		// rows 0..HS-1 of the exchange area now hold the output pairs of frames s + 512 k + 2 t (+1)
-		if (MODE != MODE_RAMP && s + BLK <= r1 && out_al8) {
+		if constexpr (MODE == MODE_SWEEP) {
+			// the sweep's test on an edge block: the same order as the generated loop (row, first / second frame of the pairs,
+			// lane), with what only edge blocks meet -- frames in front of sw_t_begin or beyond the call are not tested, the dry
+			// term is 0 while t < sw_dry_from (Q1; the raw peak takes the frame all the same)
+			float2* const list    = sw_list ();
+			const float   sw_thr2 = sw_thr ();
+			for (int k = 0; k < HS; ++k) {
+				const f2      hp   = st[256 * k + t];
+				const int64_t pos0 = s + 512 * (int64_t)k + 2 * (int64_t)t;
+				const f2      dp   = row_pair (pos0 - 2 * (int64_t)t - Dd, t);
+#pragma unroll
+				for (int e = 0; e < 2; ++e) {
+					const int64_t pos = pos0 + e;
+					const bool    in_ = pos >= p.sw_t_begin && pos < r1;
+					const float   raw = e ? dp.y : dp.x, h = e ? hp.y : hp.x;
+					const float   d   = pos >= p.sw_dry_from ? raw : 0.f;
+					if (in_) {
+						sw_raw = fmaxf (sw_raw, fabsf (raw));
+					}
+					const bool     live = in_ && d * d + h * h > sw_thr2;
+					const uint64_t mask = __builtin_amdgcn_ballot_w64 (live);
+					if (live) {
+						list[sw_cnt + __builtin_amdgcn_mbcnt_hi ((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned)mask, 0u))] = make_float2 (d, h);
+					}
+					sw_cnt += (unsigned)__builtin_popcountll (mask);
+				}
+			}
+		} else if (MODE != MODE_RAMP && s + BLK <= r1 && out_al8) {
 #pragma unroll
 			for (int m = 0; m < HS / 2; ++m) {
 				PROT_GLOBAL f2* __restrict__ ob = reinterpret_cast<PROT_GLOBAL f2*> (uniform_ptr (out + s + 1024 * m));
@@ -308,13 +409,33 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 	if (!piped) {
 		hist_write_slice (p, blockIdx.y, threadIdx.x);
 	}
+	if constexpr (MODE == MODE_SWEEP) {
+		if ((t0 & 63) == 0) {
+			p.surv_cnt[((int64_t)c * gridDim.x + blockIdx.x) * 4 + (t0 >> 6)] = sw_cnt;
+		}
+		if (p.sw_raw_slot >= 0) {
+			sw_raw = sw_wave_reduce (sw_raw, true);
+			if ((t0 & 63) == 0 && sw_raw > 0.f) { // (non-negative floats order as their bit patterns; look before the atomic)
+				unsigned* const slot = reinterpret_cast<unsigned*> (p.sw_peaks + (int64_t)c * kMaxSample + p.sw_raw_slot);
+				if (__float_as_uint (sw_raw) > __hip_atomic_load (slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+					atomicMax (slot, __float_as_uint (sw_raw));
+				}
+			}
+		}
+	}
 }
 
 template <int HS>
 static hipError_t launch_sv_m (const OlaParams& p, dim3 grid, hipStream_t s)
 {
 	const dim3 block (256);
-	if (p.hilbert_only) {
+	if (p.surv != nullptr) {
+		if constexpr (HS == 8 || HS == 12) {
+			hipLaunchKernelGGL ((olasave_kernel<HS, MODE_SWEEP>), grid, block, 0, s, p);
+		} else {
+			return hipErrorInvalidValue;
+		}
+	} else if (p.hilbert_only) {
 		hipLaunchKernelGGL ((olasave_kernel<HS, MODE_HILBERT>), grid, block, 0, s, p);
 	} else if (p.rot_s != nullptr) {
 		hipLaunchKernelGGL ((olasave_kernel<HS, MODE_RAMP>), grid, block, 0, s, p);
@@ -333,7 +454,8 @@ hipError_t launch_ola_save (const OlaParams& p, int hop_rows, int n_rho_rows, in
 	if (p.n_out <= 0) {
 		return hipSuccess;
 	}
-	const int64_t runs = (p.n_out + p.run_frames - 1) / p.run_frames;
+	const int64_t unit = p.run_stride > 0 ? p.run_stride : p.run_frames;
+	const int64_t runs = (p.n_out + unit - 1) / unit;
 	dim3          grid ((unsigned)runs, (unsigned)n_chn);
 	switch (hop_rows * 4 + n_rho_rows) {
 		case 8 * 4 + 1: return launch_sv_m<8> (p, grid, s);

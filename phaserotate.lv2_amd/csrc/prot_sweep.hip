@@ -44,7 +44,7 @@ static_assert (kRing >= 64 + kBatch && (kRing & (kRing - 1)) == 0, "ring too sma
 constexpr unsigned kCtr = 32;             // step counters per channel (a cache line each): workgroup b draws from counter b mod kCtr
 constexpr int kPause0 = 2, kPauseMax = 256; // steps fed untested after a step on which > 7/8 of the frames survived: first, cap
 
-template <int NBLK, bool PRUNE>
+template <int NBLK, bool PRUNE, bool COMPACT = false>
 __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const SweepParams p)
 {
 	__shared__ float stage_s[2 * 2 * kStage]; // [buffer][d | h][frame]: planar, so that a loaded dwordx4 is parked as it is
@@ -220,7 +220,8 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 	// A step's frames are loaded once per workgroup and parked in LDS, where all four waves test them; with every wave
 	// loading every frame itself (rounds 1-2) the loads in flight per CU were 4 x redundant.
 	__shared__ unsigned sh_seq[8];
-	const unsigned  n_total = p.t_end > p.t_begin ? (unsigned)((p.t_end - p.t_begin + kStage - 1) / kStage) : 0u;
+	const unsigned  n_total = COMPACT ? (unsigned)__builtin_amdgcn_readfirstlane ((int)p.n_steps[blockIdx.y])
+	                                  : p.t_end > p.t_begin ? (unsigned)((p.t_end - p.t_begin + kStage - 1) / kStage) : 0u;
 	// (kCtr counters per channel, each on a cache line of its own, each handing out every kCtr-th step to the workgroups
 	// with that blockIdx.x mod kCtr: ONE counter serves its atomics one at a time -- 675 K of them made cfg4 9 ms instead of 3)
 	// (a launch of fewer than kCtr workgroups per channel -- many channels, a small device -- uses as many counters as it has
@@ -259,7 +260,21 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 		return (base + kStage <= p.t_end) && (base - p.delay >= 0) && (base + kStage - p.delay <= p.n_x) &&
 		       (base + p.t_abs0 >= p.dry_from);
 	};
+	// COMPACT: entries [first, first + n) of the lists; a lane takes four consecutive (d, h) pairs twice (what lies beyond n -- the
+	// rest of a list's last step -- is allocated memory and is zeroed when it is parked)
+	const uint2* const dsc = COMPACT ? p.desc + (int64_t)blockIdx.y * p.desc_stride : nullptr; // (lists, tables: by the launch's own channel index)
 	auto request = [&] (unsigned s) { // frames of step s -> dv, hv (plain stream only; the edges are fetched when they are parked)
+		if (COMPACT) {
+			const uint2         ds = dsc[s];
+			const float4* const q  = reinterpret_cast<const float4*> (p.surv + (int64_t)ds.x + ld_half + 4 * lane);
+#pragma unroll
+			for (int i = 0; i < 2; ++i) {
+				const float4 a = q[128 * i], b = q[128 * i + 1]; // entries 256 i + 4 lane .. + 3: (d0 h0 d1 h1) (d2 h2 d3 h3)
+				dv[i]          = make_float4 (a.x, a.z, b.x, b.z);
+				hv[i]          = make_float4 (a.y, a.w, b.y, b.w);
+			}
+			return;
+		}
 		int64_t t0;
 		if (locate (s, t0)) {
 			typedef float f4u __attribute__ ((ext_vector_type (4), aligned (4)));
@@ -273,6 +288,24 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 		}
 	};
 	auto park = [&] (int buf, unsigned s) { // frames of step s: dv, hv -> (d, h) pairs of the stage
+		if (COMPACT) {
+			const int n = (int)dsc[s].y;
+#pragma unroll
+			for (int i = 0; i < 2; ++i) {
+				const int    e0 = ld_half + 256 * i + 4 * lane;
+				float* const q  = stage_s + buf * 2 * kStage + e0;
+				const float4 z  = make_float4 (0.f, 0.f, 0.f, 0.f);
+				float4       d = dv[i], h = hv[i];
+				if (e0 + 4 > n) { // (|0| never raises a maximum)
+					d = make_float4 (e0 < n ? d.x : 0.f, e0 + 1 < n ? d.y : 0.f, e0 + 2 < n ? d.z : 0.f, 0.f);
+					h = make_float4 (e0 < n ? h.x : 0.f, e0 + 1 < n ? h.y : 0.f, e0 + 2 < n ? h.z : 0.f, 0.f);
+				}
+				(void)z;
+				*reinterpret_cast<float4*> (q)          = d;
+				*reinterpret_cast<float4*> (q + kStage) = h;
+			}
+			return;
+		}
 		int64_t t0;
 		if (locate (s, t0)) {
 #pragma unroll
@@ -306,7 +339,7 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 			}
 		}
 	};
-	if (p.raw_slot >= 0 && p.raw_tail && blockIdx.x == 0) {
+	if (!COMPACT && p.raw_slot >= 0 && p.raw_tail && blockIdx.x == 0) {
 		// the call's last `delay` input frames: the loaders reach them only as the next chunk's history (x[t - delay], t < t_end),
 		// the reference's calc_peak has them in this block -- folded here so that peaks[c][0] is complete when the call returns
 		for (int64_t i = p.n_x - p.delay + tid; i < p.n_x; i += 256) {
@@ -592,15 +625,20 @@ hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s)
 	const int nb   = (p.n_angles + 31) / 32;
 	const int nblk = nb >= 3 ? (nb + 3) / 4 : 1;
 	typedef void (*kern_t) (SweepParams);
-	static const kern_t kern[2][4] = {
+	static const kern_t kern[3][4] = {
 		{ nullptr, sweep_kernel<1, false>, sweep_kernel<2, false>, sweep_kernel<3, false> },
 		{ nullptr, sweep_kernel<1, true>, sweep_kernel<2, true>, sweep_kernel<3, true> },
+		{ nullptr, sweep_kernel<1, true, true>, sweep_kernel<2, true, true>, sweep_kernel<3, true, true> },
 	};
-	const int    pr = p.prune ? 1 : 0;
+	const bool compact = p.surv != nullptr;
+	if (compact && (!p.prune || p.desc == nullptr || p.n_steps == nullptr)) {
+		return hipErrorInvalidValue;
+	}
+	const int    pr = compact ? 2 : p.prune ? 1 : 0;
 	const kern_t fn = kern[pr][nblk];
 	// persistent grid: exactly the workgroups the chip keeps resident, so the grid-stride loop ends without a ragged
 	// last round
-	static int slots[2][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+	static int slots[3][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
 	if (slots[pr][nblk] == 0) {
 		int dev = 0, cus = 256, occ = 2;
 		(void)hipGetDevice (&dev);
@@ -611,6 +649,7 @@ hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s)
 		slots[pr][nblk] = cus * occ;
 	}
 	const int64_t span  = kStage;
+	// (COMPACT: the number of steps is on the device; t_end - t_begin is the host's upper bound of the entries -- every frame)
 	const int64_t tiles = (p.t_end - p.t_begin + span - 1) / span;
 	if (p.part == nullptr) {
 		return hipErrorInvalidValue;
@@ -641,6 +680,52 @@ hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s)
 		}
 	}
 	return hipSuccess;
+}
+
+// The step table of a COMPACT sweep (one workgroup per channel): list l has cnt[l] entries from entry l * cap on; its steps of
+// up to 1024 entries follow those of the lists before it.
+__global__ __launch_bounds__ (256) void sweep_plan_kernel (const unsigned* __restrict__ cnt, int n_lists, int64_t cap, uint2* __restrict__ desc,
+                                                             int64_t desc_stride, unsigned* __restrict__ n_steps, unsigned long long* total)
+{
+	__shared__ unsigned part[256];
+	const int       c   = blockIdx.x, t = threadIdx.x;
+	const unsigned* cn  = cnt + (int64_t)c * n_lists;
+	uint2*          dsc = desc + (int64_t)c * desc_stride;
+	const int       per = (n_lists + 255) / 256, l0 = t * per, l1 = l0 + per < n_lists ? l0 + per : n_lists;
+	unsigned        mine = 0;
+	unsigned long long ents = 0;
+	for (int l = l0; l < l1; ++l) {
+		mine += (cn[l] + kStage - 1) / kStage;
+		ents += cn[l];
+	}
+	if (total != nullptr && ents != 0) {
+		atomicAdd (total, ents);
+	}
+	part[t] = mine;
+	__syncthreads ();
+	for (int d = 1; d < 256; d <<= 1) { // inclusive scan
+		const unsigned v = t >= d ? part[t - d] : 0u;
+		__syncthreads ();
+		part[t] += v;
+		__syncthreads ();
+	}
+	unsigned at = part[t] - mine;
+	for (int l = l0; l < l1; ++l) {
+		const unsigned n = cn[l];
+		for (unsigned i = 0; i * kStage < n; ++i) {
+			dsc[at++] = make_uint2 ((unsigned)(((int64_t)c * n_lists + l) * cap + (int64_t)i * kStage), n - i * kStage < (unsigned)kStage ? n - i * kStage : (unsigned)kStage);
+		}
+	}
+	if (t == 255) {
+		n_steps[c] = part[255];
+	}
+}
+
+hipError_t launch_sweep_plan (const unsigned* cnt, int n_lists, int64_t cap, uint2* desc, int64_t desc_stride, unsigned* n_steps, int n_chn,
+                              unsigned long long* total, hipStream_t s)
+{
+	hipLaunchKernelGGL (sweep_plan_kernel, dim3 ((unsigned)n_chn), dim3 (256), 0, s, cnt, n_lists, cap, desc, desc_stride, n_steps, total);
+	return hipGetLastError ();
 }
 
 // floats of scratch a sweep launch may need on this device (every resident-workgroup slot x 4 waves x 360 angles)

@@ -915,13 +915,14 @@ def emit(path, opts=()):
         out.append('\t""')
         out.append("")
     # MODE_SWEEP (run kind only; edge blocks take the Hilbert core and are tested by the C++ code): operands %0 survivor cursor
-    # (in / out), %1 running max |x| (in / out), %2 in, %3 blocks, %4 LDS byte offset, %5 constants table, %6 bound, %7 gain, %8 thread id
+    # (out), %1 running max |x| (out), %2 in, %3 blocks, %4 LDS byte offset, %5 constants table, %6 bound, %7 gain, %8 thread id, %9 and
+    # %10 the cursor and the running maximum on entry
     for HS in (8, 12):
         g = Gen(HS, MODE_SWEEP, 1, opts, "run")
         P = g.build()
-        head = ["s_mov_b64 %r, %%2" % S_IN, "s_mov_b64 %r, %%0" % S_OUT, "s_mov_b32 %r, %%3" % S_NBLK, "s_mov_b32 %r, %%4" % S_LDS,
+        head = ["s_mov_b64 %r, %%2" % S_IN, "s_mov_b64 %r, %%9" % S_OUT, "s_mov_b32 %r, %%3" % S_NBLK, "s_mov_b32 %r, %%4" % S_LDS,
                 "s_mov_b64 %r, %%5" % S_SV, "s_mov_b32 %r, %%6" % S_ROT.lo, "s_mov_b32 %r, %%7" % S_ROT.hi, "v_mov_b32 %r, %%8" % g.TMP[0].lo,
-                "v_mov_b32 %r, %%1" % g.V_RAW, "s_waitcnt vmcnt(0) lgkmcnt(0)"]
+                "v_mov_b32 %r, %%10" % g.V_RAW, "s_waitcnt vmcnt(0) lgkmcnt(0)"]
         for n, (lo, hi) in sorted(g.constants().items()):
             head.append("s_mov_b32 s%d, %r" % (n, Lit(float(lo))))
             head.append("s_mov_b32 s%d, %r" % (n + 1, Lit(float(hi))))
