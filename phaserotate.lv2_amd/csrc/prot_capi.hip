@@ -1662,6 +1662,10 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		return PROT_EINVAL;
 	}
 	HIP_TRY (hipSetDevice (e->device));
+	// (a long call in two pieces -- the first eighth listed against the seeding pass's bound, the rest against the table it leaves --
+	// was measured and changes nothing: 1.77-1.80 / 4.12 ms in one piece, 1.76-2.09 / 4.07-4.32 ms in two, harmonic / noise, cfg4)
+	const bool fusable = e->use_save && (e->hopseg == 16 || e->hopseg == 24) && !(e->sv_flags & 1) && !g_test_opt[PROT_TEST_SWEEP_UNPRUNED].load () &&
+	                     !g_test_opt[PROT_TEST_SWEEP_UNFUSED].load ();
 	hipStream_t s   = pick_stream (e, stream);
 	const int   c0  = chn < 0 ? 0 : chn;                       // cli/phase-rotate.cc:434-435
 	const int   nc  = chn < 0 ? (int)e->info.n_chn : 1;
@@ -1711,8 +1715,7 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 	// pairs -- a few percent of the frames -- is written), the matrix-core kernel evaluates the lists.  For the engines whose
 	// Hilbert pass is the overlap-save kernel (blksiz 2048, 4096), pruned sweeps, calls long enough to carry five more launches;
 	// the tables are bit-identical to the separate passes' (same blocks, same arithmetic per frame, max is order-free).
-	const bool fused = e->use_save && (e->hopseg == 16 || e->hopseg == 24) && n_ang > 0 && !unpruned && !(e->sv_flags & 1) &&
-	                   n_out >= ((uint64_t)1 << 20) && !g_test_opt[PROT_TEST_SWEEP_UNFUSED].load ();
+	const bool fused = fusable && n_ang > 0 && n_out >= ((uint64_t)1 << 20);
 	if (fused) {
 		const float* hist_old = e->d_hist[e->hist_cur].p; (void)hist_old;
 		if (e->pos == 0) {
@@ -1734,7 +1737,10 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 			fs.raw_slot      = raw0 ? 0 : -1;
 			fs.raw_tail      = (raw0 && !end && pass == 1) ? 1 : 0;
 			fs.sample        = pass == 0;
-			fs.stride_blocks = 64;
+			fs.stride_blocks = 256; // (64 ... 512: the same times to the run-to-run spread; the bound hardly depends on it)
+			if (const char* o = tuning_env ("PROT_FUSE_STRIDE")) {
+				fs.stride_blocks = std::max (2, atoi (o));
+			}
 			fs.t_begin       = beg ? P / 2 : 0; // :418-419
 			fs.dry_from      = beg ? P : 0;     // (local frames: the first block's dry term is the silent previous block, Q1)
 			if (pass == 0 && n_out < (uint64_t)fs.stride_blocks * e->info.run_align * 8) {

@@ -30,7 +30,7 @@ for name, x in sigs.items():
         e = pkg.Engine(pkg.KIND_CLI, P, nc)
         pk = torch.zeros(nc * 360, device=dev)
         e.sweep_dev(x.data_ptr(), n, n, 0, 360, 1, -1, pk.data_ptr(), pkg.F_STREAM_START | pkg.F_STREAM_END, st)   # (warm: buffers allocated)
-        e.reset(); pk.zero_(); torch.cuda.synchronize()
+        torch.cuda.synchronize(); e.reset(); pk.zero_(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         e.sweep_dev(x.data_ptr(), n, n, 0, 360, 1, -1, pk.data_ptr(), pkg.F_STREAM_START | pkg.F_STREAM_END, st)
         torch.cuda.synchronize()
