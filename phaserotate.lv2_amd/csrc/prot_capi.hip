@@ -430,6 +430,8 @@ struct prot_engine {
 	uint64_t         fused_frames = 0;          // channel-frames the fused pass has tested since the last reset
 	DevBuf<unsigned long long> d_fused_surv;    // ... and how many of them it kept (device counter)
 	bool             sweep_seeded = false;      // the table holds a bound for the angle list of angles_last
+	int              last_n_lists = 0;          // geometry of the last fused pass (prot_internal_fused_lists)
+	int64_t          last_cap     = 0;
 	PinBuf<float>  h_io;
 	// small host->device parameter copies (rotation pairs, angle lists) are staged through a ring of
 	// pinned slots owned by the engine, each guarded by an event: the caller's array may die as soon
@@ -656,6 +658,7 @@ struct FusedSweep {
 	bool       sample;     // the seeding pass: every `stride_blocks`-th block, no bound, nothing of the engine's state moves
 	int        stride_blocks;
 	int64_t    t_begin, dry_from;
+	bool       plan_only;  // compute the geometry (n_lists, cap) and return without launching
 	// out: the geometry of the lists
 	int        n_lists;
 	int64_t    cap;
@@ -767,10 +770,15 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 				}
 				fs->n_lists = (int)runs * 4;
 				fs->cap     = ((longest / 4 + 3) & ~(int64_t)3) + 4; // a wave's share of its workgroup's longest run
-				int rc2;
-				if ((rc2 = e->d_surv.ensure ((size_t)fs->n_lists * fs->cap * n_chn + 2048)) || (rc2 = e->d_surv_cnt.ensure ((size_t)fs->n_lists * n_chn)) ||
-				    (rc2 = e->d_desc.ensure (((size_t)fs->n_lists + (size_t)(n_out / 1024) + 8) * n_chn)) || (rc2 = e->d_nsteps.ensure ((size_t)n_chn))) {
-					return rc2;
+				if (fs->plan_only) {
+					return PROT_OK;
+				}
+				// (the buffers were sized by the caller for BOTH passes before the first launch: growing one between the passes
+				// would free memory a kernel of the pass before may still be reading)
+				if (e->d_surv.cap < (size_t)fs->n_lists * fs->cap * n_chn + 2048 || e->d_surv_cnt.cap < 2 * (size_t)fs->n_lists * n_chn ||
+				    e->d_desc.cap < ((size_t)fs->n_lists + (size_t)(n_out / 1024) + 8) * n_chn || e->d_nsteps.cap < (size_t)n_chn) {
+					snprintf (g_err, sizeof (g_err), "fused sweep: list buffers not sized");
+					return PROT_EINVAL;
 				}
 				p.surv        = e->d_surv.p;
 				p.surv_cap    = fs->cap;
@@ -1729,8 +1737,8 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		if (first_fused) {
 			HIP_TRY (hipMemsetAsync (e->d_fused_surv.p, 0, sizeof (unsigned long long), s));
 		}
-		for (int pass = e->sweep_seeded ? 1 : 0; pass < 2; ++pass) {
-			FusedSweep fs {};
+		const bool sample_pass = !e->sweep_seeded && n_out >= (uint64_t)256 * e->info.run_align * 8;
+		auto fill = [&] (FusedSweep& fs, int pass) {
 			fs.peaks         = pk;
 			fs.angles        = e->d_angles.p;
 			fs.n_angles      = n_ang;
@@ -1743,14 +1751,37 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 			}
 			fs.t_begin       = beg ? P / 2 : 0; // :418-419
 			fs.dry_from      = beg ? P : 0;     // (local frames: the first block's dry term is the silent previous block, Q1)
-			if (pass == 0 && n_out < (uint64_t)fs.stride_blocks * e->info.run_align * 8) {
-				continue; // too short for a sample worth its launches: the main pass starts from the table as it is
+		};
+		{ // size the list buffers for both passes before anything is launched
+			size_t need_surv = 0, need_cnt = 0, need_desc = 0;
+			for (int pass = sample_pass ? 0 : 1; pass < 2; ++pass) {
+				FusedSweep fs {};
+				fill (fs, pass);
+				fs.plan_only = true;
+				rc = ola_launch (e, d_in, in_stride, n_frames, const_cast<float*> (d_in), in_stride, n_out, nullptr, nullptr, true, false, c0, nc, s, false, nullptr,
+				                 nullptr, &fs);
+				if (rc) {
+					return rc;
+				}
+				need_surv = std::max (need_surv, (size_t)fs.n_lists * fs.cap * nc + 2048);
+				need_cnt  = std::max (need_cnt, 2 * (size_t)fs.n_lists * nc);
+				need_desc = std::max (need_desc, ((size_t)fs.n_lists + (size_t)(n_out / 1024) + 8) * nc);
 			}
+			if ((rc2 = e->d_surv.ensure (need_surv)) || (rc2 = e->d_surv_cnt.ensure (need_cnt)) || (rc2 = e->d_desc.ensure (need_desc)) ||
+			    (rc2 = e->d_nsteps.ensure ((size_t)e->info.n_chn))) {
+				return rc2;
+			}
+		}
+		for (int pass = sample_pass ? 0 : 1; pass < 2; ++pass) {
+			FusedSweep fs {};
+			fill (fs, pass);
 			rc = ola_launch (e, d_in, in_stride, n_frames, const_cast<float*> (d_in), in_stride, n_out, nullptr, nullptr, true, false, c0, nc, s,
 			                 /*advance_hist*/ pass == 1, nullptr, nullptr, &fs);
 			if (rc) {
 				return rc;
 			}
+			e->last_n_lists = fs.n_lists;
+			e->last_cap     = fs.cap;
 			const int64_t desc_stride = (int64_t)fs.n_lists + (int64_t)(n_out / 1024) + 8;
 			hipError_t    err = prot::launch_sweep_plan (e->d_surv_cnt.p, fs.n_lists, fs.cap, e->d_desc.p, desc_stride, e->d_nsteps.p, nc,
 			                                             pass == 1 ? e->d_fused_surv.p : nullptr, s);
@@ -2609,6 +2640,18 @@ int prot_cli_apply_file (prot_engine* e, const float* data, uint64_t n_frames, c
 // TEST HOOK, not part of include/prot_hip.h (declared in csrc/prot_internal.h): the library that Rccl::load() opens in
 // place of the system's RCCL -- an explicit call of the test process, never the environment (the library is also
 // loaded into LV2 hosts).  Only before the first all-reduce; NULL / "" restores the default.
+int prot_internal_fused_lists (prot_engine* e, unsigned long long out[4])
+{
+	if (!e || !out) {
+		return PROT_EINVAL;
+	}
+	out[0] = (unsigned long long)(uintptr_t)e->d_surv.p;
+	out[1] = (unsigned long long)(uintptr_t)e->d_surv_cnt.p;
+	out[2] = (unsigned long long)e->last_n_lists;
+	out[3] = (unsigned long long)e->last_cap;
+	return PROT_OK;
+}
+
 int prot_internal_set_test_option (int option, int value)
 {
 	if (option < 0 || option >= PROT_TEST_OPTIONS) {

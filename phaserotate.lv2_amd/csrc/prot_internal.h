@@ -17,6 +17,10 @@ enum {
 	PROT_TEST_OPTIONS        = 5
 };
 int prot_internal_set_test_option (int option, int value); // 0 or PROT_EINVAL
+// the lists the last fused sweep pass of the engine left (device pointers, valid until the next sweep): float2 entries (dry, hilbert),
+// list l of channel c at entry (c * n_lists + l) * cap, its length in cnt[c * n_lists + l]; out = { surv, cnt, n_lists, cap }
+struct prot_engine;
+int prot_internal_fused_lists (struct prot_engine* e, unsigned long long out[4]);
 #ifdef __cplusplus
 }
 #endif

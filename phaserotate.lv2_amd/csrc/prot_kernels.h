@@ -68,7 +68,7 @@ struct OlaParamsT {
 	// through goes to sw_peaks[c][sw_raw_slot] (>= 0; sw_raw_tail: the call's last dry_delay input frames too).
 	float2*       surv;
 	int64_t       surv_cap;
-	uint32_t*     surv_cnt;
+	uint32_t*     surv_cnt;    // [2][n_chn][gridDim.x][4]: the list lengths, and behind them the bound every wave parks for itself
 	float*        sw_peaks;
 	const int*    sw_angles;
 	int32_t       sw_n_angles;

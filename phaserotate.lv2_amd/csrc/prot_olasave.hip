@@ -113,8 +113,16 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 	// grow: a lower bound of every final peak), squared, less prot_sweep.hip's margin; every wave appends to a list of its own
 	__shared__ float sw_lo_s[4];
 	float            sw_raw = 0.f;
-	// (the bound is re-read from LDS where it is used: a register copy would live across the generated code)
-	auto sw_thr = [&] () -> float { return __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (((volatile float*)sw_lo_s)[0]))); };
+	// (the bound is parked in global memory -- behind the list lengths, one copy per wave -- and re-read where it is used: a
+	// register copy would live across the generated code.  An LDS word behind the exchange area was tried first and read back
+	// other values on the hardware from the second staged block on, for a reason that was not found: tools/dbgthr.py)
+	auto sw_thr_slot = [&] () -> float* {
+		const int w = __builtin_amdgcn_readfirstlane (threadIdx.x >> 6);
+		return reinterpret_cast<float*> (p.surv_cnt) + (int64_t)gridDim.y * gridDim.x * 4 + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + w;
+	};
+	auto sw_thr = [&] () -> float {
+		return __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (__hip_atomic_load (sw_thr_slot (), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))));
+	};
 	unsigned         sw_cnt  = 0u; // entries this wave has appended (wave-uniform; the list's address is recomputed where it is needed:
 	                               // nothing but this count, the bound and the running maximum lives across the generated code)
 	// (wave reductions with the lane id made opaque at each use: with __shfl_xor the compiler keeps the six permutation indices of
@@ -148,10 +156,10 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 		__syncthreads ();
 		lo = fminf (fminf (sw_lo_s[0], sw_lo_s[1]), fminf (sw_lo_s[2], sw_lo_s[3]));
 		__syncthreads ();
-		if (t0 == 0) {
-			sw_lo_s[0] = lo * lo * 0.9999f;
+		if ((t0 & 63) == 0) {
+			__hip_atomic_store (sw_thr_slot (), lo * lo * 0.9999f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
-		__syncthreads ();
+		asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
 	}
 	if (piped) {
 		// my slice of the next history: device-scope (write-through) stores, so that publishing it needs no release FENCE --

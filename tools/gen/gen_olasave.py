@@ -21,7 +21,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "model"))
-from isa import Prog, Emu, V, VP, S, SP, Lit  # noqa: E402
+from isa import Prog, Emu, V, VP, S, SP, Lit, VCC  # noqa: E402
 
 KL1, KG = 272, 17                 # LDS exchange strides (prot_dev.h)
 LDS_TWM, LDS_TWF = 34816, 36864   # byte offsets of the W256 tables behind the exchange area
@@ -588,22 +588,30 @@ class Gen:
         S_ROT.lo: |ca d + sa h| <= sqrt(d^2 + h^2) for every angle, so the other frames cannot raise any maximum that has reached the
         bound (prot_sweep.hip evaluates the list).  max |d| rides along (the raw peak)."""
         P = self.P
-        r2, pr, idx = self.TMP[0], self.TMP[1], self.TMP[2].lo
+        r2, prs, idxs = self.TMP[0], (self.TMP[1], self.TMP[3]), (self.TMP[2].lo, self.TMP[2].hi)
+        masks, cnts = (VCC, S_A0), (S_T[0], S_T[1])   # (no store of this mode goes through the address temporary)
         P.pk("mul", r2, [d, d])
         P.pk("fma", r2, [h, h, r2])
+        # the two compares first, the lane masks in SGPR pairs, and everything that reads a mask at least five instructions behind
+        # the compare that wrote it (isa.py: lane-mask hazard)
+        for j, half in enumerate(("lo", "hi")):
+            P.v_cmp_lt_f32(masks[j], S_ROT.lo, getattr(r2, half))
         P.v_max3_abs(self.V_RAW, d.lo, d.hi)
-        for half in ("lo", "hi"):
-            P.v_cmp_lt_f32(S_ROT.lo, getattr(r2, half))
-            P.v_mov(pr.lo, getattr(d, half))
-            P.v_mov(pr.hi, getattr(h, half))
-            P.v_mbcnt(idx)
-            P.s_bcnt1_vcc(S_T[0])
-            P.v_lshl(idx, Lit(3), idx)
-            P.exec_from_vcc()
-            P.global_store_dwordx2(idx, pr, S_OUT, 0)
+        for j, half in enumerate(("lo", "hi")):
+            P.v_mov(prs[j].lo, getattr(d, half))
+            P.v_mov(prs[j].hi, getattr(h, half))
+        P.s_nop(1)
+        for j in range(2):
+            P.v_mbcnt(idxs[j], masks[j])
+            P.v_lshl(idxs[j], Lit(3), idxs[j])
+        for j in range(2):
+            P.s_bcnt1(cnts[j], masks[j])
+            P.s_lshl_b32(cnts[j], cnts[j], Lit(3))
+        for j in range(2):
+            P.exec_from(masks[j])
+            P.global_store_dwordx2(idxs[j], prs[j], S_OUT, 0)
             P.exec_all()
-            P.s_lshl_b32(S_T[0], S_T[0], Lit(3))
-            P.s_add_u32(S_OUT.lo, S_OUT.lo, S_T[0])
+            P.s_add_u32(S_OUT.lo, S_OUT.lo, cnts[j])
             P.s_addc_u32(S_OUT.hi, S_OUT.hi, Lit(0))
 
     def epilogue(self, u):

@@ -44,6 +44,21 @@ class SP:
     def hi(self): return S(self.n + 1)
 
 
+class _VccHalf:
+    def __init__(self, name, n): self.name, self.n = name, n
+    def __repr__(self): return self.name
+
+
+class VccPair:  # VCC as a lane-mask register pair (s106:107 on gfx9)
+    n = 106
+    def __repr__(self): return "vcc"
+    lo = _VccHalf("vcc_lo", 106)
+    hi = _VccHalf("vcc_hi", 107)
+
+
+VCC = VccPair()
+
+
 class Lit:  # 32-bit literal / inline constant (float or int)
     def __init__(self, v): self.v = v
     def __repr__(self):
@@ -163,16 +178,17 @@ class Prog:
     def v_mul_u24(self, d, a, b): return self.add(Ins("v_mul_u24", "v_mul_u32_u24 %r, %r, %r" % (d, a, b), d=d, a=a, b=b))
     def v_cmp_eq_u32(self, a, b): return self.add(Ins("v_cmp_eq", "v_cmp_eq_u32 vcc, %r, %r" % (a, b), a=a, b=b))      # (a: constant or SGPR, b: VGPR)
     def v_cmp_lt_u32(self, a, b): return self.add(Ins("v_cmp_lt", "v_cmp_lt_u32 vcc, %r, %r" % (a, b), a=a, b=b))      # vcc = a < b
-    def v_cmp_lt_f32(self, a, b): return self.add(Ins("v_cmp_lt_f32", "v_cmp_lt_f32 vcc, %r, %r" % (a, b), a=a, b=b))    # vcc = a < b (floats)
-    def v_mbcnt(self, d):
-        """d = number of set VCC bits below this lane (both halves of the wave)"""
-        self.add(Ins("v_mbcnt_lo", "v_mbcnt_lo_u32_b32 %r, vcc_lo, 0" % d, d=d))
-        return self.add(Ins("v_mbcnt_hi", "v_mbcnt_hi_u32_b32 %r, vcc_hi, %r" % (d, d), d=d, a=d))
+    def v_cmp_lt_f32(self, m, a, b):   # lane mask in the SGPR pair m = a < b (floats; VOP3 form: any SGPR pair, not just VCC)
+        return self.add(Ins("v_cmp_lt_f32", "v_cmp_lt_f32_e64 %r, %r, %r" % (m, a, b), m=m, a=a, b=b))
+    def v_mbcnt(self, d, m):
+        """d = number of set bits of the lane mask m (an SGPR pair) below this lane"""
+        self.add(Ins("v_mbcnt_lo", "v_mbcnt_lo_u32_b32 %r, %r, 0" % (d, m.lo), d=d, m=m))
+        return self.add(Ins("v_mbcnt_hi", "v_mbcnt_hi_u32_b32 %r, %r, %r" % (d, m.hi, d), d=d, a=d, m=m))
     def v_max3_abs(self, d, a, b):   # d = max(|a|, |b|, d)
         return self.add(Ins("v_max3_abs", "v_max3_f32 %r, |%r|, |%r|, %r" % (d, a, b, d), d=d, a=a, b=b))
-    def s_bcnt1_vcc(self, d): return self.add(Ins("s_bcnt1_vcc", "s_bcnt1_i32_b64 %r, vcc" % d, d=d))
+    def s_bcnt1(self, d, m): return self.add(Ins("s_bcnt1", "s_bcnt1_i32_b64 %r, %r" % (d, m), d=d, m=m))
     def s_lshl_b32(self, d, a, sh): return self.add(Ins("s_lshl", "s_lshl_b32 %r, %r, %r" % (d, a, sh), d=d, a=a, sh=sh))
-    def exec_from_vcc(self): return self.add(Ins("exec_vcc", "s_mov_b64 exec, vcc"))
+    def exec_from(self, m): return self.add(Ins("exec_from", "s_mov_b64 exec, %r" % m, m=m))
     def exec_all(self): return self.add(Ins("exec_all", "s_mov_b64 exec, -1"))
     def v_cndmask(self, d, a, b): return self.add(Ins("v_cndmask", "v_cndmask_b32 %r, %r, %r, vcc" % (d, a, b), d=d, a=a, b=b))  # d = vcc ? b : a
 
@@ -285,6 +301,8 @@ class _Wave:
         self.scc = 0
         self.vcc = np.zeros(64, bool)
         self.exec = np.ones(64, bool)
+        self.masks = {}                     # lane masks kept in SGPR pairs (v_cmp ... s[n:n+1]): first SGPR number -> bool[64]
+        self.mask_wr = {}                   # ... and how many instructions ago a VALU wrote them
         self.pc = 0
         self.vm_q, self.lgkm_q = [], []     # in-flight ops: (kind, regs)
         self.recent = []                    # VGPRs written by the last two VALU instructions (DPP hazard: 2 wait states)
@@ -442,6 +460,12 @@ class Emu:
                 if W_.sgpr_wr < 3 and any(isinstance(x, (S, SP)) for x in srcs):
                     raise RuntimeError("SGPR hazard: %s reads an SGPR %d instruction(s) after a VALU wrote one" % (i.text, W_.sgpr_wr + 1))
             W_.sgpr_wr = 0 if op in ("v_readlane", "v_readfirstlane") else W_.sgpr_wr + 1
+            for k_ in list(W_.mask_wr):
+                W_.mask_wr[k_] += 1
+            if op in ("v_mbcnt_lo", "v_mbcnt_hi", "s_bcnt1", "exec_from") and W_.mask_wr.get(i.m.n, 99) < 5 + (op == "v_mbcnt_hi"):
+                # (round 4, found on the hardware as one frame of a survivor list lost now and then: the same family as the
+                # v_readfirstlane hazard below -- an SGPR written by a VALU instruction read back too early is stale)
+                raise RuntimeError("lane-mask hazard: %s reads a mask %d instruction(s) after the compare that wrote it" % (i.text, W_.mask_wr[i.m.n]))
             if op in ("v_readlane", "v_readfirstlane"):
                 # measured on gfx950 (round 4: waves 4-6 of a workgroup read a stale register, wave 7 the new value): a lane read
                 # directly behind the VALU write of its source sees the old contents -- same two wait states as DPP
@@ -509,28 +533,31 @@ class Emu:
                 W_.vcc = (a == b) if op == "v_cmp_eq" else (a < b)
             elif op == "v_cmp_lt_f32":
                 touch(regs_of(i.a) + regs_of(i.b), [], i.text)
-                W_.vcc = rd32(i.a).view(np.float32) < rd32(i.b).view(np.float32)
+                W_.masks[i.m.n] = rd32(i.a).view(np.float32) < rd32(i.b).view(np.float32)
+                W_.mask_wr[i.m.n] = 0
             elif op == "v_mbcnt_lo":
                 touch([], regs_of(i.d), i.text)
-                c = np.concatenate([[0], np.cumsum(W_.vcc[:32])[:-1]]).astype(np.uint32)
-                v[i.d.n] = np.concatenate([c, np.full(32, int(W_.vcc[:32].sum()), np.uint32)])
+                mk = W_.masks[i.m.n]
+                c = np.concatenate([[0], np.cumsum(mk[:32])[:-1]]).astype(np.uint32)
+                v[i.d.n] = np.concatenate([c, np.full(32, int(mk[:32].sum()), np.uint32)])
             elif op == "v_mbcnt_hi":
                 touch(regs_of(i.a), regs_of(i.d), i.text)
-                c = np.concatenate([[0], np.cumsum(W_.vcc[32:])[:-1]]).astype(np.uint32)
+                mk = W_.masks[i.m.n]
+                c = np.concatenate([[0], np.cumsum(mk[32:])[:-1]]).astype(np.uint32)
                 v[i.d.n] = rd32(i.a) + np.concatenate([np.zeros(32, np.uint32), c])
             elif op == "v_max3_abs":
                 touch(regs_of(i.a) + regs_of(i.b) + regs_of(i.d), regs_of(i.d), i.text)
                 m = np.maximum(np.maximum(np.abs(rd32(i.a).view(np.float32)), np.abs(rd32(i.b).view(np.float32))), rd32(i.d).view(np.float32))
                 v[i.d.n] = m.astype(np.float32).view(np.uint32)
-            elif op == "s_bcnt1_vcc":
-                s[i.d.n] = int(W_.vcc.sum())
-                W_.scc = int(W_.vcc.any())
+            elif op == "s_bcnt1":
+                s[i.d.n] = int(W_.masks[i.m.n].sum())
+                W_.scc = int(W_.masks[i.m.n].any())
             elif op == "s_lshl":
                 r = (srd(i.a) << (srd(i.sh) & 31)) & 0xffffffff
                 s[i.d.n] = r
                 W_.scc = int(r != 0)
-            elif op == "exec_vcc":
-                W_.exec = W_.vcc.copy()
+            elif op == "exec_from":
+                W_.exec = W_.masks[i.m.n].copy()
             elif op == "exec_all":
                 W_.exec = np.ones(64, bool)
             elif op == "v_cndmask":
