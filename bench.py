@@ -649,6 +649,7 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             per_rank = [float(v) for v in t.cpu()]
         exs = eng.sweep_stats_ex() if hasattr(eng, "sweep_stats_ex") else {}
+        fus = eng.sweep_stats_fused() if hasattr(eng, "sweep_stats_fused") else {"tested": 0, "listed": 0}
         n_ang = 359  # (angle 0 is the plain abs-max of the input, Q4)
         res[kind] = {"ms": wall * 1e3, "value": total * n_chn / wall, "unpruned_ms": wall_np * 1e3,
                      "evaluated_fraction": ev / max(seen, 1), "table_identical_unpruned": same,
@@ -658,6 +659,12 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
                      # core: fraction of the 157 TFLOP/s fp32 matrix peak the unpruned pass reaches, and the HBM fraction of
                      # the pruned pass at its algorithmic 4 B per channel-frame
                      "hbm_frac_algorithmic": total * n_chn * 4.0 / wall / 1e9 / HBM_PEAK_GBS,
+                     # the FUSED route (blksiz 2048 / 4096, round 4): the Hilbert pass tests every frame against the call's bound and
+                     # writes only the listed (dry, hilbert) pairs -- bytes per channel-frame by construction: 4 read + 16 x listed
+                     # fraction (8 written, 8 read back by the matrix-core kernel); the separate passes move 16 (blksiz 16384: 28)
+                     "fused": bool(fus["tested"]),
+                     "listed_fraction": (fus["listed"] / fus["tested"]) if fus["tested"] else None,
+                     "bytes_per_channel_frame_by_construction": (4.0 + 16.0 * fus["listed"] / fus["tested"]) if fus["tested"] else (28.0 if P >= 16384 else 16.0),
                      "unpruned_frac_of_fp32_matrix_peak": total * n_chn * n_ang * 4.0 / wall_np / 157.3e12,
                      "per_rank_device_ms": per_rank,
                      "min_angle_index": [int(pk[c].argmin()) for c in range(n_chn)]}

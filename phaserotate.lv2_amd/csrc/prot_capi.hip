@@ -446,6 +446,8 @@ struct prot_engine {
 	bool           pipeline   = false;
 	hipStream_t    pipe_stream[kPipe] = {};
 	hipEvent_t     pipe_ev[kPipe + 1] = {};
+	hipStream_t    last_stream = nullptr; // the stream of the last call that launched work (prot_engine_reset waits for it)
+	hipEvent_t     ev_reset    = nullptr;
 	DevBuf<uint32_t> d_pipe;      // [0..7] generation g's history is complete when slot g & 7 holds g; [8..11] slice counters;
 	                              // [12] status: the generation a kernel gave up waiting for (0: none) -- checked by prot_engine_sync
 	bool           pipe_used  = false; // pipelined launches since the status word was last looked at
@@ -919,6 +921,7 @@ hipStream_t pick_stream (prot_engine* e, void* stream)
 {
 	hipStream_t s = stream ? (hipStream_t)stream : e->stream;
 	(void)join_pipe (e, s);
+	e->last_stream = s;
 	return s;
 }
 
@@ -1160,6 +1163,7 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 		return nullptr;
 	};
 
+	(void)hipEventCreateWithFlags (&e->ev_reset, hipEventDisableTiming);
 	if (hipStreamCreateWithFlags (&e->stream, hipStreamNonBlocking) != hipSuccess) {
 		return fail (PROT_EHIP);
 	}
@@ -1388,6 +1392,9 @@ void prot_engine_destroy (prot_engine* e)
 	if (e->stream) {
 		(void)hipStreamDestroy (e->stream);
 	}
+	if (e->ev_reset) {
+		(void)hipEventDestroy (e->ev_reset);
+	}
 	if (e->counted) {
 		std::lock_guard<std::mutex> lk (g_rccl_lock);
 		if (--g_engines == 0) {
@@ -1404,6 +1411,12 @@ int prot_engine_reset (prot_engine* e)
 	}
 	HIP_TRY (hipSetDevice (e->device));
 	(void)join_pipe (e, e->stream);
+	if (e->last_stream != nullptr && e->last_stream != e->stream && e->ev_reset != nullptr) {
+		// the engine's work on the caller's stream of its last call may still be running (its kernels read the history and
+		// write the counters this reset zeroes): the reset is ordered behind it
+		HIP_TRY (hipEventRecord (e->ev_reset, e->last_stream));
+		HIP_TRY (hipStreamWaitEvent (e->stream, e->ev_reset, 0));
+	}
 	int rc = zero_state (e);
 	if (rc) {
 		return rc;

@@ -1,0 +1,1292 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the
+same seeded inputs.  Tolerances: samples 2e-6 abs at
+|y| <= 1, ramp regions 1e-5, peak table 1e-3 dB, min-peak angle index exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from conftest import harmonic_stack, xorshift_uniform
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-6
+TOL_RAMP = 1e-5
+TOL_DB = 1e-3
+
+
+def db(x):
+    return 20.0 * np.log10(np.maximum(np.asarray(x, np.float64), 1e-30))
+
+
+# ------------------------------------------------------------------ FIR ---
+@pytest.mark.parametrize("kind,param,n", [(0, 2048, 2048), (0, 1024, 1024), (1, 48000, 3072),
+                                          (0, 8192, 8192), (1, 96000, 4096), (1, 192000, 8192)])
+def test_engine_fir_matches_reference_design(pkg, kind, param, n):
+    e = pkg.Engine(kind, param, 1)
+    f = e.fir()
+    assert f.shape == (n,)
+    ref = orc.fir_design(n)  # spectrum -> c2r -> window, as the reference does
+    assert np.abs(f - ref).max() < 2e-7
+    cf = orc.fir_closed_form(n)
+    assert np.abs(f - cf).max() < 6e-8  # the engine uses the closed form, rounded once
+    assert f[n // 2 - 1] == pytest.approx((2 / n) / np.tan(np.pi / n) * 0.5 * (1 + np.cos(2 * np.pi / n)), abs=1e-7)
+    assert f[n // 2 + 1] == -f[n // 2 - 1]
+    assert np.all(f[(np.arange(n) - n // 2) % 2 == 0] == 0)
+    e.close()
+
+
+# ------------------------------------------------------------ CLI apply ---
+@pytest.mark.parametrize("blksiz,n_chn,angles,nblk", [
+    (2048, 1, [90], 20),       # "4096-pt OLA", 45 deg
+    (2048, 1, [-61], 20),      # -30.5 deg (Q9: negative wraps by +360)
+    (2048, 2, [20, 40], 8),    # -a 10,20
+    (1024, 1, [340], 12),      # 170 deg
+    (2048, 1, [360], 4),       # +-180 deg is a no-op rotation index 0 (Q9)
+    (4096, 1, [180], 9),       # "8192-pt FFT" in the reference = 2 FIR partitions here
+    (8192, 2, [340, -100], 6), # CLI default at 48 kHz = 4 partitions
+    (16384, 1, [77], 4),       # CLI default at 96 kHz = 8 partitions
+    (32768, 1, [-359], 3),     # largest block the CLI accepts = 16 partitions
+])
+def test_cli_apply_blocks(pkg, blksiz, n_chn, angles, nblk):
+    x = xorshift_uniform(blksiz * n_chn * nblk, seed=blksiz + n_chn)
+    g = pkg.PhaseRotate(blksiz, n_chn)
+    o = orc.CliEngine(blksiz, n_chn)
+    worst = 0.0
+    for b in range(nblk):
+        blk = x[b * blksiz * n_chn:(b + 1) * blksiz * n_chn]
+        yg = g.apply(blk, angles)
+        yo = o.apply(blk, angles)
+        worst = max(worst, float(np.abs(yg - yo).max()))
+    assert worst < TOL, worst
+    g.close()
+
+
+def test_cli_apply_file_matches_float64_model(pkg):
+    """y[t] = cos th x[t] + sin th (fir*x)[t + blksiz/2], th = -a pi/360."""
+    P, a = 2048, 90
+    n = P * 16
+    x = xorshift_uniform(n, seed=5)
+    g = pkg.PhaseRotate(P, 1)
+    y = g.apply_file(x, [a])
+    fir = orc.fir_closed_form(P)
+    u = np.convolve(x.astype(np.float64), fir)
+    th = -a * np.pi / 360
+    ym = np.cos(th) * x + np.sin(th) * u[P // 2:P // 2 + n]
+    assert np.abs(y - ym).max() < TOL
+    # and against the oracle's restatement of main()'s apply loop
+    yo = orc.cli_apply_file_mono(P, x, a)
+    assert np.abs(y - yo).max() < TOL
+    g.close()
+
+
+def test_cli_apply_file_ragged_length(pkg):
+    """Partial last block: the reference is broken here (Q3); we do the right thing."""
+    P, a = 2048, 180
+    n = P * 5 + 777
+    x = xorshift_uniform(n, seed=6)
+    g = pkg.PhaseRotate(P, 1)
+    y = g.apply_file(x, [a])
+    fir = orc.fir_closed_form(P)
+    u = np.convolve(x.astype(np.float64), fir)
+    th = -a * np.pi / 360
+    ym = np.cos(th) * x + np.sin(th) * u[P // 2:P // 2 + n]
+    assert np.abs(y - ym).max() < TOL
+    g.close()
+
+
+@pytest.mark.parametrize("P", [2048, 8192])
+def test_cli_apply_file_across_device_chunks(pkg, P):
+    """A file longer than one device chunk (2^22 frames rounded down to whole blocks AND whole device
+    transform blocks: 4 190 208 frames at blksiz 2048, whose transform block is 6144 frames): the chunk
+    seams carry state through the input history.  Against the oracle's restatement of main()'s apply loop,
+    with the largest error located to make a seam problem obvious."""
+    a = -77
+    n = (1 << 22) + (1 << 21) + 12345  # two chunks, ragged end
+    x = xorshift_uniform(n, seed=13)
+    g = pkg.PhaseRotate(P, 1)
+    y = g.apply_file(x, [a])
+    g.close()
+    yo = orc.cli_apply_file_mono(P, x, a)
+    # the reference's own tail handling is broken for a partial last block (Q3): its last blksiz/2 output
+    # frames are wrong (measured: exactly the last 1024 / 4096 frames differ), the device path flushes
+    # properly -- compare up to one block before the ragged end; the seam is far inside
+    m = n - n % P - P
+    d = np.abs(y[:m] - yo[:m])
+    assert d.max() < TOL, (float(d.max()), int(d.argmax()))
+    L = 6144 if P == 2048 else 8192  # lcm(blksiz, device transform block)
+    seam = (1 << 22) // L * L
+    assert seam < m and d[seam - 3 * P:seam + 3 * P].max() < TOL
+
+
+# -------------------------------------------------------------- LV2 run ---
+@pytest.mark.parametrize("rate,bufsize,angle,n_chn", [
+    (48000, 1024, 90.0, 1),    # BASELINE config 2
+    (48000, 64, -120.0, 1),
+    (48000, 4096, 180.0, 1),
+    (44100, 333, -77.0, 1),
+    (48000, 1024, (30.0, -45.0), 2),
+    (96000, 1024, 45.0, 1),             # 4096-tap FIR: 2 partitions (BASELINE config 3 filter)
+    (96000, 256, (10.0, -170.0), 2),
+    (192000, 333, -77.0, 1),            # 8192-tap FIR: 4 partitions
+])
+def test_lv2_run_stream(pkg, rate, bufsize, angle, n_chn):
+    n = 20000 if rate < 64000 else 40000
+    x = xorshift_uniform(n * n_chn, seed=int(rate) + bufsize).reshape(n_chn, n)
+    g = pkg.Lv2Instance(rate, n_chn)
+    g.activate()
+    o = orc.Lv2Engine(rate, n_chn)
+    assert g.latency == o.latency == {48000: 1792, 44100: 1792, 96000: 2560, 192000: 5120}[rate]
+    yg = g.run_stream(x, angle, bufsize)
+    yo = o.run_stream(x, angle, bufsize)
+    d = np.abs(yg - yo)
+    ramp_end = g.latency + 2304  # Q10: first blocks ramp from 0 deg
+    assert d[:, ramp_end:].max() < TOL, d[:, ramp_end:].max()
+    assert d[:, :ramp_end].max() < TOL_RAMP, d[:, :ramp_end].max()
+    g.close()
+
+
+def test_lv2_three_device_geometries_are_the_same_filter(pkg):
+    """LV2 48 kHz filter in the three device forms: polyphase (default: the odd taps on the stream
+    read as complex samples, one partition, 5120-frame blocks), direct form with two 2048-tap
+    partitions sharing a forward transform, and one zero-padded 4096-pt FFT per 1024-frame hop --
+    same LTI filter."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 300001  # odd: the last complex sample of the polyphase form is half outside
+    x = torch.from_numpy(xorshift_uniform(n, seed=31)).to(dev)
+    rot = np.array([0.28, -0.96], np.float32)
+    ys = []
+    # default for <= 4096 taps is the direct form (measured 2 % faster than polyphase there)
+    # (polyphase, the default: the 1536 odd taps need a 6-row tail, so 10 rows x 512 = 5120 frames are new per block)
+    want = {0: (1, 5120), pkg.CFG_POLYPHASE: (1, 5120), pkg.CFG_DIRECT_FORM: (2, 2048), pkg.CFG_SINGLE_FFT_PER_HOP: (1, 1024)}
+    for flags in want:
+        e = pkg.Engine(pkg.KIND_LV2, 48000, 1, flags=flags)
+        assert (e.info.partitions, e.info.hop) == want[flags]
+        y = torch.empty_like(x)
+        torch.cuda.synchronize()
+        e.apply_dev(x.data_ptr(), n, n, y.data_ptr(), n, n, rot, pkg.F_STATELESS)
+        e.sync()
+        ys.append(y)
+        e.close()
+    for other in ys[1:]:
+        assert (ys[0] - other).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("kind,param,hop", [(1, 48000, 5120), (1, 96000, 4096), (1, 192000, 4096), (0, 1024, 7168),
+                                            (0, 2048, 6144), (0, 4096, 4096), (0, 8192, 4096), (0, 16384, 4096)])
+def test_polyphase_equals_direct_form(pkg, kind, param, hop):
+    """Every FIR length, polyphase vs direct form, on misaligned (odd-offset) stereo streams, stateless
+    and stateful in uneven chunks.  Short partitions take long hops (5120 / 6144 / 7168 frames per block)."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, stride = 150001, 150003            # odd stride: channel 1 starts 4 bytes off an 8-byte boundary
+    xb = torch.from_numpy(xorshift_uniform(2 * stride + 1, seed=7)).to(dev)
+    x = xb[1:]                            # channel 0 misaligned too
+    rot = np.array([0.6, 0.8, -0.8, 0.6], np.float32)
+    res = []
+    for flags in (pkg.CFG_POLYPHASE, pkg.CFG_DIRECT_FORM):
+        e = pkg.Engine(kind, param, 2, flags=flags)
+        assert (e.info.hop == hop) == (flags == pkg.CFG_POLYPHASE)  # really two different forms
+        yb = torch.zeros(2 * stride + 1, device=dev)
+        y = yb[1:]
+        torch.cuda.synchronize()
+        e.apply_dev(x.data_ptr(), stride, n, y.data_ptr(), stride, n, rot, pkg.F_STATELESS)
+        e.sync()
+        # the same stream in uneven stateful chunks (history carried between calls)
+        zb = torch.zeros(2 * stride + 1, device=dev)
+        z = zb[1:]
+        pos = 0
+        for m in (1, 4095, 4097, 50000, n):
+            m = min(m, n - pos)
+            if m <= 0:
+                break
+            e.apply_dev(x.data_ptr() + 4 * pos, stride, m, z.data_ptr() + 4 * pos, stride, m, rot, 0)
+            pos += m
+        e.sync()
+        res.append((y[:n].clone(), y[stride:stride + n].clone(), z[:n].clone(), z[stride:stride + n].clone()))
+        e.close()
+    for a, b in zip(res[0], res[1]):
+        assert (a - b).abs().max().item() < TOL
+    # stateful == one-shot within one form
+    assert (res[0][0] - res[0][2]).abs().max().item() < TOL
+    assert (res[0][1] - res[0][3]).abs().max().item() < TOL
+
+
+def test_lv2_angle_change_mid_stream(pkg):
+    n, bs = 24000, 512
+    x = xorshift_uniform(n, seed=99).reshape(1, n)
+    g = pkg.Lv2Instance(48000, 1)
+    g.activate()
+    o = orc.Lv2Engine(48000, 1)
+    yg, yo = np.empty_like(x), np.empty_like(x)
+    for s in range(0, n, bs):
+        ang = 45.0 if s < 10240 else -135.0  # 180 deg step: longest ramp, wraps
+        yg[:, s:s + bs] = g.run(x[:, s:s + bs], ang)
+        yo[:, s:s + bs] = o.run(x[:, s:s + bs], ang)
+    assert np.abs(yg - yo).max() < TOL_RAMP
+    assert np.abs(yg[:, 16000:] - yo[:, 16000:]).max() < TOL
+    g.close()
+
+
+def test_lv2_reactivate_clears_history(pkg):
+    x = xorshift_uniform(4096, seed=3).reshape(1, -1)
+    g = pkg.Lv2Instance(48000, 1)
+    g.activate()
+    g.run_stream(x, 90.0, 1024)
+    g.activate()
+    y = g.run(np.zeros((1, 1024), np.float32), 90.0)
+    assert np.abs(y).max() == 0.0
+    g.close()
+
+
+# ---------------------------------------------------------------- sweep ---
+def _signal(n, n_chn, seed):
+    chans = []
+    for c in range(n_chn):
+        h = harmonic_stack(n, f0=110.0 * (1 + 0.31 * c))
+        chans.append(0.85 * h + 0.1 * xorshift_uniform(n, seed=seed + c))
+    return np.stack(chans, axis=1).astype(np.float32).reshape(-1)  # interleaved
+
+
+@pytest.mark.parametrize("blksiz,n_chn,nblk_frac", [(2048, 1, 10.0), (2048, 2, 7.37), (1024, 1, 9.5),
+                                                    (8192, 2, 4.2), (16384, 1, 3.5), (16384, 2, 30.3), (32768, 1, 6.5),
+                                                    (4096, 2, 41.7)])
+def test_sweep_full_table(pkg, blksiz, n_chn, nblk_frac):
+    n = int(blksiz * nblk_frac)
+    data = _signal(n, n_chn, seed=11)
+    g = pkg.PhaseRotate(blksiz, n_chn)
+    g.analyze_file(data, 0, 360, 1)
+    o = orc.CliEngine(blksiz, n_chn)
+    o.analyze_file(data, 0, 360, 1)
+    pg, po = g.peaks(), o.peaks()
+    assert np.abs(db(pg) - db(po)).max() < TOL_DB
+    assert pg[:, 0].tolist() == po[:, 0].tolist()  # angle 0 is an exact abs-max (Q4)
+    for c in range(n_chn):
+        assert int(np.argmin(pg[c])) == int(np.argmin(po[c]))
+    g.close()
+
+
+def test_sweep_block_by_block_matches_oracle(pkg):
+    """PhaseRotate::analyze call for call, incl. start=True on the first block (Q1),
+    stride 24 (Q5) and a single-channel fine pass with negative angles."""
+    P, n_chn, nblk = 2048, 2, 6
+    data = _signal(P * nblk, n_chn, seed=21).reshape(nblk, P * n_chn)
+    g = pkg.PhaseRotate(P, n_chn)
+    o = orc.CliEngine(P, n_chn)
+    for b in range(nblk):
+        g.analyze(data[b], 0, 360, 24, -1, b == 0)
+        o.analyze(data[b], 0, 360, 24, -1, b == 0)
+    assert np.abs(db(g.peaks()) - db(o.peaks())).max() < TOL_DB
+    for a in range(0, 360, 24):
+        assert g.peak(-1, a) == pytest.approx(o.peaks()[:, a].max(), rel=1e-6)
+    g.reset()
+    o.reset()
+    for b in range(nblk):
+        g.analyze(data[b], -12, 13, 1, 1, b == 0)
+        o.analyze(data[b], -12, 13, 1, 1, b == 0)
+    pg, po = g.peaks(), o.peaks()
+    assert np.abs(db(pg) - db(po)).max() < TOL_DB
+    assert np.all(pg[0] == 0)  # channel 0 untouched by a chn=1 pass
+    g.close()
+
+
+def test_sweep_mid_stream_raw_peak_is_complete_call_by_call(pkg):
+    """Angle 0 (the raw peak, calc_peak over the whole new block: cli/phase-rotate.cc:413-414) rides along in the sweep's
+    loaders, which see x[t - P/2]: the last P/2 frames of a call that is not the stream's last must still be in
+    peaks[c][0] when the call returns -- the loudest frame of every block sits in its second half here."""
+    P, n_chn, nblk = 2048, 2, 5
+    data = (0.05 * _signal(P * nblk, n_chn, seed=23)).reshape(nblk, P, n_chn).copy()
+    for b in range(nblk):
+        data[b, P - 3 - b, b % n_chn] = 0.1 + 0.15 * b      # in the last P/2 frames of block b
+    g = pkg.PhaseRotate(P, n_chn)
+    o = orc.CliEngine(P, n_chn)
+    for b in range(nblk):
+        g.analyze(data[b].reshape(-1), 0, 360, 24, -1, b == 0)
+        o.analyze(data[b].reshape(-1), 0, 360, 24, -1, b == 0)
+        pg, po = g.peaks(), o.peaks()
+        assert pg[:, 0].tobytes() == po[:, 0].astype(np.float32).tobytes(), b
+        assert pg[b % n_chn, 0] == np.float32(0.1 + 0.15 * b)
+    # ... and the same through the angle-0-only route and a mixed sequence of the two
+    g.reset()
+    o.reset()
+    for b in range(nblk):
+        a1, st = (1, 24) if b % 2 else (360, 24)
+        g.analyze(data[b].reshape(-1), 0, a1, st, -1, b == 0)
+        o.analyze(data[b].reshape(-1), 0, a1, st, -1, b == 0)
+        assert g.peaks()[:, 0].tobytes() == o.peaks()[:, 0].astype(np.float32).tobytes(), b
+    g.close()
+
+
+def test_sweep_first_block_quirk_q1(pkg):
+    """An early impulse: dry contributions of t < blksiz/2 never enter a rotated peak."""
+    P = 2048
+    x = np.zeros(P * 3, np.float32)
+    x[5] = 0.9
+    g = pkg.PhaseRotate(P, 1)
+    g.analyze_file(x, 0, 360, 1)
+    pg = g.peaks()[0]
+    o = orc.CliEngine(P, 1)
+    o.analyze_file(x, 0, 360, 1)
+    po = o.peaks()[0]
+    assert pg[0] == np.float32(0.9)
+    assert db(pg[2]) < -35.0  # ~ -40 dB at 1 deg
+    assert np.abs(db(pg[1:]) - db(po[1:])).max() < 0.01
+    g.close()
+
+
+def test_sweep_empty_and_tiny_files(pkg):
+    P = 2048
+    g = pkg.PhaseRotate(P, 1)
+    g.analyze_file(np.zeros(0, np.float32), 0, 360, 24)
+    assert np.all(g.peaks() == 0)
+    g.reset()
+    x = xorshift_uniform(100, seed=2)
+    g.analyze_file(x, 0, 360, 1)
+    o = orc.CliEngine(P, 1)
+    o.analyze_file(x, 0, 360, 1)
+    assert np.abs(g.peaks() - o.peaks()).max() < 1e-6
+    g.close()
+
+
+# ------------------------------------------------- device-resident stream ---
+def test_apply_dev_large_stream_properties(pkg):
+    """BASELINE-size style checks through size-independent properties:
+    linearity, time-invariance across run boundaries and a 90+90 = polarity flip."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 1 << 22
+    e = pkg.Engine(pkg.KIND_LV2, 48000, 1)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = (torch.rand(n, generator=g) - 0.5).to(dev)
+    y1 = torch.empty_like(x)
+    y2 = torch.empty_like(x)
+    s, c = np.sin(-np.pi / 2), np.cos(-np.pi / 2)
+    rot = np.array([c, s], np.float32)
+    torch.cuda.synchronize()  # the engine uses its own non-blocking stream
+    e.apply_dev(x.data_ptr(), n, n, y1.data_ptr(), n, n, rot, pkg.F_STATELESS)
+    e.apply_dev(y1.data_ptr(), n, n, y2.data_ptr(), n, n, rot, pkg.F_STATELESS)
+    e.sync()
+    # two 90-degree rotations = -x delayed by 2 * latency (band-limited error of the FIR aside)
+    L = e.info.latency
+    ref = -x[: n - 2 * L]
+    got = y2[2 * L:]
+    # the Hilbert FIR is not flat below ~50 Hz: compare energy, not samples
+    err = torch.sqrt(torch.mean((got - ref) ** 2)) / torch.sqrt(torch.mean(ref ** 2))
+    assert err.item() < 0.05
+    # linearity: A(2x) == 2 A(x) bit-exactly (power-of-two scaling)
+    x2 = 2 * x
+    y3 = torch.empty_like(x)
+    torch.cuda.synchronize()
+    e.apply_dev(x2.data_ptr(), n, n, y3.data_ptr(), n, n, rot, pkg.F_STATELESS)
+    e.sync()
+    assert torch.equal(y3, 2 * y1)
+    # shift-invariance across workgroup-run boundaries: shifting the input by one hop
+    hop = e.info.hop
+    xs = torch.zeros_like(x)
+    xs[hop:] = x[:-hop]
+    y4 = torch.empty_like(x)
+    torch.cuda.synchronize()
+    e.apply_dev(xs.data_ptr(), n, n, y4.data_ptr(), n, n, rot, pkg.F_STATELESS)
+    e.sync()
+    assert (y4[hop:] - y1[:-hop]).abs().max().item() < TOL
+    e.close()
+
+
+def test_apply_dev_stateful_chunks_equal_one_shot(pkg):
+    import torch
+    dev = torch.device("cuda:0")
+    n = 50000
+    e = pkg.Engine(pkg.KIND_CLI, 2048, 2)
+    x = torch.from_numpy(xorshift_uniform(2 * n, seed=8).reshape(2, n)).to(dev)
+    rot = np.array([0.6, 0.8, -0.8, 0.6], np.float32)
+    y_one = torch.empty_like(x)
+    torch.cuda.synchronize()
+    e.apply_dev(x.data_ptr(), n, n, y_one.data_ptr(), n, n, rot, pkg.F_STATELESS)
+    y_chunks = torch.zeros_like(x)
+    pos = 0
+    for sz in (1, 1023, 2048, 4097, 10000, 32831):
+        xin = x[:, pos:pos + sz].contiguous()
+        yo = torch.empty_like(xin)
+        torch.cuda.synchronize()
+        e.apply_dev(xin.data_ptr(), sz, sz, yo.data_ptr(), sz, sz, rot, 0)
+        e.sync()
+        y_chunks[:, pos:pos + sz] = yo
+        pos += sz
+    assert pos == n
+    assert (y_chunks - y_one).abs().max().item() < TOL
+    e.close()
+
+
+# ------------------------------------------------------- fp16 sample path ---
+@pytest.mark.parametrize("kind,param,flags", [(1, 48000, 0), (1, 48000, 1), (1, 96000, 0), (0, 2048, 0)])
+def test_fp16_sample_path_tolerance_report(pkg, kind, param, flags, capsys):
+    """BASELINE config 5: half samples + packed-half butterflies, fp32 accumulate.
+    No gate beyond a stated tolerance: report the error against the fp32 path."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 1 << 20
+    e = pkg.Engine(kind, param, 1, flags=flags)  # two-partition (p2) and single-transform geometries
+    x32 = torch.from_numpy(0.9 * harmonic_stack(n) + 0.05 * xorshift_uniform(n, seed=4)).to(dev)
+    x16 = x32.half()
+    y32 = torch.empty_like(x32)
+    y16 = torch.empty_like(x16)
+    rot = np.array([np.cos(-0.7), np.sin(-0.7)], np.float32)
+    x16f = x16.float().contiguous()
+    torch.cuda.synchronize()
+    e.apply_dev(x16f.data_ptr(), n, n, y32.data_ptr(), n, n, rot, pkg.F_STATELESS)
+    e.apply_dev_f16(x16.data_ptr(), n, n, y16.data_ptr(), n, n, rot)
+    e.sync()
+    torch.cuda.synchronize()
+    err = (y16.float() - y32).abs()
+    rms = float(torch.sqrt(torch.mean(err ** 2)))
+    ref_rms = float(torch.sqrt(torch.mean(y32 ** 2)))
+    with capsys.disabled():
+        print("\n[fp16 path, kind=%d param=%d flags=%d] max abs err %.3e, rms err %.3e (signal rms %.3f, SNR %.1f dB)"
+              % (kind, param, flags, float(err.max()), rms, ref_rms, 20 * np.log10(ref_rms / rms)))
+    assert float(err.max()) < 2e-2 and rms < 3e-3  # stated tolerance: ~1e-3 rms at |y| <= 1
+    e.close()
+
+
+# --------------------------------------------------------- BASELINE sizes ---
+def test_full_size_stream_2p27_properties(pkg):
+    """The bench workload itself (LV2 48 kHz filter, 2^27 frames, one launch), checked through
+    size-independent properties: (1) three random windows against the float64 LTI model,
+    (2) a checksum of the one-shot output equals the checksum of a stateful two-chunk pass
+    to within float tolerance, (3) exact linearity under scaling by 2."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 1 << 27
+    e = pkg.Engine(pkg.KIND_LV2, 48000, 1)
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.rand(n, generator=g, device=dev) - 0.5
+    y = torch.empty_like(x)
+    ang = 33.0
+    th = -2 * np.pi * ang / 360
+    rot = np.array([np.cos(th), np.sin(th)], np.float32)
+    torch.cuda.synchronize()  # inputs come from torch's stream; the engine has its own
+    e.apply_dev(x.data_ptr(), n, n, y.data_ptr(), n, n, rot, pkg.F_STATELESS)
+    e.sync()
+    L, P, N = e.info.latency, e.info.blksiz, e.info.firlen
+    fir = orc.fir_closed_form(N)
+    rng = np.random.default_rng(5)
+    for t0 in [0, int(rng.integers(1 << 20, n - (1 << 20))), n - 8192]:
+        W = 8192
+        lo = max(0, t0 - (P + N))
+        xs = x[lo:t0 + W].cpu().numpy().astype(np.float64)
+        u = np.convolve(xs, fir)[:xs.size]
+        pad = t0 - lo
+
+        def at(arr, d):  # arr delayed by d frames, window [t0, t0 + W)
+            idx = np.arange(pad, pad + W) - d
+            out = np.zeros(W)
+            ok = idx >= 0
+            out[ok] = arr[idx[ok]]
+            return out
+        ym = np.cos(th) * at(xs, L) + np.sin(th) * at(u, P)
+        if lo > 0:  # the model window lacks history older than lo: only frames with full support count
+            valid = np.arange(W) + pad >= P + N
+        else:
+            valid = np.ones(W, bool)
+        got = y[t0:t0 + W].cpu().numpy()
+        assert np.abs(got - ym)[valid].max() < TOL
+    # stateful two-chunk pass == one shot
+    e.reset()
+    y2 = torch.empty_like(x)
+    h = (n // 2) + 12345
+    torch.cuda.synchronize()
+    e.apply_dev(x.data_ptr(), h, h, y2.data_ptr(), h, h, rot, 0)
+    e.apply_dev(x[h:].data_ptr(), n - h, n - h, y2[h:].data_ptr(), n - h, n - h, rot, 0)
+    e.sync()
+    assert (y2 - y).abs().max().item() < TOL
+    assert abs(y2.double().sum().item() - y.double().sum().item()) < 1e-2
+    # linearity
+    x2 = 2 * x
+    torch.cuda.synchronize()
+    e.apply_dev(x2.data_ptr(), n, n, y2.data_ptr(), n, n, rot, pkg.F_STATELESS)
+    e.sync()
+    assert torch.equal(y2, 2 * y)
+    e.close()
+
+
+def test_full_size_sweep_shards_equal_single_pass(pkg):
+    """The multi-GPU sweep plumbing on ONE device: two engines sweep the two halves of a
+    stereo stream (second one primed with the history in front of its shard), the tables
+    are MAX-merged -- bit-identical to the single-engine table."""
+    import torch
+    from phaserotate_lv2_amd import sweep_dist
+    dev = torch.device("cuda:0")
+    P, n_chn = 2048, 2
+    nb = 3001
+    n = nb * P - 777  # ragged last block
+    g = torch.Generator(device=dev).manual_seed(2)
+    x = (torch.rand((n_chn, n), generator=g, device=dev) - 0.5) * 0.9
+    one = pkg.Engine(pkg.KIND_CLI, P, n_chn)
+    pk1 = torch.zeros((n_chn, 360), device=dev)
+    torch.cuda.synchronize()
+    one.sweep_dev(x.data_ptr(), n, n, 0, 360, 1, -1, pk1.data_ptr(), pkg.F_STREAM_START | pkg.F_STREAM_END)
+    one.sync()
+    # shard boundaries on whole device transform blocks (6144 frames = 3 blocks for this engine)
+    plan = sweep_dist.plan_shards(n, P, 2, align=one.shard_align_blocks())
+    assert all(b0 % one.shard_align_blocks() == 0 for b0, _ in plan)
+    pk2 = torch.zeros((n_chn, 360), device=dev)
+    for r, (b0, b1) in enumerate(plan):
+        f0, nf = sweep_dist.shard_frames(n, P, plan, r)
+        eng = pkg.Engine(pkg.KIND_CLI, P, n_chn)
+        H = eng.info.history
+        if r > 0:
+            halo = x[:, f0 - H:f0].contiguous()
+            torch.cuda.synchronize()
+            keep = sweep_dist.prime_history(eng, halo)
+        xs = x[:, f0:f0 + nf].contiguous()
+        part = torch.zeros((n_chn, 360), device=dev)
+        torch.cuda.synchronize()
+        flags = (pkg.F_STREAM_START if r == 0 else 0) | (pkg.F_STREAM_END if r == len(plan) - 1 else 0)
+        eng.sweep_dev(xs.data_ptr(), nf, nf, 0, 360, 1, -1, part.data_ptr(), flags)
+        eng.sync()
+        pk2 = torch.maximum(pk2, part)
+        eng.close()
+    assert torch.equal(pk1, pk2)
+    one.close()
+
+
+def test_lv2_random_buffer_sizes_and_angle_moves(pkg):
+    """run() with ragged host buffer sizes (1..5000 frames) and the angle port moving at
+    random times: every reference block boundary / ramp start lands somewhere else."""
+    rng = np.random.default_rng(2024)
+    n = 60000
+    x = xorshift_uniform(2 * n, seed=17).reshape(2, n)
+    g = pkg.Lv2Instance(48000, 2)
+    g.activate()
+    o = orc.Lv2Engine(48000, 2)
+    yg, yo = np.empty_like(x), np.empty_like(x)
+    pos, ang = 0, np.array([10.0, -20.0], np.float32)
+    while pos < n:
+        sz = int(min(n - pos, rng.choice([1, 7, 64, 255, 256, 257, 1000, 1024, 3333, 5000])))
+        if rng.random() < 0.15:
+            ang = rng.uniform(-200, 200, 2).astype(np.float32)  # beyond +-180: clamped (src/phaserotate.c:566-571)
+        yg[:, pos:pos + sz] = g.run(x[:, pos:pos + sz], ang)
+        yo[:, pos:pos + sz] = o.run(x[:, pos:pos + sz], ang)
+        pos += sz
+    assert np.abs(yg - yo).max() < TOL_RAMP
+    g.close()
+
+
+def _sweep_table(pkg, x, P, stride, prune, passes=((0, 360, 24), (100, 140, 1)), fused=False):
+    """Peak table [n_chn][360] after a coarse and a fine pass over the interleaved file x, and the
+    fraction of tile groups the sweep actually evaluated.  fused=False keeps the separate Hilbert and sweep
+    passes (whose statistics count tiles of ALL frames) also where the engine would fuse them."""
+    pkg.set_test_option(pkg.TEST_SWEEP_UNPRUNED, 0 if prune else 1)
+    pkg.set_test_option(pkg.TEST_SWEEP_UNFUSED, 0 if fused else 1)
+    try:
+        pr = pkg.PhaseRotate(P, x.shape[1])
+        for a0, a1, st in passes:
+            pr.analyze_file(x, a0, a1, st)
+        tab = np.array([[pr.peak(c, a) for a in range(360)] for c in range(x.shape[1])], np.float32)
+        ev, seen = pr.sweep_stats()
+        _sweep_table.last_stats = pr.sweep_stats_ex()
+        _sweep_table.last_fused = pr.sweep_stats_fused()
+        pr.close()
+    finally:
+        pkg.set_test_option(pkg.TEST_SWEEP_UNPRUNED, 0)
+        pkg.set_test_option(pkg.TEST_SWEEP_UNFUSED, 0)
+    return tab, (ev / seen if seen else None)  # the unpruned kernel keeps no statistics: seen == 0
+
+
+@pytest.mark.parametrize("signal", ["noise+harmonics", "steady-tone", "silence-then-burst", "long-multichunk", "constant",
+                                    "stationary-noise", "tone-then-noise", "bursts"])
+def test_pruned_sweep_is_bit_identical_to_unpruned(pkg, signal):
+    """The sweep tests every frame's r = sqrt(d^2 + h^2) against a lower bound of every final peak and
+    evaluates only compacted tiles of survivors.  That must not change a single bit of the table --
+    including when nothing can be skipped (a steady tone: every frame's r equals every angle's peak; a
+    GROWING signal is no worst case on a parallel machine -- the waves working on the loud end publish
+    their bound to those working on the quiet start), when the bound starts
+    at zero (leading silence), across chunks (> 2^22 frames: later chunks start from the table of the
+    earlier ones) and across passes.  The evaluated fraction is asserted too, both ways: a test in which
+    nothing was skipped would compare the unpruned sweep with itself (that happened with the first,
+    per-wave version of the bound); the steady tone must NOT be skippable and must go through the
+    untested feed; long stationary noise -- the case the group-granular pruning of rounds 1-2 could not
+    touch -- must stay below one half; and a wave that switched the test off on a tone must find its
+    way back once the material turns quiet (two-way switch: "bursts" inside one launch, "tone-then-noise"
+    across chunks)."""
+    P = 2048
+    rng = np.random.default_rng(11)
+    if signal == "noise+harmonics":
+        n = 600000
+        x = np.stack([0.5 * harmonic_stack(n, 48000) + 0.1 * xorshift_uniform(n, seed=3), xorshift_uniform(n, seed=4)], 1)
+    elif signal == "steady-tone":
+        # constant envelope: r(t) = A for every frame and every angle's peak tends to A -- nothing is skippable
+        n = 400000
+        x = (0.7 * np.sin(2 * np.pi * 997.0 / 48000 * np.arange(n)))[:, None]
+    elif signal == "tone-then-noise":
+        # 2^22 frames of the steady tone (test switched off), then 3 x 2^22 of noise below it
+        n = (1 << 22) * 4
+        x = np.empty((n, 1), np.float32)
+        g = 1 << 22
+        x[:g, 0] = 0.7 * np.sin(2 * np.pi * 997.0 / 48000 * np.arange(g))
+        x[g:, 0] = 0.5 * xorshift_uniform(n - g, seed=12)
+    elif signal == "bursts":
+        # ONE launch (a device chunk holds 2^22 frames; a workgroup walks it in steps of 1024 frames, grid-strided, so it
+        # meets the material in file order): a quarter of steady tone -- all of it survives, the test goes off --, then
+        # three quarters of quiet noise, where the wave must switch the test back on
+        n, g = 1 << 22, 1 << 20
+        x = np.empty((n, 1), np.float32)
+        x[:g, 0] = 0.7 * np.sin(2 * np.pi * 997.0 / 48000 * np.arange(g))
+        x[g:, 0] = 0.2 * xorshift_uniform(n - g, seed=30)
+    elif signal == "silence-then-burst":
+        n = 300000
+        x = np.zeros((n, 2), np.float32)
+        x[200000:200700, 0] = xorshift_uniform(700, seed=6)
+        x[299990:, 1] = 0.9
+    elif signal == "long-multichunk":
+        # four device chunks (2^22 frames each): loud material in the first, 40 dB quieter afterwards --
+        # the later chunks start from the bound the first one left in the table and are skipped -- plus
+        # one late click louder than everything, which must still land in the table
+        n = (1 << 22) * 3 + 12345
+        x = (0.8 * harmonic_stack(n, 48000) + 0.05 * xorshift_uniform(n, seed=8))[:, None].astype(np.float32)
+        x[1 << 22:] *= 0.01
+        x[n - 3000:n - 2990] = 0.97
+    elif signal == "stationary-noise":
+        n = (1 << 22) * 3 + 777
+        x = np.stack([0.9 * xorshift_uniform(n, seed=9), 0.9 * xorshift_uniform(n, seed=10)], 1)
+    else:
+        n = 100000
+        x = np.full((n, 1), 0.25, np.float32)
+    x = np.ascontiguousarray(x, np.float32)
+    a, frac_pruned = _sweep_table(pkg, x, P, 24, prune=True)
+    st = dict(_sweep_table.last_stats)
+    b, frac_plain = _sweep_table(pkg, x, P, 24, prune=False)
+    assert a.tobytes() == b.tobytes()
+    # FUSED (round 4): the Hilbert pass lists the frames above the bound of the whole call, the matrix-core kernel evaluates the
+    # lists -- the same table bit for bit; chunks of 2^20 frames and more take that route, the others the separate passes
+    f, _ = _sweep_table(pkg, x, P, 24, prune=True, fused=True)
+    fu = dict(_sweep_table.last_fused)
+    assert f.tobytes() == b.tobytes()
+    assert (fu["tested"] > 0) == (x.shape[0] >= (1 << 20)), fu
+    if fu["tested"]:
+        print("\n[fused sweep, %s] %.1f %% of the tested frames listed" % (signal, 100.0 * fu["listed"] / fu["tested"]))
+        assert fu["listed"] <= fu["tested"]
+        if signal == "long-multichunk":
+            assert fu["listed"] < 0.3 * fu["tested"], fu   # the quiet chunks are listed against the loud one's table
+        if signal == "stationary-noise":
+            assert fu["listed"] < 0.6 * fu["tested"], fu
+    assert a.max() > 0            # every signal here has energy
+    assert frac_plain is None and frac_pruned is not None  # the switch really selects the two kernels
+    assert st["evaluated"] <= st["seen"] + 2 * 4 * 4096 and st["untested"] <= st["evaluated"]  # (+ zero-padded last tiles)
+    print("\n[sweep pruning, %s] evaluated %.1f %% of the tiles, %.1f %% fed untested" %
+          (signal, 100 * frac_pruned, 100.0 * st["untested"] / st["seen"]))
+    # ... and the comparison is not vacuous: pruning must have skipped work where the signal allows it
+    # (no expectation for "constant": its Hilbert branch is ~0, so the peaks near 90 degrees are ~0 and
+    # little is skippable)
+    if signal == "silence-then-burst":
+        assert frac_pruned < 0.1, frac_pruned   # the silences cannot raise anything
+    if signal == "long-multichunk":
+        assert frac_pruned < 0.3, frac_pruned   # a part of the loud quarter is evaluated, the rest is not
+    if signal == "stationary-noise":
+        assert frac_pruned < 0.5, frac_pruned
+        assert st["untested"] < 0.2 * st["seen"], st
+    if signal == "growing":
+        assert frac_pruned > 0.9, frac_pruned   # every frame holds a new record: nothing may be skipped
+        assert st["untested"] > 0.5 * st["seen"], st  # ... and the test is switched off most of the time
+    if signal == "bursts":
+        assert 0.2 < frac_pruned < 0.85, frac_pruned  # (the tone quarter + the pauses that reach into the noise)
+        assert 0.05 * st["seen"] < st["untested"] < 0.6 * st["seen"], st  # off in the tone, back on in the noise
+    if signal == "growing-then-steady":
+        assert frac_pruned < 0.6, frac_pruned   # the steady 3/4 are tested again (and mostly skipped)
+        assert 0.1 * st["seen"] < st["untested"] < 0.4 * st["seen"], st
+
+
+@pytest.mark.parametrize("stride,blocks", [(1, 12), (3, 4), (4, 3), (5, 3), (6, 2), (8, 2), (24, 1)])
+def test_pruned_sweep_every_angle_block_layout(pkg, stride, blocks):
+    """The sweep kernel spreads 32-angle blocks over four wave groups; 65..96 angles (3 blocks) leave one
+    group without a block -- its waves must neither evaluate nor publish a bound --, 33..64 use two groups,
+    <= 32 one.  Pruned and unpruned tables must be bit-identical in every layout, and equal to the oracle's
+    within the gate."""
+    from phaserotate_lv2_amd import sweep_dist
+    P, n = 2048, 300000
+    x = np.ascontiguousarray(np.stack([0.6 * harmonic_stack(n, 48000) + 0.05 * xorshift_uniform(n, seed=21),
+                                       0.3 * xorshift_uniform(n, seed=22)], 1), np.float32)
+    x[150000:, :] *= 0.05  # something to skip
+    swept = [k for k in sweep_dist.angle_list(0, 360, stride) if k != 0]  # angle 0 is the raw peak, not swept
+    assert (len(swept) + 31) // 32 == blocks
+    passes = ((0, 360, stride),)
+    a, frac = _sweep_table(pkg, x, P, stride, prune=True, passes=passes)
+    b, _ = _sweep_table(pkg, x, P, stride, prune=False, passes=passes)
+    assert a.tobytes() == b.tobytes()
+    assert (a[:, swept] > 0).all()
+    o = orc.CliEngine(P, 2)
+    o.analyze_file(x, 0, 360, stride)
+    ref = o.peaks()
+    d_db = np.abs(20 * np.log10(a[:, swept] / ref[:, swept]))
+    assert d_db.max() < 1e-3, d_db.max()
+
+
+@pytest.mark.parametrize("n_chn,n,passes", [
+    (3, 100000, ((0, 360, 24),)),                 # three channels: the scratch table's channel stride, 15 angles (one block)
+    (1, 700, ((0, 360, 1),)),                     # less than one 1024-frame step, all angles
+    (4, 5000, ((0, 1, 24),)),                     # angle 0 only: no sweep launch, the stand-alone abs-max kernel
+    (2, 2048 * 3 + 1, ((0, 360, 8), (200, 236, 1))),  # a ragged last block, a second pass over a few angles without angle 0
+    (5, 40000, ((1, 360, 7),)),                   # five channels, angle 0 NOT asked for (slot 0 must stay untouched)
+    (33, 9000, ((0, 360, 1),)),                   # more channels than step counters per workgroup slot: fewer than 32 workgroups
+    (64, 7000, ((0, 360, 3),)),                   #   per channel draw from as many counters as there are workgroups
+    (1100, 2500, ((0, 360, 24),)),                # more channels than resident-workgroup slots: the scratch table in several launches
+])
+def test_sweep_table_small_and_many_channel_calls(pkg, n_chn, n, passes):
+    """The sweep's per-launch scratch table and merge kernel (one value per angle, workgroup and wave; the raw peak of angle 0
+    riding along in the loaders) at shapes the long-file tests do not reach: more channels than two, inputs shorter than
+    one step, calls that ask for angle 0 alone or not at all.  Against the oracle (1e-3 dB, angle 0 exact)."""
+    P = 2048
+    x = np.ascontiguousarray(np.stack([0.5 * harmonic_stack(n, 48000) * (0.4 + 0.1 * c) + 0.02 * xorshift_uniform(n, seed=40 + c)
+                                       for c in range(n_chn)], 1), np.float32)
+    g = pkg.PhaseRotate(P, n_chn)
+    o = orc.CliEngine(P, n_chn)
+    asked = set()
+    for a0, a1, st in passes:
+        g.analyze_file(x, a0, a1, st)
+        o.analyze_file(x, a0, a1, st)
+        a = a0
+        while a <= a1:           # the loop bounds of cli/phase-rotate.cc:409-428
+            asked.add(((a % 360) + 360) % 360)
+            a += st
+            if a >= a1:
+                break
+    tab = np.array([[g.peak(c, a) for a in range(360)] for c in range(n_chn)], np.float32)
+    ref = o.peaks()
+    g.close()
+    for a in range(360):
+        if a not in asked:
+            assert (tab[:, a] == 0).all(), a            # untouched slots stay untouched
+    swept = sorted(a for a in asked if a != 0)
+    if 0 in asked:
+        assert tab[:, 0].tobytes() == ref[:, 0].astype(np.float32).tobytes()  # the raw peak: exact
+        assert (tab[:, 0] > 0).all()
+    if swept:
+        assert (tab[:, swept] > 0).all()
+        d_db = np.abs(20 * np.log10(tab[:, swept] / ref[:, swept]))
+        assert d_db.max() < 1e-3, d_db.max()
+
+
+@pytest.mark.parametrize("blksiz,n_chn,n", [(2048, 2, 1 << 23), (8192, 1, 5_000_003), (1024, 3, 777), (2048, 3, 600_001)])
+def test_resident_file_passes_equal_streamed_ones(pkg, blksiz, n_chn, n):
+    """prot_cli_file_resident: after the first analyze_file of a file the engine sweeps its de-interleaved device copy; a
+    coarse pass, a fine pass and a pass over another file (new pointer: uploaded afresh) must leave the same table, bit for
+    bit, as an engine that streams the file from the host every time (two device chunks at the first shape)."""
+    x = np.ascontiguousarray(np.stack([0.5 * harmonic_stack(n, 48000) * (0.5 + 0.2 * c) + 0.03 * xorshift_uniform(n, seed=60 + c)
+                                       for c in range(n_chn)], 1), np.float32)
+    y = np.ascontiguousarray(x[::-1] * 0.9)
+    tabs = []
+    for resident in (False, True):
+        g = pkg.PhaseRotate(blksiz, n_chn)
+        if resident:
+            g.file_resident(True)
+        out = []
+        for data, (a0, a1, st) in ((x, (0, 360, 24)), (x, (100, 140, 1)), (y, (0, 360, 8)), (x, (0, 360, 3))):
+            g.reset()
+            g.analyze_file(data, a0, a1, st)
+            out.append(np.array([[g.peak(c, a) for a in range(360)] for c in range(n_chn)], np.float32))
+        g.reset()
+        out.append(g.apply_file(x, [37 + 5 * c for c in range(n_chn)]).copy())  # (resident: the input is not uploaded again)
+        if resident:
+            g.file_resident(False)
+            g.reset()
+            g.analyze_file(x, 0, 360, 24)   # streams again
+            assert np.array([[g.peak(c, a) for a in range(360)] for c in range(n_chn)], np.float32).tobytes() == out[0].tobytes()
+        g.close()
+        tabs.append(out)
+    for a, b in zip(*tabs):
+        assert a.max() > 0 and a.tobytes() == b.tobytes()
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_overlap_save_equals_overlap_add_on_random_chunkings(pkg, seed):
+    """Two independent kernels for the same filter -- the generated overlap-save loop (default) and the overlap-add kernel
+    with its spectrum table (PROT_CFG_OVERLAP_ADD) -- fed the same stream in random stateful chunks (1 frame ... 300 000),
+    random channel counts, odd and even row strides (the aligned and the frame-by-frame paths), steady rotation and the
+    Hilbert-only mode: the two must agree to 2e-6 everywhere, and each must equal its own one-shot stateless pass bit for
+    bit where the chunk boundaries allow the same block cuts (checked as <= 2e-6 as well: cuts differ)."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(seed)
+    kind, param = [(pkg.KIND_LV2, 48000), (pkg.KIND_LV2, 96000), (pkg.KIND_CLI, 2048), (pkg.KIND_CLI, 4096)][seed % 4]
+    nc = int(rng.integers(1, 4))
+    n = int(rng.integers(200_000, 900_000))
+    stride = n + int(rng.integers(0, 9))
+    x = torch.from_numpy(xorshift_uniform(nc * stride + 1, seed=seed)).to(dev)[1 if seed % 2 else 0:][:nc * stride]
+    rot = np.array([[np.cos(0.7 * c + 0.1), np.sin(0.7 * c + 0.1)] for c in range(nc)], np.float32).reshape(-1)
+    hil = (pkg.F_HILBERT if seed % 3 == 0 else 0)
+    cuts = [0]
+    while cuts[-1] < n:
+        cuts.append(min(n, cuts[-1] + int(rng.choice([1, 2, 63, 1024, 4096, 5121, 70001, 300000]))))
+    outs = []
+    for flags in (0, pkg.CFG_OVERLAP_ADD):
+        e = pkg.Engine(kind, param, nc, flags=flags)
+        assert e.info.form == ((pkg.FORM_POLY_SAVE8K if kind == pkg.KIND_LV2 else pkg.FORM_POLY_SAVE) if flags == 0 else pkg.FORM_POLY_OLA)
+        y = torch.zeros(nc * stride, device=dev)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            e.apply_dev(x.data_ptr() + 4 * a, stride, b - a, y.data_ptr() + 4 * a, stride, b - a, rot, hil)
+        e.sync()
+        y1 = torch.zeros(nc * stride, device=dev)
+        e.reset()
+        e.apply_dev(x.data_ptr(), stride, n, y1.data_ptr(), stride, n, rot, hil | pkg.F_STATELESS)
+        e.sync()
+        torch.cuda.synchronize()
+        yy = y.cpu().numpy().reshape(nc, stride)[:, :n]
+        assert np.abs(yy - y1.cpu().numpy().reshape(nc, stride)[:, :n]).max() < 2e-6
+        outs.append(yy)
+        e.close()
+    assert np.abs(outs[0]).max() > 0.05
+    assert np.abs(outs[0] - outs[1]).max() < 2e-6, (kind, param, nc, n, stride, len(cuts))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_sweep_random_shapes_against_oracle_and_unpruned(pkg, seed):
+    """Randomised: block size, channel count, length (1 frame ... 150 000), angle range and stride, signal shape per channel
+    (noise, tone, growing tone, bursts in silence, level steps, DC), one or two passes.  The pruned table must equal the
+    unpruned one bit for bit and the oracle's within 1e-3 dB, the raw peak (angle 0) exactly.  (tools/sweep_fuzz.py is the
+    long-running pruned-vs-unpruned version of this.)"""
+    rng = np.random.default_rng(seed)
+
+    def signal(n, nc):
+        t = np.arange(n)
+        x = np.zeros((n, nc), np.float32)
+        for c in range(nc):
+            kind, amp = rng.integers(0, 6), rng.uniform(0.05, 0.9)
+            if kind == 0:
+                x[:, c] = amp * (rng.random(n) - 0.5)
+            elif kind == 1:
+                x[:, c] = amp * np.sin(2 * np.pi * rng.uniform(0.001, 0.2) * t)
+            elif kind == 2:
+                x[:, c] = amp * np.sin(2 * np.pi * rng.uniform(0.001, 0.05) * t) * np.linspace(0.1, 1, n)
+            elif kind == 3:
+                for _ in range(rng.integers(1, 6)):
+                    a = rng.integers(0, n)
+                    b = min(n, a + rng.integers(1, 5000))
+                    x[a:b, c] = amp * (rng.random(b - a) - 0.5)
+            elif kind == 4:
+                lev = rng.uniform(0.01, 1.0, 8)
+                x[:, c] = lev[np.minimum(t * 8 // max(n, 1), 7)] * 0.5 * np.sign(np.sin(2 * np.pi * 0.01 * t) + 1e-9) + 0.01 * (rng.random(n) - 0.5)
+            else:
+                x[:, c] = amp * 0.25
+        return np.ascontiguousarray(x)
+
+    for k in range(14):
+        P = int(rng.choice([1024, 2048, 2048, 4096, 8192]))
+        nc = int(rng.choice([1, 2, 2, 3]))
+        n = int(rng.choice([rng.integers(1, 3000), rng.integers(3000, 150000)]))
+        st = int(rng.choice([1, 2, 3, 5, 8, 24]))
+        a0 = int(rng.choice([0, 0, 1, rng.integers(0, 300)]))
+        a1 = int(min(360, a0 + rng.choice([1, 40, 100, 360])))
+        x = signal(n, nc)
+        passes = ((a0, a1, st),) if k % 3 else ((a0, a1, st), (max(0, a0 - 7), min(360, a1 + 9), 1))
+        a, _ = _sweep_table(pkg, x, P, st, prune=True, passes=passes)
+        b, _ = _sweep_table(pkg, x, P, st, prune=False, passes=passes)
+        assert a.tobytes() == b.tobytes(), (seed, k, P, nc, n, passes)
+        o = orc.CliEngine(P, nc)
+        for q0, q1, qs in passes:
+            o.analyze_file(x, q0, q1, qs)
+        ref = o.peaks().astype(np.float32)
+        assert a[:, 0].tobytes() == ref[:, 0].tobytes(), (seed, k, "raw peak")
+        nz = ref[:, 1:] > 1e-12
+        assert ((a[:, 1:] > 0) == (ref[:, 1:] > 0)).all(), (seed, k, "touched slots")
+        if nz.any():
+            d_db = np.abs(20 * np.log10(a[:, 1:][nz] / ref[:, 1:][nz]))
+            assert d_db.max() < 1e-3, (seed, k, P, nc, n, passes, float(d_db.max()))
+
+
+@pytest.mark.parametrize("stride", [70004, 70003])
+@pytest.mark.parametrize("kind,param", [(1, 48000), (1, 96000), (0, 1024), (0, 8192)])
+def test_many_channels_equal_independent_mono_streams(pkg, kind, param, stride):
+    """A 5-channel engine (per-channel rotation) processes a stream in three stateful chunks; every channel
+    must equal a mono engine run on that channel alone.  With an even channel stride every channel takes the
+    same (8-byte aligned) code path as the mono run: bit-identical.  With an odd stride channels 1 and 3 take
+    the 4-byte-aligned load/store path, whose rotation epilogue is scalar instead of packed (the compiler may
+    contract it differently under -ffast-math): equal to a rounding error.  Covers channel indexing and the
+    fused per-channel history write of every default kernel form (polyphase long hop, direct two-partition,
+    polyphase two-partition)."""
+    import torch
+    dev = torch.device("cuda:0")
+    nc, n = 5, 70001
+    x = torch.from_numpy(xorshift_uniform(nc * stride, seed=77)).to(dev)
+    rot = np.array([[np.cos(0.3 * c), np.sin(0.3 * c)] for c in range(nc)], np.float32).reshape(-1)
+    cuts = [0, 333, 40000, n]
+    e = pkg.Engine(kind, param, nc)
+    y = torch.zeros(nc * stride, device=dev)
+    torch.cuda.synchronize()
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        e.apply_dev(x.data_ptr() + 4 * a, stride, b - a, y.data_ptr() + 4 * a, stride, b - a, rot, 0)
+    e.sync()
+    e.close()
+    for c in range(nc):
+        m = pkg.Engine(kind, param, 1)
+        ym = torch.zeros(n, device=dev)
+        xc = x[c * stride:c * stride + n].contiguous()
+        torch.cuda.synchronize()
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            m.apply_dev(xc.data_ptr() + 4 * a, n, b - a, ym.data_ptr() + 4 * a, n, b - a, rot[2 * c:2 * c + 2].copy(), 0)
+        m.sync()
+        m.close()
+        got = y[c * stride:c * stride + n]
+        if stride % 2 == 0:
+            assert torch.equal(got, ym), c
+        else:
+            assert (got - ym).abs().max().item() < 2.5e-7, (c, (got - ym).abs().max().item())
+
+
+def test_in_place_device_call_is_rejected(pkg):
+    """Device streams cannot be processed in place (workgroups read each other's input regions): the call
+    must say so instead of racing.  Adjacent, non-overlapping buffers are fine."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 20000
+    buf = torch.zeros(3 * n, device=dev)
+    rot = np.array([0.6, 0.8], np.float32)
+    e = pkg.Engine(pkg.KIND_LV2, 48000, 1)
+    torch.cuda.synchronize()
+    with pytest.raises(pkg.ProtError):
+        e.apply_dev(buf.data_ptr(), n, n, buf.data_ptr(), n, n, rot, pkg.F_STATELESS)
+    with pytest.raises(pkg.ProtError):
+        e.apply_dev(buf.data_ptr(), n, n, buf.data_ptr() + 4 * (n - 1), n, n, rot, pkg.F_STATELESS)
+    e.apply_dev(buf.data_ptr(), n, n, buf.data_ptr() + 4 * n, n, n, rot, pkg.F_STATELESS)  # adjacent: allowed
+    e.sync()
+    e.close()
+
+
+def test_lv2_96k_engine_switches_form_between_long_and_short_launches(pkg):
+    """The 96 kHz LV2 engine runs the direct two-partition form on long launches and the polyphase form on
+    short ones (fewer halo blocks).  State is input history only, so a stream may alternate between them:
+    long chunk (direct), short chunks (polyphase), long again -- equal to one long launch within the gate,
+    with no step at the seams."""
+    import torch
+    dev = torch.device("cuda:0")
+    big = 1 << 25                      # 16 blocks per workgroup: direct form
+    cuts = [0, big, big + 700, big + 700 + 4096 * 3, 2 * big + 5000]
+    n = cuts[-1]
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.rand(n, generator=g, device=dev) - 0.5
+    rot = np.array([0.6, -0.8], np.float32)
+    e = pkg.Engine(pkg.KIND_LV2, 96000, 1)
+    y1 = torch.empty_like(x)
+    torch.cuda.synchronize()
+    e.apply_dev(x.data_ptr(), n, n, y1.data_ptr(), n, n, rot, pkg.F_STATELESS)   # one launch (direct form)
+    y2 = torch.empty_like(x)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        e.apply_dev(x.data_ptr() + 4 * a, n, b - a, y2.data_ptr() + 4 * a, n, b - a, rot, 0)
+    e.sync()
+    e.close()
+    d = (y1 - y2).abs()
+    assert d.max().item() < TOL, (d.max().item(), int(d.argmax().item()))
+    for c in cuts[1:-1]:
+        assert d[c - 6000:c + 6000].max().item() < TOL
+
+
+@pytest.mark.parametrize("kind,param", [(1, 48000), (0, 2048), (1, 96000)])
+def test_fp16_path_misaligned_and_multichannel(pkg, kind, param):
+    """fp16 streams that start on an odd sample (2-byte aligned only: the frame-pair loads/stores fall back
+    to single halfs) with an odd channel stride, two channels, ragged length: each channel must equal the
+    aligned mono run to an fp16 rounding error, and the frames around the buffers must stay untouched."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, stride = 100001, 100003
+    g = torch.Generator(device=dev).manual_seed(9)
+    big = ((torch.rand(2 * stride + 8, generator=g, device=dev) - 0.5) * 0.9).half()
+    x = big[1:]                               # odd offset
+    ybig = torch.full((2 * stride + 8,), 7.0, device=dev, dtype=torch.float16)
+    y = ybig[1:]
+    rot = np.array([0.6, 0.8, -0.8, 0.6], np.float32)
+    e = pkg.Engine(kind, param, 2)
+    torch.cuda.synchronize()
+    e.apply_dev_f16(x.data_ptr(), stride, n, y.data_ptr(), stride, n, rot)
+    e.sync()
+    e.close()
+    for c in range(2):
+        m = pkg.Engine(kind, param, 1)
+        xc = x[c * stride:c * stride + n].clone()    # fresh allocation: aligned
+        yc = torch.empty_like(xc)
+        torch.cuda.synchronize()
+        m.apply_dev_f16(xc.data_ptr(), n, n, yc.data_ptr(), n, n, rot[2 * c:2 * c + 2].copy())
+        m.sync()
+        m.close()
+        d = (y[c * stride:c * stride + n].float() - yc.float()).abs().max().item()
+        assert d < 2e-3, (c, d)                # one fp16 ulp at |y| <= 1 is 4.9e-4
+    # guard frames: before the first sample, between the channels' ends, after the last sample
+    assert ybig[0].item() == 7.0
+    assert (y[n:stride] == 7.0).all() and (y[stride + n:2 * stride + 7] == 7.0).all()
+
+
+@pytest.mark.parametrize("kind,param", [(1, 48000), (1, 96000), (1, 192000), (0, 1024), (0, 2048), (0, 8192)])
+@pytest.mark.parametrize("n", [1, 2, 4095, 5121, 70001])
+def test_no_frame_written_outside_the_requested_range(pkg, kind, param, n):
+    """Every default kernel form stores frame PAIRS on its fast path: with ragged lengths (1 frame, odd counts,
+    one frame past a transform block) and both buffer alignments nothing outside [0, n) of each channel may be
+    touched."""
+    import torch
+    dev = torch.device("cuda:0")
+    stride = n + 5
+    for off in (0, 1):
+        xb = torch.zeros(2 * stride + 2, device=dev)
+        xb[:] = torch.from_numpy(xorshift_uniform(2 * stride + 2, seed=n + off)).to(dev)
+        yb = torch.full((2 * stride + 2,), 9.0, device=dev)
+        x, y = xb[off:], yb[off:]
+        rot = np.array([0.6, 0.8, 0.8, -0.6], np.float32)
+        e = pkg.Engine(kind, param, 2)
+        torch.cuda.synchronize()
+        e.apply_dev(x.data_ptr(), stride, n, y.data_ptr(), stride, n, rot, 0)
+        e.sync()
+        e.close()
+        assert (y[:n] != 9.0).any() or n < 3
+        assert (y[n:stride] == 9.0).all() and (y[stride + n:2 * stride] == 9.0).all(), (off, n)
+        assert (yb[:off] == 9.0).all() and (yb[off + 2 * stride:] == 9.0).all()
+
+
+def test_cfg3_shape_against_oracle(pkg):
+    """BASELINE configs[2] in its own shape: LV2 stereo at 96 kHz (4096-tap FIR), 256 buffers of 1024 frames per STATEFUL
+    device launch, three launches back to back -- against the oracle's run() over the same 786 432 frames per channel."""
+    import torch
+    dev = torch.device("cuda:0")
+    n_chn, per = 2, 256 * 1024
+    n = 3 * per
+    x = xorshift_uniform(n_chn * n, seed=96).reshape(n_chn, n)
+    angles = [40.0, -115.0]
+    yo = orc.Lv2Engine(96000, n_chn).run_stream(x, angles, 1024)
+    e = pkg.Engine(pkg.KIND_LV2, 96000, n_chn)
+    rot = np.array([[np.cos(-2 * np.pi * a / 360.0), np.sin(-2 * np.pi * a / 360.0)] for a in angles], np.float32).reshape(-1)
+    xd = torch.from_numpy(x).to(dev)
+    yd = torch.empty_like(xd)
+    for k in range(3):
+        xin = xd[:, k * per:(k + 1) * per].contiguous()
+        yout = torch.empty_like(xin)
+        torch.cuda.synchronize()
+        e.apply_dev(xin.data_ptr(), per, per, yout.data_ptr(), per, per, rot, 0)  # stateful: the history carries over
+        e.sync()
+        yd[:, k * per:(k + 1) * per] = yout
+    yg = yd.cpu().numpy()
+    s0 = 2560 + 2 * 1024  # Q10: run() ramps from 0 deg on its first blocks; the device call starts steady
+    assert np.abs(yg[:, s0:] - yo[:, s0:]).max() < TOL
+    e.close()
+
+
+@pytest.mark.parametrize("rate,per,n_launch", [(96000, 256 * 1024, 24), (48000, 64 * 1024, 40), (96000, 20480, 33)])
+def test_pipelined_launches_equal_sequential_ones(pkg, rate, per, n_launch):
+    """PROT_CFG_PIPELINE: stateful launches on the engine's own streams alternate between two streams and
+    hand the history over on the device.  N pipelined launches must equal N sequential ones bit for bit -- outputs AND the
+    state they leave (one more, sequential, call on both engines) --, also when other calls (a ramp call, a sync, a call on
+    a caller's stream) interrupt the series and force a join, and for launches too short to qualify (n_in < history)."""
+    import torch
+    dev = torch.device("cuda:0")
+    n_chn = 2
+    n = (n_launch + 3) * per
+    x = torch.from_numpy(xorshift_uniform(n_chn * n, seed=77).reshape(n_chn, n)).to(dev)
+    rot = np.array([0.6, 0.8, -0.28, 0.96], np.float32)
+    outs = []
+    for flags in (0, pkg.CFG_PIPELINE):
+        e = pkg.Engine(pkg.KIND_LV2, rate, n_chn, flags=flags)
+        assert e.info.form in (pkg.FORM_POLY_SAVE, pkg.FORM_POLY_SAVE8K)   # (these launches are short: the 4096-point kernel either way)
+        y = torch.zeros_like(x)
+        ts = torch.cuda.Stream()
+        for k in range(n_launch):
+            xin, yout = x[:, k * per:(k + 1) * per], y[:, k * per:(k + 1) * per]
+            if k == 9:      # a call on a caller's stream in the middle of the series: ordered behind it, and the series after it
+                e.apply_dev(xin.data_ptr(), n, per, yout.data_ptr(), n, per, rot, 0, ts.cuda_stream)
+                ts.synchronize()
+            elif k == 17:   # a short call (less input than the history is long) cannot take the pipelined route
+                h = per // 2 if per // 2 < e.info.history else 1000
+                e.apply_dev(xin.data_ptr(), n, h, yout.data_ptr(), n, h, rot, 0)
+                e.apply_dev(xin.data_ptr() + 4 * h, n, per - h, yout.data_ptr() + 4 * h, n, per - h, rot, 0)
+            else:
+                e.apply_dev(xin.data_ptr(), n, per, yout.data_ptr(), n, per, rot, 0)
+            if k == 5:
+                e.sync()
+        # the state the series leaves: one more call, per-frame rotation (never pipelined)
+        k = n_launch
+        rs = torch.from_numpy(np.tile(rot, (per, 1)).reshape(per, n_chn, 2).transpose(1, 0, 2).copy()).to(dev)
+        e.apply_dev_ramp(x[:, k * per:].data_ptr(), n, per, y[:, k * per:].data_ptr(), n, per, rs.data_ptr(), 0)
+        e.sync()
+        torch.cuda.synchronize()
+        outs.append(y.cpu().numpy())
+        e.close()
+    assert np.abs(outs[0][:, :(n_launch + 1) * per]).max() > 0.05
+    assert outs[0].tobytes() == outs[1].tobytes()
+
+
+@pytest.mark.parametrize("kind,param,chn,n", [(1, 48000, 1, 50_000_017), (1, 48000, 2, 33_333_333), (0, 2048, 1, (1 << 27) - 3),
+                                              (0, 1024, 2, 40_000_001), (0, 8192, 1, 70_000_001), (1, 192000, 2, 40_000_003),
+                                              (0, 16384, 1, 60_000_001)])
+def test_rank_weighted_runs_ragged_sizes(pkg, kind, param, chn, n):
+    """One-round launches cut the stream into runs of unequal length by dispatch rank (olapoly_kernel, rank_runs in the C
+    ABI); sizes that are no multiple of anything, odd-offset channel rows, one and two channels: the one-shot stateless
+    result against the same stream pushed through in stateful chunks (whose launches are small enough for equal runs)."""
+    import torch
+    dev = torch.device("cuda:0")
+    e = pkg.Engine(kind, param, chn)
+    stride = n + 5  # rows start at odd offsets
+    g = torch.Generator(device=dev).manual_seed(1234)
+    xb = torch.rand(chn * stride + 1, generator=g, device=dev) - 0.5
+    x = xb[1:]
+    rot = np.array([0.28, -0.96, -0.6, 0.8][:2 * chn], np.float32)
+    y1 = torch.zeros(chn * stride + 1, device=dev)[1:]
+    y2 = torch.zeros(chn * stride + 1, device=dev)[1:]
+    torch.cuda.synchronize()
+    e.apply_dev(x.data_ptr(), stride, n, y1.data_ptr(), stride, n, rot, pkg.F_STATELESS)
+    pos, k = 0, 0
+    while pos < n:
+        m = min(n - pos, 1_100_003 + 7919 * (k % 5))
+        e.apply_dev(x.data_ptr() + 4 * pos, stride, m, y2.data_ptr() + 4 * pos, stride, m, rot, 0)
+        pos += m
+        k += 1
+    e.sync()
+    for c in range(chn):
+        d = (y1[c * stride:c * stride + n] - y2[c * stride:c * stride + n]).abs()
+        assert d.max().item() < TOL, (c, int(d.argmax()))
+    e.close()
+
+
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("chn", [3, 4, 6])
+def test_rank_weighted_runs_three_and_more_channels(pkg, chn, half):
+    """rank_runs with three or more channels: a channel may consist of lower-rank workgroups only, and the covering loop
+    used to lengthen the LAST rank for ever (round-2 advisor finding: the host call never returned).  One-shot launches at
+    sizes that take the rank-weighted path (>= 12 blocks per run at one round of resident workgroups) against the same
+    streams pushed through in stateful chunks; fp32 and fp16 samples."""
+    import torch
+    dev = torch.device("cuda:0")
+    e = pkg.Engine(1, 48000, chn)
+    slots = 256 * (4 if half else 3)
+    n = (slots // chn + 1) * 13 * 5120 + 777
+    stride = n + 6
+    g = torch.Generator(device=dev).manual_seed(99 + chn)
+    x = torch.rand(chn * stride, generator=g, device=dev) - 0.5
+    ang = np.linspace(0.3, 2.7, chn)
+    rot = np.stack([np.cos(ang), np.sin(ang)], 1).astype(np.float32).ravel()
+    if half:
+        x = x.half()
+        y1, y2 = torch.zeros_like(x), torch.zeros_like(x)
+        esz, one, tol = 2, e.apply_dev_f16, 4e-3
+    else:
+        y1, y2 = torch.zeros_like(x), torch.zeros_like(x)
+        esz, one, tol = 4, e.apply_dev, TOL
+    torch.cuda.synchronize()
+    if half:
+        one(x.data_ptr(), stride, n, y1.data_ptr(), stride, n, rot, flags=pkg.F_STATELESS)
+    else:
+        one(x.data_ptr(), stride, n, y1.data_ptr(), stride, n, rot, pkg.F_STATELESS)
+    pos, k = 0, 0
+    while pos < n:
+        m = min(n - pos, 900_001 + 7919 * (k % 5))
+        if half:
+            one(x.data_ptr() + esz * pos, stride, m, y2.data_ptr() + esz * pos, stride, m, rot, flags=0)
+        else:
+            one(x.data_ptr() + esz * pos, stride, m, y2.data_ptr() + esz * pos, stride, m, rot, 0)
+        pos += m
+        k += 1
+    e.sync()
+    for c in range(chn):
+        d = (y1[c * stride:c * stride + n].float() - y2[c * stride:c * stride + n].float()).abs()
+        assert d.max().item() < tol, (c, int(d.argmax()), d.max().item())
+    e.close()
+
+
+@pytest.mark.parametrize("kind,param", [(1, 48000), (1, 96000), (0, 2048)])
+def test_generated_loop_and_cpp_blocks_give_the_same_bits(pkg, kind, param):
+    """olasave_kernel runs whole in-range blocks through its generated assembly loop and every other block through C++
+    code with the same packed instructions in the same order: the two must agree BIT FOR BIT (sharded and chunked sweeps
+    rely on it: where a chunk ends decides which path a block takes).  One stream through an engine created with
+    the test option EDGE_PATH_ONLY (every block the staged way) and through a default engine; also the Hilbert-only form the sweep uses."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 3_000_017
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.rand(n, generator=g, device=dev) - 0.5
+    rot = np.array([0.28, -0.96], np.float32)
+    outs = []
+    for noasm in (False, True):
+        pkg.set_test_option(pkg.TEST_EDGE_PATH_ONLY, 1 if noasm else 0)
+        try:
+            e = pkg.Engine(kind, param, 1)
+        finally:
+            pkg.set_test_option(pkg.TEST_EDGE_PATH_ONLY, 0)
+        y, u = torch.zeros_like(x), torch.zeros_like(x)
+        torch.cuda.synchronize()
+        e.apply_dev(x.data_ptr(), n, n, y.data_ptr(), n, n, rot, pkg.F_STATELESS)
+        e.hilbert_dev(x.data_ptr(), n, n, u.data_ptr(), n, n, pkg.F_STATELESS)
+        e.sync()
+        outs.append((y, u))
+        e.close()
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][0].abs().max()) > 0.1
+
+
+# ------------------------------------------------- 8192-point blocks (round 4) ---
+@pytest.mark.parametrize("rate,chn,n,odd", [(48000, 1, (1 << 24) + 12345, 0), (96000, 1, (1 << 24) + 777, 0), (48000, 2, (1 << 23) + 4099, 0),
+                                             (96000, 2, 9_000_001, 1)])
+def test_block8192_kernel_against_oracle_and_block4096(pkg, rate, chn, n, odd):
+    """Long launches of the overlap-save LV2 engines run on 8192-point blocks (olasave8k_kernel: 512-thread workgroups, the radix-2
+    layer taken by the readers of the LDS exchanges, half-row rotation at 48 kHz).  The whole stream against the 4096-point
+    kernel (PROT_CFG_BLOCK4096: two different fp32 transforms of the same filter, 2e-6), windows of it against the CPU oracle's
+    run(), and -- every block through the LDS-staged path -- bit for bit against the generated loop.  Ragged length, stereo with
+    different rotations, an odd channel stride (4-byte aligned streams: every block staged)."""
+    import torch
+    dev = torch.device("cuda:0")
+    stride = n + 2 + odd
+    g = torch.Generator(device=dev).manual_seed(31 + chn)
+    x = torch.rand(chn * stride, generator=g, device=dev) - 0.5
+    rot = np.array([0.28, -0.96, -0.6, 0.8][:2 * chn], np.float32)
+    outs = {}
+    for tag, flags, edge in (("8k", 0, 0), ("4k", pkg.CFG_BLOCK4096, 0), ("8k-staged", 0, 1)):
+        pkg.set_test_option(pkg.TEST_EDGE_PATH_ONLY, edge)
+        try:
+            e = pkg.Engine(pkg.KIND_LV2, rate, chn, flags=flags)
+        finally:
+            pkg.set_test_option(pkg.TEST_EDGE_PATH_ONLY, 0)
+        assert int(e.info.form) == (pkg.FORM_POLY_SAVE8K if flags == 0 else pkg.FORM_POLY_SAVE)
+        y = torch.zeros_like(x)
+        e.apply_dev(x.data_ptr(), stride, n, y.data_ptr(), stride, n, rot, pkg.F_STATELESS)
+        e.sync()
+        outs[tag] = y
+        e.close()
+    assert float((outs["8k"] - outs["4k"]).abs().max()) < TOL
+    assert torch.equal(outs["8k"], outs["8k-staged"])
+    for c in range(chn):    # nothing written beyond the requested frames
+        assert float(outs["8k"][c * stride + n:(c + 1) * stride].abs().max()) == 0.0
+    # windows against the oracle: the start of the stream (history = silence), two inside, the ragged end
+    W = 16384
+    rng = np.random.default_rng(5)
+    lat = {48000: 1792, 96000: 2560}[rate]
+    for t0 in [0, n - W] + [int(v) for v in rng.integers(1 << 16, n - (1 << 16), size=2)]:
+        lo = max(0, t0 - 20000)
+        for c in range(chn):
+            xs = x[c * stride + lo:c * stride + t0 + W].cpu().numpy()[None, :]
+            o = orc.Lv2Engine(rate, 1)
+            o.activate()
+            ang = np.degrees(np.arctan2(-rot[2 * c + 1], rot[2 * c]))   # rot = {cos, sin}(-2 pi angle / 360)
+            yo = o.run_stream(xs, float(ang), 1024)[0]
+            skip = 2 * lat + 4096 if lo == 0 else 0                      # (Q10: the oracle instance ramps from 0 degrees on its first blocks)
+            got = outs["8k"][c * stride + t0 + skip:c * stride + t0 + W].cpu().numpy()
+            assert np.abs(got - yo[t0 - lo + skip:]).max() < TOL, (t0, c)
+
+
+def test_block8192_hilbert_branch_and_history(pkg):
+    """The same kernel in its Hilbert-only mode and with the engine's history in front of the stream: two stateful calls of
+    2^24 frames against one stateless call over both (the second call's first blocks read the history buffer the first one
+    wrote: the staged path's job), to rounding -- the blocks of the second call start on its own first frame."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 1 << 24
+    g = torch.Generator(device=dev).manual_seed(9)
+    x = torch.rand(2 * n, generator=g, device=dev) - 0.5
+    rot = np.array([0.0, -1.0], np.float32)
+    e = pkg.Engine(pkg.KIND_LV2, 48000, 1)
+    y1, y2, u1 = torch.zeros_like(x), torch.zeros_like(x), torch.zeros_like(x)
+    e.apply_dev(x.data_ptr(), 2 * n, 2 * n, y1.data_ptr(), 2 * n, 2 * n, rot, pkg.F_STATELESS)
+    e.hilbert_dev(x.data_ptr(), 2 * n, 2 * n, u1.data_ptr(), 2 * n, 2 * n, pkg.F_STATELESS)
+    e.reset()
+    for k in range(2):
+        e.apply_dev(x.data_ptr() + 4 * k * n, n, n, y2.data_ptr() + 4 * k * n, n, n, rot, 0)
+    e.sync()
+    assert float((y1 - y2).abs().max()) < TOL
+    # angle 90 degrees: cos = 0 to rounding, sin = -1: the rotated output is the negated Hilbert branch (to the rounding of cos)
+    assert float((y1 + u1).abs().max()) < 1e-6
+    assert float(u1.abs().max()) > 0.3
+    e.close()
