@@ -1750,7 +1750,9 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		if (first_fused) {
 			HIP_TRY (hipMemsetAsync (e->d_fused_surv.p, 0, sizeof (unsigned long long), s));
 		}
-		const bool sample_pass = !e->sweep_seeded && n_out >= (uint64_t)256 * e->info.run_align * 8;
+		// the bound is seeded from a sparse sample of the call: every k-th block, about 64 of them, at most every 8th
+		const uint64_t n_blocks    = n_out / (uint64_t)e->info.run_align;
+		const bool     sample_pass = !e->sweep_seeded && n_blocks >= 64;
 		auto fill = [&] (FusedSweep& fs, int pass) {
 			fs.peaks         = pk;
 			fs.angles        = e->d_angles.p;
@@ -1758,7 +1760,8 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 			fs.raw_slot      = raw0 ? 0 : -1;
 			fs.raw_tail      = (raw0 && !end && pass == 1) ? 1 : 0;
 			fs.sample        = pass == 0;
-			fs.stride_blocks = 256; // (64 ... 512: the same times to the run-to-run spread; the bound hardly depends on it)
+			fs.stride_blocks = (int)std::min<uint64_t> (256, std::max<uint64_t> (8, n_blocks / 64)); // (64 ... 512 on an hour of
+			// material: the same times to the run-to-run spread; the bound hardly depends on it)
 			if (const char* o = tuning_env ("PROT_FUSE_STRIDE")) {
 				fs.stride_blocks = std::max (2, atoi (o));
 			}
