@@ -283,6 +283,7 @@ def main():
     bytes_per_launch = 8.0 * n  # 4 B read + 4 B written per frame
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
     rows = int(eng.info.hop) // 512
+    is8k = int(eng.info.form) == pkg.FORM_POLY_SAVE8K
     if int(eng.info.form) == pkg.FORM_POLY_SAVE8K:
         rows8 = 16 - int(eng.info.firlen) // 1024
         kname = "olasave8k_kernel<%d, 0>" % rows8
@@ -326,9 +327,11 @@ def main():
                      "untimed launches (clocks settle over ~150 launches: DESIGN.md section 5)" % args.steps,
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "LV2 mono 48 kHz: 3072-tap Hilbert FIR (latency 1792), 4096-pt OLA in polyphase form (1536 odd taps "
-                               "on the stream read as complex samples, 5120 new frames per transform pair), angle 90 deg, "
-                               "device-resident stream of 2^%d frames per GPU per step" % args.frames_log2,
+        "config": {"workload": ("LV2 mono 48 kHz: 3072-tap Hilbert FIR (latency 1792) -- the filter of the reference's 4096-pt OLA --, in "
+                                "polyphase form (1536 odd taps on the stream read as complex samples) " +
+                                ("on 8192-point overlap-save blocks (13312 new frames per block), " if is8k else
+                                 "on 4096-point blocks (5120 new frames per block), ") +
+                                "angle 90 deg, device-resident stream of 2^%d frames per GPU per step" % args.frames_log2),
                    "partitions": int(eng.info.partitions),
                    "fftlen": int(eng.info.fftlen), "hop": int(eng.info.hop), "firlen": int(eng.info.firlen),
                    "latency": int(eng.info.latency), "frames_per_gpu": n, "streams_per_gpu": 1,
@@ -340,9 +343,12 @@ def main():
                                     "traffic_latest.json and profiles/pmc_latest.json (rocprofv3 --pmc passes of the same command, "
                                     "builder-side run, NOT this run)",
                           "kernel": klabel, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                          "binding_resource": "packed-fp32 VALU issue (4 cycles per v_pk_*_f32, tools/ubench/pk_rate.hip) at the clock the "
-                                              "chip holds under this load (1.7 GHz in-kernel, tools/sv_clock.py), with LDS at about half of "
-                                              "its cycles: DESIGN.md section 5"}, **pmc),
+                          "binding_resource": ("the stream itself at two 512-thread workgroups per CU: the kernel with its arithmetic and LDS "
+                                               "traffic removed (generator ablations, DESIGN.md section 5) takes 0.252 of the complete kernel's "
+                                               "0.2533 ms; VALU alone 0.122, LDS alone 0.098" if is8k else
+                                               "packed-fp32 VALU issue (4 cycles per v_pk_*_f32, tools/ubench/pk_rate.hip) at the clock the "
+                                               "chip holds under this load (1.7 GHz in-kernel, tools/sv_clock.py), with LDS at about half of "
+                                               "its cycles: DESIGN.md section 5")}, **pmc),
         "oracle_check": head_check,
     }
     eng.close()
@@ -579,6 +585,24 @@ def bench_sweep(args, pkg, torch, dist, dev, st, world, rank, local_rank, barrie
     96 kHz material, 16384 (cli/phase-rotate.cc:749-755: samplerate / 8 rounded up to a power of two)."""
     main_line = _bench_sweep_at(2048, True, args, pkg, torch, dist, dev, st, world, rank, local_rank, barrier)
     main_line["blksiz_16384"] = _bench_sweep_at(16384, False, args, pkg, torch, dist, dev, st, world, rank, local_rank, barrier)
+    # the sweep against ITS roofline (SURVEY 8d: 4 B read per channel-frame): achieved from this run's wall clock, traffic = HBM
+    # bytes per channel-frame by counter (tools/sweep_traffic.py under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, builder-side run
+    # on 600 s of the same material, summary committed as profiles/sweep_traffic_latest.json; NOT of this run)
+    tr = {}
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "sweep_traffic_latest.json")))
+    except Exception:
+        pass
+    cf = main_line["seconds_of_audio"] * 96000.0 * main_line["channels"]
+    for line, key in ((main_line, "harmonic_2048"), (main_line["noise_worst_case"], "noise_2048"), (main_line["blksiz_16384"], "harmonic_16384")):
+        t = tr.get(key, {})
+        ach = 4.0 * cf / (line["ms"] * 1e-3) / 1e9
+        line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                            "algorithmic_bytes_per_channel_frame": 4.0,
+                            "traffic_bytes_per_channel_frame": t.get("hbm_bytes_per_channel_frame"),
+                            "traffic": (t.get("hbm_bytes_per_channel_frame") * cf) if t.get("hbm_bytes_per_channel_frame") else None,
+                            "traffic_ratio_to_algorithmic": t.get("ratio_to_algorithmic"),
+                            "source": "achieved: this run's pass; traffic: profiles/sweep_traffic_latest.json (counter passes, builder-side run)"}
     return main_line
 
 

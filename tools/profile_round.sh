@@ -3,7 +3,7 @@
 # rocprofv3 kernel stats of the default bench command, then separate --pmc passes (never combined with traces) for HBM
 # traffic and the SQ counters of the headline kernel and of the sweep; raw output under gpurun_out/prof_<tag>/, the
 # summaries that are meant to be judged are written to profiles/ by tools/summarize_round.py (run it there, copy back).
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -21,6 +21,12 @@ rocprofv3 --output-format csv --pmc SQ_INSTS_VMEM SQ_INSTS_SALU SQ_LDS_IDX_ACTIV
 W="python3 bench.py --no-extra --no-cpu-baseline --steps 2 --warmup 1 --preroll 1 --sweep-seconds 600"
 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA -d $OUT/sw1 -- $W > /dev/null 2> $OUT/sw1.err
 rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM SQ_INSTS_SALU GRBM_GUI_ACTIVE -d $OUT/sw2 -- $W > /dev/null 2> $OUT/sw2.err
+# the sweep's HBM bytes by counter (harmonic and noise at blksiz 2048, harmonic at 16384): tools/sweep_traffic.py
+for K in harmonic_2048 noise_2048 harmonic_16384; do
+  rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/swt/fetch_$K -- python3 tools/sweep_traffic.py ${K%_*} ${K#*_} > $OUT/swt_fetch_$K.txt 2> $OUT/swt_fetch_$K.err
+  rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/swt/write_$K -- python3 tools/sweep_traffic.py ${K%_*} ${K#*_} > $OUT/swt_write_$K.txt 2> $OUT/swt_write_$K.err
+done
+python3 tools/sweep_traffic.py --summarize $OUT/swt $TAG
 rocprofv3 -L 2>/dev/null | grep -i "mfma\|SQ_INSTS_VALU\b" | head -20 > $OUT/counters_available.txt
 python3 tools/summarize_round.py $TAG $OUT
 ls $OUT

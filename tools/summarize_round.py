@@ -10,7 +10,8 @@ import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
 tag, out = sys.argv[1], sys.argv[2]
-HEAD, SWEEP, SWEEP_PLAIN = "olasave_kernel<10, 0>", "sweep_kernel<3, true>", "sweep_kernel<3, false>"
+HEAD, SWEEP, SWEEP_PLAIN = "olasave8k_kernel<13, 0>", "sweep_kernel<3, true, true>", "sweep_kernel<3, false, false>"
+SWEEP_FUSED = "olasave_kernel<12, 3>"  # the Hilbert pass with the sweep's test in its epilogue (cfg4: 96 kHz, blksiz 2048)
 
 
 def counters(d):
@@ -73,10 +74,11 @@ sq = {"note": "separate --pmc passes (8 SQ slots each); per-launch means; SQ_* s
 h = {}
 for d in ("sq1", "sq2"):
     h.update(pick(counters(os.path.join(out, d)), HEAD))
-s, s_plain = {}, {}
+s, s_plain, s_fused = {}, {}, {}
 for d in ("sw1", "sw2"):
     s.update(pick(counters(os.path.join(out, d)), SWEEP))
     s_plain.update(pick(counters(os.path.join(out, d)), SWEEP_PLAIN))
+    s_fused.update(pick(counters(os.path.join(out, d)), SWEEP_FUSED))
 if h:
     if "SQ_ACTIVE_INST_ANY" in h and "SQ_WAVE_CYCLES" in h:
         h["active_fraction = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES"] = h["SQ_ACTIVE_INST_ANY"]["mean"] / h["SQ_WAVE_CYCLES"]["mean"]
@@ -100,6 +102,8 @@ if s:
     sq["sweep"] = s
 if s_plain:
     sq["sweep_unpruned"] = s_plain
+if s_fused:
+    sq["sweep_fused_hilbert_pass"] = s_fused
 json.dump(sq, open(os.path.join(PROF, tag + "_pmc_sq.json"), "w"), indent=1)
 print(json.dumps({k: (v if not isinstance(v, dict) else v.get("mean")) for k, v in h.items()}, indent=0)[:1500])
 print(json.dumps({k: (v if not isinstance(v, dict) else v.get("mean")) for k, v in s.items()}, indent=0)[:1500])
