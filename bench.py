@@ -662,6 +662,8 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
         wall, dev_ms = timed_passes()
         pk = peaks.cpu().numpy()
         ev, seen = eng.sweep_stats()
+        exs = eng.sweep_stats_ex() if hasattr(eng, "sweep_stats_ex") else {}
+        fus = eng.sweep_stats_fused() if hasattr(eng, "sweep_stats_fused") else {"tested": 0, "listed": 0}
         pkg.set_test_option(pkg.TEST_SWEEP_UNPRUNED, 1)
         wall_np, _ = timed_passes()
         pkg.set_test_option(pkg.TEST_SWEEP_UNPRUNED, 0)
@@ -672,10 +674,9 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
             t[rank] = dev_ms
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             per_rank = [float(v) for v in t.cpu()]
-        exs = eng.sweep_stats_ex() if hasattr(eng, "sweep_stats_ex") else {}
-        fus = eng.sweep_stats_fused() if hasattr(eng, "sweep_stats_fused") else {"tested": 0, "listed": 0}
         n_ang = 359  # (angle 0 is the plain abs-max of the input, Q4)
         res[kind] = {"ms": wall * 1e3, "value": total * n_chn / wall, "unpruned_ms": wall_np * 1e3,
+                     # (of the tiles the matrix-core kernel was handed: on the fused route those are the LISTED frames' tiles)
                      "evaluated_fraction": ev / max(seen, 1), "table_identical_unpruned": same,
                      "untested_fraction": exs.get("untested", 0) / max(seen, 1),
                      # SURVEY 8d, "for completeness": the sweep reads 4 B per channel-frame (its Hilbert branch is written and
