@@ -142,7 +142,7 @@ def load_library():
 
 
 # csrc/prot_internal.h: process-wide switches for tests and bench.py (NOT part of the drop-in boundary)
-TEST_SWEEP_UNPRUNED, TEST_EDGE_PATH_ONLY, TEST_LV2_STAGED, TEST_ALLREDUCE, TEST_SWEEP_UNFUSED = 0, 1, 2, 3, 4
+TEST_SWEEP_UNPRUNED, TEST_EDGE_PATH_ONLY, TEST_LV2_STAGED, TEST_ALLREDUCE, TEST_SWEEP_UNFUSED, TEST_LV2_NO_SERVER = 0, 1, 2, 3, 4, 5
 
 
 def set_test_option(option, value):
@@ -260,6 +260,14 @@ class Engine:
         v = (C.c_uint64 * 2)()
         _check(self._lib.prot_sweep_stats_fused(self._h, v), "prot_sweep_stats_fused")
         return dict(tested=v[0], listed=v[1])
+
+    def server_stats(self):
+        """{calls, starts}: run() calls the resident server kernel has taken / kernels started for it (test hook)."""
+        v = (C.c_ulonglong * 2)()
+        self._lib.prot_internal_server_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+        self._lib.prot_internal_server_stats.restype = C.c_int
+        _check(self._lib.prot_internal_server_stats(self._h, v), "prot_internal_server_stats")
+        return dict(calls=v[0], starts=v[1])
 
     def sweep_dev(self, d_in, in_stride, n_frames, ang_start, ang_end, ang_stride, chn=-1,
                   d_peaks=0, flags=0, stream=0):

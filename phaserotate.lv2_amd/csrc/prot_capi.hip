@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <dlfcn.h>
 #include <thread>
 #include <climits>
@@ -284,6 +285,7 @@ template <typename T>
 struct PinBuf {
 	T*     p   = nullptr;
 	size_t cap = 0;
+	bool   coherent = false;
 	int    ensure (size_t n)
 	{
 		if (n <= cap) {
@@ -294,7 +296,8 @@ struct PinBuf {
 			p   = nullptr;
 			cap = 0;
 		}
-		hipError_t e = hipHostMalloc ((void**)&p, n * sizeof (T), hipHostMallocDefault);
+		// (coherent: what a RESIDENT kernel reads and writes while the host does -- the run() server's mailbox and port block)
+		hipError_t e = hipHostMalloc ((void**)&p, n * sizeof (T), coherent ? (hipHostMallocCoherent | hipHostMallocMapped) : hipHostMallocDefault);
 		if (e != hipSuccess) {
 			return hip_fail (e, "hipHostMalloc");
 		}
@@ -423,7 +426,7 @@ struct prot_engine {
 	DevBuf<unsigned> d_ctr; // [n_chn][32][32] step counters of a sweep launch (zero between launches)
 	DevBuf<float>  d_part;  // per-workgroup maxima of one sweep launch (prot_sweep.hip), allocated by the first sweep
 	DevBuf<unsigned long long> d_stats; // {tiles evaluated, tiles seen, tiles untested, surviving frames} since the last reset
-	// fused sweep (olasave_kernel MODE_SWEEP + sweep_kernel COMPACT): the survivor lists of one pass, their lengths, the step table
+	// fused sweep (olasave_kernel MODE_SWEEP + sweep_eval_kernel): the survivor lists of one pass, their lengths, the step table
 	DevBuf<float2>   d_surv;
 	DevBuf<unsigned> d_surv_cnt, d_nsteps;
 	DevBuf<uint2>    d_desc;
@@ -433,6 +436,16 @@ struct prot_engine {
 	int              last_n_lists = 0;          // geometry of the last fused pass (prot_internal_fused_lists)
 	int64_t          last_cap     = 0;
 	PinBuf<float>  h_io;
+	// the run() server (prot_olasave.hip): a resident kernel that takes prot_lv2_run's calls through a pinned mailbox
+	PinBuf<prot::SvServerBox> srv_box;
+	DevBuf<unsigned> d_srv_relay;
+	hipStream_t    srv_stream  = nullptr;
+	hipEvent_t     srv_ev      = nullptr;
+	bool           srv_eligible = false; // LV2 engine on the overlap-save kernel, <= 16 channels, not pipelined
+	bool           srv_running = false;
+	uint32_t       srv_seq     = 0;      // number of the last call posted
+	uint64_t       srv_calls   = 0;      // calls the server took / kernels started for it (prot_internal_server_stats)
+	uint64_t       srv_starts  = 0;
 	// small host->device parameter copies (rotation pairs, angle lists) are staged through a ring of
 	// pinned slots owned by the engine, each guarded by an event: the caller's array may die as soon
 	// as the call returns, and a slot is never rewritten before its previous copy has been consumed
@@ -488,7 +501,7 @@ int zero_state (prot_engine* e)
 	// what a sweep launch shares (bounds, step counters): its merge kernel leaves them zero, a launch that failed or was
 	// aborted between the two does not -- a reset restores the known-good state
 	z.p[4] = reinterpret_cast<uint32_t*> (e->d_thr.p);
-	z.n[4] = e->d_thr.p ? 4 * (size_t)e->info.n_chn : 0;
+	z.n[4] = e->d_thr.p ? prot::kSweepThrFloats * (size_t)e->info.n_chn : 0;
 	z.p[5] = reinterpret_cast<uint32_t*> (e->d_ctr.p);
 	z.n[5] = e->d_ctr.p ? (size_t)e->info.n_chn * 32 * 32 : 0;
 	hipError_t err = prot::launch_zero_regions (z, e->stream);
@@ -669,7 +682,8 @@ struct FusedSweep {
 int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_in, float* d_out,
                 int64_t out_stride, uint64_t n_out, const float* d_rot, const float* d_rot_s,
                 bool hilbert_only, bool stateless, int chn0, int n_chn, hipStream_t s, bool advance_hist = false,
-                const float* h_rot = nullptr, const uint32_t* pipe_wait_post = nullptr, FusedSweep* fs = nullptr)
+                const float* h_rot = nullptr, const uint32_t* pipe_wait_post = nullptr, FusedSweep* fs = nullptr,
+                prot::SvServerBox* srv = nullptr)
 {
 	prot::OlaParams p {};
 	if (pipe_wait_post) { // pipelined stateful launch (prot_apply_dev): history handed over on the device
@@ -710,6 +724,9 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 		}
 		return hist_advance (e, d_in, in_stride, n_in, chn0, n_chn, s);
 	};
+	if (srv && !(e->use_poly && e->use_save)) {
+		return PROT_EUNSUPPORTED;
+	}
 	if (e->use_p2 && e->d_Hp.p != nullptr && e->info.kind == PROT_KIND_LV2) {
 		// short launch of a direct-form LV2 engine: blocks per workgroup (k) against halo blocks -- direct (k + 2),
 		// polyphase 1.07 (k + 1): polyphase below k ~ 13
@@ -793,6 +810,12 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 				p.sw_thr_zero = fs->sample ? 1 : 0;
 				p.sw_t_begin  = fs->t_begin;
 				p.sw_dry_from = fs->dry_from;
+			}
+			if (srv) { // the run() server takes the call: its parameters go into the mailbox, nothing is launched
+				if (prot::post_ola_save_server (p, e->hopseg / 2, e->sv_rows, n_chn, srv) != hipSuccess) {
+					return PROT_EUNSUPPORTED; // (more than one block per channel, ...: the caller launches it)
+				}
+				return finish ();
 			}
 			hipError_t err = prot::launch_ola_save (p, e->hopseg / 2, e->sv_rows, n_chn, s);
 			if (err != hipSuccess) {
@@ -917,8 +940,65 @@ int join_pipe (prot_engine* e, hipStream_t s)
 	return PROT_OK;
 }
 
-hipStream_t pick_stream (prot_engine* e, void* stream)
+// ---- the run() server: at most ONE resident kernel per process (a resident kernel holds its hardware queue, and the
+// runtime multiplexes all streams of a process onto a few: one on a high-priority stream of its own keeps out of the way of
+// every other stream; a second LV2 instance takes the launch route).  Every other use of any engine -- a launch on an engine
+// stream, a reset, a synchronisation, create / destroy (hipFree waits for the whole device) -- first tells the server to leave
+// and waits for it; the next run() of its engine starts it again.
+std::mutex   g_srv_mu;
+prot_engine* g_srv_owner = nullptr;
+
+int server_stop_locked ()
 {
+	prot_engine* o = g_srv_owner;
+	if (o == nullptr) {
+		return PROT_OK;
+	}
+	g_srv_owner = nullptr;
+	if (o->srv_running) {
+		o->srv_running = false;
+		prot::SvServerBox* b = o->srv_box.p;
+		b->cmd               = 1u;
+		o->srv_seq           = (o->srv_seq % (1u << 30)) + 1u;
+		__atomic_store_n (&b->seq, o->srv_seq, __ATOMIC_RELEASE);
+		HIP_TRY (hipStreamSynchronize (o->srv_stream));
+	}
+	return PROT_OK;
+}
+int server_stop_any ()
+{
+	std::lock_guard<std::mutex> lk (g_srv_mu);
+	return server_stop_locked ();
+}
+// (g_srv_mu held) start e's server behind whatever the engine's own stream still has to do
+int server_start_locked (prot_engine* e)
+{
+	if (e->srv_running) { // it has left by itself (idle): the kernel is over or about to be
+		HIP_TRY (hipStreamSynchronize (e->srv_stream));
+		e->srv_running = false;
+	}
+	HIP_TRY (hipEventRecord (e->srv_ev, e->stream));
+	HIP_TRY (hipStreamWaitEvent (e->srv_stream, e->srv_ev, 0));
+	prot::SvServerBox* b = e->srv_box.p;
+	b->cmd               = 0u;
+	b->seq               = e->srv_seq;
+	__atomic_store_n (&b->alive, 1u, __ATOMIC_RELEASE);
+	hipError_t err = prot::launch_ola_save_server (b, e->d_srv_relay.p, e->srv_seq, e->hopseg / 2, (int)e->info.n_chn, e->srv_stream);
+	if (err != hipSuccess) {
+		b->alive = 0u;
+		return hip_fail (err, "run() server launch");
+	}
+	e->srv_running = true;
+	e->srv_starts++;
+	g_srv_owner = e;
+	return PROT_OK;
+}
+
+hipStream_t pick_stream (prot_engine* e, void* stream, bool keep_server = false)
+{
+	if (!keep_server) {
+		(void)server_stop_any ();
+	}
 	hipStream_t s = stream ? (hipStream_t)stream : e->stream;
 	(void)join_pipe (e, s);
 	e->last_stream = s;
@@ -989,6 +1069,7 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 		return nullptr;
 	}
 	std::call_once (g_lut_once, lut_init);
+	(void)server_stop_any (); // (engine creation allocates, uploads and synchronises: nothing resident meanwhile)
 
 	prot_info inf {};
 	inf.kind  = cfg->kind;
@@ -1266,7 +1347,7 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	    (rc = e->d_rot.ensure (2 * (size_t)inf.n_chn)) || (rc = e->d_hist[0].ensure (hn)) || (rc = e->d_hist[2].ensure (hn)) || (rc = e->d_hist[3].ensure (hn)) ||
 	    (use_poly && n_part <= 2 && ((rc = e->d_hist16[0].ensure (hn)) || (rc = e->d_hist16[1].ensure (hn)))) ||
 	    (rc = e->d_hist[1].ensure (hn)) || (rc = e->d_peaks.ensure ((size_t)PROT_MAXSAMPLE * inf.n_chn)) ||
-	    (rc = e->d_angles.ensure (PROT_MAXSAMPLE + 8)) || (rc = e->d_thr.ensure (4 * (size_t)inf.n_chn)) || (rc = e->d_ctr.ensure ((size_t)inf.n_chn * 32 * 32)) ||
+	    (rc = e->d_angles.ensure (PROT_MAXSAMPLE + 8)) || (rc = e->d_thr.ensure (prot::kSweepThrFloats * (size_t)inf.n_chn)) || (rc = e->d_ctr.ensure ((size_t)inf.n_chn * 32 * 32)) ||
 	    (rc = e->d_stats.ensure (4)) || (e->use_save && (rc = e->d_sv.ensure (sv_h.size ()))) ||
 	    (e->use_save8 && (rc = e->d_sv8.ensure (sv8_h.size ())))) {
 		return fail (rc);
@@ -1285,15 +1366,28 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	    hipMemcpy (e->d_lut.p, g_lut, sizeof (g_lut), hipMemcpyHostToDevice) != hipSuccess) {
 		return fail (PROT_EHIP);
 	}
-	if (hipMemset (e->d_thr.p, 0, 4 * (size_t)inf.n_chn * sizeof (float)) != hipSuccess ||
+	if (hipMemset (e->d_thr.p, 0, prot::kSweepThrFloats * (size_t)inf.n_chn * sizeof (float)) != hipSuccess ||
 	    hipMemset (e->d_ctr.p, 0, (size_t)inf.n_chn * 32 * 32 * sizeof (unsigned)) != hipSuccess || zero_state (e) != PROT_OK ||
 	    hipStreamSynchronize (e->stream) != hipSuccess) {
 		return fail (PROT_EHIP);
 	}
 
 	if (inf.kind == PROT_KIND_LV2) {
+		e->h_io.coherent = true; // (the server reads and writes the port block while it is resident)
 		if (lv2_reserve (e, 8192) != PROT_OK) { // run() buffers up front; prot_lv2_set_max_block raises it
 			return fail (PROT_ENOMEM);
+		}
+		// the run() server: engines on the overlap-save kernel (both LV2 rates), up to 16 channels, not pipelined
+		if (e->use_poly && e->use_save && e->d_pipe.p == nullptr && inf.n_chn <= (uint32_t)prot::kServerMaxChn && (e->hopseg == 16 || e->hopseg == 20)) {
+			int lo = 0, hi = 0;
+			(void)hipDeviceGetStreamPriorityRange (&lo, &hi); // (hi = the numerically smallest = greatest priority)
+			e->srv_box.coherent = true;
+			if (e->srv_box.ensure (1) == PROT_OK && e->d_srv_relay.ensure (16) == PROT_OK &&
+			    hipStreamCreateWithPriority (&e->srv_stream, hipStreamNonBlocking, hi) == hipSuccess &&
+			    hipEventCreateWithFlags (&e->srv_ev, hipEventDisableTiming) == hipSuccess) {
+				memset (e->srv_box.p, 0, sizeof (prot::SvServerBox));
+				e->srv_eligible = true;
+			}
 		}
 		e->interp_th = inf.blksiz * 1e-6f; // src/phaserotate.c:295
 		e->interp_nm = 1.f / inf.blksiz;   // :296
@@ -1320,6 +1414,18 @@ void prot_engine_destroy (prot_engine* e)
 		return;
 	}
 	(void)hipSetDevice (e->device);
+	(void)server_stop_any (); // (whoever's it is: hipFree waits for the whole device)
+	if (e->srv_stream) {
+		(void)hipStreamSynchronize (e->srv_stream);
+		(void)hipStreamDestroy (e->srv_stream);
+		e->srv_stream = nullptr;
+	}
+	if (e->srv_ev) {
+		(void)hipEventDestroy (e->srv_ev);
+		e->srv_ev = nullptr;
+	}
+	e->srv_box.release ();
+	e->d_srv_relay.release ();
 	for (int i = 0; i < prot_engine::kPipe; ++i) {
 		if (e->pipe_stream[i]) {
 			(void)hipStreamSynchronize (e->pipe_stream[i]);
@@ -1410,6 +1516,7 @@ int prot_engine_reset (prot_engine* e)
 		return PROT_EINVAL;
 	}
 	HIP_TRY (hipSetDevice (e->device));
+	(void)server_stop_any ();
 	(void)join_pipe (e, e->stream);
 	if (e->last_stream != nullptr && e->last_stream != e->stream && e->ev_reset != nullptr) {
 		// the engine's work on the caller's stream of its last call may still be running (its kernels read the history and
@@ -1453,6 +1560,7 @@ int prot_engine_sync (prot_engine* e)
 		return PROT_EINVAL;
 	}
 	HIP_TRY (hipSetDevice (e->device));
+	(void)server_stop_any ();
 	(void)join_pipe (e, e->stream);
 	HIP_TRY (hipStreamSynchronize (e->stream));
 	if (e->pipe_used && e->d_pipe.p) {
@@ -1760,8 +1868,8 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 			fs.raw_slot      = raw0 ? 0 : -1;
 			fs.raw_tail      = (raw0 && !end && pass == 1) ? 1 : 0;
 			fs.sample        = pass == 0;
-			fs.stride_blocks = (int)std::min<uint64_t> (256, std::max<uint64_t> (8, n_blocks / 64)); // (64 ... 512 on an hour of
-			// material: the same times to the run-to-run spread; the bound hardly depends on it)
+			fs.stride_blocks = (int)std::max<uint64_t> (8, n_blocks / 64); // (every 64th ... 512th block of an hour of material:
+			// the same times to the run-to-run spread; the bound hardly depends on it)
 			if (const char* o = tuning_env ("PROT_FUSE_STRIDE")) {
 				fs.stride_blocks = std::max (2, atoi (o));
 			}
@@ -1818,6 +1926,8 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 			sp.chn0        = c0;
 			sp.prune       = 1;
 			sp.thr         = e->d_thr.p;
+			sp.thr_blk     = e->d_thr.p + 4 * (size_t)e->info.n_chn;
+			sp.angles_host = lut_idx;
 			sp.stats       = e->d_stats.p;
 			sp.ctr         = e->d_ctr.p;
 			sp.part        = e->d_part.p;
@@ -1825,7 +1935,7 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 			sp.raw_slot    = -1; // (the raw peak went into the table from the fused pass)
 			err            = prot::launch_sweep (sp, nc, s);
 			if (err != hipSuccess) {
-				(void)hipMemsetAsync (e->d_thr.p, 0, 4 * (size_t)e->info.n_chn * sizeof (float), s);
+				(void)hipMemsetAsync (e->d_thr.p, 0, prot::kSweepThrFloats * (size_t)e->info.n_chn * sizeof (float), s);
 				(void)hipMemsetAsync (e->d_ctr.p, 0, (size_t)e->info.n_chn * 32 * 32 * sizeof (unsigned), s);
 				return hip_fail (err, "sweep kernel launch (lists)");
 			}
@@ -1885,7 +1995,7 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		if (err != hipSuccess) {
 			// the launch may have died between the sweep and its merge kernel: the shared bounds and step counters are
 			// not known to be zero any more
-			(void)hipMemsetAsync (e->d_thr.p, 0, 4 * (size_t)e->info.n_chn * sizeof (float), s);
+			(void)hipMemsetAsync (e->d_thr.p, 0, prot::kSweepThrFloats * (size_t)e->info.n_chn * sizeof (float), s);
 			(void)hipMemsetAsync (e->d_ctr.p, 0, (size_t)e->info.n_chn * 32 * 32 * sizeof (unsigned), s);
 			return hip_fail (err, "sweep kernel launch");
 		}
@@ -2039,6 +2149,7 @@ int prot_lv2_set_max_block (prot_engine* e, uint32_t frames)
 		return PROT_EINVAL;
 	}
 	HIP_TRY (hipSetDevice (e->device));
+	(void)server_stop_any ();
 	(void)join_pipe (e, e->stream);
 	HIP_TRY (hipStreamSynchronize (e->stream));
 	return lv2_reserve (e, frames);
@@ -2051,7 +2162,9 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 	const uint32_t nc = e->info.n_chn;
 	const uint32_t P  = e->info.blksiz;
 	const size_t   n  = n_samples;
-	hipStream_t    s  = pick_stream (e, nullptr);
+	// (another engine's run() server stays: this call is itself a run(); this engine's own is stopped below if the call
+	// does not go through it)
+	hipStream_t    s  = pick_stream (e, nullptr, /*keep_server*/ true);
 
 	int rc;
 	// Zero-copy (default): the kernels read the input, the per-frame rotation and write the output
@@ -2138,6 +2251,90 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 		}
 	}
 
+	// The run() server (prot_olasave.hip): the call's parameters go into the pinned mailbox, the doorbell is rung, the resident
+	// kernel does the block and stores the call's number when the output is in h_out -- no launch, no stream synchronisation.
+	// One server per process (the first LV2 engine to ask: see g_srv_owner); calls of more than one block per channel, staged
+	// calls and PROT_TEST_LV2_NO_SERVER take the launch below.  tools/run_latency.py: 38-40 us -> the figure in DESIGN.md.
+	bool served = false;
+	if (!staged && e->srv_eligible && g_test_opt[PROT_TEST_LV2_NO_SERVER].load () == 0) {
+		std::lock_guard<std::mutex> lk (g_srv_mu);
+		if (g_srv_owner == nullptr || g_srv_owner == e) {
+			prot::SvServerBox* b = e->srv_box.p;
+			const float* d_rot_c = nullptr;
+			if (steady) {
+				float* h_rotc = e->h_io.p + 4 * n * nc; // [nc][2]
+				for (uint32_t c = 0; c < nc; ++c) {
+					h_rotc[2 * c]     = h_rot[2 * n * c];
+					h_rotc[2 * c + 1] = h_rot[2 * n * c + 1];
+				}
+				d_rot_c = h_rotc;
+			}
+			const int hist_before = e->hist_cur;
+			rc = ola_launch (e, h_in, (int64_t)n, n, h_out, (int64_t)n, n, d_rot_c, steady ? nullptr : h_rot, false, false, 0, (int)nc, s,
+			                 /*advance_hist*/ true, nullptr, nullptr, nullptr, b);
+			if (rc == PROT_OK) {
+				if (!e->srv_running || __atomic_load_n (&b->alive, __ATOMIC_ACQUIRE) == 0u) {
+					rc = server_start_locked (e);
+				}
+				if (rc == PROT_OK) {
+					b->cmd     = 0u;
+					e->srv_seq = (e->srv_seq % (1u << 30)) + 1u;
+					const uint32_t seq = e->srv_seq;
+					__atomic_store_n (&b->seq, seq, __ATOMIC_RELEASE);
+					// wait for every channel's done word; a server that left by itself between the check above and the doorbell
+					// (idle time-out) is started again -- with the number of the last served call, so that it takes this one at once
+					const auto t_0 = std::chrono::steady_clock::now ();
+					for (uint32_t c = 0; c < nc;) {
+						if (__atomic_load_n (&b->done[c], __ATOMIC_ACQUIRE) == seq) {
+							++c;
+							continue;
+						}
+						if (__atomic_load_n (&b->alive, __ATOMIC_ACQUIRE) == 0u) {
+							HIP_TRY (hipStreamSynchronize (e->srv_stream)); // the kernel is over: what it served is complete
+							bool all = true;
+							for (uint32_t k = 0; k < nc; ++k) {
+								all = all && __atomic_load_n (&b->done[k], __ATOMIC_ACQUIRE) == seq;
+							}
+							if (all) {
+								break;
+							}
+							e->srv_running = false;
+							e->srv_seq     = seq - 1u; // (any number but seq: the new kernel takes the call at once)
+							rc             = server_start_locked (e);
+							e->srv_seq     = seq;
+							if (rc) {
+								return rc;
+							}
+							__atomic_store_n (&b->seq, seq, __ATOMIC_RELEASE);
+							continue;
+						}
+						if (std::chrono::steady_clock::now () - t_0 > std::chrono::seconds (2)) {
+							snprintf (g_err, sizeof (g_err), "run() server: call %u not served within 2 s", seq);
+							return PROT_EHIP;
+						}
+					}
+					e->srv_calls++;
+					served = true;
+				}
+			} else if (rc == PROT_EUNSUPPORTED) {
+				(void)hist_before; // (ola_launch returns before it touches the engine's state when the server cannot take the call)
+				rc = PROT_OK;
+			}
+			if (rc) {
+				return rc;
+			}
+			if (!served) {
+				(void)server_stop_locked (); // the launch below uses the engine's stream and history
+			}
+		}
+	}
+	if (served) {
+		e->pos += n;
+		for (uint32_t c = 0; c < nc; ++c) {
+			memcpy (out[c] + off, h_out + c * n, n * sizeof (float));
+		}
+		return PROT_OK;
+	}
 	if (!staged) {
 		const float* d_rot_c = nullptr;
 		if (steady) {
@@ -2159,6 +2356,12 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 			memcpy (out[c] + off, h_out + c * n, n * sizeof (float));
 		}
 		return PROT_OK;
+	}
+	{ // (the staged route uses the engine's stream and history: not beside this engine's own server)
+		std::lock_guard<std::mutex> lk (g_srv_mu);
+		if (g_srv_owner == e) {
+			(void)server_stop_locked ();
+		}
 	}
 	HIP_TRY (hipMemcpyAsync (e->d_in.p, h_in, n * nc * sizeof (float), hipMemcpyHostToDevice, s));
 	if (steady) {
@@ -2665,6 +2868,16 @@ int prot_internal_fused_lists (prot_engine* e, unsigned long long out[4])
 	out[1] = (unsigned long long)(uintptr_t)e->d_surv_cnt.p;
 	out[2] = (unsigned long long)e->last_n_lists;
 	out[3] = (unsigned long long)e->last_cap;
+	return PROT_OK;
+}
+
+int prot_internal_server_stats (prot_engine* e, unsigned long long out[2])
+{
+	if (!e || !out) {
+		return PROT_EINVAL;
+	}
+	out[0] = e->srv_calls;
+	out[1] = e->srv_starts;
 	return PROT_OK;
 }
 

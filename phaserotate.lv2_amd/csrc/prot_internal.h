@@ -14,13 +14,16 @@ enum {
 	PROT_TEST_LV2_STAGED     = 2, // != 0: prot_lv2_run copies its buffers through staging memory whatever their size
 	PROT_TEST_ALLREDUCE      = 3, // 0 automatic; 1 merge through the host; 2 the RCCL collective even when engines share a device
 	PROT_TEST_SWEEP_UNFUSED  = 4, // != 0: prot_sweep_dev keeps the separate Hilbert and sweep passes where it would fuse them (bit-identical tables)
-	PROT_TEST_OPTIONS        = 5
+	PROT_TEST_LV2_NO_SERVER  = 5, // != 0: prot_lv2_run launches every call (no resident server kernel)
+	PROT_TEST_OPTIONS        = 6
 };
 int prot_internal_set_test_option (int option, int value); // 0 or PROT_EINVAL
 // the lists the last fused sweep pass of the engine left (device pointers, valid until the next sweep): float2 entries (dry, hilbert),
 // list l of channel c at entry (c * n_lists + l) * cap, its length in cnt[c * n_lists + l]; out = { surv, cnt, n_lists, cap }
 struct prot_engine;
 int prot_internal_fused_lists (struct prot_engine* e, unsigned long long out[4]);
+// the run() server of an LV2 engine: out = { calls it has taken, kernels started for it }
+int prot_internal_server_stats (struct prot_engine* e, unsigned long long out[2]);
 #ifdef __cplusplus
 }
 #endif

@@ -103,6 +103,18 @@ hipError_t launch_ola_poly_f16 (const OlaParamsH& p, int n_part, int hop_rows, i
 hipError_t launch_ola_save (const OlaParams& p, int hop_rows, int n_rho_rows, int n_chn, hipStream_t s);
 // the same on 8192-point blocks (prot_olasave8k.hip): 512-thread workgroups, two per CU; hop_rows in {12, 13} (x 1024 new
 // frames per block: firlen = 1024 (16 - hop_rows)); p.sv = the five-row table of save_tables8k; no pipelined launches
+// ---- the run() server (prot_olasave.hip): pinned, host-coherent mailbox of one LV2 engine
+constexpr int kServerMaxChn = 16;
+struct SvServerBox {
+	uint32_t          seq;      // host -> device: the call's number (1 .. 2^30, never the same twice in a row), stored LAST: the doorbell
+	uint32_t          cmd;      // host -> device: 0 run the call in p, 1 leave
+	uint32_t          alive;    // device -> host: set by the host before the launch, cleared by the kernel as its last store
+	uint32_t          pad0[13];
+	uint32_t          done[kServerMaxChn]; // device -> host: done[c] = seq when channel c's output (and its next history) is complete
+	OlaParamsT<float> p;        // host -> device: what the launch would have carried
+};
+hipError_t launch_ola_save_server (SvServerBox* box, unsigned* relay, unsigned last_seq, int hop_rows, int n_chn, hipStream_t s);
+hipError_t post_ola_save_server (const OlaParamsT<float>& p, int hop_rows, int n_rho_rows, int n_chn, SvServerBox* box);
 hipError_t launch_ola_save8k (const OlaParams& p, int hop_rows, int n_chn, hipStream_t s);
 
 // fp16 sample path (BASELINE config 5): half samples in HBM, packed-half butterflies,
@@ -143,15 +155,23 @@ struct SweepParams {
 	float*       part;        // device scratch, >= sweep_scratch_floats () floats: per-workgroup maxima of one launch (merged into peaks)
 	size_t       part_floats;
 	unsigned long long* stats; // device, [4] += {tiles evaluated, tiles seen, tiles fed untested, surviving frames of tested tiles}, or NULL
-	// COMPACT source (surv != NULL; round 4): the frames come as (d, h) pairs from the lists the fused Hilbert pass left
+	// the LISTS as the source (surv != NULL; round 4; "compact" in launch_sweep): the frames come as (d, h) pairs from the lists the fused Hilbert pass left
 	// (olasave_kernel MODE_SWEEP) instead of from x, hist and u: step gs of channel c is desc[c * desc_stride + gs] = {first entry
 	// (index into surv), entries (1..1024)}, n_steps[c] steps in all (sweep_plan_kernel); x, u, t_begin .. delay are unused
 	const float2*   surv;
 	const uint2*    desc;
 	int64_t         desc_stride;
 	const unsigned* n_steps;
+	// ... evaluated by sweep_eval_kernel, which tests every listed frame against each BLOCK of 32 angles: thr_blk = device,
+	// [n_chn][16] shared per-block bounds (zeros at launch, left so by the merge kernel); sect[b] = {cos psi, sin psi, cos D, sin D}
+	// of block b's angles: all of them lie within D of psi (modulo pi; margins included; D <= pi / 2), launch_sweep fills it
+	// from angles_host
+	float*          thr_blk;
+	const int*      angles_host; // the same n_angles LUT indices on the host (lists only)
+	float           sect[12][4];
 };
-// the step table of a COMPACT sweep from the list lengths: cnt[c][n_lists] -> desc, n_steps; list l of channel c starts at entry
+constexpr int kSweepThrFloats = 4 + 16; // per channel: thr [n_chn][4], then thr_blk [n_chn][16]
+// the step table of a sweep over lists from the list lengths: cnt[c][n_lists] -> desc, n_steps; list l of channel c starts at entry
 // (c * n_lists + l) * cap
 // (total, optional: += the number of entries of all lists)
 hipError_t launch_sweep_plan (const unsigned* cnt, int n_lists, int64_t cap, uint2* desc, int64_t desc_stride, unsigned* n_steps, int n_chn,

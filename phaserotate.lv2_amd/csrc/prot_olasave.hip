@@ -27,6 +27,8 @@
 // workgroup-wide and one wave-local LDS exchange per direction (prot_dev.h), packed-fp32 butterflies, split outer twiddles.
 #include "prot_dev.h"
 
+#include <cstring>
+
 namespace prot {
 
 typedef volatile __attribute__ ((address_space (3))) f2 LdsC;
@@ -87,7 +89,7 @@ extern "C" int prot_debug_sv_wg (unsigned long long* out, int n_wg)
 //    the generated CORE (the same instructions on the same values: the two paths agree bit for bit, and a sharded or chunked
 //    sweep does not depend on where its chunks end), and stored from LDS with bounds.
 template <int HS, int MODE>
-__global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
+PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_lo_s)
 {
 	constexpr int BLK = 512 * HS; // output frames per block
 	constexpr int NT  = 16 - HS;  // context rows
@@ -95,8 +97,6 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 	constexpr int AM  = MODE == MODE_ROT ? 0 : 2; // the generated code's mode (per-frame rotation, sweep: Hilbert branch, mixed / tested here)
 	static_assert (HS == 8 || HS == 10 || HS == 12, "rows per block (HS = 14 needs 124 VGPRs before any temporary: olapoly_kernel)");
 	static_assert (MODE != MODE_SWEEP || HS != 10, "the fused sweep exists for the CLI engines (blksiz 2048, 4096)");
-
-	__shared__ f2 smem[kLdsExchange + 512]; // the exchange area + the two W256 tables (written by the generated prologue)
 
 	const int t0 = threadIdx.x;
 	const int c  = blockIdx.y;
@@ -111,7 +111,6 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 	const bool piped = MODE != MODE_SWEEP && p.hs_flag != nullptr;
 	// MODE_SWEEP: the bound of this launch -- the smallest of the table's entries for the call's angles as they stand now (they only
 	// grow: a lower bound of every final peak), squared, less prot_sweep.hip's margin; every wave appends to a list of its own
-	__shared__ float sw_lo_s[4];
 	float            sw_raw = 0.f;
 	// (the bound is parked in global memory -- behind the list lengths, one copy per wave -- and re-read where it is used: a
 	// register copy would live across the generated code.  An LDS word behind the exchange area was tried first and read back
@@ -431,6 +430,127 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 			}
 		}
 	}
+}
+
+template <int HS, int MODE>
+__global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
+{
+	__shared__ f2    smem[kLdsExchange + 512]; // the exchange area + the two W256 tables (written by the generated prologue)
+	__shared__ float sw_lo_s[4];
+	olasave_body<HS, MODE> (p, smem, sw_lo_s);
+}
+
+// ---- the run() server (round 4) ----------------------------------------------------------------------------------------------
+// An LV2 host calls run() (src/phaserotate.c:774-852) with ~1024 frames at a time, and a kernel launch plus a stream
+// synchronisation cost more than the block itself: 38-40 us per call, no faster than one host core.  The server is the same block
+// code as a RESIDENT kernel -- one workgroup per channel, started by the first run() and left running: the host stores the call's
+// parameters (the OlaParams the launch would have carried) and its input into pinned, host-coherent memory and rings a doorbell
+// word; workgroup 0 polls the doorbell over the host link, relays the decision to the other channels' workgroups through a
+// device word (ONE decision for all: serve call s, or leave), every workgroup runs the call's block with the code of the
+// launched kernel (olasave_body: same bits), publishes its output with a system-scope release and stores the call's number into
+// its done word, which the host polls.  No launch, no stream synchronisation, no copy command per call.
+// Leaving: on the host's stop command (any other use of the engine stops the server first: prot_capi.hip) and BY ITSELF after
+// 0.25 s without a doorbell (s_memrealtime: 100 MHz) -- a resident kernel blocks whatever shares its hardware queue and
+// every device-wide synchronisation of the process, so it never outlives the stream of calls it serves; `alive` is its last
+// store.  The host treats a server that has left as absent and starts a new one (with the last served call's number).
+constexpr uint64_t kServerIdleTicks = 25000000ull;
+
+template <int HS>
+__global__ __launch_bounds__ (256, 1) void olasave_server_kernel (SvServerBox* const box, unsigned* const relay, const unsigned last_seq)
+{
+	__shared__ f2       smem[kLdsExchange + 512];
+	__shared__ float    sw_lo_s[4];
+	__shared__ unsigned sh_w[2];
+	__shared__ __attribute__ ((aligned (16))) unsigned sh_p[(sizeof (OlaParams) + 3) / 4]; // the call's parameters (read in place)
+	const int tid  = threadIdx.x;
+	unsigned  seen = last_seq;
+	for (;;) {
+		if (tid == 0) {
+			unsigned word;
+			if (blockIdx.y == 0) {
+				unsigned       s = seen, cmd = 0u;
+				const uint64_t t_0 = __builtin_amdgcn_s_memrealtime ();
+				for (;;) {
+					s = __hip_atomic_load (&box->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					if (s != seen) {
+						cmd = __hip_atomic_load (&box->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ? 1u : 0u;
+						break;
+					}
+					if (__builtin_amdgcn_s_memrealtime () - t_0 > kServerIdleTicks) {
+						cmd = 1u;
+						break;
+					}
+					__builtin_amdgcn_s_sleep (4);
+				}
+				word = 2u * s + cmd;
+				if (gridDim.y > 1) {
+					__hip_atomic_store (relay, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+			} else {
+				while ((word = __hip_atomic_load (relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 2u * seen) {
+					__builtin_amdgcn_s_sleep (2);
+				}
+			}
+			sh_w[0] = word;
+		}
+		__syncthreads ();
+		const unsigned word = sh_w[0];
+		if (word & 1u) {
+			break;
+		}
+		// the host's stores (parameters, input frames, per-frame rotation) happened before its doorbell store
+		__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "");
+		for (int i = tid; i < (int)(sizeof (OlaParams) / 4); i += 256) {
+			sh_p[i] = __hip_atomic_load (reinterpret_cast<unsigned*> (&box->p) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+		__syncthreads ();
+		const OlaParams& p = *reinterpret_cast<const OlaParams*> (sh_p);
+		if (p.rot_s != nullptr) {
+			olasave_body<HS, MODE_RAMP> (p, smem, sw_lo_s);
+		} else {
+			olasave_body<HS, MODE_ROT> (p, smem, sw_lo_s);
+		}
+		__builtin_amdgcn_fence (__ATOMIC_RELEASE, ""); // output frames and the next history: visible to the host / to later launches
+		__syncthreads ();
+		if (tid == 0) {
+			__hip_atomic_store (&box->done[blockIdx.y], word >> 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+		seen = word >> 1;
+	}
+	if (tid == 0 && blockIdx.y == 0) {
+		__hip_atomic_store (&box->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+}
+
+hipError_t launch_ola_save_server (SvServerBox* box, unsigned* relay, unsigned last_seq, int hop_rows, int n_chn, hipStream_t s)
+{
+	if (n_chn < 1 || n_chn > kServerMaxChn) {
+		return hipErrorInvalidValue;
+	}
+	hipError_t err = hipMemsetD32Async (reinterpret_cast<hipDeviceptr_t> (relay), (int)(2u * last_seq), 1, s);
+	if (err != hipSuccess) {
+		return err;
+	}
+	const dim3 grid (1, (unsigned)n_chn), block (256);
+	switch (hop_rows) {
+		case 8: hipLaunchKernelGGL ((olasave_server_kernel<8>), grid, block, 0, s, box, relay, last_seq); break;
+		case 10: hipLaunchKernelGGL ((olasave_server_kernel<10>), grid, block, 0, s, box, relay, last_seq); break;
+		default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError ();
+}
+
+// what launch_ola_save checks, for a call the server is to take: one workgroup per channel, rotation (steady or per frame) --
+// and the parameters go into the box instead of into a launch
+hipError_t post_ola_save_server (const OlaParams& p, int hop_rows, int n_rho_rows, int n_chn, SvServerBox* box)
+{
+	if ((p.dry_delay & 1) || (p.run_frames % (512 * hop_rows)) != 0 || p.accumulate || p.sv == nullptr || n_rho_rows != 1 ||
+	    2 * (p.dry_delay - p.conv_delay) != 512 * (16 - hop_rows) || p.n_out <= 0 || p.run_stride != 0 || p.surv != nullptr || p.hilbert_only ||
+	    p.hs_flag != nullptr || (p.n_out + p.run_frames - 1) / p.run_frames != 1 || n_chn > kServerMaxChn || (hop_rows != 8 && hop_rows != 10)) {
+		return hipErrorInvalidValue;
+	}
+	memcpy (&box->p, &p, sizeof (OlaParams));
+	return hipSuccess;
 }
 
 template <int HS>

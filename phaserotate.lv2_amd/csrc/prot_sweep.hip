@@ -31,10 +31,29 @@
 #include "prot_kernels.h"
 
 #include <algorithm>
+#include <cmath>
+#include <cstring>
 
 namespace prot {
 
 typedef float f32x16 __attribute__ ((ext_vector_type (16)));
+
+// max over the 32 lanes of each half of the wave by DPP (quad_perm [1 0 3 2], [2 3 0 1], row_ror 4 and 8, then row_bcast15 into
+// the odd rows): five VALU instructions, the result valid in lanes 16-31 and 48-63.  (__shfl_xor compiles to ds_bpermute_b32 and
+// a wait each: the 240 of a wave's final 48-value reduction were ~12 us of every sweep launch.)
+template <int CTRL, int ROW_MASK = 0xf>
+PROT_DEV float dpp_move (float old, float v)
+{
+	return __uint_as_float ((unsigned)__builtin_amdgcn_update_dpp ((int)__float_as_uint (old), (int)__float_as_uint (v), CTRL, ROW_MASK, 0xf, false));
+}
+PROT_DEV float half_max_odd_rows (float v)
+{
+	v = fmaxf (v, dpp_move<0xB1> (v, v));
+	v = fmaxf (v, dpp_move<0x4E> (v, v));
+	v = fmaxf (v, dpp_move<0x124> (v, v));
+	v = fmaxf (v, dpp_move<0x128> (v, v));
+	return fmaxf (v, dpp_move<0x142, 0xa> (v, v)); // rows 1 and 3: max (own row, the row before)
+}
 
 constexpr int kStage  = 1024;             // frames per step: loaded ONCE per workgroup, shared through LDS
 constexpr int kSteps  = 8;                // steps between two looks at the shared bound
@@ -44,7 +63,7 @@ static_assert (kRing >= 64 + kBatch && (kRing & (kRing - 1)) == 0, "ring too sma
 constexpr unsigned kCtr = 32;             // step counters per channel (a cache line each): workgroup b draws from counter b mod kCtr
 constexpr int kPause0 = 2, kPauseMax = 256; // steps fed untested after a step on which > 7/8 of the frames survived: first, cap
 
-template <int NBLK, bool PRUNE, bool COMPACT = false>
+template <int NBLK, bool PRUNE>
 __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const SweepParams p)
 {
 	__shared__ float stage_s[2 * 2 * kStage]; // [buffer][d | h][frame]: planar, so that a loaded dwordx4 is parked as it is
@@ -220,8 +239,7 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 	// A step's frames are loaded once per workgroup and parked in LDS, where all four waves test them; with every wave
 	// loading every frame itself (rounds 1-2) the loads in flight per CU were 4 x redundant.
 	__shared__ unsigned sh_seq[8];
-	const unsigned  n_total = COMPACT ? (unsigned)__builtin_amdgcn_readfirstlane ((int)p.n_steps[blockIdx.y])
-	                                  : p.t_end > p.t_begin ? (unsigned)((p.t_end - p.t_begin + kStage - 1) / kStage) : 0u;
+	const unsigned  n_total = p.t_end > p.t_begin ? (unsigned)((p.t_end - p.t_begin + kStage - 1) / kStage) : 0u;
 	// (kCtr counters per channel, each on a cache line of its own, each handing out every kCtr-th step to the workgroups
 	// with that blockIdx.x mod kCtr: ONE counter serves its atomics one at a time -- 675 K of them made cfg4 9 ms instead of 3)
 	// (a launch of fewer than kCtr workgroups per channel -- many channels, a small device -- uses as many counters as it has
@@ -260,21 +278,7 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 		return (base + kStage <= p.t_end) && (base - p.delay >= 0) && (base + kStage - p.delay <= p.n_x) &&
 		       (base + p.t_abs0 >= p.dry_from);
 	};
-	// COMPACT: entries [first, first + n) of the lists; a lane takes four consecutive (d, h) pairs twice (what lies beyond n -- the
-	// rest of a list's last step -- is allocated memory and is zeroed when it is parked)
-	const uint2* const dsc = COMPACT ? p.desc + (int64_t)blockIdx.y * p.desc_stride : nullptr; // (lists, tables: by the launch's own channel index)
 	auto request = [&] (unsigned s) { // frames of step s -> dv, hv (plain stream only; the edges are fetched when they are parked)
-		if (COMPACT) {
-			const uint2         ds = dsc[s];
-			const float4* const q  = reinterpret_cast<const float4*> (p.surv + (int64_t)ds.x + ld_half + 4 * lane);
-#pragma unroll
-			for (int i = 0; i < 2; ++i) {
-				const float4 a = q[128 * i], b = q[128 * i + 1]; // entries 256 i + 4 lane .. + 3: (d0 h0 d1 h1) (d2 h2 d3 h3)
-				dv[i]          = make_float4 (a.x, a.z, b.x, b.z);
-				hv[i]          = make_float4 (a.y, a.w, b.y, b.w);
-			}
-			return;
-		}
 		int64_t t0;
 		if (locate (s, t0)) {
 			typedef float f4u __attribute__ ((ext_vector_type (4), aligned (4)));
@@ -288,24 +292,6 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 		}
 	};
 	auto park = [&] (int buf, unsigned s) { // frames of step s: dv, hv -> (d, h) pairs of the stage
-		if (COMPACT) {
-			const int n = (int)dsc[s].y;
-#pragma unroll
-			for (int i = 0; i < 2; ++i) {
-				const int    e0 = ld_half + 256 * i + 4 * lane;
-				float* const q  = stage_s + buf * 2 * kStage + e0;
-				const float4 z  = make_float4 (0.f, 0.f, 0.f, 0.f);
-				float4       d = dv[i], h = hv[i];
-				if (e0 + 4 > n) { // (|0| never raises a maximum)
-					d = make_float4 (e0 < n ? d.x : 0.f, e0 + 1 < n ? d.y : 0.f, e0 + 2 < n ? d.z : 0.f, 0.f);
-					h = make_float4 (e0 < n ? h.x : 0.f, e0 + 1 < n ? h.y : 0.f, e0 + 2 < n ? h.z : 0.f, 0.f);
-				}
-				(void)z;
-				*reinterpret_cast<float4*> (q)          = d;
-				*reinterpret_cast<float4*> (q + kStage) = h;
-			}
-			return;
-		}
 		int64_t t0;
 		if (locate (s, t0)) {
 #pragma unroll
@@ -339,7 +325,7 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 			}
 		}
 	};
-	if (!COMPACT && p.raw_slot >= 0 && p.raw_tail && blockIdx.x == 0) {
+	if (p.raw_slot >= 0 && p.raw_tail && blockIdx.x == 0) {
 		// the call's last `delay` input frames: the loaders reach them only as the next chunk's history (x[t - delay], t < t_end),
 		// the reference's calc_peak has them in this block -- folded here so that peaks[c][0] is complete when the call returns
 		for (int64_t i = p.n_x - p.delay + tid; i < p.n_x; i += 256) {
@@ -563,15 +549,342 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 	for (int q = 0; q < NBLK; ++q) {
 #pragma unroll
 		for (int r = 0; r < 16; ++r) {
-			float v = m[q][r];
-			v       = fmaxf (v, __shfl_xor (v, 1));
-			v       = fmaxf (v, __shfl_xor (v, 2));
-			v       = fmaxf (v, __shfl_xor (v, 4));
-			v       = fmaxf (v, __shfl_xor (v, 8));
-			v       = fmaxf (v, __shfl_xor (v, 16));
-			const int row = (r & 3) + 8 * (r >> 2) + 4 * kk_e;
-			const int idx = (g + q * G) * 32 + row;
-			if (j_e == 0 && g + q * G < nb && idx < p.n_angles) {
+			const float v   = half_max_odd_rows (m[q][r]); // (valid in lanes 16-31, 48-63)
+			const int   row = (r & 3) + 8 * (r >> 2) + 4 * kk_e;
+			const int   idx = (g + q * G) * 32 + row;
+			if (j_e == 16 && g + q * G < nb && idx < p.n_angles) {
+				part[idx] = v;
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// sweep_eval_kernel (round 4): the matrix-core evaluation of the LISTS the fused Hilbert pass left (olasave_kernel MODE_SWEEP:
+// the (d, h) pairs of the frames whose r exceeds the smallest peak of the whole table).  A listed frame matters to few angles:
+// |ca d + sa h| = r |cos (a - phi)| (phi = the frame's phase), so against a BLOCK of 32 angles that all lie within D of psi
+// (modulo pi) it can reach at most r cos (max (0, delta - D)), delta = the distance of phi from psi folded into [0, pi / 2]:
+// with u = |d cos psi + h sin psi| = r |cos (phi - psi)| and v = |h cos psi - d sin psi| = r |sin (phi - psi)| that is r when
+// v <= u tan D, and u cos D + v sin D otherwise -- ten VALU operations per frame and block.  Every wave tests the listed frames
+// against each of its (up to three) blocks' own bounds -- the smallest table entry of the block's angles at launch, raised by
+// what the block's running maxima and the other workgroups (p.thr_blk) prove since -- and compacts the survivors into a ring
+// per block; the matrix core sees full tile pairs of one block's survivors.  On the 60-minute material 3-6 % of the (listed
+// frame, block) pairs survive (harmonic stack 4.6 %, stationary noise 3.4 %: a frame barely above the smallest peak of the
+// table is below the bound of most blocks, and above it only near its own phase).
+// Exact for the same reason as the list test: a (frame, block) pair that fails could not have raised a maximum of the block;
+// the margins (D widened by 2e-3 rad, 2e-6 (u + v) added to the reach, 1e-4 relative on the bounds) cover the float rounding of the test, of the
+// table's sines and cosines and of the product itself (each ~1e-7 r).  A block whose angles span the half circle (a coarse pass: every 24th
+// angle) has D = pi / 2: the test is r > bound.
+constexpr int kERing = 128; // (d, h) entries of one block's ring: < 64 left over + 64 new
+
+template <int NBLK>
+__global__ __launch_bounds__ (256, 4) void sweep_eval_kernel (const SweepParams p)
+{
+	__shared__ float    stage_s[2 * 2 * kStage];
+	__shared__ float2   ring_s[4 * NBLK * kERing];
+	__shared__ unsigned sh_seq[8];
+
+	const int tid  = threadIdx.x;
+	const int w    = __builtin_amdgcn_readfirstlane (tid >> 6);
+	const int lane = tid & 63;
+	const int j    = lane & 31;
+	const int kk   = lane >> 5;
+	const int c    = p.chn0 + blockIdx.y;
+
+	const int  nb   = (p.n_angles + 31) >> 5;
+	const int  G    = nb >= 3 ? 4 : nb;
+	const int  wr_  = (w + (int)blockIdx.x) & 3; // (as in sweep_kernel: the place in the scratch table the merge kernel expects)
+	const int  g    = wr_ % G;
+	const int  sub  = wr_ / G;
+	const int  nsub = 4 / G;
+	const bool idle = g >= nb;
+
+	auto uniform_f = [] (float v) { return __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (v))); };
+	auto wave_min  = [] (float v) {
+		v = fminf (v, __shfl_xor (v, 1));
+		v = fminf (v, __shfl_xor (v, 2));
+		v = fminf (v, __shfl_xor (v, 4));
+		v = fminf (v, __shfl_xor (v, 8));
+		v = fminf (v, __shfl_xor (v, 16));
+		v = fminf (v, __shfl_xor (v, 32));
+		return v;
+	};
+	constexpr float kBig = 1.0e18f;
+
+	float a_op[NBLK];
+	float cps[NBLK], sps[NBLK], cdl[NBLK], sdl[NBLK], tdl[NBLK]; // the blocks' sectors (wave-uniform)
+	float bnd[NBLK], bnd2[NBLK];                                 // the blocks' bounds, margin included (wave-uniform)
+	unsigned* slot[NBLK];
+#pragma unroll
+	for (int q = 0; q < NBLK; ++q) {
+		const int  blk = g + q * G;
+		const int  idx = blk * 32 + j;
+		const bool ok  = blk < nb && idx < p.n_angles;
+		float      v = 0.f, lo = kBig;
+		if (ok) {
+			const int a = p.angles[idx];
+			v           = p.lut[2 * a + (kk ? 0 : 1)]; // lut = {sin, cos}
+			lo          = __builtin_nontemporal_load (&p.peaks[(int64_t)c * kMaxSample + a]);
+		}
+		a_op[q]      = v;
+		lo           = wave_min (lo); // (a block without angles keeps kBig: nothing passes its test)
+		bnd[q]       = uniform_f (lo * 0.99995f);
+		bnd2[q]      = uniform_f (lo * lo * 0.9999f);
+		const int bs = blk < 12 ? blk : 0;
+		cps[q]       = p.sect[bs][0];
+		sps[q]       = p.sect[bs][1];
+		cdl[q]       = p.sect[bs][2] + 2e-6f;
+		sdl[q]       = p.sect[bs][3] + 2e-6f;
+		tdl[q]       = p.sect[bs][2] > 1e-6f ? p.sect[bs][3] / p.sect[bs][2] : 1e30f;
+		slot[q]      = reinterpret_cast<unsigned*> (p.thr_blk) + ((int64_t)c * 16 + bs);
+	}
+#pragma unroll
+	for (int q = 0; q < NBLK; ++q) {
+		asm volatile ("" : "+v"(a_op[q])); // (see sweep_kernel: keeps the first s_waitcnt of these loads out of the loop)
+	}
+	f32x16 m[NBLK];
+#pragma unroll
+	for (int q = 0; q < NBLK; ++q) {
+#pragma unroll
+		for (int r = 0; r < 16; ++r) {
+			m[q][r] = 0.f;
+		}
+	}
+	const f32x16 zero = m[0];
+
+	// what the block's running maxima prove by now, shared with every workgroup that serves the block (read first, atomicMax only
+	// when it improves: sweep_kernel's rule)
+	// (a lane's smallest maximum among its 16 rows bounds the smallest final peak of those rows from below, so does the LARGEST such
+	// value among the 32 lanes of the half -- one loud frame raises all 32 angles of a block to within cos 8 deg of its r, so this is
+	// nearly the min over rows of the max over lanes, for 16 v_min and 5 DPP instead of 80 reductions --; the block's bound is the
+	// smaller of the two halves')
+	auto refresh = [&] (int q, f32x16& mq) {
+		const int blk = g + q * G;
+		float     lo  = kBig;
+#pragma unroll
+		for (int r = 0; r < 16; ++r) {
+			const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+			if (blk < nb && blk * 32 + row < p.n_angles) {
+				lo = fminf (lo, mq[r]);
+			}
+		}
+		lo            = lo >= kBig ? -1.f : lo; // (a half without rows must not win the max)
+		const float v = half_max_odd_rows (lo);
+		const float h0 = __uint_as_float ((unsigned)__builtin_amdgcn_readlane ((int)__float_as_uint (v), 16));
+		const float h1 = __uint_as_float ((unsigned)__builtin_amdgcn_readlane ((int)__float_as_uint (v), 48));
+		lo             = h0 < 0.f ? h1 : h1 < 0.f ? h0 : fminf (h0, h1);
+		if (lo <= 0.f) {
+			return;
+		}
+		float best = lo;
+		if (lane == 0) {
+			float cur = __uint_as_float (__hip_atomic_load (slot[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+			if (lo > cur) {
+				cur = __uint_as_float (atomicMax (slot[q], __float_as_uint (lo)));
+			}
+			best = fmaxf (lo, cur);
+		}
+		best    = uniform_f (best);
+		bnd[q]  = fmaxf (bnd[q], best * 0.99995f);
+		bnd2[q] = fmaxf (bnd2[q], best * best * 0.9999f);
+	};
+
+	// ---- the steps of the lists: handed out by counters, loaded once per workgroup, parked planar in the stage (sweep_kernel's scheme)
+	const unsigned  n_total = (unsigned)__builtin_amdgcn_readfirstlane ((int)p.n_steps[blockIdx.y]);
+	const unsigned  ngrp    = gridDim.x < kCtr ? gridDim.x : kCtr;
+	const unsigned  grp     = blockIdx.x % ngrp;
+	unsigned* const ctr     = p.ctr + ((size_t)c * kCtr + grp) * 32;
+	if (tid == 0) {
+		const unsigned b0 = atomicAdd (ctr, 4u);
+		sh_seq[0]         = ngrp * b0 + grp;
+		sh_seq[1]         = ngrp * (b0 + 1u) + grp;
+		sh_seq[2]         = ngrp * (b0 + 2u) + grp;
+		sh_seq[3]         = ngrp * (b0 + 3u) + grp;
+	}
+	__syncthreads ();
+	auto seq = [&] (int s) { return (unsigned)__builtin_amdgcn_readfirstlane ((int)sh_seq[s & 7]); };
+	const int          ld_par  = w >> 1;
+	const int          ld_half = (w & 1) * 512;
+	float4             dv[2], hv[2];
+	const uint2* const dsc = p.desc + (int64_t)blockIdx.y * p.desc_stride;
+	auto request = [&] (unsigned s) { // entries [first, first + n) of the lists; a lane takes four consecutive (d, h) pairs twice
+		const uint2         ds = dsc[s];
+		const float4* const q  = reinterpret_cast<const float4*> (p.surv + (int64_t)ds.x + ld_half + 4 * lane);
+#pragma unroll
+		for (int i = 0; i < 2; ++i) {
+			const float4 a = q[128 * i], b = q[128 * i + 1];
+			dv[i]          = make_float4 (a.x, a.z, b.x, b.z);
+			hv[i]          = make_float4 (a.y, a.w, b.y, b.w);
+		}
+	};
+	auto park = [&] (int buf, unsigned s) { // (what lies beyond n -- the rest of a list's last step -- is allocated memory: zeroed here)
+		const int n = (int)dsc[s].y;
+#pragma unroll
+		for (int i = 0; i < 2; ++i) {
+			const int    e0 = ld_half + 256 * i + 4 * lane;
+			float* const q  = stage_s + buf * 2 * kStage + e0;
+			float4       d = dv[i], h = hv[i];
+			if (e0 + 4 > n) {
+				d = make_float4 (e0 < n ? d.x : 0.f, e0 + 1 < n ? d.y : 0.f, e0 + 2 < n ? d.z : 0.f, 0.f);
+				h = make_float4 (e0 < n ? h.x : 0.f, e0 + 1 < n ? h.y : 0.f, e0 + 2 < n ? h.z : 0.f, 0.f);
+			}
+			*reinterpret_cast<float4*> (q)          = d;
+			*reinterpret_cast<float4*> (q + kStage) = h;
+		}
+	};
+	{
+		const unsigned g0 = seq (0), g1 = seq (1), g2 = seq (2);
+		if (ld_par == 1) {
+			if (g0 < n_total) {
+				request (g0);
+				park (0, g0);
+			}
+			if (g2 < n_total) {
+				request (g2);
+			}
+		} else if (g1 < n_total) {
+			request (g1);
+		}
+	}
+	__syncthreads ();
+
+	float2* const ring0 = ring_s + w * NBLK * kERing;
+	unsigned      wrc[NBLK], rdc[NBLK];
+#pragma unroll
+	for (int q = 0; q < NBLK; ++q) {
+		wrc[q] = rdc[q] = 0u;
+	}
+	unsigned n_seen = 0, n_eval = 0, n_surv = 0;
+	for (int s = 0;; ++s) {
+		const unsigned gs0 = seq (s), gs1 = seq (s + 1), gs3 = seq (s + 3);
+		if (gs0 >= n_total) {
+			break;
+		}
+		const int  buf  = s & 1;
+		const bool asks = tid == ((s & 1) << 7 ^ 128);
+		unsigned   got  = 0u;
+		if (asks) {
+			got = ngrp * atomicAdd (ctr, 1u) + grp;
+		}
+		if ((s & 1) == ld_par) {
+			if (gs1 < n_total) {
+				park (buf ^ 1, gs1);
+			}
+			if (gs3 < n_total) {
+				request (gs3);
+			}
+		}
+		if (!idle) {
+			const float* const st = stage_s + buf * 2 * kStage;
+			const int          nch = ((int)dsc[gs0].y + 63) >> 6; // (a list's last step is short: the chunks beyond its entries are zeros)
+#pragma unroll 1
+			for (int it = sub; it < nch; it += nsub) {
+				const float d  = st[it * 64 + lane];
+				const float h  = st[kStage + it * 64 + lane];
+				const float r2 = d * d + h * h;
+#pragma unroll
+				for (int q = 0; q < NBLK; ++q) {
+					const float    u    = fabsf (d * cps[q] + h * sps[q]);
+					const float    v    = fabsf (h * cps[q] - d * sps[q]);
+					const float    t    = u * cdl[q] + v * sdl[q];
+					const bool     live = r2 > bnd2[q] && (v <= u * tdl[q] || t > bnd[q]);
+					const uint64_t mask = __builtin_amdgcn_ballot_w64 (live);
+					float2* const  ring = ring0 + q * kERing;
+					if (live) {
+						const unsigned at = (wrc[q] + __builtin_amdgcn_mbcnt_hi ((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned)mask, 0u))) & (kERing - 1);
+						ring[at]          = make_float2 (d, h);
+					}
+					const unsigned nl = (unsigned)__builtin_popcountll (mask);
+					wrc[q] += nl;
+					n_surv += nl;
+					if (wrc[q] - rdc[q] >= 64u) { // a full tile pair of this block's survivors (wave-uniform)
+						wave_sync ();
+						const float* const rg = reinterpret_cast<const float*> (ring);
+						const float        b0 = rg[2 * ((rdc[q] + j) & (kERing - 1)) + kk];
+						const float        b1 = rg[2 * ((rdc[q] + 32 + j) & (kERing - 1)) + kk];
+						const f32x16       r0 = __builtin_amdgcn_mfma_f32_32x32x2f32 (a_op[q], b0, zero, 0, 0, 0);
+						const f32x16       r1 = __builtin_amdgcn_mfma_f32_32x32x2f32 (a_op[q], b1, zero, 0, 0, 0);
+#pragma unroll
+						for (int r = 0; r < 16; ++r) {
+							m[q][r] = fmaxf (m[q][r], fmaxf (fabsf (r0[r]), fabsf (r1[r])));
+						}
+						rdc[q] += 64u;
+						n_eval += 2;
+						wave_sync ();
+					}
+				}
+			}
+			n_seen += (kStage / 32) / nsub;
+			// the bounds: after the workgroup's steps 1, 2, 4, 8, 16, then every 16th
+			if (((s + 1) & s) == 0 || (s & 15) == 15) {
+#pragma unroll
+				for (int q = 0; q < NBLK; ++q) {
+					refresh (q, m[q]);
+				}
+			}
+		}
+		if (asks) {
+			sh_seq[(s + 4) & 7] = got;
+		}
+		__syncthreads ();
+	}
+	if (!idle) {
+		// what is left in the rings (< 64 entries each), padded with zeros
+#pragma unroll
+		for (int q = 0; q < NBLK; ++q) {
+			const unsigned left = wrc[q] - rdc[q];
+			if (left > 0u) {
+				wave_sync ();
+				const float* const rg = reinterpret_cast<const float*> (ring0 + q * kERing);
+				float              b0 = rg[2 * ((rdc[q] + j) & (kERing - 1)) + kk];
+				float              b1 = rg[2 * ((rdc[q] + 32 + j) & (kERing - 1)) + kk];
+				b0                    = (unsigned)j < left ? b0 : 0.f;
+				b1                    = (unsigned)j + 32u < left ? b1 : 0.f;
+				const f32x16 r0 = __builtin_amdgcn_mfma_f32_32x32x2f32 (a_op[q], b0, zero, 0, 0, 0);
+				const f32x16 r1 = __builtin_amdgcn_mfma_f32_32x32x2f32 (a_op[q], b1, zero, 0, 0, 0);
+#pragma unroll
+				for (int r = 0; r < 16; ++r) {
+					m[q][r] = fmaxf (m[q][r], fmaxf (fabsf (r0[r]), fabsf (r1[r])));
+				}
+				n_eval += left > 32u ? 2 : 1;
+			}
+		}
+	}
+	// statistics in sweep_kernel's units (tiles of a wave's share, all its blocks at once): a tile of ONE block counts 1 / NBLK
+	if (p.stats != nullptr) {
+		unsigned* const acc = reinterpret_cast<unsigned*> (stage_s);
+		__syncthreads ();
+		if (tid < 4) {
+			acc[tid] = 0u;
+		}
+		__syncthreads ();
+		if (lane == 0 && !idle) {
+			atomicAdd (&acc[0], n_eval / (unsigned)NBLK);
+			atomicAdd (&acc[1], n_seen);
+			atomicAdd (&acc[3], n_surv / (unsigned)NBLK);
+		}
+		__syncthreads ();
+		if (tid < 4) {
+			atomicAdd (&p.stats[tid], (unsigned long long)acc[tid]);
+		}
+	}
+	float* const part = p.part + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wr_) * (p.n_angles + 1);
+	if (lane == 0) {
+		part[p.n_angles] = 0.f; // (the raw peak went into the table from the fused pass)
+	}
+	if (idle) {
+		return;
+	}
+	int kk_e = kk, j_e = j;
+	asm volatile ("" : "+v"(kk_e), "+v"(j_e));
+#pragma unroll
+	for (int q = 0; q < NBLK; ++q) {
+#pragma unroll
+		for (int r = 0; r < 16; ++r) {
+			const float v   = half_max_odd_rows (m[q][r]); // (valid in lanes 16-31, 48-63)
+			const int   row = (r & 3) + 8 * (r >> 2) + 4 * kk_e;
+			const int   idx = (g + q * G) * 32 + row;
+			if (j_e == 16 && g + q * G < nb && idx < p.n_angles) {
 				part[idx] = v;
 			}
 		}
@@ -581,11 +894,14 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 // peaks[c][angle] = max (peaks[c][angle], max over the launch's workgroups and the waves that served the angle's block):
 // one thread per (angle slot, slice of workgroups), up to 64 slices -> at most 64 atomics per table entry
 __global__ __launch_bounds__ (64) void sweep_merge_kernel (const float* __restrict__ part, int n_wg, int n_angles, const int* __restrict__ angles,
-                                                             float* peaks, int chn0, int raw_slot, float* thr, unsigned* ctr)
+                                                             float* peaks, int chn0, int raw_slot, float* thr, unsigned* ctr, float* thr_blk)
 {
 	if (blockIdx.x == 0 && blockIdx.z == 0) { // what the launch that just ended shared: zero for the next one
 		if (thr != nullptr && threadIdx.x < 4) {
 			thr[(chn0 + blockIdx.y) * 4 + threadIdx.x] = 0.f;
+		}
+		if (thr_blk != nullptr && threadIdx.x < 16) {
+			thr_blk[(chn0 + blockIdx.y) * 16 + threadIdx.x] = 0.f;
 		}
 		if (threadIdx.x < kCtr) {
 			ctr[((size_t)(chn0 + blockIdx.y) * kCtr + threadIdx.x) * 32] = 0u;
@@ -625,17 +941,36 @@ hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s)
 	const int nb   = (p.n_angles + 31) / 32;
 	const int nblk = nb >= 3 ? (nb + 3) / 4 : 1;
 	typedef void (*kern_t) (SweepParams);
-	static const kern_t kern[3][4] = {
+	static const kern_t kern[2][4] = {
 		{ nullptr, sweep_kernel<1, false>, sweep_kernel<2, false>, sweep_kernel<3, false> },
 		{ nullptr, sweep_kernel<1, true>, sweep_kernel<2, true>, sweep_kernel<3, true> },
-		{ nullptr, sweep_kernel<1, true, true>, sweep_kernel<2, true, true>, sweep_kernel<3, true, true> },
 	};
+	static const kern_t kern_eval[4] = { nullptr, sweep_eval_kernel<1>, sweep_eval_kernel<2>, sweep_eval_kernel<3> };
 	const bool compact = p.surv != nullptr;
-	if (compact && (!p.prune || p.desc == nullptr || p.n_steps == nullptr)) {
+	if (compact && (!p.prune || p.desc == nullptr || p.n_steps == nullptr || p.thr_blk == nullptr || p.angles_host == nullptr)) {
 		return hipErrorInvalidValue;
 	}
 	const int    pr = compact ? 2 : p.prune ? 1 : 0;
-	const kern_t fn = kern[pr][nblk];
+	const kern_t fn = compact ? kern_eval[nblk] : kern[p.prune ? 1 : 0][nblk];
+	float        sect[12][4];
+	if (compact) {
+		// the sector of each block of 32 requested angles: LUT index a is the angle -a pi / 360 (SinCosLut, cli/phase-rotate.cc:46),
+		// the table's 360 entries cover half a circle -- all that matters to |ca d + sa h|; a block whose indices wrap (..., 359, 0,
+		// ...) gets the whole half circle, which is merely not tight
+		for (int b = 0; b < 12; ++b) {
+			int lo = 1 << 30, hi = -1;
+			for (int k = 32 * b; k < 32 * b + 32 && k < p.n_angles; ++k) {
+				lo = std::min (lo, p.angles_host[k]);
+				hi = std::max (hi, p.angles_host[k]);
+			}
+			const double psi = hi < 0 ? 0.0 : -0.5 * (lo + hi) * M_PI / 360.0;
+			const double del = hi < 0 ? 0.0 : std::min (0.5 * M_PI, 0.5 * (hi - lo) * M_PI / 360.0 + 2e-3);
+			sect[b][0]       = (float)std::cos (psi);
+			sect[b][1]       = (float)std::sin (psi);
+			sect[b][2]       = del >= 0.5 * M_PI ? 0.f : (float)std::cos (del);
+			sect[b][3]       = del >= 0.5 * M_PI ? 1.f : (float)std::sin (del);
+		}
+	}
 	// persistent grid: exactly the workgroups the chip keeps resident, so the grid-stride loop ends without a ragged
 	// last round
 	static int slots[3][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
@@ -649,7 +984,7 @@ hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s)
 		slots[pr][nblk] = cus * occ;
 	}
 	const int64_t span  = kStage;
-	// (COMPACT: the number of steps is on the device; t_end - t_begin is the host's upper bound of the entries -- every frame)
+	// (lists: the number of steps is on the device; t_end - t_begin is the host's upper bound of the entries -- every frame)
 	const int64_t tiles = (p.t_end - p.t_begin + span - 1) / span;
 	if (p.part == nullptr) {
 		return hipErrorInvalidValue;
@@ -663,9 +998,14 @@ hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s)
 	}
 	for (int c0 = 0; c0 < n_chn; c0 += (int)chn_most) {
 		const int     nc = (int)std::min<int64_t> (chn_most, n_chn - c0);
-		const int64_t gx = std::min<int64_t> (std::min<int64_t> (tiles, std::max (1, slots[pr][nblk] / nc)), chn_most / nc);
+		// (lists: a workgroup learns its blocks' bounds from its first steps -- give each at least four when there are few)
+		const int64_t want = compact ? std::max<int64_t> (1, tiles / 4) : tiles;
+		const int64_t gx = std::min<int64_t> (std::min<int64_t> (want, std::max (1, slots[pr][nblk] / nc)), chn_most / nc);
 		SweepParams   q  = p;
 		q.chn0           = p.chn0 + c0;
+		if (compact) {
+			memcpy (q.sect, sect, sizeof (sect));
+		}
 		const dim3 grid ((unsigned)gx, (unsigned)nc), block (256);
 		hipLaunchKernelGGL (fn, grid, block, 0, s, q);
 		hipError_t err = hipGetLastError ();
@@ -673,7 +1013,8 @@ hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s)
 			return err;
 		}
 		const dim3 mgrid ((unsigned)((p.n_angles + 1 + 63) / 64), (unsigned)nc, (unsigned)std::min<int64_t> (64, gx)); // (slices of workgroups)
-		hipLaunchKernelGGL (sweep_merge_kernel, mgrid, dim3 (64), 0, s, q.part, (int)gx, q.n_angles, q.angles, q.peaks, q.chn0, q.raw_slot, q.prune ? q.thr : nullptr, q.ctr);
+		hipLaunchKernelGGL (sweep_merge_kernel, mgrid, dim3 (64), 0, s, q.part, (int)gx, q.n_angles, q.angles, q.peaks, q.chn0, q.raw_slot, q.prune ? q.thr : nullptr, q.ctr,
+		                    compact ? q.thr_blk : nullptr);
 		err = hipGetLastError ();
 		if (err != hipSuccess) {
 			return err;
@@ -682,7 +1023,7 @@ hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s)
 	return hipSuccess;
 }
 
-// The step table of a COMPACT sweep (one workgroup per channel): list l has cnt[l] entries from entry l * cap on; its steps of
+// The step table of a sweep over lists (one workgroup per channel): list l has cnt[l] entries from entry l * cap on; its steps of
 // up to 1024 entries follow those of the lists before it.
 __global__ __launch_bounds__ (256) void sweep_plan_kernel (const unsigned* __restrict__ cnt, int n_lists, int64_t cap, uint2* __restrict__ desc,
                                                              int64_t desc_stride, unsigned* __restrict__ n_steps, unsigned long long* total)
