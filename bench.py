@@ -504,23 +504,32 @@ def bench_cfg3(args, pkg, torch, np, dev, ts, st, local_rank, barrier, world):
 
 
 def bench_run_host(pkg, np, local_rank):
-    """BASELINE config 2, literal form: the LV2 run() drop-in on HOST buffers, 1024 frames per
-    call (zero-copy: the kernel reads/writes the pinned host block over the host link and writes the
-    next call's input history; one launch + one stream sync per call).  Latency-bound; never `value`."""
-    g = pkg.Lv2Instance(48000, 1, device=local_rank)
-    g.activate()
+    """BASELINE config 2, literal form: the LV2 run() drop-in on HOST buffers, 1024 frames per call.  Default route (round 4):
+    the run() SERVER -- a resident one-workgroup kernel takes the call through a pinned mailbox (doorbell, parameters, the port
+    block; no launch, no stream synchronisation); `launch_route_us_per_run` = the route of rounds 1-3 (one OLA launch on the
+    zero-copy host block + a stream sync per call).  Latency-bound; never `value`."""
     x = (np.random.default_rng(3).random((1, 1024), dtype=np.float32) - 0.5)
-    for _ in range(20):
-        g.run(x, 90.0)
-    calls = 500
-    t0 = time.perf_counter()
-    for _ in range(calls):
-        g.run(x, 90.0)
-    dt = (time.perf_counter() - t0) / calls
-    g.close()
-    return {"workload": "prot_lv2_run, mono 48 kHz, 1024-frame host buffers (zero-copy pinned host block: one OLA launch, which "
-                        "also writes the next history, + stream sync per call; ctypes call overhead included)",
-            "us_per_run": dt * 1e6, "frames_per_s": 1024 / dt, "realtime_factor_48k": 1024 / dt / 48000.0}
+    res = {}
+    for key, no_server in (("server", 0), ("launch", 1)):
+        pkg.set_test_option(pkg.TEST_LV2_NO_SERVER, no_server)
+        g = pkg.Lv2Instance(48000, 1, device=local_rank)
+        g.activate()
+        for _ in range(50):
+            g.run(x, 90.0)
+        calls = 1000
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            g.run(x, 90.0)
+        res[key] = (time.perf_counter() - t0) / calls
+        res[key + "_stats"] = g.server_stats()
+        g.close()
+    pkg.set_test_option(pkg.TEST_LV2_NO_SERVER, 0)
+    dt = res["server"]
+    return {"workload": "prot_lv2_run, mono 48 kHz, 1024-frame host buffers, through the run() server (resident kernel, pinned mailbox + "
+                        "doorbell: no launch and no stream sync per call; ctypes call overhead included)",
+            "us_per_run": dt * 1e6, "frames_per_s": 1024 / dt, "realtime_factor_48k": 1024 / dt / 48000.0,
+            "launch_route_us_per_run": res["launch"] * 1e6, "server_calls": res["server_stats"]["calls"],
+            "server_kernels_started": res["server_stats"]["starts"]}
 
 
 def bench_file_host(pkg, np, local_rank):

@@ -958,9 +958,8 @@ int server_stop_locked ()
 	if (o->srv_running) {
 		o->srv_running = false;
 		prot::SvServerBox* b = o->srv_box.p;
-		b->cmd               = 1u;
 		o->srv_seq           = (o->srv_seq % (1u << 30)) + 1u;
-		__atomic_store_n (&b->seq, o->srv_seq, __ATOMIC_RELEASE);
+		__atomic_store_n (&b->bell, (uint64_t)o->srv_seq | ((uint64_t)1 << 63), __ATOMIC_RELEASE);
 		HIP_TRY (hipStreamSynchronize (o->srv_stream));
 	}
 	return PROT_OK;
@@ -980,10 +979,9 @@ int server_start_locked (prot_engine* e)
 	HIP_TRY (hipEventRecord (e->srv_ev, e->stream));
 	HIP_TRY (hipStreamWaitEvent (e->srv_stream, e->srv_ev, 0));
 	prot::SvServerBox* b = e->srv_box.p;
-	b->cmd               = 0u;
-	b->seq               = e->srv_seq;
+	b->bell              = e->srv_seq;
 	__atomic_store_n (&b->alive, 1u, __ATOMIC_RELEASE);
-	hipError_t err = prot::launch_ola_save_server (b, e->d_srv_relay.p, e->srv_seq, e->hopseg / 2, (int)e->info.n_chn, e->srv_stream);
+	hipError_t err = prot::launch_ola_save_server (b, e->h_io.p, e->d_srv_relay.p, e->srv_seq, e->hopseg / 2, (int)e->info.n_chn, e->srv_stream);
 	if (err != hipSuccess) {
 		b->alive = 0u;
 		return hip_fail (err, "run() server launch");
@@ -2270,17 +2268,19 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 				d_rot_c = h_rotc;
 			}
 			const int hist_before = e->hist_cur;
-			rc = ola_launch (e, h_in, (int64_t)n, n, h_out, (int64_t)n, n, d_rot_c, steady ? nullptr : h_rot, false, false, 0, (int)nc, s,
-			                 /*advance_hist*/ true, nullptr, nullptr, nullptr, b);
+			// (steady rotation: by value in the parameters -- a pointer into the pinned block would be one more read over the host link)
+			const bool rot_inline = steady && (int)nc <= prot::kRotInline;
+			rc = ola_launch (e, h_in, (int64_t)n, n, h_out, (int64_t)n, n, rot_inline ? nullptr : d_rot_c, steady ? nullptr : h_rot, false, false, 0, (int)nc, s,
+			                 /*advance_hist*/ true, rot_inline ? d_rot_c : nullptr, nullptr, nullptr, b);
 			if (rc == PROT_OK) {
 				if (!e->srv_running || __atomic_load_n (&b->alive, __ATOMIC_ACQUIRE) == 0u) {
 					rc = server_start_locked (e);
 				}
 				if (rc == PROT_OK) {
-					b->cmd     = 0u;
 					e->srv_seq = (e->srv_seq % (1u << 30)) + 1u;
-					const uint32_t seq = e->srv_seq;
-					__atomic_store_n (&b->seq, seq, __ATOMIC_RELEASE);
+					const uint32_t seq  = e->srv_seq;
+					const uint64_t bell = (uint64_t)seq | ((uint64_t)n << 32);
+					__atomic_store_n (&b->bell, bell, __ATOMIC_RELEASE);
 					// wait for every channel's done word; a server that left by itself between the check above and the doorbell
 					// (idle time-out) is started again -- with the number of the last served call, so that it takes this one at once
 					const auto t_0 = std::chrono::steady_clock::now ();
@@ -2305,11 +2305,12 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 							if (rc) {
 								return rc;
 							}
-							__atomic_store_n (&b->seq, seq, __ATOMIC_RELEASE);
+							__atomic_store_n (&b->bell, bell, __ATOMIC_RELEASE);
 							continue;
 						}
 						if (std::chrono::steady_clock::now () - t_0 > std::chrono::seconds (2)) {
-							snprintf (g_err, sizeof (g_err), "run() server: call %u not served within 2 s", seq);
+							snprintf (g_err, sizeof (g_err), "run() server: call %u not served within 2 s (stages %u %u, done %u %u, alive %u)", seq, b->pad0[0],
+							          b->pad0[1], b->done[0], b->done[1], b->alive);
 							return PROT_EHIP;
 						}
 					}
@@ -2880,6 +2881,19 @@ int prot_internal_server_stats (prot_engine* e, unsigned long long out[2])
 	out[1] = e->srv_starts;
 	return PROT_OK;
 }
+#ifdef PROT_SERVER_STAMPS
+// diagnostic builds (tools/ab_build.py): 100 MHz ticks of the last call's stages (doorbell seen, parameters read, block done, done stored)
+int prot_internal_server_stamps (prot_engine* e, unsigned out[4])
+{
+	if (!e || !out || !e->srv_box.p) {
+		return PROT_EINVAL;
+	}
+	for (int i = 0; i < 4; ++i) {
+		out[i] = e->srv_box.p->pad0[8 + i];
+	}
+	return PROT_OK;
+}
+#endif
 
 int prot_internal_set_test_option (int option, int value)
 {

@@ -106,14 +106,16 @@ hipError_t launch_ola_save (const OlaParams& p, int hop_rows, int n_rho_rows, in
 // ---- the run() server (prot_olasave.hip): pinned, host-coherent mailbox of one LV2 engine
 constexpr int kServerMaxChn = 16;
 struct SvServerBox {
-	uint32_t          seq;      // host -> device: the call's number (1 .. 2^30, never the same twice in a row), stored LAST: the doorbell
-	uint32_t          cmd;      // host -> device: 0 run the call in p, 1 leave
+	// host -> device, ONE 8-byte store, LAST: the doorbell.  bits 0..31 the call's number (1 .. 2^30, never the same twice in a row),
+	// bits 32..62 frames per channel of the call (the server fetches them from the port block beside the parameters: one trip over
+	// the host link for both), bit 63: leave
+	uint64_t          bell;
 	uint32_t          alive;    // device -> host: set by the host before the launch, cleared by the kernel as its last store
-	uint32_t          pad0[13];
+	uint32_t          pad0[13]; // device -> host: how far each channel's workgroup has come (diagnostics)
 	uint32_t          done[kServerMaxChn]; // device -> host: done[c] = seq when channel c's output (and its next history) is complete
 	OlaParamsT<float> p;        // host -> device: what the launch would have carried
 };
-hipError_t launch_ola_save_server (SvServerBox* box, unsigned* relay, unsigned last_seq, int hop_rows, int n_chn, hipStream_t s);
+hipError_t launch_ola_save_server (SvServerBox* box, const float* port_in, unsigned* relay, unsigned last_seq, int hop_rows, int n_chn, hipStream_t s);
 hipError_t post_ola_save_server (const OlaParamsT<float>& p, int hop_rows, int n_rho_rows, int n_chn, SvServerBox* box);
 hipError_t launch_ola_save8k (const OlaParams& p, int hop_rows, int n_chn, hipStream_t s);
 

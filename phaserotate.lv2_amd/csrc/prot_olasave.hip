@@ -51,6 +51,16 @@ extern "C" int prot_debug_sv_wg (unsigned long long* out, int n_wg)
 	return hipMemcpyFromSymbol (out, HIP_SYMBOL (g_sv_wg), sizeof (unsigned long long) * 4 * (size_t)(n_wg < 4096 ? n_wg : 4096)) == hipSuccess ? 0 : -1;
 }
 #endif
+#ifdef PROT_SERVER_STAMPS
+__device__ unsigned g_srv_t[16];
+extern "C" int prot_debug_srv_t (unsigned* out)
+{
+	return hipMemcpyFromSymbol (out, HIP_SYMBOL (g_srv_t), sizeof (g_srv_t)) == hipSuccess ? 0 : -1;
+}
+#define PROT_SRV_T(i) if (WIDE && threadIdx.x == 0 && blockIdx.y == 0) { g_srv_t[i] = (unsigned)__builtin_amdgcn_s_memrealtime (); }
+#else
+#define PROT_SRV_T(i)
+#endif
 #define PROT_SV_CAT_(k, a, b, c) PROT_SV_##k##_##a##_##b##_##c
 #define PROT_SV_CLOB_(a) PROT_SV_ASM_CLOBBERS_##a
 // one generated block of code: KIND_ = ASM (a run of nf whole blocks streamed from / to global memory) or CORE (one block staged
@@ -88,7 +98,9 @@ extern "C" int prot_debug_sv_wg (unsigned long long* out, int n_wg)
 //    here into the LDS exchange area (16 rows of (q, c) pairs + the frames in front of each wave's first pair), transformed by
 //    the generated CORE (the same instructions on the same values: the two paths agree bit for bit, and a sharded or chunked
 //    sweep does not depend on where its chunks end), and stored from LDS with bounds.
-template <int HS, int MODE>
+// WIDE (the run() server: one workgroup per CU, registers to spare, and every load a round trip nothing else hides): the 16 rows of
+// a staged block are fetched before the first is parked, the history slice moves eight frames per thread at a time, without a branch per frame
+template <int HS, int MODE, bool WIDE = false>
 PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_lo_s)
 {
 	constexpr int BLK = 512 * HS; // output frames per block
@@ -100,6 +112,7 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 
 	const int t0 = threadIdx.x;
 	const int c  = blockIdx.y;
+	PROT_SRV_T (5)
 #ifdef PROT_SV_CLOCK
 	const uint64_t wg_t0 = __builtin_amdgcn_s_memrealtime ();
 	uint64_t       wg_a0 = 0, wg_a1 = 0;
@@ -251,22 +264,55 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 	// running: frame by frame with device-scope loads -- the aligned 8-byte route could hit a stale line of this XCD's L2,
 	// found as launch 5 of a series reading what launch 1 had read from the same buffer of the ring)
 	const bool hist_al8 = !piped && hist != nullptr && (reinterpret_cast<uintptr_t> (hist) & 7) == 0 && (p.hist_len & 1) == 0;
+	// (WIDE: the server's parameters come out of LDS, so every pointer in them is a generic one to the compiler, and a generic load
+	// is waited for with both counters at zero before the next goes out -- the 16 row loads of a staged block went one at a time, 3.7 us;
+	// the address spaces are said here: the input is the server's LDS copy, everything else is global)
+	typedef __attribute__ ((address_space (3))) const float LdsInF;
+	typedef __attribute__ ((address_space (3))) const f2    LdsInC;
+	auto in_f = [] (const float* q) -> float {
+		if constexpr (WIDE) {
+			return *(LdsInF*)q;
+		} else {
+			return *q;
+		}
+	};
+	auto in_c = [] (const f2* q) -> f2 {
+		if constexpr (WIDE) {
+			return *(LdsInC*)q;
+		} else {
+			return *q;
+		}
+	};
+	auto gl_f = [] (const float* q) -> float {
+		if constexpr (WIDE) {
+			return *(PROT_GLOBAL const float*)q;
+		} else {
+			return *q;
+		}
+	};
+	auto gl_c = [] (const f2* q) -> f2 {
+		if constexpr (WIDE) {
+			return *(PROT_GLOBAL const f2*)q;
+		} else {
+			return *q;
+		}
+	};
 	auto ldv = [&] (const float* in_, int64_t n_in_, const float* hist_, int hist_len_, int64_t i) -> float {
 		if (i >= 0) {
-			return i < n_in_ ? in_[i] : 0.f;
+			return i < n_in_ ? in_f (in_ + i) : 0.f;
 		}
 		const int64_t h = i + hist_len_;
 		if (hist_ == nullptr || h < 0) {
 			return 0.f;
 		}
-		return piped ? __hip_atomic_load (const_cast<float*> (hist_) + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : hist_[h];
+		return piped ? __hip_atomic_load (const_cast<float*> (hist_) + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gl_f (hist_ + h);
 	};
 	auto row_pair = [&] (int64_t ar, int t) -> f2 {
 		if (in_al8 && ar >= 0 && ar + 512 <= n_in) {
-			return reinterpret_cast<const f2*> (in + ar)[t];
+			return in_c (reinterpret_cast<const f2*> (in + ar) + t);
 		}
 		if (hist_al8 && ar + 512 <= 0 && ar + p.hist_len >= 0) {
-			return reinterpret_cast<const f2*> (hist + (ar + p.hist_len))[t];
+			return gl_c (reinterpret_cast<const f2*> (hist + (ar + p.hist_len)) + t);
 		}
 		const int64_t a = ar + 2 * (int64_t)t;
 		return mkf2 (ldv (in, n_in, hist, p.hist_len, a), ldv (in, n_in, hist, p.hist_len, a + 1));
@@ -274,7 +320,7 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 
 	for (int64_t s = r0; s < r1;) {
 		const int64_t a0 = s - Dd - 512 * R0; // frame of (row 0, thread 0).q: the dry frame of output row r is input row r
-		if (MODE != MODE_RAMP && in_al8 && (out_al8 || MODE == MODE_SWEEP) && a0 >= 1 && !(p.sv_flags & 1) &&
+		if (!WIDE && MODE != MODE_RAMP && in_al8 && (out_al8 || MODE == MODE_SWEEP) && a0 >= 1 && !(p.sv_flags & 1) &&
 		    (MODE != MODE_SWEEP || (s >= p.sw_t_begin && s >= p.sw_dry_from))) {
 			// blocks from here on that read only frames inside the array and are emitted whole
 			const int64_t n1 = (r1 - s) / BLK;
@@ -319,17 +365,40 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 		LdsF* const gcar = (LdsF*)(smem + 4096);      // gathered frames in the generated code's lane layout:
 		LdsF* const gnx  = (LdsF*)(smem + 4096 + 128); //   lanes HS-NT..HS-1 <-> rows 0..NT-1, lanes 0..HS-1 <-> rows NT..15
 		__syncthreads (); // (every wave has left the generated loop, if that is where it comes from)
+		PROT_SRV_T (0)
 		{
+			if constexpr (WIDE) {
+				// (all of the block's loads in flight before the first is parked: one round trip)
+				f2 v[16];
+#pragma unroll
+				for (int k = 0; k < 16; ++k) {
+					v[k] = row_pair (a0 + 512 * (int64_t)k, t);
+				}
+				const int   l = t & 63, w = t >> 6;
+				const int   rc = l - (HS - NT), rn = NT + l;
+				const float gc = (rc >= 0 && rc < NT) ? ldv (in, n_in, hist, p.hist_len, a0 + 512 * (int64_t)rc + 128 * w - 1) : 0.f;
+				const float gn = (l < HS) ? ldv (in, n_in, hist, p.hist_len, a0 + 512 * (int64_t)rn + 128 * w - 1) : 0.f;
+#pragma unroll
+				for (int k = 0; k < 16; ++k) {
+					st[256 * k + t] = v[k];
+				}
+				gcar[t] = gc;
+				gnx[t]  = gn;
+			} else {
 #pragma unroll 2
-			for (int k = 0; k < 16; ++k) {
-				st[256 * k + t] = row_pair (a0 + 512 * (int64_t)k, t);
+				for (int k = 0; k < 16; ++k) {
+					st[256 * k + t] = row_pair (a0 + 512 * (int64_t)k, t);
+				}
 			}
-			const int l = t & 63, w = t >> 6;
-			const int rc = l - (HS - NT), rn = NT + l; // the row this lane gathers for, as a carried / as a new row
-			gcar[t] = (rc >= 0 && rc < NT) ? ldv (in, n_in, hist, p.hist_len, a0 + 512 * (int64_t)rc + 128 * w - 1) : 0.f;
-			gnx[t]  = (l < HS) ? ldv (in, n_in, hist, p.hist_len, a0 + 512 * (int64_t)rn + 128 * w - 1) : 0.f;
+			if constexpr (!WIDE) {
+				const int l = t & 63, w = t >> 6;
+				const int rc = l - (HS - NT), rn = NT + l; // the row this lane gathers for, as a carried / as a new row
+				gcar[t] = (rc >= 0 && rc < NT) ? ldv (in, n_in, hist, p.hist_len, a0 + 512 * (int64_t)rc + 128 * w - 1) : 0.f;
+				gnx[t]  = (l < HS) ? ldv (in, n_in, hist, p.hist_len, a0 + 512 * (int64_t)rn + 128 * w - 1) : 0.f;
+			}
 		}
 		__syncthreads ();
+		PROT_SRV_T (1)
 		{
 			const float  cca = (MODE == MODE_RAMP || MODE == MODE_SWEEP) ? 0.f : ca, csa = MODE == MODE_RAMP ? __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (p.sv_gain))) : sa;
 			const float* a_in  = a_sv; // (unused by the core)
@@ -338,6 +407,7 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 			PROT_SV_ALL (CORE, a_in, a_out, one, cca, csa)
 		}
 		__syncthreads ();
+		PROT_SRV_T (2)
 		// The thread id opaque AGAIN: nothing per-lane may be kept alive across the generated code (which owns v0..v119) except
 		// the thread id itself -- the compiler otherwise carries hoisted per-lane addresses across it through scratch, and a
 		// spill placed inside one of the divergent branches above comes back with the inactive lanes' slots stale
@@ -390,8 +460,8 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 				if (MODE == MODE_RAMP && pos0 < r1) {
 					// per-frame rotation: the dry pair of output row k is the (q, c) pair of input row R0 + k
 					const f2 d   = row_pair (pos0 - 2 * (int64_t)t - Dd, t);
-					const f2 cs0 = reinterpret_cast<const f2*> (p.rot_s)[(int64_t)c * p.n_out + pos0];
-					const f2 cs1 = pos0 + 1 < r1 ? reinterpret_cast<const f2*> (p.rot_s)[(int64_t)c * p.n_out + pos0 + 1] : mkf2 (0.f, 0.f);
+					const f2 cs0 = gl_c (reinterpret_cast<const f2*> (p.rot_s) + ((int64_t)c * p.n_out + pos0));
+					const f2 cs1 = pos0 + 1 < r1 ? gl_c (reinterpret_cast<const f2*> (p.rot_s) + ((int64_t)c * p.n_out + pos0 + 1)) : mkf2 (0.f, 0.f);
 					o            = mkf2 (cs0.x * d.x + cs0.y * o.x, cs1.x * d.y + cs1.y * o.y);
 				}
 				if (pos0 < r1) {
@@ -403,6 +473,7 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 			}
 		}
 		__syncthreads (); // (the output rows have been read: the exchange area is free for whatever comes next)
+		PROT_SRV_T (3)
 		s += BLK;
 	}
 #ifdef PROT_SV_CLOCK
@@ -414,8 +485,62 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 	}
 #endif
 	if (!piped) {
-		hist_write_slice (p, blockIdx.y, threadIdx.x);
+		if constexpr (WIDE) {
+			if (p.hist_out != nullptr) {
+				const int per = (p.hist_len + (int)gridDim.x - 1) / (int)gridDim.x;
+				const int i0  = (int)blockIdx.x * per;
+				const int i1  = i0 + per < p.hist_len ? i0 + per : p.hist_len;
+				float* __restrict__ ho = p.hist_out + (int64_t)c * p.hist_len;
+				// next history [i] = old history [i + n_in] while that exists, input [i - (hist_len - n_in)] after it: two loops without
+				// a branch per frame, eight loads in flight per thread (with the per-frame choice the loads went out one at a time)
+				const int64_t keep64 = (int64_t)p.hist_len - n_in;
+				const int     keep   = keep64 > 0 ? (int)keep64 : 0; // entries that come from the old history
+				const int     a1     = i1 < keep ? i1 : keep;
+				if (hist != nullptr) {
+					const float* __restrict__ hs = hist + n_in;
+					for (int base = i0 + (int)threadIdx.x; base < a1; base += 256 * 8) {
+						float v[8];
+#pragma unroll
+						for (int q = 0; q < 8; ++q) {
+							const int i = base + 256 * q;
+							v[q]        = gl_f (hs + (i < a1 ? i : a1 - 1));
+						}
+#pragma unroll
+						for (int q = 0; q < 8; ++q) {
+							const int i = base + 256 * q;
+							if (i < a1) {
+								*(PROT_GLOBAL float*)(ho + i) = v[q];
+							}
+						}
+					}
+				} else {
+					for (int i = i0 + (int)threadIdx.x; i < a1; i += 256) {
+						ho[i] = 0.f;
+					}
+				}
+				const float* __restrict__ is = in - keep64; // (keep64 < 0: more input than history, the last hist_len frames of it)
+				const int b0 = i0 > keep ? i0 : keep;
+				for (int base = b0 + (int)threadIdx.x; base < i1; base += 256 * 8) {
+					float v[8];
+#pragma unroll
+					for (int q = 0; q < 8; ++q) {
+						const int i = base + 256 * q;
+						v[q]        = in_f (is + (i < i1 ? i : i1 - 1));
+					}
+#pragma unroll
+					for (int q = 0; q < 8; ++q) {
+						const int i = base + 256 * q;
+						if (i < i1) {
+							*(PROT_GLOBAL float*)(ho + i) = v[q];
+						}
+					}
+				}
+			}
+		} else {
+			hist_write_slice (p, blockIdx.y, threadIdx.x);
+		}
 	}
+	PROT_SRV_T (4)
 	if constexpr (MODE == MODE_SWEEP) {
 		if ((t0 & 63) == 0) {
 			p.surv_cnt[((int64_t)c * gridDim.x + blockIdx.x) * 4 + (t0 >> 6)] = sw_cnt;
@@ -456,24 +581,52 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 constexpr uint64_t kServerIdleTicks = 25000000ull;
 
 template <int HS>
-__global__ __launch_bounds__ (256, 1) void olasave_server_kernel (SvServerBox* const box, unsigned* const relay, const unsigned last_seq)
+__global__ __launch_bounds__ (256, 1) void olasave_server_kernel (SvServerBox* const box, const float* const port_in, unsigned* const relay,
+                                                                    const unsigned last_seq)
 {
 	__shared__ f2       smem[kLdsExchange + 512];
 	__shared__ float    sw_lo_s[4];
 	__shared__ unsigned sh_w[2];
+	// the call's input frames of this channel, fetched from the pinned port block ONCE (the block reads them twice -- its rows and
+	// the next history -- and every read of host memory is a trip over the host link that nothing hides)
+	__shared__ __attribute__ ((aligned (16))) float sh_in[512 * HS];
 	__shared__ __attribute__ ((aligned (16))) unsigned sh_p[(sizeof (OlaParams) + 3) / 4]; // the call's parameters (read in place)
 	const int tid  = threadIdx.x;
 	unsigned  seen = last_seq;
+	// (pad0[c]: how far channel c's workgroup has come -- 1 resident, 2 doorbell seen, 3 parameters read, 4 block done, 5 done
+	// word stored, 9 left; what the host prints when a call is not served)
+	auto stage = [&] (unsigned v) {
+		int tid_s = tid;
+		asm volatile ("" : "+v"(tid_s));
+		if (tid_s == 0 && blockIdx.y < 8) {
+			__hip_atomic_store (&box->pad0[blockIdx.y], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef PROT_SERVER_STAMPS
+			if (blockIdx.y == 0 && v >= 2u && v <= 5u) { // 100 MHz ticks at the stages of channel 0's workgroup
+				__hip_atomic_store (&box->pad0[6 + v], (unsigned)__builtin_amdgcn_s_memrealtime (), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			}
+#endif
+		}
+	};
+	stage (1u);
 	for (;;) {
-		if (tid == 0) {
+		// (the thread id made opaque at each use, the decision made wave-uniform by readfirstlane: with `tid == 0` guarding both
+		// the end of one pass -- the done word -- and the start of the next -- the poll --, the compiler rotated the loop into
+		// "thread 0: store, poll; everybody else: straight back to the barrier", and the other 255 threads served the same call
+		// again and again while thread 0 waited, masked off, to store its done word: found on the hardware with the stage words)
+		int tid_poll = tid;
+		asm volatile ("" : "+v"(tid_poll));
+		if (tid_poll == 0) {
 			unsigned word;
+			unsigned frames = 0u;
 			if (blockIdx.y == 0) {
 				unsigned       s = seen, cmd = 0u;
 				const uint64_t t_0 = __builtin_amdgcn_s_memrealtime ();
 				for (;;) {
-					s = __hip_atomic_load (&box->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					const uint64_t bell = __hip_atomic_load (&box->bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					s                   = (unsigned)bell;
 					if (s != seen) {
-						cmd = __hip_atomic_load (&box->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ? 1u : 0u;
+						cmd    = (unsigned)(bell >> 63);
+						frames = (unsigned)(bell >> 32) & 0x7fffffffu;
 						break;
 					}
 					if (__builtin_amdgcn_s_memrealtime () - t_0 > kServerIdleTicks) {
@@ -484,45 +637,74 @@ __global__ __launch_bounds__ (256, 1) void olasave_server_kernel (SvServerBox* c
 				}
 				word = 2u * s + cmd;
 				if (gridDim.y > 1) {
-					__hip_atomic_store (relay, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store (relay + 1, frames, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store (relay, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 				}
 			} else {
-				while ((word = __hip_atomic_load (relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 2u * seen) {
+				while ((word = __hip_atomic_load (relay, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 2u * seen) {
 					__builtin_amdgcn_s_sleep (2);
 				}
+				frames = __hip_atomic_load (relay + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 			sh_w[0] = word;
+			sh_w[1] = frames;
 		}
 		__syncthreads ();
-		const unsigned word = sh_w[0];
+		const unsigned word = (unsigned)__builtin_amdgcn_readfirstlane ((int)sh_w[0]);
 		if (word & 1u) {
 			break;
 		}
-		// the host's stores (parameters, input frames, per-frame rotation) happened before its doorbell store
-		__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "");
+		stage (2u);
+		// The host's stores (parameters, input frames, per-frame rotation) happened before its doorbell store, and what is read of
+		// them below is read past the caches (system-scope loads of host-coherent memory) after thread 0 has seen the doorbell.
+		// NO acquire fence: at system scope it invalidates the XCD's L2, and the block's own history -- written by this very
+		// workgroup on this very CU one call ago, the only device data of a call -- came back from HBM instead (staging 3.6 ->
+		// us, history slice 3.3 -> us per call, measured with the stage stamps).
+		// An agent-scope acquire it has to be: it empties this CU's vector cache, which otherwise still holds lines of the history
+		// ring as they were three calls ago (found as outputs that differed from the launched kernel's).
+		__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");
+		const int frames = __builtin_amdgcn_readfirstlane ((int)sh_w[1]) < 512 * HS ? __builtin_amdgcn_readfirstlane ((int)sh_w[1]) : 512 * HS;
 		for (int i = tid; i < (int)(sizeof (OlaParams) / 4); i += 256) {
 			sh_p[i] = __hip_atomic_load (reinterpret_cast<unsigned*> (&box->p) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
+		{ // (the port block: [channel][frames], prot_capi.hip lv2_run_chunk)
+			const float* const src = port_in + (int64_t)blockIdx.y * frames;
+			for (int i = tid; i < frames; i += 256) {
+				sh_in[i] = __hip_atomic_load (src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			}
+		}
+		__syncthreads ();
+		if (tid == 0) { // the block reads its input from here (a generic pointer into LDS; one workgroup = one channel: no stride)
+			OlaParams* const pw = reinterpret_cast<OlaParams*> (sh_p);
+			pw->in              = sh_in;
+			pw->in_stride       = 0;
+		}
 		__syncthreads ();
 		const OlaParams& p = *reinterpret_cast<const OlaParams*> (sh_p);
+		stage (3u);
 		if (p.rot_s != nullptr) {
-			olasave_body<HS, MODE_RAMP> (p, smem, sw_lo_s);
+			olasave_body<HS, MODE_RAMP, true> (p, smem, sw_lo_s);
 		} else {
-			olasave_body<HS, MODE_ROT> (p, smem, sw_lo_s);
+			olasave_body<HS, MODE_ROT, true> (p, smem, sw_lo_s);
 		}
+		stage (4u);
 		__builtin_amdgcn_fence (__ATOMIC_RELEASE, ""); // output frames and the next history: visible to the host / to later launches
 		__syncthreads ();
-		if (tid == 0) {
+		int tid_done = tid;
+		asm volatile ("" : "+v"(tid_done));
+		if (tid_done == 0) {
 			__hip_atomic_store (&box->done[blockIdx.y], word >> 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
+		stage (5u);
 		seen = word >> 1;
 	}
+	stage (9u);
 	if (tid == 0 && blockIdx.y == 0) {
 		__hip_atomic_store (&box->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 }
 
-hipError_t launch_ola_save_server (SvServerBox* box, unsigned* relay, unsigned last_seq, int hop_rows, int n_chn, hipStream_t s)
+hipError_t launch_ola_save_server (SvServerBox* box, const float* port_in, unsigned* relay, unsigned last_seq, int hop_rows, int n_chn, hipStream_t s)
 {
 	if (n_chn < 1 || n_chn > kServerMaxChn) {
 		return hipErrorInvalidValue;
@@ -533,8 +715,8 @@ hipError_t launch_ola_save_server (SvServerBox* box, unsigned* relay, unsigned l
 	}
 	const dim3 grid (1, (unsigned)n_chn), block (256);
 	switch (hop_rows) {
-		case 8: hipLaunchKernelGGL ((olasave_server_kernel<8>), grid, block, 0, s, box, relay, last_seq); break;
-		case 10: hipLaunchKernelGGL ((olasave_server_kernel<10>), grid, block, 0, s, box, relay, last_seq); break;
+		case 8: hipLaunchKernelGGL ((olasave_server_kernel<8>), grid, block, 0, s, box, port_in, relay, last_seq); break;
+		case 10: hipLaunchKernelGGL ((olasave_server_kernel<10>), grid, block, 0, s, box, port_in, relay, last_seq); break;
 		default: return hipErrorInvalidValue;
 	}
 	return hipGetLastError ();

@@ -148,6 +148,80 @@ def test_lv2_run_stream(pkg, rate, bufsize, angle, n_chn):
     g.close()
 
 
+@pytest.mark.parametrize("rate,bufsize,n_chn,angles", [
+    (48000, 1024, 1, (90.0,)),                         # BASELINE config 2
+    (48000, 1024, 2, ((30.0, -45.0),)),
+    (48000, 64, 1, (90.0, 45.0, 45.0, 10.0, -120.0)),  # ramps most of the time
+    (96000, 256, 2, ((10.0, -170.0), (10.0, -170.0), (0.0, 90.0))),
+    (44100, 333, 1, (-77.0,)),
+])
+def test_lv2_run_server_gives_the_launched_kernels_bits(pkg, rate, bufsize, n_chn, angles):
+    """prot_lv2_run's default route is the run() SERVER (a resident kernel that takes each call through a pinned mailbox: no
+    launch, no stream synchronisation); TEST_LV2_NO_SERVER = the launch route of rounds 1-3.  Same block code: the outputs are
+    equal bit for bit, call by call -- steady rotation, ramps, stereo, odd buffer sizes -- and the server really took the calls."""
+    xs = [xorshift_uniform(n_chn * bufsize, seed=100 + i).reshape(n_chn, bufsize) for i in range(40)]
+    outs, stats = {}, {}
+    try:
+        for mode in (1, 0):
+            pkg.set_test_option(pkg.TEST_LV2_NO_SERVER, mode)
+            g = pkg.Lv2Instance(rate, n_chn)
+            g.activate()
+            outs[mode] = np.stack([g.run(x, angles[i % len(angles)]).copy() for i, x in enumerate(xs)])
+            stats[mode] = g.server_stats()
+            g.close()
+    finally:
+        pkg.set_test_option(pkg.TEST_LV2_NO_SERVER, 0)
+    assert outs[0].tobytes() == outs[1].tobytes()
+    assert stats[1] == dict(calls=0, starts=0)
+    assert stats[0]["calls"] == len(xs) and 1 <= stats[0]["starts"] <= 3, stats  # (a start more if the box stalled past the idle time-out)
+
+
+def test_lv2_run_server_leaves_when_idle_and_for_every_other_use_of_the_engine(pkg):
+    """The resident kernel must never outlive the stream of run() calls it serves (it holds a hardware queue, and every
+    device-wide synchronisation of the process waits for it): it leaves by itself after 0.25 s without a doorbell and is
+    started again by the next call; reset, a device call on the engine, a long call (more than one block per channel: the
+    launch route) and a second instance (one server per process: it takes the launch route) all keep the stream of samples intact."""
+    import time
+    import torch
+    n_buf, bs = 30, 512
+    x = xorshift_uniform(n_buf * bs, seed=77).reshape(1, -1)
+    o = orc.Lv2Engine(48000, 1)
+    want = o.run_stream(x, 90.0, bs)
+    g = pkg.Lv2Instance(48000, 1)
+    g.activate()
+    h = pkg.Lv2Instance(48000, 1)
+    h.activate()
+    got, got_h = [], []
+    for i in range(n_buf):
+        blk = x[:, i * bs:(i + 1) * bs]
+        got.append(g.run(blk, 90.0).copy())
+        got_h.append(h.run(blk, 90.0).copy())      # the second instance: launch route beside g's server
+        if i == 5:
+            time.sleep(0.4)                          # idle time-out: the server leaves, the next call starts a new one
+        if i == 9:
+            t0 = time.perf_counter()
+            torch.cuda.synchronize()                 # a device-wide synchronisation ends when the server has left
+            assert time.perf_counter() - t0 < 2.0
+        if i == 12:
+            g.sync()                                 # any other use of the engine stops the server first
+    st, st_h = g.server_stats(), h.server_stats()
+    y, y_h = np.concatenate(got, 1), np.concatenate(got_h, 1)
+    lat = g.latency + 2304
+    assert np.abs(y - want)[:, lat:].max() < TOL and np.abs(y - want)[:, :lat].max() < TOL_RAMP
+    assert y_h.tobytes() == y.tobytes()
+    assert st["calls"] == n_buf and st["starts"] >= 3, st     # first start, after the idle exit, after the syncs
+    assert st_h == dict(calls=0, starts=0), st_h
+    # a call of more than one block per channel goes through a launch, and the stream continues through the server afterwards
+    big = xorshift_uniform(6000, seed=78).reshape(1, -1)
+    tail = xorshift_uniform(bs, seed=79).reshape(1, -1)
+    w2 = np.concatenate([o.run_stream(big, 90.0, 6000), o.run_stream(tail, 90.0, bs)], 1)  # (the oracle engine of `want` goes on)
+    y2 = np.concatenate([g.run(big, 90.0).copy(), g.run(tail, 90.0).copy()], 1)
+    assert np.abs(y2 - w2).max() < TOL
+    assert g.server_stats()["calls"] == n_buf + 1
+    g.close()
+    h.close()
+
+
 def test_lv2_three_device_geometries_are_the_same_filter(pkg):
     """LV2 48 kHz filter in the three device forms: polyphase (default: the odd taps on the stream
     read as complex samples, one partition, 5120-frame blocks), direct form with two 2048-tap
