@@ -1353,6 +1353,7 @@ def test_block8192_hilbert_branch_and_history(pkg):
     rot = np.array([0.0, -1.0], np.float32)
     e = pkg.Engine(pkg.KIND_LV2, 48000, 1)
     y1, y2, u1 = torch.zeros_like(x), torch.zeros_like(x), torch.zeros_like(x)
+    torch.cuda.synchronize()   # (the engine's stream does not wait for torch's: the fills must be over before it writes)
     e.apply_dev(x.data_ptr(), 2 * n, 2 * n, y1.data_ptr(), 2 * n, 2 * n, rot, pkg.F_STATELESS)
     e.hilbert_dev(x.data_ptr(), 2 * n, 2 * n, u1.data_ptr(), 2 * n, 2 * n, pkg.F_STATELESS)
     e.reset()
