@@ -200,7 +200,7 @@ bool save_tables8k (const std::vector<float>& fir, std::vector<float>& tab, floa
 {
 	const uint32_t F  = 8192;
 	const size_t   Lg = fir.size () / 2;
-	if (Lg % 512 != 0 || (Lg != 1536 && Lg != 2048)) {
+	if (Lg % 512 != 0 || (Lg != 1536 && Lg != 2048 && Lg != 4096)) { // 3 / 4 / 8 context rows of 512 complex samples
 		return false;
 	}
 	std::vector<double> re (F, 0.0), im (F, 0.0);
@@ -441,6 +441,7 @@ struct prot_engine {
 	DevBuf<unsigned> d_srv_relay;
 	hipStream_t    srv_stream  = nullptr;
 	hipEvent_t     srv_ev      = nullptr;
+	bool           sv8_always   = false; // CLI blksiz 8192: every fp32 launch on 8192-point blocks (one table-free partition)
 	bool           srv_eligible = false; // LV2 engine on the overlap-save kernel, <= 16 channels, not pipelined
 	bool           srv_running = false;
 	uint32_t       srv_seq     = 0;      // number of the last call posted
@@ -749,7 +750,7 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 		if (e->info.partitions == np) {
 			rank_runs (p, (int64_t)e->info.run_align, n_chn, n_out, e->wg_slots, e->cus, false);
 		}
-		if (e->use_save8 && pipe_wait_post == nullptr && (uint64_t)n_out * (uint64_t)n_chn >= ((uint64_t)1 << 24)) {
+		if (e->use_save8 && pipe_wait_post == nullptr && (e->sv8_always || (uint64_t)n_out * (uint64_t)n_chn >= ((uint64_t)1 << 24))) {
 			// a long launch: 8192-point blocks, 512-thread workgroups, two per CU (run lengths 1.2 : 0.8 by dispatch rank)
 			const int blk8 = 1024 * e->sv8_rows, slots8 = e->cus * 2;
 			p.run_frames   = pick_run_frames (e, n_out, n_chn, blk8, slots8);
@@ -1288,6 +1289,26 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	    tuning_env ("PROT_NO_SAVE8K") == nullptr) {
 		e->use_save8 = save_tables8k (fir_taps, sv8_h, e->sv8_gain);
 		e->sv8_rows  = 16 - (int)(inf.firlen / 1024);
+	}
+	// The CLI's default engine at 44.1 / 48 kHz (blksiz 8192, cli/phase-rotate.cc:749-755): 4096 odd taps = 8 context rows of an
+	// 8192-point block -- ONE table-free partition, 8192 new frames per block, instead of two 2048-tap partitions with a spectrum
+	// table on 4096-point transforms (olapoly_kernel, which stays for the fp16 path and under the flags that ask for it).  EVERY
+	// fp32 launch of such an engine takes this kernel, whatever its length: one form per CLI engine is what makes chunked and
+	// sharded sweeps bit-identical (the block grid starts at the call's first frame either way).
+	if (use_poly && n_part == 2 && inf.kind == PROT_KIND_CLI && inf.firlen == 8192 && inf.conv_delay == 0 && inf.dry_delay == 4096 &&
+	    !(cfg->flags & (PROT_CFG_BLOCK4096 | PROT_CFG_OVERLAP_ADD | PROT_CFG_POLYPHASE)) && tuning_env ("PROT_NO_SAVE8K") == nullptr) {
+		e->use_save8 = save_tables8k (fir_taps, sv8_h, e->sv8_gain);
+		if (e->use_save8) {
+			e->sv8_rows   = 8;
+			e->sv8_always = true;
+			inf.hop       = 8192;
+			inf.run_align = 8192;
+			inf.history   = std::max<uint32_t> (inf.history, 8192 + 256);
+			e->info.hop = inf.hop, e->info.run_align = inf.run_align, e->info.history = inf.history;
+			if (e->cus > 0 && tuning_env ("PROT_WG_PER_CU") == nullptr) {
+				e->wg_slots = e->cus * 2;
+			}
+		}
 	}
 	const char* pipe_env = tuning_env ("PROT_PIPELINE");
 	if (e->use_save && ((cfg->flags & PROT_CFG_PIPELINE) || (pipe_env && atoi (pipe_env) != 0)) && !(pipe_env && atoi (pipe_env) == 0)) {

@@ -38,6 +38,8 @@ constexpr int kSv8LdsBytes = 16 * 560 * 8 + 8192; // exchange area (16 rows of 5
 		              : PROT_SV8_CLOB_ (HS_));                                                                                          \
 	}
 #define PROT_SV8_ALL(KIND_, in_, out_, nf_, ca_, sa_)                                                                                  \
+	PROT_SV8_CALL (KIND_, 8, 0, in_, out_, nf_, ca_, sa_)                                                                               \
+	PROT_SV8_CALL (KIND_, 8, 2, in_, out_, nf_, ca_, sa_)                                                                               \
 	PROT_SV8_CALL (KIND_, 12, 0, in_, out_, nf_, ca_, sa_)                                                                              \
 	PROT_SV8_CALL (KIND_, 12, 2, in_, out_, nf_, ca_, sa_)                                                                              \
 	PROT_SV8_CALL (KIND_, 13, 0, in_, out_, nf_, ca_, sa_)                                                                              \
@@ -55,7 +57,7 @@ __global__ __launch_bounds__ (512, 4) void olasave8k_kernel (const OlaParams p)
 	constexpr int R0  = NT / 2;              // first valid output row = first dry row
 	constexpr int ROT = (NT & 1) ? 256 : 0;  // complex samples the block is rotated by
 	constexpr int AM  = MODE == MODE_ROT ? 0 : 2;
-	static_assert (HS == 12 || HS == 13, "rows per block");
+	static_assert (HS == 8 || HS == 12 || HS == 13, "rows per block");
 
 	extern __shared__ f2 smem8[]; // kSv8LdsBytes: the exchange area + the two tables (written by the generated prologue)
 
@@ -228,6 +230,7 @@ hipError_t launch_ola_save8k (const OlaParams& p, int hop_rows, int n_chn, hipSt
 	const int64_t runs = (p.n_out + p.run_frames - 1) / p.run_frames;
 	dim3          grid ((unsigned)runs, (unsigned)n_chn);
 	switch (hop_rows) {
+		case 8: return launch_sv8_m<8> (p, grid, s);
 		case 12: return launch_sv8_m<12> (p, grid, s);
 		case 13: return launch_sv8_m<13> (p, grid, s);
 		default: return hipErrorInvalidValue;
