@@ -363,11 +363,15 @@ def main():
             "value": world * n * args.steps / wall2, "unit": "frames/s",
             "roofline_frac": 8.0 * n / (kms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": kms2}
         eng2.close()
-        # CLI default block size at 48 kHz (8192-tap FIR): one polyphase launch with two partitions
+        # CLI default block size at 48 kHz (8192-tap FIR).  Round 4: ONE table-free partition of the 4096 odd taps on 8192-point
+        # blocks (olasave8k_kernel<8, 0>: 8 context rows, 8192 new frames per block); rounds 2-3: two 2048-tap partitions with a
+        # spectrum table on 4096-point transforms (olapoly_kernel<T32, 2, 8, ...>: 0.356-0.362 ms = 0.37-0.38)
         eng3 = pkg.Engine(pkg.KIND_CLI, 8192, 1, device=local_rank)
         wall3, kms3 = timed(eng3, args.steps, args.warmup, n)
         out["cli_8192"] = {
-            "workload": "CLI engine blksiz 8192 (8192-tap FIR): polyphase, two 2048-tap partitions of the odd taps in one launch",
+            "workload": ("CLI engine blksiz 8192 (8192-tap FIR): polyphase, the 4096 odd taps as one table-free partition on 8192-point "
+                         "overlap-save blocks (8 of 16 rows new)" if int(eng3.info.form) == pkg.FORM_POLY_SAVE8K else
+                         "CLI engine blksiz 8192 (8192-tap FIR): polyphase, two 2048-tap partitions of the odd taps in one launch"),
             "value": world * n * args.steps / wall3, "unit": "frames/s",
             "roofline_frac": 8.0 * n / (kms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": kms3}
         eng3.close()
