@@ -873,7 +873,7 @@ def test_resident_file_passes_equal_streamed_ones(pkg, blksiz, n_chn, n):
         assert a.max() > 0 and a.tobytes() == b.tobytes()
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 24])
 def test_overlap_save_equals_overlap_add_on_random_chunkings(pkg, seed):
     """Two independent kernels for the same filter -- the generated overlap-save loop (default) and the overlap-add kernel
     with its spectrum table (PROT_CFG_OVERLAP_ADD) -- fed the same stream in random stateful chunks (1 frame ... 300 000),
@@ -883,7 +883,7 @@ def test_overlap_save_equals_overlap_add_on_random_chunkings(pkg, seed):
     import torch
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(seed)
-    kind, param = [(pkg.KIND_LV2, 48000), (pkg.KIND_LV2, 96000), (pkg.KIND_CLI, 2048), (pkg.KIND_CLI, 4096)][seed % 4]
+    kind, param = [(pkg.KIND_LV2, 48000), (pkg.KIND_LV2, 96000), (pkg.KIND_CLI, 2048), (pkg.KIND_CLI, 4096), (pkg.KIND_CLI, 8192)][seed % 5]
     nc = int(rng.integers(1, 4))
     n = int(rng.integers(200_000, 900_000))
     stride = n + int(rng.integers(0, 9))
@@ -896,7 +896,8 @@ def test_overlap_save_equals_overlap_add_on_random_chunkings(pkg, seed):
     outs = []
     for flags in (0, pkg.CFG_OVERLAP_ADD):
         e = pkg.Engine(kind, param, nc, flags=flags)
-        assert e.info.form == ((pkg.FORM_POLY_SAVE8K if kind == pkg.KIND_LV2 else pkg.FORM_POLY_SAVE) if flags == 0 else pkg.FORM_POLY_OLA)
+        # (LV2 engines: 8192-point blocks for long launches; CLI blksiz 8192: 8192-point blocks for every launch, one table-free partition)
+        assert e.info.form == ((pkg.FORM_POLY_SAVE8K if kind == pkg.KIND_LV2 or param == 8192 else pkg.FORM_POLY_SAVE) if flags == 0 else pkg.FORM_POLY_OLA)
         y = torch.zeros(nc * stride, device=dev)
         for a, b in zip(cuts[:-1], cuts[1:]):
             e.apply_dev(x.data_ptr() + 4 * a, stride, b - a, y.data_ptr() + 4 * a, stride, b - a, rot, hil)
