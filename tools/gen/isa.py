@@ -224,6 +224,7 @@ class Prog:
     def s_cselect(self, d, a, b): return self.add(Ins("s_cselect", "s_cselect_b32 %r, %r, %r" % (d, a, b), d=d, a=a, b=b))
     def s_cmp_lg_u32(self, a, b): return self.add(Ins("s_cmp_lg", "s_cmp_lg_u32 %r, %r" % (a, b), a=a, b=b))
     def s_cmp_eq_u32(self, a, b): return self.add(Ins("s_cmp_eq", "s_cmp_eq_u32 %r, %r" % (a, b), a=a, b=b))
+    def s_cmp_lt_u32(self, a, b): return self.add(Ins("s_cmp_lt", "s_cmp_lt_u32 %r, %r" % (a, b), a=a, b=b))
     def s_cbranch_scc1(self, label): return self.add(Ins("s_cbranch_scc1", "s_cbranch_scc1 %s" % label, label=label))
     def s_cbranch_scc0(self, label): return self.add(Ins("s_cbranch_scc0", "s_cbranch_scc0 %s" % label, label=label))
     def s_branch(self, label): return self.add(Ins("s_branch", "s_branch %s" % label, label=label))
@@ -640,9 +641,9 @@ class Emu:
                 s[i.d.n] = r & 0xffffffff
             elif op == "s_cselect":
                 s[i.d.n] = srd(i.a) if W_.scc else srd(i.b)
-            elif op in ("s_cmp_lg", "s_cmp_eq"):
+            elif op in ("s_cmp_lg", "s_cmp_eq", "s_cmp_lt"):
                 a, b = srd(i.a), srd(i.b)
-                W_.scc = int((a != b) if op == "s_cmp_lg" else (a == b))
+                W_.scc = int((a != b) if op == "s_cmp_lg" else (a < b) if op == "s_cmp_lt" else (a == b))
             elif op in ("s_cbranch_scc1", "s_cbranch_scc0", "s_branch"):
                 take = True if op == "s_branch" else (W_.scc == 1) if op == "s_cbranch_scc1" else (W_.scc == 0)
                 if take:
