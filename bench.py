@@ -823,8 +823,10 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
                 "evaluated_fraction": h["evaluated_fraction"], "table_identical_unpruned": h["table_identical_unpruned"],
                 "min_angle_index": h["min_angle_index"], "per_rank_device_ms": h["per_rank_device_ms"],
                 "predicted_8gpu": h.get("predicted_8gpu"), "oracle_check_10s": check,
+                "fused": h["fused"], "listed_fraction": h["listed_fraction"],
                 "engine": "16384-tap FIR = four 2048-tap partitions of the odd taps: two accumulating launches of two partitions each "
-                          "for the Hilbert branch (olapoly_kernel<T32, 2, 8, ...>), then the MFMA sweep"}
+                          "for the Hilbert branch (olapoly_kernel<T32, 2, 8, ...>); round 4: the SECOND launch tests the complete Hilbert value "
+                          "with its dry frame instead of storing it and lists the survivors (MODE_SWEEP), sweep_eval_kernel evaluates the lists"}
     return {"metric": "channel-frames/s through the 360-angle min-peak sweep (cli -s 1 -f 2048)",
             "signal": "32-harmonic asymmetric stack (110 / 137.5 Hz) under a slow swell + 2 % noise, generated on the device; resident in HBM",
             "value": h["value"], "unit": "channel-frames/s", "ms": h["ms"], "unpruned_ms": h["unpruned_ms"],

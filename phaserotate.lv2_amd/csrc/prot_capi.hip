@@ -728,6 +728,46 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 	if (srv && !(e->use_poly && e->use_save)) {
 		return PROT_EUNSUPPORTED;
 	}
+	// The fused sweep (fs): the test rides in the (last) Hilbert launch -- one list per wave (4 per workgroup), long enough for
+	// every frame of the workgroup's run to survive.  0: launch; 1: plan_only, nothing to launch; < 0: -status
+	auto fs_prepare = [&] () -> int {
+		const int64_t blk = (int64_t)e->info.run_align;
+		if (fs->sample) {
+			p.run_frames = (int)blk;
+			p.run_stride = (int)(blk * fs->stride_blocks);
+			p.rank_cu    = 0;
+		}
+		const int64_t unit   = p.run_stride > 0 ? p.run_stride : p.run_frames;
+		const int64_t runs   = ((int64_t)n_out + unit - 1) / unit;
+		int64_t       longest = p.run_frames;
+		for (int k = 0; k < p.n_rank && p.rank_cu > 0; ++k) {
+			longest = std::max<int64_t> (longest, p.rank_frames[k]);
+		}
+		fs->n_lists = (int)runs * 4;
+		fs->cap     = ((longest / 4 + 3) & ~(int64_t)3) + 4; // a wave's share of its workgroup's longest run
+		if (fs->plan_only) {
+			return 1;
+		}
+		// (the buffers were sized by the caller for BOTH passes before the first launch: growing one between the passes
+		// would free memory a kernel of the pass before may still be reading)
+		if (e->d_surv.cap < (size_t)fs->n_lists * fs->cap * n_chn + 2048 || e->d_surv_cnt.cap < 2 * (size_t)fs->n_lists * n_chn ||
+		    e->d_desc.cap < ((size_t)fs->n_lists + (size_t)(n_out / 1024) + 8) * n_chn || e->d_nsteps.cap < (size_t)n_chn) {
+			snprintf (g_err, sizeof (g_err), "fused sweep: list buffers not sized");
+			return -PROT_EINVAL;
+		}
+		p.surv        = e->d_surv.p;
+		p.surv_cap    = fs->cap;
+		p.surv_cnt    = e->d_surv_cnt.p;
+		p.sw_peaks    = fs->peaks + (size_t)chn0 * PROT_MAXSAMPLE;
+		p.sw_angles   = fs->angles;
+		p.sw_n_angles = fs->n_angles;
+		p.sw_raw_slot = fs->raw_slot;
+		p.sw_raw_tail = fs->raw_tail;
+		p.sw_thr_zero = fs->sample ? 1 : 0;
+		p.sw_t_begin  = fs->t_begin;
+		p.sw_dry_from = fs->dry_from;
+		return 0;
+	};
 	if (e->use_p2 && e->d_Hp.p != nullptr && e->info.kind == PROT_KIND_LV2) {
 		// short launch of a direct-form LV2 engine: blocks per workgroup (k) against halo blocks -- direct (k + 2),
 		// polyphase 1.07 (k + 1): polyphase below k ~ 13
@@ -774,43 +814,10 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 			p.conv_delay = (int)e->info.conv_delay;
 			p.accumulate = 0;
 			if (fs) {
-				// the sweep's test rides in the Hilbert pass: one list per wave (4 per workgroup), long enough for every frame of
-				// the workgroup's run to survive
-				const int64_t blk = (int64_t)e->info.run_align;
-				if (fs->sample) {
-					p.run_frames = (int)blk;
-					p.run_stride = (int)(blk * fs->stride_blocks);
-					p.rank_cu    = 0;
+				const int st = fs_prepare ();
+				if (st != 0) {
+					return st > 0 ? PROT_OK : -st;
 				}
-				const int64_t unit   = p.run_stride > 0 ? p.run_stride : p.run_frames;
-				const int64_t runs   = ((int64_t)n_out + unit - 1) / unit;
-				int64_t       longest = p.run_frames;
-				for (int k = 0; k < p.n_rank && p.rank_cu > 0; ++k) {
-					longest = std::max<int64_t> (longest, p.rank_frames[k]);
-				}
-				fs->n_lists = (int)runs * 4;
-				fs->cap     = ((longest / 4 + 3) & ~(int64_t)3) + 4; // a wave's share of its workgroup's longest run
-				if (fs->plan_only) {
-					return PROT_OK;
-				}
-				// (the buffers were sized by the caller for BOTH passes before the first launch: growing one between the passes
-				// would free memory a kernel of the pass before may still be reading)
-				if (e->d_surv.cap < (size_t)fs->n_lists * fs->cap * n_chn + 2048 || e->d_surv_cnt.cap < 2 * (size_t)fs->n_lists * n_chn ||
-				    e->d_desc.cap < ((size_t)fs->n_lists + (size_t)(n_out / 1024) + 8) * n_chn || e->d_nsteps.cap < (size_t)n_chn) {
-					snprintf (g_err, sizeof (g_err), "fused sweep: list buffers not sized");
-					return PROT_EINVAL;
-				}
-				p.surv        = e->d_surv.p;
-				p.surv_cap    = fs->cap;
-				p.surv_cnt    = e->d_surv_cnt.p;
-				p.sw_peaks    = fs->peaks + (size_t)chn0 * PROT_MAXSAMPLE;
-				p.sw_angles   = fs->angles;
-				p.sw_n_angles = fs->n_angles;
-				p.sw_raw_slot = fs->raw_slot;
-				p.sw_raw_tail = fs->raw_tail;
-				p.sw_thr_zero = fs->sample ? 1 : 0;
-				p.sw_t_begin  = fs->t_begin;
-				p.sw_dry_from = fs->dry_from;
 			}
 			if (srv) { // the run() server takes the call: its parameters go into the mailbox, nothing is launched
 				if (prot::post_ola_save_server (p, e->hopseg / 2, e->sv_rows, n_chn, srv) != hipSuccess) {
@@ -824,10 +831,22 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 			}
 			return finish ();
 		}
-		for (uint32_t l = 0; l < e->info.partitions / np; ++l) {
+		const uint32_t n_launch = e->info.partitions / np;
+		if (fs) { // (long FIRs, CLI blksiz 16384 / 32768: the LAST accumulating launch tests instead of storing)
+			if (n_launch < 2 || np != 2 || !hilbert_only) {
+				return PROT_EUNSUPPORTED;
+			}
+			const int st = fs_prepare ();
+			if (st != 0) {
+				return st > 0 ? PROT_OK : -st;
+			}
+		}
+		float2* const fs_surv = p.surv;
+		for (uint32_t l = 0; l < n_launch; ++l) {
 			p.H          = e->d_H.p + (size_t)(np * l) * e->info.fftlen;
 			p.conv_delay = (int)(e->info.conv_delay + np * l * e->info.fftlen); // a partition of g spans 4096 frames
 			p.accumulate = l > 0;
+			p.surv       = l + 1 == n_launch ? fs_surv : nullptr;
 			hipError_t err = prot::launch_ola_poly (p, (int)np, e->hopseg / 2, n_chn, s);
 			if (err != hipSuccess) {
 				return hip_fail (err, "polyphase ola kernel launch");
@@ -1812,8 +1831,12 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 	HIP_TRY (hipSetDevice (e->device));
 	// (a long call in two pieces -- the first eighth listed against the seeding pass's bound, the rest against the table it leaves --
 	// was measured and changes nothing: 1.77-1.80 / 4.12 ms in one piece, 1.76-2.09 / 4.07-4.32 ms in two, harmonic / noise, cfg4)
-	const bool fusable = e->use_save && (e->hopseg == 16 || e->hopseg == 24) && !(e->sv_flags & 1) && !g_test_opt[PROT_TEST_SWEEP_UNPRUNED].load () &&
-	                     !g_test_opt[PROT_TEST_SWEEP_UNFUSED].load ();
+	// (two routes: the overlap-save kernel's MODE_SWEEP -- blksiz 2048, 4096 --, and for the long FIRs whose Hilbert branch takes
+	// several accumulating olapoly launches -- blksiz 16384, 32768 -- the LAST of those launches, which then tests the complete
+	// Hilbert value instead of storing it; the earlier launches leave their partial sums in the engine's Hilbert workspace)
+	const bool fuse_poly = e->use_poly && !e->use_save && !e->sv8_always && e->info.partitions >= 4 && e->hopseg == 16;
+	const bool fusable = ((e->use_save && (e->hopseg == 16 || e->hopseg == 24) && !(e->sv_flags & 1)) || fuse_poly) &&
+	                     !g_test_opt[PROT_TEST_SWEEP_UNPRUNED].load () && !g_test_opt[PROT_TEST_SWEEP_UNFUSED].load ();
 	hipStream_t s   = pick_stream (e, stream);
 	const int   c0  = chn < 0 ? 0 : chn;                       // cli/phase-rotate.cc:434-435
 	const int   nc  = chn < 0 ? (int)e->info.n_chn : 1;
@@ -1871,6 +1894,19 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		}
 		int rc2;
 		const bool first_fused = e->d_fused_surv.p == nullptr;
+		// where the Hilbert launches write: nowhere (one launch: the overlap-save kernel lists only), or the workspace for the partial
+		// sums of the launches before the last
+		float*       f_out     = const_cast<float*> (d_in);
+		int64_t      f_ostride = in_stride;
+		if (fuse_poly) {
+			const size_t ustride = (size_t)((n_out + 255) & ~(uint64_t)255);
+			int          rcu     = e->d_u.ensure (ustride * e->info.n_chn);
+			if (rcu) {
+				return rcu;
+			}
+			f_out     = e->d_u.p;
+			f_ostride = (int64_t)ustride;
+		}
 		if ((rc2 = e->d_part.ensure (prot::sweep_scratch_floats ())) || (rc2 = e->d_fused_surv.ensure (1))) {
 			return rc2;
 		}
@@ -1901,7 +1937,7 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 				FusedSweep fs {};
 				fill (fs, pass);
 				fs.plan_only = true;
-				rc = ola_launch (e, d_in, in_stride, n_frames, const_cast<float*> (d_in), in_stride, n_out, nullptr, nullptr, true, false, c0, nc, s, false, nullptr,
+				rc = ola_launch (e, d_in, in_stride, n_frames, f_out, f_ostride, n_out, nullptr, nullptr, true, false, c0, nc, s, false, nullptr,
 				                 nullptr, &fs);
 				if (rc) {
 					return rc;
@@ -1918,7 +1954,7 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		for (int pass = sample_pass ? 0 : 1; pass < 2; ++pass) {
 			FusedSweep fs {};
 			fill (fs, pass);
-			rc = ola_launch (e, d_in, in_stride, n_frames, const_cast<float*> (d_in), in_stride, n_out, nullptr, nullptr, true, false, c0, nc, s,
+			rc = ola_launch (e, d_in, in_stride, n_frames, f_out, f_ostride, n_out, nullptr, nullptr, true, false, c0, nc, s,
 			                 /*advance_hist*/ pass == 1, nullptr, nullptr, &fs);
 			if (rc) {
 				return rc;

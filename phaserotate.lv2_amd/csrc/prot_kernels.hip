@@ -1101,8 +1101,15 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 	} else {
 		r0 = (int64_t)bx * p.run_frames;
 	}
+	if (p.run_stride > 0) { // a sparse sample of the stream (the fused sweep's bound-seeding pass): run g starts at g * run_stride
+		r0   = (int64_t)blockIdx.x * p.run_stride;
+		rlen = p.run_frames;
+	}
 	if (r0 >= p.n_out) {
 		hist_write_slice (p, blockIdx.y, threadIdx.x);
+		if (MODE == MODE_SWEEP && (t & 63) == 0) {
+			p.surv_cnt[((int64_t)c * gridDim.x + blockIdx.x) * 4 + (t >> 6)] = 0u;
+		}
 		return;
 	}
 	const int64_t r1 = (r0 + rlen < p.n_out) ? r0 + rlen : p.n_out;
@@ -1116,6 +1123,38 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 	const bool in_al8  = (reinterpret_cast<uintptr_t> (in) & (2 * sizeof (S) - 1)) == 0;  // a frame pair is one aligned access
 	const bool out_al8 = (reinterpret_cast<uintptr_t> (out) & (2 * sizeof (S) - 1)) == 0;
 
+	// MODE_SWEEP (round 4; the LAST launch of the Hilbert branch of a long FIR, CLI blksiz 16384 / 32768): the complete Hilbert
+	// value of a frame -- what the earlier launches left in `out` plus this launch's share -- is not stored but TESTED with its dry
+	// frame against the call's bound, and the surviving (dry, hilbert) pairs go to this wave's list (prot_olasave.hip's MODE_SWEEP
+	// does the same in generated code; the lists, the plan and the evaluation are prot_sweep.hip's)
+	__shared__ float sw_lo_s[4];
+	float            sw_thr2 = 0.f, sw_raw = 0.f;
+	unsigned         sw_cnt  = 0u;
+	if constexpr (MODE == MODE_SWEEP) {
+		float lo = 1.0e18f;
+		if (!p.sw_thr_zero) {
+			for (int i = t; i < p.sw_n_angles; i += 256) {
+				lo = fminf (lo, __builtin_nontemporal_load (&p.sw_peaks[(int64_t)c * kMaxSample + p.sw_angles[i]]));
+			}
+		} else {
+			lo = 0.f;
+		}
+		for (int m = 1; m < 64; m <<= 1) {
+			lo = fminf (lo, __shfl_xor (lo, m));
+		}
+		if ((t & 63) == 0) {
+			sw_lo_s[t >> 6] = lo;
+		}
+		__syncthreads ();
+		lo      = fminf (fminf (sw_lo_s[0], sw_lo_s[1]), fminf (sw_lo_s[2], sw_lo_s[3]));
+		sw_thr2 = __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (lo * lo * 0.9999f)));
+		if (p.sw_raw_slot >= 0 && p.sw_raw_tail && blockIdx.x == 0) {
+			// the call's last dry_delay input frames: the rows reach them only as the next chunk's history (see prot_sweep.hip)
+			for (int64_t i = n_in - Dd + t; i < n_in; i += 256) {
+				sw_raw = fmaxf (sw_raw, i >= 0 ? fabsf ((float)in[i]) : 0.f);
+			}
+		}
+	}
 	const f2* __restrict__ twp = reinterpret_cast<const f2*> (p.tw);
 	C tw1[16];
 	// the tables of this workgroup (outer twiddles in registers, W256 and the filter spectrum in LDS): set up BEHIND the
@@ -1335,7 +1374,9 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 		// blocks ago) -- late, between the last exchange and the last pass of the inverse, so that no copy of the block
 		// occupies 2 HS registers through both transforms
 		auto dry_reread = [&] () {
-			if (DH == 0 && MODE != MODE_HILBERT && !ACC && it >= NP) {
+			// (MODE_SWEEP with dry_delay == conv_delay -- the last launch of blksiz 16384's Hilbert branch --: the dry frames are this
+			// block's own input rows, kept in `cur`; read again they were 0.8 ms of cfg4's 5.7)
+			if (DH == 0 && ((MODE != MODE_HILBERT && !ACC) || (MODE == MODE_SWEEP && Dd != Dc)) && it >= NP) {
 				const int64_t d0 = s - Dd;
 				if (d0 >= 0 && d0 + BLK <= n_in && in_al8 && !(Dd & 1)) {
 #pragma unroll
@@ -1381,7 +1422,53 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 			asm volatile ("" : "+v"(nxg));
 			__builtin_amdgcn_sched_barrier (0);
 		}
-		if (it >= NP) {
+		if (it >= NP && MODE == MODE_SWEEP) {
+			if constexpr (MODE == MODE_SWEEP) {
+				const bool    full = s + BLK <= r1;
+				float2* __restrict__ const list = p.surv + (((int64_t)c * gridDim.x + blockIdx.x) * 4 + (t >> 6)) * p.surv_cap;
+				if (ACC) { // what the earlier launches of the Hilbert branch stored: all rows' loads in flight before the first test
+					// (fetched row by row inside the loop below, each load waited behind the list stores of the row before it)
+					f2 prev[HS];
+#pragma unroll
+					for (int k = 0; k < HS; ++k) {
+						const int64_t pos0 = s + 2 * (int64_t)(t + 256 * k);
+						if (full && out_al8) {
+							prev[k] = to_f2 (reinterpret_cast<const PROT_GLOBAL C*> (uniform_ptr (out + s + 512 * k))[(unsigned)t]);
+						} else {
+							prev[k] = mkf2 (pos0 < r1 ? (float)out[pos0] : 0.f, pos0 + 1 < r1 ? (float)out[pos0 + 1] : 0.f);
+						}
+					}
+#pragma unroll
+					for (int k = 0; k < HS; ++k) {
+						u[k] = u[k] + prev[k];
+					}
+				}
+#pragma unroll
+				for (int k = 0; k < HS; ++k) {
+					const int64_t pos0 = s + 2 * (int64_t)(t + 256 * k);
+					const f2      hp   = u[k];
+					// the same rules as the edge blocks of prot_olasave.hip: frames in front of sw_t_begin or beyond the call are not
+					// tested, the dry term is 0 while t < sw_dry_from (Q1; the raw peak takes the frame all the same).  Both frames of
+					// the pair are tested first: most rows of most blocks have no survivor in the whole wave and skip the compaction
+					const f2   dk  = Dd == Dc ? cur[k] : dry[k];
+					const bool in0 = pos0 >= p.sw_t_begin && pos0 < r1, in1 = pos0 + 1 >= p.sw_t_begin && pos0 + 1 < r1;
+					const float d0 = pos0 >= p.sw_dry_from ? dk.x : 0.f, d1 = pos0 + 1 >= p.sw_dry_from ? dk.y : 0.f;
+					sw_raw         = fmaxf (sw_raw, fmaxf (in0 ? fabsf (dk.x) : 0.f, in1 ? fabsf (dk.y) : 0.f));
+					const bool     l0 = in0 && d0 * d0 + hp.x * hp.x > sw_thr2, l1 = in1 && d1 * d1 + hp.y * hp.y > sw_thr2;
+					const uint64_t m0 = __builtin_amdgcn_ballot_w64 (l0), m1 = __builtin_amdgcn_ballot_w64 (l1);
+					if ((m0 | m1) != 0) {
+						if (l0) {
+							list[sw_cnt + __builtin_amdgcn_mbcnt_hi ((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned)m0, 0u))] = make_float2 (d0, hp.x);
+						}
+						sw_cnt += (unsigned)__builtin_popcountll (m0);
+						if (l1) {
+							list[sw_cnt + __builtin_amdgcn_mbcnt_hi ((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned)m1, 0u))] = make_float2 (d1, hp.y);
+						}
+						sw_cnt += (unsigned)__builtin_popcountll (m1);
+					}
+				}
+			}
+		} else if (it >= NP) {
 			const bool full = s + BLK <= r1;
 			if (MODE == MODE_ROT && !ACC && full && out_al8 && !(PROT_ABL2 & 64)) {
 				const f2 ca2 = mkf2 (ca, ca), sa2 = mkf2 (sa, sa);
@@ -1490,6 +1577,22 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 	}
 #endif
 	hist_write_slice (p, blockIdx.y, threadIdx.x);
+	if constexpr (MODE == MODE_SWEEP) {
+		if ((t & 63) == 0) {
+			p.surv_cnt[((int64_t)c * gridDim.x + blockIdx.x) * 4 + (t >> 6)] = sw_cnt;
+		}
+		if (p.sw_raw_slot >= 0) {
+			for (int m = 1; m < 64; m <<= 1) {
+				sw_raw = fmaxf (sw_raw, __shfl_xor (sw_raw, m));
+			}
+			if ((t & 63) == 0 && sw_raw > 0.f) { // (non-negative floats order as their bit patterns; look before the atomic)
+				unsigned* const slot = reinterpret_cast<unsigned*> (p.sw_peaks + (int64_t)c * kMaxSample + p.sw_raw_slot);
+				if (__float_as_uint (sw_raw) > __hip_atomic_load (slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+					atomicMax (slot, __float_as_uint (sw_raw));
+				}
+			}
+		}
+	}
 }
 
 template <class T, int NP, int HS, int MODE>
@@ -1509,6 +1612,18 @@ static hipError_t launch_poly_m (const OlaParamsT<typename T::samp>& p, dim3 gri
 	constexpr int WPS = sizeof (typename T::samp) == 2 ? (NP == 1 ? 4 : 3)
 	                  : (NP == 1 && !(MODE == MODE_RAMP && HS >= 12)) ? 3 : 2;
 	const dim3 block (256);
+	if constexpr (sizeof (typename T::samp) == 4 && NP == 2 && HS == 8 && MODE == MODE_HILBERT) {
+		if (p.surv != nullptr) { // the last launch of a long FIR's Hilbert branch with the sweep's test (lists instead of stores)
+			if (!p.accumulate) {
+				return hipErrorInvalidValue;
+			}
+			hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE_SWEEP, 0, true, WPS>), grid, block, 0, s, p);
+			return hipGetLastError ();
+		}
+	}
+	if (p.surv != nullptr) {
+		return hipErrorInvalidValue;
+	}
 	if (p.accumulate) {
 		hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE, 0, true, WPS>), grid, block, 0, s, p);
 	} else if (MODE != MODE_HILBERT && dd == DHS) {
@@ -1527,7 +1642,8 @@ static hipError_t launch_poly_n (const OlaParamsT<typename T::samp>& p, int n_ch
 	if (p.n_out <= 0) {
 		return hipSuccess;
 	}
-	const int64_t runs = (p.n_out + p.run_frames - 1) / p.run_frames;
+	const int64_t unit = p.run_stride > 0 ? p.run_stride : p.run_frames; // (run_stride: every k-th block only, the fused sweep's sample pass)
+	const int64_t runs = (p.n_out + unit - 1) / unit;
 	dim3          grid ((unsigned)runs, (unsigned)n_chn);
 	if (p.hilbert_only) {
 		return launch_poly_m<T, NP, HS, MODE_HILBERT> (p, grid, s);

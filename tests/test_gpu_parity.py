@@ -915,6 +915,30 @@ def test_overlap_save_equals_overlap_add_on_random_chunkings(pkg, seed):
     assert np.abs(outs[0] - outs[1]).max() < 2e-6, (kind, param, nc, n, stride, len(cuts))
 
 
+@pytest.mark.parametrize("P,signal", [(16384, "harmonic"), (16384, "noise"), (32768, "harmonic")])
+def test_fused_sweep_of_the_long_fir_engines_is_bit_identical(pkg, P, signal):
+    """CLI blksiz 16384 (the reference's default at 96 kHz, cli/phase-rotate.cc:749-755) and 32768: the Hilbert branch takes two /
+    four accumulating launches; on the fused route the LAST one tests the complete Hilbert value with its dry frame instead of
+    storing it and lists the survivors (olapoly_kernel MODE_SWEEP).  Same table as the separate passes and as the unpruned
+    kernel, bit for bit, over several device chunks (2^22 frames each), a coarse and a fine pass, stereo."""
+    n = (1 << 22) * 2 + 54321
+    if signal == "noise":
+        x = np.stack([0.9 * xorshift_uniform(n, seed=21), 0.6 * xorshift_uniform(n, seed=22)], 1)
+    else:
+        x = np.stack([0.6 * harmonic_stack(n, 96000) + 0.03 * xorshift_uniform(n, seed=23),
+                      0.5 * harmonic_stack(n, 96000)[::-1] + 0.03 * xorshift_uniform(n, seed=24)], 1)
+        x[n // 3:n // 2] *= 0.1
+    x = np.ascontiguousarray(x, np.float32)
+    b, _ = _sweep_table(pkg, x, P, 24, prune=False)
+    a, _ = _sweep_table(pkg, x, P, 24, prune=True)
+    f, _ = _sweep_table(pkg, x, P, 24, prune=True, fused=True)
+    fu = dict(_sweep_table.last_fused)
+    assert a.tobytes() == b.tobytes()
+    assert f.tobytes() == b.tobytes()
+    assert fu["tested"] > 0 and 0 < fu["listed"] < 0.7 * fu["tested"], fu
+    print("\n[fused sweep, blksiz %d, %s] %.1f %% of the tested frames listed" % (P, signal, 100.0 * fu["listed"] / fu["tested"]))
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_sweep_random_shapes_against_oracle_and_unpruned(pkg, seed):
     """Randomised: block size, channel count, length (1 frame ... 150 000), angle range and stride, signal shape per channel
