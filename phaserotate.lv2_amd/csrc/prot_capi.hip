@@ -833,7 +833,7 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 		}
 		const uint32_t n_launch = e->info.partitions / np;
 		if (fs) { // (long FIRs, CLI blksiz 16384 / 32768: the LAST accumulating launch tests instead of storing)
-			if (n_launch < 2 || np != 2 || !hilbert_only) {
+			if (!hilbert_only || !((n_launch >= 2 && np == 2) || (n_launch == 1 && np == 1 && e->hopseg == 28))) {
 				return PROT_EUNSUPPORTED;
 			}
 			const int st = fs_prepare ();
@@ -1834,7 +1834,9 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 	// (two routes: the overlap-save kernel's MODE_SWEEP -- blksiz 2048, 4096 --, and for the long FIRs whose Hilbert branch takes
 	// several accumulating olapoly launches -- blksiz 16384, 32768 -- the LAST of those launches, which then tests the complete
 	// Hilbert value instead of storing it; the earlier launches leave their partial sums in the engine's Hilbert workspace)
-	const bool fuse_poly = e->use_poly && !e->use_save && !e->sv8_always && e->info.partitions >= 4 && e->hopseg == 16;
+	// (... and the one launch of CLI blksiz 1024, whose 14-row blocks the overlap-save kernel does not take)
+	const bool fuse_poly = e->use_poly && !e->use_save && !e->sv8_always &&
+	                       ((e->info.partitions >= 4 && e->hopseg == 16) || (e->info.partitions == 1 && e->hopseg == 28));
 	const bool fusable = ((e->use_save && (e->hopseg == 16 || e->hopseg == 24) && !(e->sv_flags & 1)) || fuse_poly) &&
 	                     !g_test_opt[PROT_TEST_SWEEP_UNPRUNED].load () && !g_test_opt[PROT_TEST_SWEEP_UNFUSED].load ();
 	hipStream_t s   = pick_stream (e, stream);

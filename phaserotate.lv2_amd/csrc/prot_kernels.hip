@@ -1039,10 +1039,13 @@ hipError_t launch_ola4096_p2_f16 (const OlaParamsH& p, int n_chn, hipStream_t s)
 // --------------------------------------------------------------------------------------
 // WPS = workgroups per CU (= waves per SIMD) the register budget is sized for: 2 (<= 256 VGPRs, tables fetched a whole
 // butterfly ahead) or 3 (<= 168 VGPRs: tables fetched in small batches, 3 x 53 KiB of LDS is the whole CU)
-template <class T, int NP, int HS, int MODE, int DH, bool ACC, int WPS = 2>
+// (LEAN_: the register-lean arithmetic of the three-per-CU form -- split outer twiddles, smaller table batches; a template
+// parameter of its own so that a two-per-CU instantiation can compute the SAME BITS as its three-per-CU twin: MODE_SWEEP of
+// CLI blksiz 1024 against the separate Hilbert launch)
+template <class T, int NP, int HS, int MODE, int DH, bool ACC, int WPS = 2, bool LEAN_ = (WPS >= 3)>
 __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<typename T::samp> p)
 {
-	constexpr bool LEAN = WPS >= 3;
+	constexpr bool LEAN = LEAN_;
 	typedef typename T::cplx C;  // one complex of the transform = one PAIR of stream frames in HBM
 	typedef typename T::ops  O;
 	typedef typename T::samp S;
@@ -1618,6 +1621,15 @@ static hipError_t launch_poly_m (const OlaParamsT<typename T::samp>& p, dim3 gri
 				return hipErrorInvalidValue;
 			}
 			hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE_SWEEP, 0, true, WPS>), grid, block, 0, s, p);
+			return hipGetLastError ();
+		}
+	}
+	if constexpr (sizeof (typename T::samp) == 4 && NP == 1 && HS == 14 && MODE == MODE_HILBERT) {
+		if (p.surv != nullptr) { // CLI blksiz 1024: the one launch of its Hilbert branch, testing instead of storing
+			if (p.accumulate) {
+				return hipErrorInvalidValue;
+			}
+			hipLaunchKernelGGL ((olapoly_kernel<T, NP, HS, MODE_SWEEP, 0, false, 2, (WPS >= 3)>), grid, block, 0, s, p);
 			return hipGetLastError ();
 		}
 	}
