@@ -730,7 +730,7 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 	}
 	// The fused sweep (fs): the test rides in the (last) Hilbert launch -- one list per wave (4 per workgroup), long enough for
 	// every frame of the workgroup's run to survive.  0: launch; 1: plan_only, nothing to launch; < 0: -status
-	auto fs_prepare = [&] () -> int {
+	auto fs_prepare = [&] (int waves = 4) -> int { // waves per workgroup of the kernel that lists (8: the 8192-point kernel)
 		const int64_t blk = (int64_t)e->info.run_align;
 		if (fs->sample) {
 			p.run_frames = (int)blk;
@@ -743,8 +743,8 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 		for (int k = 0; k < p.n_rank && p.rank_cu > 0; ++k) {
 			longest = std::max<int64_t> (longest, p.rank_frames[k]);
 		}
-		fs->n_lists = (int)runs * 4;
-		fs->cap     = ((longest / 4 + 3) & ~(int64_t)3) + 4; // a wave's share of its workgroup's longest run
+		fs->n_lists = (int)runs * waves;
+		fs->cap     = ((longest / waves + 3) & ~(int64_t)3) + 4; // a wave's share of its workgroup's longest run
 		if (fs->plan_only) {
 			return 1;
 		}
@@ -801,6 +801,15 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 			p.sv_flags   = e->sv_flags;
 			p.conv_delay = (int)e->info.conv_delay;
 			p.accumulate = 0;
+			if (fs) { // (CLI blksiz 8192: the fused sweep on 8192-point blocks, eight lists per workgroup)
+				if (e->sv8_rows != 8 || !hilbert_only) {
+					return PROT_EUNSUPPORTED;
+				}
+				const int st = fs_prepare (8);
+				if (st != 0) {
+					return st > 0 ? PROT_OK : -st;
+				}
+			}
 			hipError_t err = prot::launch_ola_save8k (p, e->sv8_rows, n_chn, s);
 			if (err != hipSuccess) {
 				return hip_fail (err, "overlap-save (8192-point) ola kernel launch");
@@ -1837,7 +1846,7 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 	// (... and the one launch of CLI blksiz 1024, whose 14-row blocks the overlap-save kernel does not take)
 	const bool fuse_poly = e->use_poly && !e->use_save && !e->sv8_always &&
 	                       ((e->info.partitions >= 4 && e->hopseg == 16) || (e->info.partitions == 1 && e->hopseg == 28));
-	const bool fusable = ((e->use_save && (e->hopseg == 16 || e->hopseg == 24) && !(e->sv_flags & 1)) || fuse_poly) &&
+	const bool fusable = ((e->use_save && (e->hopseg == 16 || e->hopseg == 24) && !(e->sv_flags & 1)) || fuse_poly || (e->sv8_always && !(e->sv_flags & 1))) &&
 	                     !g_test_opt[PROT_TEST_SWEEP_UNPRUNED].load () && !g_test_opt[PROT_TEST_SWEEP_UNFUSED].load ();
 	hipStream_t s   = pick_stream (e, stream);
 	const int   c0  = chn < 0 ? 0 : chn;                       // cli/phase-rotate.cc:434-435

@@ -45,7 +45,18 @@ constexpr int kSv8LdsBytes = 16 * 560 * 8 + 8192; // exchange area (16 rows of 5
 	PROT_SV8_CALL (KIND_, 13, 0, in_, out_, nf_, ca_, sa_)                                                                              \
 	PROT_SV8_CALL (KIND_, 13, 2, in_, out_, nf_, ca_, sa_)
 
-// HS new rows (1024 HS frames) per block; MODE_ROT / MODE_RAMP / MODE_HILBERT.  Same division of labour as olasave_kernel:
+// MODE_SWEEP: the generated loop with the sweep's test in its epilogue (no output rows: survivors appended at cursor_, the running
+// max |x| in raw_); cursor_ and raw_ are read and written (prot_olasave.hip's PROT_SV_SWEEP_CALL)
+#define PROT_SV8_SWEEP_CALL(HS_, in_, cursor_, raw_, nf_, thr_, gain_)                                                                 \
+	if (HS == HS_) {                                                                                                                    \
+		asm volatile (PROT_SV8_SWEEP_##HS_                                                                                              \
+		              : "=s"(cursor_), "=v"(raw_)                                                                                       \
+		              : "s"(in_), "s"(nf_), "s"(lds_off), "s"(a_sv), "s"(thr_), "s"(gain_), "v"(t0), "s"(cursor_), "v"(raw_)             \
+		              : PROT_SV8_SWEEP_CLOBBERS_##HS_);                                                                                 \
+	}
+
+// HS new rows (1024 HS frames) per block; MODE_ROT / MODE_RAMP / MODE_HILBERT / MODE_SWEEP (HS = 8: the fused sweep of the CLI's
+// blksiz 8192 engine -- the Hilbert branch tested against the call's bound, survivors listed per wave: prot_olasave.hip).  Same division of labour as olasave_kernel:
 // consecutive whole in-range blocks are ONE call of the generated loop; every other block is staged here, position by
 // position, into the LDS exchange area, transformed by the generated CORE (the same instructions on the same values: the
 // two paths agree bit for bit) and stored from LDS with bounds.
@@ -58,16 +69,66 @@ __global__ __launch_bounds__ (512, 4) void olasave8k_kernel (const OlaParams p)
 	constexpr int ROT = (NT & 1) ? 256 : 0;  // complex samples the block is rotated by
 	constexpr int AM  = MODE == MODE_ROT ? 0 : 2;
 	static_assert (HS == 8 || HS == 12 || HS == 13, "rows per block");
+	static_assert (MODE != MODE_SWEEP || HS == 8, "the fused sweep exists for the CLI engine on these blocks (blksiz 8192)");
 
 	extern __shared__ f2 smem8[]; // kSv8LdsBytes: the exchange area + the two tables (written by the generated prologue)
 
 	const int t0 = threadIdx.x;
 	const int c  = blockIdx.y;
+	// MODE_SWEEP state (as in prot_olasave.hip: the bound parked per wave in global memory behind the list lengths and re-read where
+	// it is used, nothing per lane but the running maximum and nothing uniform but the count lives across the generated code)
+	__shared__ float sw_lo_s[8];
+	float            sw_raw = 0.f;
+	unsigned         sw_cnt = 0u;
+	auto sw_thr_slot = [&] () -> float* {
+		const int w = __builtin_amdgcn_readfirstlane (threadIdx.x >> 6);
+		return reinterpret_cast<float*> (p.surv_cnt) + (int64_t)gridDim.y * gridDim.x * 8 + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + w;
+	};
+	auto sw_thr = [&] () -> float {
+		return __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (__hip_atomic_load (sw_thr_slot (), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))));
+	};
+	auto sw_wave_reduce = [] (float v, bool take_max) -> float {
+		int lane;
+		asm volatile ("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+		for (int m = 1; m < 64; m <<= 1) {
+			const float o = __int_as_float (__builtin_amdgcn_ds_bpermute ((lane ^ m) << 2, __float_as_int (v)));
+			v             = take_max ? fmaxf (v, o) : fminf (v, o);
+		}
+		return v;
+	};
+	auto sw_list = [&] () -> float2* {
+		const int w = __builtin_amdgcn_readfirstlane (threadIdx.x >> 6);
+		return uniform_ptr_generic (p.surv + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + w) * p.surv_cap);
+	};
+	if (MODE == MODE_SWEEP) {
+		float lo = 1.0e18f;
+		if (!p.sw_thr_zero) {
+			for (int i = t0; i < p.sw_n_angles; i += 512) {
+				lo = fminf (lo, __builtin_nontemporal_load (&p.sw_peaks[(int64_t)c * kMaxSample + p.sw_angles[i]]));
+			}
+		} else {
+			lo = 0.f;
+		}
+		lo = sw_wave_reduce (lo, false);
+		if ((t0 & 63) == 0) {
+			sw_lo_s[t0 >> 6] = lo;
+		}
+		__syncthreads ();
+		lo = fminf (fminf (fminf (sw_lo_s[0], sw_lo_s[1]), fminf (sw_lo_s[2], sw_lo_s[3])), fminf (fminf (sw_lo_s[4], sw_lo_s[5]), fminf (sw_lo_s[6], sw_lo_s[7])));
+		__syncthreads ();
+		if ((t0 & 63) == 0) {
+			__hip_atomic_store (sw_thr_slot (), lo * lo * 0.9999f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+	}
 	int64_t   r0, rlen;
 	run_of_workgroup (p, r0, rlen);
 	if (r0 >= p.n_out) {
 		if (t0 < 256) {
 			hist_write_slice (p, blockIdx.y, t0);
+		}
+		if (MODE == MODE_SWEEP && (t0 & 63) == 0) {
+			p.surv_cnt[((int64_t)c * gridDim.x + blockIdx.x) * 8 + (t0 >> 6)] = 0u;
 		}
 		return;
 	}
@@ -81,6 +142,12 @@ __global__ __launch_bounds__ (512, 4) void olasave8k_kernel (const OlaParams p)
 	const bool in_al8  = (reinterpret_cast<uintptr_t> (in) & 7) == 0;
 	const bool out_al8 = (reinterpret_cast<uintptr_t> (out) & 7) == 0;
 
+	if (MODE == MODE_SWEEP && p.sw_raw_slot >= 0 && p.sw_raw_tail && blockIdx.x == 0) {
+		// the call's last dry_delay input frames: the rows reach them only as the next chunk's history (see prot_sweep.hip)
+		for (int64_t i = n_in - Dd + t0; i < n_in; i += 512) {
+			sw_raw = fmaxf (sw_raw, i >= 0 ? fabsf (in[i]) : 0.f);
+		}
+	}
 	float ca = 0.f, sa = p.sv_gain;
 	if (MODE == MODE_ROT) {
 		ca = p.rot ? p.rot[2 * c] : p.rot_v[2 * c];
@@ -110,7 +177,8 @@ __global__ __launch_bounds__ (512, 4) void olasave8k_kernel (const OlaParams p)
 		// frame of local sample 0's aligned pair: the dry frame of output position p is input position p, and output row R0
 		// starts at local sample 512 R0 + ROT
 		const int64_t a0 = s - Dd - 1024 * R0 - 2 * ROT;
-		if (MODE != MODE_RAMP && in_al8 && out_al8 && a0 >= 1 && !(p.sv_flags & 1)) {
+		if (MODE != MODE_RAMP && in_al8 && (out_al8 || MODE == MODE_SWEEP) && a0 >= 1 && !(p.sv_flags & 1) &&
+		    (MODE != MODE_SWEEP || (s >= p.sw_t_begin && s >= p.sw_dry_from))) {
 			// blocks from here on that read only frames inside the array (local samples 0..8191 and the frame in front) and
 			// are emitted whole
 			const int64_t n1 = (r1 - s) / BLK;
@@ -119,8 +187,16 @@ __global__ __launch_bounds__ (512, 4) void olasave8k_kernel (const OlaParams p)
 			if (nf > 0) {
 				nf                 = __builtin_amdgcn_readfirstlane (nf);
 				const float* a_in  = uniform_ptr_generic (in + a0);
-				float*       a_out = uniform_ptr_generic (out + s);
-				PROT_SV8_ALL (ASM, a_in, a_out, nf, ca, sa)
+				if constexpr (MODE == MODE_SWEEP) {
+					float2* const base  = sw_list ();
+					float2*       cur   = uniform_ptr_generic (base + sw_cnt);
+					const float   thr_u = sw_thr ();
+					PROT_SV8_SWEEP_CALL (8, a_in, cur, sw_raw, nf, thr_u, sa)
+					sw_cnt = (unsigned)__builtin_amdgcn_readfirstlane ((int)(cur - sw_list ()));
+				} else {
+					float* a_out = uniform_ptr_generic (out + s);
+					PROT_SV8_ALL (ASM, a_in, a_out, nf, ca, sa)
+				}
 				s += (int64_t)nf * BLK;
 				continue;
 			}
@@ -145,7 +221,7 @@ __global__ __launch_bounds__ (512, 4) void olasave8k_kernel (const OlaParams p)
 		}
 		__syncthreads ();
 		{
-			const float  cca = MODE == MODE_RAMP ? 0.f : ca, csa = MODE == MODE_RAMP ? __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (p.sv_gain))) : sa;
+			const float  cca = (MODE == MODE_RAMP || MODE == MODE_SWEEP) ? 0.f : ca, csa = MODE == MODE_RAMP ? __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (p.sv_gain))) : sa;
 			const float* a_in  = a_sv; // (unused by the core)
 			float*       a_out = nullptr;
 			const int    one   = 1;
@@ -157,7 +233,33 @@ __global__ __launch_bounds__ (512, 4) void olasave8k_kernel (const OlaParams p)
 		asm volatile ("" : "+v"(t));
 		t &= 511;
 		// rows 0..HS-1 of the staging area now hold the output pairs of frames s + 1024 k + 2 t (+1)
-		if (MODE != MODE_RAMP && s + BLK <= r1 && out_al8) {
+		if constexpr (MODE == MODE_SWEEP) {
+			// the sweep's test on an edge block (prot_olasave.hip): frames in front of sw_t_begin or beyond the call are not tested, the
+			// dry term is 0 while t < sw_dry_from (Q1; the raw peak takes the frame all the same)
+			float2* const list    = sw_list ();
+			const float   sw_thr2 = sw_thr ();
+			for (int k = 0; k < HS; ++k) {
+				const f2      hp   = st[512 * k + t];
+				const int64_t pos0 = s + 1024 * (int64_t)k + 2 * (int64_t)t;
+				const f2      dp   = half_pair (pos0 - 2 * (int64_t)(t & 255) - Dd, t & 255);
+#pragma unroll
+				for (int e = 0; e < 2; ++e) {
+					const int64_t pos = pos0 + e;
+					const bool    in_ = pos >= p.sw_t_begin && pos < r1;
+					const float   raw = e ? dp.y : dp.x, h = e ? hp.y : hp.x;
+					const float   d   = pos >= p.sw_dry_from ? raw : 0.f;
+					if (in_) {
+						sw_raw = fmaxf (sw_raw, fabsf (raw));
+					}
+					const bool     live = in_ && d * d + h * h > sw_thr2;
+					const uint64_t mask = __builtin_amdgcn_ballot_w64 (live);
+					if (live) {
+						list[sw_cnt + __builtin_amdgcn_mbcnt_hi ((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned)mask, 0u))] = make_float2 (d, h);
+					}
+					sw_cnt += (unsigned)__builtin_popcountll (mask);
+				}
+			}
+		} else if (MODE != MODE_RAMP && s + BLK <= r1 && out_al8) {
 #pragma unroll
 			for (int k = 0; k < HS; ++k) {
 				PROT_GLOBAL f2* __restrict__ ob = reinterpret_cast<PROT_GLOBAL f2*> (uniform_ptr (out + s + 1024 * k));
@@ -189,6 +291,20 @@ __global__ __launch_bounds__ (512, 4) void olasave8k_kernel (const OlaParams p)
 	if (t0 < 256) {
 		hist_write_slice (p, blockIdx.y, t0);
 	}
+	if constexpr (MODE == MODE_SWEEP) {
+		if ((t0 & 63) == 0) {
+			p.surv_cnt[((int64_t)c * gridDim.x + blockIdx.x) * 8 + (t0 >> 6)] = sw_cnt;
+		}
+		if (p.sw_raw_slot >= 0) {
+			sw_raw = sw_wave_reduce (sw_raw, true);
+			if ((t0 & 63) == 0 && sw_raw > 0.f) { // (non-negative floats order as their bit patterns; look before the atomic)
+				unsigned* const slot = reinterpret_cast<unsigned*> (p.sw_peaks + (int64_t)c * kMaxSample + p.sw_raw_slot);
+				if (__float_as_uint (sw_raw) > __hip_atomic_load (slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+					atomicMax (slot, __float_as_uint (sw_raw));
+				}
+			}
+		}
+	}
 }
 
 template <int HS>
@@ -196,12 +312,19 @@ static hipError_t launch_sv8_m (const OlaParams& p, dim3 grid, hipStream_t s)
 {
 	const dim3 block (512);
 	typedef void (*kern_t) (OlaParams);
-	const kern_t fn = p.hilbert_only ? olasave8k_kernel<HS, MODE_HILBERT> : p.rot_s != nullptr ? olasave8k_kernel<HS, MODE_RAMP> : olasave8k_kernel<HS, MODE_ROT>;
+	kern_t fn = p.hilbert_only ? olasave8k_kernel<HS, MODE_HILBERT> : p.rot_s != nullptr ? olasave8k_kernel<HS, MODE_RAMP> : olasave8k_kernel<HS, MODE_ROT>;
+	if (p.surv != nullptr) { // the fused sweep: the Hilbert pass with the test in its epilogue (lists instead of output rows)
+		if constexpr (HS == 8) {
+			fn = olasave8k_kernel<HS, MODE_SWEEP>;
+		} else {
+			return hipErrorInvalidValue;
+		}
+	}
 	// (more than 64 KiB of LDS per workgroup has to be asked for, once per kernel and device)
-	static bool asked[3][8] = {};
+	static bool asked[4][8] = {};
 	int         dev = 0;
 	(void)hipGetDevice (&dev);
-	const int mi = p.hilbert_only ? 2 : p.rot_s != nullptr ? 1 : 0;
+	const int mi = p.surv != nullptr ? 3 : p.hilbert_only ? 2 : p.rot_s != nullptr ? 1 : 0;
 	if (dev >= 0 && dev < 8 && !asked[mi][dev]) {
 		hipError_t err = hipFuncSetAttribute ((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, kSv8LdsBytes);
 		if (err != hipSuccess) {
@@ -227,7 +350,8 @@ hipError_t launch_ola_save8k (const OlaParams& p, int hop_rows, int n_chn, hipSt
 	if (p.n_out <= 0) {
 		return hipSuccess;
 	}
-	const int64_t runs = (p.n_out + p.run_frames - 1) / p.run_frames;
+	const int64_t unit = p.run_stride > 0 ? p.run_stride : p.run_frames;
+	const int64_t runs = (p.n_out + unit - 1) / unit;
 	dim3          grid ((unsigned)runs, (unsigned)n_chn);
 	switch (hop_rows) {
 		case 8: return launch_sv8_m<8> (p, grid, s);

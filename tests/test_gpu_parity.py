@@ -915,11 +915,13 @@ def test_overlap_save_equals_overlap_add_on_random_chunkings(pkg, seed):
     assert np.abs(outs[0] - outs[1]).max() < 2e-6, (kind, param, nc, n, stride, len(cuts))
 
 
-@pytest.mark.parametrize("P,signal", [(16384, "harmonic"), (16384, "noise"), (32768, "harmonic"), (1024, "harmonic"), (1024, "noise")])
+@pytest.mark.parametrize("P,signal", [(16384, "harmonic"), (16384, "noise"), (32768, "harmonic"), (1024, "harmonic"), (1024, "noise"),
+                                      (8192, "harmonic"), (8192, "noise")])
 def test_fused_sweep_of_the_long_fir_engines_is_bit_identical(pkg, P, signal):
     """CLI blksiz 16384 (the reference's default at 96 kHz, cli/phase-rotate.cc:749-755) and 32768: the Hilbert branch takes two /
     four accumulating launches; on the fused route the LAST one tests the complete Hilbert value with its dry frame instead of
-    storing it and lists the survivors (olapoly_kernel MODE_SWEEP); blksiz 1024: its one launch does.  Same table as the separate passes and as the unpruned
+    storing it and lists the survivors (olapoly_kernel MODE_SWEEP); blksiz 1024: its one launch does; blksiz 8192 (the default at 44.1 /
+    48 kHz): olasave8k_kernel<8, MODE_SWEEP>, the generated loop of the 8192-point blocks with the test in its epilogue.  Same table as the separate passes and as the unpruned
     kernel, bit for bit, over several device chunks (2^22 frames each), a coarse and a fine pass, stereo."""
     n = (1 << 22) * 2 + 54321
     if signal == "noise":

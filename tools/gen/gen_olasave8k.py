@@ -29,7 +29,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "model"))
 from isa import Prog, Emu, V, VP, S, SP, Lit  # noqa: E402
 import gen_olasave as G4  # noqa: E402  (the butterfly network, the packed helpers and the SGPR numbers of its constants)
-from gen_olasave import Gen, S_IN, S_OUT, S_NBLK, S_LDS, S_SV, S_ROT, S_C32, S_RR, S_W1, S_W3, S_W9, S_T, S_A0, MODE_ROT, MODE_HILBERT  # noqa: E402
+from gen_olasave import Gen, S_IN, S_OUT, S_NBLK, S_LDS, S_SV, S_ROT, S_C32, S_RR, S_W1, S_W3, S_W9, S_T, S_A0, MODE_ROT, MODE_HILBERT, MODE_SWEEP  # noqa: E402
 
 NTHR = 512
 ROWS = 560                          # slots (8 B) per k1 row of the exchange area: two 16 x 17 chunks + 16 (rows 4480 B apart: no bank conflict)
@@ -92,6 +92,8 @@ class Gen8k(Gen):
             n += 2
         self.n_vgpr = n
         assert len(self.TMP) >= 7, "temporaries: %d" % len(self.TMP)
+        if MODE == MODE_SWEEP:      # the running max |x| of the frames that pass through (the raw peak) lives across blocks: one
+            self.V_RAW = V(120)     # register beyond the plan (gen_olasave.py's sweep_row is inherited as it is)
         self.TB = self.TMP[:4]
         self.TR = self.TMP[4:5]
         self.TT = self.TMP[5:9] if len(self.TMP) >= 9 else self.TMP[5:6] * 4
@@ -576,6 +578,9 @@ class Gen8k(Gen):
         P, R0 = self.P, self.R0
         nt = "nt" in self.opts
         x = u[R0 + k]
+        if self.MODE == MODE_SWEEP: # (run kind only: edge blocks take the Hilbert core and are tested by the C++ code)
+            self.sweep_row(self.K[R0 + k], x)
+            return
         if self.MODE == MODE_ROT:   # (sa * gain rides in the inverse table: prologue_rows)
             P.pk("fma", x, [self.K[R0 + k], S_ROT, x], op_sel=[0, 0, 0], op_sel_hi=[1, 0, 1])
         if self.kind == "core":
@@ -591,8 +596,9 @@ class Gen8k(Gen):
         if not core:
             P.s_waitcnt(vmcnt=0)
             P.label("L_top")
-            P.s_waitcnt(vmcnt=HS, lgkmcnt=0)
-            P.reset_queues(vm_stores=HS)
+            n_st = 2 * HS if self.MODE == MODE_SWEEP else HS   # (two appends per row instead of one store)
+            P.s_waitcnt(vmcnt=n_st, lgkmcnt=0)
+            P.reset_queues(vm_stores=n_st)
         P.comment("---- (p, q) pairs")
         self.build_pq()
         self.tap("pq", self.D)
@@ -685,8 +691,9 @@ class Gen8k(Gen):
             self.epilogue_row(u, k)
         P.s_add_u32(S_IN.lo, S_IN.lo, Lit(4 * self.BLK))
         P.s_addc_u32(S_IN.hi, S_IN.hi, Lit(0))
-        P.s_add_u32(S_OUT.lo, S_OUT.lo, Lit(4 * self.BLK))
-        P.s_addc_u32(S_OUT.hi, S_OUT.hi, Lit(0))
+        if self.MODE != MODE_SWEEP:    # (SWEEP: S_OUT is the survivor cursor, advanced by what was appended)
+            P.s_add_u32(S_OUT.lo, S_OUT.lo, Lit(4 * self.BLK))
+            P.s_addc_u32(S_OUT.hi, S_OUT.hi, Lit(0))
         P.s_sub_u32(S_NBLK, S_NBLK, Lit(1))
         P.s_cmp_lg_u32(S_NBLK, Lit(0))
         P.s_cbranch_scc1("L_top")
@@ -760,6 +767,12 @@ def self_test(HS, MODE, nblk=3, seed=1, verbose=True, opts=(), kind="run"):
     emu.map(SV_BASE, tab.view(np.uint32))
     ldsf = emu.lds.view(np.float32)
     ca, sa = 0.6, -0.8
+    thr2 = 0.30
+    if MODE == MODE_SWEEP:   # S_ROT.lo is the bound, the Hilbert branch is unscaled, every wave appends to a list of its own
+        ca, sa = thr2, 1.0
+        SURV_BASE, CAP = 0x40000000, 2 * BLK * nblk
+        surv = np.zeros(8 * CAP, np.float32)
+        emu.map(SURV_BASE, surv.view(np.uint32))
     def sset(sp, lo, hi):
         emu.s[:, sp.n] = np.float32(lo).view(np.uint32)
         emu.s[:, sp.n + 1] = np.float32(hi).view(np.uint32)
@@ -773,6 +786,11 @@ def self_test(HS, MODE, nblk=3, seed=1, verbose=True, opts=(), kind="run"):
     emu.s[:, S_NBLK.n] = nblk
     emu.s[:, S_LDS.n] = 0
     emu.v[g.TMP[0].n] = np.arange(NTHR, dtype=np.uint32)
+    if MODE == MODE_SWEEP:
+        for w in range(8):
+            a_ = SURV_BASE + 4 * CAP * w
+            emu.s[w, S_OUT.n], emu.s[w, S_OUT.n + 1] = a_ & 0xffffffff, a_ >> 32
+        emu.v[g.V_RAW.n] = np.zeros(NTHR, np.float32).view(np.uint32)
     tt = np.arange(NTHR)
     if kind == "core":   # what the C++ code stages: position (r, T) <-> local sample (512 r + T + ROT) mod 8192, as (q, c) pairs
         for r in range(16):
@@ -801,11 +819,51 @@ def self_test(HS, MODE, nblk=3, seed=1, verbose=True, opts=(), kind="run"):
             y = full[j + Lg // 2]
             dq, dc = xd[a0 + 2 * j], xd[a0 + 2 * j + 1]
             pos = b * BLK + 1024 * k + 2 * np.arange(512)
-            if MODE == MODE_ROT:
+            if MODE == MODE_SWEEP:     # keep (d, h) per frame for the survivor check below
+                want[pos], want[pos + 1] = y.real, y.imag
+                if b == 0 and k == 0:
+                    dry = np.zeros(BLK * nblk)
+                dry[pos], dry[pos + 1] = dq, dc
+            elif MODE == MODE_ROT:
                 want[pos], want[pos + 1] = ca * dq + sa * y.real, ca * dc + sa * y.imag
             else:
                 want[pos], want[pos + 1] = sa * y.real, sa * y.imag
-    err = np.abs(out[:BLK * nblk] - want).max()
+    if MODE == MODE_SWEEP:
+        # every wave's list: frames in the order (block, row, first / second frame of the pairs, lane); exact d, h to rounding,
+        # membership by d^2 + h^2 > bound (frames within rounding of the bound may go either way)
+        err = 0.0
+        for w in range(8):
+            end = (int(emu.s[w, S_OUT.n]) | (int(emu.s[w, S_OUT.n + 1]) << 32)) - (SURV_BASE + 4 * CAP * w)
+            got = surv[CAP * w:CAP * w + end // 4].reshape(-1, 2)
+            exp = []
+            for b in range(nblk):
+                for k in range(HS):
+                    for half in range(2):
+                        pos = b * BLK + 1024 * k + 2 * (64 * w + np.arange(64)) + half
+                        exp += [(dry[p_], want[p_]) for p_ in pos]
+            exp = np.array(exp)
+            r2 = exp[:, 0] ** 2 + exp[:, 1] ** 2
+            sure, maybe = r2 > thr2 + 1e-5, np.abs(r2 - thr2) <= 1e-5
+            gi = 0
+            for j in range(len(exp)):
+                hit = gi < len(got) and got[gi, 0] == np.float32(exp[j, 0]) and abs(got[gi, 1] - exp[j, 1]) < 1e-6
+                if sure[j] or (maybe[j] and hit):
+                    assert hit, ("survivor list of wave %d differs at entry %d" % (w, gi))
+                    err = max(err, abs(got[gi, 1] - exp[j, 1]))
+                    gi += 1
+            assert gi == len(got), "wave %d appended %d entries, expected %d" % (w, len(got), gi)
+            raw = emu.v[g.V_RAW.n].view(np.float32)[64 * w:64 * w + 64]
+            lanes = 64 * w + np.arange(64)
+            rexp = np.zeros(64)
+            for b in range(nblk):
+                for k in range(HS):
+                    pos = b * BLK + 1024 * k + 2 * lanes
+                    rexp = np.maximum(rexp, np.maximum(np.abs(dry[pos]), np.abs(dry[pos + 1])))
+            assert np.array_equal(raw, rexp.astype(np.float32)), "running max |x|"
+        frac = sum(((int(emu.s[w, S_OUT.n]) | (int(emu.s[w, S_OUT.n + 1]) << 32)) - (SURV_BASE + 4 * CAP * w)) // 8 for w in range(8)) / (BLK * nblk)
+        kind = kind + " sweep (%.0f %% of the frames survive)" % (100 * frac)
+    else:
+        err = np.abs(out[:BLK * nblk] - want).max()
     st = P.stats()
     npk = sum(v for k, v in st.items() if k.startswith("pk_"))
     nval = sum(v for k, v in st.items() if k.startswith("v_"))
@@ -821,6 +879,7 @@ def self_test(HS, MODE, nblk=3, seed=1, verbose=True, opts=(), kind="run"):
 # HS = 8: the CLI's default engine at 48 kHz (blksiz 8192: 4096 odd taps = 8 context rows) as ONE table-free partition.
 # (HS = 14, CLI blksiz 2048, passes the self-test too and is not emitted: the 4096-point kernel that serves it is faster)
 VARIANTS = [(hs, mode) for hs in (8, 12, 13) for mode in (MODE_ROT, MODE_HILBERT)]
+SWEEP_HS = (8,)   # MODE_SWEEP: the fused sweep of the CLI engine on these blocks
 
 
 def emit(path, opts=()):
@@ -854,9 +913,36 @@ def emit(path, opts=()):
                 out.append('\t"%s\\n\t" \\' % l)
             out.append('\t""')
             out.append("")
+    # MODE_SWEEP (run kind only; edge blocks take the Hilbert core and are tested by the C++ code), for the CLI engine that runs
+    # on these blocks (blksiz 8192: HS = 8).  Operands as prot_olasave_asm.inc's PROT_SV_SWEEP_*: %0 survivor cursor (out), %1
+    # running max |x| (out), %2 in, %3 blocks, %4 LDS byte offset, %5 constants table, %6 bound, %7 gain, %8 thread id, %9 and %10 the
+    # cursor and the running maximum on entry
+    for HS in SWEEP_HS:
+        g = Gen8k(HS, MODE_SWEEP, opts, "run")
+        P = g.build()
+        nv[HS] = max(nv.get(HS, 0), g.n_vgpr)
+        head = ["s_mov_b64 %r, %%2" % S_IN, "s_mov_b64 %r, %%9" % S_OUT, "s_mov_b32 %r, %%3" % S_NBLK, "s_mov_b32 %r, %%4" % S_LDS,
+                "s_mov_b64 %r, %%5" % S_SV, "s_mov_b32 %r, %%6" % S_ROT.lo, "s_mov_b32 %r, %%7" % S_ROT.hi, "v_mov_b32 %r, %%8" % g.TMP[0].lo,
+                "v_mov_b32 %r, %%10" % g.V_RAW, "s_waitcnt vmcnt(0) lgkmcnt(0)"]
+        for n, (lo, hi) in sorted(g.constants().items()):
+            head.append("s_mov_b32 s%d, %r" % (n, Lit(float(lo))))
+            head.append("s_mov_b32 s%d, %r" % (n + 1, Lit(float(hi))))
+        tail = ["s_mov_b64 %%0, %r" % S_OUT, "v_mov_b32 %%1, %r" % g.V_RAW]
+        lines = head + P.text(label_suffix="%=") + tail
+        st = P.stats()
+        out.append("// sweep, HS %d: %d VGPRs, %d instructions" % (HS, g.n_vgpr, sum(v for k, v in st.items() if k not in ("comment", "label", "probe"))))
+        out.append("#define PROT_SV8_SWEEP_%d \\" % HS)
+        for l in lines:
+            if l.startswith(";"):
+                continue
+            out.append('\t"%s\\n\t" \\' % l)
+        out.append('\t""')
+        out.append("")
     for HS in sorted(nv):
         clob = ['"memory"', '"vcc"', '"scc"'] + ['"s%d"' % i for i in SGPR_CLOBBER] + ['"v%d"' % i for i in range(0, nv[HS])]
         out.append("#define PROT_SV8_ASM_CLOBBERS_%d " % HS + ", ".join(clob))
+        if HS in SWEEP_HS:
+            out.append("#define PROT_SV8_SWEEP_CLOBBERS_%d PROT_SV8_ASM_CLOBBERS_%d, \"v120\"" % (HS, HS))
     out.append("")
     open(path, "w").write("\n".join(out))
 
@@ -879,6 +965,8 @@ if __name__ == "__main__":
     for HS, MODE in VARIANTS:
         self_test(HS, MODE, nblk=2 if "--quick" in sys.argv else 3)
         self_test(HS, MODE, kind="core")
+    for HS in SWEEP_HS:
+        self_test(HS, MODE_SWEEP, nblk=2)
     if "--check" not in sys.argv:
         dst = os.path.join(csrc, "prot_olasave8k_asm.inc")
         emit(dst)
