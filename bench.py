@@ -602,6 +602,8 @@ def bench_sweep(args, pkg, torch, dist, dev, st, world, rank, local_rank, barrie
     96 kHz material, 16384 (cli/phase-rotate.cc:749-755: samplerate / 8 rounded up to a power of two)."""
     main_line = _bench_sweep_at(2048, True, args, pkg, torch, dist, dev, st, world, rank, local_rank, barrier)
     main_line["blksiz_16384"] = _bench_sweep_at(16384, False, args, pkg, torch, dist, dev, st, world, rank, local_rank, barrier)
+    # ... and at the reference's default for 44.1 / 48 kHz material, 8192 (the same 96 kHz synthetic material: only the engine differs)
+    main_line["blksiz_8192"] = _bench_sweep_at(8192, False, args, pkg, torch, dist, dev, st, world, rank, local_rank, barrier)
     # the sweep against ITS roofline (SURVEY 8d: 4 B read per channel-frame): achieved from this run's wall clock, traffic = HBM
     # bytes per channel-frame by counter (tools/sweep_traffic.py under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, builder-side run
     # on 600 s of the same material, summary committed as profiles/sweep_traffic_latest.json; NOT of this run)
@@ -611,7 +613,8 @@ def bench_sweep(args, pkg, torch, dist, dev, st, world, rank, local_rank, barrie
     except Exception:
         pass
     cf = main_line["seconds_of_audio"] * 96000.0 * main_line["channels"]
-    for line, key in ((main_line, "harmonic_2048"), (main_line["noise_worst_case"], "noise_2048"), (main_line["blksiz_16384"], "harmonic_16384")):
+    for line, key in ((main_line, "harmonic_2048"), (main_line["noise_worst_case"], "noise_2048"), (main_line["blksiz_16384"], "harmonic_16384"),
+                      (main_line["blksiz_8192"], "harmonic_8192")):
         t = tr.get(key, {})
         ach = 4.0 * cf / (line["ms"] * 1e-3) / 1e9
         line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -818,15 +821,19 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
     eng.close()
     h = res["harmonic"]
     if not full:
-        return {"metric": "channel-frames/s through the 360-angle min-peak sweep (cli -s 1, default block size at 96 kHz: %d)" % P,
+        return {"metric": "channel-frames/s through the 360-angle min-peak sweep (cli -s 1 -f %d: the reference's default block size at %s)"
+                          % (P, "88.2 / 96 kHz" if P == 16384 else "44.1 / 48 kHz"),
                 "value": h["value"], "unit": "channel-frames/s", "ms": h["ms"], "unpruned_ms": h["unpruned_ms"],
                 "evaluated_fraction": h["evaluated_fraction"], "table_identical_unpruned": h["table_identical_unpruned"],
                 "min_angle_index": h["min_angle_index"], "per_rank_device_ms": h["per_rank_device_ms"],
                 "predicted_8gpu": h.get("predicted_8gpu"), "oracle_check_10s": check,
                 "fused": h["fused"], "listed_fraction": h["listed_fraction"],
-                "engine": "16384-tap FIR = four 2048-tap partitions of the odd taps: two accumulating launches of two partitions each "
-                          "for the Hilbert branch (olapoly_kernel<T32, 2, 8, ...>); round 4: the SECOND launch tests the complete Hilbert value "
-                          "with its dry frame instead of storing it and lists the survivors (MODE_SWEEP), sweep_eval_kernel evaluates the lists"}
+                "engine": ("16384-tap FIR = four 2048-tap partitions of the odd taps: two accumulating launches of two partitions each "
+                           "for the Hilbert branch (olapoly_kernel<T32, 2, 8, ...>); round 4: the SECOND launch tests the complete Hilbert value "
+                           "with its dry frame instead of storing it and lists the survivors (MODE_SWEEP), sweep_eval_kernel evaluates the lists")
+                          if P == 16384 else
+                          ("8192-tap FIR = 4096 odd taps as ONE table-free partition on 8192-point overlap-save blocks (olasave8k_kernel<8, MODE_SWEEP>: "
+                           "the Hilbert pass tests and lists), sweep_eval_kernel evaluates the lists")}
     return {"metric": "channel-frames/s through the 360-angle min-peak sweep (cli -s 1 -f 2048)",
             "signal": "32-harmonic asymmetric stack (110 / 137.5 Hz) under a slow swell + 2 % noise, generated on the device; resident in HBM",
             "value": h["value"], "unit": "channel-frames/s", "ms": h["ms"], "unpruned_ms": h["unpruned_ms"],

@@ -22,7 +22,7 @@ W="python3 bench.py --no-extra --no-cpu-baseline --steps 2 --warmup 1 --preroll 
 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA -d $OUT/sw1 -- $W > /dev/null 2> $OUT/sw1.err
 rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM SQ_INSTS_SALU GRBM_GUI_ACTIVE -d $OUT/sw2 -- $W > /dev/null 2> $OUT/sw2.err
 # the sweep's HBM bytes by counter (harmonic and noise at blksiz 2048, harmonic at 16384): tools/sweep_traffic.py
-for K in harmonic_2048 noise_2048 harmonic_16384; do
+for K in harmonic_2048 noise_2048 harmonic_16384 harmonic_8192; do
   rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/swt/fetch_$K -- python3 tools/sweep_traffic.py ${K%_*} ${K#*_} > $OUT/swt_fetch_$K.txt 2> $OUT/swt_fetch_$K.err
   rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/swt/write_$K -- python3 tools/sweep_traffic.py ${K%_*} ${K#*_} > $OUT/swt_write_$K.txt 2> $OUT/swt_write_$K.err
 done
