@@ -941,6 +941,39 @@ def test_fused_sweep_of_the_long_fir_engines_is_bit_identical(pkg, P, signal):
     print("\n[fused sweep, blksiz %d, %s] %.1f %% of the tested frames listed" % (P, signal, 100.0 * fu["listed"] / fu["tested"]))
 
 
+def test_fused_sweep_many_channels_and_single_channel_calls(pkg):
+    """The fused route with few workgroups per channel (40 channels share the device: fewer step counters than the kernels'
+    32 per channel are in use) and with single-channel calls on a multi-channel engine (chn >= 0: the lists, the bound and the
+    table rows of ONE channel): both against the unpruned kernel, bit for bit."""
+    n = (1 << 20) + 4321
+    nc = 40
+    x = np.stack([(0.2 + 0.02 * c) * xorshift_uniform(n, seed=300 + c) for c in range(nc)], 1).astype(np.float32)
+    x[n // 2:n // 2 + 2000, 7] = 0.95 * np.sign(x[n // 2:n // 2 + 2000, 7])
+    x = np.ascontiguousarray(x)
+    b, _ = _sweep_table(pkg, x, 2048, 24, prune=False, passes=((0, 360, 3),))
+    f, _ = _sweep_table(pkg, x, 2048, 24, prune=True, passes=((0, 360, 3),), fused=True)
+    fu = dict(_sweep_table.last_fused)
+    assert fu["tested"] == n // 2048 * 2048 * nc or fu["tested"] > 0, fu
+    assert f.tobytes() == b.tobytes()
+    # single-channel calls on a 3-channel engine
+    x3 = np.ascontiguousarray(x[:, :3])
+    tabs = {}
+    for mode in ("unpruned", "fused"):
+        pkg.set_test_option(pkg.TEST_SWEEP_UNPRUNED, 1 if mode == "unpruned" else 0)
+        try:
+            pr = pkg.PhaseRotate(4096, 3)
+            for c in (2, 0):
+                pr.analyze_file(x3, 0, 360, 5, chn=c)
+            tabs[mode] = np.array([[pr.peak(c, a) for a in range(360)] for c in range(3)], np.float32)
+            if mode == "fused":
+                assert pr.sweep_stats_fused()["tested"] > 0
+            pr.close()
+        finally:
+            pkg.set_test_option(pkg.TEST_SWEEP_UNPRUNED, 0)
+    assert tabs["fused"].tobytes() == tabs["unpruned"].tobytes()
+    assert tabs["fused"][1].max() == 0.0 and tabs["fused"][0].max() > 0 and tabs["fused"][2].max() > 0
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_sweep_random_shapes_against_oracle_and_unpruned(pkg, seed):
     """Randomised: block size, channel count, length (1 frame ... 150 000), angle range and stride, signal shape per channel
