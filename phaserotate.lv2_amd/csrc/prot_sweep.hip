@@ -777,26 +777,34 @@ __global__ __launch_bounds__ (256, 4) void sweep_eval_kernel (const SweepParams 
 		if (!idle) {
 			const float* const st = stage_s + buf * 2 * kStage;
 			const int          nch = ((int)dsc[gs0].y + 63) >> 6; // (a list's last step is short: the chunks beyond its entries are zeros)
+			// (fetching the next chunk's frames from the stage while this one is tested was measured: 1.5-3 % slower -- the other
+			// waves of the SIMD cover the LDS round trip already; tools/sweep_ab_libs.py)
 #pragma unroll 1
 			for (int it = sub; it < nch; it += nsub) {
-				const float d  = st[it * 64 + lane];
-				const float h  = st[kStage + it * 64 + lane];
+				const float d = st[it * 64 + lane], h = st[kStage + it * 64 + lane];
 				const float r2 = d * d + h * h;
 #pragma unroll
 				for (int q = 0; q < NBLK; ++q) {
+					// (straight-line: the three compares as lane masks, combined on the scalar unit -- written with && / || the
+					// compiler nests two EXEC-masked regions per block, ~20 scalar instructions of bookkeeping around ten vector ones;
+					// the compaction is skipped when nothing of the chunk survives)
 					const float    u    = fabsf (d * cps[q] + h * sps[q]);
 					const float    v    = fabsf (h * cps[q] - d * sps[q]);
 					const float    t    = u * cdl[q] + v * sdl[q];
-					const bool     live = r2 > bnd2[q] && (v <= u * tdl[q] || t > bnd[q]);
-					const uint64_t mask = __builtin_amdgcn_ballot_w64 (live);
+					const uint64_t m1   = __builtin_amdgcn_ballot_w64 (r2 > bnd2[q]);
+					const uint64_t mi   = __builtin_amdgcn_ballot_w64 (v <= u * tdl[q]);
+					const uint64_t m2   = __builtin_amdgcn_ballot_w64 (t > bnd[q]);
+					const uint64_t mask = m1 & (mi | m2);
 					float2* const  ring = ring0 + q * kERing;
-					if (live) {
-						const unsigned at = (wrc[q] + __builtin_amdgcn_mbcnt_hi ((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned)mask, 0u))) & (kERing - 1);
-						ring[at]          = make_float2 (d, h);
+					if (mask != 0) {
+						if ((mask >> lane) & 1) {
+							const unsigned at = (wrc[q] + __builtin_amdgcn_mbcnt_hi ((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned)mask, 0u))) & (kERing - 1);
+							ring[at]          = make_float2 (d, h);
+						}
+						const unsigned nl = (unsigned)__builtin_popcountll (mask);
+						wrc[q] += nl;
+						n_surv += nl;
 					}
-					const unsigned nl = (unsigned)__builtin_popcountll (mask);
-					wrc[q] += nl;
-					n_surv += nl;
 					if (wrc[q] - rdc[q] >= 64u) { // a full tile pair of this block's survivors (wave-uniform)
 						wave_sync ();
 						const float* const rg = reinterpret_cast<const float*> (ring);
