@@ -679,7 +679,13 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
             barrier()
             return gmax((time.perf_counter() - t0) / reps), e0.elapsed_time(e1) / reps
 
-        wall, dev_ms = timed_passes()
+        # `cold`: the first three passes after one untimed pass (what rounds 1-3 reported); `ms` / `value`: five passes after twelve
+        # more untimed ones -- the same steady state the headline is quoted at (its pre-roll): the clocks settle over tens of
+        # milliseconds of continuous work, a 2 ms pass right after an idle period runs ~20 % slower
+        cold_wall, cold_dev_ms = timed_passes()
+        for _ in range(12):
+            one_pass()
+        wall, dev_ms = timed_passes(5)
         pk = peaks.cpu().numpy()
         ev, seen = eng.sweep_stats()
         exs = eng.sweep_stats_ex() if hasattr(eng, "sweep_stats_ex") else {}
@@ -696,6 +702,7 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
             per_rank = [float(v) for v in t.cpu()]
         n_ang = 359  # (angle 0 is the plain abs-max of the input, Q4)
         res[kind] = {"ms": wall * 1e3, "value": total * n_chn / wall, "unpruned_ms": wall_np * 1e3,
+                     "cold_ms": cold_wall * 1e3, "warmup_passes": 16,
                      # (of the tiles the matrix-core kernel was handed: on the fused route those are the LISTED frames' tiles)
                      "evaluated_fraction": ev / max(seen, 1), "table_identical_unpruned": same,
                      "untested_fraction": exs.get("untested", 0) / max(seen, 1),
@@ -731,15 +738,16 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
                     if r8 > 0:
                         sweep_dist.prime_history(eng, halo8, st)
                     eng.sweep_dev(xs8.data_ptr(), x.shape[1], xs8.shape[1], 0, 360, 1, -1, peaks.data_ptr(), fl8, st)
-                shard_pass()
+                for _ in range(8):  # (the same steady state as the single pass it is compared with)
+                    shard_pass()
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(torch.cuda.current_stream())
-                for _ in range(3):
+                for _ in range(5):
                     shard_pass()
                 e1.record(torch.cuda.current_stream())
                 torch.cuda.synchronize()
-                shard_ms.append(e0.elapsed_time(e1) / 3)
+                shard_ms.append(e0.elapsed_time(e1) / 5)
             res[kind]["predicted_8gpu"] = {"per_shard_ms": shard_ms, "single_pass_ms": dev_ms,
                                            "predicted_speedup": dev_ms / max(shard_ms),
                                            "note": "PREDICTED from eight same-device shard passes; no N > 1 run exists"}
@@ -823,7 +831,8 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
     if not full:
         return {"metric": "channel-frames/s through the 360-angle min-peak sweep (cli -s 1 -f %d: the reference's default block size at %s)"
                           % (P, "88.2 / 96 kHz" if P == 16384 else "44.1 / 48 kHz"),
-                "value": h["value"], "unit": "channel-frames/s", "ms": h["ms"], "unpruned_ms": h["unpruned_ms"],
+                "value": h["value"], "unit": "channel-frames/s", "ms": h["ms"], "cold_ms": h["cold_ms"], "warmup_passes": h["warmup_passes"],
+                "unpruned_ms": h["unpruned_ms"],
                 "evaluated_fraction": h["evaluated_fraction"], "table_identical_unpruned": h["table_identical_unpruned"],
                 "min_angle_index": h["min_angle_index"], "per_rank_device_ms": h["per_rank_device_ms"],
                 "predicted_8gpu": h.get("predicted_8gpu"), "oracle_check_10s": check,
@@ -836,7 +845,10 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
                            "the Hilbert pass tests and lists), sweep_eval_kernel evaluates the lists")}
     return {"metric": "channel-frames/s through the 360-angle min-peak sweep (cli -s 1 -f 2048)",
             "signal": "32-harmonic asymmetric stack (110 / 137.5 Hz) under a slow swell + 2 % noise, generated on the device; resident in HBM",
-            "value": h["value"], "unit": "channel-frames/s", "ms": h["ms"], "unpruned_ms": h["unpruned_ms"],
+            "value": h["value"], "unit": "channel-frames/s", "ms": h["ms"], "cold_ms": h["cold_ms"], "warmup_passes": h["warmup_passes"],
+            "cold_note": "ms / value: five passes after 16 untimed ones (the steady state, as the headline's pre-roll); cold_ms: the first "
+                         "three passes after ONE untimed pass (what rounds 1-3 reported as ms)",
+            "unpruned_ms": h["unpruned_ms"],
             "evaluated_fraction": h["evaluated_fraction"], "table_identical_unpruned": h["table_identical_unpruned"],
             "min_angle_index": h["min_angle_index"], "per_rank_device_ms": h["per_rank_device_ms"],
             "oracle_check_10s": check,
