@@ -41,3 +41,21 @@ def test_committed_include_is_current(tmp_path):
     G.emit(str(dst))
     cur = open(os.path.join(ROOT, "phaserotate.lv2_amd", "csrc", "prot_olasave_asm.inc")).read()
     assert open(dst).read() == cur, "run python3 tools/gen/gen_olasave.py"
+
+
+@pytest.mark.parametrize("hs,mode,kind", [(13, 0, "run"), (8, 3, "run"), (8, 2, "core")])
+def test_generated_8192_point_block_matches_float64_convolution(hs, mode, kind):
+    """tools/gen/gen_olasave8k.py (round 4: 8192-point blocks, 512 threads, the radix-2 layer taken by the readers of the LDS
+    exchanges): the LV2 48 kHz loop with its half-row rotation, the CLI blksiz 8192 sweep variant (survivor lists of the eight waves
+    against the float64 convolution) and a staged block, in the emulator -- per-wave control flow, the LDS race detector, the
+    lane-read and lane-mask hazards found on the hardware.  (All variants: python3 tools/gen/gen_olasave8k.py, ~10 minutes.)"""
+    import gen_olasave8k as G8
+    G8.self_test(hs, mode, nblk=2, kind=kind, verbose=False)
+
+
+def test_committed_8192_point_include_is_current(tmp_path):
+    import gen_olasave8k as G8
+    dst = tmp_path / "asm8k.inc"
+    G8.emit(str(dst))
+    cur = open(os.path.join(ROOT, "phaserotate.lv2_amd", "csrc", "prot_olasave8k_asm.inc")).read()
+    assert open(dst).read() == cur, "run python3 tools/gen/gen_olasave8k.py"

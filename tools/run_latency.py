@@ -1,4 +1,6 @@
-"""Latency of the LV2 run() drop-in on host buffers: zero-copy (default) vs staged (test option LV2_STAGED), per buffer size.
+"""Latency of the LV2 run() drop-in on host buffers: default (round 4: the resident run() server for calls of up to one transform
+block per channel, a launch on the zero-copy host block beyond) vs staged (test option LV2_STAGED), per buffer size; the server
+against the launch route: tools/server_probe.py.
 Each variant in its own process; median of 2000 calls after 200 warm-up calls."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
