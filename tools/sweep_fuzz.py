@@ -1,6 +1,7 @@
 """Randomised differential test of the sweep: pruned against unpruned tables (bit for bit) over random sizes, channel counts,
 angle ranges / strides, block sizes, signal shapes (bursts, silences, steps, tones, noise), chunked and one-shot calls.
-python3 tools/sweep_fuzz.py [cases] [seed]"""
+python3 tools/sweep_fuzz.py [cases] [seed] [big]     (big: every case long enough for the fused route -- 2^20 frames and more --,
+block sizes up to 32768)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -35,9 +36,10 @@ def signal(n, nc):
 
 bad = 0
 for k in range(cases):
-    P = int(rng.choice([1024, 2048, 2048, 4096, 8192]))
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"
+    P = int(rng.choice([1024, 2048, 2048, 4096, 8192, 16384, 32768] if big else [1024, 2048, 2048, 4096, 8192]))
     nc = int(rng.choice([1, 1, 2, 2, 3, 4]))
-    n = int(rng.choice([rng.integers(1, 3000), rng.integers(3000, 200000), rng.integers(200000, 3000000)]))
+    n = int(rng.integers(1 << 20, 5 << 20)) if big else int(rng.choice([rng.integers(1, 3000), rng.integers(3000, 200000), rng.integers(200000, 3000000)]))
     st = int(rng.choice([1, 1, 2, 3, 5, 8, 24]))
     a0 = int(rng.choice([0, 0, 1, rng.integers(0, 300)]))
     a1 = int(min(360, a0 + rng.choice([1, 40, 100, 360])))
