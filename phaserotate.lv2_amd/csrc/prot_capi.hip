@@ -9,6 +9,7 @@
 #include "prot_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <immintrin.h>
 
 #include <algorithm>
 #include <atomic>
@@ -437,7 +438,11 @@ struct prot_engine {
 	int64_t          last_cap     = 0;
 	PinBuf<float>  h_io;
 	// the run() server (prot_olasave.hip): a resident kernel that takes prot_lv2_run's calls through a pinned mailbox
-	PinBuf<prot::SvServerBox> srv_box;
+	char*          srv_box = nullptr;      // host -> device half (prot::SvServerBox + input frames + per-frame rotation): device memory
+	                                       // the CPU stores into through the BAR (srv_bar), or pinned host-coherent memory
+	size_t         srv_box_bytes = 0;
+	bool           srv_bar = false;
+	PinBuf<prot::SvServerAck> srv_ack;     // device -> host half: pinned host-coherent memory
 	DevBuf<unsigned> d_srv_relay;
 	hipStream_t    srv_stream  = nullptr;
 	hipEvent_t     srv_ev      = nullptr;
@@ -947,6 +952,31 @@ int lv2_reserve (prot_engine* e, uint32_t frames)
 		return rc;
 	}
 	e->lv2_max_block = std::max (e->lv2_max_block, frames);
+	if (e->srv_eligible) { // the server's mailbox: box, then [nc][frames] input, then [nc][frames][2] per-frame rotation
+		const size_t need = prot::kServerInOffset + 3 * (size_t)e->lv2_max_block * nc * sizeof (float);
+		if (need > e->srv_box_bytes) {
+			if (e->srv_box) {
+				(void)(e->srv_bar ? hipFree (e->srv_box) : hipHostFree (e->srv_box));
+				e->srv_box = nullptr;
+			}
+			int large_bar = 0;
+			(void)hipDeviceGetAttribute (&large_bar, hipDeviceAttributeIsLargeBar, e->device);
+			void* q = nullptr;
+			e->srv_bar = large_bar != 0 && hipExtMallocWithFlags (&q, need, hipDeviceMallocFinegrained) == hipSuccess;
+			if (!e->srv_bar && hipHostMalloc (&q, need, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+				e->srv_eligible  = false; // (no mailbox: every call is launched)
+				e->srv_box_bytes = 0;
+				return PROT_OK;
+			}
+			e->srv_box       = (char*)q;
+			e->srv_box_bytes = need;
+			if (e->srv_bar) {
+				HIP_TRY (hipMemset (q, 0, sizeof (prot::SvServerBox)));
+			} else {
+				memset (q, 0, sizeof (prot::SvServerBox));
+			}
+		}
+	}
 	return PROT_OK;
 }
 
@@ -986,9 +1016,11 @@ int server_stop_locked ()
 	g_srv_owner = nullptr;
 	if (o->srv_running) {
 		o->srv_running = false;
-		prot::SvServerBox* b = o->srv_box.p;
+		prot::SvServerBox* b = reinterpret_cast<prot::SvServerBox*> (o->srv_box);
 		o->srv_seq           = (o->srv_seq % (1u << 30)) + 1u;
+		_mm_sfence ();
 		__atomic_store_n (&b->bell, (uint64_t)o->srv_seq | ((uint64_t)1 << 63), __ATOMIC_RELEASE);
+		_mm_sfence ();
 		HIP_TRY (hipStreamSynchronize (o->srv_stream));
 	}
 	return PROT_OK;
@@ -1007,12 +1039,14 @@ int server_start_locked (prot_engine* e)
 	}
 	HIP_TRY (hipEventRecord (e->srv_ev, e->stream));
 	HIP_TRY (hipStreamWaitEvent (e->srv_stream, e->srv_ev, 0));
-	prot::SvServerBox* b = e->srv_box.p;
-	b->bell              = e->srv_seq;
-	__atomic_store_n (&b->alive, 1u, __ATOMIC_RELEASE);
-	hipError_t err = prot::launch_ola_save_server (b, e->h_io.p, e->d_srv_relay.p, e->srv_seq, e->hopseg / 2, (int)e->info.n_chn, e->srv_stream);
+	prot::SvServerBox* b = reinterpret_cast<prot::SvServerBox*> (e->srv_box);
+	prot::SvServerAck* a = e->srv_ack.p;
+	__atomic_store_n (&b->bell, (uint64_t)e->srv_seq, __ATOMIC_RELEASE);
+	_mm_sfence ();
+	__atomic_store_n (&a->alive, 1u, __ATOMIC_RELEASE);
+	hipError_t err = prot::launch_ola_save_server (b, a, e->d_srv_relay.p, e->srv_seq, e->hopseg / 2, (int)e->info.n_chn, e->srv_stream);
 	if (err != hipSuccess) {
-		b->alive = 0u;
+		a->alive = 0u;
 		return hip_fail (err, "run() server launch");
 	}
 	e->srv_running = true;
@@ -1428,12 +1462,15 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 		if (e->use_poly && e->use_save && e->d_pipe.p == nullptr && inf.n_chn <= (uint32_t)prot::kServerMaxChn && (e->hopseg == 16 || e->hopseg == 20)) {
 			int lo = 0, hi = 0;
 			(void)hipDeviceGetStreamPriorityRange (&lo, &hi); // (hi = the numerically smallest = greatest priority)
-			e->srv_box.coherent = true;
-			if (e->srv_box.ensure (1) == PROT_OK && e->d_srv_relay.ensure (16) == PROT_OK &&
+			e->srv_ack.coherent = true;
+			if (e->srv_ack.ensure (1) == PROT_OK && e->d_srv_relay.ensure (16) == PROT_OK &&
 			    hipStreamCreateWithPriority (&e->srv_stream, hipStreamNonBlocking, hi) == hipSuccess &&
 			    hipEventCreateWithFlags (&e->srv_ev, hipEventDisableTiming) == hipSuccess) {
-				memset (e->srv_box.p, 0, sizeof (prot::SvServerBox));
+				memset (e->srv_ack.p, 0, sizeof (prot::SvServerAck));
 				e->srv_eligible = true;
+				if (lv2_reserve (e, 8192) != PROT_OK) { // (again, now with the mailbox)
+					return fail (PROT_ENOMEM);
+				}
 			}
 		}
 		e->interp_th = inf.blksiz * 1e-6f; // src/phaserotate.c:295
@@ -1471,7 +1508,11 @@ void prot_engine_destroy (prot_engine* e)
 		(void)hipEventDestroy (e->srv_ev);
 		e->srv_ev = nullptr;
 	}
-	e->srv_box.release ();
+	if (e->srv_box) {
+		(void)(e->srv_bar ? hipFree (e->srv_box) : hipHostFree (e->srv_box));
+		e->srv_box = nullptr;
+	}
+	e->srv_ack.release ();
 	e->d_srv_relay.release ();
 	for (int i = 0; i < prot_engine::kPipe; ++i) {
 		if (e->pipe_stream[i]) {
@@ -2325,7 +2366,18 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 	if (!staged && e->srv_eligible && g_test_opt[PROT_TEST_LV2_NO_SERVER].load () == 0) {
 		std::lock_guard<std::mutex> lk (g_srv_mu);
 		if (g_srv_owner == nullptr || g_srv_owner == e) {
-			prot::SvServerBox* b = e->srv_box.p;
+			prot::SvServerBox* b = reinterpret_cast<prot::SvServerBox*> (e->srv_box);
+			prot::SvServerAck* a = e->srv_ack.p;
+			// the host -> device half of the mailbox is STORED into, never read (through the BAR a CPU load is microseconds): the
+			// call's input frames behind the box, the per-frame rotation of a ramp behind them
+			float* const srv_in  = reinterpret_cast<float*> (e->srv_box + prot::kServerInOffset);
+			float* const srv_rot = srv_in + (size_t)e->lv2_max_block * nc;
+			for (uint32_t c = 0; c < nc; ++c) {
+				memcpy (srv_in + c * n, in[c] + off, n * sizeof (float));
+			}
+			if (!steady) {
+				memcpy (srv_rot, h_rot, 2 * n * nc * sizeof (float));
+			}
 			const float* d_rot_c = nullptr;
 			if (steady) {
 				float* h_rotc = e->h_io.p + 4 * n * nc; // [nc][2]
@@ -2338,30 +2390,32 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 			const int hist_before = e->hist_cur;
 			// (steady rotation: by value in the parameters -- a pointer into the pinned block would be one more read over the host link)
 			const bool rot_inline = steady && (int)nc <= prot::kRotInline;
-			rc = ola_launch (e, h_in, (int64_t)n, n, h_out, (int64_t)n, n, rot_inline ? nullptr : d_rot_c, steady ? nullptr : h_rot, false, false, 0, (int)nc, s,
+			rc = ola_launch (e, srv_in, (int64_t)n, n, h_out, (int64_t)n, n, rot_inline ? nullptr : d_rot_c, steady ? nullptr : srv_rot, false, false, 0, (int)nc, s,
 			                 /*advance_hist*/ true, rot_inline ? d_rot_c : nullptr, nullptr, nullptr, b);
 			if (rc == PROT_OK) {
-				if (!e->srv_running || __atomic_load_n (&b->alive, __ATOMIC_ACQUIRE) == 0u) {
+				if (!e->srv_running || __atomic_load_n (&a->alive, __ATOMIC_ACQUIRE) == 0u) {
 					rc = server_start_locked (e);
 				}
 				if (rc == PROT_OK) {
 					e->srv_seq = (e->srv_seq % (1u << 30)) + 1u;
 					const uint32_t seq  = e->srv_seq;
 					const uint64_t bell = (uint64_t)seq | ((uint64_t)n << 32);
+					_mm_sfence (); // (write-combined stores through the BAR: parameters and frames before the doorbell)
 					__atomic_store_n (&b->bell, bell, __ATOMIC_RELEASE);
+					_mm_sfence ();
 					// wait for every channel's done word; a server that left by itself between the check above and the doorbell
 					// (idle time-out) is started again -- with the number of the last served call, so that it takes this one at once
 					const auto t_0 = std::chrono::steady_clock::now ();
 					for (uint32_t c = 0; c < nc;) {
-						if (__atomic_load_n (&b->done[c], __ATOMIC_ACQUIRE) == seq) {
+						if (__atomic_load_n (&a->done[c], __ATOMIC_ACQUIRE) == seq) {
 							++c;
 							continue;
 						}
-						if (__atomic_load_n (&b->alive, __ATOMIC_ACQUIRE) == 0u) {
+						if (__atomic_load_n (&a->alive, __ATOMIC_ACQUIRE) == 0u) {
 							HIP_TRY (hipStreamSynchronize (e->srv_stream)); // the kernel is over: what it served is complete
 							bool all = true;
 							for (uint32_t k = 0; k < nc; ++k) {
-								all = all && __atomic_load_n (&b->done[k], __ATOMIC_ACQUIRE) == seq;
+								all = all && __atomic_load_n (&a->done[k], __ATOMIC_ACQUIRE) == seq;
 							}
 							if (all) {
 								break;
@@ -2373,12 +2427,14 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 							if (rc) {
 								return rc;
 							}
+							_mm_sfence ();
 							__atomic_store_n (&b->bell, bell, __ATOMIC_RELEASE);
+							_mm_sfence ();
 							continue;
 						}
 						if (std::chrono::steady_clock::now () - t_0 > std::chrono::seconds (2)) {
-							snprintf (g_err, sizeof (g_err), "run() server: call %u not served within 2 s (stages %u %u, done %u %u, alive %u)", seq, b->pad0[0],
-							          b->pad0[1], b->done[0], b->done[1], b->alive);
+							snprintf (g_err, sizeof (g_err), "run() server: call %u not served within 2 s (stages %u %u, done %u %u, alive %u)", seq, a->pad0[0],
+							          a->pad0[1], a->done[0], a->done[1], a->alive);
 							return PROT_EHIP;
 						}
 					}
@@ -2953,15 +3009,53 @@ int prot_internal_server_stats (prot_engine* e, unsigned long long out[2])
 // diagnostic builds (tools/ab_build.py): 100 MHz ticks of the last call's stages (doorbell seen, parameters read, block done, done stored)
 int prot_internal_server_stamps (prot_engine* e, unsigned out[4])
 {
-	if (!e || !out || !e->srv_box.p) {
+	if (!e || !out || !e->srv_ack.p) {
 		return PROT_EINVAL;
 	}
 	for (int i = 0; i < 4; ++i) {
-		out[i] = e->srv_box.p->pad0[8 + i];
+		out[i] = e->srv_ack.p->pad0[8 + i];
 	}
 	return PROT_OK;
 }
 #endif
+
+// What an LV2 host's audio thread sees: `calls` calls of prot_lv2_run on `frames` frames per channel straight from C (no binding in
+// between), mean microseconds per call into *us.  The input is a fixed pseudo-random block, the angle 90 degrees.
+int prot_internal_time_lv2_run (prot_engine* e, uint32_t frames, uint32_t calls, double* us)
+{
+	if (!e || !us || e->info.kind != PROT_KIND_LV2 || frames == 0 || calls == 0) {
+		return PROT_EINVAL;
+	}
+	const uint32_t nc = e->info.n_chn;
+	std::vector<float>        buf ((size_t)2 * nc * frames);
+	std::vector<const float*> in (nc);
+	std::vector<float*>       out (nc);
+	std::vector<float>        ang (nc, 90.f);
+	uint32_t                  x = 12345u;
+	for (size_t i = 0; i < (size_t)nc * frames; ++i) {
+		x ^= x << 13, x ^= x >> 17, x ^= x << 5;
+		buf[i] = (float)(x >> 8) * (1.f / 16777216.f) - 0.5f;
+	}
+	for (uint32_t c = 0; c < nc; ++c) {
+		in[c]  = buf.data () + (size_t)c * frames;
+		out[c] = buf.data () + (size_t)(nc + c) * frames;
+	}
+	for (uint32_t k = 0; k < 50; ++k) {
+		const int rc = prot_lv2_run (e, in.data (), out.data (), frames, ang.data ());
+		if (rc) {
+			return rc;
+		}
+	}
+	const auto t_0 = std::chrono::steady_clock::now ();
+	for (uint32_t k = 0; k < calls; ++k) {
+		const int rc = prot_lv2_run (e, in.data (), out.data (), frames, ang.data ());
+		if (rc) {
+			return rc;
+		}
+	}
+	*us = std::chrono::duration<double, std::micro> (std::chrono::steady_clock::now () - t_0).count () / calls;
+	return PROT_OK;
+}
 
 int prot_internal_set_test_option (int option, int value)
 {

@@ -22,6 +22,9 @@ int prot_internal_set_test_option (int option, int value); // 0 or PROT_EINVAL
 // list l of channel c at entry (c * n_lists + l) * cap, its length in cnt[c * n_lists + l]; out = { surv, cnt, n_lists, cap }
 struct prot_engine;
 int prot_internal_fused_lists (struct prot_engine* e, unsigned long long out[4]);
+// mean microseconds per prot_lv2_run call on `frames` frames per channel, `calls` calls straight from C (what an LV2 host's audio
+// thread sees, without a binding in between)
+int prot_internal_time_lv2_run (struct prot_engine* e, unsigned frames, unsigned calls, double* us);
 // the run() server of an LV2 engine: out = { calls it has taken, kernels started for it }
 int prot_internal_server_stats (struct prot_engine* e, unsigned long long out[2]);
 #ifdef __cplusplus

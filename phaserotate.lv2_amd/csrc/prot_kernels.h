@@ -103,19 +103,29 @@ hipError_t launch_ola_poly_f16 (const OlaParamsH& p, int n_part, int hop_rows, i
 hipError_t launch_ola_save (const OlaParams& p, int hop_rows, int n_rho_rows, int n_chn, hipStream_t s);
 // the same on 8192-point blocks (prot_olasave8k.hip): 512-thread workgroups, two per CU; hop_rows in {12, 13} (x 1024 new
 // frames per block: firlen = 1024 (16 - hop_rows)); p.sv = the five-row table of save_tables8k; no pipelined launches
-// ---- the run() server (prot_olasave.hip): pinned, host-coherent mailbox of one LV2 engine
-constexpr int kServerMaxChn = 16;
+// ---- the run() server (prot_olasave.hip): the mailbox of one LV2 engine, in two halves.
+// SvServerBox (host -> device): what the host writes and the resident kernel reads -- in DEVICE memory that the CPU stores into through
+// the PCIe BAR when the device has a large one (write-combined, posted: 4 KiB in ~0.2 us; the kernel then polls and fetches LOCAL
+// memory instead of reading host memory over the link at ~1 GB/s), else in pinned host-coherent memory.  The call's input frames
+// ([channel][frames]) and per-frame rotation ([channel][frames][2]) follow it at kServerInOffset.  The host never READS this half
+// (a CPU load through the BAR is 5-7 us).
+// SvServerAck (device -> host): pinned host-coherent memory the kernel stores into and the host polls.
+constexpr int    kServerMaxChn   = 16;
+constexpr size_t kServerInOffset = 1024; // bytes from the box to the input frames
 struct SvServerBox {
-	// host -> device, ONE 8-byte store, LAST: the doorbell.  bits 0..31 the call's number (1 .. 2^30, never the same twice in a row),
-	// bits 32..62 frames per channel of the call (the server fetches them from the port block beside the parameters: one trip over
-	// the host link for both), bit 63: leave
+	// ONE 8-byte store, LAST: the doorbell.  bits 0..31 the call's number (1 .. 2^30, never the same twice in a row), bits 32..62 frames
+	// per channel of the call, bit 63: leave
 	uint64_t          bell;
-	uint32_t          alive;    // device -> host: set by the host before the launch, cleared by the kernel as its last store
-	uint32_t          pad0[13]; // device -> host: how far each channel's workgroup has come (diagnostics)
-	uint32_t          done[kServerMaxChn]; // device -> host: done[c] = seq when channel c's output (and its next history) is complete
-	OlaParamsT<float> p;        // host -> device: what the launch would have carried
+	uint64_t          pad[7];
+	OlaParamsT<float> p;        // what the launch would have carried
 };
-hipError_t launch_ola_save_server (SvServerBox* box, const float* port_in, unsigned* relay, unsigned last_seq, int hop_rows, int n_chn, hipStream_t s);
+static_assert (sizeof (SvServerBox) <= kServerInOffset, "the input frames follow the box");
+struct SvServerAck {
+	uint32_t alive;    // set by the host before the launch, cleared by the kernel as its last store
+	uint32_t pad0[15]; // how far each channel's workgroup has come (diagnostics)
+	uint32_t done[kServerMaxChn]; // done[c] = the call's number when channel c's output (and its next history) is complete
+};
+hipError_t launch_ola_save_server (const SvServerBox* box, SvServerAck* ack, unsigned* relay, unsigned last_seq, int hop_rows, int n_chn, hipStream_t s);
 hipError_t post_ola_save_server (const OlaParamsT<float>& p, int hop_rows, int n_rho_rows, int n_chn, SvServerBox* box);
 hipError_t launch_ola_save8k (const OlaParams& p, int hop_rows, int n_chn, hipStream_t s);
 

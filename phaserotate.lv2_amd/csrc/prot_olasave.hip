@@ -581,9 +581,10 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 constexpr uint64_t kServerIdleTicks = 25000000ull;
 
 template <int HS>
-__global__ __launch_bounds__ (256, 1) void olasave_server_kernel (SvServerBox* const box, const float* const port_in, unsigned* const relay,
+__global__ __launch_bounds__ (256, 1) void olasave_server_kernel (const SvServerBox* const box, SvServerAck* const ack, unsigned* const relay,
                                                                     const unsigned last_seq)
 {
+	const float* const port_in = reinterpret_cast<const float*> (reinterpret_cast<const char*> (box) + kServerInOffset);
 	__shared__ f2       smem[kLdsExchange + 512];
 	__shared__ float    sw_lo_s[4];
 	__shared__ unsigned sh_w[2];
@@ -599,10 +600,10 @@ __global__ __launch_bounds__ (256, 1) void olasave_server_kernel (SvServerBox* c
 		int tid_s = tid;
 		asm volatile ("" : "+v"(tid_s));
 		if (tid_s == 0 && blockIdx.y < 8) {
-			__hip_atomic_store (&box->pad0[blockIdx.y], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store (&ack->pad0[blockIdx.y], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef PROT_SERVER_STAMPS
 			if (blockIdx.y == 0 && v >= 2u && v <= 5u) { // 100 MHz ticks at the stages of channel 0's workgroup
-				__hip_atomic_store (&box->pad0[6 + v], (unsigned)__builtin_amdgcn_s_memrealtime (), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				__hip_atomic_store (&ack->pad0[6 + v], (unsigned)__builtin_amdgcn_s_memrealtime (), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 			}
 #endif
 		}
@@ -622,7 +623,7 @@ __global__ __launch_bounds__ (256, 1) void olasave_server_kernel (SvServerBox* c
 				unsigned       s = seen, cmd = 0u;
 				const uint64_t t_0 = __builtin_amdgcn_s_memrealtime ();
 				for (;;) {
-					const uint64_t bell = __hip_atomic_load (&box->bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					const uint64_t bell = __hip_atomic_load (const_cast<uint64_t*> (&box->bell), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 					s                   = (unsigned)bell;
 					if (s != seen) {
 						cmd    = (unsigned)(bell >> 63);
@@ -665,12 +666,25 @@ __global__ __launch_bounds__ (256, 1) void olasave_server_kernel (SvServerBox* c
 		__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");
 		const int frames = __builtin_amdgcn_readfirstlane ((int)sh_w[1]) < 512 * HS ? __builtin_amdgcn_readfirstlane ((int)sh_w[1]) : 512 * HS;
 		for (int i = tid; i < (int)(sizeof (OlaParams) / 4); i += 256) {
-			sh_p[i] = __hip_atomic_load (reinterpret_cast<unsigned*> (&box->p) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			sh_p[i] = __hip_atomic_load (reinterpret_cast<unsigned*> (const_cast<OlaParams*> (&box->p)) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 		{ // (the port block: [channel][frames], prot_capi.hip lv2_run_chunk)
+			// (system-scope loads: past the caches, whichever memory the box lives in; eight bytes per lane when the channel's frames
+			// start on an 8-byte boundary)
 			const float* const src = port_in + (int64_t)blockIdx.y * frames;
-			for (int i = tid; i < frames; i += 256) {
-				sh_in[i] = __hip_atomic_load (src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			if (((blockIdx.y * frames) & 1) == 0) {
+				uint64_t* const       dst8 = reinterpret_cast<uint64_t*> (sh_in);
+				const uint64_t* const src8 = reinterpret_cast<const uint64_t*> (src);
+				for (int i = tid; i < frames / 2; i += 256) {
+					dst8[i] = __hip_atomic_load (const_cast<uint64_t*> (src8) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				}
+				if ((frames & 1) && tid == 0) {
+					sh_in[frames - 1] = __hip_atomic_load (const_cast<float*> (src) + frames - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				}
+			} else {
+				for (int i = tid; i < frames; i += 256) {
+					sh_in[i] = __hip_atomic_load (const_cast<float*> (src) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				}
 			}
 		}
 		__syncthreads ();
@@ -693,18 +707,18 @@ __global__ __launch_bounds__ (256, 1) void olasave_server_kernel (SvServerBox* c
 		int tid_done = tid;
 		asm volatile ("" : "+v"(tid_done));
 		if (tid_done == 0) {
-			__hip_atomic_store (&box->done[blockIdx.y], word >> 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store (&ack->done[blockIdx.y], word >> 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 		stage (5u);
 		seen = word >> 1;
 	}
 	stage (9u);
 	if (tid == 0 && blockIdx.y == 0) {
-		__hip_atomic_store (&box->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		__hip_atomic_store (&ack->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 }
 
-hipError_t launch_ola_save_server (SvServerBox* box, const float* port_in, unsigned* relay, unsigned last_seq, int hop_rows, int n_chn, hipStream_t s)
+hipError_t launch_ola_save_server (const SvServerBox* box, SvServerAck* ack, unsigned* relay, unsigned last_seq, int hop_rows, int n_chn, hipStream_t s)
 {
 	if (n_chn < 1 || n_chn > kServerMaxChn) {
 		return hipErrorInvalidValue;
@@ -715,8 +729,8 @@ hipError_t launch_ola_save_server (SvServerBox* box, const float* port_in, unsig
 	}
 	const dim3 grid (1, (unsigned)n_chn), block (256);
 	switch (hop_rows) {
-		case 8: hipLaunchKernelGGL ((olasave_server_kernel<8>), grid, block, 0, s, box, port_in, relay, last_seq); break;
-		case 10: hipLaunchKernelGGL ((olasave_server_kernel<10>), grid, block, 0, s, box, port_in, relay, last_seq); break;
+		case 8: hipLaunchKernelGGL ((olasave_server_kernel<8>), grid, block, 0, s, box, ack, relay, last_seq); break;
+		case 10: hipLaunchKernelGGL ((olasave_server_kernel<10>), grid, block, 0, s, box, ack, relay, last_seq); break;
 		default: return hipErrorInvalidValue;
 	}
 	return hipGetLastError ();
