@@ -972,9 +972,12 @@ int lv2_reserve (prot_engine* e, uint32_t frames)
 			e->srv_box_bytes = need;
 			if (e->srv_bar) {
 				HIP_TRY (hipMemset (q, 0, sizeof (prot::SvServerBox)));
-			} else {
-				memset (q, 0, sizeof (prot::SvServerBox));
+				HIP_TRY (hipDeviceSynchronize ());
 			}
+			// (every page touched by the CPU now: the first store into a page through the BAR costs 20-30 us, tools/bar_probe.py --
+			// not in the audio callback)
+			memset (q, 0, need);
+			_mm_sfence ();
 		}
 	}
 	return PROT_OK;
