@@ -529,7 +529,13 @@ def bench_run_host(pkg, np, local_rank):
         res[key] = float(np.median(batches))
         res[key + "_worst"] = float(max(batches))
         res[key + "_stats"] = g.server_stats()
-        res[key + "_c"] = float(np.median([g.time_lv2_run(1024, 250) for _ in range(8)])) * 1e-6  # the same calls looped in C
+        runs_c = []
+        worst_c = 0.0
+        for _ in range(8):   # the same calls looped in C: 8 x 500
+            runs_c.append(g.time_lv2_run(1024, 500))
+            worst_c = max(worst_c, g.last_worst_call[0])
+        res[key + "_c"] = float(np.median(runs_c)) * 1e-6
+        res[key + "_c_worst"] = worst_c
         g.close()
     pkg.set_test_option(pkg.TEST_LV2_NO_SERVER, 0)
     # what the harness itself adds per call: Lv2Instance.run() = numpy -> ctypes pointer arrays + one ctypes call + a copy of the output;
@@ -548,10 +554,11 @@ def bench_run_host(pkg, np, local_rank):
                         "per call), called in a loop from C (prot_internal_time_lv2_run: what an LV2 host's audio thread sees)",
             "us_per_run": dt * 1e6, "frames_per_s": 1024 / dt, "realtime_factor_48k": 1024 / dt / 48000.0,
             "through_python_harness_us_per_run": res["server"] * 1e6,
-            "worst_batch_us_per_run": res["server_worst"] * 1e6,
+            "worst_single_call_us": res["server_c_worst"], "launch_route_worst_single_call_us": res["launch_c_worst"],
+            "python_harness_worst_batch_us_per_run": res["server_worst"] * 1e6,
             "harness_us_per_call": harness * 1e6,
             "launch_route_us_per_run": res["launch_c"] * 1e6, "launch_route_through_python_harness_us_per_run": res["launch"] * 1e6,
-            "note": "us_per_run / launch_route_us_per_run: median of 8 x 250 calls looped in C; through_python_harness_*: the same calls through "
+            "note": "us_per_run / launch_route_us_per_run: median of 8 x 500 calls looped in C (worst_single_call_us: the slowest of those 4000 calls); through_python_harness_*: the same calls through "
                     "this harness's numpy / ctypes wrapper (harness_us_per_call of its own; what rounds 1-3 reported: 38-40 us)",
             "server_calls": res["server_stats"]["calls"],
             "server_kernels_started": res["server_stats"]["starts"]}

@@ -263,11 +263,12 @@ class Engine:
 
     def time_lv2_run(self, frames, calls):
         """mean microseconds per prot_lv2_run call, looped in C (test hook prot_internal_time_lv2_run)"""
-        us = C.c_double(0.0)
+        us = (C.c_double * 3)()
         self._lib.prot_internal_time_lv2_run.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.POINTER(C.c_double)]
         self._lib.prot_internal_time_lv2_run.restype = C.c_int
-        _check(self._lib.prot_internal_time_lv2_run(self._h, frames, calls, C.byref(us)), "prot_internal_time_lv2_run")
-        return us.value
+        _check(self._lib.prot_internal_time_lv2_run(self._h, frames, calls, us), "prot_internal_time_lv2_run")
+        self.last_worst_call = (us[1], int(us[2]))
+        return us[0]
 
     def server_stats(self):
         """{calls, starts}: run() calls the resident server kernel has taken / kernels started for it (test hook)."""

@@ -3023,8 +3023,8 @@ int prot_internal_server_stamps (prot_engine* e, unsigned out[4])
 #endif
 
 // What an LV2 host's audio thread sees: `calls` calls of prot_lv2_run on `frames` frames per channel straight from C (no binding in
-// between), mean microseconds per call into *us.  The input is a fixed pseudo-random block, the angle 90 degrees.
-int prot_internal_time_lv2_run (prot_engine* e, uint32_t frames, uint32_t calls, double* us)
+// between), into us[3]: mean microseconds per call, the slowest single call, its index.  The input is a fixed pseudo-random block, the angle 90 degrees.
+int prot_internal_time_lv2_run (prot_engine* e, uint32_t frames, uint32_t calls, double us[3])
 {
 	if (!e || !us || e->info.kind != PROT_KIND_LV2 || frames == 0 || calls == 0) {
 		return PROT_EINVAL;
@@ -3050,13 +3050,25 @@ int prot_internal_time_lv2_run (prot_engine* e, uint32_t frames, uint32_t calls,
 		}
 	}
 	const auto t_0 = std::chrono::steady_clock::now ();
+	auto       t_p = t_0;
+	double     worst = 0.0;
+	uint32_t   worst_at = 0;
 	for (uint32_t k = 0; k < calls; ++k) {
 		const int rc = prot_lv2_run (e, in.data (), out.data (), frames, ang.data ());
 		if (rc) {
 			return rc;
 		}
+		const auto   t_n = std::chrono::steady_clock::now ();
+		const double d   = std::chrono::duration<double, std::micro> (t_n - t_p).count ();
+		if (d > worst) {
+			worst    = d;
+			worst_at = k;
+		}
+		t_p = t_n;
 	}
-	*us = std::chrono::duration<double, std::micro> (std::chrono::steady_clock::now () - t_0).count () / calls;
+	us[0] = std::chrono::duration<double, std::micro> (t_p - t_0).count () / calls;
+	us[1] = worst;            // the slowest single call
+	us[2] = (double)worst_at; // ... and which
 	return PROT_OK;
 }
 
