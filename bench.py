@@ -521,8 +521,8 @@ def bench_run_host(pkg, np, local_rank):
         for _ in range(50):
             g.run(x, 90.0)
         batches = []
-        for _ in range(12):  # (batches of 250 calls: the median is the steady state; one batch early in a process's life holds a
-            t0 = time.perf_counter()  # single stall of tens of milliseconds -- reported as worst_batch --, tools/server_probe.py)
+        for _ in range(12):  # (batches of 250 calls through the Python wrapper: the median is its steady state; one batch early in a
+            t0 = time.perf_counter()  # process's life holds a single stall of tens of milliseconds that the C loop below never shows)
             for _ in range(250):
                 g.run(x, 90.0)
             batches.append((time.perf_counter() - t0) / 250)
