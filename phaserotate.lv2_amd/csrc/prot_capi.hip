@@ -962,7 +962,7 @@ int lv2_reserve (prot_engine* e, uint32_t frames)
 			int large_bar = 0;
 			(void)hipDeviceGetAttribute (&large_bar, hipDeviceAttributeIsLargeBar, e->device);
 			void* q = nullptr;
-			e->srv_bar = large_bar != 0 && hipExtMallocWithFlags (&q, need, hipDeviceMallocFinegrained) == hipSuccess;
+			e->srv_bar = large_bar != 0 && g_test_opt[PROT_TEST_LV2_NO_BAR].load () == 0 && hipExtMallocWithFlags (&q, need, hipDeviceMallocFinegrained) == hipSuccess;
 			if (!e->srv_bar && hipHostMalloc (&q, need, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
 				e->srv_eligible  = false; // (no mailbox: every call is launched)
 				e->srv_box_bytes = 0;

@@ -15,7 +15,8 @@ enum {
 	PROT_TEST_ALLREDUCE      = 3, // 0 automatic; 1 merge through the host; 2 the RCCL collective even when engines share a device
 	PROT_TEST_SWEEP_UNFUSED  = 4, // != 0: prot_sweep_dev keeps the separate Hilbert and sweep passes where it would fuse them (bit-identical tables)
 	PROT_TEST_LV2_NO_SERVER  = 5, // != 0: prot_lv2_run launches every call (no resident server kernel)
-	PROT_TEST_OPTIONS        = 6
+	PROT_TEST_LV2_NO_BAR     = 6, // != 0: engines created from now on keep the run() server's mailbox in pinned host memory (as on a device without a large BAR)
+	PROT_TEST_OPTIONS        = 7
 };
 int prot_internal_set_test_option (int option, int value); // 0 or PROT_EINVAL
 // the lists the last fused sweep pass of the engine left (device pointers, valid until the next sweep): float2 entries (dry, hilbert),

@@ -162,8 +162,11 @@ def test_lv2_run_server_gives_the_launched_kernels_bits(pkg, rate, bufsize, n_ch
     xs = [xorshift_uniform(n_chn * bufsize, seed=100 + i).reshape(n_chn, bufsize) for i in range(40)]
     outs, stats = {}, {}
     try:
-        for mode in (1, 0):
-            pkg.set_test_option(pkg.TEST_LV2_NO_SERVER, mode)
+        # mode 1: every call launched; 0: the server, its mailbox in device memory through the PCIe BAR (where the device has a large
+        # one: this pool does); 2: the server with the mailbox in pinned host memory (the route of a device without)
+        for mode in (1, 0, 2):
+            pkg.set_test_option(pkg.TEST_LV2_NO_SERVER, 1 if mode == 1 else 0)
+            pkg.set_test_option(pkg.TEST_LV2_NO_BAR, 1 if mode == 2 else 0)
             g = pkg.Lv2Instance(rate, n_chn)
             g.activate()
             outs[mode] = np.stack([g.run(x, angles[i % len(angles)]).copy() for i, x in enumerate(xs)])
@@ -171,9 +174,11 @@ def test_lv2_run_server_gives_the_launched_kernels_bits(pkg, rate, bufsize, n_ch
             g.close()
     finally:
         pkg.set_test_option(pkg.TEST_LV2_NO_SERVER, 0)
-    assert outs[0].tobytes() == outs[1].tobytes()
+        pkg.set_test_option(pkg.TEST_LV2_NO_BAR, 0)
+    assert outs[0].tobytes() == outs[1].tobytes() and outs[2].tobytes() == outs[1].tobytes()
     assert stats[1] == dict(calls=0, starts=0)
-    assert stats[0]["calls"] == len(xs) and 1 <= stats[0]["starts"] <= 3, stats  # (a start more if the box stalled past the idle time-out)
+    for mode in (0, 2):
+        assert stats[mode]["calls"] == len(xs) and 1 <= stats[mode]["starts"] <= 3, stats  # (a start more if the box stalled past the idle time-out)
 
 
 def test_lv2_run_server_leaves_when_idle_and_for_every_other_use_of_the_engine(pkg):
