@@ -164,8 +164,9 @@ int prot_apply_dev_ramp (prot_engine* e, const float* d_in, int64_t in_stride, u
 /* fp16 sample path (BASELINE config 5): d_in/d_out are DEVICE arrays of IEEE half (2 bytes per frame), planar;
  * packed-half butterflies, fp32 overlap-add and rotation; flags as prot_apply_dev (PROT_F_STATELESS; without it
  * the engine carries the fp16 stream's own input history from call to call -- a stream is EITHER fed through the
- * fp32 calls OR through the fp16 calls between two resets).  Engines with FIRs of up to 8192 taps (LV2 at every
- * rate, CLI blksiz <= 8192); longer FIRs would accumulate partitions in half precision: PROT_EUNSUPPORTED.
+ * fp32 calls OR through the fp16 calls between two resets).  Every polyphase engine (LV2 at every rate, every CLI block size);
+ * FIRs of more than 8192 taps (CLI blksiz 16384, 32768) take two / four launches whose shares are added in the half-precision
+ * output -- one more rounding to half per launch, inside the path's stated tolerance (round 4; refused before).
  * Accuracy against the fp32 path on the same fp16-rounded input: rms ~2e-4, max ~2e-3 at |x| <= 0.5 (tests). */
 int prot_apply_dev_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint64_t n_in,
                         void* d_out, int64_t out_stride, uint64_t n_out,

@@ -1429,7 +1429,7 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	if ((rc = e->d_H.ensure ((size_t)F * n_part)) ||
 	    (!Hp_h.empty () && (rc = e->d_Hp.ensure (Hp_h.size ()))) || (rc = e->d_tw.ensure (F)) || (rc = e->d_lut.ensure (PROT_MAXSAMPLE * 2)) ||
 	    (rc = e->d_rot.ensure (2 * (size_t)inf.n_chn)) || (rc = e->d_hist[0].ensure (hn)) || (rc = e->d_hist[2].ensure (hn)) || (rc = e->d_hist[3].ensure (hn)) ||
-	    (use_poly && n_part <= 2 && ((rc = e->d_hist16[0].ensure (hn)) || (rc = e->d_hist16[1].ensure (hn)))) ||
+	    (use_poly && ((rc = e->d_hist16[0].ensure (hn)) || (rc = e->d_hist16[1].ensure (hn)))) ||
 	    (rc = e->d_hist[1].ensure (hn)) || (rc = e->d_peaks.ensure ((size_t)PROT_MAXSAMPLE * inf.n_chn)) ||
 	    (rc = e->d_angles.ensure (PROT_MAXSAMPLE + 8)) || (rc = e->d_thr.ensure (prot::kSweepThrFloats * (size_t)inf.n_chn)) || (rc = e->d_ctr.ensure ((size_t)inf.n_chn * 32 * 32)) ||
 	    (rc = e->d_stats.ensure (4)) || (e->use_save && (rc = e->d_sv.ensure (sv_h.size ()))) ||
@@ -1763,9 +1763,11 @@ int prot_apply_dev_ramp (prot_engine* e, const float* d_in, int64_t in_stride, u
 }
 
 // fp16 sample path (BASELINE config 5): half samples in HBM, packed-half butterflies, fp32 overlap-add + rotation.
-// Polyphase engines of one or two partitions per launch (FIRs up to 8192 taps) carry history (its own, in half
-// precision) and take per-frame rotations like the fp32 path; the direct-form cross-check engines (PROT_CFG_*) only
-// offer the stateless steady call.
+// Polyphase engines carry history (its own, in half precision) and take per-frame rotations like the fp32 path; FIRs of more
+// than 8192 taps (CLI blksiz 16384, 32768: four / eight partitions of the odd taps) take two / four launches of two partitions
+// each, the later ones adding their share to the half-precision output the earlier ones stored -- one more rounding to half per
+// launch (round 4: measured against the oracle inside the path's stated tolerance, tests/test_gpu_fp16.py; refused before).  The
+// direct-form cross-check engines (PROT_CFG_*) only offer the stateless steady call.
 static int apply_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint64_t n_in, void* d_out, int64_t out_stride,
                       uint64_t n_out, const float* rot, const float* d_rot_s, uint32_t flags, void* stream)
 {
@@ -1773,11 +1775,11 @@ static int apply_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint6
 		return PROT_EINVAL;
 	}
 	const bool stateless = flags & PROT_F_STATELESS;
-	const bool f16_poly  = e->use_poly && e->info.partitions <= 2;
+	const bool f16_poly  = e->use_poly && (e->info.partitions <= 2 || e->info.partitions % 2 == 0);
 	const bool f16_p2    = e->use_p2 && e->info.partitions == 2;
 	const bool f16_one   = !e->use_poly && !e->use_p2 && e->info.partitions == 1;
 	if (!f16_poly && !f16_p2 && !f16_one) {
-		snprintf (g_err, sizeof (g_err), "fp16 sample path: FIRs of more than 8192 taps would accumulate partitions in half precision");
+		snprintf (g_err, sizeof (g_err), "fp16 sample path: this engine form has no half-precision kernel");
 		return PROT_EUNSUPPORTED;
 	}
 	if (!f16_poly && (!stateless || d_rot_s)) {
@@ -1832,6 +1834,8 @@ static int apply_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint6
 	static const bool slots_forced = tuning_env ("PROT_WG_PER_CU") != nullptr; // tuning
 	// (two partitions per launch: 128-158 VGPRs, 34 KiB -- three per CU where the fp32 kernel has two; 0.367 -> 0.336 ms)
 	const int slots16 = (!f16_poly || slots_forced) ? e->wg_slots : e->cus * (e->info.partitions == 1 ? 4 : 3);
+	const uint32_t np16    = std::min<uint32_t> (2, e->info.partitions);
+	const uint32_t n_l16   = f16_poly ? e->info.partitions / np16 : 1;
 	p.run_frames = pick_run_frames (e, n_out, nc, 0, slots16); // the engine's own transform block: the fp16 kernels share its form
 	p.conv_delay = (int)e->info.conv_delay;
 	p.dry_delay  = (int)e->info.dry_delay;
@@ -1841,12 +1845,21 @@ static int apply_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint6
 		p.hist     = (const _Float16*)e->d_hist16[e->hist16_cur].p;
 		p.hist_out = carry ? (_Float16*)e->d_hist16[1 - e->hist16_cur].p : nullptr;
 	}
-	if (f16_poly) {
+	if (f16_poly && n_l16 == 1) {
 		rank_runs (p, (int64_t)e->info.run_align, nc, n_out, slots16, e->cus, true);
 	}
-	hipError_t err = f16_poly ? prot::launch_ola_poly_f16 (p, (int)e->info.partitions, e->hopseg / 2, nc, s)
-	               : f16_p2   ? prot::launch_ola4096_p2_f16 (p, nc, s)
-	                          : prot::launch_ola4096_f16 (p, e->hopseg, nc, s);
+	hipError_t err = hipSuccess;
+	if (f16_poly) {
+		for (uint32_t l = 0; l < n_l16 && err == hipSuccess; ++l) {
+			p.H          = e->d_H.p + (size_t)(np16 * l) * e->info.fftlen;
+			p.conv_delay = (int)(e->info.conv_delay + np16 * l * e->info.fftlen); // a partition of g spans 4096 frames
+			p.accumulate = l > 0;
+			err          = prot::launch_ola_poly_f16 (p, (int)np16, e->hopseg / 2, nc, s);
+			p.hist_out   = nullptr;
+		}
+	} else {
+		err = f16_p2 ? prot::launch_ola4096_p2_f16 (p, nc, s) : prot::launch_ola4096_f16 (p, e->hopseg, nc, s);
+	}
 	if (err != hipSuccess) {
 		return hip_fail (err, "fp16 ola kernel launch");
 	}

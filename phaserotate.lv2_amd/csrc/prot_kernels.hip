@@ -1687,7 +1687,7 @@ hipError_t launch_ola_poly (const OlaParams& p, int n_part, int hop_rows, int n_
 // per-frame rotation, with or without history
 hipError_t launch_ola_poly_f16 (const OlaParamsH& p, int n_part, int hop_rows, int n_chn, hipStream_t s)
 {
-	if ((p.conv_delay & 1) || (p.run_frames % (512 * hop_rows)) != 0 || p.accumulate || (n_part != 1 && n_part != 2) ||
+	if ((p.conv_delay & 1) || (p.run_frames % (512 * hop_rows)) != 0 || (p.accumulate && n_part != 2) || (n_part != 1 && n_part != 2) ||
 	    (hop_rows != 8 && (n_part != 1 || (hop_rows != 10 && hop_rows != 12 && hop_rows != 14)))) {
 		return hipErrorInvalidValue;
 	}

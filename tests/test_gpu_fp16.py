@@ -149,15 +149,43 @@ def test_fp16_ramp_against_oracle(pkg, capsys):
     e.close()
 
 
-def test_fp16_long_fir_is_refused(pkg):
-    """FIRs beyond 8192 taps would accumulate partitions in half precision: refused, not approximated."""
+@pytest.mark.parametrize("blksiz", [16384, 32768])
+def test_fp16_long_fir_against_oracle(pkg, blksiz, capsys):
+    """FIRs beyond 8192 taps (CLI blksiz 16384 -- the reference's default at 96 kHz -- and 32768): two / four launches of two
+    partitions each, the later ones adding their share to the half-precision output of the earlier ones (one more rounding to half
+    per launch).  Rounds 2-3 refused these engines; measured against the oracle on the rounded input the error stays inside the
+    path's stated tolerance, so they are served (steady rotation, stateless and in stateful chunks)."""
     import torch
+    nblk = 16 if blksiz == 16384 else 10
+    n = nblk * blksiz
+    x16 = _signal(n, 8).astype(np.float16)
+    xr = x16.astype(np.float32)
+    o = orc.CliEngine(blksiz, 1)
+    a = 251  # half-degree index
+    yo = np.concatenate([o.apply(xr[b * blksiz:(b + 1) * blksiz], [a]) for b in range(nblk)])
+    e = pkg.Engine(pkg.KIND_CLI, blksiz, 1)
     dev = torch.device("cuda:0")
-    e = pkg.Engine(pkg.KIND_CLI, 16384, 1)
-    x = torch.zeros(65536, device=dev, dtype=torch.float16)
-    y = torch.empty_like(x)
-    with pytest.raises(pkg.ProtError):
-        e.apply_dev_f16(x.data_ptr(), 65536, 65536, y.data_ptr(), 65536, 65536, np.array([1, 0], np.float32))
+    xd = torch.from_numpy(x16).to(dev)
+    yd = torch.empty_like(xd)
+    s, c = orc.sincos_lut(a)
+    rot = np.array([c, s], np.float32)
+    torch.cuda.synchronize()
+    e.apply_dev_f16(xd.data_ptr(), n, n, yd.data_ptr(), n, n, rot)
+    e.sync()
+    yg = yd.float().cpu().numpy()
+    mx, rms = _report(capsys, "CLI blksiz %d (%d launches), %d frames" % (blksiz, blksiz // 8192, n), np.abs(yg - yo), yo)
+    assert mx < MAX_ABS and rms < RMS
+    # stateful chunks on whole transform blocks: the same bits as the one-shot call
+    e.reset()
+    y2 = torch.zeros_like(xd)
+    A = int(e.info.run_align)
+    pos = 0
+    for sz in (3 * A, 7 * A, n - 10 * A):
+        torch.cuda.synchronize()
+        e.apply_dev_f16(xd.data_ptr() + 2 * pos, sz, sz, y2.data_ptr() + 2 * pos, sz, sz, rot, flags=0)
+        e.sync()
+        pos += sz
+    assert torch.equal(y2, yd)
     e.close()
 
 
