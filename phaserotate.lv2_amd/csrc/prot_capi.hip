@@ -437,7 +437,7 @@ struct prot_engine {
 	int              last_n_lists = 0;          // geometry of the last fused pass (prot_internal_fused_lists)
 	int64_t          last_cap     = 0;
 	PinBuf<float>  h_io;
-	// the run() server (prot_olasave.hip): a resident kernel that takes prot_lv2_run's calls through a pinned mailbox
+	// the run() server (prot_olasave.hip): a resident kernel that takes prot_lv2_run's calls through a mailbox
 	char*          srv_box = nullptr;      // host -> device half (prot::SvServerBox + input frames + per-frame rotation): device memory
 	                                       // the CPU stores into through the BAR (srv_bar), or pinned host-coherent memory
 	size_t         srv_box_bytes = 0;
@@ -2374,7 +2374,7 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 		}
 	}
 
-	// The run() server (prot_olasave.hip): the call's parameters go into the pinned mailbox, the doorbell is rung, the resident
+	// The run() server (prot_olasave.hip): the call's parameters and frames go into the mailbox, the doorbell is rung, the resident
 	// kernel does the block and stores the call's number when the output is in h_out -- no launch, no stream synchronisation.
 	// One server per process (the first LV2 engine to ask: see g_srv_owner); calls of more than one block per channel, staged
 	// calls and PROT_TEST_LV2_NO_SERVER take the launch below.  tools/run_latency.py: 38-40 us -> the figure in DESIGN.md.

@@ -569,7 +569,8 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 // An LV2 host calls run() (src/phaserotate.c:774-852) with ~1024 frames at a time, and a kernel launch plus a stream
 // synchronisation cost more than the block itself: 38-40 us per call, no faster than one host core.  The server is the same block
 // code as a RESIDENT kernel -- one workgroup per channel, started by the first run() and left running: the host stores the call's
-// parameters (the OlaParams the launch would have carried) and its input into pinned, host-coherent memory and rings a doorbell
+// parameters (the OlaParams the launch would have carried) and its input into the mailbox (SvServerBox, prot_kernels.h: device memory
+// through the PCIe BAR where there is a large one, pinned host-coherent memory otherwise) and rings a doorbell
 // word; workgroup 0 polls the doorbell over the host link, relays the decision to the other channels' workgroups through a
 // device word (ONE decision for all: serve call s, or leave), every workgroup runs the call's block with the code of the
 // launched kernel (olasave_body: same bits), publishes its output with a system-scope release and stores the call's number into
@@ -588,7 +589,7 @@ __global__ __launch_bounds__ (256, 1) void olasave_server_kernel (const SvServer
 	__shared__ f2       smem[kLdsExchange + 512];
 	__shared__ float    sw_lo_s[4];
 	__shared__ unsigned sh_w[2];
-	// the call's input frames of this channel, fetched from the pinned port block ONCE (the block reads them twice -- its rows and
+	// the call's input frames of this channel, fetched from the mailbox ONCE (the block reads them twice -- its rows and
 	// the next history -- and every read of host memory is a trip over the host link that nothing hides)
 	__shared__ __attribute__ ((aligned (16))) float sh_in[512 * HS];
 	__shared__ __attribute__ ((aligned (16))) unsigned sh_p[(sizeof (OlaParams) + 3) / 4]; // the call's parameters (read in place)
