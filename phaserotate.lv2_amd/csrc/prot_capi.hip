@@ -1355,6 +1355,14 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 		e->use_save8 = save_tables8k (fir_taps, sv8_h, e->sv8_gain);
 		e->sv8_rows  = 16 - (int)(inf.firlen / 1024);
 	}
+	// LV2 at 176.4 / 192 kHz (8192 taps = 8 context rows of an 8192-point block, one table-free partition): long launches only, like
+	// the other LV2 rates (shorter ones keep olapoly_kernel's two partitions on 4096-point transforms)
+	if (use_poly && n_part == 2 && inf.kind == PROT_KIND_LV2 && inf.firlen == 8192 && 2 * (inf.dry_delay - inf.conv_delay) == 8192 &&
+	    inf.dry_delay % 2 == 0 && inf.history >= inf.dry_delay + 4096 + 2 &&
+	    !(cfg->flags & (PROT_CFG_BLOCK4096 | PROT_CFG_OVERLAP_ADD | PROT_CFG_POLYPHASE)) && tuning_env ("PROT_NO_SAVE8K") == nullptr) {
+		e->use_save8 = save_tables8k (fir_taps, sv8_h, e->sv8_gain);
+		e->sv8_rows  = 8;
+	}
 	// The CLI's default engine at 44.1 / 48 kHz (blksiz 8192, cli/phase-rotate.cc:749-755): 4096 odd taps = 8 context rows of an
 	// 8192-point block -- ONE table-free partition, 8192 new frames per block, instead of two 2048-tap partitions with a spectrum
 	// table on 4096-point transforms (olapoly_kernel, which stays for the fp16 path and under the flags that ask for it).  EVERY

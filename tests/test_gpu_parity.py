@@ -1406,6 +1406,39 @@ def test_block8192_kernel_against_oracle_and_block4096(pkg, rate, chn, n, odd):
             assert np.abs(got - yo[t0 - lo + skip:]).max() < TOL, (t0, c)
 
 
+def test_block8192_kernel_lv2_192k(pkg):
+    """LV2 at 192 kHz (8192 taps): long launches on 8192-point blocks as ONE table-free partition (HS = 8) against the two-partition
+    overlap-add kernel on 4096-point transforms (PROT_CFG_BLOCK4096) and, in windows, against the CPU oracle's run()."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, chn = (1 << 24) + 3001, 1
+    g = torch.Generator(device=dev).manual_seed(77)
+    x = torch.rand(n, generator=g, device=dev) - 0.5
+    rot = np.array([0.6, 0.8], np.float32)
+    outs = {}
+    for tag, flags in (("8k", 0), ("4k", pkg.CFG_BLOCK4096)):
+        e = pkg.Engine(pkg.KIND_LV2, 192000, chn, flags=flags)
+        assert int(e.info.form) == (pkg.FORM_POLY_SAVE8K if flags == 0 else pkg.FORM_POLY_OLA)
+        y = torch.zeros_like(x)
+        torch.cuda.synchronize()
+        e.apply_dev(x.data_ptr(), n, n, y.data_ptr(), n, n, rot, pkg.F_STATELESS)
+        e.sync()
+        outs[tag] = y
+        e.close()
+    assert float((outs["8k"] - outs["4k"]).abs().max()) < TOL
+    W, lat = 32768, 5120
+    for t0 in (0, n - W, 5_000_000):
+        lo = max(0, t0 - 40000)
+        xs = x[lo:t0 + W].cpu().numpy()[None, :]
+        o = orc.Lv2Engine(192000, 1)
+        o.activate()
+        ang = np.degrees(np.arctan2(-rot[1], rot[0]))
+        yo = o.run_stream(xs, float(ang), 1024)[0]
+        skip = 2 * lat + 8192 if lo == 0 else 0
+        got = outs["8k"][t0 + skip:t0 + W].cpu().numpy()
+        assert np.abs(got - yo[t0 - lo + skip:]).max() < TOL, t0
+
+
 def test_block8192_hilbert_branch_and_history(pkg):
     """The same kernel in its Hilbert-only mode and with the engine's history in front of the stream: two stateful calls of
     2^24 frames against one stateless call over both (the second call's first blocks read the history buffer the first one
