@@ -69,7 +69,7 @@ __global__ __launch_bounds__ (512, 4) void olasave8k_kernel (const OlaParams p)
 	constexpr int ROT = (NT & 1) ? 256 : 0;  // complex samples the block is rotated by
 	constexpr int AM  = MODE == MODE_ROT ? 0 : 2;
 	static_assert (HS == 8 || HS == 12 || HS == 13, "rows per block");
-	static_assert (MODE != MODE_SWEEP || HS == 8, "the fused sweep exists for the CLI engine on these blocks (blksiz 8192)");
+	static_assert (MODE != MODE_SWEEP || HS == 8 || HS == 12, "the fused sweep exists for the CLI engines on these blocks (blksiz 8192, 4096)");
 
 	extern __shared__ f2 smem8[]; // kSv8LdsBytes: the exchange area + the two tables (written by the generated prologue)
 
@@ -192,6 +192,7 @@ __global__ __launch_bounds__ (512, 4) void olasave8k_kernel (const OlaParams p)
 					float2*       cur   = uniform_ptr_generic (base + sw_cnt);
 					const float   thr_u = sw_thr ();
 					PROT_SV8_SWEEP_CALL (8, a_in, cur, sw_raw, nf, thr_u, sa)
+					PROT_SV8_SWEEP_CALL (12, a_in, cur, sw_raw, nf, thr_u, sa)
 					sw_cnt = (unsigned)__builtin_amdgcn_readfirstlane ((int)(cur - sw_list ()));
 				} else {
 					float* a_out = uniform_ptr_generic (out + s);
@@ -314,7 +315,7 @@ static hipError_t launch_sv8_m (const OlaParams& p, dim3 grid, hipStream_t s)
 	typedef void (*kern_t) (OlaParams);
 	kern_t fn = p.hilbert_only ? olasave8k_kernel<HS, MODE_HILBERT> : p.rot_s != nullptr ? olasave8k_kernel<HS, MODE_RAMP> : olasave8k_kernel<HS, MODE_ROT>;
 	if (p.surv != nullptr) { // the fused sweep: the Hilbert pass with the test in its epilogue (lists instead of output rows)
-		if constexpr (HS == 8) {
+		if constexpr (HS == 8 || HS == 12) {
 			fn = olasave8k_kernel<HS, MODE_SWEEP>;
 		} else {
 			return hipErrorInvalidValue;

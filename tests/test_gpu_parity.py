@@ -901,8 +901,8 @@ def test_overlap_save_equals_overlap_add_on_random_chunkings(pkg, seed):
     outs = []
     for flags in (0, pkg.CFG_OVERLAP_ADD):
         e = pkg.Engine(kind, param, nc, flags=flags)
-        # (LV2 engines: 8192-point blocks for long launches; CLI blksiz 8192: 8192-point blocks for every launch, one table-free partition)
-        assert e.info.form == ((pkg.FORM_POLY_SAVE8K if kind == pkg.KIND_LV2 or param == 8192 else pkg.FORM_POLY_SAVE) if flags == 0 else pkg.FORM_POLY_OLA)
+        # (LV2 engines: 8192-point blocks for long launches; CLI blksiz 4096 and 8192: 8192-point blocks for every launch, one table-free partition)
+        assert e.info.form == ((pkg.FORM_POLY_SAVE8K if kind == pkg.KIND_LV2 or param in (4096, 8192) else pkg.FORM_POLY_SAVE) if flags == 0 else pkg.FORM_POLY_OLA)
         y = torch.zeros(nc * stride, device=dev)
         for a, b in zip(cuts[:-1], cuts[1:]):
             e.apply_dev(x.data_ptr() + 4 * a, stride, b - a, y.data_ptr() + 4 * a, stride, b - a, rot, hil)
@@ -921,7 +921,7 @@ def test_overlap_save_equals_overlap_add_on_random_chunkings(pkg, seed):
 
 
 @pytest.mark.parametrize("P,signal", [(16384, "harmonic"), (16384, "noise"), (32768, "harmonic"), (1024, "harmonic"), (1024, "noise"),
-                                      (8192, "harmonic"), (8192, "noise")])
+                                      (8192, "harmonic"), (8192, "noise"), (4096, "harmonic"), (4096, "noise")])
 def test_fused_sweep_of_the_long_fir_engines_is_bit_identical(pkg, P, signal):
     """CLI blksiz 16384 (the reference's default at 96 kHz, cli/phase-rotate.cc:749-755) and 32768: the Hilbert branch takes two /
     four accumulating launches; on the fused route the LAST one tests the complete Hilbert value with its dry frame instead of

@@ -879,7 +879,7 @@ def self_test(HS, MODE, nblk=3, seed=1, verbose=True, opts=(), kind="run"):
 # HS = 8: the CLI's default engine at 48 kHz (blksiz 8192: 4096 odd taps = 8 context rows) as ONE table-free partition.
 # (HS = 14, CLI blksiz 2048, passes the self-test too and is not emitted: the 4096-point kernel that serves it is faster)
 VARIANTS = [(hs, mode) for hs in (8, 12, 13) for mode in (MODE_ROT, MODE_HILBERT)]
-SWEEP_HS = (8,)   # MODE_SWEEP: the fused sweep of the CLI engine on these blocks
+SWEEP_HS = (8, 12)   # MODE_SWEEP: the fused sweep of the CLI engines on these blocks (blksiz 8192, 4096)
 
 
 def emit(path, opts=()):
