@@ -785,15 +785,18 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
             cs = torch.cuda.Stream(device=dev)
             ms_stream = torch.cuda.current_stream()
 
-            def host_pass():
+            def host_pass(h0=0, h1=None, fl_all=None, halo_=None, prime=None, reduce_=True):
+                """frames [h0, h1) of this rank's pinned copy (default: all of it) through upload + sweep"""
+                h1 = n if h1 is None else h1
+                fl_all = flags if fl_all is None else fl_all
                 eng.reset()
                 peaks.zero_()
-                if rank > 0:
-                    sweep_dist.prime_history(eng, halo, st)
+                if (rank > 0 if prime is None else prime):
+                    sweep_dist.prime_history(eng, halo if halo_ is None else halo_, st)
                 evs, done = [None, None], [None, None]
-                pos, i = 0, 0
-                while pos < n or (n == 0 and i == 0):
-                    m = min(chunk, n - pos)
+                pos, i = h0, 0
+                while pos < h1 or (h1 == h0 and i == 0):
+                    m = min(chunk, h1 - pos)
                     b = i & 1
                     with torch.cuda.stream(cs):
                         if done[b] is not None:
@@ -802,14 +805,14 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
                             bufs[b][c, :m].copy_(xh[c, pos:pos + m], non_blocking=True)
                         evs[b] = cs.record_event()
                     ms_stream.wait_event(evs[b])
-                    fl = (flags & pkg.F_STREAM_START if pos == 0 else 0) | (flags & pkg.F_STREAM_END if pos + m >= n else 0)
+                    fl = (fl_all & pkg.F_STREAM_START if pos == h0 else 0) | (fl_all & pkg.F_STREAM_END if pos + m >= h1 else 0)
                     eng.sweep_dev(bufs[b].data_ptr(), chunk, m, 0, 360, 1, -1, peaks.data_ptr(), fl, st)
                     done[b] = ms_stream.record_event()
                     pos += m
                     i += 1
-                    if n == 0:
+                    if h1 == h0:
                         break
-                if world > 1:
+                if world > 1 and reduce_:
                     dist.all_reduce(peaks, op=dist.ReduceOp.MAX)
                 return peaks.cpu()  # the reduced table on the host ends the pass
 
@@ -824,6 +827,24 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
                                              "%d-frame chunks, upload of chunk k+1 under the sweep of chunk k) to the reduced table on the host" % chunk,
                                      "table_identical_resident": bool((tab.numpy() == pk).all()),
                                      "host_GBps_per_rank": n_chn * n * 4 / hw / 1e9}
+            if world == 1:
+                # SURVEY 8d's multi-GPU wall starts at the first H2D copy: what eight GPUs with a host link EACH would take, predicted
+                # on one -- every shard of plan_shards uploaded from pinned host memory and swept (the same chunked, double-buffered
+                # pass), one after the other; predicted wall = the slowest shard.  A PREDICTION: one device's link and clocks, no
+                # collective (2.9 KB, latency-bound), and a host that really has eight times this link's bandwidth to its memory.
+                plan8 = sweep_dist.plan_shards(total, P, 8, align=eng.shard_align_blocks())
+                sh = []
+                for r8, (c0, c1) in enumerate(plan8):
+                    halo8 = _sweep_signal(torch, np, dev, n_chn, c0 * P - H, H, 4321, kind).contiguous() if r8 > 0 else None
+                    fl8 = (pkg.F_STREAM_START if r8 == 0 else 0) | (pkg.F_STREAM_END if r8 == 7 else 0)
+                    host_pass(c0 * P, c1 * P, fl8, halo8, r8 > 0, False)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    host_pass(c0 * P, c1 * P, fl8, halo8, r8 > 0, False)
+                    sh.append((time.perf_counter() - t0) * 1e3)
+                res["host_inclusive"]["predicted_8gpu"] = {"per_shard_ms": sh, "predicted_wall_ms": max(sh), "predicted_speedup": hw * 1e3 / max(sh),
+                                                           "note": "PREDICTED from eight same-device host-inclusive shard passes (each with this device's "
+                                                                   "host link to itself); no N > 1 run exists"}
             del xh, bufs
         del x
 
