@@ -127,7 +127,7 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 	float            sw_raw = 0.f;
 	// (the bound is parked in global memory -- behind the list lengths, one copy per wave -- and re-read where it is used: a
 	// register copy would live across the generated code.  An LDS word behind the exchange area was tried first and read back
-	// other values on the hardware from the second staged block on, for a reason that was not found: tools/dbgthr.py)
+	// other values on the hardware from the second staged block on, for a reason that was not found: tools/sweep_shard_repro.py shows the symptom when the word is moved back)
 	auto sw_thr_slot = [&] () -> float* {
 		const int w = __builtin_amdgcn_readfirstlane (threadIdx.x >> 6);
 		return reinterpret_cast<float*> (p.surv_cnt) + (int64_t)gridDim.y * gridDim.x * 4 + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + w;
