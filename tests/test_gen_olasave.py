@@ -20,6 +20,15 @@ def test_generated_block_matches_float64_convolution(hs, mode, kind):
     G.self_test(hs, mode, 1, nblk=2, kind=kind, verbose=False)  # asserts max error < 1e-6 and a clean wait / hazard record
 
 
+@pytest.mark.parametrize("thr2", [0.30, 0.75, 50.0])
+def test_generated_sweep_block_lists_the_survivors(thr2):
+    """MODE_SWEEP of the 4096-point loop (blksiz 2048's fused pass): the four waves' survivor lists and raw maxima against the
+    float64 convolution, with one frame in seven surviving (every row appends), one in five hundred (most rows take the branch
+    around the appends, some do not) and none"""
+    import gen_olasave as G
+    G.self_test(12, 3, 1, nblk=2, kind="run", verbose=False, thr2=thr2)
+
+
 def test_model_of_the_table_free_form():
     """tools/model/olasave_model.py: the half-shifted transform pair with |B| = 1 outside the bins next to DC reproduces the
     convolution with g to 1e-7 for every FIR the engines use"""
@@ -51,6 +60,8 @@ def test_generated_8192_point_block_matches_float64_convolution(hs, mode, kind):
     lane-read and lane-mask hazards found on the hardware.  (All variants: python3 tools/gen/gen_olasave8k.py, ~10 minutes.)"""
     import gen_olasave8k as G8
     G8.self_test(hs, mode, nblk=2, kind=kind, verbose=False)
+    if mode == 3:   # ... and with few survivors: rows that skip their appends
+        G8.self_test(hs, mode, nblk=2, kind=kind, verbose=False, thr2=0.7)
 
 
 def test_committed_8192_point_include_is_current(tmp_path):

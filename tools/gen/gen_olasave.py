@@ -58,6 +58,7 @@ class Gen:
         self.R0 = self.NT // 2
         self.BLK = 512 * HS
         P = self.P = Prog()
+        self.sw_rows, self.sw_label = [], 0
         if "nolds" in self.opts:
             P.ds_write_b64 = lambda *a, **k: None
             P.ds_read_b64 = lambda *a, **k: None
@@ -587,32 +588,60 @@ class Gen:
         wave (a plain append at the SGPR cursor S_OUT: lanes compacted by ballot + mbcnt) if d^2 + h^2 exceeds the bound in
         S_ROT.lo: |ca d + sa h| <= sqrt(d^2 + h^2) for every angle, so the other frames cannot raise any maximum that has reached the
         bound (prot_sweep.hip evaluates the list).  max |d| rides along (the raw peak)."""
+        self.sw_rows.append((d, h))
+
+    def sweep_flush(self):
+        """the rows sweep_row collected, tested one behind the next row's norm (round 4, last change): the two compares of a row,
+        its raw maximum and the NEXT row's packed norm (four instructions between a compare and the first reader of its lane mask --
+        isa.py: lane-mask hazard), the two population counts, and the transposing moves, lane ranks and appends only if the wave has a
+        survivor in this row at all -- on material that prunes well most rows of most blocks have none, and the ten vector
+        instructions and two masked-off stores of a row were a tenth of the loop.  The appends sit behind a branch, so the loop top
+        cannot count them: every load is waited for here (they were issued passes ago), and the top waits for nothing in flight."""
         P = self.P
-        r2, prs, idxs = self.TMP[0], (self.TMP[1], self.TMP[3]), (self.TMP[2].lo, self.TMP[2].hi)
-        masks, cnts = (VCC, S_A0), (S_T[0], S_T[1])   # (no store of this mode goes through the address temporary)
-        P.pk("mul", r2, [d, d])
-        P.pk("fma", r2, [h, h, r2])
-        # the two compares first, the lane masks in SGPR pairs, and everything that reads a mask at least five instructions behind
-        # the compare that wrote it (isa.py: lane-mask hazard)
-        for j, half in enumerate(("lo", "hi")):
-            P.v_cmp_lt_f32(masks[j], S_ROT.lo, getattr(r2, half))
-        P.v_max3_abs(self.V_RAW, d.lo, d.hi)
-        for j, half in enumerate(("lo", "hi")):
-            P.v_mov(prs[j].lo, getattr(d, half))
-            P.v_mov(prs[j].hi, getattr(h, half))
-        P.s_nop(1)
-        for j in range(2):
-            P.v_mbcnt(idxs[j], masks[j])
-            P.v_lshl(idxs[j], Lit(3), idxs[j])
-        for j in range(2):
-            P.s_bcnt1(cnts[j], masks[j])
-            P.s_lshl_b32(cnts[j], cnts[j], Lit(3))
-        for j in range(2):
-            P.exec_from(masks[j])
-            P.global_store_dwordx2(idxs[j], prs[j], S_OUT, 0)
-            P.exec_all()
-            P.s_add_u32(S_OUT.lo, S_OUT.lo, cnts[j])
-            P.s_addc_u32(S_OUT.hi, S_OUT.hi, Lit(0))
+        rows, self.sw_rows = self.sw_rows, []
+        if not rows:
+            return
+        P.s_waitcnt(vmcnt=0)
+        r2s, prs, idxs = (self.TMP[0], self.TMP[4]), (self.TMP[1], self.TMP[3]), (self.TMP[2].lo, self.TMP[2].hi)
+        masks, cnts, tot = (VCC, S_A0), (S_T[0], S_T[1]), S_T[2]   # (no store of this mode goes through the address temporary)
+
+        def norm(k):
+            d, h = rows[k]
+            P.pk("mul", r2s[k % 2], [d, d])
+            P.pk("fma", r2s[k % 2], [h, h, r2s[k % 2]])
+        norm(0)
+        for k, (d, h) in enumerate(rows):
+            for j, half in enumerate(("lo", "hi")):
+                P.v_cmp_lt_f32(masks[j], S_ROT.lo, getattr(r2s[k % 2], half))
+            P.v_max3_abs(self.V_RAW, d.lo, d.hi)
+            if k + 1 < len(rows):
+                norm(k + 1)
+            else:   # (the last row: two of its moves as the filler)
+                P.v_mov(prs[0].lo, d.lo)
+                P.v_mov(prs[0].hi, h.lo)
+            for j in range(2):
+                P.s_bcnt1(cnts[j], masks[j])
+            P.s_add_u32(tot, cnts[0], cnts[1])
+            P.s_cmp_eq_u32(tot, Lit(0))
+            lab = "L_sw%d" % self.sw_label
+            self.sw_label += 1
+            P.s_cbranch_scc1(lab)
+            mark = len(P.vmq)
+            for j, half in enumerate(("lo", "hi")):
+                P.v_mov(prs[j].lo, getattr(d, half))
+                P.v_mov(prs[j].hi, getattr(h, half))
+            for j in range(2):
+                P.v_mbcnt(idxs[j], masks[j])
+                P.v_lshl(idxs[j], Lit(3), idxs[j])
+                P.s_lshl_b32(cnts[j], cnts[j], Lit(3))
+            for j in range(2):
+                P.exec_from(masks[j])
+                P.global_store_dwordx2(idxs[j], prs[j], S_OUT, 0)
+                P.exec_all()
+                P.s_add_u32(S_OUT.lo, S_OUT.lo, cnts[j])
+                P.s_addc_u32(S_OUT.hi, S_OUT.hi, Lit(0))
+            P.label(lab)
+            del P.vmq[mark:]   # (conservative for whoever waits next: the appends may not have been issued)
 
     def epilogue(self, u):
         for k in range(self.HS):
@@ -626,8 +655,11 @@ class Gen:
             P.label("L_top")
             # whichever way the top is reached, what may still be in flight: the previous block's HS stores (younger than its
             # prefetch, which the wait below therefore completes)
-            n_st = 2 * HS if self.MODE == MODE_SWEEP else HS   # (two appends per row instead of one store)
-            P.s_waitcnt(vmcnt=n_st, lgkmcnt=0)
+            n_st = 0 if self.MODE == MODE_SWEEP else HS   # (SWEEP: sweep_flush has waited for the loads; appends are not counted)
+            if self.MODE == MODE_SWEEP:
+                P.s_waitcnt(lgkmcnt=0)
+            else:
+                P.s_waitcnt(vmcnt=n_st, lgkmcnt=0)
             P.reset_queues(vm_stores=n_st)
         P.comment("---- (p, q) pairs")
         if "prio1" in self.opts:
@@ -701,6 +733,7 @@ class Gen:
             return
         if not self.stored:
             self.epilogue(u)
+        self.sweep_flush()
         if "prio2" in self.opts:
             P.s_setprio(0)
         P.s_add_u32(S_IN.lo, S_IN.lo, Lit(4 * self.BLK))
@@ -734,7 +767,7 @@ class Gen:
 
 
 # ---------------------------------------------------------------------------------------------------- self-test
-def self_test(HS, MODE, NA=1, nblk=3, seed=1, verbose=True, opts=(), kind="run"):
+def self_test(HS, MODE, NA=1, nblk=3, seed=1, verbose=True, opts=(), kind="run", thr2=0.30):
     import olasave_model as M
     g = Gen(HS, MODE, NA, opts, kind)
     if kind == "core":
@@ -776,7 +809,6 @@ def self_test(HS, MODE, NA=1, nblk=3, seed=1, verbose=True, opts=(), kind="run")
         put(12 * 256 + t, -2 * math.pi * ((t & 15) - 0.5) * (t >> 4) / 256)
         put(14 * 256 + t, -2 * math.pi * (((t & 15) * (t >> 4)) & 255) / 256)
     ca, sa = 0.6, -0.8
-    thr2 = 0.30
     if MODE == MODE_SWEEP:   # S_ROT.lo is the bound, the Hilbert branch is unscaled, every wave appends to a list of its own
         ca, sa = thr2, 1.0
         SURV_BASE, CAP = 0x40000000, 2 * BLK * nblk
@@ -876,7 +908,7 @@ def self_test(HS, MODE, NA=1, nblk=3, seed=1, verbose=True, opts=(), kind="run")
                     rexp = np.maximum(rexp, np.maximum(np.abs(dry[pos]), np.abs(dry[pos + 1])))
             assert np.array_equal(raw, rexp.astype(np.float32)), "running max |x|"
         frac = sum(((int(emu.s[w, S_OUT.n]) | (int(emu.s[w, S_OUT.n + 1]) << 32)) - (SURV_BASE + 4 * CAP * w)) // 8 for w in range(4)) / (BLK * nblk)
-        kind = kind + " sweep (%.0f %% of the frames survive)" % (100 * frac)
+        kind = kind + " sweep (%.1f %% of the frames survive)" % (100 * frac)
     else:
         err = np.abs(out[:BLK * nblk] - want).max()
     st = P.stats()

@@ -61,6 +61,7 @@ class Gen8k(Gen):
         self.ROT = 256 if self.ODD else 0      # complex samples the block is rotated by
         self.BLK = 1024 * HS                   # frames per block
         P = self.P = Prog()
+        self.sw_rows, self.sw_label = [], 0
         if "nolds" in self.opts:
             P.ds_write_b64 = lambda *a, **k: None
             P.ds_read_b64 = lambda *a, **k: None
@@ -596,8 +597,11 @@ class Gen8k(Gen):
         if not core:
             P.s_waitcnt(vmcnt=0)
             P.label("L_top")
-            n_st = 2 * HS if self.MODE == MODE_SWEEP else HS   # (two appends per row instead of one store)
-            P.s_waitcnt(vmcnt=n_st, lgkmcnt=0)
+            n_st = 0 if self.MODE == MODE_SWEEP else HS   # (SWEEP: sweep_flush has waited for the loads; appends are not counted)
+            if self.MODE == MODE_SWEEP:
+                P.s_waitcnt(lgkmcnt=0)
+            else:
+                P.s_waitcnt(vmcnt=n_st, lgkmcnt=0)
             P.reset_queues(vm_stores=n_st)
         P.comment("---- (p, q) pairs")
         self.build_pq()
@@ -689,6 +693,7 @@ class Gen8k(Gen):
             return
         for k in range(HS):
             self.epilogue_row(u, k)
+        self.sweep_flush()
         P.s_add_u32(S_IN.lo, S_IN.lo, Lit(4 * self.BLK))
         P.s_addc_u32(S_IN.hi, S_IN.hi, Lit(0))
         if self.MODE != MODE_SWEEP:    # (SWEEP: S_OUT is the survivor cursor, advanced by what was appended)
@@ -748,7 +753,7 @@ def device_table(HS, fir=None):
     return tab, np.float32(mean / 8192), gt
 
 
-def self_test(HS, MODE, nblk=3, seed=1, verbose=True, opts=(), kind="run"):
+def self_test(HS, MODE, nblk=3, seed=1, verbose=True, opts=(), kind="run", thr2=0.30):
     g = Gen8k(HS, MODE, opts, kind)
     if kind == "core":
         nblk = 1
@@ -767,7 +772,6 @@ def self_test(HS, MODE, nblk=3, seed=1, verbose=True, opts=(), kind="run"):
     emu.map(SV_BASE, tab.view(np.uint32))
     ldsf = emu.lds.view(np.float32)
     ca, sa = 0.6, -0.8
-    thr2 = 0.30
     if MODE == MODE_SWEEP:   # S_ROT.lo is the bound, the Hilbert branch is unscaled, every wave appends to a list of its own
         ca, sa = thr2, 1.0
         SURV_BASE, CAP = 0x40000000, 2 * BLK * nblk
@@ -861,7 +865,7 @@ def self_test(HS, MODE, nblk=3, seed=1, verbose=True, opts=(), kind="run"):
                     rexp = np.maximum(rexp, np.maximum(np.abs(dry[pos]), np.abs(dry[pos + 1])))
             assert np.array_equal(raw, rexp.astype(np.float32)), "running max |x|"
         frac = sum(((int(emu.s[w, S_OUT.n]) | (int(emu.s[w, S_OUT.n + 1]) << 32)) - (SURV_BASE + 4 * CAP * w)) // 8 for w in range(8)) / (BLK * nblk)
-        kind = kind + " sweep (%.0f %% of the frames survive)" % (100 * frac)
+        kind = kind + " sweep (%.1f %% of the frames survive)" % (100 * frac)
     else:
         err = np.abs(out[:BLK * nblk] - want).max()
     st = P.stats()
