@@ -467,6 +467,8 @@ struct prot_engine {
 	hipEvent_t     pipe_ev[kPipe + 1] = {};
 	hipStream_t    last_stream = nullptr; // the stream of the last call that launched work (prot_engine_reset waits for it)
 	hipEvent_t     ev_reset    = nullptr;
+	hipStream_t    reset_stream  = nullptr; // where the last prot_engine_reset put its zeroing, behind ev_reset ...
+	bool           reset_pending = false;   // ... until a call has taken a stream (pick_stream orders a DIFFERENT stream behind it)
 	DevBuf<uint32_t> d_pipe;      // [0..7] generation g's history is complete when slot g & 7 holds g; [8..11] slice counters;
 	                              // [12] status: the generation a kernel gave up waiting for (0: none) -- checked by prot_engine_sync
 	bool           pipe_used  = false; // pipelined launches since the status word was last looked at
@@ -490,8 +492,9 @@ struct prot_engine {
 
 namespace {
 
-int zero_state (prot_engine* e)
+int zero_state (prot_engine* e, hipStream_t zs = nullptr)
 {
+	zs = zs ? zs : e->stream;
 	// one launch: the history buffer that becomes current (the others of the ring are written in full before they are
 	// read), the peak table, the sweep statistics, the half-precision history that becomes current
 	const size_t hn = (size_t)e->info.history * e->info.n_chn;
@@ -510,12 +513,12 @@ int zero_state (prot_engine* e)
 	z.n[4] = e->d_thr.p ? prot::kSweepThrFloats * (size_t)e->info.n_chn : 0;
 	z.p[5] = reinterpret_cast<uint32_t*> (e->d_ctr.p);
 	z.n[5] = e->d_ctr.p ? (size_t)e->info.n_chn * 32 * 32 : 0;
-	hipError_t err = prot::launch_zero_regions (z, e->stream);
+	hipError_t err = prot::launch_zero_regions (z, zs);
 	if (err != hipSuccess) {
 		return hip_fail (err, "state reset launch");
 	}
 	if (e->d_fused_surv.p) {
-		(void)hipMemsetAsync (e->d_fused_surv.p, 0, sizeof (unsigned long long), e->stream);
+		(void)hipMemsetAsync (e->d_fused_surv.p, 0, sizeof (unsigned long long), zs);
 	}
 	e->fused_frames  = 0;
 	e->sweep_seeded  = false;
@@ -1065,8 +1068,26 @@ hipStream_t pick_stream (prot_engine* e, void* stream, bool keep_server = false)
 	}
 	hipStream_t s = stream ? (hipStream_t)stream : e->stream;
 	(void)join_pipe (e, s);
+	if (e->reset_pending) {
+		// prot_engine_reset does not block the host (round 4, last day): its zeroing sits on the stream of the call before it; a
+		// call that arrives on another stream is put behind it here
+		if (s != e->reset_stream) {
+			(void)hipStreamWaitEvent (s, e->ev_reset, 0);
+		}
+		e->reset_pending = false;
+	}
 	e->last_stream = s;
 	return s;
+}
+
+// the engine's own stream AND a reset that went to a caller's stream: what the readers of device state wait for
+hipError_t sync_own (prot_engine* e)
+{
+	hipError_t err = hipStreamSynchronize (e->stream);
+	if (err == hipSuccess && e->reset_pending && e->reset_stream != e->stream) {
+		err = hipEventSynchronize (e->ev_reset);
+	}
+	return err;
 }
 
 // copy a small host array to device memory in stream order without keeping a reference to `src`
@@ -1550,6 +1571,9 @@ void prot_engine_destroy (prot_engine* e)
 	if (e->stream) {
 		(void)hipStreamSynchronize (e->stream);
 	}
+	if (e->reset_pending && e->ev_reset) { // a reset's zeroing on a caller's stream writes the buffers released below
+		(void)hipEventSynchronize (e->ev_reset);
+	}
 	e->d_H.release ();
 	e->d_sv.release ();
 	e->d_sv8.release ();
@@ -1633,22 +1657,27 @@ int prot_engine_reset (prot_engine* e)
 	}
 	HIP_TRY (hipSetDevice (e->device));
 	(void)server_stop_any ();
-	(void)join_pipe (e, e->stream);
-	if (e->last_stream != nullptr && e->last_stream != e->stream && e->ev_reset != nullptr) {
-		// the engine's work on the caller's stream of its last call may still be running (its kernels read the history and
-		// write the counters this reset zeroes): the reset is ordered behind it
-		HIP_TRY (hipEventRecord (e->ev_reset, e->last_stream));
-		HIP_TRY (hipStreamWaitEvent (e->stream, e->ev_reset, 0));
-	}
-	int rc = zero_state (e);
+	// Stream-ordered, and no host wait (until the last day of round 4 the zeroing went to the engine's own stream behind an event
+	// of the last call's stream, and the host waited for it: a sweep pass per reset -- the bench's loop, a host that analyses file
+	// after file -- paid a blocking wait per pass, 0.05-0.25 ms by the state of the runtime's queues; tools/_state_probe.py).
+	// The zeroing goes to the stream of the engine's last call -- behind the kernels that read what it zeroes --; pick_stream puts
+	// a call that arrives on another stream behind ev_reset, the readers of device state wait for it (sync_own).
+	hipStream_t zs = (e->last_stream != nullptr && e->ev_reset != nullptr) ? e->last_stream : e->stream;
+	(void)join_pipe (e, zs);
+	int rc = zero_state (e, zs);
 	if (rc) {
 		return rc;
 	}
 	for (auto& c : e->lv2) { // channel_reset: offset = 0, buf_out = 0 (angle state kept, Q10)
 		c.offset = 0;
 	}
-	(void)join_pipe (e, e->stream);
-	HIP_TRY (hipStreamSynchronize (e->stream));
+	if (e->ev_reset != nullptr) {
+		HIP_TRY (hipEventRecord (e->ev_reset, zs));
+		e->reset_stream  = zs;
+		e->reset_pending = true;
+	} else {
+		HIP_TRY (hipStreamSynchronize (zs));
+	}
 	return PROT_OK;
 }
 
@@ -1678,7 +1707,7 @@ int prot_engine_sync (prot_engine* e)
 	HIP_TRY (hipSetDevice (e->device));
 	(void)server_stop_any ();
 	(void)join_pipe (e, e->stream);
-	HIP_TRY (hipStreamSynchronize (e->stream));
+	HIP_TRY (sync_own (e));
 	if (e->pipe_used && e->d_pipe.p) {
 		// did a pipelined launch give up waiting for the history of the one before it (prot_olasave.hip: bounded wait)?
 		uint32_t st = 0;
@@ -2193,7 +2222,7 @@ int prot_sweep_stats_ex (prot_engine* e, uint64_t out[4])
 	}
 	HIP_TRY (hipSetDevice (e->device));
 	(void)join_pipe (e, e->stream);
-	HIP_TRY (hipStreamSynchronize (e->stream));
+	HIP_TRY (sync_own (e));
 	unsigned long long h[4] = { 0, 0, 0, 0 };
 	HIP_TRY (hipMemcpy (h, e->d_stats.p, sizeof (h), hipMemcpyDeviceToHost));
 	for (int i = 0; i < 4; ++i) {
@@ -2209,7 +2238,7 @@ int prot_sweep_stats_fused (prot_engine* e, uint64_t out[2])
 	}
 	HIP_TRY (hipSetDevice (e->device));
 	(void)join_pipe (e, e->stream);
-	HIP_TRY (hipStreamSynchronize (e->stream));
+	HIP_TRY (sync_own (e));
 	unsigned long long kept = 0;
 	if (e->d_fused_surv.p) {
 		HIP_TRY (hipMemcpy (&kept, e->d_fused_surv.p, sizeof (kept), hipMemcpyDeviceToHost));
@@ -2240,7 +2269,7 @@ int prot_cli_peaks (prot_engine* e, float* out)
 	}
 	HIP_TRY (hipSetDevice (e->device));
 	(void)join_pipe (e, e->stream);
-	HIP_TRY (hipStreamSynchronize (e->stream));
+	HIP_TRY (sync_own (e));
 	HIP_TRY (hipMemcpy (out, e->d_peaks.p, (size_t)PROT_MAXSAMPLE * e->info.n_chn * sizeof (float), hipMemcpyDeviceToHost));
 	return PROT_OK;
 }
@@ -2299,7 +2328,7 @@ int prot_lv2_set_max_block (prot_engine* e, uint32_t frames)
 	HIP_TRY (hipSetDevice (e->device));
 	(void)server_stop_any ();
 	(void)join_pipe (e, e->stream);
-	HIP_TRY (hipStreamSynchronize (e->stream));
+	HIP_TRY (sync_own (e));
 	return lv2_reserve (e, frames);
 }
 
@@ -2708,7 +2737,7 @@ int prot_cli_file_resident (prot_engine* e, int on)
 	e->file_resident = on != 0;
 	if (!on) {
 		(void)join_pipe (e, e->stream);
-		HIP_TRY (hipStreamSynchronize (e->stream));
+		HIP_TRY (sync_own (e));
 		e->d_file.release ();
 		e->file_key = nullptr;
 		e->file_n   = 0;
