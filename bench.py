@@ -354,13 +354,11 @@ def main():
     }
     eng.close()
 
-    # The sweep is timed directly behind the headline, BEFORE the informative sections: measured on one box, in one process
-    # (round 4, bisected section by section), the sweep passes run 6-8 % slower once the pipelined-LV2 section or the host-file
-    # section has run (noise pass 2.33-2.38 ms in front of them, 2.56 behind either one; their engines closed, their streams
-    # destroyed; a pause or an emptied allocator cache changes nothing; the mechanism -- hardware-queue or device-memory state the
-    # runtime keeps for the process -- was not isolated).  A file analysis is one engine on one stream in a fresh process: the
-    # state measured here, and the one tools/sweep_ab_libs.py's child processes see (same box: 1.40 there, 1.44 here, 1.54 behind
-    # the other sections).
+    # The sweep is timed directly behind the headline.  (Found on the last day of round 4 by bisecting the sections: behind the
+    # pipelined-LV2 section or the host-file section the sweep passes ran 6-8 % slower -- not a kernel: prot_engine_reset blocked
+    # the host once per pass, and that wait costs 0.05-0.25 ms by the state of the runtime's queues once streams have waited on
+    # one another.  The reset is stream-ordered now and the order of the sections no longer matters:
+    # tools/process_state_probe.py.)
     if not args.no_sweep:
         out["sweep"] = bench_sweep(args, pkg, torch, dist, dev, st, world, rank, local_rank, barrier)
 

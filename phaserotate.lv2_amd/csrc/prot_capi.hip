@@ -1659,7 +1659,7 @@ int prot_engine_reset (prot_engine* e)
 	(void)server_stop_any ();
 	// Stream-ordered, and no host wait (until the last day of round 4 the zeroing went to the engine's own stream behind an event
 	// of the last call's stream, and the host waited for it: a sweep pass per reset -- the bench's loop, a host that analyses file
-	// after file -- paid a blocking wait per pass, 0.05-0.25 ms by the state of the runtime's queues; tools/_state_probe.py).
+	// after file -- paid a blocking wait per pass, 0.05-0.25 ms by the state of the runtime's queues; tools/process_state_probe.py).
 	// The zeroing goes to the stream of the engine's last call -- behind the kernels that read what it zeroes --; pick_stream puts
 	// a call that arrives on another stream behind ev_reset, the readers of device state wait for it (sync_own).
 	hipStream_t zs = (e->last_stream != nullptr && e->ev_reset != nullptr) ? e->last_stream : e->stream;

@@ -1,3 +1,9 @@
+"""Does what a process did before change the time of a headline launch or of a cfg4 sweep pass?  Both are timed twice in a fresh
+process, then after ONE of: file (bench_file_host), pinned / pageable (H2D copies), streams (three torch streams at once), events
+(two streams and the caller's chained by event waits), apply_file / analyze_file / engine8192 -- and timed twice again.
+Round 4's finding: only `events` (and the bench sections that wait across streams) moved anything -- the sweep pass by +8 %, the
+headline not at all -- and the cause was prot_engine_reset's host wait per pass, not a kernel (the reset is stream-ordered now).
+    python3 tools/process_state_probe.py events"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
