@@ -1463,3 +1463,35 @@ def test_block8192_hilbert_branch_and_history(pkg):
     assert float((y1 + u1).abs().max()) < 1e-6
     assert float(u1.abs().max()) > 0.3
     e.close()
+
+
+def test_reset_is_stream_ordered_and_does_not_need_the_host(pkg):
+    """prot_engine_reset queues its zeroing behind the engine's last call and returns (round 4): a sweep on stream A, the reset,
+    and at once -- no host synchronisation anywhere -- another file's sweep on stream B must give the table of a fresh engine;
+    a reader of device state called right behind a reset sees the zeroed table, not the last file's."""
+    import torch
+    P, n_chn = 2048, 2
+    n = P * 1100                                         # (long enough for the fused route and for kernels still running at the reset)
+    dev = torch.device("cuda", 0)
+    xa = torch.from_numpy(np.ascontiguousarray(_signal(n, n_chn, seed=41).reshape(n, n_chn).T)).to(dev).contiguous()
+    xb = torch.from_numpy(np.ascontiguousarray(0.5 * _signal(n, n_chn, seed=42).reshape(n, n_chn).T)).to(dev).contiguous()
+    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    fl = pkg.F_STREAM_START | pkg.F_STREAM_END
+    ref = pkg.Engine(pkg.KIND_CLI, P, n_chn)
+    ref.sweep_dev(xb.data_ptr(), n, n, 0, 360, 1, -1, 0, fl, sb.cuda_stream)
+    sb.synchronize()
+    want = ref.peaks()
+    ref.close()
+    torch.cuda.synchronize()
+    eng = pkg.Engine(pkg.KIND_CLI, P, n_chn)
+    for rep in range(3):
+        eng.sweep_dev(xa.data_ptr(), n, n, 0, 360, 1, -1, 0, fl, sa.cuda_stream)
+        eng.reset()
+        eng.sweep_dev(xb.data_ptr(), n, n, 0, 360, 1, -1, 0, fl, sb.cuda_stream)
+        sb.synchronize()
+        assert eng.peaks().tobytes() == want.tobytes(), rep
+    eng.sweep_dev(xa.data_ptr(), n, n, 0, 360, 1, -1, 0, fl, sa.cuda_stream)
+    eng.reset()
+    assert not eng.peaks().any()                         # (the reader waits for the reset's event on stream A)
+    torch.cuda.synchronize()
+    eng.close()
