@@ -121,10 +121,11 @@ void prot_engine_destroy (prot_engine* e);
 /* PhaseRotate::reset (cli/phase-rotate.cc:355-366) / activate -> channel_reset
  * (src/phaserotate.c:169-177, :511-520): clears input history, OLA state,
  * peak table and block position.  The LV2 angle state is NOT reset (Q10).
- * Does not block the host: the zeroing is queued on the stream of the engine's last
- * call (behind its kernels); the next call, on whatever stream, is ordered behind it,
- * and every entry point that reads device state (peaks, statistics, prot_engine_sync)
- * waits for it. */
+ * After a call on a stream of the caller's it does not block the host: the zeroing is
+ * queued on that stream (behind the call's kernels), the next call, on whatever stream,
+ * is ordered behind it, and every entry point that reads device state (peaks,
+ * statistics, prot_engine_sync) waits for it.  After a call on the engine's own stream
+ * (stream = NULL) it returns when that stream has drained, as it always did. */
 int prot_engine_reset (prot_engine* e);
 int prot_engine_info (const prot_engine* e, prot_info* out);
 /* the time-domain FIR the engine convolves with (firlen floats); reference

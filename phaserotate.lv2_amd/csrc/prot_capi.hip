@@ -1657,7 +1657,7 @@ int prot_engine_reset (prot_engine* e)
 	}
 	HIP_TRY (hipSetDevice (e->device));
 	(void)server_stop_any ();
-	// Stream-ordered, and no host wait (until the last day of round 4 the zeroing went to the engine's own stream behind an event
+	// Behind a call on a caller's stream: stream-ordered, and no host wait (until the last day of round 4 the zeroing went to the engine's own stream behind an event
 	// of the last call's stream, and the host waited for it: a sweep pass per reset -- the bench's loop, a host that analyses file
 	// after file -- paid a blocking wait per pass, 0.05-0.25 ms by the state of the runtime's queues; tools/process_state_probe.py).
 	// The zeroing goes to the stream of the engine's last call -- behind the kernels that read what it zeroes --; pick_stream puts
@@ -1671,12 +1671,15 @@ int prot_engine_reset (prot_engine* e)
 	for (auto& c : e->lv2) { // channel_reset: offset = 0, buf_out = 0 (angle state kept, Q10)
 		c.offset = 0;
 	}
-	if (e->ev_reset != nullptr) {
+	if (e->ev_reset != nullptr && zs != e->stream) {
 		HIP_TRY (hipEventRecord (e->ev_reset, zs));
 		e->reset_stream  = zs;
 		e->reset_pending = true;
 	} else {
+		// the engine's own stream (stream = NULL in the last call): the caller has no way to order anything of its own against it
+		// but the host -- a table of the caller's zeroed between reset and the next call, say -- so the reset still ends with the wait
 		HIP_TRY (hipStreamSynchronize (zs));
+		e->reset_pending = false;
 	}
 	return PROT_OK;
 }

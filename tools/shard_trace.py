@@ -24,7 +24,9 @@ def run(P, world=8, which=3, kind="harmonic"):
     x = bench._sweep_signal(torch, np, dev, n_chn, c0 * P, (c1 - c0) * P, 1234, kind)
     halo = bench._sweep_signal(torch, np, dev, n_chn, c0 * P - H, H, 4321, kind).contiguous() if which > 0 else None
     peaks = torch.zeros((n_chn, 360), device=dev)
-    st = torch.cuda.current_stream().cuda_stream
+    ts = torch.cuda.Stream(device=dev)   # (a stream of the caller's, so that peaks.zero_() is ordered with the engine's kernels)
+    torch.cuda.set_stream(ts)
+    st = ts.cuda_stream
     import time
     for k in range(6):
         torch.cuda.synchronize()

@@ -27,7 +27,9 @@ def run(kind, P):
     x = bench._sweep_signal(torch, np, dev, n_chn, 0, total, 1234, kind)
     eng = pkg.Engine(pkg.KIND_CLI, P, n_chn, device=0)
     peaks = torch.zeros((n_chn, 360), device=dev)
-    st = torch.cuda.current_stream().cuda_stream
+    ts = torch.cuda.Stream(device=dev)   # (a stream of the caller's: peaks.zero_() below must be ORDERED with the engine's kernels; on
+    torch.cuda.set_stream(ts)            # stream 0 -- the engine's own -- it was only the reset's host wait that kept them apart)
+    st = ts.cuda_stream
     torch.cuda.synchronize()
     for _ in range(PASSES):
         eng.reset()
