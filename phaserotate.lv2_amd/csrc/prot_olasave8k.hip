@@ -132,7 +132,16 @@ __global__ __launch_bounds__ (512, 4) void olasave8k_kernel (const OlaParams p)
 		}
 		return;
 	}
+#ifdef PROT_SV8_CYCLIC
+	// TIMING EXPERIMENT (tools/ab_build.py sv8:cyc:-DPROT_SV8_CYCLIC with the generator's "cyclic" loop; results wrong): workgroup
+	// b takes blocks 2 + b, 2 + b + 512, ... -- the resident workgroups read and write ONE dense window that moves through the
+	// stream -- instead of a run of its own; the same number of blocks for every workgroup, the remainder of the stream untouched
+	const int64_t cyc_per = (p.n_out / BLK - 8) / 512;
+	r0                    = (2 + (int64_t)blockIdx.x) * BLK;
+	const int64_t r1      = r0 + cyc_per * BLK;
+#else
 	const int64_t r1 = (r0 + rlen < p.n_out) ? r0 + rlen : p.n_out;
+#endif
 
 	const float* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
 	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;

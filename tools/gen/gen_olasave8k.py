@@ -62,6 +62,9 @@ class Gen8k(Gen):
         self.BLK = 1024 * HS                   # frames per block
         P = self.P = Prog()
         self.sw_rows, self.sw_label = [], 0
+        # "cyclic" (timing experiment, results wrong): the workgroup's next block lies 512 blocks on -- the resident workgroups
+        # move through the stream as ONE dense window instead of 512 runs of their own (the context rows are NOT reloaded)
+        self.adv = 4 * self.BLK * (512 if "cyclic" in opts else 1)   # bytes from a block to the workgroup's next one
         if "nolds" in self.opts:
             P.ds_write_b64 = lambda *a, **k: None
             P.ds_read_b64 = lambda *a, **k: None
@@ -618,7 +621,7 @@ class Gen8k(Gen):
             self.run_ops(self.stage1_twiddle_ops(v, 1, self.scratch_pairs()))
         else:
             P.s_cmp_eq_u32(S_NBLK, Lit(1))
-            P.s_cselect(S_T[3], Lit(0), Lit(4 * self.BLK))
+            P.s_cselect(S_T[3], Lit(0), Lit(self.adv))
             lds_ = self.load_new_rows(1, thunks=True, soff=S_T[3])
             main = self.stage1_ops(v, 1) + self.stage1_twiddle_ops(v, 1, self.scratch_pairs())
             self.run_ops(self.weave(main, lds_, max(1, len(main) // (len(lds_) + 1)) if lds_ else 1))
@@ -694,10 +697,10 @@ class Gen8k(Gen):
         for k in range(HS):
             self.epilogue_row(u, k)
         self.sweep_flush()
-        P.s_add_u32(S_IN.lo, S_IN.lo, Lit(4 * self.BLK))
+        P.s_add_u32(S_IN.lo, S_IN.lo, Lit(self.adv))
         P.s_addc_u32(S_IN.hi, S_IN.hi, Lit(0))
         if self.MODE != MODE_SWEEP:    # (SWEEP: S_OUT is the survivor cursor, advanced by what was appended)
-            P.s_add_u32(S_OUT.lo, S_OUT.lo, Lit(4 * self.BLK))
+            P.s_add_u32(S_OUT.lo, S_OUT.lo, Lit(self.adv))
             P.s_addc_u32(S_OUT.hi, S_OUT.hi, Lit(0))
         P.s_sub_u32(S_NBLK, S_NBLK, Lit(1))
         P.s_cmp_lg_u32(S_NBLK, Lit(0))
@@ -957,7 +960,7 @@ if __name__ == "__main__":
     if "--variant" in sys.argv:   # timing experiments: python3 gen_olasave8k.py --variant NAME --opts a,b  -> csrc/variants/
         name = sys.argv[sys.argv.index("--variant") + 1]
         opts = [o for o in sys.argv[sys.argv.index("--opts") + 1].split(",") if o] if "--opts" in sys.argv else []
-        wrong = {"nolds", "nomem", "novalu"} & set(opts)
+        wrong = {"nolds", "nomem", "novalu", "cyclic"} & set(opts)
         if not wrong:
             for HS, MODE in VARIANTS:
                 self_test(HS, MODE, nblk=2, opts=opts, verbose=False)
