@@ -37,6 +37,7 @@
 //       nothing but the FFT exchange;
 //     * a run starts (fftlen/hop) halo blocks early to rebuild the tail from
 //       input history, so workgroups never exchange data.
+#include <type_traits>
 #include "prot_fft.h"
 #include "prot_kernels.h"
 #include "prot_dev.h"
@@ -1446,29 +1447,39 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 						u[k] = u[k] + prev[k];
 					}
 				}
+				// a block wholly inside [sw_t_begin, r1) and behind sw_dry_from -- all but the first and last of a call -- needs none of the
+				// per-frame position tests (64-bit compares and selects per lane and row: a twentieth of this launch)
+				auto test_rows = [&] (auto inner) {
+					constexpr bool I = decltype (inner)::value;
 #pragma unroll
-				for (int k = 0; k < HS; ++k) {
-					const int64_t pos0 = s + 2 * (int64_t)(t + 256 * k);
-					const f2      hp   = u[k];
-					// the same rules as the edge blocks of prot_olasave.hip: frames in front of sw_t_begin or beyond the call are not
-					// tested, the dry term is 0 while t < sw_dry_from (Q1; the raw peak takes the frame all the same).  Both frames of
-					// the pair are tested first: most rows of most blocks have no survivor in the whole wave and skip the compaction
-					const f2   dk  = Dd == Dc ? cur[k] : dry[k];
-					const bool in0 = pos0 >= p.sw_t_begin && pos0 < r1, in1 = pos0 + 1 >= p.sw_t_begin && pos0 + 1 < r1;
-					const float d0 = pos0 >= p.sw_dry_from ? dk.x : 0.f, d1 = pos0 + 1 >= p.sw_dry_from ? dk.y : 0.f;
-					sw_raw         = fmaxf (sw_raw, fmaxf (in0 ? fabsf (dk.x) : 0.f, in1 ? fabsf (dk.y) : 0.f));
-					const bool     l0 = in0 && d0 * d0 + hp.x * hp.x > sw_thr2, l1 = in1 && d1 * d1 + hp.y * hp.y > sw_thr2;
-					const uint64_t m0 = __builtin_amdgcn_ballot_w64 (l0), m1 = __builtin_amdgcn_ballot_w64 (l1);
-					if ((m0 | m1) != 0) {
-						if (l0) {
-							list[sw_cnt + __builtin_amdgcn_mbcnt_hi ((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned)m0, 0u))] = make_float2 (d0, hp.x);
+					for (int k = 0; k < HS; ++k) {
+						const int64_t pos0 = s + 2 * (int64_t)(t + 256 * k);
+						const f2      hp   = u[k];
+						// the same rules as the edge blocks of prot_olasave.hip: frames in front of sw_t_begin or beyond the call are not
+						// tested, the dry term is 0 while t < sw_dry_from (Q1; the raw peak takes the frame all the same).  Both frames of
+						// the pair are tested first: most rows of most blocks have no survivor in the whole wave and skip the compaction
+						const f2   dk  = Dd == Dc ? cur[k] : dry[k];
+						const bool in0 = I || (pos0 >= p.sw_t_begin && pos0 < r1), in1 = I || (pos0 + 1 >= p.sw_t_begin && pos0 + 1 < r1);
+						const float d0 = (I || pos0 >= p.sw_dry_from) ? dk.x : 0.f, d1 = (I || pos0 + 1 >= p.sw_dry_from) ? dk.y : 0.f;
+						sw_raw         = fmaxf (sw_raw, fmaxf (in0 ? fabsf (dk.x) : 0.f, in1 ? fabsf (dk.y) : 0.f));
+						const bool     l0 = in0 && d0 * d0 + hp.x * hp.x > sw_thr2, l1 = in1 && d1 * d1 + hp.y * hp.y > sw_thr2;
+						const uint64_t m0 = __builtin_amdgcn_ballot_w64 (l0), m1 = __builtin_amdgcn_ballot_w64 (l1);
+						if ((m0 | m1) != 0) {
+							if (l0) {
+								list[sw_cnt + __builtin_amdgcn_mbcnt_hi ((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned)m0, 0u))] = make_float2 (d0, hp.x);
+							}
+							sw_cnt += (unsigned)__builtin_popcountll (m0);
+							if (l1) {
+								list[sw_cnt + __builtin_amdgcn_mbcnt_hi ((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned)m1, 0u))] = make_float2 (d1, hp.y);
+							}
+							sw_cnt += (unsigned)__builtin_popcountll (m1);
 						}
-						sw_cnt += (unsigned)__builtin_popcountll (m0);
-						if (l1) {
-							list[sw_cnt + __builtin_amdgcn_mbcnt_hi ((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned)m1, 0u))] = make_float2 (d1, hp.y);
-						}
-						sw_cnt += (unsigned)__builtin_popcountll (m1);
 					}
+				};
+				if (full && s >= p.sw_t_begin && s >= p.sw_dry_from) {
+					test_rows (std::true_type {});
+				} else {
+					test_rows (std::false_type {});
 				}
 			}
 		} else if (it >= NP) {
