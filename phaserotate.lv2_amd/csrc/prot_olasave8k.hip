@@ -30,6 +30,63 @@ constexpr int kSv8LdsBytes = 16 * 560 * 8 + 8192; // exchange area (16 rows of 5
 
 #define PROT_SV8_CAT_(k, a, b) PROT_SV8_##k##_##a##_##b
 #define PROT_SV8_CLOB_(a) PROT_SV8_ASM_CLOBBERS_##a
+#if defined(PROT_SV8_STAMPS) && !defined(PROT_SV8_TIMELINE)
+#define PROT_SV8_TIMELINE
+#endif
+#ifdef PROT_SV8_TIMELINE
+// diagnostic builds (tools/sv8_stamps.py; -DPROT_SV8_TIMELINE alone: the per-workgroup timeline around the SHIPPED loop, nothing inside it; python3 tools/gen/gen_olasave8k.py --variant stamps --opts stamps, then
+// tools/ab_build.py sv8:stamps:-DPROT_SV8_STAMPS): the generated loop stamps the shader clock at 15 points of a block (around
+// each of its four barriers and its waits) and sums the intervals per wave in the lanes of one more operand; per-workgroup
+// entry / end times beside it.  Nothing of this exists in the shipped library.
+__device__ unsigned g_sv8_acc[2048 * 8 * 16];         // per workgroup and wave: [0] blocks, [1..14] cycles per interval (stamped loop), [15] 1
+extern "C" int prot_debug_sv8_stamps (unsigned long long* out, int n, int reset)
+{
+	// out[1..14] = cycles per interval summed over the waves of the launches since the last reset is NOT kept any more: the slots hold
+	// the LAST launch (every wave overwrites its own); out[16] = wave-blocks, out[17] = waves of that launch
+	static unsigned h[2048 * 8 * 16];
+	if (reset) {
+		for (auto& x : h) {
+			x = 0u;
+		}
+		return (int)hipMemcpyToSymbol (HIP_SYMBOL (g_sv8_acc), h, sizeof (h));
+	}
+	hipError_t e = hipMemcpyFromSymbol (h, HIP_SYMBOL (g_sv8_acc), sizeof (h));
+	unsigned long long sum[32] = {};
+	for (int i = 0; i < 2048 * 8; ++i) {
+		if (h[16 * i + 15] == 0u || h[16 * i] == 0u) {
+			continue;
+		}
+		for (int l = 1; l < 15; ++l) {
+			sum[l] += h[16 * i + l];
+		}
+		sum[16] += h[16 * i];
+		sum[17] += 1;
+	}
+	for (int i = 0; i < n && i < 32; ++i) {
+		out[i] = sum[i];
+	}
+	return (int)e;
+}
+__device__ unsigned g_sv8_prog[64 * 2048];           // "tick" variant of the loop: per workgroup, lane k = 100 MHz time at which the block with k blocks left ended
+extern "C" int prot_debug_sv8_prog (unsigned* out, int n_wg)
+{
+	return (int)hipMemcpyFromSymbol (out, HIP_SYMBOL (g_sv8_prog), sizeof (unsigned) * 64 * (n_wg < 2048 ? n_wg : 2048));
+}
+__device__ unsigned long long g_sv8_wg[4 * 2048];    // per workgroup: entry, loop start, end (s_memrealtime, 100 MHz), XCC_ID << 32 | HW_ID
+extern "C" int prot_debug_sv8_wg (unsigned long long* out, int n_wg)
+{
+	return (int)hipMemcpyFromSymbol (out, HIP_SYMBOL (g_sv8_wg), sizeof (unsigned long long) * 4 * (n_wg < 2048 ? n_wg : 2048));
+}
+#endif
+#ifdef PROT_SV8_STAMPS
+#define PROT_SV8_CALL(KIND_, HS_, AM_, in_, out_, nf_, ca_, sa_)                                                                       \
+	if (HS == HS_ && AM == AM_) {                                                                                                       \
+		asm volatile (PROT_SV8_CAT_ (KIND_, HS_, AM_)                                                                                   \
+		              : "+v"(sv8_acc)                                                                                                   \
+		              : "s"(in_), "s"(out_), "s"(nf_), "s"(lds_off), "s"(a_sv), "s"(ca_), "s"(sa_), "v"(t0)                                \
+		              : PROT_SV8_CLOB_ (HS_));                                                                                          \
+	}
+#else
 #define PROT_SV8_CALL(KIND_, HS_, AM_, in_, out_, nf_, ca_, sa_)                                                                       \
 	if (HS == HS_ && AM == AM_) {                                                                                                       \
 		asm volatile (PROT_SV8_CAT_ (KIND_, HS_, AM_)                                                                                   \
@@ -37,6 +94,7 @@ constexpr int kSv8LdsBytes = 16 * 560 * 8 + 8192; // exchange area (16 rows of 5
 		              : "s"(in_), "s"(out_), "s"(nf_), "s"(lds_off), "s"(a_sv), "s"(ca_), "s"(sa_), "v"(t0)                                \
 		              : PROT_SV8_CLOB_ (HS_));                                                                                          \
 	}
+#endif
 #define PROT_SV8_ALL(KIND_, in_, out_, nf_, ca_, sa_)                                                                                  \
 	PROT_SV8_CALL (KIND_, 8, 0, in_, out_, nf_, ca_, sa_)                                                                               \
 	PROT_SV8_CALL (KIND_, 8, 2, in_, out_, nf_, ca_, sa_)                                                                               \
@@ -75,6 +133,14 @@ __global__ __launch_bounds__ (512, 4) void olasave8k_kernel (const OlaParams p)
 
 	const int t0 = threadIdx.x;
 	const int c  = blockIdx.y;
+#ifdef PROT_SV8_TIMELINE
+	unsigned sv8_acc = 0u, sv8_blocks = 0u;
+	(void)sv8_acc;
+	if (t0 == 0 && blockIdx.y == 0 && blockIdx.x < 2048) { // (stored at once: nothing of the timeline lives across the generated code)
+		g_sv8_wg[4 * blockIdx.x]     = __builtin_amdgcn_s_memrealtime ();
+		g_sv8_wg[4 * blockIdx.x + 1] = 0ull;
+	}
+#endif
 	// MODE_SWEEP state (as in prot_olasave.hip: the bound parked per wave in global memory behind the list lengths and re-read where
 	// it is used, nothing per lane but the running maximum and nothing uniform but the count lives across the generated code)
 	__shared__ float sw_lo_s[8];
@@ -205,7 +271,15 @@ __global__ __launch_bounds__ (512, 4) void olasave8k_kernel (const OlaParams p)
 					sw_cnt = (unsigned)__builtin_amdgcn_readfirstlane ((int)(cur - sw_list ()));
 				} else {
 					float* a_out = uniform_ptr_generic (out + s);
+#ifdef PROT_SV8_TIMELINE
+					if (t0 == 0 && blockIdx.y == 0 && blockIdx.x < 2048 && sv8_blocks == 0u) {
+						g_sv8_wg[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime ();
+					}
+#endif
 					PROT_SV8_ALL (ASM, a_in, a_out, nf, ca, sa)
+#ifdef PROT_SV8_TIMELINE
+					sv8_blocks += (unsigned)nf;
+#endif
 				}
 				s += (int64_t)nf * BLK;
 				continue;
@@ -301,6 +375,25 @@ __global__ __launch_bounds__ (512, 4) void olasave8k_kernel (const OlaParams p)
 	if (t0 < 256) {
 		hist_write_slice (p, blockIdx.y, t0);
 	}
+#ifdef PROT_SV8_TIMELINE
+	// (plain stores into per-workgroup slots, summed by the host: atomics on a few shared words -- 57 K of them per launch -- took
+	// longer than the kernel's own tail and were mistaken for it at first)
+	if (blockIdx.y == 0 && blockIdx.x < 2048) {
+		const int l = t0 & 63, w8 = t0 >> 6;
+		if (l < 16) {
+			g_sv8_acc[(blockIdx.x * 8 + w8) * 16 + l] = l == 0 ? sv8_blocks : l == 15 ? 1u : sv8_acc;
+		}
+		if (t0 < 64) {
+			g_sv8_prog[64 * blockIdx.x + t0] = sv8_acc;
+		}
+		if (t0 == 0) {
+			unsigned hw, xcc;
+			asm volatile ("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+			unsigned long long* w = g_sv8_wg + 4 * blockIdx.x;
+			w[2] = __builtin_amdgcn_s_memrealtime (), w[3] = ((unsigned long long)xcc << 32) | hw;
+		}
+	}
+#endif
 	if constexpr (MODE == MODE_SWEEP) {
 		if ((t0 & 63) == 0) {
 			p.surv_cnt[((int64_t)c * gridDim.x + blockIdx.x) * 8 + (t0 >> 6)] = sw_cnt;

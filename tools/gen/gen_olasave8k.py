@@ -124,6 +124,50 @@ class Gen8k(Gen):
         self.lab += 1
         return "%s_%d" % (stem, self.lab)
 
+    STAMP_NAMES = ["(loop top)", "wait: next block's rows (vmcnt)", "(p, q) pairs + forward pass 1", "barrier 1 (last exchange read by all)",
+                   "pass-1 twiddles + exchange-1 writes + lgkmcnt(0)", "barrier 2 (exchange 1 written)",
+                   "exchange-1 reads, radix-2 fold, W32 twiddle, pass-2 stage 1 + prefetch issue", "barrier 3 (columns read; chunks free)",
+                   "pass-2 stage 2 + twiddles + wave-local exchange 2 (drained)", "forward pass 3 + constants",
+                   "inverse pass 1 + wave-local exchange 3 (drained)", "inverse pass 2 + W32 twiddle + exchange-4 writes + lgkmcnt(0)",
+                   "barrier 4 (exchange 4 written)", "exchange-4 reads, fold, inverse pass 3", "mix + stores issued + loop end"]
+
+    def stamp(self, i):
+        """opts "stamps" (diagnostic variant, tools/sv8_stamps.py): shader-clock stamp number i of the block into lane i of v121.  Text
+        the emulator does not see (P.raw): s_memtime returns through lgkmcnt, so a stamp drains the LDS queue -- the points are
+        chosen where it is empty or about to be waited for anyway; s[92:93] are free in this generator's SGPR plan"""
+        if "stamps" not in self.opts or self.kind == "core":
+            return
+        P = self.P
+        P.raw("s_memtime s[92:93]")
+        P.raw("s_waitcnt lgkmcnt(0)")
+        P.raw("v_writelane_b32 v121, s92, %d" % i)
+
+    def tick(self):
+        """opts "tick" (diagnostic variant): ONE 100 MHz stamp per block at the loop's end, into lane S_NBLK (blocks left, this one
+        included) of operand %0 -- the progress of every workgroup through its run (tools/sv8_progress.py)"""
+        if "tick" not in self.opts or self.kind == "core":
+            return
+        P = self.P
+        P.raw("s_memrealtime s[92:93]")
+        P.raw("s_waitcnt lgkmcnt(0)")
+        P.raw("s_mov_b32 s93, m0")          # (one SGPR per VOP3 on gfx9: the lane select goes through M0)
+        P.raw("s_mov_b32 m0, %r" % S_NBLK)
+        P.raw("s_nop 1")
+        P.raw("v_writelane_b32 %0, s92, m0")
+        P.raw("s_mov_b32 m0, s93")
+
+    def stamps_fold(self):
+        """at the loop's end: operand %0 (a VGPR)[i] += stamp[i] - stamp[i - 1] (lanes 1..14; low 32 bits: a block is ~25 K cycles)"""
+        if "stamps" not in self.opts or self.kind == "core":
+            return
+        P = self.P
+        t = self.TMP[0].lo     # (free here: the stores read the D registers)
+        P.raw("s_nop 1")
+        P.raw("v_mov_b32_dpp %r, v121 wave_shr:1 row_mask:0xf bank_mask:0xf" % t)
+        P.raw("s_nop 1")
+        P.raw("v_sub_u32 %r, v121, %r" % (t, t))
+        P.raw("v_add_u32 %%0, %%0, %r" % t)
+
     # ------------------------------------------------------------ helpers
     def cmul_c32(self, d, a, k, conj, r):
         """d = a * W32^k (conj: W32^-k), k = 1..15, from the pointwise constants S_C32[k] = (-sin phi, cos phi), phi = pi k / 16
@@ -459,7 +503,9 @@ class Gen8k(Gen):
         self.cmul(B[2], self.TB1, self.TB1, 1, sc[0])
         self.cmul(B[3], B[2], self.TB1, 1, sc[1])
         # the previous block's last exchange has been read by both waves that share a column: its slots may be written
+        self.stamp(2)
         P.s_barrier()
+        self.stamp(3)
         up, done = self.label("L_wu"), self.label("L_wd")
         P.settle(list(v) + sc + [B[2], B[3]])
         P.s_cmp_eq_u32(S_HI, Lit(1))
@@ -530,10 +576,13 @@ class Gen8k(Gen):
                 P.ds_read_b64(self.TB[la], self.A_TL, tw_off + 128 * (ka + 4 * la))
         bfl = [self.stage2_ops(v, ka, DIR, self.TT[0]) for ka in range(4)]
         r = self.TR[0]
+        if DIR > 0:
+            self.stamp(6)
         fetch(0)
         if DIR > 0:
             # every wave has read both halves of its columns of the first exchange: the chunks (which lie in them) may be written
             P.s_barrier()
+            self.stamp(7)
         for ka in range(4):
             self.run_ops(bfl[ka])
             for la in range(4):
@@ -600,19 +649,23 @@ class Gen8k(Gen):
         if not core:
             P.s_waitcnt(vmcnt=0)
             P.label("L_top")
+            self.stamp(0)
             n_st = 0 if self.MODE == MODE_SWEEP else HS   # (SWEEP: sweep_flush has waited for the loads; appends are not counted)
             if self.MODE == MODE_SWEEP:
                 P.s_waitcnt(lgkmcnt=0)
             else:
                 P.s_waitcnt(vmcnt=n_st, lgkmcnt=0)
             P.reset_queues(vm_stores=n_st)
+            self.stamp(1)
         P.comment("---- (p, q) pairs")
         self.build_pq()
         self.tap("pq", self.D)
         P.comment("---- forward pass 1 + exchange 1")
         self.fwd_pass1()
         P.s_waitcnt(lgkmcnt=0)
+        self.stamp(4)
         P.s_barrier()
+        self.stamp(5)
         P.comment("---- forward pass 2 (the radix-2 layer first)")
         v = self.fwd_pass2_reads()
         self.tap("p2in", self.D)
@@ -626,6 +679,7 @@ class Gen8k(Gen):
             main = self.stage1_ops(v, 1) + self.stage1_twiddle_ops(v, 1, self.scratch_pairs())
             self.run_ops(self.weave(main, lds_, max(1, len(main) // (len(lds_) + 1)) if lds_ else 1))
         self.twiddled_exchange8(v, 1, 0, self.A_X2, 8, self.A_CH, KG * 8)
+        self.stamp(8)
         P.comment("---- forward pass 3")
         v = self.D
         self.tap("p3in", self.D)
@@ -638,10 +692,12 @@ class Gen8k(Gen):
         P.comment("---- constants")
         self.pointwise(v)
         self.tap("pw", v)
+        self.stamp(9)
         P.comment("---- inverse pass 1")
         self.stage1(v, -1)
         self.run_ops(self.stage1_twiddle_ops(v, -1, self.scratch_pairs()))
         self.twiddled_exchange8(v, -1, LDS_TWI - LDS_TWF, self.A_CH, KG * 8, self.A_X2, 8)
+        self.stamp(10)
         P.comment("---- inverse pass 2, the radix-2 layer's twiddle, exchange 4")
         v = self.D
         self.tap("ip2in", self.D)
@@ -656,7 +712,9 @@ class Gen8k(Gen):
         for b in range(16):
             P.ds_write_b64(self.A_CH, u[b], 128 * b)   # into the group's own chunk: wave-local, no barrier in front
         P.s_waitcnt(lgkmcnt=0)
+        self.stamp(11)
         P.s_barrier()
+        self.stamp(12)
         # the reader's half of the inverse layer: thread T takes Y0 + sigma Y1 of its column (rows 4 al + be with al >= 1 first)
         order = [4, 8, 12, 0, 5, 9, 13, 1, 6, 10, 14, 2, 7, 11, 15, 3]
         sets = [self.TMP[:4], self.TMP[4:8] if len(self.TMP) >= 8 else []]
@@ -685,6 +743,7 @@ class Gen8k(Gen):
         P.comment("---- inverse pass 3")
         u = self.inv_pass3()
         self.tap("ip3out", u)
+        self.stamp(13)
         P.comment("---- mix and store")
         if core:
             P.s_barrier()   # every wave has read its share of the last exchange: the area takes the output rows
@@ -697,6 +756,9 @@ class Gen8k(Gen):
         for k in range(HS):
             self.epilogue_row(u, k)
         self.sweep_flush()
+        self.stamp(14)
+        self.stamps_fold()
+        self.tick()
         P.s_add_u32(S_IN.lo, S_IN.lo, Lit(self.adv))
         P.s_addc_u32(S_IN.hi, S_IN.hi, Lit(0))
         if self.MODE != MODE_SWEEP:    # (SWEEP: S_OUT is the survivor cursor, advanced by what was appended)
@@ -899,14 +961,17 @@ def emit(path, opts=()):
            "// offset of the exchange area, %4 constants table, %5 ca, %6 sa * gain, %7 thread id",
            "#pragma once", ""]
     nv = {}
+    # "stamps": one more operand IN FRONT of the others (an in/out VGPR, "+v": lane i = cycles spent in interval i, summed over the
+    # blocks), so the inputs are %1..%8 there
+    sh = 1 if ("stamps" in opts or "tick" in opts) else 0
     for kind in ("run", "core"):
         for HS, MODE in VARIANTS:
             g = Gen8k(HS, MODE, opts if kind == "run" else [o for o in opts if o in ("nolds", "novalu")], kind)
             P = g.build()
             nv[HS] = max(nv.get(HS, 0), g.n_vgpr)
-            head = ["s_mov_b64 %r, %%0" % S_IN, "s_mov_b64 %r, %%1" % S_OUT, "s_mov_b32 %r, %%2" % S_NBLK, "s_mov_b32 %r, %%3" % S_LDS,
-                    "s_mov_b64 %r, %%4" % S_SV, "s_mov_b32 %r, %%5" % S_ROT.lo, "s_mov_b32 %r, %%6" % S_ROT.hi, "v_mov_b32 %r, %%7" % g.TMP[0].lo,
-                    "s_waitcnt vmcnt(0) lgkmcnt(0)"]
+            head = ["s_mov_b64 %r, %%%d" % (S_IN, sh), "s_mov_b64 %r, %%%d" % (S_OUT, 1 + sh), "s_mov_b32 %r, %%%d" % (S_NBLK, 2 + sh),
+                    "s_mov_b32 %r, %%%d" % (S_LDS, 3 + sh), "s_mov_b64 %r, %%%d" % (S_SV, 4 + sh), "s_mov_b32 %r, %%%d" % (S_ROT.lo, 5 + sh),
+                    "s_mov_b32 %r, %%%d" % (S_ROT.hi, 6 + sh), "v_mov_b32 %r, %%%d" % (g.TMP[0].lo, 7 + sh), "s_waitcnt vmcnt(0) lgkmcnt(0)"]
             for n, (lo, hi) in sorted(g.constants().items()):
                 head.append("s_mov_b32 s%d, %r" % (n, Lit(float(lo))))
                 head.append("s_mov_b32 s%d, %r" % (n + 1, Lit(float(hi))))
@@ -925,7 +990,7 @@ def emit(path, opts=()):
     # running max |x| (out), %2 in, %3 blocks, %4 LDS byte offset, %5 constants table, %6 bound, %7 gain, %8 thread id, %9 and %10 the
     # cursor and the running maximum on entry
     for HS in SWEEP_HS:
-        g = Gen8k(HS, MODE_SWEEP, opts, "run")
+        g = Gen8k(HS, MODE_SWEEP, [o for o in opts if o not in ("stamps", "tick")], "run")
         P = g.build()
         nv[HS] = max(nv.get(HS, 0), g.n_vgpr)
         head = ["s_mov_b64 %r, %%2" % S_IN, "s_mov_b64 %r, %%9" % S_OUT, "s_mov_b32 %r, %%3" % S_NBLK, "s_mov_b32 %r, %%4" % S_LDS,
@@ -947,6 +1012,8 @@ def emit(path, opts=()):
         out.append("")
     for HS in sorted(nv):
         clob = ['"memory"', '"vcc"', '"scc"'] + ['"s%d"' % i for i in SGPR_CLOBBER] + ['"v%d"' % i for i in range(0, nv[HS])]
+        if "stamps" in opts:
+            clob += ['"v121"']
         out.append("#define PROT_SV8_ASM_CLOBBERS_%d " % HS + ", ".join(clob))
         if HS in SWEEP_HS:
             out.append("#define PROT_SV8_SWEEP_CLOBBERS_%d PROT_SV8_ASM_CLOBBERS_%d, \"v120\"" % (HS, HS))
