@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define PROT_ABI_VERSION 5
+#define PROT_ABI_VERSION 6
 #define PROT_SUBSAMPLE 2                      /* cli/phase-rotate.cc:38 */
 #define PROT_MAXSAMPLE (180 * PROT_SUBSAMPLE) /* cli/phase-rotate.cc:39 */
 
@@ -83,6 +83,11 @@ typedef struct {
  * for cross-checks and timing comparisons.  CLI engines always use ONE block size (sharded sweeps are bit-identical
  * whatever the shard sizes because of it). */
 #define PROT_CFG_BLOCK4096 32u
+/* Engines on 8192-point blocks: keep the STATIC run plan (every resident workgroup a run of consecutive blocks, lengths by
+ * dispatch rank) for long launches, instead of letting the workgroups claim their blocks one at a time as they go
+ * (olasave8k_dyn_kernel).  The same blocks through the same generated arithmetic: results equal bit for bit; for cross-checks
+ * and timing comparisons. */
+#define PROT_CFG_STATIC_RUNS 64u
 
 typedef struct {
 	int32_t  kind;

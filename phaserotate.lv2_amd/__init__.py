@@ -29,6 +29,7 @@ CFG_POLYPHASE = 4
 CFG_OVERLAP_ADD = 8
 CFG_PIPELINE = 16
 CFG_BLOCK4096 = 32
+CFG_STATIC_RUNS = 64
 FORM_DIRECT, FORM_POLY_OLA, FORM_POLY_SAVE, FORM_POLY_SAVE8K = 0, 1, 2, 3
 
 # every symbol include/prot_hip.h declares (tests check the .so exports them all)

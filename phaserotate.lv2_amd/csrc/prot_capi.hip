@@ -402,10 +402,16 @@ struct prot_engine {
 	int            sv8_rows  = 0;     // new rows per 8192-point block (12 or 13)
 	float          sv8_gain  = 0.f;
 	DevBuf<float>  d_sv8;
+	// dynamic blocks (olasave8k_dyn_kernel): kDynSets counter records per channel, one set per launch in turn (a launch leaves its
+	// set zeroed; the turn keeps launches that overlap on different streams of the caller's apart)
+	DevBuf<uint32_t> d_dyn;
+	unsigned         dyn_seq = 0;
+	bool             dyn_off = false; // PROT_CFG_STATIC_RUNS
 	DevBuf<float>  d_sv;
 	float          sv_gain = 0.f;
 	int            sv_rows = 0;
 	int            sv_flags = 0; // 1 (PROT_SV_NOASM at creation, tests): every block through the C++ form of olasave_kernel
+	static constexpr int kDynSets = 8;
 	static constexpr int kPipe = 3, kHist = kPipe + 1; // pipelined launches in flight; history ring (one more)
 	DevBuf<float>  d_lut, d_rot, d_hist[kHist], d_peaks, d_in, d_out, d_u, d_inter, d_rot_s;
 	// whole-file calls: two sets of staging buffers, a copy stream and events, so that chunk k+1 is uploaded and
@@ -465,7 +471,12 @@ struct prot_engine {
 	bool           pipeline   = false;
 	hipStream_t    pipe_stream[kPipe] = {};
 	hipEvent_t     pipe_ev[kPipe + 1] = {};
-	hipStream_t    last_stream = nullptr; // the stream of the last call that launched work (prot_engine_reset waits for it)
+	// The last call's stream is NOT kept (a caller's stream need not outlive its call): a call on a caller's stream ends
+	// by recording ev_last on it; whoever must come behind that call -- prot_engine_reset, a call on another stream -- waits for the
+	// event on the device.  last_stream_id is compared, never used.
+	hipEvent_t     ev_last        = nullptr;
+	bool           last_foreign   = false;
+	const void*    last_stream_id = nullptr;
 	hipEvent_t     ev_reset    = nullptr;
 	hipStream_t    reset_stream  = nullptr; // where the last prot_engine_reset put its zeroing, behind ev_reset ...
 	bool           reset_pending = false;   // ... until a call has taken a stream (pick_stream orders a DIFFERENT stream behind it)
@@ -818,6 +829,28 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 					return st > 0 ? PROT_OK : -st;
 				}
 			}
+			// Dynamic blocks (round 5): when the stream is long enough for every resident workgroup to transform several blocks, the
+			// whole in-range blocks are CLAIMED one at a time instead of dealt out as runs (prot_olasave8k.hip: the static plan leaves
+			// the CUs half empty for the last fifth of a launch).  Block b covers output frames [b BLK, (b + 1) BLK) and reads input
+			// frames a0 - 1 ... a0 + 16383, a0 = b BLK - off: whole and in range for lo <= b < hi.
+			if (!fs && !e->dyn_off && p.rot_s == nullptr && !(e->sv_flags & 1) && e->d_dyn.p != nullptr &&
+			    ((reinterpret_cast<uintptr_t> (p.in) | reinterpret_cast<uintptr_t> (p.out)) & 7) == 0 && ((in_stride | out_stride) & 1) == 0) {
+				const int64_t nt = 16 - e->sv8_rows, off = (int64_t)p.dry_delay + 1024 * (nt / 2) + ((nt & 1) ? 512 : 0);
+				const int64_t lo = (1 + off + blk8 - 1) / blk8;
+				const int64_t hi = std::min<int64_t> ((int64_t)n_out / blk8, (int64_t)n_in - 16384 + off >= 0 ? ((int64_t)n_in - 16384 + off) / blk8 + 1 : 0);
+				const int     gx = std::max (1, slots8 / std::max (1, n_chn));
+				if (hi - lo >= 2 * (int64_t)gx && hi - lo < ((int64_t)1 << 30) && ((int64_t)n_out + blk8 - 1) / blk8 - (hi - lo) <= 64) {
+					p.dyn_ctr = e->d_dyn.p + (size_t)(e->dyn_seq++ % prot_engine::kDynSets) * e->info.n_chn * prot::kDynWords + (size_t)chn0 * prot::kDynWords;
+					p.dyn_lo  = lo;
+					p.dyn_nb  = hi - lo;
+					p.rank_cu = 0;
+					hipError_t err = prot::launch_ola_save8k_dyn (p, e->sv8_rows, n_chn, gx, s);
+					if (err != hipSuccess) {
+						return hip_fail (err, "overlap-save (8192-point, dynamic blocks) ola kernel launch");
+					}
+					return finish ();
+				}
+			}
 			hipError_t err = prot::launch_ola_save8k (p, e->sv8_rows, n_chn, s);
 			if (err != hipSuccess) {
 				return hip_fail (err, "overlap-save (8192-point) ola kernel launch");
@@ -1012,6 +1045,11 @@ int join_pipe (prot_engine* e, hipStream_t s)
 // and waits for it; the next run() of its engine starts it again.
 std::mutex   g_srv_mu;
 prot_engine* g_srv_owner = nullptr;
+// Calls that allocate, free or synchronise the whole device (create, destroy, reserve, reset, sync) HOLD the server off for
+// their whole duration: stopping it once is not enough when another thread's run() -- an audio thread calling every few
+// milliseconds -- may start it again while hipMalloc / hipFree / hipDeviceSynchronize are still waiting for a device without a
+// resident kernel.  run() takes the launch route while the count is non-zero.
+int g_srv_hold = 0;
 
 int server_stop_locked ()
 {
@@ -1036,6 +1074,21 @@ int server_stop_any ()
 	std::lock_guard<std::mutex> lk (g_srv_mu);
 	return server_stop_locked ();
 }
+struct ServerHold {
+	ServerHold ()
+	{
+		std::lock_guard<std::mutex> lk (g_srv_mu);
+		++g_srv_hold;
+		(void)server_stop_locked ();
+	}
+	~ServerHold ()
+	{
+		std::lock_guard<std::mutex> lk (g_srv_mu);
+		--g_srv_hold;
+	}
+	ServerHold (const ServerHold&)            = delete;
+	ServerHold& operator= (const ServerHold&) = delete;
+};
 // (g_srv_mu held) start e's server behind whatever the engine's own stream still has to do
 int server_start_locked (prot_engine* e)
 {
@@ -1068,17 +1121,40 @@ hipStream_t pick_stream (prot_engine* e, void* stream, bool keep_server = false)
 	}
 	hipStream_t s = stream ? (hipStream_t)stream : e->stream;
 	(void)join_pipe (e, s);
+	if (e->last_foreign && (const void*)s != e->last_stream_id) {
+		// the call before this one ran on a stream of the caller's: this one reads the state it left (history, tables)
+		(void)hipStreamWaitEvent (s, e->ev_last, 0);
+	}
 	if (e->reset_pending) {
-		// prot_engine_reset does not block the host (round 4, last day): its zeroing sits on the stream of the call before it; a
-		// call that arrives on another stream is put behind it here
+		// prot_engine_reset behind a call on a caller's stream does not block the host: its zeroing sits on the engine's stream behind
+		// that call's event; a call that arrives on another stream is put behind it here
 		if (s != e->reset_stream) {
 			(void)hipStreamWaitEvent (s, e->ev_reset, 0);
 		}
 		e->reset_pending = false;
 	}
-	e->last_stream = s;
 	return s;
 }
+
+// the stream of one API call: picked at its start, and at its end -- when it is the caller's -- marked with ev_last
+struct CallStream {
+	prot_engine* e;
+	hipStream_t  s;
+	CallStream (prot_engine* e_, void* stream, bool keep_server = false) : e (e_), s (pick_stream (e_, stream, keep_server)) {}
+	~CallStream ()
+	{
+		if (s != e->stream && e->ev_last != nullptr && hipEventRecord (e->ev_last, s) == hipSuccess) {
+			e->last_foreign   = true;
+			e->last_stream_id = (const void*)s;
+		} else {
+			e->last_foreign   = false;
+			e->last_stream_id = nullptr;
+		}
+	}
+	CallStream (const CallStream&)            = delete;
+	CallStream& operator= (const CallStream&) = delete;
+	operator hipStream_t () const { return s; }
+};
 
 // the engine's own stream AND a reset that went to a caller's stream: what the readers of device state wait for
 hipError_t sync_own (prot_engine* e)
@@ -1154,7 +1230,7 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 		return nullptr;
 	}
 	std::call_once (g_lut_once, lut_init);
-	(void)server_stop_any (); // (engine creation allocates, uploads and synchronises: nothing resident meanwhile)
+	ServerHold srv_hold; // (engine creation allocates, uploads and synchronises: nothing resident until it returns)
 
 	prot_info inf {};
 	inf.kind  = cfg->kind;
@@ -1330,6 +1406,7 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	};
 
 	(void)hipEventCreateWithFlags (&e->ev_reset, hipEventDisableTiming);
+	(void)hipEventCreateWithFlags (&e->ev_last, hipEventDisableTiming);
 	if (hipStreamCreateWithFlags (&e->stream, hipStreamNonBlocking) != hipSuccess) {
 		return fail (PROT_EHIP);
 	}
@@ -1479,9 +1556,13 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	    (rc = e->d_hist[1].ensure (hn)) || (rc = e->d_peaks.ensure ((size_t)PROT_MAXSAMPLE * inf.n_chn)) ||
 	    (rc = e->d_angles.ensure (PROT_MAXSAMPLE + 8)) || (rc = e->d_thr.ensure (prot::kSweepThrFloats * (size_t)inf.n_chn)) || (rc = e->d_ctr.ensure ((size_t)inf.n_chn * 32 * 32)) ||
 	    (rc = e->d_stats.ensure (4)) || (e->use_save && (rc = e->d_sv.ensure (sv_h.size ()))) ||
-	    (e->use_save8 && (rc = e->d_sv8.ensure (sv8_h.size ())))) {
+	    (e->use_save8 && ((rc = e->d_sv8.ensure (sv8_h.size ())) || (rc = e->d_dyn.ensure ((size_t)prot_engine::kDynSets * inf.n_chn * prot::kDynWords))))) {
 		return fail (rc);
 	}
+	if (e->use_save8 && hipMemset (e->d_dyn.p, 0, (size_t)prot_engine::kDynSets * inf.n_chn * prot::kDynWords * sizeof (uint32_t)) != hipSuccess) {
+		return fail (PROT_EHIP);
+	}
+	e->dyn_off = (cfg->flags & PROT_CFG_STATIC_RUNS) != 0 || tuning_env ("PROT_STATIC") != nullptr;
 	if (e->use_save8 && hipMemcpy (e->d_sv8.p, sv8_h.data (), sv8_h.size () * sizeof (float), hipMemcpyHostToDevice) != hipSuccess) {
 		return fail (PROT_EHIP);
 	}
@@ -1547,7 +1628,7 @@ void prot_engine_destroy (prot_engine* e)
 		return;
 	}
 	(void)hipSetDevice (e->device);
-	(void)server_stop_any (); // (whoever's it is: hipFree waits for the whole device)
+	ServerHold srv_hold; // (whoever's it is: hipFree waits for the whole device)
 	if (e->srv_stream) {
 		(void)hipStreamSynchronize (e->srv_stream);
 		(void)hipStreamDestroy (e->srv_stream);
@@ -1577,6 +1658,7 @@ void prot_engine_destroy (prot_engine* e)
 	e->d_H.release ();
 	e->d_sv.release ();
 	e->d_sv8.release ();
+	e->d_dyn.release ();
 	e->d_surv.release ();
 	e->d_surv_cnt.release ();
 	e->d_nsteps.release ();
@@ -1638,6 +1720,11 @@ void prot_engine_destroy (prot_engine* e)
 	if (e->stream) {
 		(void)hipStreamDestroy (e->stream);
 	}
+	if (e->ev_last) {
+		(void)hipEventSynchronize (e->ev_last);
+		(void)hipEventDestroy (e->ev_last);
+		e->ev_last = nullptr;
+	}
 	if (e->ev_reset) {
 		(void)hipEventDestroy (e->ev_reset);
 	}
@@ -1656,13 +1743,17 @@ int prot_engine_reset (prot_engine* e)
 		return PROT_EINVAL;
 	}
 	HIP_TRY (hipSetDevice (e->device));
-	(void)server_stop_any ();
-	// Behind a call on a caller's stream: stream-ordered, and no host wait (until the last day of round 4 the zeroing went to the engine's own stream behind an event
-	// of the last call's stream, and the host waited for it: a sweep pass per reset -- the bench's loop, a host that analyses file
-	// after file -- paid a blocking wait per pass, 0.05-0.25 ms by the state of the runtime's queues; tools/process_state_probe.py).
-	// The zeroing goes to the stream of the engine's last call -- behind the kernels that read what it zeroes --; pick_stream puts
-	// a call that arrives on another stream behind ev_reset, the readers of device state wait for it (sync_own).
-	hipStream_t zs = (e->last_stream != nullptr && e->ev_reset != nullptr) ? e->last_stream : e->stream;
+	ServerHold srv_hold;
+	// Behind a call on a caller's stream: stream-ordered, and no host wait (a host that analyses file after file, the bench's loop:
+	// a blocking wait per pass costs 0.05-0.25 ms by the state of the runtime's queues; tools/process_state_probe.py).  The zeroing
+	// goes to the ENGINE's stream behind the event the last call left on its own (the caller's stream handle is not kept: ADVICE r4);
+	// pick_stream puts a call that arrives on another stream behind ev_reset, the readers of device state wait for the engine's
+	// stream (sync_own).
+	const bool  foreign = e->last_foreign && e->ev_reset != nullptr;
+	hipStream_t zs      = e->stream;
+	if (e->last_foreign) {
+		HIP_TRY (hipStreamWaitEvent (zs, e->ev_last, 0));
+	}
 	(void)join_pipe (e, zs);
 	int rc = zero_state (e, zs);
 	if (rc) {
@@ -1671,16 +1762,18 @@ int prot_engine_reset (prot_engine* e)
 	for (auto& c : e->lv2) { // channel_reset: offset = 0, buf_out = 0 (angle state kept, Q10)
 		c.offset = 0;
 	}
-	if (e->ev_reset != nullptr && zs != e->stream) {
+	if (foreign) {
 		HIP_TRY (hipEventRecord (e->ev_reset, zs));
 		e->reset_stream  = zs;
 		e->reset_pending = true;
 	} else {
-		// the engine's own stream (stream = NULL in the last call): the caller has no way to order anything of its own against it
+		// behind a call on the engine's own stream (stream = NULL): the caller has no way to order anything of its own against it
 		// but the host -- a table of the caller's zeroed between reset and the next call, say -- so the reset still ends with the wait
 		HIP_TRY (hipStreamSynchronize (zs));
 		e->reset_pending = false;
 	}
+	e->last_foreign   = false; // (whatever comes next is ordered behind the engine's stream, which is behind that call)
+	e->last_stream_id = nullptr;
 	return PROT_OK;
 }
 
@@ -1708,7 +1801,7 @@ int prot_engine_sync (prot_engine* e)
 		return PROT_EINVAL;
 	}
 	HIP_TRY (hipSetDevice (e->device));
-	(void)server_stop_any ();
+	ServerHold srv_hold;
 	(void)join_pipe (e, e->stream);
 	HIP_TRY (sync_own (e));
 	if (e->pipe_used && e->d_pipe.p) {
@@ -1749,6 +1842,17 @@ int prot_apply_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 	    ((int64_t)n_out + e->info.run_align - 1) / (int64_t)e->info.run_align * nc <= e->wg_slots / (2 * prot_engine::kPipe)) {
 		hipStream_t ps = e->pipe_stream[e->pipe_q % prot_engine::kPipe];
 		uint32_t    wp[2];
+		if (e->last_foreign) { // (this route bypasses pick_stream -- a call on a caller's stream, and a reset's zeroing behind it)
+			HIP_TRY (hipStreamWaitEvent (e->stream, e->ev_last, 0));
+			e->last_foreign   = false;
+			e->last_stream_id = nullptr;
+		}
+		if (e->reset_pending) {
+			if (e->reset_stream != e->stream) {
+				HIP_TRY (hipStreamWaitEvent (e->stream, e->ev_reset, 0));
+			}
+			e->reset_pending = false;
+		}
 		if (!e->pipe_dirty) { // first of a series: behind whatever the engine's stream holds; its history came by stream order
 			HIP_TRY (hipEventRecord (e->pipe_ev[prot_engine::kPipe], e->stream));
 			for (int i = 1; i < prot_engine::kPipe; ++i) {
@@ -1775,7 +1879,7 @@ int prot_apply_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		}
 		return rc;
 	}
-	hipStream_t s = pick_stream (e, stream);
+	CallStream s (e, stream);
 	if (rot && !inl) {
 		int rcs = stage_small (e, e->d_rot.p, rot, 2 * (size_t)nc * sizeof (float), s);
 		if (rcs) {
@@ -1805,7 +1909,7 @@ int prot_apply_dev_ramp (prot_engine* e, const float* d_in, int64_t in_stride, u
 		return PROT_EINVAL;
 	}
 	HIP_TRY (hipSetDevice (e->device));
-	hipStream_t s         = pick_stream (e, stream);
+	CallStream  s (e, stream);
 	const int   nc        = (int)e->info.n_chn;
 	const bool  stateless = flags & PROT_F_STATELESS;
 	int rc = ola_launch (e, d_in, in_stride, n_in, d_out, out_stride, n_out, nullptr, d_rot, false, stateless, 0, nc, s,
@@ -1849,7 +1953,7 @@ static int apply_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint6
 		return PROT_EINVAL;
 	}
 	HIP_TRY (hipSetDevice (e->device));
-	hipStream_t s  = pick_stream (e, stream);
+	CallStream  s (e, stream);
 	const int   nc = (int)e->info.n_chn;
 	const bool inl = rot && nc <= prot::kRotInline;
 	if (rot && !inl) {
@@ -1962,7 +2066,7 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 	                       ((e->info.partitions >= 4 && e->hopseg == 16) || (e->info.partitions == 1 && e->hopseg == 28));
 	const bool fusable = ((e->use_save && (e->hopseg == 16 || e->hopseg == 24) && !(e->sv_flags & 1)) || fuse_poly || (e->sv8_always && !(e->sv_flags & 1))) &&
 	                     !g_test_opt[PROT_TEST_SWEEP_UNPRUNED].load () && !g_test_opt[PROT_TEST_SWEEP_UNFUSED].load ();
-	hipStream_t s   = pick_stream (e, stream);
+	CallStream  s (e, stream);
 	const int   c0  = chn < 0 ? 0 : chn;                       // cli/phase-rotate.cc:434-435
 	const int   nc  = chn < 0 ? (int)e->info.n_chn : 1;
 	float*      pk  = d_peaks ? d_peaks : e->d_peaks.p;
@@ -2329,7 +2433,7 @@ int prot_lv2_set_max_block (prot_engine* e, uint32_t frames)
 		return PROT_EINVAL;
 	}
 	HIP_TRY (hipSetDevice (e->device));
-	(void)server_stop_any ();
+	ServerHold srv_hold;
 	(void)join_pipe (e, e->stream);
 	HIP_TRY (sync_own (e));
 	return lv2_reserve (e, frames);
@@ -2344,7 +2448,7 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 	const size_t   n  = n_samples;
 	// (another engine's run() server stays: this call is itself a run(); this engine's own is stopped below if the call
 	// does not go through it)
-	hipStream_t    s  = pick_stream (e, nullptr, /*keep_server*/ true);
+	CallStream    s (e, nullptr, /*keep_server*/ true);
 
 	int rc;
 	// Zero-copy (default): the kernels read the input, the per-frame rotation and write the output
@@ -2438,7 +2542,7 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 	bool served = false;
 	if (!staged && e->srv_eligible && g_test_opt[PROT_TEST_LV2_NO_SERVER].load () == 0) {
 		std::lock_guard<std::mutex> lk (g_srv_mu);
-		if (g_srv_owner == nullptr || g_srv_owner == e) {
+		if (g_srv_hold == 0 && (g_srv_owner == nullptr || g_srv_owner == e)) {
 			prot::SvServerBox* b = reinterpret_cast<prot::SvServerBox*> (e->srv_box);
 			prot::SvServerAck* a = e->srv_ack.p;
 			// the host -> device half of the mailbox is STORED into, never read (through the BAR a CPU load is microseconds): the
@@ -2508,6 +2612,10 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 						if (std::chrono::steady_clock::now () - t_0 > std::chrono::seconds (2)) {
 							snprintf (g_err, sizeof (g_err), "run() server: call %u not served within 2 s (stages %u %u, done %u %u, alive %u)", seq, a->pad0[0],
 							          a->pad0[1], a->done[0], a->done[1], a->alive);
+							// (the engine's state as it was before the call, and no further call of this engine goes to a server that
+							// does not answer: the launch route from here on -- ADVICE r4)
+							e->hist_cur     = hist_before;
+							e->srv_eligible = false;
 							return PROT_EHIP;
 						}
 					}
@@ -2628,7 +2736,7 @@ int prot_cli_apply (prot_engine* e, float* buf, const int* angles)
 	HIP_TRY (hipSetDevice (e->device));
 	const uint32_t nc = e->info.n_chn;
 	const size_t   P  = e->info.blksiz;
-	hipStream_t    s  = pick_stream (e, nullptr);
+	CallStream    s (e, nullptr);
 	int rc;
 	if ((rc = e->d_inter.ensure (P * nc)) || (rc = e->d_in.ensure (P * nc)) || (rc = e->d_out.ensure (P * nc))) {
 		return rc;
@@ -2666,7 +2774,7 @@ int prot_cli_analyze (prot_engine* e, const float* buf, int ang_start, int ang_e
 	HIP_TRY (hipSetDevice (e->device));
 	const uint32_t nc = e->info.n_chn;
 	const size_t   P  = e->info.blksiz;
-	hipStream_t    s  = pick_stream (e, nullptr);
+	CallStream    s (e, nullptr);
 	int rc;
 	if ((rc = e->d_inter.ensure (P * nc)) || (rc = e->d_in.ensure (P * nc))) {
 		return rc;
@@ -2694,7 +2802,7 @@ int prot_cli_analyze_file (prot_engine* e, const float* data, uint64_t n_frames,
 	HIP_TRY (hipSetDevice (e->device));
 	const uint32_t nc = e->info.n_chn;
 	const uint64_t P  = e->info.blksiz;
-	hipStream_t    s  = pick_stream (e, nullptr);
+	CallStream    s (e, nullptr);
 	(void)P;
 	if (e->file_resident && n_frames > 0) {
 		size_t free_b = 0, total_b = 0;
@@ -2776,7 +2884,7 @@ static int analyze_range_impl (prot_engine* e, const float* data, uint64_t f0, u
 {
 	HIP_TRY (hipSetDevice (e->device));
 	const uint32_t nc = e->info.n_chn;
-	hipStream_t    s  = pick_stream (e, nullptr);
+	CallStream    s (e, nullptr);
 	const uint64_t chunk = file_chunk_frames (e);
 	const uint64_t H     = e->info.history;
 	const uint64_t cap   = std::max<uint64_t> (std::min<uint64_t> (chunk, std::max<uint64_t> (nf, 1)), H);
@@ -3002,7 +3110,7 @@ int prot_cli_apply_file (prot_engine* e, const float* data, uint64_t n_frames, c
 	const uint32_t nc  = e->info.n_chn;
 	const uint64_t P   = e->info.blksiz;
 	const uint64_t lat = P / 2; // cli/phase-rotate.cc:963
-	hipStream_t    s   = pick_stream (e, nullptr);
+	CallStream    s (e, nullptr);
 	const uint64_t chunk = file_chunk_frames (e);
 	const uint64_t cap   = std::min<uint64_t> (chunk, n_frames) + lat;
 	int rc;

@@ -78,12 +78,23 @@ struct OlaParamsT {
 	int64_t       sw_t_begin;
 	int64_t       sw_dry_from;
 	int32_t       run_stride; // > 0: workgroup g's run starts at frame g * run_stride (instead of g * run_frames)
+	// olasave8k_dyn_kernel (round 5): the channel's whole in-range blocks [dyn_lo, dyn_lo + dyn_nb) are not dealt out as runs but
+	// CLAIMED one at a time by the resident workgroups (eight contiguous regions, one per XCD, each behind a counter of its own;
+	// a workgroup draws from its XCD's region first and moves on when it is empty); the blocks in front of and behind them -- history,
+	// silence, a partial last block -- are staged through LDS by the first workgroups as before.  dyn_ctr: channel c's record at
+	// dyn_ctr + c * kDynWords -- counters at words 0, 32, ... 224 (128 bytes apart), the exit count at word 256; all zero at launch,
+	// left zero by the last workgroup to leave.
+	uint32_t*     dyn_ctr;
+	int64_t       dyn_lo, dyn_nb;
 };
+constexpr int kDynWords = 512; // per channel: 2 KiB
 typedef OlaParamsT<float>    OlaParams;
 typedef OlaParamsT<_Float16> OlaParamsH; // fp16 sample path (BASELINE config 5)
 
 // fftlen 4096; hop = 256 * hopseg, hopseg in {4, 8}
 hipError_t launch_ola4096 (const OlaParams& p, int hopseg, int n_chn, hipStream_t s);
+// 8192-point overlap-save blocks claimed dynamically (prot_olasave8k.hip); grid_x resident workgroups per channel
+hipError_t launch_ola_save8k_dyn (const OlaParams& p, int hop_rows, int n_chn, int grid_x, hipStream_t s);
 
 // two 2048-tap FIR partitions sharing one forward transform (frequency-domain delay line);
 // p.H = [2][4096] spectra, p.conv_delay = delay of partition 0, (dry_delay - conv_delay)/256 in {6, 8},

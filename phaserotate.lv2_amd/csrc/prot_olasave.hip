@@ -580,6 +580,11 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 // every device-wide synchronisation of the process, so it never outlives the stream of calls it serves; `alive` is its last
 // store.  The host treats a server that has left as absent and starts a new one (with the last served call's number).
 constexpr uint64_t kServerIdleTicks = 25000000ull;
+// ... and it never stays longer than this, calls or no calls: between two calls it leaves when it has been resident for
+// 0.25 s, and the next run() starts a new one (130-330 us, once) -- so that a hipFree or a device-wide synchronisation of ANY
+// code in the process, which the library cannot see and cannot stop the server for, completes within a quarter of a second even
+// under continuous audio.
+constexpr uint64_t kServerLifeTicks = 25000000ull;
 
 template <int HS>
 __global__ __launch_bounds__ (256, 1) void olasave_server_kernel (const SvServerBox* const box, SvServerAck* const ack, unsigned* const relay,
@@ -610,6 +615,7 @@ __global__ __launch_bounds__ (256, 1) void olasave_server_kernel (const SvServer
 		}
 	};
 	stage (1u);
+	const uint64_t t_born = __builtin_amdgcn_s_memrealtime ();
 	for (;;) {
 		// (the thread id made opaque at each use, the decision made wave-uniform by readfirstlane: with `tid == 0` guarding both
 		// the end of one pass -- the done word -- and the start of the next -- the poll --, the compiler rotated the loop into
@@ -631,7 +637,8 @@ __global__ __launch_bounds__ (256, 1) void olasave_server_kernel (const SvServer
 						frames = (unsigned)(bell >> 32) & 0x7fffffffu;
 						break;
 					}
-					if (__builtin_amdgcn_s_memrealtime () - t_0 > kServerIdleTicks) {
+					const uint64_t now = __builtin_amdgcn_s_memrealtime ();
+					if (now - t_0 > kServerIdleTicks || now - t_born > kServerLifeTicks) {
 						cmd = 1u;
 						break;
 					}

@@ -381,7 +381,7 @@ __global__ __launch_bounds__ (512, 4) void olasave8k_kernel (const OlaParams p)
 	if (blockIdx.y == 0 && blockIdx.x < 2048) {
 		const int l = t0 & 63, w8 = t0 >> 6;
 		if (l < 16) {
-			g_sv8_acc[(blockIdx.x * 8 + w8) * 16 + l] = l == 0 ? sv8_blocks : l == 15 ? 1u : sv8_acc;
+			g_sv8_acc[(blockIdx.x * 8 + w8) * 16 + l] = l == 15 ? 1u : l == 0 && sv8_acc == 0u ? sv8_blocks : sv8_acc; // (lane 0: the stamped loop counts its blocks)
 		}
 		if (t0 < 64) {
 			g_sv8_prog[64 * blockIdx.x + t0] = sv8_acc;
@@ -407,6 +407,266 @@ __global__ __launch_bounds__ (512, 4) void olasave8k_kernel (const OlaParams p)
 				}
 			}
 		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------- dynamic blocks (round 5)
+// The static run plan leaves the CUs half empty for the last fifth of a launch: while both workgroups of a CU are resident the
+// one dispatched first takes 7.5 us per block and the other 17.4 (the hardware serves the oldest wave first), the first ends its
+// run at 198 us and the second works on alone until 252 (tools/sv8_progress.py, profiles/r05_sv8_progress_static.json) -- 40
+// blocks/us over the launch against 48.5 in its steady state, whatever the run lengths.  Here a workgroup CLAIMS its next block
+// when it needs it: tools/gen/gen_olasave8k.py, Gen8kDyn (the claim protocol, the mailbox, why a scalar atomic).
+#define PROT_SV8_DYN_CAT_(a, b) PROT_SV8_DYN_##a##_##b
+#ifdef PROT_SV8_STAMPS
+#define PROT_SV8_DYN_OUT_ "+v"(sv8_acc)
+#else
+#define PROT_SV8_DYN_OUT_
+#endif
+#define PROT_SV8_DYN_CALL(HS_, AM_)                                                                                                     \
+	if (HS == HS_ && AM == AM_) {                                                                                                       \
+		asm volatile (PROT_SV8_DYN_CAT_ (HS_, AM_)                                                                                      \
+		              : PROT_SV8_DYN_OUT_                                                                                               \
+		              : "s"(a_in), "s"(a_out), "s"(first), "s"(lds_off), "s"(a_sv), "s"(ca), "s"(sa), "v"(t0), "s"(a_ctr), "s"(xr), "s"(tries),  \
+		                "s"(per), "s"(nb)                                                                                               \
+		              : PROT_SV8_CLOB_ (HS_));                                                                                          \
+	}
+
+template <int HS, int MODE>
+__global__ __launch_bounds__ (512, 4) void olasave8k_dyn_kernel (const OlaParams p)
+{
+	constexpr int BLK = 1024 * HS;
+	constexpr int NT  = 16 - HS;
+	constexpr int R0  = NT / 2;
+	constexpr int ROT = (NT & 1) ? 256 : 0;
+	constexpr int AM  = MODE == MODE_ROT ? 0 : 2;
+	static_assert (MODE == MODE_ROT || MODE == MODE_HILBERT, "steady rotation or the Hilbert branch alone");
+
+	extern __shared__ f2 smem8[];
+	__shared__ int       sh_claim[4];
+	const int            t0 = threadIdx.x;
+	const int            c  = blockIdx.y;
+#ifdef PROT_SV8_TIMELINE
+	unsigned sv8_acc = 0u;
+	(void)sv8_acc;
+	if (t0 == 0 && blockIdx.y == 0 && blockIdx.x < 2048) {
+		g_sv8_wg[4 * blockIdx.x]     = __builtin_amdgcn_s_memrealtime ();
+		g_sv8_wg[4 * blockIdx.x + 1] = 0ull;
+	}
+#endif
+	const float* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
+	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
+	float* __restrict__ out        = p.out + (int64_t)c * p.out_stride;
+	const int64_t n_in = p.n_in;
+	const int     Dd   = p.dry_delay;
+	const bool in_al8  = (reinterpret_cast<uintptr_t> (in) & 7) == 0;
+	const bool out_al8 = (reinterpret_cast<uintptr_t> (out) & 7) == 0;
+	float ca = 0.f, sa = p.sv_gain;
+	if (MODE == MODE_ROT) {
+		ca = p.rot ? p.rot[2 * c] : p.rot_v[2 * c];
+		sa = (p.rot ? p.rot[2 * c + 1] : p.rot_v[2 * c + 1]) * p.sv_gain;
+	}
+	ca = __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (ca)));
+	sa = __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (sa)));
+	const unsigned lds_off = (unsigned)(uintptr_t)(__attribute__ ((address_space (3))) f2*)smem8;
+	const float*   a_sv    = uniform_ptr_generic (p.sv);
+	const bool hist_al8 = hist != nullptr && (reinterpret_cast<uintptr_t> (hist) & 7) == 0 && (p.hist_len & 1) == 0;
+	auto half_pair = [&] (int64_t ar, int t) -> f2 {
+		if (in_al8 && ar >= 0 && ar + 512 <= n_in) {
+			return reinterpret_cast<const f2*> (in + ar)[t];
+		}
+		if (hist_al8 && ar + 512 <= 0 && ar + p.hist_len >= 0) {
+			return reinterpret_cast<const f2*> (hist + (ar + p.hist_len))[t];
+		}
+		const int64_t a = ar + 2 * (int64_t)t;
+		return mkf2 (ldv (in, n_in, hist, p.hist_len, a), ldv (in, n_in, hist, p.hist_len, a + 1));
+	};
+
+	// ---- the blocks in front of and behind the claimed range: staged through LDS exactly as olasave8k_kernel stages them (the
+	// same generated CORE on the same values), one per workgroup
+	// (the 64-bit division is done in vector registers: its result is made wave-uniform again, or it lives -- and spills -- per lane)
+	const uint64_t n_blocks_v = (uint64_t)(p.n_out + BLK - 1) / (uint64_t)BLK;
+	const int64_t  n_blocks   = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane ((int)(n_blocks_v >> 32)) << 32) |
+	                                      (uint32_t)__builtin_amdgcn_readfirstlane ((int)(uint32_t)n_blocks_v));
+	const int n_edge = (int)(n_blocks - p.dyn_nb); // (a handful: the host takes this route only for streams that are almost all whole blocks)
+	for (int eb = (int)blockIdx.x; eb < n_edge; eb += (int)gridDim.x) {
+		const int64_t b  = eb < p.dyn_lo ? (int64_t)eb : (int64_t)eb + p.dyn_nb;
+		const int64_t s  = b * BLK;
+		const int64_t r1 = p.n_out;
+		const int64_t a0 = s - Dd - 1024 * R0 - 2 * ROT;
+		int t = t0;
+		asm volatile ("" : "+v"(t));
+		t &= 511;
+		LdsC8* const st = (LdsC8*)smem8;
+		LdsF8* const gc = (LdsF8*)(smem8 + 8192);
+		__syncthreads ();
+		{
+			const int h = t >> 8, tl = t & 255;
+#pragma unroll 2
+			for (int k = 0; k < 16; ++k) {
+				const int nloc = (512 * k + 256 * h + ROT) & 8191;
+				st[512 * k + t] = half_pair (a0 + 2 * (int64_t)nloc, tl);
+			}
+			const int l = t & 63, w = t >> 6;
+			const int nl = (512 * (l & 15) + 64 * w + ROT) & 8191;
+			gc[t]        = l < 16 ? ldv (in, n_in, hist, p.hist_len, a0 + 2 * (int64_t)nl - 1) : 0.f;
+		}
+		__syncthreads ();
+		{
+			const float* a_in  = a_sv; // (unused by the core)
+			float*       a_out = nullptr;
+			const int    one   = 1;
+			PROT_SV8_ALL (CORE, a_in, a_out, one, ca, sa)
+		}
+		__syncthreads ();
+		t = t0;
+		asm volatile ("" : "+v"(t));
+		t &= 511;
+		if (s + BLK <= r1 && out_al8) {
+#pragma unroll
+			for (int k = 0; k < HS; ++k) {
+				PROT_GLOBAL f2* __restrict__ ob = reinterpret_cast<PROT_GLOBAL f2*> (uniform_ptr (out + s + 1024 * k));
+				ob[(unsigned)t]                 = st[512 * k + t];
+			}
+		} else {
+#pragma unroll 2
+			for (int k = 0; k < HS; ++k) {
+				const f2      o    = st[512 * k + t];
+				const int64_t pos0 = s + 1024 * (int64_t)k + 2 * (int64_t)t;
+				if (pos0 < r1) {
+					out[pos0] = o.x;
+				}
+				if (pos0 + 1 < r1) {
+					out[pos0 + 1] = o.y;
+				}
+			}
+		}
+		__syncthreads ();
+	}
+
+	// ---- the workgroup's first claim (thread 0; the generated loop makes the later ones, wave 0 with a scalar atomic): its XCD's
+	// region first, the next ones when that is empty
+	const int nb  = (int)p.dyn_nb;
+	const int per = (nb + 7) / 8;
+	unsigned* const ctr = p.dyn_ctr + (int64_t)c * kDynWords;
+	if (nb > 0) {
+		int tid_c = t0;
+		asm volatile ("" : "+v"(tid_c));
+		if (tid_c == 0) {
+			unsigned xcc;
+			asm volatile ("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+			int r = (int)(xcc & 7u), left = 8, blk = -1;
+			for (;;) {
+				const int      start = r * per;
+				const int      len   = start >= nb ? 0 : (nb - start < per ? nb - start : per);
+				const unsigned tk    = atomicAdd (ctr + 32 * r, 1u);
+				if (tk < (unsigned)len) {
+					blk = start + (int)tk;
+					break;
+				}
+				if (--left == 0) {
+					break;
+				}
+				r = (r + 1) & 7;
+			}
+			sh_claim[0] = blk;
+			sh_claim[1] = r;
+			sh_claim[2] = left;
+		}
+		__syncthreads ();
+		const int first = __builtin_amdgcn_readfirstlane (sh_claim[0]);
+		const int xr    = __builtin_amdgcn_readfirstlane (sh_claim[1]);
+		const int tries = __builtin_amdgcn_readfirstlane (sh_claim[2]);
+		if (first >= 0) {
+			// block 0 of the numbering = the channel's first whole in-range block
+			const int64_t   s0    = p.dyn_lo * BLK;
+			const float*    a_in  = uniform_ptr_generic (in + (s0 - Dd - 1024 * R0 - 2 * ROT));
+			float*          a_out = uniform_ptr_generic (out + s0);
+			unsigned* const a_ctr = uniform_ptr_generic (ctr + 32 * xr);
+#ifdef PROT_SV8_TIMELINE
+			if (t0 == 0 && blockIdx.y == 0 && blockIdx.x < 2048) {
+				g_sv8_wg[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime ();
+			}
+#endif
+			PROT_SV8_DYN_CALL (8, 0)
+			PROT_SV8_DYN_CALL (8, 2)
+			PROT_SV8_DYN_CALL (12, 0)
+			PROT_SV8_DYN_CALL (12, 2)
+			PROT_SV8_DYN_CALL (13, 0)
+			PROT_SV8_DYN_CALL (13, 2)
+		}
+	}
+	if (t0 < 256) {
+		hist_write_slice (p, blockIdx.y, t0);
+	}
+#ifdef PROT_SV8_TIMELINE
+	if (blockIdx.y == 0 && blockIdx.x < 2048) {
+		if ((t0 & 63) < 16) {
+			g_sv8_acc[(blockIdx.x * 8 + (t0 >> 6)) * 16 + (t0 & 63)] = (t0 & 63) == 15 ? 1u : sv8_acc;
+		}
+		if (t0 < 64) {
+			g_sv8_prog[64 * blockIdx.x + t0] = sv8_acc;
+		}
+		if (t0 == 0) {
+			unsigned hw, xcc;
+			asm volatile ("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+			unsigned long long* w = g_sv8_wg + 4 * blockIdx.x;
+			w[2] = __builtin_amdgcn_s_memrealtime (), w[3] = ((unsigned long long)xcc << 32) | hw;
+		}
+	}
+#endif
+	// ---- the last workgroup of the channel to leave puts the counters back to zero for the next launch (every workgroup has made
+	// all its draws by now, and their results have come back)
+	{
+		int tid_x = t0;
+		asm volatile ("" : "+v"(tid_x));
+		if (tid_x == 0) {
+			const unsigned gone = atomicAdd (ctr + 256, 1u);
+			if (gone == gridDim.x - 1u) {
+#pragma unroll
+				for (int r = 0; r < 8; ++r) {
+					__hip_atomic_store (ctr + 32 * r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				__hip_atomic_store (ctr + 256, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+	}
+}
+
+template <int HS>
+static hipError_t launch_sv8_dyn_m (const OlaParams& p, dim3 grid, hipStream_t s)
+{
+	const dim3 block (512);
+	typedef void (*kern_t) (OlaParams);
+	kern_t fn = p.hilbert_only ? olasave8k_dyn_kernel<HS, MODE_HILBERT> : olasave8k_dyn_kernel<HS, MODE_ROT>;
+	static bool asked[2][8] = {};
+	int         dev = 0;
+	(void)hipGetDevice (&dev);
+	const int mi = p.hilbert_only ? 1 : 0;
+	if (dev < 0 || dev >= 8 || !asked[mi][dev]) {
+		hipError_t err = hipFuncSetAttribute ((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, kSv8LdsBytes);
+		if (err != hipSuccess) {
+			return err;
+		}
+		if (dev >= 0 && dev < 8) {
+			asked[mi][dev] = true;
+		}
+	}
+	hipLaunchKernelGGL (fn, grid, block, kSv8LdsBytes, s, p);
+	return hipGetLastError ();
+}
+
+hipError_t launch_ola_save8k_dyn (const OlaParams& p, int hop_rows, int n_chn, int grid_x, hipStream_t s)
+{
+	if ((p.dry_delay & 1) || p.accumulate || p.sv == nullptr || p.hs_flag != nullptr || p.rot_s != nullptr || p.surv != nullptr || p.dyn_ctr == nullptr ||
+	    p.dyn_nb < 1 || p.dyn_lo < 0 || grid_x < 1 || 2 * (p.dry_delay - p.conv_delay) != 1024 * (16 - hop_rows) || (p.sv_flags & 1)) {
+		return hipErrorInvalidValue;
+	}
+	dim3 grid ((unsigned)grid_x, (unsigned)n_chn);
+	switch (hop_rows) {
+		case 8: return launch_sv8_dyn_m<8> (p, grid, s);
+		case 12: return launch_sv8_dyn_m<12> (p, grid, s);
+		case 13: return launch_sv8_dyn_m<13> (p, grid, s);
+		default: return hipErrorInvalidValue;
 	}
 }
 

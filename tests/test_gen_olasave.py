@@ -64,6 +64,47 @@ def test_generated_8192_point_block_matches_float64_convolution(hs, mode, kind):
         G8.self_test(hs, mode, nblk=2, kind=kind, verbose=False, thr2=0.7)
 
 
+@pytest.mark.parametrize("hs,mode,nb,xr,stride", [(13, 0, 6, 2, 3), (12, 2, 5, 7, 1), (8, 0, 3, 5, 2)])
+def test_generated_dynamic_loop_transforms_the_blocks_its_tickets_name(hs, mode, nb, xr, stride):
+    """Gen8kDyn (round 5: a workgroup claims its next block from a counter instead of walking a run): one workgroup in the emulator
+    with the other workgroups' draws simulated by the stride of the counters -- the odd-context rotation at 48 kHz, regions that run
+    out (the workgroup moves on to the next one, wraps around, and stops after eight), the scalar atomic's wait discipline, the LDS
+    mailbox under the race detector.  Every claimed block against the float64 convolution, every other block untouched."""
+    import gen_olasave8k as G8
+    G8.self_test_dyn(hs, mode, nb=nb, xr=xr, stride=stride, verbose=False)
+
+
+def test_dynamic_claim_model_covers_every_block_exactly_once():
+    """the claim protocol restated in Python (dyn_claims): W workgroups drawing in any interleaving transform each block once"""
+    import random
+    import gen_olasave8k as G8
+    for nb, W, seed in ((37, 5, 1), (8, 16, 2), (100, 64, 3), (3, 9, 4)):
+        rnd = random.Random(seed)
+        per = (nb + 7) // 8
+        ctr = [0] * 8
+        wgs = [{"xr": rnd.randrange(8), "tries": 8, "done": False} for _ in range(W)]
+        got = []
+        while not all(w["done"] for w in wgs):
+            w = rnd.choice([w for w in wgs if not w["done"]])
+            t = ctr[w["xr"]]
+            ctr[w["xr"]] += 1
+            while True:
+                start = w["xr"] * per
+                ln = 0 if start >= nb else min(per, nb - start)
+                if t < ln:
+                    got.append(start + t)
+                    break
+                w["tries"] -= 1
+                if w["tries"] == 0:
+                    w["done"] = True
+                    break
+                w["xr"] = (w["xr"] + 1) & 7
+                t = ctr[w["xr"]]
+                ctr[w["xr"]] += 1
+        assert sorted(got) == list(range(nb)), (nb, W)
+        assert G8.dyn_claims(nb, 3, 1)[0] == sorted(G8.dyn_claims(nb, 3, 1)[0], key=lambda b: ((b // per - 3) % 8, b))
+
+
 def test_committed_8192_point_include_is_current(tmp_path):
     import gen_olasave8k as G8
     dst = tmp_path / "asm8k.inc"

@@ -1406,6 +1406,44 @@ def test_block8192_kernel_against_oracle_and_block4096(pkg, rate, chn, n, odd):
             assert np.abs(got - yo[t0 - lo + skip:]).max() < TOL, (t0, c)
 
 
+@pytest.mark.parametrize("kind,param,chn,n,stateless", [("lv2", 48000, 1, (1 << 24) + 12346, True), ("lv2", 48000, 2, (1 << 24) + 2, True),
+                                                         ("lv2", 96000, 1, (1 << 24) + 777, True), ("lv2", 48000, 1, (1 << 24) + 4098, False),
+                                                         ("lv2", 192000, 3, (1 << 24) + 2, True), ("cli", 8192, 2, 1 << 24, True)])
+def test_dynamic_blocks_equal_static_runs(pkg, kind, param, chn, n, stateless):
+    """Round 5: long launches on 8192-point blocks let the resident workgroups CLAIM their blocks one at a time (olasave8k_dyn_kernel:
+    eight regions, one per XCD, a scalar atomic per block) instead of walking runs planned by the host (PROT_CFG_STATIC_RUNS keeps
+    that).  The same blocks through the same generated arithmetic: outputs bit for bit, on mono / stereo / three channels, lengths
+    that are not whole blocks, a stateful call pair (the second call's first block reads the history), the Hilbert branch alone, and
+    twice in a row (the second launch finds the counters as the first one's last workgroup left them)."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5 + chn)
+    x = torch.rand(chn * n, generator=g, device=dev) - 0.5
+    rot = np.array([0.6, -0.8, -0.28, 0.96, 0.0, 1.0][:2 * chn], np.float32)
+    k = pkg.KIND_LV2 if kind == "lv2" else pkg.KIND_CLI
+    fl = pkg.F_STATELESS if stateless else 0
+    outs = {}
+    for tag, flags in (("dynamic", 0), ("static", pkg.CFG_STATIC_RUNS)):
+        e = pkg.Engine(k, param, chn, flags=flags)
+        assert int(e.info.form) == pkg.FORM_POLY_SAVE8K
+        ys = []
+        for rep in range(2):
+            y, u = torch.zeros_like(x), torch.zeros_like(x)
+            torch.cuda.synchronize()
+            e.apply_dev(x.data_ptr(), n, n, y.data_ptr(), n, n, rot, fl)
+            if stateless:
+                e.hilbert_dev(x.data_ptr(), n, n, u.data_ptr(), n, n, fl)
+            e.sync()
+            ys += [y, u]
+        outs[tag] = ys
+        e.close()
+    for a, b in zip(outs["dynamic"], outs["static"]):
+        assert torch.equal(a, b)
+    assert float(outs["dynamic"][0].abs().max()) > 0.1
+    if stateless:
+        assert torch.equal(outs["dynamic"][0], outs["dynamic"][2])   # (a stateless call twice: the same bits)
+
+
 def test_block8192_kernel_lv2_192k(pkg):
     """LV2 at 192 kHz (8192 taps): long launches on 8192-point blocks as ONE table-free partition (HS = 8) against the two-partition
     overlap-add kernel on 4096-point transforms (PROT_CFG_BLOCK4096) and, in windows, against the CPU oracle's run()."""

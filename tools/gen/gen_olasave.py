@@ -152,8 +152,21 @@ class Gen:
         return out
 
     def run_ops(self, ops):
+        """run the thunks; while `pending` thunks are queued (the prefetch of the next block's rows: gen_olasave8k.py, Gen8kDyn with
+        "spread") one of them is issued after every `pend_every` arithmetic thunks, across calls"""
+        pend = getattr(self, "pending", None)
         for f in ops:
             f()
+            if pend and not getattr(self, "no_weave", False):
+                self.pend_n = getattr(self, "pend_n", 0) + 1
+                if self.pend_n >= self.pend_every:
+                    self.pend_n = 0
+                    pend.pop(0)()
+
+    def flush_pending(self):
+        pend = getattr(self, "pending", None)
+        while pend:
+            pend.pop(0)()
 
     @staticmethod
     def weave(main, extra, every):

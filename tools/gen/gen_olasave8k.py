@@ -131,6 +131,11 @@ class Gen8k(Gen):
                    "inverse pass 1 + wave-local exchange 3 (drained)", "inverse pass 2 + W32 twiddle + exchange-4 writes + lgkmcnt(0)",
                    "barrier 4 (exchange 4 written)", "exchange-4 reads, fold, inverse pass 3", "mix + stores issued + loop end"]
 
+    S_STAMP = 92     # (s[92:93] are free in this generator's SGPR plan)
+
+    def tick_lane(self):
+        return S_NBLK
+
     def stamp(self, i):
         """opts "stamps" (diagnostic variant, tools/sv8_stamps.py): shader-clock stamp number i of the block into lane i of v121.  Text
         the emulator does not see (P.raw): s_memtime returns through lgkmcnt, so a stamp drains the LDS queue -- the points are
@@ -138,9 +143,9 @@ class Gen8k(Gen):
         if "stamps" not in self.opts or self.kind == "core":
             return
         P = self.P
-        P.raw("s_memtime s[92:93]")
+        P.raw("s_memtime s[%d:%d]" % (self.S_STAMP, self.S_STAMP + 1))
         P.raw("s_waitcnt lgkmcnt(0)")
-        P.raw("v_writelane_b32 v121, s92, %d" % i)
+        P.raw("v_writelane_b32 v121, s%d, %d" % (self.S_STAMP, i))
 
     def tick(self):
         """opts "tick" (diagnostic variant): ONE 100 MHz stamp per block at the loop's end, into lane S_NBLK (blocks left, this one
@@ -148,13 +153,14 @@ class Gen8k(Gen):
         if "tick" not in self.opts or self.kind == "core":
             return
         P = self.P
-        P.raw("s_memrealtime s[92:93]")
+        a = self.S_STAMP
+        P.raw("s_memrealtime s[%d:%d]" % (a, a + 1))
         P.raw("s_waitcnt lgkmcnt(0)")
-        P.raw("s_mov_b32 s93, m0")          # (one SGPR per VOP3 on gfx9: the lane select goes through M0)
-        P.raw("s_mov_b32 m0, %r" % S_NBLK)
+        P.raw("s_mov_b32 s%d, m0" % (a + 1))   # (one SGPR per VOP3 on gfx9: the lane select goes through M0)
+        P.raw("s_mov_b32 m0, %r" % self.tick_lane())
         P.raw("s_nop 1")
-        P.raw("v_writelane_b32 %0, s92, m0")
-        P.raw("s_mov_b32 m0, s93")
+        P.raw("v_writelane_b32 %%0, s%d, m0" % a)
+        P.raw("s_mov_b32 m0, s%d" % (a + 1))
 
     def stamps_fold(self):
         """at the loop's end: operand %0 (a VGPR)[i] += stamp[i] - stamp[i - 1] (lanes 1..14; low 32 bits: a block is ~25 K cycles)"""
@@ -166,6 +172,7 @@ class Gen8k(Gen):
         P.raw("v_mov_b32_dpp %r, v121 wave_shr:1 row_mask:0xf bank_mask:0xf" % t)
         P.raw("s_nop 1")
         P.raw("v_sub_u32 %r, v121, %r" % (t, t))
+        P.raw("v_writelane_b32 %r, 1, 0" % t)      # (lane 0 counts the blocks)
         P.raw("v_add_u32 %%0, %%0, %r" % t)
 
     # ------------------------------------------------------------ helpers
@@ -203,8 +210,10 @@ class Gen8k(Gen):
         P.s_cbranch_scc1(skip)
         st = P.fork()
         lists = [self.cmul_c32(v[b], v[b], b, conj, sc[(b - 1) % len(sc)]) for b in range(1, 16)]
+        self.no_weave = True     # (nothing that every wave must issue inside a region some waves skip)
         for g in range(0, len(lists), len(sc)):
             self.run_ops(self.interleave(lists[g:g + len(sc)]))
+        self.no_weave = False
         P.assert_no_waits_since(st)
         P.label(skip)
 
@@ -790,6 +799,447 @@ class Gen8k(Gen):
         return self.P
 
 
+# ---------------------------------------------------------------------------------------------------- dynamic blocks (round 5)
+# SGPRs of the dynamic loop (the plan above minus S_NBLK, S_MIX, S_A1; S_T[0..2] are persistent here, S_T[3] stays a temporary)
+S_BLK = S(38)                       # the block being transformed (index among the launch's whole in-range blocks of this channel)
+S_NEXT = S(89)                      # the block after it, or 0xffffffff: none left
+S_CTRX = SP(90)                     # wave 0: address of the counter of the region it draws from
+S_TK = S(92)                        # wave 0: the ticket in flight / arrived
+S_XR = S(93)                        # wave 0: the region it draws from (0..7: one per XCD, its own first)
+S_TRIES, S_PER, S_NB = S(94), S(95), S(96)   # wave 0: regions left to try; blocks per region; blocks in all
+S_ADV = S_SV                        # byte offset from the current block to the next one (the table pointer is dead behind the prologue)
+NONE = 0xffffffff
+SPREAD = 16                         # arithmetic instructions between two loads of the prefetch (option "spread<n>"; 0: all inside one stage)
+LDS_MAIL = 8 * 544                  # byte offset of the mailbox in the exchange area: the 16 spare slots at the end of row 0
+
+
+class Gen8kDyn(Gen8k):
+    """The same block with the workgroup's NEXT block drawn from a counter instead of lying behind the current one (round 5).
+
+    tools/sv8_progress.py on the static run plan: while both workgroups of a CU are resident the one dispatched first takes 7.5 us
+    per block and the other 17.4 (the hardware serves the oldest wave first), the first finishes its run at 198 us and the second
+    works on alone -- at 0.144 blocks/us per CU instead of 0.191 -- until 252: the launch averages 40 blocks/us against 48.5 in its
+    steady state, whatever the run lengths (1.0 : 1.0 ... 1.55 : 0.45 all measure the same).  Here every block is claimed when it is
+    needed: the stream's whole in-range blocks are dealt out in eight contiguous regions, one per XCD (a block's context rows are
+    the rows its predecessor's workgroup has just read: they hit in that XCD's L2), each behind a counter of its own; wave 0 of a
+    workgroup draws a ticket with a scalar atomic (s_atomic_add ... glc: wave-uniform, through the scalar cache, lgkmcnt) a block
+    ahead -- issued behind the last LDS read of block B, collected in front of the first LDS write of block B + 1, published through
+    a mailbox word in LDS in front of that block's second barrier and read by all eight waves behind it, in time for the prefetch of
+    block B + 2's rows -- and moves on to the next region when its own is exhausted.  All 16 rows of a block are loaded (nothing is
+    carried from block to block, so the odd-context "mixed row" is just an address), the dry rows are copied aside as before."""
+
+    def __init__(self, HS, MODE, opts=(), kind="run"):
+        assert kind == "run" and MODE != MODE_SWEEP
+        self.HS, self.MODE, self.NA = HS, MODE, 1
+        self.opts = set(opts)
+        self.kind = kind
+        self.NT = 16 - HS
+        self.R0 = self.NT // 2
+        self.ODD = self.NT % 2
+        self.ROT = 256 if self.ODD else 0
+        self.BLK = 1024 * HS
+        P = self.P = Prog()
+        self.sw_rows, self.sw_label = [], 0
+        if "nolds" in self.opts:
+            P.ds_write_b64 = lambda *a, **k: None
+            P.ds_read_b64 = lambda *a, **k: None
+            P.s_barrier = lambda *a, **k: None
+        if "novalu" in self.opts:
+            P.pk = lambda *a, **k: None
+        self.D = [VP(2 * k) for k in range(16)]
+        n = 32
+        self.K = {}
+        for r in range(self.R0, self.R0 + HS):       # the dry rows = the valid output rows
+            self.K[r] = VP(n)
+            n += 2
+        self.N = []
+        for i in range(16):                          # the next block's rows, all of them
+            self.N.append(VP(n))
+            n += 2
+        self.TA1, self.TB1 = VP(n), VP(n + 2)
+        n += 4
+        self.RHO = [VP(n)]
+        n += 2
+        self.G_NX, self.VT = V(n), V(n + 1)          # gathered frames (lanes 0..15); mailbox value
+        n += 2
+        (self.A_RZ, self.A_RZH, self.A_R1, self.A_CH, self.A_X2, self.A_TL, self.VOFF, self.VG) = [V(n + i) for i in range(8)]
+        n += 8
+        self.TMP = []
+        cap = 119
+        while n + 1 <= cap:
+            self.TMP.append(VP(n))
+            n += 2
+        self.n_vgpr = n
+        assert len(self.TMP) >= 7, "temporaries: %d" % len(self.TMP)
+        self.TB = self.TMP[:4]
+        self.TR = self.TMP[4:5]
+        self.TT = self.TMP[5:9] if len(self.TMP) >= 9 else self.TMP[5:6] * 4
+        self.nbf = len(set(t.n for t in self.TT))
+        self.lab = 0
+        self.n_tick = 0
+
+    S_STAMP = 40     # (S_SV is dead behind the prologue; S_ADV below shares it and is not live across any stamp)
+
+    def tick_lane(self):
+        return S_TRIES   # (diagnostic "tick" variant only: see tick())
+
+    # ------------------------------------------------------------ wave 0's side of the claims
+    def if_wave0(self, body):
+        """body() in wave 0 only (VOFF = 8 T: lane 0 of wave w holds 512 w); no wait may be inserted inside"""
+        P = self.P
+        skip = self.label("L_w0")
+        P.v_readfirstlane(S_T[3], self.VOFF)
+        P.s_nop(4)
+        P.s_cmp_eq_u32(S_T[3], Lit(0))
+        P.s_cbranch_scc0(skip)
+        st = P.fork()
+        body()
+        P.assert_no_waits_since(st)
+        P.restore(st)     # (what wave 0 alone has put in flight is not in the other waves' queues: the bookkeeping forgets it -- wave
+        P.label(skip)     # 0's own waits become stricter by that much, nobody's laxer)
+
+    def claim_issue(self):
+        """wave 0: draw the next ticket of the current region (if the block after this one exists: there is nothing to draw behind
+        the end).  Nothing waits for it here."""
+        P = self.P
+        def body():
+            none = self.label("L_ci")
+            P.s_cmp_eq_u32(S_NEXT, Lit(NONE))
+            P.s_cbranch_scc1(none)
+            P.s_mov(S_TK, Lit(1))
+            P.s_atomic_add(S_TK, S_CTRX)
+            P.label(none)
+        self.if_wave0(body)
+
+    def claim_collect_publish(self):
+        """wave 0: the ticket has had a block's time to arrive; turn it into a block (or move on to the next region, or find that
+        nothing is left) and put the answer into the mailbox.  The LDS queue is empty here (the explicit wait is for the scalar
+        atomic alone) and the workgroup barrier that follows the first exchange's writes orders the mailbox for the readers."""
+        P = self.P
+        def body():
+            retry, valid, none, pub = [self.label(x) for x in ("L_cr", "L_cv", "L_cn", "L_cp")]
+            P.s_wait_lgkm0_here()
+            P.label(retry)
+            P.s_mul_i32(S_T[3], S_XR, S_PER)                    # first block of the region
+            P.s_sub_u32(S_A0.lo, S_NB, S_T[3])
+            P.s_min_u32(S_A0.lo, S_A0.lo, S_PER)                # its length ...
+            P.s_cmp_ge_u32(S_T[3], S_NB)
+            P.s_cselect(S_A0.lo, Lit(0), S_A0.lo)               # ... 0 if it starts behind the end
+            P.s_cmp_lt_u32(S_TK, S_A0.lo)
+            P.s_cbranch_scc1(valid)
+            P.s_sub_u32(S_TRIES, S_TRIES, Lit(1))
+            P.s_cmp_eq_u32(S_TRIES, Lit(0))
+            P.s_cbranch_scc1(none)
+            P.s_add_u32(S_XR, S_XR, Lit(1))
+            P.s_and_b32(S_XR, S_XR, Lit(7))
+            P.s_add_u32(S_CTRX.lo, S_CTRX.lo, Lit(128))         # the counters lie 128 bytes apart, region 0's first
+            P.s_addc_u32(S_CTRX.hi, S_CTRX.hi, Lit(0))
+            P.s_cmp_eq_u32(S_XR, Lit(0))
+            P.s_cselect(S_A0.lo, Lit(1024), Lit(0))
+            P.s_sub_u32(S_CTRX.lo, S_CTRX.lo, S_A0.lo)
+            P.s_subb_u32(S_CTRX.hi, S_CTRX.hi, Lit(0))
+            P.s_mov(S_TK, Lit(1))
+            P.s_atomic_add(S_TK, S_CTRX)
+            P.s_wait_lgkm0_here()
+            P.s_branch(retry)
+            P.label(valid)
+            P.s_add_u32(S_NEXT, S_T[3], S_TK)
+            P.s_branch(pub)
+            P.label(none)
+            P.s_mov(S_NEXT, Lit(NONE))
+            P.label(pub)
+            ad = self.TMP[0].lo                      # (the first exchange's writes have read their data: the temporaries are free)
+            P.v_mov(ad, S_LDS)
+            P.v_mov(self.VT, S_NEXT)
+            P.exec_lane0()
+            P.ds_write_b32(ad, self.VT, LDS_MAIL)
+            P.exec_all()
+        self.if_wave0(body)
+
+    # ------------------------------------------------------------ phases
+    def prologue(self):
+        P, HS, NT = self.P, self.HS, self.NT
+        P.comment("---- prologue: wave type, addresses")
+        T_ = self.TMP
+        t, a, b, c, d, lane, wv, m = T_[0].lo, T_[0].hi, T_[1].lo, T_[1].hi, T_[2].lo, T_[2].hi, T_[3].lo, T_[3].hi
+        tabs = (T_[5], T_[6])
+        P.v_lshr(a, Lit(8), t)                                  # e = ke = T >> 8: wave-uniform
+        P.v_and(b, Lit(255), t)
+        P.v_lshl(self.VOFF, Lit(3), t)                          # 8 T
+        P.v_lshl(b, Lit(3), b)
+        P.v_add_u32(self.A_RZ, S_LDS, b)
+        P.v_add_u32(self.A_RZH, Lit(8 * ROWS * HI_ROW), self.A_RZ)
+        P.v_readfirstlane(S_HI, a)
+        P.s_nop(4)
+        P.s_cmp_eq_u32(S_HI, Lit(1))
+        P.s_cselect(S_SIG.lo, Lit(-1.0), Lit(1.0))
+        P.s_cselect(S_SIG.hi, Lit(-1.0), Lit(1.0))
+        P.v_lshr(b, Lit(4), t)
+        P.v_and(b, Lit(15), b)                                  # k1
+        P.v_and(c, Lit(15), t)                                  # c
+        P.v_mul_u24(b, Lit(8 * ROWS), b)
+        P.v_add_u32(b, S_LDS, b)
+        P.v_lshl(d, Lit(3), c)
+        P.v_add_u32(self.A_R1, b, d)
+        P.v_mul_u24(m, Lit(8 * HALF), a)
+        P.v_add_u32(self.A_CH, self.A_R1, m)
+        P.v_mul_u24(d, Lit(8 * KG), c)
+        P.v_add_u32(self.A_X2, b, d)
+        P.v_add_u32(self.A_X2, self.A_X2, m)
+        P.v_lshl(m, Lit(11), a)
+        P.v_lshl(d, Lit(3), c)
+        P.v_add_u32(m, m, d)
+        P.v_add_u32(self.A_TL, S_LDS, m)
+        P.v_add_u32(self.A_TL, Lit(LDS_TWF), self.A_TL)
+        # the first block: S_IN / S_OUT come as block 0's, the block's number in S_BLK
+        P.s_mul_i32(S_A0.lo, S_BLK, Lit(4 * self.BLK))
+        P.s_mul_hi_u32(S_A0.hi, S_BLK, Lit(4 * self.BLK))
+        P.s_add_u32(S_IN.lo, S_IN.lo, S_A0.lo)
+        P.s_addc_u32(S_IN.hi, S_IN.hi, S_A0.hi)
+        P.s_add_u32(S_OUT.lo, S_OUT.lo, S_A0.lo)
+        P.s_addc_u32(S_OUT.hi, S_OUT.hi, S_A0.hi)
+        if self.ROT:
+            P.s_add_u32(S_IN.lo, S_IN.lo, Lit(8 * self.ROT))
+            P.s_addc_u32(S_IN.hi, S_IN.hi, Lit(0))
+        # gather offsets: lane l (< 16) of a wave fetches the frame in front of this wave's first sample of row l; with an odd
+        # number of context rows row 15 of the upper waves is the block's first half row (the rotation wraps there)
+        P.v_and(lane, Lit(63), t)
+        P.v_lshr(wv, Lit(6), t)
+        P.v_lshl(wv, Lit(9), wv)                                # 512 B per wave
+        P.v_lshl(a, Lit(12), lane)                              # 4096 lane
+        P.v_add_u32(a, a, wv)
+        P.v_mov(b, Lit(16))
+        P.v_cmp_lt_u32(lane, b)                                 # lane < 16
+        P.v_mov(b, Lit(0))
+        P.v_cndmask(a, b, a)                                    # lanes without a row: offset 0 (a valid address)
+        if self.ODD:
+            # the upper waves' row 15 lies 65536 bytes lower (load_block_rows); the VGPR offset of a global access is unsigned, so
+            # those waves gather from S_IN - 65536 with every other lane's offset 65536 higher
+            P.v_mov(c, Lit(65536))
+            P.v_add_u32(c, c, a)
+            P.v_cmp_eq_u32(Lit(15), lane)
+            P.v_cndmask(c, c, a)                                # lane 15: as it is
+            P.v_mov(d, S_HI)
+            P.v_cmp_eq_u32(Lit(1), d)                           # (every lane: an upper wave?)
+            P.v_cndmask(self.VG, a, c)
+        else:
+            P.v_mov(self.VG, a)
+        P.comment("---- prologue: twiddle registers, |B| factors, the two tables of the middle passes")
+        for row, dst in ((0, self.TA1), (1, self.TB1), (4, self.RHO[0]), (2, tabs[0]), (3, tabs[1])):
+            P.s_add_u32(S_A0.lo, S_SV.lo, Lit(4096 * row))
+            P.s_addc_u32(S_A0.hi, S_SV.hi, Lit(0))
+            P.global_load_dwordx2(dst, self.VOFF, S_A0, 0)
+        return tabs, t
+
+    def load_block_rows(self, soff, thunks=False):
+        """all 16 rows of the block at S_IN + soff (an SGPR pair holding a 64-bit byte offset, or None) -> N; the gathered frames -> G_NX"""
+        P = self.P
+        if "nomem" in self.opts and soff is not None:
+            return []
+        nt = "nt" in self.opts
+        ops = []
+        def base(extra):
+            # S_A0 = S_IN + soff + extra (extra may be negative)
+            src = S_IN
+            if soff is not None:
+                P.s_add_u32(S_A0.lo, S_IN.lo, soff.lo)
+                P.s_addc_u32(S_A0.hi, S_IN.hi, soff.hi)
+                src = S_A0
+            if extra < 0:
+                P.s_sub_u32(S_A0.lo, src.lo, Lit(-extra))
+                P.s_subb_u32(S_A0.hi, src.hi, Lit(0))
+            else:
+                P.s_add_u32(S_A0.lo, src.lo, Lit(extra))
+                P.s_addc_u32(S_A0.hi, src.hi, Lit(0))
+        def step(nbytes, sub=False):
+            if sub:
+                P.s_sub_u32(S_A0.lo, S_A0.lo, nbytes)
+                P.s_subb_u32(S_A0.hi, S_A0.hi, Lit(0))
+            else:
+                P.s_add_u32(S_A0.lo, S_A0.lo, nbytes)
+                P.s_addc_u32(S_A0.hi, S_A0.hi, Lit(0))
+        for r in range(16):
+            def f(r=r):
+                if r == 0:
+                    base(0)
+                else:
+                    step(Lit(4096))                 # (the thunks run in order: S_A0 walks from row to row)
+                if self.ODD and r == 15:            # the upper waves' row 15 is the block's first half row
+                    P.s_cmp_eq_u32(S_HI, Lit(1))
+                    P.s_cselect(S_T[3], Lit(65536), Lit(0))
+                    step(S_T[3], sub=True)
+                P.global_load_dwordx2(self.N[r], self.VOFF, S_A0, 0, nt=nt)
+            ops.append(f)
+        def g():
+            step(Lit(4096 * 15), sub=True)          # back to row 0 (less 65536 in the upper waves of an odd-context block: VG there)
+            P.global_load_dword(self.G_NX, self.VG, S_A0, -4, nt=nt)
+        ops.append(g)
+        if thunks:
+            return ops
+        for f in ops:
+            f()
+        return []
+
+    def prologue_rows(self, tabs, t):
+        P = self.P
+        P.comment("---- prologue: the first block's rows (requested early), the first ticket")
+        self.load_block_rows(None)
+        # wave 0 draws the ticket of the block after the first one
+        P.s_mov(S_NEXT, Lit(0))                  # (anything but NONE: claim_issue draws)
+        self.claim_issue()
+        w = self.TMP[1].lo
+        wt = self.TMP[1].hi
+        P.v_add_u32(w, S_LDS, self.VOFF)
+        P.v_add_u32(wt, Lit(LDS_TWF), w)
+        P.pk("mul", tabs[1], [tabs[1], S_ROT], op_sel=[0, 1], op_sel_hi=[1, 1])
+        P.ds_write_b64(wt, tabs[0], 0)
+        P.ds_write_b64(wt, tabs[1], LDS_TWI - LDS_TWF)
+        P.comment("---- prologue done")
+
+    def build_pq(self):
+        P, HS, R0 = self.P, self.HS, self.R0
+        self.build_rows([(k, self.N[k], self.G_NX, k) for k in range(16)])
+        for r in range(R0, R0 + HS):
+            P.v_mov(self.K[r].lo, self.N[r].lo)
+            P.v_mov(self.K[r].hi, self.N[r].hi)
+
+    def loop(self):
+        P, HS = self.P, self.HS
+        P.s_waitcnt(vmcnt=0)
+        P.label("L_top")
+        self.stamp(0)
+        # the next block's rows have arrived (its 16 row loads and the gather were issued in front of this block's HS stores);
+        # no LDS operation is in flight here (the last ones were the reads of the fourth exchange, all consumed), and the scalar
+        # atomic of wave 0 may be: lgkmcnt is not waited for
+        P.s_waitcnt(vmcnt=HS)
+        P.reset_queues(vm_stores=HS)
+        self.stamp(1)
+        P.comment("---- (p, q) pairs")
+        self.build_pq()
+        self.tap("pq", self.D)
+        P.comment("---- forward pass 1 + exchange 1")
+        self.fwd_pass1()
+        self.claim_collect_publish()
+        P.s_waitcnt(lgkmcnt=0)
+        self.stamp(4)
+        P.s_barrier()
+        self.stamp(5)
+        P.comment("---- forward pass 2 (the radix-2 layer first); the mailbox")
+        P.v_mov(self.VT, S_LDS)
+        P.ds_read_b32(self.VT, self.VT, LDS_MAIL)
+        v = self.fwd_pass2_reads()
+        self.tap("p2in", self.D)
+        # byte offset from this block to the next one (0 behind the end: the prefetch then re-reads this block, in range)
+        P.settle([self.VT])
+        P.v_readfirstlane(S_NEXT, self.VT)
+        P.s_nop(4)
+        P.s_cmp_eq_u32(S_NEXT, Lit(NONE))
+        P.s_cselect(S_T[3], S_BLK, S_NEXT)
+        P.s_sub_u32(S_T[3], S_T[3], S_BLK)                      # blocks ahead: negative when the regions wrap around (a signed
+        P.s_mul_hi_i32(S_ADV.hi, S_T[3], Lit(4 * self.BLK))     # 64-bit byte offset, added with carry)
+        P.s_mul_i32(S_ADV.lo, S_T[3], Lit(4 * self.BLK))
+        lds_ = self.load_block_rows(S_ADV, thunks=True)
+        main = self.stage1_ops(v, 1) + self.stage1_twiddle_ops(v, 1, self.scratch_pairs())
+        spread = [int(o[6:]) for o in self.opts if o.startswith("spread")] or [SPREAD]
+        if spread[0] > 0:
+            # the 17 loads of the prefetch one after every `spread` arithmetic instructions from here on (through the second and third
+            # forward passes, the constants and the first inverse pass if need be) instead of all of them inside this stage: eight
+            # waves that issue 17 x 512 bytes each at the same moment queue on the CU's one address path, and whatever stands behind
+            # a load that cannot issue waits with it.  Measured (tools/ab_bench.py, ms per 2^27 frames, two rounds): all in the stage
+            # 0.2460 / 0.2453, every 4: 0.2433 / 0.2426, 8: 0.2383 / 0.2392, 12: 0.2392 / 0.2366, 20: 0.2365 / 0.2379
+            self.pending, self.pend_every, self.pend_n = list(lds_), spread[0], 0
+            self.run_ops(main)
+        else:
+            self.run_ops(self.weave(main, lds_, max(1, len(main) // (len(lds_) + 1)) if lds_ else 1))
+        self.twiddled_exchange8(v, 1, 0, self.A_X2, 8, self.A_CH, KG * 8)
+        self.stamp(8)
+        P.comment("---- forward pass 3")
+        v = self.D
+        self.stage1(v, 1)
+        self.run_ops(self.stage1_twiddle_ops(v, 1, self.scratch_pairs()))
+        bfl = self.stage2_lists(v, 1)
+        self.run_ops(self.interleave(bfl) if self.nbf >= 4 else sum(bfl, []))
+        v = self.natural(v)
+        P.comment("---- constants")
+        self.pointwise(v)
+        self.stamp(9)
+        P.comment("---- inverse pass 1")
+        self.stage1(v, -1)
+        self.run_ops(self.stage1_twiddle_ops(v, -1, self.scratch_pairs()))
+        self.twiddled_exchange8(v, -1, LDS_TWI - LDS_TWF, self.A_CH, KG * 8, self.A_X2, 8)
+        self.stamp(10)
+        P.comment("---- inverse pass 2, the radix-2 layer's twiddle, exchange 4")
+        self.flush_pending()
+        v = self.D
+        self.stage1(v, -1)
+        self.run_ops(self.stage1_twiddle_ops(v, -1, self.scratch_pairs()))
+        bfl = self.stage2_lists(v, -1)
+        self.run_ops(self.interleave(bfl) if self.nbf >= 4 else sum(bfl, []))
+        u = self.natural(v)
+        self.ke_twiddle(u, True)
+        for b in range(16):
+            P.ds_write_b64(self.A_CH, u[b], 128 * b)
+        P.s_waitcnt(lgkmcnt=0)
+        self.stamp(11)
+        P.s_barrier()
+        self.stamp(12)
+        order = [4, 8, 12, 0, 5, 9, 13, 1, 6, 10, 14, 2, 7, 11, 15, 3]
+        sets = [self.TMP[:4], self.TMP[4:8] if len(self.TMP) >= 8 else []]
+        def issue(j):
+            for i, k in enumerate(order[4 * j:4 * j + 4]):
+                base, imm = self.row_slot(k)
+                P.ds_read_b64(self.D[k], base, imm)
+            for i, k in enumerate(order[4 * j:4 * j + 4]):
+                base, imm = self.row_slot(k)
+                P.ds_read_b64(sets[j % 2][i], base, imm + 8 * HALF)
+        def fold(j):
+            for i, k in enumerate(order[4 * j:4 * j + 4]):
+                P.pk("fma", self.D[k], [sets[j % 2][i], S_SIG, self.D[k]])
+        if len(sets[1]) < 4:
+            for j in range(4):
+                sets[1] = sets[0]
+                issue(j)
+                fold(j)
+        else:
+            issue(0)
+            for j in range(1, 4):
+                issue(j)
+                fold(j - 1)
+            fold(3)
+        # every LDS read of the block has been consumed: from here to the next block's first exchange no wait counts lgkmcnt --
+        # the ticket of the block after next has that long to arrive
+        P.settle(self.D)
+        self.claim_issue()
+        P.comment("---- inverse pass 3")
+        u = self.inv_pass3()
+        self.stamp(13)
+        P.comment("---- mix and store")
+        for k in range(HS):
+            self.epilogue_row(u, k)
+        self.stamp(14)
+        self.stamps_fold()
+        self.tick()
+        # on to the next block
+        P.s_cmp_eq_u32(S_NEXT, Lit(NONE))
+        P.s_cbranch_scc1("L_done")
+        P.s_sub_u32(S_T[3], S_NEXT, S_BLK)
+        P.s_mul_hi_i32(S_ADV.hi, S_T[3], Lit(4 * self.BLK))
+        P.s_mul_i32(S_ADV.lo, S_T[3], Lit(4 * self.BLK))
+        P.s_add_u32(S_IN.lo, S_IN.lo, S_ADV.lo)
+        P.s_addc_u32(S_IN.hi, S_IN.hi, S_ADV.hi)
+        P.s_add_u32(S_OUT.lo, S_OUT.lo, S_ADV.lo)
+        P.s_addc_u32(S_OUT.hi, S_OUT.hi, S_ADV.hi)
+        P.s_mov(S_BLK, S_NEXT)
+        P.s_branch("L_top")
+        P.label("L_done")
+
+    def build(self):
+        tabs, t = self.prologue()
+        self.prologue_rows(tabs, t)
+        self.loop()
+        return self.P
+
+
 # ---------------------------------------------------------------------------------------------------- self-test
 def device_table(HS, fir=None):
     """the per-engine constants as prot_capi.hip (save_tables8k) lays them out: five rows of 512 float2 -- W_N^{(T - 1/2)},
@@ -945,6 +1395,125 @@ def self_test(HS, MODE, nblk=3, seed=1, verbose=True, opts=(), kind="run", thr2=
     return g, P
 
 
+def dyn_claims(nb, xr, stride, ctr=None):
+    """the blocks one workgroup transforms, in order, when every draw advances a counter by `stride` (the other workgroups' draws):
+    the claim logic of Gen8kDyn / olasave8k_kernel's dynamic path restated"""
+    per = (nb + 7) // 8
+    ctr = [0] * 8 if ctr is None else ctr
+    st = {"xr": xr, "tries": 8}
+    def draw():
+        t = ctr[st["xr"]]
+        ctr[st["xr"]] += stride
+        return t
+    def claim():
+        t = draw()
+        while True:
+            start = st["xr"] * per
+            ln = 0 if start >= nb else min(per, nb - start)
+            if t < ln:
+                return start + t
+            st["tries"] -= 1
+            if st["tries"] == 0:
+                return None
+            st["xr"] = (st["xr"] + 1) & 7
+            t = draw()
+    out = []
+    while True:
+        b = claim()
+        if b is None:
+            return out, per
+        out.append(b)
+
+
+def self_test_dyn(HS, MODE, nb=11, xr=2, stride=3, seed=1, verbose=True, opts=()):
+    """one workgroup of the dynamic loop in the emulator: it must transform exactly the blocks its tickets name (and leave the
+    others alone), each against the float64 convolution"""
+    g = Gen8kDyn(HS, MODE, opts)
+    P = g.build()
+    NT, R0, BLK, ROT = g.NT, g.R0, g.BLK, g.ROT
+    tab, gain, gt = device_table(HS)
+    rng = np.random.default_rng(seed)
+    n_frames = 16384 + BLK * nb + 64
+    x = (rng.random(n_frames, dtype=np.float32) - 0.5)
+    a0 = 2
+    out = np.zeros(BLK * nb + 16, np.float32)
+    emu = Emu(lds_bytes=LDS_BYTES, n_threads=NTHR)
+    emu.atomic_stride = stride
+    IN_BASE, OUT_BASE, SV_BASE, CTR_BASE = 0x10000000, 0x20000000, 0x30000000, 0x50000000
+    ctr = np.zeros(8 * 32, np.uint32)
+    emu.map(IN_BASE, x.view(np.uint32))
+    emu.map(OUT_BASE, out.view(np.uint32))
+    emu.map(SV_BASE, tab.view(np.uint32))
+    emu.map(CTR_BASE, ctr)
+    ca, sa = 0.6, -0.8
+    def sset(sp, lo, hi):
+        emu.s[:, sp.n] = np.float32(lo).view(np.uint32)
+        emu.s[:, sp.n + 1] = np.float32(hi).view(np.uint32)
+    for n, (lo, hi) in g.constants().items():
+        sset(SP(n), lo, hi)
+    sset(S_ROT, ca, np.float32(sa) * gain)
+    blocks, per = dyn_claims(nb, xr, stride)
+    # what the C++ side does in front of the generated code: the workgroup's first claim
+    st_ctr = [0] * 8
+    first_xr, tries = xr, 8
+    while True:
+        t = st_ctr[first_xr]
+        st_ctr[first_xr] += stride
+        start = first_xr * per
+        ln = 0 if start >= nb else min(per, nb - start)
+        if t < ln:
+            first = start + t
+            break
+        tries -= 1
+        first_xr = (first_xr + 1) & 7
+    assert first == blocks[0]
+    for r in range(8):
+        ctr[32 * r] = st_ctr[r]
+    addr = IN_BASE + 4 * a0
+    emu.s[:, S_IN.n], emu.s[:, S_IN.n + 1] = addr & 0xffffffff, addr >> 32
+    emu.s[:, S_OUT.n], emu.s[:, S_OUT.n + 1] = OUT_BASE & 0xffffffff, OUT_BASE >> 32
+    emu.s[:, S_SV.n], emu.s[:, S_SV.n + 1] = SV_BASE & 0xffffffff, SV_BASE >> 32
+    emu.s[:, S_BLK.n] = first
+    emu.s[:, S_LDS.n] = 0
+    ca_ = CTR_BASE + 128 * first_xr
+    emu.s[:, S_CTRX.n], emu.s[:, S_CTRX.n + 1] = ca_ & 0xffffffff, ca_ >> 32
+    emu.s[:, S_XR.n] = first_xr
+    emu.s[:, S_TRIES.n] = tries
+    emu.s[:, S_PER.n] = per
+    emu.s[:, S_NB.n] = nb
+    emu.v[g.TMP[0].n] = np.arange(NTHR, dtype=np.uint32)
+    emu.run(P)
+    xd = x.astype(np.float64)
+    nz = (n_frames - a0) // 2 - 1
+    z = xd[a0 - 1:a0 - 1 + 2 * nz:2] + 1j * xd[a0:a0 + 2 * nz:2]
+    full = np.convolve(z, gt)
+    Lg = len(gt)
+    want = np.zeros(BLK * nb)
+    for b in blocks:
+        for k in range(HS):
+            j = b * 512 * HS + 512 * (R0 + k) + ROT + np.arange(512)
+            y = full[j + Lg // 2]
+            dq, dc = xd[a0 + 2 * j], xd[a0 + 2 * j + 1]
+            pos = b * BLK + 1024 * k + 2 * np.arange(512)
+            if MODE == MODE_ROT:
+                want[pos], want[pos + 1] = ca * dq + sa * y.real, ca * dc + sa * y.imag
+            else:
+                want[pos], want[pos + 1] = sa * y.real, sa * y.imag
+    err = np.abs(out[:BLK * nb] - want).max()
+    st = P.stats()
+    npk = sum(v for k, v in st.items() if k.startswith("pk_"))
+    nval = sum(v for k, v in st.items() if k.startswith("v_"))
+    if verbose:
+        print("8k dyn HS %2d mode %d: blocks %s of %d (region %d, stride %d): max err %.2e; VGPRs %d (temporaries %d pairs); loop+prologue: %d packed, "
+              "%d other VALU, %d ds, %d vmem, %d salu, %d waits, %d barriers" % (
+                  HS, MODE, blocks, nb, xr, stride, err, g.n_vgpr, len(g.TMP), npk, nval,
+                  sum(v for k, v in st.items() if k.startswith("ds_")), st.get("gload2", 0) + st.get("gload1", 0) + st.get("gstore2", 0),
+                  sum(v for k, v in st.items() if k.startswith("s_") and k not in ("s_waitcnt", "s_barrier", "s_nop", "s_waitcnt_x")),
+                  st.get("s_waitcnt", 0), st.get("s_barrier", 0)))
+    assert err < 1e-6, err
+    return g, P
+
+
 # HS = 8: the CLI's default engine at 48 kHz (blksiz 8192: 4096 odd taps = 8 context rows) as ONE table-free partition.
 # (HS = 14, CLI blksiz 2048, passes the self-test too and is not emitted: the 4096-point kernel that serves it is faster, DESIGN.md)
 VARIANTS = [(hs, mode) for hs in (8, 12, 13) for mode in (MODE_ROT, MODE_HILBERT)]
@@ -985,6 +1554,32 @@ def emit(path, opts=()):
                 out.append('\t"%s\\n\t" \\' % l)
             out.append('\t""')
             out.append("")
+    # the dynamic loop (Gen8kDyn): operands %0 in (aligned pair of local sample 0 of the channel's whole-block 0), %1 out (first output
+    # frame of block 0), %2 the workgroup's first block, %3 LDS byte offset, %4 constants table, %5 ca, %6 sa * gain, %7 thread id, %8
+    # address of the counter of the region the first block was drawn from, %9 that region, %10 regions left to try, %11 blocks per
+    # region, %12 blocks in all
+    for HS, MODE in VARIANTS:
+        g = Gen8kDyn(HS, MODE, [o for o in opts if o != "cyclic"])
+        P = g.build()
+        nv[HS] = max(nv.get(HS, 0), g.n_vgpr)
+        head = ["s_mov_b64 %r, %%%d" % (S_IN, sh), "s_mov_b64 %r, %%%d" % (S_OUT, 1 + sh), "s_mov_b32 %r, %%%d" % (S_BLK, 2 + sh),
+                "s_mov_b32 %r, %%%d" % (S_LDS, 3 + sh), "s_mov_b64 %r, %%%d" % (S_SV, 4 + sh), "s_mov_b32 %r, %%%d" % (S_ROT.lo, 5 + sh),
+                "s_mov_b32 %r, %%%d" % (S_ROT.hi, 6 + sh), "v_mov_b32 %r, %%%d" % (g.TMP[0].lo, 7 + sh), "s_mov_b64 %r, %%%d" % (S_CTRX, 8 + sh),
+                "s_mov_b32 %r, %%%d" % (S_XR, 9 + sh), "s_mov_b32 %r, %%%d" % (S_TRIES, 10 + sh), "s_mov_b32 %r, %%%d" % (S_PER, 11 + sh),
+                "s_mov_b32 %r, %%%d" % (S_NB, 12 + sh), "s_waitcnt vmcnt(0) lgkmcnt(0)"]
+        for n, (lo, hi) in sorted(g.constants().items()):
+            head.append("s_mov_b32 s%d, %r" % (n, Lit(float(lo))))
+            head.append("s_mov_b32 s%d, %r" % (n + 1, Lit(float(hi))))
+        lines = head + P.text(label_suffix="%=")
+        st = P.stats()
+        out.append("// dyn, HS %d, mode %d: %d VGPRs, %d instructions" % (HS, MODE, g.n_vgpr, sum(v for k, v in st.items() if k not in ("comment", "label", "probe"))))
+        out.append("#define PROT_SV8_DYN_%d_%d \\" % (HS, MODE))
+        for l in lines:
+            if l.startswith(";"):
+                continue
+            out.append('\t"%s\\n\t" \\' % l)
+        out.append('\t""')
+        out.append("")
     # MODE_SWEEP (run kind only; edge blocks take the Hilbert core and are tested by the C++ code), for the CLI engine that runs
     # on these blocks (blksiz 8192: HS = 8).  Operands as prot_olasave_asm.inc's PROT_SV_SWEEP_*: %0 survivor cursor (out), %1
     # running max |x| (out), %2 in, %3 blocks, %4 LDS byte offset, %5 constants table, %6 bound, %7 gain, %8 thread id, %9 and %10 the
@@ -1031,6 +1626,7 @@ if __name__ == "__main__":
         if not wrong:
             for HS, MODE in VARIANTS:
                 self_test(HS, MODE, nblk=2, opts=opts, verbose=False)
+                self_test_dyn(HS, MODE, nb=3, xr=1, stride=1, opts=opts, verbose=False)
         os.makedirs(os.path.join(csrc, "variants"), exist_ok=True)
         dst = os.path.join(csrc, "variants", "prot_olasave8k_asm_%s.inc" % name)
         emit(dst, opts)
@@ -1041,6 +1637,8 @@ if __name__ == "__main__":
         self_test(HS, MODE, kind="core")
     for HS in SWEEP_HS:
         self_test(HS, MODE_SWEEP, nblk=2)
+    for HS, MODE in VARIANTS:
+        self_test_dyn(HS, MODE, nb=4 if "--quick" in sys.argv else 7, xr=(3 * HS) & 7, stride=2 if MODE else 1)
     if "--check" not in sys.argv:
         dst = os.path.join(csrc, "prot_olasave8k_asm.inc")
         emit(dst)

@@ -141,8 +141,11 @@ class Prog:
                 if len(self.lgq) >= 15:   # the counter has 4 bits: the 16th operation in flight would stall the wave anyway
                     pass
                 self.lgq.append(self._regs(i.d))
-            elif i.op == "ds_write_b64":
+            elif i.op in ("ds_write_b64", "ds_write_b32"):
                 self.lgq.append(set())
+            # (s_atomic_add is NOT counted: scalar memory returns out of order with LDS, so a count that leaned on its position
+            # could be satisfied with the LDS operation in front of it still in flight; a wait computed from the LDS operations
+            # alone is at worst stricter than needed while the atomic is out.  Its result is waited for with an explicit lgkmcnt(0).)
         elif i.op == "s_waitcnt":
             if i.vmcnt is not None: del self.vmq[:max(0, len(self.vmq) - i.vmcnt)]
             if i.lgkmcnt is not None: del self.lgq[:max(0, len(self.lgq) - i.lgkmcnt)]
@@ -190,6 +193,7 @@ class Prog:
     def s_lshl_b32(self, d, a, sh): return self.add(Ins("s_lshl", "s_lshl_b32 %r, %r, %r" % (d, a, sh), d=d, a=a, sh=sh))
     def exec_from(self, m): return self.add(Ins("exec_from", "s_mov_b64 exec, %r" % m, m=m))
     def exec_all(self): return self.add(Ins("exec_all", "s_mov_b64 exec, -1"))
+    def exec_lane0(self): return self.add(Ins("exec_lane0", "s_mov_b64 exec, 1"))
     def v_cndmask(self, d, a, b): return self.add(Ins("v_cndmask", "v_cndmask_b32 %r, %r, %r, vcc" % (d, a, b), d=d, a=a, b=b))  # d = vcc ? b : a
 
     # ---- LDS ----
@@ -225,6 +229,19 @@ class Prog:
     def s_cmp_lg_u32(self, a, b): return self.add(Ins("s_cmp_lg", "s_cmp_lg_u32 %r, %r" % (a, b), a=a, b=b))
     def s_cmp_eq_u32(self, a, b): return self.add(Ins("s_cmp_eq", "s_cmp_eq_u32 %r, %r" % (a, b), a=a, b=b))
     def s_cmp_lt_u32(self, a, b): return self.add(Ins("s_cmp_lt", "s_cmp_lt_u32 %r, %r" % (a, b), a=a, b=b))
+    def s_cmp_ge_u32(self, a, b): return self.add(Ins("s_cmp_ge", "s_cmp_ge_u32 %r, %r" % (a, b), a=a, b=b))
+    def s_mul_i32(self, d, a, b): return self.add(Ins("s_mul_i32", "s_mul_i32 %r, %r, %r" % (d, a, b), d=d, a=a, b=b))
+    def s_mul_hi_u32(self, d, a, b): return self.add(Ins("s_mul_hi_u32", "s_mul_hi_u32 %r, %r, %r" % (d, a, b), d=d, a=a, b=b))
+    def s_mul_hi_i32(self, d, a, b): return self.add(Ins("s_mul_hi_i32", "s_mul_hi_i32 %r, %r, %r" % (d, a, b), d=d, a=a, b=b))
+    def s_and_b32(self, d, a, b): return self.add(Ins("s_and_b32", "s_and_b32 %r, %r, %r" % (d, a, b), d=d, a=a, b=b))
+    def s_min_u32(self, d, a, b): return self.add(Ins("s_min_u32", "s_min_u32 %r, %r, %r" % (d, a, b), d=d, a=a, b=b))
+    def s_atomic_add(self, d, sbase):
+        """d (holding the addend) <- the 32-bit word at sbase before the add (glc: a wave-uniform fetch-and-add through the scalar
+        cache; returns through lgkmcnt, OUT of order with LDS operations: only lgkmcnt(0) says it has arrived)"""
+        return self.add(Ins("s_atomic_add", "s_atomic_add %r, %r, 0x0 glc" % (d, sbase), d=d, sbase=sbase))
+    def ds_write_b32(self, addr, data, off=0):
+        assert 0 <= off < 65536
+        return self.add(Ins("ds_write_b32", "ds_write_b32 %r, %r%s" % (addr, data, " offset:%d" % off if off else ""), addr=addr, data=data, off=off))
     def s_cbranch_scc1(self, label): return self.add(Ins("s_cbranch_scc1", "s_cbranch_scc1 %s" % label, label=label))
     def s_cbranch_scc0(self, label): return self.add(Ins("s_cbranch_scc0", "s_cbranch_scc0 %s" % label, label=label))
     def s_branch(self, label): return self.add(Ins("s_branch", "s_branch %s" % label, label=label))
@@ -240,6 +257,10 @@ class Prog:
             assert 0 <= lgkmcnt <= 15
             parts.append("lgkmcnt(%d)" % lgkmcnt)
         return self.add(Ins("s_waitcnt", "s_waitcnt " + " ".join(parts), vmcnt=vmcnt, lgkmcnt=lgkmcnt))
+    def s_wait_lgkm0_here(self):
+        """an explicit `s_waitcnt lgkmcnt(0)` inside a region only some waves execute (a scalar atomic's result): seen by the emulator,
+        not by the generator's own wait bookkeeping (which describes every wave) nor by assert_no_waits_since"""
+        return self.add(Ins("s_waitcnt_x", "s_waitcnt lgkmcnt(0)", vmcnt=None, lgkmcnt=0))
     def s_barrier(self): return self.add(Ins("s_barrier", "s_barrier"))
     def s_nop(self, n=0): return self.add(Ins("s_nop", "s_nop %d" % n))
     def s_setprio(self, n): return self.add(Ins("s_nop", "s_setprio %d" % n))
@@ -309,6 +330,7 @@ class _Wave:
         self.recent = []                    # VGPRs written by the last two VALU instructions (DPP hazard: 2 wait states)
         self.sgpr_wr = 99                   # instructions since a VALU wrote an SGPR (v_readlane / v_readfirstlane)
         self.done = False
+        self.smem_regs = set()              # SGPRs a scalar atomic in flight will write
 
 
 class Emu:
@@ -429,6 +451,8 @@ class Emu:
             raise TypeError(x)
 
         def srd(x):
+            if isinstance(x, S) and x.n in W_.smem_regs:
+                raise RuntimeError("s%d is read while the scalar atomic that writes it is in flight (no lgkmcnt(0) since)" % x.n)
             if isinstance(x, S): return int(s[x.n])
             if isinstance(x, Lit): return int(x.bits())
             if isinstance(x, (int, np.integer)): return int(x) & 0xffffffff
@@ -561,6 +585,9 @@ class Emu:
                 W_.exec = W_.masks[i.m.n].copy()
             elif op == "exec_all":
                 W_.exec = np.ones(64, bool)
+            elif op == "exec_lane0":
+                W_.exec = np.zeros(64, bool)
+                W_.exec[0] = True
             elif op == "v_cndmask":
                 touch(regs_of(i.a) + regs_of(i.b), regs_of(i.d), i.text)
                 v[i.d.n] = np.where(W_.vcc, rd32(i.b), rd32(i.a))
@@ -578,6 +605,15 @@ class Emu:
                 self._lds_write(w, np.concatenate([wd, wd + 1]), "writes")
                 lo, hi = rd64(i.data)
                 self.lds[wd], self.lds[wd + 1] = lo, hi
+                W_.lgkm_q.append(("dswrite", regs_of(i.data)))
+            elif op == "ds_write_b32":
+                touch(regs_of(i.addr) + regs_of(i.data), [], i.text)
+                a = (rd32(i.addr).astype(np.int64) + i.off)[W_.exec]
+                assert np.all(a % 4 == 0) and a.max() + 4 <= self.lds.size * 4, "LDS address"
+                wd = a // 4
+                assert len(set(wd.tolist())) == len(wd), "two lanes store to one LDS word"
+                self._lds_write(w, wd, "writes")
+                self.lds[wd] = rd32(i.data)[W_.exec]
                 W_.lgkm_q.append(("dswrite", regs_of(i.data)))
             elif op == "ds_read_b64":
                 touch(regs_of(i.addr), regs_of(i.d), i.text)
@@ -620,11 +656,22 @@ class Emu:
                     m = W_.exec
                     arr[wd[m]], arr[wd[m] + 1] = lo[m], hi[m]
                     W_.vm_q.append(("store", regs_of(i.data)))
-            elif op == "s_waitcnt":
+            elif op in ("s_waitcnt", "s_waitcnt_x"):
                 if i.vmcnt is not None:
                     while len(W_.vm_q) > i.vmcnt: W_.vm_q.pop(0)
                 if i.lgkmcnt is not None:
-                    while len(W_.lgkm_q) > i.lgkmcnt: W_.lgkm_q.pop(0)
+                    # (scalar memory returns out of order with LDS: with one in flight only lgkmcnt(0) guarantees anything about IT;
+                    # the LDS operations in front of the allowed count are complete either way -- an smem entry is kept at the
+                    # queue's end until a wait for zero)
+                    if i.lgkmcnt == 0:
+                        W_.lgkm_q.clear()
+                        W_.smem_regs.clear()
+                    else:
+                        # the case that matters for safety: the atomic has already returned, so only LDS operations hold the count
+                        lds_q = [x for x in W_.lgkm_q if x[0] != "smem"]
+                        n_sm = len(W_.lgkm_q) - len(lds_q)
+                        while len(lds_q) > i.lgkmcnt: lds_q.pop(0)
+                        W_.lgkm_q = lds_q + [("smem", [])] * n_sm
             elif op == "s_mov":
                 s[i.d.n] = srd(i.a)
             elif op == "s_mov64":
@@ -641,9 +688,35 @@ class Emu:
                 s[i.d.n] = r & 0xffffffff
             elif op == "s_cselect":
                 s[i.d.n] = srd(i.a) if W_.scc else srd(i.b)
-            elif op in ("s_cmp_lg", "s_cmp_eq", "s_cmp_lt"):
+            elif op in ("s_cmp_lg", "s_cmp_eq", "s_cmp_lt", "s_cmp_ge"):
                 a, b = srd(i.a), srd(i.b)
-                W_.scc = int((a != b) if op == "s_cmp_lg" else (a < b) if op == "s_cmp_lt" else (a == b))
+                W_.scc = int((a != b) if op == "s_cmp_lg" else (a < b) if op == "s_cmp_lt" else (a >= b) if op == "s_cmp_ge" else (a == b))
+            elif op == "s_mul_i32":
+                s[i.d.n] = (srd(i.a) * srd(i.b)) & 0xffffffff
+            elif op == "s_mul_hi_u32":
+                s[i.d.n] = ((srd(i.a) * srd(i.b)) >> 32) & 0xffffffff
+            elif op == "s_mul_hi_i32":
+                sg = lambda u: u - (1 << 32) if u & 0x80000000 else u
+                s[i.d.n] = ((sg(srd(i.a)) * sg(srd(i.b))) >> 32) & 0xffffffff
+            elif op == "s_and_b32":
+                r = srd(i.a) & srd(i.b)
+                s[i.d.n] = r
+                W_.scc = int(r != 0)
+            elif op == "s_min_u32":
+                a, b = srd(i.a), srd(i.b)
+                s[i.d.n] = min(a, b)
+                W_.scc = int(a <= b)
+            elif op == "s_atomic_add":
+                # (the waves of the emulated workgroup run one after the other: the read-modify-write is atomic by construction;
+                # `atomic_stride` > 1 stands for the other workgroups of a launch that draw from the same counter in between)
+                base = srd(i.sbase.lo) | (srd(i.sbase.hi) << 32)
+                b0, arr = self._region(base)
+                wd = (base - b0) // 4
+                old = int(arr[wd])
+                arr[wd] = (old + srd(i.d) * getattr(self, "atomic_stride", 1)) & 0xffffffff
+                s[i.d.n] = old
+                W_.smem_regs.add(i.d.n)
+                W_.lgkm_q.append(("smem", []))
             elif op in ("s_cbranch_scc1", "s_cbranch_scc0", "s_branch"):
                 take = True if op == "s_branch" else (W_.scc == 1) if op == "s_cbranch_scc1" else (W_.scc == 0)
                 if take:
