@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert set(declared_symbols()) <= exported
     # library and header agree on the ABI revision (2: prot_info.run_align, prot_sweep_stats, PROT_CFG_* flags; 4: PROT_CFG_OVERLAP_ADD)
     declared = int(re.search(r"#define\s+PROT_ABI_VERSION\s+(\d+)", open(HDR).read()).group(1))
-    assert lib.prot_abi_version() == declared == 5
+    assert lib.prot_abi_version() == declared == 6   # (6: PROT_CFG_STATIC_RUNS)
 
 
 def test_header_constants_and_python_mirror_agree(pkg):
