@@ -692,7 +692,12 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
             eng.reset()
             peaks.zero_()
             if rank > 0:
-                sweep_dist.prime_history(eng, halo, st)
+                eng.prime_dev(halo.data_ptr(), H, H, st)   # (the frames in front of the shard pass into the history: a copy)
+            if world > 1:
+                # two phases (round 5): every rank seeds the pruning bound from a sparse sample of its shard, the sampled tables are
+                # merged, and the main pass lists against the GLOBAL bound (a shard alone lists twice what the whole file lists)
+                eng.sweep_seed_dev(x.data_ptr(), n, n, 0, 360, 1, -1, peaks.data_ptr(), flags, max(8, 64 // world), st)
+                dist.all_reduce(peaks, op=dist.ReduceOp.MAX)
             eng.sweep_dev(x.data_ptr(), n, n, 0, 360, 1, -1, peaks.data_ptr(), flags, st)
             if world > 1:
                 dist.all_reduce(peaks, op=dist.ReduceOp.MAX)
@@ -756,17 +761,32 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
             # makes the sweep's time depend on the material, so the shards are not equal; predicted_speedup = single pass /
             # slowest shard.  A PREDICTION (no collective, no host link, one device's clocks), never `value`.
             plan8 = sweep_dist.plan_shards(total, P, 8, align=eng.shard_align_blocks())
-            shard_ms = []
+            # phase one of all eight shards first (untimed here): the merged table every shard would hold after the first all-reduce
+            seeds = []
             for r8, (c0, c1) in enumerate(plan8):
                 xs8 = x[:, c0 * P:c1 * P]
-                halo8 = _sweep_signal(torch, np, dev, n_chn, c0 * P - H, H, 4321, kind).contiguous() if r8 > 0 else None
+                fl8 = (pkg.F_STREAM_START if r8 == 0 else 0) | (pkg.F_STREAM_END if r8 == 7 else 0)
+                eng.reset()
+                peaks.zero_()
+                eng.sweep_seed_dev(xs8.data_ptr(), x.shape[1], xs8.shape[1], 0, 360, 1, -1, peaks.data_ptr(), fl8, 8, st)
+                torch.cuda.synchronize()
+                seeds.append(peaks.clone())
+            gseed = torch.stack(seeds).amax(0)
+            shard_ms, merged = [], torch.zeros_like(peaks)
+            for r8, (c0, c1) in enumerate(plan8):
+                xs8 = x[:, c0 * P:c1 * P]
+                halo8 = x[:, c0 * P - H:c0 * P].contiguous() if r8 > 0 else None   # (the frames really in front of the shard: the tables are compared below)
                 fl8 = (pkg.F_STREAM_START if r8 == 0 else 0) | (pkg.F_STREAM_END if r8 == 7 else 0)
 
                 def shard_pass():
+                    # what one rank of eight does: reset, prime, its own seeding pass, [all-reduce: here the merged table is copied
+                    # in its place], the main pass against the global bound, [all-reduce]
                     eng.reset()
                     peaks.zero_()
                     if r8 > 0:
-                        sweep_dist.prime_history(eng, halo8, st)
+                        eng.prime_dev(halo8.data_ptr(), H, H, st)
+                    eng.sweep_seed_dev(xs8.data_ptr(), x.shape[1], xs8.shape[1], 0, 360, 1, -1, peaks.data_ptr(), fl8, 8, st)
+                    peaks.copy_(gseed)
                     eng.sweep_dev(xs8.data_ptr(), x.shape[1], xs8.shape[1], 0, 360, 1, -1, peaks.data_ptr(), fl8, st)
                 for _ in range(8):  # (the same steady state as the single pass it is compared with)
                     shard_pass()
@@ -778,9 +798,14 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
                 e1.record(torch.cuda.current_stream())
                 torch.cuda.synchronize()
                 shard_ms.append(e0.elapsed_time(e1) / 5)
+                merged = torch.maximum(merged, peaks)
             res[kind]["predicted_8gpu"] = {"per_shard_ms": shard_ms, "single_pass_ms": dev_ms,
                                            "predicted_speedup": dev_ms / max(shard_ms),
-                                           "note": "PREDICTED from eight same-device shard passes; no N > 1 run exists"}
+                                           "two_phase": True,
+                                           "merged_table_identical_single_pass": bool((merged.cpu().numpy() == pk).all()),
+                                           "note": "PREDICTED from eight same-device shard passes (each: reset, history primed by a copy, its "
+                                                   "own seeding pass, the merged seed table copied in where the first all-reduce would write "
+                                                   "it, the main pass against that global bound); no collective, no host link; no N > 1 run exists"}
         if kind == "harmonic" and full:
             # host-inclusive pass: the shard comes from pinned host memory inside the timed region, in chunks whose
             # upload overlaps the sweep of the chunk before (two device buffers, a copy stream)

@@ -288,6 +288,18 @@ int prot_sweep_stats_ex (prot_engine* e, uint64_t out[4]);
  * out = { channel-frames the fused pass has tested since the last reset, channel-frames it listed }.  Same tables, bit for bit. */
 int prot_sweep_stats_fused (prot_engine* e, uint64_t out[2]);
 
+/* ABI 6.  Sharded sweeps in two phases.  A shard that seeds its pruning bound from its own frames lists about twice what the whole
+ * file lists against one bound; so: every shard calls prot_sweep_seed_dev on its data (ONLY the seeding pass of the fused route, over
+ * about n_blocks device blocks spread through the call -- 64 / shards is plenty; nothing of the engine's state moves, the table gets
+ * the sample's maxima), the tables are merged (MAX all-reduce), and prot_sweep_dev on the same data then skips its own seeding
+ * and lists against the merged bound.  Every entry a seed raises is a peak of real frames, so the final merged table is
+ * bit-identical to a single pass.  Engines / calls the fused route does not take seed nothing (PROT_OK).
+ * prot_engine_prime_dev: n_frames of input pass into the history without being transformed -- what a shard does with the frames
+ * in front of its range (cli/phase-rotate.cc: the previous block + the filter's memory). */
+int prot_sweep_seed_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_frames, int ang_start,
+                         int ang_end, int ang_stride, int chn, float* d_peaks, uint32_t flags, int n_blocks, void* stream);
+int prot_engine_prime_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_frames, void* stream);
+
 /* ---- several GPUs of one node, single process --------------------------- */
 /* MAX all-reduce of the engines' OWN peak tables (prot_cli_peaks_dev) across
  * their GPUs: one ncclAllReduce(ncclMax, float[n_chn][360]) per engine inside
@@ -302,8 +314,9 @@ int prot_allreduce_peaks (prot_engine* const* engines, int n);
 /* analyze_file (cli/phase-rotate.cc:565-587) sharded over n engines: engine r
  * sweeps a run_align-aligned range of frame blocks for all requested angles, primed
  * with the input history in front of its range; the first-block rule stays
- * with engine 0, zero-padding and the flush block with the last one; then
- * prot_allreduce_peaks.  Bit-identical to prot_cli_analyze_file on one engine. */
+ * with engine 0, zero-padding and the flush block with the last one; in two
+ * phases (seed, prot_allreduce_peaks, main pass, prot_allreduce_peaks: see
+ * prot_sweep_seed_dev).  Bit-identical to prot_cli_analyze_file on one engine. */
 int prot_cli_analyze_file_multi (prot_engine* const* engines, int n, const float* data, uint64_t n_frames,
                                  int ang_start, int ang_end, int ang_stride, int chn);
 

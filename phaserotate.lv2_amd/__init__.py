@@ -42,6 +42,7 @@ ABI_SYMBOLS = (
     "prot_cli_apply_file", "prot_cli_peak", "prot_cli_peak_all", "prot_cli_peaks",
     "prot_cli_peaks_dev", "prot_allreduce_peaks", "prot_cli_analyze_file_multi", "prot_sweep_stats",
     "prot_sweep_stats_ex", "prot_sweep_stats_fused", "prot_cli_file_resident",
+    "prot_sweep_seed_dev", "prot_engine_prime_dev",
 )
 
 
@@ -117,6 +118,11 @@ def load_library():
     lib.prot_lv2_set_max_block.argtypes = [C.c_void_p, C.c_uint32]
     lib.prot_sweep_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.prot_sweep_seed_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+    lib.prot_sweep_seed_dev.restype = C.c_int
+    lib.prot_engine_prime_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]
+    lib.prot_engine_prime_dev.restype = C.c_int
     lib.prot_lv2_run.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                  C.c_uint32, _f32p]
     lib.prot_lv2_get_angle.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
@@ -143,7 +149,7 @@ def load_library():
 
 
 # csrc/prot_internal.h: process-wide switches for tests and bench.py (NOT part of the drop-in boundary)
-TEST_SWEEP_UNPRUNED, TEST_EDGE_PATH_ONLY, TEST_LV2_STAGED, TEST_ALLREDUCE, TEST_SWEEP_UNFUSED, TEST_LV2_NO_SERVER, TEST_LV2_NO_BAR = 0, 1, 2, 3, 4, 5, 6
+TEST_SWEEP_UNPRUNED, TEST_EDGE_PATH_ONLY, TEST_LV2_STAGED, TEST_ALLREDUCE, TEST_SWEEP_UNFUSED, TEST_LV2_NO_SERVER, TEST_LV2_NO_BAR, TEST_SEED_MFMA = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 def set_test_option(option, value):
@@ -284,6 +290,17 @@ class Engine:
         _check(self._lib.prot_sweep_dev(self._h, d_in, in_stride, n_frames, ang_start, ang_end,
                                         ang_stride, chn, d_peaks or None, flags, stream),
                "prot_sweep_dev")
+
+    def sweep_seed_dev(self, d_in, in_stride, n_frames, ang_start, ang_end, ang_stride, chn=-1,
+                       d_peaks=0, flags=0, n_blocks=8, stream=0):
+        """phase one of a sharded sweep: only the seeding pass of the fused route, over about n_blocks device blocks of the call"""
+        _check(self._lib.prot_sweep_seed_dev(self._h, d_in, in_stride, n_frames, ang_start, ang_end,
+                                             ang_stride, chn, d_peaks or None, flags, n_blocks, stream),
+               "prot_sweep_seed_dev")
+
+    def prime_dev(self, d_in, in_stride, n_frames, stream=0):
+        """n_frames of input pass into the history untransformed (the frames in front of a shard)"""
+        _check(self._lib.prot_engine_prime_dev(self._h, d_in, in_stride, n_frames, stream), "prot_engine_prime_dev")
 
     def peaks(self):
         out = np.empty((self.n_chn, MAXSAMPLE), np.float32)

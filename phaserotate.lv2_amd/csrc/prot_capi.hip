@@ -440,6 +440,8 @@ struct prot_engine {
 	uint64_t         fused_frames = 0;          // channel-frames the fused pass has tested since the last reset
 	DevBuf<unsigned long long> d_fused_surv;    // ... and how many of them it kept (device counter)
 	bool             sweep_seeded = false;      // the table holds a bound for the angle list of angles_last
+	bool             sweep_seeded_ext = false;  // ... put there by prot_sweep_seed_dev (and whatever the caller merged into it): the next prot_sweep_dev keeps it even at pos 0
+	bool             seed_chunk_ready = false;  // analyze_range: the range's first chunk is on the device already (its seeding phase uploaded it)
 	int              last_n_lists = 0;          // geometry of the last fused pass (prot_internal_fused_lists)
 	int64_t          last_cap     = 0;
 	PinBuf<float>  h_io;
@@ -591,8 +593,10 @@ int pick_run_frames (const prot_engine* e, uint64_t n_out, int n_chn, int unit_f
 }
 
 int hist_advance (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_in, int chn0, int n_chn, hipStream_t s);
+// phase 0: the whole range (one engine); 1: prime the history, upload the range's first chunk and SEED the bound from it (sharded
+// analysis: the tables are merged before the main pass); 2: the main pass behind phase 1
 int analyze_range (prot_engine* e, const float* data, uint64_t f0, uint64_t nf, bool is_first, bool is_last, int ang_start,
-                   int ang_end, int ang_stride, int chn);
+                   int ang_end, int ang_stride, int chn, int phase = 0, int seed_blocks = 64);
 
 // One-round launches of the polyphase kernel (every workgroup resident at once): run lengths by DISPATCH RANK, see
 // olapoly_kernel.  `slots` = resident workgroups (CUs x 3 for fp32 samples, CUs x 4 for fp16 samples).
@@ -1772,6 +1776,8 @@ int prot_engine_reset (prot_engine* e)
 		HIP_TRY (hipStreamSynchronize (zs));
 		e->reset_pending = false;
 	}
+	e->sweep_seeded_ext = false;
+	e->seed_chunk_ready = false;
 	e->last_foreign   = false; // (whatever comes next is ordered behind the engine's stream, which is behind that call)
 	e->last_stream_id = nullptr;
 	return PROT_OK;
@@ -2043,8 +2049,10 @@ int prot_apply_dev_f16_ramp (prot_engine* e, const void* d_in, int64_t in_stride
 	return d_rot ? apply_f16 (e, d_in, in_stride, n_in, d_out, out_stride, n_out, nullptr, d_rot, flags, stream) : PROT_EINVAL;
 }
 
-int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_frames, int ang_start,
-                    int ang_end, int ang_stride, int chn, float* d_peaks, uint32_t flags, void* stream)
+// seed_blocks > 0: ONLY the seeding pass of the fused route over about that many blocks of the call (nothing of the engine's state
+// moves; a call the fused route does not take seeds nothing and returns PROT_OK)
+static int sweep_dev_impl (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_frames, int ang_start,
+                           int ang_end, int ang_stride, int chn, float* d_peaks, uint32_t flags, void* stream, int seed_blocks)
 {
 	if (!e || !d_in || e->info.kind != PROT_KIND_CLI || ang_stride < 1 || chn >= (int)e->info.n_chn) {
 		return PROT_EINVAL;
@@ -2116,10 +2124,17 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 	// Hilbert pass is the overlap-save kernel (blksiz 2048, 4096), pruned sweeps, calls long enough to carry five more launches;
 	// the tables are bit-identical to the separate passes' (same blocks, same arithmetic per frame, max is order-free).
 	const bool fused = fusable && n_ang > 0 && n_out >= ((uint64_t)1 << 20);
+	if (seed_blocks > 0 && !fused) {
+		return PROT_OK;
+	}
 	if (fused) {
 		const float* hist_old = e->d_hist[e->hist_cur].p; (void)hist_old;
-		if (e->pos == 0) {
+		if (e->pos == 0 && !e->sweep_seeded_ext) {
 			e->sweep_seeded = false;
+		}
+		if (e->sweep_seeded_ext && seed_blocks == 0) { // the bound was seeded (and merged across shards) by the caller: two-phase sharded sweeps
+			e->sweep_seeded     = true;
+			e->sweep_seeded_ext = false;
 		}
 		int rc2;
 		const bool first_fused = e->d_fused_surv.p == nullptr;
@@ -2144,7 +2159,7 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		}
 		// the bound is seeded from a sparse sample of the call: every k-th block, about 64 of them, at most every 8th
 		const uint64_t n_blocks    = n_out / (uint64_t)e->info.run_align;
-		const bool     sample_pass = !e->sweep_seeded && n_blocks >= 64;
+		const bool     sample_pass = seed_blocks > 0 || (!e->sweep_seeded && n_blocks >= 64);
 		auto fill = [&] (FusedSweep& fs, int pass) {
 			fs.peaks         = pk;
 			fs.angles        = e->d_angles.p;
@@ -2154,6 +2169,9 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 			fs.sample        = pass == 0;
 			fs.stride_blocks = (int)std::max<uint64_t> (8, n_blocks / 64); // (every 64th ... 512th block of an hour of material:
 			// the same times to the run-to-run spread; the bound hardly depends on it)
+			if (seed_blocks > 0) { // a shard's share of the sample (prot_sweep_seed_dev)
+				fs.stride_blocks = (int)std::max<uint64_t> (1, std::min<uint64_t> (n_blocks / (uint64_t)seed_blocks, (uint64_t)1 << 20));
+			}
 			if (const char* o = tuning_env ("PROT_FUSE_STRIDE")) {
 				fs.stride_blocks = std::max (2, atoi (o));
 			}
@@ -2180,7 +2198,7 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 				return rc2;
 			}
 		}
-		for (int pass = sample_pass ? 0 : 1; pass < 2; ++pass) {
+		for (int pass = sample_pass ? 0 : 1; pass < (seed_blocks > 0 ? 1 : 2); ++pass) {
 			FusedSweep fs {};
 			fill (fs, pass);
 			rc = ola_launch (e, d_in, in_stride, n_frames, f_out, f_ostride, n_out, nullptr, nullptr, true, false, c0, nc, s,
@@ -2190,6 +2208,17 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 			}
 			e->last_n_lists = fs.n_lists;
 			e->last_cap     = fs.cap;
+			if (pass == 0 && g_test_opt[PROT_TEST_SEED_MFMA].load () == 0) {
+				// the seeding pass's lists: a lower bound is all they have to give (prot_sweep.hip: sweep_seed_eval_kernel)
+				hipError_t err0 = prot::launch_sweep_seed_eval (e->d_surv.p, e->d_surv_cnt.p, fs.n_lists, fs.cap, e->d_angles.p, n_ang, e->d_lut.p, pk, c0, nc,
+				                                                e->d_part.p, prot::sweep_scratch_floats (), s);
+				if (err0 == hipSuccess) {
+					continue;
+				}
+				if (err0 != hipErrorInvalidValue) { // (InvalidValue: more lists than the scratch table holds -- the matrix-core route below)
+					return hip_fail (err0, "sweep seed evaluation launch");
+				}
+			}
 			const int64_t desc_stride = (int64_t)fs.n_lists + (int64_t)(n_out / 1024) + 8;
 			hipError_t    err = prot::launch_sweep_plan (e->d_surv_cnt.p, fs.n_lists, fs.cap, e->d_desc.p, desc_stride, e->d_nsteps.p, nc,
 			                                             pass == 1 ? e->d_fused_surv.p : nullptr, s);
@@ -2223,6 +2252,10 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 				(void)hipMemsetAsync (e->d_ctr.p, 0, (size_t)e->info.n_chn * 32 * 32 * sizeof (unsigned), s);
 				return hip_fail (err, "sweep kernel launch (lists)");
 			}
+		}
+		if (seed_blocks > 0) {
+			e->sweep_seeded_ext = true;
+			return PROT_OK;
 		}
 		e->sweep_seeded = true;
 		e->fused_frames += n_out * (uint64_t)nc;
@@ -2315,6 +2348,38 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 	}
 	e->pos += n_out;
 	return PROT_OK;
+}
+
+int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_frames, int ang_start,
+                    int ang_end, int ang_stride, int chn, float* d_peaks, uint32_t flags, void* stream)
+{
+	return sweep_dev_impl (e, d_in, in_stride, n_frames, ang_start, ang_end, ang_stride, chn, d_peaks, flags, stream, 0);
+}
+
+int prot_sweep_seed_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_frames, int ang_start,
+                         int ang_end, int ang_stride, int chn, float* d_peaks, uint32_t flags, int n_blocks, void* stream)
+{
+	if (n_blocks < 1) {
+		return PROT_EINVAL;
+	}
+	return sweep_dev_impl (e, d_in, in_stride, n_frames, ang_start, ang_end, ang_stride, chn, d_peaks, flags, stream, n_blocks);
+}
+
+int prot_engine_prime_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_frames, void* stream)
+{
+	if (!e || (!d_in && n_frames)) {
+		return PROT_EINVAL;
+	}
+	if (n_frames == 0) {
+		return PROT_OK;
+	}
+	HIP_TRY (hipSetDevice (e->device));
+	CallStream s (e, stream);
+	const int  rc = hist_advance (e, d_in, in_stride, n_frames, 0, (int)e->info.n_chn, s);
+	if (rc == PROT_OK) {
+		e->pos += n_frames;
+	}
+	return rc;
 }
 
 float* prot_cli_peaks_dev (prot_engine* e)
@@ -2864,11 +2929,11 @@ constexpr int kNcclFloat32 = 7, kNcclMax = 2; // rccl.h: ncclDataType_t / ncclRe
 
 // sweep frames [f0, f0 + nf) of an in-memory interleaved file on one engine
 static int analyze_range_impl (prot_engine* e, const float* data, uint64_t f0, uint64_t nf, bool is_first, bool is_last,
-                               int ang_start, int ang_end, int ang_stride, int chn);
+                               int ang_start, int ang_end, int ang_stride, int chn, int phase, int seed_blocks);
 int analyze_range (prot_engine* e, const float* data, uint64_t f0, uint64_t nf, bool is_first, bool is_last,
-                   int ang_start, int ang_end, int ang_stride, int chn)
+                   int ang_start, int ang_end, int ang_stride, int chn, int phase, int seed_blocks)
 {
-	const int rc = analyze_range_impl (e, data, f0, nf, is_first, is_last, ang_start, ang_end, ang_stride, chn);
+	const int rc = analyze_range_impl (e, data, f0, nf, is_first, is_last, ang_start, ang_end, ang_stride, chn, phase, seed_blocks);
 	if (rc != PROT_OK) {
 		// an error exit of the double-buffered path may leave an upload from the caller's `data` or kernels on the
 		// staging buffers in flight: drain both streams before the caller frees the file or destroys the engine
@@ -2880,7 +2945,7 @@ int analyze_range (prot_engine* e, const float* data, uint64_t f0, uint64_t nf, 
 	return rc;
 }
 static int analyze_range_impl (prot_engine* e, const float* data, uint64_t f0, uint64_t nf, bool is_first, bool is_last,
-                               int ang_start, int ang_end, int ang_stride, int chn)
+                               int ang_start, int ang_end, int ang_stride, int chn, int phase, int seed_blocks)
 {
 	HIP_TRY (hipSetDevice (e->device));
 	const uint32_t nc = e->info.n_chn;
@@ -2901,20 +2966,46 @@ static int analyze_range_impl (prot_engine* e, const float* data, uint64_t f0, u
 			HIP_TRY (hipEventCreateWithFlags (&e->ev_free[i], hipEventDisableTiming));
 		}
 	}
-	if (!is_first) {
-		// prime the input history with the H frames in front of the range (Hilbert output discarded)
+	if (!is_first && phase != 2) {
+		// prime the input history with the H frames in front of the range: they only have to pass into the history (round 5: a copy
+		// kernel instead of a Hilbert launch whose output was thrown away)
 		const uint64_t h = std::min<uint64_t> (H, f0);
 		HIP_TRY (hipMemcpyAsync (e->d_inter.p, data + (f0 - h) * nc, h * nc * sizeof (float), hipMemcpyHostToDevice, s));
 		hipError_t err = prot::launch_deinterleave (e->d_inter.p, e->d_in.p, (int64_t)cap, (int64_t)h, (int)nc, s);
 		if (err != hipSuccess) {
 			return hip_fail (err, "deinterleave launch");
 		}
-		rc = prot_apply_dev (e, e->d_in.p, (int64_t)cap, h, e->d_out.p, (int64_t)cap, h, nullptr, PROT_F_HILBERT, s);
+		rc = hist_advance (e, e->d_in.p, (int64_t)cap, h, 0, (int)nc, s);
+		if (rc) {
+			return rc;
+		}
+		e->pos += h;
+		HIP_TRY (hipStreamSynchronize (s));
+	}
+	if (phase == 1) {
+		// the range's first chunk goes up now and stays where the main pass expects it; the bound is seeded from a sparse sample of it
+		const uint64_t n = std::min (chunk, nf);
+		e->seed_chunk_ready = false;
+		if (n == 0) {
+			return PROT_OK;
+		}
+		HIP_TRY (hipMemcpyAsync (e->d_inter.p, data + f0 * nc, n * nc * sizeof (float), hipMemcpyHostToDevice, s));
+		hipError_t err = prot::launch_deinterleave (e->d_inter.p, e->d_in.p, (int64_t)cap, (int64_t)n, (int)nc, s);
+		if (err != hipSuccess) {
+			return hip_fail (err, "deinterleave launch");
+		}
+		const bool     last = n >= nf;
+		const uint32_t fl   = (is_first ? PROT_F_STREAM_START : 0) | (last && is_last ? PROT_F_STREAM_END : 0);
+		rc = prot_sweep_seed_dev (e, e->d_in.p, (int64_t)cap, n, ang_start, ang_end, ang_stride, chn, nullptr, fl, seed_blocks, s);
 		if (rc) {
 			return rc;
 		}
 		HIP_TRY (hipStreamSynchronize (s));
+		e->seed_chunk_ready = true;
+		return PROT_OK;
 	}
+	const bool have_first = phase == 2 && e->seed_chunk_ready;
+	e->seed_chunk_ready   = false;
 	uint64_t pos   = 0;
 	bool     first = true;
 	int      i     = 0;
@@ -2926,7 +3017,7 @@ static int analyze_range_impl (prot_engine* e, const float* data, uint64_t f0, u
 		float*         di   = b ? e->d_inter_b.p : e->d_inter.p;
 		float*         dn   = b ? e->d_in_b.p : e->d_in.p;
 		hipStream_t    cs   = dbl ? e->copy_stream : s;
-		if (n) {
+		if (n && !(have_first && i == 0)) { // (the seeding phase of a sharded analysis has put the first chunk there already)
 			if (dbl && used[b]) {
 				HIP_TRY (hipStreamWaitEvent (cs, e->ev_free[b], 0)); // the sweep that read this pair two chunks ago
 			}
@@ -3076,26 +3167,39 @@ int prot_cli_analyze_file_multi (prot_engine* const* engines, int n, const float
 			last_nonempty = r;
 		}
 	}
-	for (int r = 0; r < n; ++r) {
-		const uint64_t f0 = b0[r] * P;
-		const uint64_t f1 = std::min (b0[r + 1] * P, n_frames);
-		const bool     is_last = r == last_nonempty;
-		if (f1 <= f0 && !(is_last && r == 0)) {
-			continue; // more engines than block pairs
+	// Two phases (round 5): every engine seeds the pruning bound from a sparse sample of ITS range's first chunk, the sampled tables
+	// are merged (one more 2.9 KB MAX all-reduce), and the main passes list against the GLOBAL bound -- a shard cannot know that the
+	// loud passage is somewhere else: on its own bound it lists twice the frames the whole file lists.  Whatever the sample raises
+	// in a table is a peak of real frames of the file, so the merged table is a valid lower bound of the final one for every
+	// engine, and the final merge is bit-identical to a single pass (max is exact and order-free).
+	const int seed_blocks = std::max (8, 64 / n);
+	for (int phase = (n > 1 ? 1 : 0); phase <= (n > 1 ? 2 : 0); ++phase) {
+		th.clear ();
+		for (int r = 0; r < n; ++r) {
+			const uint64_t f0 = b0[r] * P;
+			const uint64_t f1 = std::min (b0[r + 1] * P, n_frames);
+			const bool     is_last = r == last_nonempty;
+			if (f1 <= f0 && !(is_last && r == 0)) {
+				continue; // more engines than block pairs
+			}
+			th.emplace_back ([=, &rcs] () {
+				rcs[r] = analyze_range (engines[r], data, f0, f1 - f0, r == 0, is_last, ang_start, ang_end, ang_stride, chn, phase, seed_blocks);
+			});
 		}
-		th.emplace_back ([=, &rcs] () {
-			rcs[r] = analyze_range (engines[r], data, f0, f1 - f0, r == 0, is_last, ang_start, ang_end, ang_stride, chn);
-		});
-	}
-	for (auto& t : th) {
-		t.join ();
-	}
-	for (int r = 0; r < n; ++r) {
-		if (rcs[r]) {
-			return rcs[r];
+		for (auto& t : th) {
+			t.join ();
+		}
+		for (int r = 0; r < n; ++r) {
+			if (rcs[r]) {
+				return rcs[r];
+			}
+		}
+		const int rc = prot_allreduce_peaks (engines, n);
+		if (rc) {
+			return rc;
 		}
 	}
-	return prot_allreduce_peaks (engines, n);
+	return PROT_OK;
 }
 
 int prot_cli_apply_file (prot_engine* e, const float* data, uint64_t n_frames, const int* angles, float* out)

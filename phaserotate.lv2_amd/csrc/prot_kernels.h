@@ -200,6 +200,9 @@ constexpr int kSweepThrFloats = 4 + 16; // per channel: thr [n_chn][4], then thr
 hipError_t launch_sweep_plan (const unsigned* cnt, int n_lists, int64_t cap, uint2* desc, int64_t desc_stride, unsigned* n_steps, int n_chn,
                               unsigned long long* total, hipStream_t s);
 hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s);
+// the seeding pass's lists against every requested angle by plain vector arithmetic, folded into the table scaled down by 1e-4
+hipError_t launch_sweep_seed_eval (const float2* surv, const unsigned* cnt, int n_lists, int64_t cap, const int* angles, int n_angles, const float* lut,
+                                   float* peaks, int chn0, int n_chn, float* part, size_t part_floats, hipStream_t s);
 size_t     sweep_scratch_floats ();
 
 // peaks[c][slot] = max(peaks[c][slot], max_{t in [0,n)} |x[c][t]|)   (angle 0, Q4)

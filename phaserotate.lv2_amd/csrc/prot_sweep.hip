@@ -1085,6 +1085,105 @@ hipError_t launch_sweep_plan (const unsigned* cnt, int n_lists, int64_t cap, uin
 	return hipGetLastError ();
 }
 
+// The SEEDING pass's evaluation (round 5).  The seeding pass lists every frame of a sparse sample of blocks (no bound yet); until
+// round 5 those lists went through the same plan / matrix-core / merge kernels as the main pass's, 55-60 us of dependent round
+// trips for a few hundred thousand frames -- a fixed cost every shard of a sharded sweep pays again.  All a seed has to be is a
+// LOWER bound of the final peaks: plain vector arithmetic, one angle per thread, every list entry from LDS, the maxima scaled
+// down by 1e-4 (whatever rounding this arithmetic has against the matrix core's, the frame that holds an angle's true maximum
+// exceeds the scaled value, is listed by the main pass and puts the exact value into the table: the tables stay bit-identical to
+// the unpruned sweep's) and folded into the table by atomics (look first): a few thousand on ninety cache lines.
+// Geometry: one workgroup per list and per 256 angles, one angle per thread; the list's entries pass through LDS in chunks of 1024
+// (coalesced loads, broadcast reads of two entries each); the per-list maxima go to a scratch table, a second small kernel folds
+// them into the peak table (as atomics they would be a few hundred thousand on ninety cache lines: the 100-200 us that made
+// sweep_kernel give up atomics in round 3).
+__global__ __launch_bounds__ (256) void sweep_seed_eval_kernel (const float2* __restrict__ surv, const unsigned* __restrict__ cnt, int n_lists, int64_t cap,
+                                                                  const int* __restrict__ angles, int n_angles, const float* __restrict__ lut,
+                                                                  float* __restrict__ part)
+{
+	__shared__ __attribute__ ((aligned (16))) float2 st[1024];
+	const int   t   = threadIdx.x;
+	const int   l   = (int)blockIdx.x >> 2, qt = (int)blockIdx.x & 3, cl = blockIdx.z; // (a quarter of list l: four workgroups per list)
+	const int   idx = (int)blockIdx.y * 256 + t; // place in the angle list
+	const bool  on  = idx < n_angles;
+	const int   a   = on ? angles[idx] : 0;
+	const float sa = lut[2 * a], ca = lut[2 * a + 1]; // lut = {sin, cos}
+	float       m0 = 0.f, m1 = 0.f;
+	const unsigned      n_all = cnt[(int64_t)cl * n_lists + l];
+	const unsigned      qn    = ((n_all + 7u) / 8u) * 2u;        // entries per quarter (even: the LDS reads take pairs)
+	const unsigned      q0    = qn * (unsigned)qt < n_all ? qn * (unsigned)qt : n_all;
+	const unsigned      n     = n_all - q0 < qn ? n_all - q0 : qn;
+	const float2* const list  = surv + ((int64_t)cl * n_lists + l) * cap + q0;
+	for (unsigned base = 0; base < n; base += 1024u) {
+		const unsigned m = n - base < 1024u ? n - base : 1024u;
+		__syncthreads ();
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const unsigned i = (unsigned)t + 256u * (unsigned)k;
+			st[i]            = i < m ? list[base + i] : make_float2 (0.f, 0.f); // (padding entries are zeros: they raise nothing)
+		}
+		__syncthreads ();
+		const float4* const s4 = reinterpret_cast<const float4*> (st);
+		const unsigned      m2 = (m + 1u) >> 1;
+#pragma unroll 8
+		for (unsigned i = 0; i < m2; ++i) {
+			const float4 e = s4[i];
+			m0             = fmaxf (m0, fabsf (fmaf (sa, e.y, ca * e.x)));
+			m1             = fmaxf (m1, fabsf (fmaf (sa, e.w, ca * e.z)));
+		}
+	}
+	if (on) {
+		part[((int64_t)cl * 4 * n_lists + blockIdx.x) * n_angles + idx] = fmaxf (m0, m1);
+	}
+}
+
+__global__ __launch_bounds__ (256) void sweep_seed_merge_kernel (const float* __restrict__ part, int n_rows, const int* __restrict__ angles, int n_angles,
+                                                                   float* __restrict__ peaks, int chn0)
+{
+	// blockIdx.z = slice of the rows (one in sixteen): eight loads in flight per thread, then one atomic per angle and slice
+	const int idx = (int)blockIdx.x * 256 + (int)threadIdx.x, cl = blockIdx.y;
+	if (idx >= n_angles) {
+		return;
+	}
+	const float* const col = part + (int64_t)cl * n_rows * n_angles + idx;
+	float m[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+	const int step = (int)gridDim.z;
+	for (int r = (int)blockIdx.z; r < n_rows; r += 8 * step) {
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const int rr = r + k * step;
+			m[k]         = fmaxf (m[k], rr < n_rows ? col[(int64_t)rr * n_angles] : 0.f);
+		}
+	}
+	const float mx = fmaxf (fmaxf (fmaxf (m[0], m[1]), fmaxf (m[2], m[3])), fmaxf (fmaxf (m[4], m[5]), fmaxf (m[6], m[7])));
+	if (mx > 0.f) {
+		const unsigned  v    = __float_as_uint (mx * 0.9999f);
+		unsigned* const slot = reinterpret_cast<unsigned*> (peaks + (int64_t)(chn0 + cl) * kMaxSample + angles[idx]);
+		if (v > __hip_atomic_load (slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { // (non-negative floats order as their bit patterns)
+			atomicMax (slot, v);
+		}
+	}
+}
+
+hipError_t launch_sweep_seed_eval (const float2* surv, const unsigned* cnt, int n_lists, int64_t cap, const int* angles, int n_angles, const float* lut,
+                                   float* peaks, int chn0, int n_chn, float* part, size_t part_floats, hipStream_t s)
+{
+	if (n_lists <= 0 || n_angles <= 0 || n_chn <= 0) {
+		return hipSuccess;
+	}
+	if (4 * (size_t)n_lists * (size_t)n_angles * (size_t)n_chn > part_floats || 4 * (int64_t)n_lists > 65535 * 16 || part == nullptr) {
+		return hipErrorInvalidValue; // (the caller takes the matrix-core route)
+	}
+	const int  halves = (n_angles + 255) / 256;
+	hipLaunchKernelGGL (sweep_seed_eval_kernel, dim3 ((unsigned)(4 * n_lists), (unsigned)halves, (unsigned)n_chn), dim3 (256), 0, s, surv, cnt, n_lists, cap, angles,
+	                    n_angles, lut, part);
+	hipError_t err = hipGetLastError ();
+	if (err != hipSuccess) {
+		return err;
+	}
+	hipLaunchKernelGGL (sweep_seed_merge_kernel, dim3 ((unsigned)halves, (unsigned)n_chn, 16), dim3 (256), 0, s, part, 4 * n_lists, angles, n_angles, peaks, chn0);
+	return hipGetLastError ();
+}
+
 // floats of scratch a sweep launch may need on this device (every resident-workgroup slot x 4 waves x 360 angles)
 size_t sweep_scratch_floats ()
 {

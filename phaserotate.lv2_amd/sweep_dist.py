@@ -52,14 +52,33 @@ def shard_frames(n_frames, blksiz, plan, rank):
 
 
 def prime_history(engine, halo, stream=0):
-    """Feed `halo` ([n_chn, H] device tensor: the H frames in front of this
-    rank's shard) through the engine so that its input history equals what a
-    single-GPU pass would hold at this point.  The Hilbert output is discarded."""
-    import torch
+    """Pass `halo` ([n_chn, H] device tensor: the H frames in front of this
+    rank's shard) into the engine's input history, which then equals what a
+    single-GPU pass would hold at this point (round 5: a copy kernel,
+    prot_engine_prime_dev; until then a Hilbert launch whose output was thrown away)."""
     n_chn, h = halo.shape
+    if hasattr(engine, "prime_dev"):
+        engine.prime_dev(halo.data_ptr(), h, h, stream)
+        return halo
+    import torch
     scratch = torch.empty_like(halo)
     engine.hilbert_dev(halo.data_ptr(), h, h, scratch.data_ptr(), h, h, 0, stream)
     return scratch  # keep alive until the stream has consumed it
+
+
+def sweep_two_phase(engine, x, peaks, flags, world, stream=0, ang=(0, 360, 1), allreduce=None):
+    """One rank's sharded sweep in two phases: seed the pruning bound from a sparse sample of this shard (x: [n_chn, n] device
+    tensor), merge the sampled tables over the ranks (MAX all-reduce of `peaks`), sweep against the GLOBAL bound, merge again.
+    Bit-identical to a single pass over the whole file (every seeded entry is a peak of real frames; max is exact)."""
+    allreduce = allreduce or allreduce_peaks
+    n_chn, n = x.shape
+    if world > 1:
+        engine.sweep_seed_dev(x.data_ptr(), x.stride(0), n, ang[0], ang[1], ang[2], -1, peaks.data_ptr(), flags, max(8, 64 // world), stream)
+        allreduce(peaks)
+    engine.sweep_dev(x.data_ptr(), x.stride(0), n, ang[0], ang[1], ang[2], -1, peaks.data_ptr(), flags, stream)
+    if world > 1:
+        allreduce(peaks)
+    return peaks
 
 
 def allreduce_peaks(peaks):

@@ -70,6 +70,87 @@ def test_cfg4_full_size_sharded_sweep_equals_single_pass(pkg):
     assert all(0 < int(pk[c].argmin()) < 360 for c in range(n_chn))  # a real minimum, not the raw-peak entry
 
 
+@pytest.mark.parametrize("P,seconds", [(2048, 600), (16384, 600), (8192, 300), (1024, 300)])
+def test_two_phase_sharded_sweep_equals_single_pass_and_lists_less(pkg, P, seconds):
+    """Round 5: a shard that seeds its pruning bound from its own frames cannot know that the loud passage is
+    somewhere else.  Two phases -- every shard's seeding pass alone (prot_sweep_seed_dev), the sampled tables MAX-merged, the main
+    passes against the merged bound -- on eight shards of material whose level swells by 20 dB towards one end: the merged final
+    table equals the single pass bit for bit (every fused route: blksiz 2048, 16384, 8192, 1024), the quiet shards list far fewer
+    frames than they do alone, and through prot_cli_analyze_file_multi (eight engines on one device, host-merged tables)."""
+    import torch
+    from phaserotate_lv2_amd import sweep_dist
+    dev = torch.device("cuda:0")
+    n_chn, world = 2, 8
+    n = seconds * 96000 // P * P
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.empty((n_chn, n), device=dev)
+    u = torch.linspace(0.0, 1.0, n, dtype=torch.float64, device=dev)
+    L = 96000
+    tt = np.arange(L, dtype=np.float64) / 96000.0
+    for c in range(n_chn):
+        pat = sum((0.5 / k) * np.cos(2 * np.pi * k * (110.0 + 11 * c) * tt + 0.3 * k) for k in range(1, 9))
+        x[c] = torch.from_numpy(pat.astype(np.float32)).to(dev).repeat(n // L + 1)[:n]
+        x[c] *= (0.08 + 0.8 * u ** 4).float()                      # quiet for most of the file, loud at the end
+        x[c] += 0.01 * (torch.rand(n, generator=g, device=dev) - 0.5)
+    del u
+    one = pkg.Engine(pkg.KIND_CLI, P, n_chn)
+    pk1 = torch.zeros((n_chn, 360), device=dev)
+    torch.cuda.synchronize()
+    one.sweep_dev(x.data_ptr(), n, n, 0, 360, 1, -1, pk1.data_ptr(), pkg.F_STREAM_START | pkg.F_STREAM_END)
+    one.sync()
+    plan = sweep_dist.plan_shards(n, P, world, align=one.shard_align_blocks())
+    H = int(one.info.history)
+    one.close()
+    engines = [pkg.Engine(pkg.KIND_CLI, P, n_chn) for _ in range(world)]
+    tabs = [torch.zeros((n_chn, 360), device=dev) for _ in range(world)]
+    listed = {}
+    for two_phase in (False, True):
+        for r, e in enumerate(engines):
+            e.reset()
+            tabs[r].zero_()
+        torch.cuda.synchronize()
+        shards = []
+        for r, e in enumerate(engines):
+            f0, nf = sweep_dist.shard_frames(n, P, plan, r)
+            if r > 0:
+                halo = x[:, f0 - H:f0].contiguous()
+                e.prime_dev(halo.data_ptr(), H, H)
+            fl = (pkg.F_STREAM_START if r == 0 else 0) | (pkg.F_STREAM_END if r == world - 1 else 0)
+            shards.append((x[:, f0:f0 + nf], nf, fl))
+        if two_phase:
+            for r, e in enumerate(engines):
+                xs, nf, fl = shards[r]
+                e.sweep_seed_dev(xs.data_ptr(), n, nf, 0, 360, 1, -1, tabs[r].data_ptr(), fl, 8)
+                e.sync()
+            seed = torch.stack(tabs).amax(0)     # (the first all-reduce)
+            assert float(seed.max()) > 0
+            for t in tabs:
+                t.copy_(seed)
+            torch.cuda.synchronize()
+        for r, e in enumerate(engines):
+            xs, nf, fl = shards[r]
+            e.sweep_dev(xs.data_ptr(), n, nf, 0, 360, 1, -1, tabs[r].data_ptr(), fl)
+            e.sync()
+        merged = torch.stack(tabs).amax(0)       # (the second all-reduce)
+        assert torch.equal(merged, pk1), two_phase
+        listed[two_phase] = [e.sweep_stats_fused()["listed"] for e in engines]
+    # the quiet shards (the first half of the file) list next to nothing against the global bound
+    assert sum(listed[True][:4]) * 4 < sum(listed[False][:4]) + 4, listed
+    for e in engines:
+        e.close()
+    # ... and the host-file entry point: eight engines on one device against one engine
+    nh = min(n, (1 << 22) * 2 + 4096 * 5)
+    xh = np.ascontiguousarray(x[:, :nh].t().cpu().numpy())
+    a = pkg.PhaseRotate(P, n_chn)
+    a.analyze_file(xh, 0, 360, 1)
+    want = a.peaks()
+    eng8 = [pkg.PhaseRotate(P, n_chn) for _ in range(world)]
+    pkg.analyze_file_multi(eng8, xh, 0, 360, 1)
+    for e in eng8:
+        assert np.array_equal(e.peaks(), want)
+    assert int(want[0].argmin()) > 0
+
+
 STUB = r"""
 #include <stddef.h>
 static int n_init, n_destroy, n_start, n_end, n_allreduce, open_groups;

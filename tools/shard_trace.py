@@ -21,12 +21,29 @@ def run(P, world=8, which=3, kind="harmonic"):
     H = int(eng.info.history)
     plan8 = sweep_dist.plan_shards(total, P, world, align=eng.shard_align_blocks())
     c0, c1 = plan8[which]
-    x = bench._sweep_signal(torch, np, dev, n_chn, c0 * P, (c1 - c0) * P, 1234, kind)
-    halo = bench._sweep_signal(torch, np, dev, n_chn, c0 * P - H, H, 4321, kind).contiguous() if which > 0 else None
+    two_phase = world > 1 and os.environ.get("SHARD_ONE_PHASE") != "1"
     peaks = torch.zeros((n_chn, 360), device=dev)
+    gseed = torch.zeros((n_chn, 360), device=dev)
     ts = torch.cuda.Stream(device=dev)   # (a stream of the caller's, so that peaks.zero_() is ordered with the engine's kernels)
     torch.cuda.set_stream(ts)
     st = ts.cuda_stream
+    if two_phase:
+        # the table the first all-reduce leaves: the seeds of ALL shards of the whole file (as bench.py's predicted_8gpu computes it)
+        xa = bench._sweep_signal(torch, np, dev, n_chn, 0, total, 1234, kind)
+        for r, (b0, b1) in enumerate(plan8):
+            xs = xa[:, b0 * P:b1 * P]
+            fl0 = (pkg.F_STREAM_START if r == 0 else 0) | (pkg.F_STREAM_END if r == world - 1 else 0)
+            eng.reset()
+            peaks.zero_()
+            eng.sweep_seed_dev(xs.data_ptr(), xa.shape[1], xs.shape[1], 0, 360, 1, -1, peaks.data_ptr(), fl0, max(8, 64 // world), st)
+            torch.cuda.synchronize()
+            gseed = torch.maximum(gseed, peaks)
+        x = xa[:, c0 * P:c1 * P].contiguous()
+        halo = xa[:, c0 * P - H:c0 * P].contiguous() if which > 0 else None
+        del xa
+    else:
+        x = bench._sweep_signal(torch, np, dev, n_chn, c0 * P, (c1 - c0) * P, 1234, kind)
+        halo = bench._sweep_signal(torch, np, dev, n_chn, c0 * P - H, H, 4321, kind).contiguous() if which > 0 else None
     import time
     for k in range(6):
         torch.cuda.synchronize()
@@ -36,6 +53,9 @@ def run(P, world=8, which=3, kind="harmonic"):
         if halo is not None:
             sweep_dist.prime_history(eng, halo, st)
         fl = (pkg.F_STREAM_START if which == 0 else 0) | (pkg.F_STREAM_END if which == world - 1 else 0)
+        if two_phase:
+            eng.sweep_seed_dev(x.data_ptr(), x.shape[1], x.shape[1], 0, 360, 1, -1, peaks.data_ptr(), fl, max(8, 64 // world), st)
+            peaks.copy_(gseed)
         eng.sweep_dev(x.data_ptr(), x.shape[1], x.shape[1], 0, 360, 1, -1, peaks.data_ptr(), fl, st)
         t1 = time.perf_counter()
         torch.cuda.synchronize()
