@@ -287,10 +287,12 @@ def main():
     is8k = int(eng.info.form) == pkg.FORM_POLY_SAVE8K
     if int(eng.info.form) == pkg.FORM_POLY_SAVE8K:
         rows8 = 16 - int(eng.info.firlen) // 1024
-        kname = "olasave8k_kernel<%d, 0>" % rows8
+        kname = "olasave8k_dyn_kernel<%d, 0>" % rows8
         klabel = ("prot::%s (polyphase form, overlap-save on 8192-POINT blocks: 512-thread workgroups, two per CU, %d of 16 sample rows new per block, "
                   "table-free centred filter, the radix-2 layer taken by the readers of the LDS exchanges; generated gfx950 assembly, 120 "
-                  "hand-allocated VGPRs; launches shorter than 2^24 channel-frames run olasave_kernel on 4096-point blocks)" % (kname, rows8))
+                  "hand-allocated VGPRs; round 5: the resident workgroups CLAIM their blocks one at a time -- eight regions, one per XCD, a scalar "
+                  "atomic per block -- instead of walking runs planned by the host; launches shorter than 2^24 channel-frames run olasave_kernel "
+                  "on 4096-point blocks)" % (kname, rows8))
     elif int(eng.info.form) == pkg.FORM_POLY_SAVE:
         kname = "olasave_kernel<%d, 0>" % rows
         klabel = ("prot::%s (polyphase form, overlap-save: one partition of the odd taps applied centred and table-free -- forward transform at "
@@ -334,7 +336,11 @@ def main():
                                  "on 4096-point blocks (5120 new frames per block), ") +
                                 "angle 90 deg, device-resident stream of 2^%d frames per GPU per step" % args.frames_log2),
                    "partitions": int(eng.info.partitions),
-                   "fftlen": int(eng.info.fftlen), "hop": int(eng.info.hop), "firlen": int(eng.info.firlen),
+                   # (the kernel that RAN: 8192-point blocks of which 16 - firlen / 1024 rows of 1024 frames are new; the engine's short-launch
+                   # form -- prot_info.fftlen / hop: 4096-point blocks, 5120 new frames -- is what run() buffers take)
+                   "fftlen": 8192 if is8k else int(eng.info.fftlen),
+                   "hop": 1024 * (16 - int(eng.info.firlen) // 1024) if is8k else int(eng.info.hop),
+                   "short_launch_fftlen": int(eng.info.fftlen), "short_launch_hop": int(eng.info.hop), "firlen": int(eng.info.firlen),
                    "latency": int(eng.info.latency), "frames_per_gpu": n, "streams_per_gpu": 1,
                    "parallelism": "independent streams x%d" % world},
         "roofline": dict({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -344,9 +350,16 @@ def main():
                                     "traffic_latest.json and profiles/pmc_latest.json (rocprofv3 --pmc passes of the same command, "
                                     "builder-side run, NOT this run)",
                           "kernel": klabel, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                          "binding_resource": ("the stream itself at two 512-thread workgroups per CU: the kernel with its arithmetic and LDS "
-                                               "traffic removed (generator ablations, DESIGN.md section 5) takes 0.252 of the complete kernel's "
-                                               "0.2533 ms; VALU alone 0.122, LDS alone 0.098" if is8k else
+                          "binding_resource": ("exposed latency inside the workgroup, at a memory system that is two thirds busy: in the steady state "
+                                               "of a launch a CU finishes 0.175-0.19 blocks/us (4.75-5.2 TB/s over the chip) with its vector pipes "
+                                               "63-69 % busy; of a wave's 19-21 K cycles per block 20-22 % are spent parked at the four workgroup "
+                                               "barriers, 17-22 % in the stretch that reads the first exchange and issues the next block's 17 row "
+                                               "loads, ~0.3 % waiting for rows (profiles/r05_sv8_stall_table*.json: shader-clock stamps inside the "
+                                               "generated loop); the older of a CU's two workgroups takes 7.5 us per block, the younger 17 "
+                                               "(oldest-first arbitration) -- with runs planned by the host that left 13 % of the workgroup slots "
+                                               "empty at the end of a launch (round 4: 40 blocks/us over the launch against 48.5 in its steady "
+                                               "state), with claimed blocks 4 %; what is left is the fill and drain of a pipeline whose stage is "
+                                               "12 us long (5 %) and the dependent chains of two 8-wave workgroups per CU (DESIGN.md section 5)" if is8k else
                                                "packed-fp32 VALU issue (4 cycles per v_pk_*_f32, tools/ubench/pk_rate.hip) at the clock the "
                                                "chip holds under this load (1.7 GHz in-kernel, tools/sv_clock.py), with LDS at about half of "
                                                "its cycles: DESIGN.md section 5")}, **pmc),
@@ -363,6 +376,16 @@ def main():
         out["sweep"] = bench_sweep(args, pkg, torch, dist, dev, st, world, rank, local_rank, barrier)
 
     if not args.no_extra:
+        # the metric's literal block size: the same filter on 4096-POINT blocks (PROT_CFG_BLOCK4096: olasave_kernel<10, 0>, four
+        # 256-thread workgroups per CU, 5120 new frames per block) -- the headline of round 3 --, and the 8192-point blocks with the
+        # runs planned by the host as in round 4 (PROT_CFG_STATIC_RUNS: olasave8k_kernel<13, 0>)
+        for key, fl, what in (("block4096", pkg.CFG_BLOCK4096, "4096-point overlap-save blocks (olasave_kernel<10, 0>, 5120 new frames per block, four workgroups per CU)"),
+                              ("static_runs", pkg.CFG_STATIC_RUNS, "8192-point blocks, runs planned by the host (olasave8k_kernel<13, 0>: round 4's headline kernel)")):
+            engb = pkg.Engine(pkg.KIND_LV2, 48000, 1, device=local_rank, flags=fl)
+            wallb, kmsb = timed(engb, args.steps, args.warmup, n)
+            out[key] = {"workload": "the headline workload on " + what, "value": world * n * args.steps / wallb, "unit": "frames/s",
+                        "roofline_frac": 8.0 * n / (kmsb * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": kmsb}
+            engb.close()
         # same filter, direct form: two 2048-tap partitions sharing one forward FFT per 2048-frame hop
         eng2 = pkg.Engine(pkg.KIND_LV2, 48000, 1, device=local_rank, flags=pkg.CFG_DIRECT_FORM)
         wall2, kms2 = timed(eng2, args.steps, args.warmup, n)
@@ -910,7 +933,8 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
     if not full:
         return {"metric": "channel-frames/s through the 360-angle min-peak sweep (cli -s 1 -f %d: the reference's default block size at %s)"
                           % (P, "88.2 / 96 kHz" if P == 16384 else "44.1 / 48 kHz"),
-                "value": h["value"], "unit": "channel-frames/s", "ms": h["ms"], "cold_ms": h["cold_ms"], "warmup_passes": h["warmup_passes"],
+                "value": h["value"], "unit": "channel-frames/s", "ms": h["ms"], "cold_ms": h["cold_ms"], "cold_value": h["value"] * h["ms"] / h["cold_ms"],
+                "warmup_passes": h["warmup_passes"],
                 "unpruned_ms": h["unpruned_ms"],
                 "evaluated_fraction": h["evaluated_fraction"], "table_identical_unpruned": h["table_identical_unpruned"],
                 "min_angle_index": h["min_angle_index"], "per_rank_device_ms": h["per_rank_device_ms"],
@@ -924,7 +948,8 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
                            "the Hilbert pass tests and lists), sweep_eval_kernel evaluates the lists")}
     return {"metric": "channel-frames/s through the 360-angle min-peak sweep (cli -s 1 -f 2048)",
             "signal": "32-harmonic asymmetric stack (110 / 137.5 Hz) under a slow swell + 2 % noise, generated on the device; resident in HBM",
-            "value": h["value"], "unit": "channel-frames/s", "ms": h["ms"], "cold_ms": h["cold_ms"], "warmup_passes": h["warmup_passes"],
+            "value": h["value"], "unit": "channel-frames/s", "ms": h["ms"], "cold_ms": h["cold_ms"], "cold_value": h["value"] * h["ms"] / h["cold_ms"],
+                "warmup_passes": h["warmup_passes"],
             "cold_note": "ms / value: five passes after %d untimed ones (the steady state, as the headline's pre-roll: the pass time settles over ~50 ms "
                          "of continuous work, tools/sweep_drift.py); cold_ms: the first " % SWEEP_WARM_PASSES +
                          "three passes after ONE untimed pass (what rounds 1-3 reported as ms)",

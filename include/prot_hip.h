@@ -74,8 +74,8 @@ typedef struct {
  * launch k + 1 needs nothing of launch k but the history, which the kernel hands over on the device.  For callers that
  * issue many short launches back to back (BASELINE config 3: 256 x 1024-frame buffers per launch).  Same results bit for
  * bit.  Outputs are complete after prot_engine_sync (or any later call on the engine, which is ordered behind them);
- * the caller must not reuse an input or output buffer of a launch before that.  PROT_PIPELINE=1 / =0 in the
- * environment forces it on / off. */
+ * the caller must not reuse an input or output buffer of a launch before that.  (The shipped library reads no
+ * environment variable: this flag is the only switch.) */
 #define PROT_CFG_PIPELINE 16u
 /* Overlap-save LV2 engines run LONG launches (>= 2^24 channel-frames) on 8192-point blocks (olasave8k_kernel: 512-thread
  * workgroups, two per CU, 12 or 13 of 16 rows of a block new) and everything shorter on 4096-point blocks (olasave_kernel).

@@ -17,7 +17,11 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # PROT_LIB_PATH: tuning only (tools/ab_bench.py times alternative builds of the same sources)
-LIB_PATH = os.environ.get("PROT_LIB_PATH") or os.path.join(_PKG, "lib", "libprot_hip.so")
+# the SHIPPED library (what the LV2 plugin and the CLI link: include/prot_hip.h's symbols and nothing else) and the test-hook build of
+# the same sources (-DPROT_TESTHOOKS: + csrc/prot_internal.h), which this mirror -- tests/ and bench.py plumbing -- loads when it is there
+SHIPPED_LIB_PATH = os.path.join(_PKG, "lib", "libprot_hip.so")
+_HOOKS = os.path.join(_PKG, "lib", "libprot_hip_hooks.so")
+LIB_PATH = os.environ.get("PROT_LIB_PATH") or (_HOOKS if os.path.exists(_HOOKS) else SHIPPED_LIB_PATH)
 
 MAXSAMPLE = 360          # cli/phase-rotate.cc:39
 SUBSAMPLE = 2            # cli/phase-rotate.cc:38

@@ -14,8 +14,22 @@ CSRC = os.path.join(PKG, "csrc")
 HOST = os.path.join(PKG, "host")
 LIBDIR = os.path.join(PKG, "lib")
 OBJDIR = os.path.join(PKG, "build")
-LIB = os.path.join(LIBDIR, "libprot_hip.so")
+LIB = os.path.join(LIBDIR, "libprot_hip.so")              # the shipped library: exports include/prot_hip.h's symbols, nothing else
+LIB_HOOKS = os.path.join(LIBDIR, "libprot_hip_hooks.so")  # the same sources with -DPROT_TESTHOOKS: + csrc/prot_internal.h (tests, bench.py)
 ARCH = "gfx950"
+
+
+def declared_symbols():
+    """the functions include/prot_hip.h declares"""
+    import re
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "prot_hip.h")).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(prot_[a-z0-9_]+)\s*\(", src)))
+
+
+def _version_script(path, names):
+    with open(path, "w") as f:
+        f.write("{\n global:\n" + "".join("  %s;\n" % n for n in names) + " local:\n  *;\n};\n")
+    return path
 
 
 def _hipcc():
@@ -70,8 +84,21 @@ def build_lib(force=False, verbose=False):
             if verbose and out:
                 print(out)
         objs.append(o)
-    if force or _newer(LIB, objs):
-        _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"])
+    # the test-hook build of the C ABI unit (prot_internal_set_test_option & co.): everything else is the same object code
+    capi_src = os.path.join(CSRC, "prot_capi.hip")
+    capi_hooks = os.path.join(OBJDIR, "prot_capi_hooks.o")
+    if force or _newer(capi_hooks, [capi_src, os.path.join(CSRC, "prot_internal.h")] + hdrs):
+        _run(common + ["-DPROT_TESTHOOKS", "-c", capi_src, "-o", capi_hooks])
+    names = declared_symbols()
+    internal = ["prot_internal_set_rccl_library", "prot_internal_set_test_option", "prot_internal_fused_lists", "prot_internal_time_lv2_run",
+                "prot_internal_server_stats"]
+    if force or _newer(LIB, objs + [os.path.join(ROOT, "include", "prot_hip.h")]):
+        vs = _version_script(os.path.join(OBJDIR, "exports.map"), names)
+        _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,--version-script=" + vs, "-o", LIB] + objs + ["-lpthread"])
+    objs_h = [capi_hooks if o.endswith("prot_capi.o") else o for o in objs]
+    if force or _newer(LIB_HOOKS, objs_h + [os.path.join(ROOT, "include", "prot_hip.h")]):
+        vs = _version_script(os.path.join(OBJDIR, "exports_hooks.map"), names + internal)
+        _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,--version-script=" + vs, "-o", LIB_HOOKS] + objs_h + ["-lpthread"])
     return LIB
 
 
@@ -101,7 +128,7 @@ def build_host(force=False):
 
 def build_all(force=False):
     lib = build_lib(force)
-    return [lib] + build_host(force)
+    return [lib, LIB_HOOKS] + build_host(force)
 
 
 if __name__ == "__main__":

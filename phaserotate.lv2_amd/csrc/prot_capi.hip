@@ -41,7 +41,15 @@ inline const char* tuning_env (const char* name) { return getenv (name); }
 #else
 inline const char* tuning_env (const char*) { return nullptr; }
 #endif
-std::atomic<int> g_test_opt[PROT_TEST_OPTIONS];
+// ... and that entry point exists only in the PROT_TESTHOOKS build of the library (libprot_hip_hooks.so: the same sources, what
+// tests/ and bench.py load); the shipped libprot_hip.so has no test hook, no switch to flip, and exports nothing but the symbols
+// include/prot_hip.h declares (version script, phaserotate.lv2_amd/build.py).
+#ifdef PROT_TESTHOOKS
+std::atomic<int> g_test_opt_v[PROT_TEST_OPTIONS];
+inline int       test_opt (int o) { return g_test_opt_v[o].load (); }
+#else
+inline int test_opt (int) { return 0; }
+#endif
 
 thread_local char g_err[256] = "";
 
@@ -1002,7 +1010,7 @@ int lv2_reserve (prot_engine* e, uint32_t frames)
 			int large_bar = 0;
 			(void)hipDeviceGetAttribute (&large_bar, hipDeviceAttributeIsLargeBar, e->device);
 			void* q = nullptr;
-			e->srv_bar = large_bar != 0 && g_test_opt[PROT_TEST_LV2_NO_BAR].load () == 0 && hipExtMallocWithFlags (&q, need, hipDeviceMallocFinegrained) == hipSuccess;
+			e->srv_bar = large_bar != 0 && test_opt (PROT_TEST_LV2_NO_BAR) == 0 && hipExtMallocWithFlags (&q, need, hipDeviceMallocFinegrained) == hipSuccess;
 			if (!e->srv_bar && hipHostMalloc (&q, need, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
 				e->srv_eligible  = false; // (no mailbox: every call is launched)
 				e->srv_box_bytes = 0;
@@ -1445,7 +1453,7 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	std::vector<float>  sv_h;
 	if (use_poly && n_part == 1 && !(cfg->flags & PROT_CFG_OVERLAP_ADD) && tuning_env ("PROT_NO_SAVE") == nullptr &&
 	    2 * (inf.dry_delay - inf.conv_delay) == 256 * (32 - (uint32_t)hopseg) && inf.dry_delay % 2 == 0) {
-		e->sv_flags = g_test_opt[PROT_TEST_EDGE_PATH_ONLY].load () ? 1 : 0; // (test hook: every block through the staged path)
+		e->sv_flags = test_opt (PROT_TEST_EDGE_PATH_ONLY) ? 1 : 0; // (test hook: every block through the staged path)
 		e->use_save = hopseg <= 24 && save_tables (fir_taps, F, sv_h, e->sv_gain, e->sv_rows) && e->sv_rows == 1;
 		if (e->use_save && e->cus > 0 && tuning_env ("PROT_WG_PER_CU") == nullptr) {
 			e->wg_slots = e->cus * 4; // 128 VGPRs, 38 KiB of LDS
@@ -2073,7 +2081,7 @@ static int sweep_dev_impl (prot_engine* e, const float* d_in, int64_t in_stride,
 	const bool fuse_poly = e->use_poly && !e->use_save && !e->sv8_always &&
 	                       ((e->info.partitions >= 4 && e->hopseg == 16) || (e->info.partitions == 1 && e->hopseg == 28));
 	const bool fusable = ((e->use_save && (e->hopseg == 16 || e->hopseg == 24) && !(e->sv_flags & 1)) || fuse_poly || (e->sv8_always && !(e->sv_flags & 1))) &&
-	                     !g_test_opt[PROT_TEST_SWEEP_UNPRUNED].load () && !g_test_opt[PROT_TEST_SWEEP_UNFUSED].load ();
+	                     !test_opt (PROT_TEST_SWEEP_UNPRUNED) && !test_opt (PROT_TEST_SWEEP_UNFUSED);
 	CallStream  s (e, stream);
 	const int   c0  = chn < 0 ? 0 : chn;                       // cli/phase-rotate.cc:434-435
 	const int   nc  = chn < 0 ? (int)e->info.n_chn : 1;
@@ -2118,7 +2126,7 @@ static int sweep_dev_impl (prot_engine* e, const float* d_in, int64_t in_stride,
 		e->angles_stream = s;
 		e->sweep_seeded  = false;
 	}
-	const bool unpruned = g_test_opt[PROT_TEST_SWEEP_UNPRUNED].load () != 0;
+	const bool unpruned = test_opt (PROT_TEST_SWEEP_UNPRUNED) != 0;
 	// FUSED (round 4): the sweep's test rides in the Hilbert pass (olasave_kernel MODE_SWEEP: nothing but the surviving (d, h)
 	// pairs -- a few percent of the frames -- is written), the matrix-core kernel evaluates the lists.  For the engines whose
 	// Hilbert pass is the overlap-save kernel (blksiz 2048, 4096), pruned sweeps, calls long enough to carry five more launches;
@@ -2208,7 +2216,7 @@ static int sweep_dev_impl (prot_engine* e, const float* d_in, int64_t in_stride,
 			}
 			e->last_n_lists = fs.n_lists;
 			e->last_cap     = fs.cap;
-			if (pass == 0 && g_test_opt[PROT_TEST_SEED_MFMA].load () == 0) {
+			if (pass == 0 && test_opt (PROT_TEST_SEED_MFMA) == 0) {
 				// the seeding pass's lists: a lower bound is all they have to give (prot_sweep.hip: sweep_seed_eval_kernel)
 				hipError_t err0 = prot::launch_sweep_seed_eval (e->d_surv.p, e->d_surv_cnt.p, fs.n_lists, fs.cap, e->d_angles.p, n_ang, e->d_lut.p, pk, c0, nc,
 				                                                e->d_part.p, prot::sweep_scratch_floats (), s);
@@ -2522,7 +2530,7 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 	// (H2D copies -> device buffers -> D2H copy) for comparison.
 	// Measured (tools/run_latency.py): 64..1024-frame buffers 37..42 us zero-copy vs 46..47 us staged; at 8192 frames the
 	// DMA copies win (70 vs 76 us: 64 KiB over the host link from inside a latency-bound kernel) -- staged above 4096 samples.
-	const bool force_staged = g_test_opt[PROT_TEST_LV2_STAGED].load () != 0;
+	const bool force_staged = test_opt (PROT_TEST_LV2_STAGED) != 0;
 	const bool        staged       = force_staged || n * nc > 4096;
 	// (buffers: lv2_reserve -- nothing is allocated on this path)
 	float* h_in  = e->h_io.p;
@@ -2605,7 +2613,7 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 	// One server per process (the first LV2 engine to ask: see g_srv_owner); calls of more than one block per channel, staged
 	// calls and PROT_TEST_LV2_NO_SERVER take the launch below.  tools/run_latency.py: 38-40 us -> the figure in DESIGN.md.
 	bool served = false;
-	if (!staged && e->srv_eligible && g_test_opt[PROT_TEST_LV2_NO_SERVER].load () == 0) {
+	if (!staged && e->srv_eligible && test_opt (PROT_TEST_LV2_NO_SERVER) == 0) {
 		std::lock_guard<std::mutex> lk (g_srv_mu);
 		if (g_srv_hold == 0 && (g_srv_owner == nullptr || g_srv_owner == e)) {
 			prot::SvServerBox* b = reinterpret_cast<prot::SvServerBox*> (e->srv_box);
@@ -3078,7 +3086,7 @@ int prot_allreduce_peaks (prot_engine* const* engines, int n)
 	}
 	// PROT_ALLREDUCE=host: merge through the host even on distinct devices; =rccl: take the collective even when the
 	// engines share a device (only meaningful with a stand-in library: real RCCL wants one rank per device)
-	const int   mode      = g_test_opt[PROT_TEST_ALLREDUCE].load (); // (prot_internal.h: 1 = through the host, 2 = the collective even on one device)
+	const int   mode      = test_opt (PROT_TEST_ALLREDUCE); // (prot_internal.h: 1 = through the host, 2 = the collective even on one device)
 	const bool  want_host = mode == 1;
 	const bool  force     = mode == 2;
 	std::lock_guard<std::mutex> lk (g_rccl_lock);
@@ -3266,6 +3274,7 @@ int prot_cli_apply_file (prot_engine* e, const float* data, uint64_t n_frames, c
 }
 
 
+#ifdef PROT_TESTHOOKS
 // TEST HOOK, not part of include/prot_hip.h (declared in csrc/prot_internal.h): the library that Rccl::load() opens in
 // place of the system's RCCL -- an explicit call of the test process, never the environment (the library is also
 // loaded into LV2 hosts).  Only before the first all-reduce; NULL / "" restores the default.
@@ -3359,7 +3368,7 @@ int prot_internal_set_test_option (int option, int value)
 	if (option < 0 || option >= PROT_TEST_OPTIONS) {
 		return PROT_EINVAL;
 	}
-	g_test_opt[option].store (value);
+	g_test_opt_v[option].store (value);
 	return PROT_OK;
 }
 
@@ -3372,5 +3381,7 @@ int prot_internal_set_rccl_library (const char* path)
 	g_rccl.override_path = path ? path : "";
 	return PROT_OK;
 }
+
+#endif // PROT_TESTHOOKS
 
 } // extern "C"

@@ -25,12 +25,23 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = pkg.load_library()
     for name in declared_symbols():
         assert hasattr(lib, name), name
+    # the SHIPPED library exports what include/prot_hip.h declares and NOTHING else (no test hook, no C++ launch_* symbol: a version
+    # script, phaserotate.lv2_amd/build.py); the test-hook build of the same sources adds csrc/prot_internal.h
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg.SHIPPED_LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+    exported = set(l.split()[-1] for l in out.splitlines() if l.strip())
+    assert exported == set(declared_symbols()), sorted(exported ^ set(declared_symbols()))
     out = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
-    exported = set(re.findall(r" T (prot_[a-z0-9_]+)", out))
-    assert set(declared_symbols()) <= exported
+    hooks = set(l.split()[-1] for l in out.splitlines() if l.strip())
+    assert set(declared_symbols()) < hooks and {"prot_internal_set_test_option", "prot_internal_fused_lists"} <= hooks
+    assert all(n.startswith("prot_") for n in hooks)
     # library and header agree on the ABI revision (2: prot_info.run_align, prot_sweep_stats, PROT_CFG_* flags; 4: PROT_CFG_OVERLAP_ADD)
     declared = int(re.search(r"#define\s+PROT_ABI_VERSION\s+(\d+)", open(HDR).read()).group(1))
-    assert lib.prot_abi_version() == declared == 6   # (6: PROT_CFG_STATIC_RUNS)
+    assert lib.prot_abi_version() == declared == 6   # (6: PROT_CFG_STATIC_RUNS, prot_sweep_seed_dev, prot_engine_prime_dev)
+    import ctypes
+    shipped = ctypes.CDLL(pkg.SHIPPED_LIB_PATH)
+    shipped.prot_abi_version.restype = ctypes.c_int
+    assert shipped.prot_abi_version() == declared
+    assert not hasattr(shipped, "prot_internal_set_test_option")
 
 
 def test_header_constants_and_python_mirror_agree(pkg):

@@ -12,7 +12,7 @@ hipcc = b._hipcc()
 # variant libraries read the tuning switches of prot_capi.hip from the environment (-DPROT_TUNING); the shipped library never does
 CAPI_T = os.path.join(b.OBJDIR, "prot_capi_tuning.o")
 if b._newer(CAPI_T, [os.path.join(b.CSRC, "prot_capi.hip"), os.path.join(b.CSRC, "prot_kernels.h")]):
-    b._run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-function", "-DPROT_TUNING",
+    b._run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-function", "-DPROT_TUNING", "-DPROT_TESTHOOKS",
             "-I" + os.path.join(ROOT, "include"), "-c", os.path.join(b.CSRC, "prot_capi.hip"), "-o", CAPI_T])
 for arg in sys.argv[1:]:
     if arg.startswith("sv8:"):
