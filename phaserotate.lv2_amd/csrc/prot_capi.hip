@@ -2072,6 +2072,26 @@ static int sweep_dev_impl (prot_engine* e, const float* d_in, int64_t in_stride,
 		return PROT_EINVAL;
 	}
 	HIP_TRY (hipSetDevice (e->device));
+	// The fused route's lists can hold every frame of the call (one 8-byte entry per channel-frame, whatever survives) and its step
+	// descriptors address them with 32-bit entry offsets: a call of more than 2^31 channel-frames (12 GiB of input; 1 h at 96 kHz
+	// with seven channels) is taken in two halves on a chunk boundary, each a call of its own -- exactly what a host that feeds the
+	// file in chunks does, so the table is the same bit for bit (above ~4.29e9 channel-frames the offsets wrapped
+	// silently).  PROT_TEST_FUSED_SPLIT_LOG2 lowers the limit for the test of this path.
+	{
+		const int      lg    = test_opt (PROT_TEST_FUSED_SPLIT_LOG2);
+		const uint64_t limit = (uint64_t)1 << (lg > 0 ? lg : 31);
+		const uint64_t ncc   = chn < 0 ? e->info.n_chn : 1;
+		const uint64_t L     = file_align_frames (e);
+		if (seed_blocks == 0 && n_frames * ncc > limit && n_frames >= 2 * L) {
+			const uint64_t half = std::max<uint64_t> (L, (n_frames / 2) / L * L);
+			int rc = sweep_dev_impl (e, d_in, in_stride, half, ang_start, ang_end, ang_stride, chn, d_peaks, flags & ~(uint32_t)PROT_F_STREAM_END, stream, 0);
+			if (rc) {
+				return rc;
+			}
+			return sweep_dev_impl (e, d_in + half, in_stride, n_frames - half, ang_start, ang_end, ang_stride, chn, d_peaks,
+			                       flags & ~(uint32_t)PROT_F_STREAM_START, stream, 0);
+		}
+	}
 	// (a long call in two pieces -- the first eighth listed against the seeding pass's bound, the rest against the table it leaves --
 	// was measured and changes nothing: 1.77-1.80 / 4.12 ms in one piece, 1.76-2.09 / 4.07-4.32 ms in two, harmonic / noise, cfg4)
 	// (two routes: the overlap-save kernel's MODE_SWEEP -- blksiz 2048, 4096 --, and for the long FIRs whose Hilbert branch takes

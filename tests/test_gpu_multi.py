@@ -151,6 +151,33 @@ def test_two_phase_sharded_sweep_equals_single_pass_and_lists_less(pkg, P, secon
     assert int(want[0].argmin()) > 0
 
 
+def test_sweep_calls_beyond_the_lists_32_bit_offsets_are_split(pkg):
+    """the fused route's step descriptors address the survivor lists with 32-bit entry offsets; a resident call of more
+    than 2^31 channel-frames is taken in two halves on a chunk boundary.  With the limit lowered by the test hook a modest call
+    splits (recursively): the same table as the unsplit call, bit for bit, for two block sizes and with a ragged end."""
+    import torch
+    dev = torch.device("cuda:0")
+    for P, n in ((2048, (1 << 23) + 12345), (16384, (1 << 23) + 999)):
+        g = torch.Generator(device=dev).manual_seed(P)
+        x = (torch.rand((2, n), generator=g, device=dev) - 0.5) * 0.9
+        x[0] += 0.4 * torch.sin(torch.arange(n, device=dev) * 0.013)
+        tabs = []
+        for lg in (0, 22):
+            pkg.set_test_option(pkg.TEST_FUSED_SPLIT_LOG2, lg)
+            try:
+                e = pkg.Engine(pkg.KIND_CLI, P, 2)
+                pk = torch.zeros((2, 360), device=dev)
+                torch.cuda.synchronize()
+                e.sweep_dev(x.data_ptr(), n, n, 0, 360, 1, -1, pk.data_ptr(), pkg.F_STREAM_START | pkg.F_STREAM_END)
+                e.sync()
+                tabs.append(pk.clone())
+                e.close()
+            finally:
+                pkg.set_test_option(pkg.TEST_FUSED_SPLIT_LOG2, 0)
+        assert torch.equal(tabs[0], tabs[1]), P
+        assert float(tabs[0].min()) > 0
+
+
 STUB = r"""
 #include <stddef.h>
 static int n_init, n_destroy, n_start, n_end, n_allreduce, open_groups;

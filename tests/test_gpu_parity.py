@@ -227,6 +227,66 @@ def test_lv2_run_server_leaves_when_idle_and_for_every_other_use_of_the_engine(p
     h.close()
 
 
+def test_lv2_run_server_is_held_off_while_another_thread_creates_and_destroys_engines(pkg):
+    """stopping the run() server ONCE is not enough -- an audio thread that calls run() every few milliseconds
+    starts it again while another thread's prot_engine_create / destroy is still inside hipMalloc / hipFree, which wait for a
+    device without a resident kernel: under continuous audio a second instance could not be instantiated or cleaned up.  Create,
+    destroy, reserve, reset and sync now HOLD the server off for their whole duration (run() takes the launch route meanwhile),
+    and the kernel leaves by itself after 0.25 s of residence whatever happens.  A run() loop on A for two seconds while B is
+    created and destroyed over and over: both threads make progress, A's stream of samples stays intact."""
+    import threading
+    import time
+    bs = 512
+    n_buf = 4000
+    x = xorshift_uniform(64 * bs, seed=5).reshape(1, -1)
+    a = pkg.Lv2Instance(48000, 1)
+    a.activate()
+    o = orc.Lv2Engine(48000, 1)
+    stop = threading.Event()
+    got, made, err = [], [0], []
+
+    def audio():
+        try:
+            i = 0
+            t_end = time.perf_counter() + 2.0
+            while time.perf_counter() < t_end and i < n_buf:
+                blk = x[:, (i % 64) * bs:(i % 64 + 1) * bs]
+                got.append(a.run(blk, 90.0).copy())
+                i += 1
+                time.sleep(0.0005)
+        except Exception as ex:   # noqa: BLE001
+            err.append(ex)
+        finally:
+            stop.set()
+
+    def churn():
+        try:
+            while not stop.is_set():
+                b = pkg.Lv2Instance(96000, 2)
+                b.activate()
+                b.run(np.zeros((2, 256), np.float32), [10.0, -20.0])
+                b.close()
+                made[0] += 1
+        except Exception as ex:   # noqa: BLE001
+            err.append(ex)
+
+    t1, t2 = threading.Thread(target=audio), threading.Thread(target=churn)
+    t0 = time.perf_counter()
+    t1.start(); t2.start()
+    t1.join(60.0); t2.join(60.0)
+    assert not t1.is_alive() and not t2.is_alive(), "a thread hangs: the resident kernel blocks the other thread's allocation"
+    assert not err, err
+    assert time.perf_counter() - t0 < 30.0
+    assert made[0] >= 3 and len(got) >= 100, (made[0], len(got))
+    # the stream of samples through the churn: against the oracle fed the same buffers
+    y = np.concatenate(got, 1)
+    xs = np.concatenate([x[:, (i % 64) * bs:(i % 64 + 1) * bs] for i in range(len(got))], 1)
+    want = o.run_stream(xs, 90.0, bs)
+    lat = a.latency + 2304
+    assert np.abs(y - want)[:, lat:].max() < TOL
+    a.close()
+
+
 def test_lv2_three_device_geometries_are_the_same_filter(pkg):
     """LV2 48 kHz filter in the three device forms: polyphase (default: the odd taps on the stream
     read as complex samples, one partition, 5120-frame blocks), direct form with two 2048-tap
