@@ -133,7 +133,27 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 		return reinterpret_cast<float*> (p.surv_cnt) + (int64_t)gridDim.y * gridDim.x * 4 + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + w;
 	};
 	auto sw_thr = [&] () -> float {
+#if defined(PROT_SW_THR_LDS) && PROT_SW_THR_LDS == 1
+		// (diagnostic build, DESIGN.md 4.4b: the round-4 form whose reads came back wrong on the hardware.  ROOT CAUSE, found in the
+		// ISA in round 5 (tools/lint_exec_copies.py): the generic pointer makes this a flat load whose 64-bit per-lane address the
+		// compiler keeps in VGPRs; the generated code owns v0..v119, so the address is copied into one of v120..v127 in front of
+		// every asm block and back behind it -- and the copy in front of the staged block's asm was placed INSIDE the divergent
+		// region that gathers the block's front frames (EXEC = lanes 8..11 of each wave): the other sixty lanes of the copy never
+		// received the address, lane 0 -- the one v_readfirstlane reads -- came back with whatever that register held before, and
+		// the load went to LDS word 0 or anywhere else.  Not an overlapping LDS write: a per-lane value kept alive across the
+		// generated code, the one thing this file forbids itself -- here by the compiler's hand.)
+		return __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (((volatile float*)sw_lo_s)[0])));
+#elif defined(PROT_SW_THR_LDS)
+		// (the same word in LDS, read through an address that is made at the point of use from a scalar: nothing per-lane lives
+		// across the generated code -- tables bit-identical on the hardware, tools/sweep_shard_repro.py)
+		unsigned a = (unsigned)(uintptr_t)(__attribute__ ((address_space (3))) float*)sw_lo_s;
+		asm volatile ("" : "+s"(a));
+		float v;
+		asm volatile ("v_mov_b32 %0, %1\n\tds_read_b32 %0, %0\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "s"(a) : "memory");
+		return __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (v)));
+#else
 		return __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (__hip_atomic_load (sw_thr_slot (), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))));
+#endif
 	};
 	unsigned         sw_cnt  = 0u; // entries this wave has appended (wave-uniform; the list's address is recomputed where it is needed:
 	                               // nothing but this count, the bound and the running maximum lives across the generated code)
@@ -172,6 +192,12 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 			__hip_atomic_store (sw_thr_slot (), lo * lo * 0.9999f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 		asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef PROT_SW_THR_LDS
+		if (t0 == 0) {
+			sw_lo_s[0] = lo * lo * 0.9999f;
+		}
+		__syncthreads ();
+#endif
 	}
 	if (piped) {
 		// my slice of the next history: device-scope (write-through) stores, so that publishing it needs no release FENCE --
