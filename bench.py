@@ -791,6 +791,9 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
                 fl8 = (pkg.F_STREAM_START if r8 == 0 else 0) | (pkg.F_STREAM_END if r8 == 7 else 0)
                 eng.reset()
                 peaks.zero_()
+                if r8 > 0:   # (the seeding pass reads the shard's first block too: the history in front of it must be the file's, as in the main pass)
+                    h8 = x[:, c0 * P - H:c0 * P].contiguous()
+                    eng.prime_dev(h8.data_ptr(), H, H, st)
                 eng.sweep_seed_dev(xs8.data_ptr(), x.shape[1], xs8.shape[1], 0, 360, 1, -1, peaks.data_ptr(), fl8, 8, st)
                 torch.cuda.synchronize()
                 seeds.append(peaks.clone())

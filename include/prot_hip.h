@@ -112,6 +112,7 @@ typedef struct {
 #define PROT_FORM_POLY_OLA 1u      /* polyphase, overlap-add, spectrum table (olapoly_kernel) */
 #define PROT_FORM_POLY_SAVE 2u     /* polyphase, overlap-save, table-free, generated loop (olasave_kernel) */
 #define PROT_FORM_POLY_SAVE8K 3u   /* the same on 8192-point blocks for long launches (olasave8k_kernel), olasave_kernel for short ones */
+#define PROT_FORM_POLY_SAVE16K 4u  /* the same on 16384-point blocks (olasave16k_kernel): CLI blksiz 16384, every fp32 launch */
 
 typedef struct prot_engine prot_engine;
 
@@ -292,8 +293,9 @@ int prot_sweep_stats_fused (prot_engine* e, uint64_t out[2]);
  * file lists against one bound; so: every shard calls prot_sweep_seed_dev on its data (ONLY the seeding pass of the fused route, over
  * about n_blocks device blocks spread through the call -- 64 / shards is plenty; nothing of the engine's state moves, the table gets
  * the sample's maxima), the tables are merged (MAX all-reduce), and prot_sweep_dev on the same data then skips its own seeding
- * and lists against the merged bound.  Every entry a seed raises is a peak of real frames, so the final merged table is
- * bit-identical to a single pass.  Engines / calls the fused route does not take seed nothing (PROT_OK).
+ * and lists against the merged bound.  Every entry a seed raises is a peak of real frames -- the engine's history must be what
+ * the main call will find (prot_engine_prime_dev FIRST: the seeding pass may sample the shard's first block) --, so the final
+ * merged table is bit-identical to a single pass.  Engines / calls the fused route does not take seed nothing (PROT_OK).
  * prot_engine_prime_dev: n_frames of input pass into the history without being transformed -- what a shard does with the frames
  * in front of its range (cli/phase-rotate.cc: the previous block + the filter's memory). */
 int prot_sweep_seed_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_frames, int ang_start,

@@ -34,7 +34,7 @@ CFG_OVERLAP_ADD = 8
 CFG_PIPELINE = 16
 CFG_BLOCK4096 = 32
 CFG_STATIC_RUNS = 64
-FORM_DIRECT, FORM_POLY_OLA, FORM_POLY_SAVE, FORM_POLY_SAVE8K = 0, 1, 2, 3
+FORM_DIRECT, FORM_POLY_OLA, FORM_POLY_SAVE, FORM_POLY_SAVE8K, FORM_POLY_SAVE16K = 0, 1, 2, 3, 4
 
 # every symbol include/prot_hip.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = (

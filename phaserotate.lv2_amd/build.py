@@ -58,7 +58,7 @@ def build_lib(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
-    hdrs = [os.path.join(CSRC, h) for h in ("prot_fft.h", "prot_kernels.h", "prot_dev.h", "prot_ablate.h", "prot_olasave_asm.inc", "prot_olasave8k_asm.inc")] + \
+    hdrs = [os.path.join(CSRC, h) for h in ("prot_fft.h", "prot_kernels.h", "prot_dev.h", "prot_ablate.h", "prot_olasave_asm.inc", "prot_olasave8k_asm.inc", "prot_olasave16k_asm.inc")] + \
            [os.path.join(ROOT, "include", "prot_hip.h")]
     common = [hipcc, "--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall",
               "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")]
@@ -72,6 +72,7 @@ def build_lib(force=False, verbose=False):
         ("prot_kernels_f16.hip", ["-ffast-math"]),
         ("prot_olasave.hip", ["-ffast-math", "-fno-slp-vectorize"]),
         ("prot_olasave8k.hip", ["-ffast-math", "-fno-slp-vectorize"]),
+        ("prot_olasave16k.hip", ["-ffast-math", "-fno-slp-vectorize"]),
         # host logic mirrors the reference's float arithmetic: no fast-math
         ("prot_capi.hip", []),
     ]

@@ -259,6 +259,64 @@ bool save_tables8k (const std::vector<float>& fir, std::vector<float>& tab, floa
 	return true;
 }
 
+// The 16384-point block's constants (prot_olasave16k.hip, tools/gen/gen_olasave16k.py: device_table): five rows of 1024 float2 --
+// W_N^{(T - 1/2)}, W_N^{4 (T - 1/2)} (N = 16384), the half-shifted and the plain table of the middle passes ([ke][k2][c] and its
+// transpose: W1024^{(c - 1/2) ke} W256^{(c - 1/2) k2}, W1024^{k2 ke} W256^{c k2}), the |B| factors of the 1024 bins either side of
+// DC per thread -- and gain = mean |B| / 16384.  firlen = 16384 (8192 odd taps = 8 context rows).
+bool save_tables16k (const std::vector<float>& fir, std::vector<float>& tab, float& gain)
+{
+	const uint32_t F  = 16384;
+	const size_t   Lg = fir.size () / 2;
+	if (Lg != 8192) {
+		return false;
+	}
+	std::vector<double> re (F, 0.0), im (F, 0.0);
+	for (size_t s = 0; s < Lg; ++s) {
+		if (fir[2 * s + 1] != -fir[2 * (Lg - 1 - s) + 1] || fir[2 * s] != 0.f) {
+			return false;
+		}
+		re[s] = fir[2 * s + 1];
+	}
+	fft_f64 (re, im);
+	std::vector<double> rho (F);
+	for (uint32_t k = 0; k < F; ++k) {
+		const double a  = 2.0 * M_PI * ((double)(Lg / 2) * k / F - (double)k / (2.0 * F));
+		const double pr = -std::sin (a), pi = -std::cos (a);
+		const double br = re[k] * pr + im[k] * pi, bi = im[k] * pr - re[k] * pi;
+		if (std::fabs (bi) > 1e-9) {
+			return false;
+		}
+		rho[k] = -br;
+	}
+	double mean = 0;
+	for (uint32_t k = 1024; k < F - 1024; ++k) {
+		mean += rho[k];
+	}
+	mean /= (double)(F - 2048);
+	for (uint32_t k = 1024; k < F - 1024; ++k) {
+		if (std::fabs (rho[k] / mean - 1.0) > 1.5e-7) {
+			return false;
+		}
+	}
+	gain = (float)(mean / F);
+	tab.assign (2 * (size_t)5 * 1024, 0.f);
+	auto put = [&] (size_t idx, double ang) {
+		tab[2 * idx]     = (float)std::cos (ang);
+		tab[2 * idx + 1] = (float)std::sin (ang);
+	};
+	for (int T = 0; T < 1024; ++T) {
+		put ((size_t)T, -2.0 * M_PI * (T - 0.5) / F);
+		put ((size_t)1024 + T, -2.0 * M_PI * (T - 0.5) * 4.0 / F);
+		const int ke = T >> 8, hi = (T >> 4) & 15, lo = T & 15;
+		put ((size_t)2 * 1024 + T, -2.0 * M_PI * ((lo - 0.5) * ke / 1024.0 + (lo - 0.5) * hi / 256.0)); // [ke][k2 = hi][c = lo]
+		put ((size_t)3 * 1024 + T, -2.0 * M_PI * ((double)hi * ke / 1024.0 + (double)(hi * lo) / 256.0)); // [ke][c = hi][k2 = lo]
+		const int q = hi + 16 * ke + 64 * lo; // pass-3 layout: k1 = hi, k2 = lo
+		tab[2 * ((size_t)4 * 1024 + T)]     = (float)(rho[q] / mean);
+		tab[2 * ((size_t)4 * 1024 + T) + 1] = (float)(rho[q + 15360] / mean);
+	}
+	return true;
+}
+
 template <typename T>
 struct DevBuf {
 	T*     p   = nullptr;
@@ -410,6 +468,10 @@ struct prot_engine {
 	int            sv8_rows  = 0;     // new rows per 8192-point block (12 or 13)
 	float          sv8_gain  = 0.f;
 	DevBuf<float>  d_sv8;
+	// CLI blksiz 16384 (round 5): every fp32 launch on 16384-point blocks (olasave16k_kernel: one table-free partition, one launch)
+	bool           use_save16 = false;
+	float          sv16_gain  = 0.f;
+	DevBuf<float>  d_sv16;
 	// dynamic blocks (olasave8k_dyn_kernel): kDynSets counter records per channel, one set per launch in turn (a launch leaves its
 	// set zeroed; the turn keeps launches that overlap on different streams of the caller's apart)
 	DevBuf<uint32_t> d_dyn;
@@ -813,6 +875,31 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 			}
 			return finish ();
 		}
+	}
+	if (e->use_save16 && pipe_wait_post == nullptr && srv == nullptr) {
+		// CLI blksiz 16384: 16384-point blocks, 1024-thread workgroups, one per CU (equal runs: one workgroup per CU has no dispatch rank)
+		const int blk16 = 16384;
+		p.run_frames = pick_run_frames (e, n_out, n_chn, blk16, e->cus);
+		p.rank_cu    = 0;
+		p.sv         = e->d_sv16.p;
+		p.sv_gain    = e->sv16_gain;
+		p.sv_flags   = e->sv_flags;
+		p.conv_delay = (int)e->info.conv_delay;
+		p.accumulate = 0;
+		if (fs) {
+			if (!hilbert_only) {
+				return PROT_EUNSUPPORTED;
+			}
+			const int st = fs_prepare (16);
+			if (st != 0) {
+				return st > 0 ? PROT_OK : -st;
+			}
+		}
+		hipError_t err = prot::launch_ola_save16k (p, 8, n_chn, s);
+		if (err != hipSuccess) {
+			return hip_fail (err, "overlap-save (16384-point) ola kernel launch");
+		}
+		return finish ();
 	}
 	if (e->use_poly) {
 		const uint32_t np = std::min<uint32_t> (2, e->info.partitions); // partitions of g per launch
@@ -1510,6 +1597,25 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 			}
 		}
 	}
+	// The CLI's default engine at 88.2 / 96 kHz (blksiz 16384, cli/phase-rotate.cc:749-755): 8192 odd taps = 8 context rows of a
+	// 16384-POINT block -- ONE table-free partition, 16384 new frames per block, ONE launch (olasave16k_kernel, 1024-thread
+	// workgroups, one per CU) instead of two accumulating olapoly_kernel launches of two 2048-tap partitions each through a
+	// workspace in HBM.  Every fp32 launch of such an engine takes it (one form per CLI engine: chunked and sharded sweeps stay
+	// bit-identical); olapoly_kernel stays for its fp16 path and under the flags that ask for it.
+	std::vector<float> sv16_h;
+	if (use_poly && inf.kind == PROT_KIND_CLI && inf.firlen == 16384 && inf.conv_delay == 0 && inf.dry_delay == 8192 &&
+	    !(cfg->flags & (PROT_CFG_BLOCK4096 | PROT_CFG_OVERLAP_ADD | PROT_CFG_POLYPHASE)) && tuning_env ("PROT_NO_SAVE16K") == nullptr) {
+		e->use_save16 = save_tables16k (fir_taps, sv16_h, e->sv16_gain);
+		if (e->use_save16) {
+			inf.hop       = 16384;
+			inf.run_align = 16384;
+			inf.history   = std::max<uint32_t> (inf.history, 16384 + 256);
+			e->info.hop = inf.hop, e->info.run_align = inf.run_align, e->info.history = inf.history;
+			if (e->cus > 0 && tuning_env ("PROT_WG_PER_CU") == nullptr) {
+				e->wg_slots = e->cus;
+			}
+		}
+	}
 	const char* pipe_env = tuning_env ("PROT_PIPELINE");
 	if (e->use_save && ((cfg->flags & PROT_CFG_PIPELINE) || (pipe_env && atoi (pipe_env) != 0)) && !(pipe_env && atoi (pipe_env) == 0)) {
 		// consecutive stateful prot_apply_dev calls on the engine's own streams overlap
@@ -1568,8 +1674,12 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	    (rc = e->d_hist[1].ensure (hn)) || (rc = e->d_peaks.ensure ((size_t)PROT_MAXSAMPLE * inf.n_chn)) ||
 	    (rc = e->d_angles.ensure (PROT_MAXSAMPLE + 8)) || (rc = e->d_thr.ensure (prot::kSweepThrFloats * (size_t)inf.n_chn)) || (rc = e->d_ctr.ensure ((size_t)inf.n_chn * 32 * 32)) ||
 	    (rc = e->d_stats.ensure (4)) || (e->use_save && (rc = e->d_sv.ensure (sv_h.size ()))) ||
-	    (e->use_save8 && ((rc = e->d_sv8.ensure (sv8_h.size ())) || (rc = e->d_dyn.ensure ((size_t)prot_engine::kDynSets * inf.n_chn * prot::kDynWords))))) {
+	    (e->use_save8 && ((rc = e->d_sv8.ensure (sv8_h.size ())) || (rc = e->d_dyn.ensure ((size_t)prot_engine::kDynSets * inf.n_chn * prot::kDynWords)))) ||
+	    (e->use_save16 && (rc = e->d_sv16.ensure (sv16_h.size ())))) {
 		return fail (rc);
+	}
+	if (e->use_save16 && hipMemcpy (e->d_sv16.p, sv16_h.data (), sv16_h.size () * sizeof (float), hipMemcpyHostToDevice) != hipSuccess) {
+		return fail (PROT_EHIP);
 	}
 	if (e->use_save8 && hipMemset (e->d_dyn.p, 0, (size_t)prot_engine::kDynSets * inf.n_chn * prot::kDynWords * sizeof (uint32_t)) != hipSuccess) {
 		return fail (PROT_EHIP);
@@ -1581,7 +1691,7 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	if (e->use_save && hipMemcpy (e->d_sv.p, sv_h.data (), sv_h.size () * sizeof (float), hipMemcpyHostToDevice) != hipSuccess) {
 		return fail (PROT_EHIP);
 	}
-	e->info.form      = e->use_save8 ? PROT_FORM_POLY_SAVE8K : e->use_save ? PROT_FORM_POLY_SAVE : use_poly ? PROT_FORM_POLY_OLA : PROT_FORM_DIRECT;
+	e->info.form      = e->use_save16 ? PROT_FORM_POLY_SAVE16K : e->use_save8 ? PROT_FORM_POLY_SAVE8K : e->use_save ? PROT_FORM_POLY_SAVE : use_poly ? PROT_FORM_POLY_OLA : PROT_FORM_DIRECT;
 	e->info.wg_per_cu = e->cus > 0 ? (uint32_t)(e->wg_slots / e->cus) : 0;
 	if ((!Hp_h.empty () && hipMemcpy (e->d_Hp.p, Hp_h.data (), Hp_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess) ||
 	    hipMemcpy (e->d_H.p, H_h.data (), H_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess ||
@@ -1670,6 +1780,7 @@ void prot_engine_destroy (prot_engine* e)
 	e->d_H.release ();
 	e->d_sv.release ();
 	e->d_sv8.release ();
+	e->d_sv16.release ();
 	e->d_dyn.release ();
 	e->d_surv.release ();
 	e->d_surv_cnt.release ();
@@ -2098,9 +2209,9 @@ static int sweep_dev_impl (prot_engine* e, const float* d_in, int64_t in_stride,
 	// several accumulating olapoly launches -- blksiz 16384, 32768 -- the LAST of those launches, which then tests the complete
 	// Hilbert value instead of storing it; the earlier launches leave their partial sums in the engine's Hilbert workspace)
 	// (... and the one launch of CLI blksiz 1024, whose 14-row blocks the overlap-save kernel does not take)
-	const bool fuse_poly = e->use_poly && !e->use_save && !e->sv8_always &&
+	const bool fuse_poly = e->use_poly && !e->use_save && !e->sv8_always && !e->use_save16 &&
 	                       ((e->info.partitions >= 4 && e->hopseg == 16) || (e->info.partitions == 1 && e->hopseg == 28));
-	const bool fusable = ((e->use_save && (e->hopseg == 16 || e->hopseg == 24) && !(e->sv_flags & 1)) || fuse_poly || (e->sv8_always && !(e->sv_flags & 1))) &&
+	const bool fusable = ((e->use_save && (e->hopseg == 16 || e->hopseg == 24) && !(e->sv_flags & 1)) || fuse_poly || ((e->sv8_always || e->use_save16) && !(e->sv_flags & 1))) &&
 	                     !test_opt (PROT_TEST_SWEEP_UNPRUNED) && !test_opt (PROT_TEST_SWEEP_UNFUSED);
 	CallStream  s (e, stream);
 	const int   c0  = chn < 0 ? 0 : chn;                       // cli/phase-rotate.cc:434-435

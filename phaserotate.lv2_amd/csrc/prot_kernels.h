@@ -139,6 +139,8 @@ struct SvServerAck {
 hipError_t launch_ola_save_server (const SvServerBox* box, SvServerAck* ack, unsigned* relay, unsigned last_seq, int hop_rows, int n_chn, hipStream_t s);
 hipError_t post_ola_save_server (const OlaParamsT<float>& p, int hop_rows, int n_rho_rows, int n_chn, SvServerBox* box);
 hipError_t launch_ola_save8k (const OlaParams& p, int hop_rows, int n_chn, hipStream_t s);
+// the same on 16384-point blocks (prot_olasave16k.hip: 1024-thread workgroups, hop_rows = 8: CLI blksiz 16384)
+hipError_t launch_ola_save16k (const OlaParams& p, int hop_rows, int n_chn, hipStream_t s);
 
 // fp16 sample path (BASELINE config 5): half samples in HBM, packed-half butterflies,
 // fp32 overlap-add + rotation.  Stateless, steady rotation.

@@ -1,0 +1,352 @@
+// prot_olasave16k.hip -- olasave16k_kernel: the overlap-save, table-free polyphase block of prot_olasave8k.hip on a 16384-POINT
+// transform pair (round 5).  1024 threads (16 waves) per workgroup, 16 points per thread, ONE workgroup per CU (154 KiB of LDS): the
+// CLI's default engine at 88.2 / 96 kHz (blksiz 16384, cli/phase-rotate.cc:749-755) has 8192 odd taps = 8 context rows of 1024
+// complex samples, 8 rows = 16384 frames new per block -- ONE table-free partition in ONE launch.  Until round 5 its Hilbert pass
+// was two accumulating olapoly_kernel launches of two 2048-tap partitions each through a workspace in HBM (cfg4: 4.7 ms, 17 bytes
+// per channel-frame by counter against the sweep's algorithmic 4: VERDICT r4 item 3).
+//
+// What it replaces: PhaseRotateProc::hilbert / rotate (cli/phase-rotate.cc:181-232) at that block size, exactly as olasave8k_kernel
+// does at blksiz 8192.  The transform is 16 x 4 x 16 x 16: the radix-4 layer over the two top bits of the thread index is taken by
+// the READER of the first LDS exchange (forward) and of the last one (inverse); tools/model/olasave_model16k.py is the numpy model,
+// tools/gen/gen_olasave16k.py the generator of ALL the arithmetic (prot_olasave16k_asm.inc: a streamed run of blocks, one LDS-staged
+// block for edges, MODE_SWEEP with the sweep's test in the epilogue); this file moves data.  Same division of labour and the same
+// C++ around the generated code as prot_olasave8k.hip (edges, history, per-frame rotation, the sweep's lists).
+#include "prot_dev.h"
+
+namespace prot {
+
+typedef volatile __attribute__ ((address_space (3))) f2 LdsC16;
+typedef volatile __attribute__ ((address_space (3))) float LdsF16;
+
+#include "prot_olasave16k_asm.inc"
+
+constexpr int kSv16LdsBytes = 16 * 1104 * 8 + 16384; // exchange area (16 rows of 1104 slots) + the two 1024-entry twiddle tables
+
+#define PROT_SV16_CAT_(k, a, b) PROT_SV16_##k##_##a##_##b
+#define PROT_SV16_CLOB_(a) PROT_SV16_ASM_CLOBBERS_##a
+#define PROT_SV16_CALL(KIND_, HS_, AM_, in_, out_, nf_, ca_, sa_)                                                                      \
+	if (HS == HS_ && AM == AM_) {                                                                                                       \
+		asm volatile (PROT_SV16_CAT_ (KIND_, HS_, AM_)                                                                                  \
+		              :                                                                                                                 \
+		              : "s"(in_), "s"(out_), "s"(nf_), "s"(lds_off), "s"(a_sv), "s"(ca_), "s"(sa_), "v"(t0)                                \
+		              : PROT_SV16_CLOB_ (HS_));                                                                                         \
+	}
+#define PROT_SV16_ALL(KIND_, in_, out_, nf_, ca_, sa_)                                                                                 \
+	PROT_SV16_CALL (KIND_, 8, 0, in_, out_, nf_, ca_, sa_)                                                                              \
+	PROT_SV16_CALL (KIND_, 8, 2, in_, out_, nf_, ca_, sa_)
+#define PROT_SV16_SWEEP_CALL(HS_, in_, cursor_, raw_, nf_, thr_, gain_)                                                                \
+	if (HS == HS_) {                                                                                                                    \
+		asm volatile (PROT_SV16_SWEEP_##HS_                                                                                             \
+		              : "=s"(cursor_), "=v"(raw_)                                                                                       \
+		              : "s"(in_), "s"(nf_), "s"(lds_off), "s"(a_sv), "s"(thr_), "s"(gain_), "v"(t0), "s"(cursor_), "v"(raw_)             \
+		              : PROT_SV16_SWEEP_CLOBBERS_##HS_);                                                                                \
+	}
+
+// HS new rows (2048 HS frames) per block; MODE_ROT / MODE_RAMP / MODE_HILBERT / MODE_SWEEP.  Consecutive whole in-range blocks are ONE
+// call of the generated loop; every other block is staged here, position by position, into the LDS exchange area, transformed by
+// the generated CORE (the same instructions on the same values: the two paths agree bit for bit) and stored from LDS with bounds.
+template <int HS, int MODE>
+__global__ __launch_bounds__ (1024) void olasave16k_kernel (const OlaParams p)
+{
+	constexpr int BLK = 2048 * HS;           // output frames per block
+	constexpr int NT  = 16 - HS;             // context rows (of 1024 complex samples = 2048 frames)
+	constexpr int R0  = NT / 2;              // first valid output row = first dry row
+	constexpr int ROT = 0;                   // (an even number of context rows: no rotation)
+	constexpr int AM  = MODE == MODE_ROT ? 0 : 2;
+	static_assert (HS == 8, "rows per block");
+	
+
+	extern __shared__ f2 smem16[]; // kSv16LdsBytes: the exchange area + the two tables (written by the generated prologue)
+
+	const int t0 = threadIdx.x;
+	const int c  = blockIdx.y;
+	// MODE_SWEEP state (as in prot_olasave.hip: the bound parked per wave in global memory behind the list lengths and re-read where
+	// it is used, nothing per lane but the running maximum and nothing uniform but the count lives across the generated code)
+	__shared__ float sw_lo_s[16];
+	float            sw_raw = 0.f;
+	unsigned         sw_cnt = 0u;
+	auto sw_thr_slot = [&] () -> float* {
+		const int w = __builtin_amdgcn_readfirstlane (threadIdx.x >> 6);
+		return reinterpret_cast<float*> (p.surv_cnt) + (int64_t)gridDim.y * gridDim.x * 16 + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + w;
+	};
+	auto sw_thr = [&] () -> float {
+		return __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (__hip_atomic_load (sw_thr_slot (), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))));
+	};
+	auto sw_wave_reduce = [] (float v, bool take_max) -> float {
+		int lane;
+		asm volatile ("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+		for (int m = 1; m < 64; m <<= 1) {
+			const float o = __int_as_float (__builtin_amdgcn_ds_bpermute ((lane ^ m) << 2, __float_as_int (v)));
+			v             = take_max ? fmaxf (v, o) : fminf (v, o);
+		}
+		return v;
+	};
+	auto sw_list = [&] () -> float2* {
+		const int w = __builtin_amdgcn_readfirstlane (threadIdx.x >> 6);
+		return uniform_ptr_generic (p.surv + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + w) * p.surv_cap);
+	};
+	if (MODE == MODE_SWEEP) {
+		float lo = 1.0e18f;
+		if (!p.sw_thr_zero) {
+			for (int i = t0; i < p.sw_n_angles; i += 1024) {
+				lo = fminf (lo, __builtin_nontemporal_load (&p.sw_peaks[(int64_t)c * kMaxSample + p.sw_angles[i]]));
+			}
+		} else {
+			lo = 0.f;
+		}
+		lo = sw_wave_reduce (lo, false);
+		if ((t0 & 63) == 0) {
+			sw_lo_s[t0 >> 6] = lo;
+		}
+		__syncthreads ();
+		lo = sw_lo_s[0];
+		for (int i = 1; i < 16; ++i) {
+			lo = fminf (lo, sw_lo_s[i]);
+		}
+		__syncthreads ();
+		if ((t0 & 63) == 0) {
+			__hip_atomic_store (sw_thr_slot (), lo * lo * 0.9999f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+	}
+	int64_t   r0, rlen;
+	run_of_workgroup (p, r0, rlen);
+	if (r0 >= p.n_out) {
+		if (t0 < 256) {
+			hist_write_slice (p, blockIdx.y, t0);
+		}
+		if (MODE == MODE_SWEEP && (t0 & 63) == 0) {
+			p.surv_cnt[((int64_t)c * gridDim.x + blockIdx.x) * 16 + (t0 >> 6)] = 0u;
+		}
+		return;
+	}
+
+	const int64_t r1 = (r0 + rlen < p.n_out) ? r0 + rlen : p.n_out;
+
+	const float* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
+	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
+	float* __restrict__ out        = p.out + (int64_t)c * p.out_stride;
+	const int64_t n_in = p.n_in;
+	const int     Dd   = p.dry_delay; // even (host guarantees)
+	const bool in_al8  = (reinterpret_cast<uintptr_t> (in) & 7) == 0;
+	const bool out_al8 = (reinterpret_cast<uintptr_t> (out) & 7) == 0;
+
+	if (MODE == MODE_SWEEP && p.sw_raw_slot >= 0 && p.sw_raw_tail && blockIdx.x == 0) {
+		// the call's last dry_delay input frames: the rows reach them only as the next chunk's history (see prot_sweep.hip)
+		for (int64_t i = n_in - Dd + t0; i < n_in; i += 1024) {
+			sw_raw = fmaxf (sw_raw, i >= 0 ? fabsf (in[i]) : 0.f);
+		}
+	}
+	float ca = 0.f, sa = p.sv_gain;
+	if (MODE == MODE_ROT) {
+		ca = p.rot ? p.rot[2 * c] : p.rot_v[2 * c];
+		sa = (p.rot ? p.rot[2 * c + 1] : p.rot_v[2 * c + 1]) * p.sv_gain;
+	}
+	ca = __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (ca)));
+	sa = __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (sa)));
+	const unsigned lds_off = (unsigned)(uintptr_t)(__attribute__ ((address_space (3))) f2*)smem16;
+	const float*   a_sv    = uniform_ptr_generic (p.sv);
+
+	const bool hist_al8 = hist != nullptr && (reinterpret_cast<uintptr_t> (hist) & 7) == 0 && (p.hist_len & 1) == 0;
+	// the (x[a], x[a+1]) pair of lane t (0..255) in the 512-frame half row that starts at frame ar: a half row lies wholly in
+	// the input array or wholly in the history (both start on half-row boundaries) -- aligned 8-byte loads; anything else
+	// (silence in reach, odd alignment) frame by frame through the virtual stream [history | input | silence]
+	auto half_pair = [&] (int64_t ar, int t) -> f2 {
+		if (in_al8 && ar >= 0 && ar + 512 <= n_in) {
+			return reinterpret_cast<const f2*> (in + ar)[t];
+		}
+		if (hist_al8 && ar + 512 <= 0 && ar + p.hist_len >= 0) {
+			return reinterpret_cast<const f2*> (hist + (ar + p.hist_len))[t];
+		}
+		const int64_t a = ar + 2 * (int64_t)t;
+		return mkf2 (ldv (in, n_in, hist, p.hist_len, a), ldv (in, n_in, hist, p.hist_len, a + 1));
+	};
+
+	for (int64_t s = r0; s < r1;) {
+		// frame of local sample 0's aligned pair: the dry frame of output position p is input position p, and output row R0
+		// starts at local sample 512 R0 + ROT
+		const int64_t a0 = s - Dd - 2048 * R0;
+		if (MODE != MODE_RAMP && in_al8 && (out_al8 || MODE == MODE_SWEEP) && a0 >= 1 && !(p.sv_flags & 1) &&
+		    (MODE != MODE_SWEEP || (s >= p.sw_t_begin && s >= p.sw_dry_from))) {
+			// blocks from here on that read only frames inside the array (local samples 0..8191 and the frame in front) and
+			// are emitted whole
+			const int64_t n1 = (r1 - s) / BLK;
+			const int64_t n2 = n_in - 32768 - a0 >= 0 ? (n_in - 32768 - a0) / BLK + 1 : 0;
+			int           nf = (int)(n1 < n2 ? n1 : n2);
+			if (nf > 0) {
+				nf                 = __builtin_amdgcn_readfirstlane (nf);
+				const float* a_in  = uniform_ptr_generic (in + a0);
+				if constexpr (MODE == MODE_SWEEP) {
+					float2* const base  = sw_list ();
+					float2*       cur   = uniform_ptr_generic (base + sw_cnt);
+					const float   thr_u = sw_thr ();
+					PROT_SV16_SWEEP_CALL (8, a_in, cur, sw_raw, nf, thr_u, sa)
+					sw_cnt = (unsigned)__builtin_amdgcn_readfirstlane ((int)(cur - sw_list ()));
+				} else {
+					float* a_out = uniform_ptr_generic (out + s);
+					PROT_SV16_ALL (ASM, a_in, a_out, nf, ca, sa)
+				}
+				s += (int64_t)nf * BLK;
+				continue;
+			}
+		}
+		// ---- one block through LDS
+		int t = t0;
+		asm volatile ("" : "+v"(t)); // (opaque per block: per-lane address terms are otherwise hoisted out of the loop)
+		t &= 1023;
+		LdsC16* const st = (LdsC16*)smem16;          // positions: slot 1024 row + T
+		LdsF16* const gc = (LdsF16*)(smem16 + 16384); // byte 131072: the frame in front of each wave's first sample of row (lane), lanes 0..15
+		__syncthreads (); // (every wave has left the generated loop, if that is where it comes from)
+		{
+			const int h = t >> 8, tl = t & 255; // (quarter rows of 256 samples = 512 frames: wholly in the input or wholly in the history)
+#pragma unroll 2
+			for (int k = 0; k < 16; ++k) {
+				const int nloc = 1024 * k + 256 * h; // first local sample of this quarter row
+				st[1024 * k + t] = half_pair (a0 + 2 * (int64_t)nloc, tl);
+			}
+			const int l = t & 63, w = t >> 6;
+			const int nl = 1024 * (l & 15) + 64 * w;
+			gc[t]        = l < 16 ? ldv (in, n_in, hist, p.hist_len, a0 + 2 * (int64_t)nl - 1) : 0.f;
+		}
+		__syncthreads ();
+		{
+			const float  cca = (MODE == MODE_RAMP || MODE == MODE_SWEEP) ? 0.f : ca, csa = MODE == MODE_RAMP ? __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (p.sv_gain))) : sa;
+			const float* a_in  = a_sv; // (unused by the core)
+			float*       a_out = nullptr;
+			const int    one   = 1;
+			PROT_SV16_ALL (CORE, a_in, a_out, one, cca, csa)
+		}
+		__syncthreads ();
+		// (the thread id opaque again: nothing per-lane may live across the generated code, see prot_olasave.hip)
+		t = t0;
+		asm volatile ("" : "+v"(t));
+		t &= 1023;
+		// rows 0..HS-1 of the staging area now hold the output pairs of frames s + 1024 k + 2 t (+1)
+		if constexpr (MODE == MODE_SWEEP) {
+			// the sweep's test on an edge block (prot_olasave.hip): frames in front of sw_t_begin or beyond the call are not tested, the
+			// dry term is 0 while t < sw_dry_from (Q1; the raw peak takes the frame all the same)
+			float2* const list    = sw_list ();
+			const float   sw_thr2 = sw_thr ();
+			for (int k = 0; k < HS; ++k) {
+				const f2      hp   = st[1024 * k + t];
+				const int64_t pos0 = s + 2048 * (int64_t)k + 2 * (int64_t)t;
+				const f2      dp   = half_pair (pos0 - 2 * (int64_t)(t & 255) - Dd, t & 255);
+#pragma unroll
+				for (int e = 0; e < 2; ++e) {
+					const int64_t pos = pos0 + e;
+					const bool    in_ = pos >= p.sw_t_begin && pos < r1;
+					const float   raw = e ? dp.y : dp.x, h = e ? hp.y : hp.x;
+					const float   d   = pos >= p.sw_dry_from ? raw : 0.f;
+					if (in_) {
+						sw_raw = fmaxf (sw_raw, fabsf (raw));
+					}
+					const bool     live = in_ && d * d + h * h > sw_thr2;
+					const uint64_t mask = __builtin_amdgcn_ballot_w64 (live);
+					if (live) {
+						list[sw_cnt + __builtin_amdgcn_mbcnt_hi ((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned)mask, 0u))] = make_float2 (d, h);
+					}
+					sw_cnt += (unsigned)__builtin_popcountll (mask);
+				}
+			}
+		} else if (MODE != MODE_RAMP && s + BLK <= r1 && out_al8) {
+#pragma unroll
+			for (int k = 0; k < HS; ++k) {
+				PROT_GLOBAL f2* __restrict__ ob = reinterpret_cast<PROT_GLOBAL f2*> (uniform_ptr (out + s + 2048 * k));
+				ob[(unsigned)t]                 = st[1024 * k + t];
+			}
+		} else {
+#pragma unroll 2
+			for (int k = 0; k < HS; ++k) {
+				f2            o    = st[1024 * k + t];
+				const int64_t pos0 = s + 2048 * (int64_t)k + 2 * (int64_t)t;
+				if (MODE == MODE_RAMP && pos0 < r1) {
+					// per-frame rotation: the dry pair of an output pair is the input pair Dd frames earlier
+					const f2 d   = half_pair (pos0 - 2 * (int64_t)(t & 255) - Dd, t & 255);
+					const f2 cs0 = reinterpret_cast<const f2*> (p.rot_s)[(int64_t)c * p.n_out + pos0];
+					const f2 cs1 = pos0 + 1 < r1 ? reinterpret_cast<const f2*> (p.rot_s)[(int64_t)c * p.n_out + pos0 + 1] : mkf2 (0.f, 0.f);
+					o            = mkf2 (cs0.x * d.x + cs0.y * o.x, cs1.x * d.y + cs1.y * o.y);
+				}
+				if (pos0 < r1) {
+					out[pos0] = o.x;
+				}
+				if (pos0 + 1 < r1) {
+					out[pos0 + 1] = o.y;
+				}
+			}
+		}
+		__syncthreads (); // (the output rows have been read: the exchange area is free for whatever comes next)
+		s += BLK;
+	}
+	if (t0 < 256) {
+		hist_write_slice (p, blockIdx.y, t0);
+	}
+	if constexpr (MODE == MODE_SWEEP) {
+		if ((t0 & 63) == 0) {
+			p.surv_cnt[((int64_t)c * gridDim.x + blockIdx.x) * 16 + (t0 >> 6)] = sw_cnt;
+		}
+		if (p.sw_raw_slot >= 0) {
+			sw_raw = sw_wave_reduce (sw_raw, true);
+			if ((t0 & 63) == 0 && sw_raw > 0.f) { // (non-negative floats order as their bit patterns; look before the atomic)
+				unsigned* const slot = reinterpret_cast<unsigned*> (p.sw_peaks + (int64_t)c * kMaxSample + p.sw_raw_slot);
+				if (__float_as_uint (sw_raw) > __hip_atomic_load (slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+					atomicMax (slot, __float_as_uint (sw_raw));
+				}
+			}
+		}
+	}
+}
+
+
+template <int HS>
+static hipError_t launch_sv16_m (const OlaParams& p, dim3 grid, hipStream_t s)
+{
+	const dim3 block (1024);
+	typedef void (*kern_t) (OlaParams);
+	kern_t fn = p.hilbert_only ? olasave16k_kernel<HS, MODE_HILBERT> : p.rot_s != nullptr ? olasave16k_kernel<HS, MODE_RAMP> : olasave16k_kernel<HS, MODE_ROT>;
+	if (p.surv != nullptr) { // the fused sweep: the Hilbert pass with the test in its epilogue (lists instead of output rows)
+		if constexpr (HS == 8) {
+			fn = olasave16k_kernel<HS, MODE_SWEEP>;
+		} else {
+			return hipErrorInvalidValue;
+		}
+	}
+	// (more than 64 KiB of LDS per workgroup has to be asked for, once per kernel and device)
+	static bool asked[4][8] = {};
+	int         dev = 0;
+	(void)hipGetDevice (&dev);
+	const int mi = p.surv != nullptr ? 3 : p.hilbert_only ? 2 : p.rot_s != nullptr ? 1 : 0;
+	if (dev >= 0 && dev < 8 && !asked[mi][dev]) {
+		hipError_t err = hipFuncSetAttribute ((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, kSv16LdsBytes);
+		if (err != hipSuccess) {
+			return err;
+		}
+		asked[mi][dev] = true;
+	} else if (dev >= 8) {
+		hipError_t err = hipFuncSetAttribute ((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, kSv16LdsBytes);
+		if (err != hipSuccess) {
+			return err;
+		}
+	}
+	hipLaunchKernelGGL (fn, grid, block, kSv16LdsBytes, s, p);
+	return hipGetLastError ();
+}
+
+hipError_t launch_ola_save16k (const OlaParams& p, int hop_rows, int n_chn, hipStream_t s)
+{
+	if ((p.dry_delay & 1) || (p.run_frames % (2048 * hop_rows)) != 0 || p.accumulate || p.sv == nullptr || p.hs_flag != nullptr ||
+	    2 * (p.dry_delay - p.conv_delay) != 2048 * (16 - hop_rows)) {
+		return hipErrorInvalidValue;
+	}
+	if (p.n_out <= 0) {
+		return hipSuccess;
+	}
+	const int64_t unit = p.run_stride > 0 ? p.run_stride : p.run_frames;
+	const int64_t runs = (p.n_out + unit - 1) / unit;
+	dim3          grid ((unsigned)runs, (unsigned)n_chn);
+	switch (hop_rows) {
+		case 8: return launch_sv16_m<8> (p, grid, s);
+		default: return hipErrorInvalidValue;
+	}
+}
+
+} // namespace prot

@@ -111,3 +111,37 @@ def test_committed_8192_point_include_is_current(tmp_path):
     G8.emit(str(dst))
     cur = open(os.path.join(ROOT, "phaserotate.lv2_amd", "csrc", "prot_olasave8k_asm.inc")).read()
     assert open(dst).read() == cur, "run python3 tools/gen/gen_olasave8k.py"
+
+
+@pytest.mark.parametrize("mode,kind", [(2, "run"), (0, "core"), (3, "run")])
+def test_generated_16384_point_block_matches_float64_convolution(mode, kind):
+    """tools/gen/gen_olasave16k.py (round 5: 16384-point blocks, 1024 threads, a radix-4 layer taken by the readers of the first and
+    last LDS exchange -- four code variants by the wave's ke --, its twiddle W64^{b ke} from the W32 constants and one more): the CLI
+    blksiz 16384 engine's Hilbert loop, a staged block with rotation, and the sweep variant (sixteen waves' survivor lists against
+    the float64 convolution), in the emulator."""
+    import gen_olasave16k as G16
+    G16.self_test(8, mode, nblk=2, kind=kind, verbose=False)
+
+
+def test_committed_16384_point_include_is_current(tmp_path):
+    import gen_olasave16k as G16
+    dst = tmp_path / "asm16k.inc"
+    G16.emit(str(dst))
+    cur = open(os.path.join(ROOT, "phaserotate.lv2_amd", "csrc", "prot_olasave16k_asm.inc")).read()
+    assert open(dst).read() == cur, "run python3 tools/gen/gen_olasave16k.py"
+
+
+def test_model_of_the_16384_point_block():
+    """tools/model/olasave_model16k.py: the radix-4 layer's index arithmetic against numpy's FFT, the table-free block against the
+    direct convolution with the 8192 odd taps of the CLI's default filter at 96 kHz"""
+    import numpy as np
+    import olasave_model16k as M
+    rng = np.random.default_rng(3)
+    w = rng.standard_normal(M.N) + 1j * rng.standard_normal(M.N)
+    Z = np.fft.fft(w) * M.W(-np.arange(M.N), 2 * M.N)
+    assert np.abs(M.fwd_shifted(w) - Z[M.kindex()]).max() < 1e-8
+    g = M.hilbert_fir(16384)[1::2]
+    B = M.tables(g)
+    z = 0.3 * (rng.standard_normal(M.N) + 1j * rng.standard_normal(M.N))
+    want = np.convolve(z, g)[len(g) // 2:len(g) // 2 + M.N]
+    assert np.abs(M.block(z, B) - want)[1024 * 4:1024 * 12].max() < 1e-7

@@ -1504,6 +1504,47 @@ def test_dynamic_blocks_equal_static_runs(pkg, kind, param, chn, n, stateless):
         assert torch.equal(outs["dynamic"][0], outs["dynamic"][2])   # (a stateless call twice: the same bits)
 
 
+def test_block16384_kernel_cli_default_engine_at_96k(pkg):
+    """Round 5: the CLI's default engine at 88.2 / 96 kHz (blksiz 16384, cli/phase-rotate.cc:749-755) on 16384-POINT blocks
+    (olasave16k_kernel: 1024-thread workgroups, the radix-4 layer taken by the readers of the LDS exchanges, ONE table-free
+    partition in ONE launch) against the two accumulating launches of olapoly_kernel it replaces (PROT_CFG_OVERLAP_ADD: another
+    fp32 transform of the same filter, 2e-6), with every block through the LDS-staged path bit for bit against the generated loop,
+    for the rotation, the Hilbert branch alone and a per-frame rotation; stereo, ragged length, stateful pair of calls."""
+    import torch
+    dev = torch.device("cuda:0")
+    P, chn, n = 16384, 2, (1 << 22) + 12346
+    g = torch.Generator(device=dev).manual_seed(16)
+    x = torch.rand(chn * n, generator=g, device=dev) - 0.5
+    rot = np.array([0.28, -0.96, -0.6, 0.8], np.float32)
+    ramp = torch.stack([torch.cos(torch.linspace(0, 3, n, device=dev)), torch.sin(torch.linspace(0, 3, n, device=dev))], 1).repeat(chn, 1).contiguous()
+    outs = {}
+    for tag, flags, edge in (("16k", 0, 0), ("ola", pkg.CFG_OVERLAP_ADD, 0), ("16k-staged", 0, 1)):
+        pkg.set_test_option(pkg.TEST_EDGE_PATH_ONLY, edge)
+        try:
+            e = pkg.Engine(pkg.KIND_CLI, P, chn, flags=flags)
+        finally:
+            pkg.set_test_option(pkg.TEST_EDGE_PATH_ONLY, 0)
+        assert int(e.info.form) == (pkg.FORM_POLY_SAVE16K if flags == 0 else pkg.FORM_POLY_OLA)
+        y, u, r, y2 = (torch.zeros_like(x) for _ in range(4))
+        torch.cuda.synchronize()
+        e.apply_dev(x.data_ptr(), n, n, y.data_ptr(), n, n, rot, pkg.F_STATELESS)
+        e.hilbert_dev(x.data_ptr(), n, n, u.data_ptr(), n, n, pkg.F_STATELESS)
+        e.apply_dev_ramp(x.data_ptr(), n, n, r.data_ptr(), n, n, ramp.data_ptr(), pkg.F_STATELESS)
+        e.reset()
+        half = (n // 2) // P * P
+        e.apply_dev(x.data_ptr(), n, half, y2.data_ptr(), n, half, rot, 0)
+        e.apply_dev(x.data_ptr() + 4 * half, n, n - half, y2.data_ptr() + 4 * half, n, n - half, rot, 0)
+        e.sync()
+        outs[tag] = (y, u, r, y2)
+        e.close()
+    for a, b in zip(outs["16k"], outs["ola"]):
+        assert float((a - b).abs().max()) < TOL
+    for a, b in zip(outs["16k"], outs["16k-staged"]):
+        assert torch.equal(a, b)
+    assert float((outs["16k"][0] - outs["16k"][3]).abs().max()) < TOL     # stateful pair == one stateless call, to rounding (other block grid)
+    assert float(outs["16k"][0].abs().max()) > 0.1
+
+
 def test_block8192_kernel_lv2_192k(pkg):
     """LV2 at 192 kHz (8192 taps): long launches on 8192-point blocks as ONE table-free partition (HS = 8) against the two-partition
     overlap-add kernel on 4096-point transforms (PROT_CFG_BLOCK4096) and, in windows, against the CPU oracle's run()."""

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-@pytest.mark.parametrize("unit", ["prot_olasave.hip", "prot_olasave8k.hip"])
+@pytest.mark.parametrize("unit", ["prot_olasave.hip", "prot_olasave8k.hip", "prot_olasave16k.hip"])
 def test_shipped_kernels_carry_nothing_across_the_generated_code_under_a_partial_exec_mask(unit):
     import lint_exec_copies as L
     hits = L.lint(L.compile_asm(unit))

@@ -8,7 +8,8 @@ UNITS = [("prot_kernels.hip", ["-ffast-math", "-fno-slp-vectorize"]),
          ("prot_sweep.hip", ["-ffast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
          ("prot_kernels_f16.hip", ["-ffast-math"]),
          ("prot_olasave.hip", ["-ffast-math", "-fno-slp-vectorize"]),
-         ("prot_olasave8k.hip", ["-ffast-math", "-fno-slp-vectorize"])]
+         ("prot_olasave8k.hip", ["-ffast-math", "-fno-slp-vectorize"]),
+         ("prot_olasave16k.hip", ["-ffast-math", "-fno-slp-vectorize"])]
 want = set(sys.argv[1:])
 print("%-78s %5s %5s %5s %7s %6s %4s" % ("kernel", "VGPR", "AGPR", "SGPR", "scratch", "LDS", "occ"))
 for unit, flags in UNITS:

@@ -35,6 +35,9 @@ def run(P, world=8, which=3, kind="harmonic"):
             fl0 = (pkg.F_STREAM_START if r == 0 else 0) | (pkg.F_STREAM_END if r == world - 1 else 0)
             eng.reset()
             peaks.zero_()
+            if r > 0:
+                hh = xa[:, b0 * P - H:b0 * P].contiguous()
+                eng.prime_dev(hh.data_ptr(), H, H, st)
             eng.sweep_seed_dev(xs.data_ptr(), xa.shape[1], xs.shape[1], 0, 360, 1, -1, peaks.data_ptr(), fl0, max(8, 64 // world), st)
             torch.cuda.synchronize()
             gseed = torch.maximum(gseed, peaks)
