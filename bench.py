@@ -401,7 +401,9 @@ def main():
         eng3 = pkg.Engine(pkg.KIND_CLI, 8192, 1, device=local_rank)
         wall3, kms3 = timed(eng3, args.steps, args.warmup, n)
         out["cli_8192"] = {
-            "workload": ("CLI engine blksiz 8192 (8192-tap FIR): polyphase, the 4096 odd taps as one table-free partition on 8192-point "
+            "workload": ("CLI engine blksiz 8192 (8192-tap FIR): polyphase, the 4096 odd taps as one table-free partition on 16384-point "
+                         "overlap-save blocks (olasave16k_kernel<12, 0>: 12 of 16 rows new)" if int(eng3.info.form) == pkg.FORM_POLY_SAVE16K else
+                         "CLI engine blksiz 8192 (8192-tap FIR): polyphase, the 4096 odd taps as one table-free partition on 8192-point "
                          "overlap-save blocks (8 of 16 rows new)" if int(eng3.info.form) == pkg.FORM_POLY_SAVE8K else
                          "CLI engine blksiz 8192 (8192-tap FIR): polyphase, two 2048-tap partitions of the odd taps in one launch"),
             "value": world * n * args.steps / wall3, "unit": "frames/s",
@@ -943,12 +945,12 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
                 "min_angle_index": h["min_angle_index"], "per_rank_device_ms": h["per_rank_device_ms"],
                 "predicted_8gpu": h.get("predicted_8gpu"), "oracle_check_10s": check,
                 "fused": h["fused"], "listed_fraction": h["listed_fraction"],
-                "engine": ("16384-tap FIR = four 2048-tap partitions of the odd taps: two accumulating launches of two partitions each "
-                           "for the Hilbert branch (olapoly_kernel<T32, 2, 8, ...>); round 4: the SECOND launch tests the complete Hilbert value "
-                           "with its dry frame instead of storing it and lists the survivors (MODE_SWEEP), sweep_eval_kernel evaluates the lists")
+                "engine": ("16384-tap FIR = 8192 odd taps as ONE table-free partition on 16384-point overlap-save blocks (olasave16k_kernel<8, MODE_SWEEP>: "
+                           "1024-thread workgroups, one per CU; ONE launch reads the stream once, tests and lists -- rounds 2-4: two accumulating "
+                           "olapoly_kernel launches of two 2048-tap partitions each through a workspace in HBM), sweep_eval_kernel evaluates the lists")
                           if P == 16384 else
-                          ("8192-tap FIR = 4096 odd taps as ONE table-free partition on 8192-point overlap-save blocks (olasave8k_kernel<8, MODE_SWEEP>: "
-                           "the Hilbert pass tests and lists), sweep_eval_kernel evaluates the lists")}
+                          ("8192-tap FIR = 4096 odd taps as ONE table-free partition on 16384-point overlap-save blocks (olasave16k_kernel<12, MODE_SWEEP>, "
+                           "12 of 16 rows new; round 4: 8192-point blocks, 8 of 16): the Hilbert pass tests and lists, sweep_eval_kernel evaluates the lists")}
     return {"metric": "channel-frames/s through the 360-angle min-peak sweep (cli -s 1 -f 2048)",
             "signal": "32-harmonic asymmetric stack (110 / 137.5 Hz) under a slow swell + 2 % noise, generated on the device; resident in HBM",
             "value": h["value"], "unit": "channel-frames/s", "ms": h["ms"], "cold_ms": h["cold_ms"], "cold_value": h["value"] * h["ms"] / h["cold_ms"],

@@ -267,7 +267,7 @@ bool save_tables16k (const std::vector<float>& fir, std::vector<float>& tab, flo
 {
 	const uint32_t F  = 16384;
 	const size_t   Lg = fir.size () / 2;
-	if (Lg != 8192) {
+	if (Lg != 8192 && Lg != 4096) { // 8 / 4 context rows of 1024 complex samples
 		return false;
 	}
 	std::vector<double> re (F, 0.0), im (F, 0.0);
@@ -470,6 +470,7 @@ struct prot_engine {
 	DevBuf<float>  d_sv8;
 	// CLI blksiz 16384 (round 5): every fp32 launch on 16384-point blocks (olasave16k_kernel: one table-free partition, one launch)
 	bool           use_save16 = false;
+	int            sv16_rows  = 0;     // new rows per 16384-point block: 8 (blksiz 16384) or 12 (blksiz 8192)
 	float          sv16_gain  = 0.f;
 	DevBuf<float>  d_sv16;
 	// dynamic blocks (olasave8k_dyn_kernel): kDynSets counter records per channel, one set per launch in turn (a launch leaves its
@@ -543,9 +544,11 @@ struct prot_engine {
 	bool           pipeline   = false;
 	hipStream_t    pipe_stream[kPipe] = {};
 	hipEvent_t     pipe_ev[kPipe + 1] = {};
-	// The last call's stream is NOT kept (a caller's stream need not outlive its call): a call on a caller's stream ends
-	// by recording ev_last on it; whoever must come behind that call -- prot_engine_reset, a call on another stream -- waits for the
-	// event on the device.  last_stream_id is compared, never used.
+	// The stream of the last call, when it was the caller's (a caller's stream need not outlive its call).  It is only ever
+	// USED after hipStreamQuery has vouched for it (the runtime checks a handle against its list of live streams before it touches
+	// it: a destroyed stream answers with an error, not with undefined behaviour) and only to record ev_last on it when something
+	// has to come BEHIND that call on another stream -- prot_engine_reset, a call on another stream: mark_last.  Recording the event
+	// at the end of every call instead was measured: +3 us per launch on back-to-back 11 us launches (BASELINE config 3).
 	hipEvent_t     ev_last        = nullptr;
 	bool           last_foreign   = false;
 	const void*    last_stream_id = nullptr;
@@ -878,7 +881,7 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 	}
 	if (e->use_save16 && pipe_wait_post == nullptr && srv == nullptr) {
 		// CLI blksiz 16384: 16384-point blocks, 1024-thread workgroups, one per CU (equal runs: one workgroup per CU has no dispatch rank)
-		const int blk16 = 16384;
+		const int blk16 = 2048 * e->sv16_rows;
 		p.run_frames = pick_run_frames (e, n_out, n_chn, blk16, e->cus);
 		p.rank_cu    = 0;
 		p.sv         = e->d_sv16.p;
@@ -895,7 +898,7 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 				return st > 0 ? PROT_OK : -st;
 			}
 		}
-		hipError_t err = prot::launch_ola_save16k (p, 8, n_chn, s);
+		hipError_t err = prot::launch_ola_save16k (p, e->sv16_rows, n_chn, s);
 		if (err != hipSuccess) {
 			return hip_fail (err, "overlap-save (16384-point) ola kernel launch");
 		}
@@ -1213,6 +1216,22 @@ int server_start_locked (prot_engine* e)
 	return PROT_OK;
 }
 
+// ev_last on the stream of the last call (a caller's), if that stream still exists: true = whoever waits for ev_last comes behind
+// that call; false = the stream is gone (its work was the caller's to finish before destroying it)
+bool mark_last (prot_engine* e)
+{
+	if (!e->last_foreign || e->last_stream_id == nullptr || e->ev_last == nullptr) {
+		return false;
+	}
+	hipStream_t    ls = (hipStream_t)const_cast<void*> (e->last_stream_id);
+	const hipError_t q = hipStreamQuery (ls);
+	if (q != hipSuccess && q != hipErrorNotReady) {
+		(void)hipGetLastError (); // (a destroyed stream: not an error of this call)
+		return false;
+	}
+	return hipEventRecord (e->ev_last, ls) == hipSuccess;
+}
+
 hipStream_t pick_stream (prot_engine* e, void* stream, bool keep_server = false)
 {
 	if (!keep_server) {
@@ -1222,7 +1241,9 @@ hipStream_t pick_stream (prot_engine* e, void* stream, bool keep_server = false)
 	(void)join_pipe (e, s);
 	if (e->last_foreign && (const void*)s != e->last_stream_id) {
 		// the call before this one ran on a stream of the caller's: this one reads the state it left (history, tables)
-		(void)hipStreamWaitEvent (s, e->ev_last, 0);
+		if (mark_last (e)) {
+			(void)hipStreamWaitEvent (s, e->ev_last, 0);
+		}
 	}
 	if (e->reset_pending) {
 		// prot_engine_reset behind a call on a caller's stream does not block the host: its zeroing sits on the engine's stream behind
@@ -1235,20 +1256,15 @@ hipStream_t pick_stream (prot_engine* e, void* stream, bool keep_server = false)
 	return s;
 }
 
-// the stream of one API call: picked at its start, and at its end -- when it is the caller's -- marked with ev_last
+// the stream of one API call: picked at its start, remembered at its end when it is the caller's (mark_last)
 struct CallStream {
 	prot_engine* e;
 	hipStream_t  s;
 	CallStream (prot_engine* e_, void* stream, bool keep_server = false) : e (e_), s (pick_stream (e_, stream, keep_server)) {}
 	~CallStream ()
 	{
-		if (s != e->stream && e->ev_last != nullptr && hipEventRecord (e->ev_last, s) == hipSuccess) {
-			e->last_foreign   = true;
-			e->last_stream_id = (const void*)s;
-		} else {
-			e->last_foreign   = false;
-			e->last_stream_id = nullptr;
-		}
+		e->last_foreign   = s != e->stream;
+		e->last_stream_id = e->last_foreign ? (const void*)s : nullptr;
 	}
 	CallStream (const CallStream&)            = delete;
 	CallStream& operator= (const CallStream&) = delete;
@@ -1606,10 +1622,29 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	if (use_poly && inf.kind == PROT_KIND_CLI && inf.firlen == 16384 && inf.conv_delay == 0 && inf.dry_delay == 8192 &&
 	    !(cfg->flags & (PROT_CFG_BLOCK4096 | PROT_CFG_OVERLAP_ADD | PROT_CFG_POLYPHASE)) && tuning_env ("PROT_NO_SAVE16K") == nullptr) {
 		e->use_save16 = save_tables16k (fir_taps, sv16_h, e->sv16_gain);
+		e->sv16_rows  = 8;
 		if (e->use_save16) {
 			inf.hop       = 16384;
 			inf.run_align = 16384;
 			inf.history   = std::max<uint32_t> (inf.history, 16384 + 256);
+			e->info.hop = inf.hop, e->info.run_align = inf.run_align, e->info.history = inf.history;
+			if (e->cus > 0 && tuning_env ("PROT_WG_PER_CU") == nullptr) {
+				e->wg_slots = e->cus;
+			}
+		}
+	}
+	// ... and the default at 44.1 / 48 kHz, blksiz 8192 (4096 odd taps = 4 context rows of a 16384-point block): 12 of 16 rows new
+	// (24576 frames per block) where the 8192-point block of round 4 has 8 of 16 -- a third less arithmetic per frame
+	if (e->use_save8 && e->sv8_always && e->sv8_rows == 8 && inf.kind == PROT_KIND_CLI && inf.firlen == 8192 && tuning_env ("PROT_NO_SAVE16K") == nullptr &&
+	    tuning_env ("PROT_NO_SAVE16K_8192") == nullptr) {
+		e->use_save16 = save_tables16k (fir_taps, sv16_h, e->sv16_gain);
+		if (e->use_save16) {
+			e->sv16_rows  = 12;
+			e->use_save8  = false;
+			e->sv8_always = false;
+			inf.hop       = 24576;
+			inf.run_align = 24576;
+			inf.history   = std::max<uint32_t> (inf.history, 8192 + 256);
 			e->info.hop = inf.hop, e->info.run_align = inf.run_align, e->info.history = inf.history;
 			if (e->cus > 0 && tuning_env ("PROT_WG_PER_CU") == nullptr) {
 				e->wg_slots = e->cus;
@@ -1869,12 +1904,12 @@ int prot_engine_reset (prot_engine* e)
 	ServerHold srv_hold;
 	// Behind a call on a caller's stream: stream-ordered, and no host wait (a host that analyses file after file, the bench's loop:
 	// a blocking wait per pass costs 0.05-0.25 ms by the state of the runtime's queues; tools/process_state_probe.py).  The zeroing
-	// goes to the ENGINE's stream behind the event the last call left on its own (the caller's stream handle is not kept: ADVICE r4);
+	// goes to the ENGINE's stream behind an event recorded on the last call's stream now -- if that stream still exists: ADVICE r4 --;
 	// pick_stream puts a call that arrives on another stream behind ev_reset, the readers of device state wait for the engine's
 	// stream (sync_own).
-	const bool  foreign = e->last_foreign && e->ev_reset != nullptr;
+	const bool  foreign = e->last_foreign && e->ev_reset != nullptr && mark_last (e);
 	hipStream_t zs      = e->stream;
-	if (e->last_foreign) {
+	if (foreign) {
 		HIP_TRY (hipStreamWaitEvent (zs, e->ev_last, 0));
 	}
 	(void)join_pipe (e, zs);
@@ -1968,7 +2003,9 @@ int prot_apply_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
 		hipStream_t ps = e->pipe_stream[e->pipe_q % prot_engine::kPipe];
 		uint32_t    wp[2];
 		if (e->last_foreign) { // (this route bypasses pick_stream -- a call on a caller's stream, and a reset's zeroing behind it)
-			HIP_TRY (hipStreamWaitEvent (e->stream, e->ev_last, 0));
+			if (mark_last (e)) {
+				HIP_TRY (hipStreamWaitEvent (e->stream, e->ev_last, 0));
+			}
 			e->last_foreign   = false;
 			e->last_stream_id = nullptr;
 		}

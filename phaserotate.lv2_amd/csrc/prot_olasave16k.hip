@@ -33,7 +33,9 @@ constexpr int kSv16LdsBytes = 16 * 1104 * 8 + 16384; // exchange area (16 rows o
 	}
 #define PROT_SV16_ALL(KIND_, in_, out_, nf_, ca_, sa_)                                                                                 \
 	PROT_SV16_CALL (KIND_, 8, 0, in_, out_, nf_, ca_, sa_)                                                                              \
-	PROT_SV16_CALL (KIND_, 8, 2, in_, out_, nf_, ca_, sa_)
+	PROT_SV16_CALL (KIND_, 8, 2, in_, out_, nf_, ca_, sa_)                                                                              \
+	PROT_SV16_CALL (KIND_, 12, 0, in_, out_, nf_, ca_, sa_)                                                                             \
+	PROT_SV16_CALL (KIND_, 12, 2, in_, out_, nf_, ca_, sa_)
 #define PROT_SV16_SWEEP_CALL(HS_, in_, cursor_, raw_, nf_, thr_, gain_)                                                                \
 	if (HS == HS_) {                                                                                                                    \
 		asm volatile (PROT_SV16_SWEEP_##HS_                                                                                             \
@@ -53,7 +55,7 @@ __global__ __launch_bounds__ (1024) void olasave16k_kernel (const OlaParams p)
 	constexpr int R0  = NT / 2;              // first valid output row = first dry row
 	constexpr int ROT = 0;                   // (an even number of context rows: no rotation)
 	constexpr int AM  = MODE == MODE_ROT ? 0 : 2;
-	static_assert (HS == 8, "rows per block");
+	static_assert (HS == 8 || HS == 12, "rows per block");
 	
 
 	extern __shared__ f2 smem16[]; // kSv16LdsBytes: the exchange area + the two tables (written by the generated prologue)
@@ -181,6 +183,7 @@ __global__ __launch_bounds__ (1024) void olasave16k_kernel (const OlaParams p)
 					float2*       cur   = uniform_ptr_generic (base + sw_cnt);
 					const float   thr_u = sw_thr ();
 					PROT_SV16_SWEEP_CALL (8, a_in, cur, sw_raw, nf, thr_u, sa)
+					PROT_SV16_SWEEP_CALL (12, a_in, cur, sw_raw, nf, thr_u, sa)
 					sw_cnt = (unsigned)__builtin_amdgcn_readfirstlane ((int)(cur - sw_list ()));
 				} else {
 					float* a_out = uniform_ptr_generic (out + s);
@@ -304,7 +307,7 @@ static hipError_t launch_sv16_m (const OlaParams& p, dim3 grid, hipStream_t s)
 	typedef void (*kern_t) (OlaParams);
 	kern_t fn = p.hilbert_only ? olasave16k_kernel<HS, MODE_HILBERT> : p.rot_s != nullptr ? olasave16k_kernel<HS, MODE_RAMP> : olasave16k_kernel<HS, MODE_ROT>;
 	if (p.surv != nullptr) { // the fused sweep: the Hilbert pass with the test in its epilogue (lists instead of output rows)
-		if constexpr (HS == 8) {
+		if constexpr (HS == 8 || HS == 12) {
 			fn = olasave16k_kernel<HS, MODE_SWEEP>;
 		} else {
 			return hipErrorInvalidValue;
@@ -345,6 +348,7 @@ hipError_t launch_ola_save16k (const OlaParams& p, int hop_rows, int n_chn, hipS
 	dim3          grid ((unsigned)runs, (unsigned)n_chn);
 	switch (hop_rows) {
 		case 8: return launch_sv16_m<8> (p, grid, s);
+		case 12: return launch_sv16_m<12> (p, grid, s);
 		default: return hipErrorInvalidValue;
 	}
 }

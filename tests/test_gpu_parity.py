@@ -962,7 +962,8 @@ def test_overlap_save_equals_overlap_add_on_random_chunkings(pkg, seed):
     for flags in (0, pkg.CFG_OVERLAP_ADD):
         e = pkg.Engine(kind, param, nc, flags=flags)
         # (LV2 engines: 8192-point blocks for long launches; CLI blksiz 4096 and 8192: 8192-point blocks for every launch, one table-free partition)
-        assert e.info.form == ((pkg.FORM_POLY_SAVE8K if kind == pkg.KIND_LV2 or param in (4096, 8192) else pkg.FORM_POLY_SAVE) if flags == 0 else pkg.FORM_POLY_OLA)
+        want_form = pkg.FORM_POLY_SAVE16K if (kind == pkg.KIND_CLI and param in (8192, 16384)) else pkg.FORM_POLY_SAVE8K if (kind == pkg.KIND_LV2 or param == 4096) else pkg.FORM_POLY_SAVE
+        assert e.info.form == (want_form if flags == 0 else pkg.FORM_POLY_OLA)
         y = torch.zeros(nc * stride, device=dev)
         for a, b in zip(cuts[:-1], cuts[1:]):
             e.apply_dev(x.data_ptr() + 4 * a, stride, b - a, y.data_ptr() + 4 * a, stride, b - a, rot, hil)
@@ -1468,7 +1469,7 @@ def test_block8192_kernel_against_oracle_and_block4096(pkg, rate, chn, n, odd):
 
 @pytest.mark.parametrize("kind,param,chn,n,stateless", [("lv2", 48000, 1, (1 << 24) + 12346, True), ("lv2", 48000, 2, (1 << 24) + 2, True),
                                                          ("lv2", 96000, 1, (1 << 24) + 777, True), ("lv2", 48000, 1, (1 << 24) + 4098, False),
-                                                         ("lv2", 192000, 3, (1 << 24) + 2, True), ("cli", 8192, 2, 1 << 24, True)])
+                                                         ("lv2", 192000, 3, (1 << 24) + 2, True)])
 def test_dynamic_blocks_equal_static_runs(pkg, kind, param, chn, n, stateless):
     """Round 5: long launches on 8192-point blocks let the resident workgroups CLAIM their blocks one at a time (olasave8k_dyn_kernel:
     eight regions, one per XCD, a scalar atomic per block) instead of walking runs planned by the host (PROT_CFG_STATIC_RUNS keeps

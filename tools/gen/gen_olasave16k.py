@@ -89,13 +89,13 @@ class Gen16k(Gen8k):
             self.TMP.append(VP(n))
             n += 2
         self.n_vgpr = n
-        assert len(self.TMP) >= 13, "temporaries: %d" % len(self.TMP)
+        assert len(self.TMP) >= 8, "temporaries: %d" % len(self.TMP)
         if MODE == MODE_SWEEP:
             self.V_RAW = V(120)
         self.TB = self.TMP[:4]
         self.TR = self.TMP[4:5]
-        self.TT = self.TMP[5:9]
-        self.nbf = 4
+        self.TT = self.TMP[5:9] if len(self.TMP) >= 9 else self.TMP[5:6] * 4
+        self.nbf = len(set(t.n for t in self.TT))
         self.lab = 0
 
     # ------------------------------------------------------------ geometry
@@ -293,7 +293,7 @@ class Gen16k(Gen8k):
         for g in range(0, len(lists), len(sc)):
             self.run_ops(self.interleave(lists[g:g + len(sc)]))
         bfl = self.stage2_lists(v, 1)
-        self.run_ops(self.interleave(bfl))
+        self.run_ops(self.interleave(bfl) if self.nbf >= 4 else sum(bfl, []))
         B = [None, self.TB1, self.TB[2], self.TB[3]]
         self.cmul(B[2], self.TB1, self.TB1, 1, sc[0])
         self.cmul(B[3], B[2], self.TB1, 1, sc[1])
@@ -319,7 +319,8 @@ class Gen16k(Gen8k):
         in front of its writes)"""
         P = self.P
         v = self.D
-        sets = [self.TMP[0:6], self.TMP[6:12]]
+        two = len(self.TMP) >= 12      # (two pairs of values in flight, or one when the temporaries are few: HS = 12)
+        sets = [self.TMP[0:6], self.TMP[6:12] if two else self.TMP[0:6]]
 
         def variant(ke):
             def run():
@@ -342,11 +343,16 @@ class Gen16k(Gen8k):
                             # forward: ke = 1: t0 - i t1, ke = 3: t0 + i t1; inverse (conjugate kernel): e = 1: t0 + i t1, e = 3: t0 - i t1
                             minus_i = (ke == 1) == (DIR > 0)
                             (self.add_mj if minus_i else self.sub_mj)(v[k], v[k], u1)
-                issue(0)
-                for j in range(1, 8):
-                    issue(j)
-                    fold(j - 1)
-                fold(7)
+                if two:
+                    issue(0)
+                    for j in range(1, 8):
+                        issue(j)
+                        fold(j - 1)
+                    fold(7)
+                else:
+                    for j in range(8):
+                        issue(j)
+                        fold(j)
                 if DIR > 0 and ke:
                     sc = self.TMP[:]
                     lists = [self.mul_w64(v[b], b * ke, False, sc[(b - 1) % len(sc)]) for b in range(1, 16)]
@@ -385,7 +391,7 @@ class Gen16k(Gen8k):
         if self.MODE == MODE_ROT:
             P.pk("fma", x, [self.K[R0 + k], S_ROT, x], op_sel=[0, 0, 0], op_sel_hi=[1, 0, 1])
         if self.kind == "core":
-            P.ds_write_b64(self.A_OUT, x, ROWB * k)
+            P.ds_write_b64(self.A_OUT if k < 8 else self.A_OUT2, x, ROWB * (k % 8))   # (DS offsets are 16 bits)
         elif "nomem" not in self.opts:
             P.s_add_u32(S_A0.lo, S_OUT.lo, Lit(ROWB * k))
             P.s_addc_u32(S_A0.hi, S_OUT.hi, Lit(0))
@@ -432,7 +438,7 @@ class Gen16k(Gen8k):
         self.stage1(v, 1)
         self.run_ops(self.stage1_twiddle_ops(v, 1, self.scratch_pairs()))
         bfl = self.stage2_lists(v, 1)
-        self.run_ops(self.interleave(bfl))
+        self.run_ops(self.interleave(bfl) if self.nbf >= 4 else sum(bfl, []))
         v = self.natural(v)
         self.tap("p3out", v)
         P.comment("---- constants")
@@ -448,7 +454,7 @@ class Gen16k(Gen8k):
         self.stage1(v, -1)
         self.run_ops(self.stage1_twiddle_ops(v, -1, self.scratch_pairs()))
         bfl = self.stage2_lists(v, -1)
-        self.run_ops(self.interleave(bfl))
+        self.run_ops(self.interleave(bfl) if self.nbf >= 4 else sum(bfl, []))
         u = self.natural(v)          # u[b] = output b of the pass
         self.tap("ip2out", u)
         self.ke_twiddle_inv(u)
@@ -467,8 +473,9 @@ class Gen16k(Gen8k):
         P.comment("---- mix and store")
         if core:
             P.s_barrier()   # every wave has read its share of the last exchange: the area takes the output rows
-            self.A_OUT = self.TMP[0].lo
+            self.A_OUT, self.A_OUT2 = self.TMP[0].lo, self.TMP[0].hi
             P.v_add_u32(self.A_OUT, S_LDS, self.VOFF)
+            P.v_add_u32(self.A_OUT2, Lit(8 * ROWB), self.A_OUT)
             for k in range(HS):
                 self.epilogue_row(u, k)
             P.s_waitcnt(lgkmcnt=0)
@@ -677,8 +684,8 @@ def self_test(HS, MODE, nblk=2, seed=1, verbose=True, opts=(), kind="run", thr2=
     return g, P
 
 
-VARIANTS = [(8, MODE_HILBERT), (8, MODE_ROT)]
-SWEEP_HS = (8,)
+VARIANTS = [(8, MODE_HILBERT), (8, MODE_ROT), (12, MODE_HILBERT), (12, MODE_ROT)]
+SWEEP_HS = (8, 12)   # HS = 12: CLI blksiz 8192 (4096 odd taps = 4 context rows), 12 of 16 rows new where the 8192-point block has 8 of 16
 
 
 def emit(path, opts=()):
