@@ -544,11 +544,11 @@ struct prot_engine {
 	bool           pipeline   = false;
 	hipStream_t    pipe_stream[kPipe] = {};
 	hipEvent_t     pipe_ev[kPipe + 1] = {};
-	// The stream of the last call, when it was the caller's (a caller's stream need not outlive its call).  It is only ever
-	// USED after hipStreamQuery has vouched for it (the runtime checks a handle against its list of live streams before it touches
-	// it: a destroyed stream answers with an error, not with undefined behaviour) and only to record ev_last on it when something
-	// has to come BEHIND that call on another stream -- prot_engine_reset, a call on another stream: mark_last.  Recording the event
-	// at the end of every call instead was measured: +3 us per launch on back-to-back 11 us launches (BASELINE config 3).
+	// The stream of the last call, when it was the caller's.  It is used once more, to record ev_last on it, when something has to come
+	// BEHIND that call on another stream -- prot_engine_reset, a call on another stream, prot_engine_sync: mark_last -- and forgotten
+	// there; until then the caller keeps it alive (the rule is in prot_hip.h).  Recording the event at the end of every
+	// call instead, so that no handle need be kept, was measured: +3 us per launch on back-to-back 11 us launches (BASELINE config
+	// 3; tools/ubench/event_cost.hip: 2.9-5.3 us per hipEventRecord behind a kernel, whatever the event's flags).
 	hipEvent_t     ev_last        = nullptr;
 	bool           last_foreign   = false;
 	const void*    last_stream_id = nullptr;
@@ -1216,20 +1216,15 @@ int server_start_locked (prot_engine* e)
 	return PROT_OK;
 }
 
-// ev_last on the stream of the last call (a caller's), if that stream still exists: true = whoever waits for ev_last comes behind
-// that call; false = the stream is gone (its work was the caller's to finish before destroying it)
+// ev_last on the stream of the last call when that was a caller's: whoever waits for ev_last comes behind that call.  The handle
+// is the caller's to keep alive until the engine has let go of it (prot_hip.h, "streams"): asking the runtime whether a stream
+// still exists is no way out -- hipStreamQuery on a destroyed stream crashes in this runtime (tried, round 5).
 bool mark_last (prot_engine* e)
 {
 	if (!e->last_foreign || e->last_stream_id == nullptr || e->ev_last == nullptr) {
 		return false;
 	}
-	hipStream_t    ls = (hipStream_t)const_cast<void*> (e->last_stream_id);
-	const hipError_t q = hipStreamQuery (ls);
-	if (q != hipSuccess && q != hipErrorNotReady) {
-		(void)hipGetLastError (); // (a destroyed stream: not an error of this call)
-		return false;
-	}
-	return hipEventRecord (e->ev_last, ls) == hipSuccess;
+	return hipEventRecord (e->ev_last, (hipStream_t)const_cast<void*> (e->last_stream_id)) == hipSuccess;
 }
 
 hipStream_t pick_stream (prot_engine* e, void* stream, bool keep_server = false)
@@ -1904,7 +1899,7 @@ int prot_engine_reset (prot_engine* e)
 	ServerHold srv_hold;
 	// Behind a call on a caller's stream: stream-ordered, and no host wait (a host that analyses file after file, the bench's loop:
 	// a blocking wait per pass costs 0.05-0.25 ms by the state of the runtime's queues; tools/process_state_probe.py).  The zeroing
-	// goes to the ENGINE's stream behind an event recorded on the last call's stream now -- if that stream still exists: ADVICE r4 --;
+	// goes to the ENGINE's stream behind an event recorded on the last call's stream now (mark_last);
 	// pick_stream puts a call that arrives on another stream behind ev_reset, the readers of device state wait for the engine's
 	// stream (sync_own).
 	const bool  foreign = e->last_foreign && e->ev_reset != nullptr && mark_last (e);
@@ -1963,6 +1958,11 @@ int prot_engine_sync (prot_engine* e)
 	HIP_TRY (hipSetDevice (e->device));
 	ServerHold srv_hold;
 	(void)join_pipe (e, e->stream);
+	if (mark_last (e)) { // the last call ran on a stream of the caller's: wait for it too, and let go of the handle
+		HIP_TRY (hipEventSynchronize (e->ev_last));
+	}
+	e->last_foreign   = false;
+	e->last_stream_id = nullptr;
 	HIP_TRY (sync_own (e));
 	if (e->pipe_used && e->d_pipe.p) {
 		// did a pipelined launch give up waiting for the history of the one before it (prot_olasave.hip: bounded wait)?

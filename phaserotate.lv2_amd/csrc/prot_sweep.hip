@@ -577,12 +577,30 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 // angle) has D = pi / 2: the test is r > bound.
 constexpr int kERing = 128; // (d, h) entries of one block's ring: < 64 left over + 64 new
 
+#ifdef PROT_EVAL_STAMPS
+// diagnostic build (tools/ab_build.py sw:<tag>:-DPROT_EVAL_STAMPS, tools/eval_stamps.py): where a workgroup of sweep_eval_kernel spends
+// its time -- thread 0 stamps the 100 MHz clock at entry, after the prologue, the first claim, the first stage, each of its first
+// twelve steps, the loop's end, the rings' rest and the end
+__device__ unsigned long long g_eval_stamps[4096 * 24];
+#define EVAL_STAMP(k)                                                                                              \
+	do {                                                                                                           \
+		if (threadIdx.x == 0) {                                                                                    \
+			g_eval_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) % 4096 * 24 + (k)] = wall_clock64 ();       \
+		}                                                                                                          \
+	} while (0)
+#else
+#define EVAL_STAMP(k) \
+	do {              \
+	} while (0)
+#endif
+
 template <int NBLK>
 __global__ __launch_bounds__ (256, 4) void sweep_eval_kernel (const SweepParams p)
 {
 	__shared__ float    stage_s[2 * 2 * kStage];
 	__shared__ float2   ring_s[4 * NBLK * kERing];
 	__shared__ unsigned sh_seq[8];
+	__shared__ int      sh_cnt[2]; // entries of the step parked in each half of the stage
 
 	const int tid  = threadIdx.x;
 	const int w    = __builtin_amdgcn_readfirstlane (tid >> 6);
@@ -591,6 +609,7 @@ __global__ __launch_bounds__ (256, 4) void sweep_eval_kernel (const SweepParams 
 	const int kk   = lane >> 5;
 	const int c    = p.chn0 + blockIdx.y;
 
+	EVAL_STAMP (0);
 	const int  nb   = (p.n_angles + 31) >> 5;
 	const int  G    = nb >= 3 ? 4 : nb;
 	const int  wr_  = (w + (int)blockIdx.x) & 3; // (as in sweep_kernel: the place in the scratch table the merge kernel expects)
@@ -694,6 +713,7 @@ __global__ __launch_bounds__ (256, 4) void sweep_eval_kernel (const SweepParams 
 	const unsigned  ngrp    = gridDim.x < kCtr ? gridDim.x : kCtr;
 	const unsigned  grp     = blockIdx.x % ngrp;
 	unsigned* const ctr     = p.ctr + ((size_t)c * kCtr + grp) * 32;
+	EVAL_STAMP (1);
 	if (tid == 0) {
 		const unsigned b0 = atomicAdd (ctr, 4u);
 		sh_seq[0]         = ngrp * b0 + grp;
@@ -702,6 +722,7 @@ __global__ __launch_bounds__ (256, 4) void sweep_eval_kernel (const SweepParams 
 		sh_seq[3]         = ngrp * (b0 + 3u) + grp;
 	}
 	__syncthreads ();
+	EVAL_STAMP (2);
 	auto seq = [&] (int s) { return (unsigned)__builtin_amdgcn_readfirstlane ((int)sh_seq[s & 7]); };
 	const int          ld_par  = w >> 1;
 	const int          ld_half = (w & 1) * 512;
@@ -712,13 +733,18 @@ __global__ __launch_bounds__ (256, 4) void sweep_eval_kernel (const SweepParams 
 		const float4* const q  = reinterpret_cast<const float4*> (p.surv + (int64_t)ds.x + ld_half + 4 * lane);
 #pragma unroll
 		for (int i = 0; i < 2; ++i) {
-			const float4 a = q[128 * i], b = q[128 * i + 1];
-			dv[i]          = make_float4 (a.x, a.z, b.x, b.z);
-			hv[i]          = make_float4 (a.y, a.w, b.y, b.w);
+			if (ld_half + 256 * i + 4 * lane < (int)ds.y) { // (a short step -- the plan cuts them to 128 entries when there are few: park zeroes the rest)
+				const float4 a = q[128 * i], b = q[128 * i + 1];
+				dv[i]          = make_float4 (a.x, a.z, b.x, b.z);
+				hv[i]          = make_float4 (a.y, a.w, b.y, b.w);
+			}
 		}
 	};
 	auto park = [&] (int buf, unsigned s) { // (what lies beyond n -- the rest of a list's last step -- is allocated memory: zeroed here)
 		const int n = (int)dsc[s].y;
+		if (tid == ld_par * 128) {
+			sh_cnt[buf] = n; // (read at the top of the step: a load from the step table there stood exposed once per step)
+		}
 #pragma unroll
 		for (int i = 0; i < 2; ++i) {
 			const int    e0 = ld_half + 256 * i + 4 * lane;
@@ -747,6 +773,7 @@ __global__ __launch_bounds__ (256, 4) void sweep_eval_kernel (const SweepParams 
 		}
 	}
 	__syncthreads ();
+	EVAL_STAMP (3);
 
 	float2* const ring0 = ring_s + w * NBLK * kERing;
 	unsigned      wrc[NBLK], rdc[NBLK];
@@ -776,53 +803,79 @@ __global__ __launch_bounds__ (256, 4) void sweep_eval_kernel (const SweepParams 
 		}
 		if (!idle) {
 			const float* const st = stage_s + buf * 2 * kStage;
-			const int          nch = ((int)dsc[gs0].y + 63) >> 6; // (a list's last step is short: the chunks beyond its entries are zeros)
+			const int          nch = (__builtin_amdgcn_readfirstlane (sh_cnt[buf]) + 63) >> 6; // (a list's last step is short: the chunks beyond its entries are zeros)
 			// (fetching the next chunk's frames from the stage while this one is tested was measured: 1.5-3 % slower -- the other
 			// waves of the SIMD cover the LDS round trip already; tools/sweep_ab_libs.py)
+			// Two chunks of 64 frames per turn, and ALL their tests -- 2 x NBLK sector tests of ten vector operations, three compares each
+			// as lane masks combined on the scalar unit -- before the first branch on any of them (round 5: with a test, a branch and a
+			// compaction per block in turn, every block's compare -> scalar -> branch chain stood exposed behind the one before: 10 us
+			// per 1024-frame step where the vector operations account for 4; tools/eval_stamps.py).  (Written with && / || the compiler
+			// nests two EXEC-masked regions per block, ~20 scalar instructions of bookkeeping around ten vector ones; the compaction is
+			// skipped when nothing of the chunk survives.)
 #pragma unroll 1
-			for (int it = sub; it < nch; it += nsub) {
-				const float d = st[it * 64 + lane], h = st[kStage + it * 64 + lane];
-				const float r2 = d * d + h * h;
+			for (int it = sub; it < nch; it += 2 * nsub) {
+				const int  it2 = it + nsub;
+				const bool two = it2 < nch;
+				float      dd[2], hh[2];
+				dd[0] = st[it * 64 + lane];
+				hh[0] = st[kStage + it * 64 + lane];
+				dd[1] = 0.f;
+				hh[1] = 0.f;
+				if (two) {
+					dd[1] = st[it2 * 64 + lane];
+					hh[1] = st[kStage + it2 * 64 + lane];
+				}
+				uint64_t mk[2][NBLK];
 #pragma unroll
-				for (int q = 0; q < NBLK; ++q) {
-					// (straight-line: the three compares as lane masks, combined on the scalar unit -- written with && / || the
-					// compiler nests two EXEC-masked regions per block, ~20 scalar instructions of bookkeeping around ten vector ones;
-					// the compaction is skipped when nothing of the chunk survives)
-					const float    u    = fabsf (d * cps[q] + h * sps[q]);
-					const float    v    = fabsf (h * cps[q] - d * sps[q]);
-					const float    t    = u * cdl[q] + v * sdl[q];
-					const uint64_t m1   = __builtin_amdgcn_ballot_w64 (r2 > bnd2[q]);
-					const uint64_t mi   = __builtin_amdgcn_ballot_w64 (v <= u * tdl[q]);
-					const uint64_t m2   = __builtin_amdgcn_ballot_w64 (t > bnd[q]);
-					const uint64_t mask = m1 & (mi | m2);
-					float2* const  ring = ring0 + q * kERing;
-					if (mask != 0) {
-						if ((mask >> lane) & 1) {
-							const unsigned at = (wrc[q] + __builtin_amdgcn_mbcnt_hi ((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned)mask, 0u))) & (kERing - 1);
-							ring[at]          = make_float2 (d, h);
-						}
-						const unsigned nl = (unsigned)__builtin_popcountll (mask);
-						wrc[q] += nl;
-						n_surv += nl;
+				for (int cn = 0; cn < 2; ++cn) {
+					const float d = dd[cn], h = hh[cn];
+					const float r2 = d * d + h * h;
+#pragma unroll
+					for (int q = 0; q < NBLK; ++q) {
+						const float    u  = fabsf (d * cps[q] + h * sps[q]);
+						const float    v  = fabsf (h * cps[q] - d * sps[q]);
+						const float    t  = u * cdl[q] + v * sdl[q];
+						const uint64_t m1 = __builtin_amdgcn_ballot_w64 (r2 > bnd2[q]);
+						const uint64_t mi = __builtin_amdgcn_ballot_w64 (v <= u * tdl[q]);
+						const uint64_t m2 = __builtin_amdgcn_ballot_w64 (t > bnd[q]);
+						mk[cn][q]         = m1 & (mi | m2);
 					}
-					if (wrc[q] - rdc[q] >= 64u) { // a full tile pair of this block's survivors (wave-uniform)
-						wave_sync ();
-						const float* const rg = reinterpret_cast<const float*> (ring);
-						const float        b0 = rg[2 * ((rdc[q] + j) & (kERing - 1)) + kk];
-						const float        b1 = rg[2 * ((rdc[q] + 32 + j) & (kERing - 1)) + kk];
-						const f32x16       r0 = __builtin_amdgcn_mfma_f32_32x32x2f32 (a_op[q], b0, zero, 0, 0, 0);
-						const f32x16       r1 = __builtin_amdgcn_mfma_f32_32x32x2f32 (a_op[q], b1, zero, 0, 0, 0);
+				}
 #pragma unroll
-						for (int r = 0; r < 16; ++r) {
-							m[q][r] = fmaxf (m[q][r], fmaxf (fabsf (r0[r]), fabsf (r1[r])));
+				for (int cn = 0; cn < 2; ++cn) {
+					const float d = dd[cn], h = hh[cn];
+#pragma unroll
+					for (int q = 0; q < NBLK; ++q) {
+						const uint64_t mask = mk[cn][q];
+						float2* const  ring = ring0 + q * kERing;
+						if (mask != 0) {
+							if ((mask >> lane) & 1) {
+								const unsigned at = (wrc[q] + __builtin_amdgcn_mbcnt_hi ((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned)mask, 0u))) & (kERing - 1);
+								ring[at]          = make_float2 (d, h);
+							}
+							const unsigned nl = (unsigned)__builtin_popcountll (mask);
+							wrc[q] += nl;
+							n_surv += nl;
 						}
-						rdc[q] += 64u;
-						n_eval += 2;
-						wave_sync ();
+						if (wrc[q] - rdc[q] >= 64u) { // a full tile pair of this block's survivors (wave-uniform)
+							wave_sync ();
+							const float* const rg = reinterpret_cast<const float*> (ring);
+							const float        b0 = rg[2 * ((rdc[q] + j) & (kERing - 1)) + kk];
+							const float        b1 = rg[2 * ((rdc[q] + 32 + j) & (kERing - 1)) + kk];
+							const f32x16       r0 = __builtin_amdgcn_mfma_f32_32x32x2f32 (a_op[q], b0, zero, 0, 0, 0);
+							const f32x16       r1 = __builtin_amdgcn_mfma_f32_32x32x2f32 (a_op[q], b1, zero, 0, 0, 0);
+#pragma unroll
+							for (int r = 0; r < 16; ++r) {
+								m[q][r] = fmaxf (m[q][r], fmaxf (fabsf (r0[r]), fabsf (r1[r])));
+							}
+							rdc[q] += 64u;
+							n_eval += 2;
+							wave_sync ();
+						}
 					}
 				}
 			}
-			n_seen += (kStage / 32) / nsub;
+			n_seen += (unsigned)(2 * nch) / nsub;
 			// the bounds: after the workgroup's steps 1, 2, 4, 8, 16, then every 16th
 			if (((s + 1) & s) == 0 || (s & 15) == 15) {
 #pragma unroll
@@ -835,7 +888,16 @@ __global__ __launch_bounds__ (256, 4) void sweep_eval_kernel (const SweepParams 
 			sh_seq[(s + 4) & 7] = got;
 		}
 		__syncthreads ();
+		if (s < 12) {
+			EVAL_STAMP (4 + s);
+		}
+#ifdef PROT_EVAL_STAMPS
+		if (threadIdx.x == 0) {
+			g_eval_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) % 4096 * 24 + 19] = (unsigned long long)(s + 1);
+		}
+#endif
 	}
+	EVAL_STAMP (16);
 	if (!idle) {
 		// what is left in the rings (< 64 entries each), padded with zeros
 #pragma unroll
@@ -858,6 +920,7 @@ __global__ __launch_bounds__ (256, 4) void sweep_eval_kernel (const SweepParams 
 			}
 		}
 	}
+	EVAL_STAMP (17);
 	// statistics in sweep_kernel's units (tiles of a wave's share, all its blocks at once): a tile of ONE block counts 1 / NBLK
 	if (p.stats != nullptr) {
 		unsigned* const acc = reinterpret_cast<unsigned*> (stage_s);
@@ -897,7 +960,19 @@ __global__ __launch_bounds__ (256, 4) void sweep_eval_kernel (const SweepParams 
 			}
 		}
 	}
+	EVAL_STAMP (18);
 }
+
+#ifdef PROT_EVAL_STAMPS
+extern "C" int prot_debug_eval_stamps (unsigned long long* out, int clear)
+{
+	if (clear) {
+		static unsigned long long z[4096 * 24];
+		return (int)hipMemcpyToSymbol (HIP_SYMBOL (g_eval_stamps), z, sizeof (z));
+	}
+	return (int)hipMemcpyFromSymbol (out, HIP_SYMBOL (g_eval_stamps), sizeof (unsigned long long) * 4096 * 24);
+}
+#endif
 
 // peaks[c][angle] = max (peaks[c][angle], max over the launch's workgroups and the waves that served the angle's block):
 // one thread per (angle slot, slice of workgroups), up to 64 slices -> at most 64 atomics per table entry
@@ -1032,9 +1107,13 @@ hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s)
 }
 
 // The step table of a sweep over lists (one workgroup per channel): list l has cnt[l] entries from entry l * cap on; its steps of
-// up to 1024 entries follow those of the lists before it.
+// up to L entries follow those of the lists before it.  L = 1024 (a full stage) when there is plenty to do; a channel with few
+// entries -- a shard of a sharded sweep behind the merged seeds of all shards: 1-2 M entries -- is cut into steps of 512, 256 or
+// 128 entries instead, until there are about `want_steps` of them: the evaluation's workgroups claim FOUR steps when they start,
+// so 1300 full steps kept 325 of a channel's 512 workgroups busy with four steps each and the others with none (round 5:
+// sweep_eval_kernel 80 us of a 340 us shard pass).
 __global__ __launch_bounds__ (256) void sweep_plan_kernel (const unsigned* __restrict__ cnt, int n_lists, int64_t cap, uint2* __restrict__ desc,
-                                                             int64_t desc_stride, unsigned* __restrict__ n_steps, unsigned long long* total)
+                                                             int64_t desc_stride, unsigned* __restrict__ n_steps, unsigned long long* total, unsigned want_steps)
 {
 	// blockIdx.x = channel; blockIdx.y = which part of every thread's lists this workgroup writes the steps of (each workgroup
 	// repeats the scan over the list lengths -- a few thousand numbers --, the writes are what takes the time: 54 -> 12 us at 140 K steps)
@@ -1043,33 +1122,48 @@ __global__ __launch_bounds__ (256) void sweep_plan_kernel (const unsigned* __res
 	const unsigned* cn  = cnt + (int64_t)c * n_lists;
 	uint2*          dsc = desc + (int64_t)c * desc_stride;
 	const int       per = (n_lists + 255) / 256, l0 = t * per, l1 = l0 + per < n_lists ? l0 + per : n_lists;
-	unsigned        mine = 0;
-	unsigned long long ents = 0;
+	unsigned        ents = 0; // (a channel of one call lists < 2^31 entries: prot_sweep_dev splits longer calls)
 	for (int l = l0; l < l1; ++l) {
-		mine += (cn[l] + kStage - 1) / kStage;
 		ents += cn[l];
 	}
 	if (total != nullptr && ents != 0 && blockIdx.y == 0) {
-		atomicAdd (total, ents);
+		atomicAdd (total, (unsigned long long)ents);
 	}
-	part[t] = mine;
+	auto scan = [&] (unsigned v) { // inclusive scan over the workgroup; returns this thread's value, part[255] = the sum
+		part[t] = v;
+		__syncthreads ();
+		for (int d = 1; d < 256; d <<= 1) {
+			const unsigned u = t >= d ? part[t - d] : 0u;
+			__syncthreads ();
+			part[t] += u;
+			__syncthreads ();
+		}
+		return part[t];
+	};
+	(void)scan (ents);
+	const unsigned tot = part[255];
 	__syncthreads ();
-	for (int d = 1; d < 256; d <<= 1) { // inclusive scan
-		const unsigned v = t >= d ? part[t - d] : 0u;
-		__syncthreads ();
-		part[t] += v;
-		__syncthreads ();
+	// steps of L = 1024 >> k entries: at most n_lists + tot / L of them; the table holds desc_stride - 8
+	const unsigned limit = (unsigned)min ((int64_t)want_steps, desc_stride - 8);
+	int            k     = 0;
+	while (k < 3 && (unsigned)n_lists + (tot >> (9 - k)) <= limit) {
+		++k;
 	}
-	unsigned  at = part[t] - mine;
+	const unsigned L = (unsigned)kStage >> k;
+	unsigned       mine = 0;
+	for (int l = l0; l < l1; ++l) {
+		mine += (cn[l] + L - 1) / L;
+	}
+	unsigned  at = scan (mine) - mine;
 	const int K = (int)gridDim.y, sub = (per + K - 1) / K, w0 = l0 + (int)blockIdx.y * sub, w1 = w0 + sub;
 	for (int l = l0; l < l1; ++l) {
 		const unsigned n = cn[l];
 		if (l >= w0 && l < w1) {
-			for (unsigned i = 0; i * kStage < n; ++i) {
-				dsc[at + i] = make_uint2 ((unsigned)(((int64_t)c * n_lists + l) * cap + (int64_t)i * kStage), n - i * kStage < (unsigned)kStage ? n - i * kStage : (unsigned)kStage);
+			for (unsigned i = 0; i * L < n; ++i) {
+				dsc[at + i] = make_uint2 ((unsigned)(((int64_t)c * n_lists + l) * cap + (int64_t)i * L), n - i * L < L ? n - i * L : L);
 			}
 		}
-		at += (n + kStage - 1) / kStage;
+		at += (n + L - 1) / L;
 	}
 	if (t == 255 && blockIdx.y == 0) {
 		n_steps[c] = part[255];
@@ -1079,9 +1173,19 @@ __global__ __launch_bounds__ (256) void sweep_plan_kernel (const unsigned* __res
 hipError_t launch_sweep_plan (const unsigned* cnt, int n_lists, int64_t cap, uint2* desc, int64_t desc_stride, unsigned* n_steps, int n_chn,
                               unsigned long long* total, hipStream_t s)
 {
-	const int per = (n_lists + 255) / 256;
+	static int cus = 0;
+	if (cus == 0) {
+		int dev = 0;
+		(void)hipGetDevice (&dev);
+		if (hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+			cus = 256;
+		}
+	}
+	// (sweep_eval_kernel runs four workgroups per CU, shared among the channels: about sixteen steps for each)
+	const unsigned want = 16u * (unsigned)std::max (1, 4 * cus / std::max (1, n_chn));
+	const int      per  = (n_lists + 255) / 256;
 	hipLaunchKernelGGL (sweep_plan_kernel, dim3 ((unsigned)n_chn, (unsigned)std::min (8, std::max (1, per))), dim3 (256), 0, s, cnt, n_lists, cap, desc, desc_stride,
-	                    n_steps, total);
+	                    n_steps, total, want);
 	return hipGetLastError ();
 }
 

@@ -1635,3 +1635,41 @@ def test_reset_is_stream_ordered_and_does_not_need_the_host(pkg):
     assert not eng.peaks().any()                         # (the reader waits for the reset's event on stream A)
     torch.cuda.synchronize()
     eng.close()
+
+
+def test_callers_stream_may_be_destroyed_after_sync(pkg):
+    """The engine keeps the handle of the last call's stream only until the next entry point that must come behind that call has
+    returned (prot_hip.h, "streams"; round 5): after prot_engine_sync, or after a call on another stream, the caller
+    may destroy it -- the reset and the call that follow give the results of a fresh engine."""
+    import ctypes
+    import os
+    import torch
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    hip.hipStreamCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+    hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    P, n_chn = 2048, 2
+    n = P * 300
+    dev = torch.device("cuda", 0)
+    xa = torch.from_numpy(np.ascontiguousarray(_signal(n, n_chn, seed=43).reshape(n, n_chn).T)).to(dev).contiguous()
+    xb = torch.from_numpy(np.ascontiguousarray(0.5 * _signal(n, n_chn, seed=44).reshape(n, n_chn).T)).to(dev).contiguous()
+    fl = pkg.F_STREAM_START | pkg.F_STREAM_END
+    ref = pkg.Engine(pkg.KIND_CLI, P, n_chn)
+    ref.sweep_dev(xb.data_ptr(), n, n, 0, 360, 1, -1, 0, fl, 0)
+    want = ref.peaks()
+    ref.close()
+    eng = pkg.Engine(pkg.KIND_CLI, P, n_chn)
+    for rep in range(3):
+        h = ctypes.c_void_p()
+        assert hip.hipStreamCreate(ctypes.byref(h)) == 0
+        eng.sweep_dev(xa.data_ptr(), n, n, 0, 360, 1, -1, 0, fl, h.value)
+        if rep != 1:
+            eng.sync()                                   # waits for the call and lets go of the handle
+        else:
+            eng.sweep_dev(xa.data_ptr(), n, n, 0, 360, 1, -1, 0, fl, 0)   # a call on another stream: ordered behind it, handle forgotten
+        assert hip.hipStreamDestroy(h) == 0
+        eng.reset()
+        eng.sweep_dev(xb.data_ptr(), n, n, 0, 360, 1, -1, 0, fl, 0)
+        assert eng.peaks().tobytes() == want.tobytes(), rep
+    torch.cuda.synchronize()
+    eng.close()

@@ -14,7 +14,26 @@ CAPI_T = os.path.join(b.OBJDIR, "prot_capi_tuning.o")
 if b._newer(CAPI_T, [os.path.join(b.CSRC, "prot_capi.hip"), os.path.join(b.CSRC, "prot_kernels.h")]):
     b._run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-function", "-DPROT_TUNING", "-DPROT_TESTHOOKS",
             "-I" + os.path.join(ROOT, "include"), "-c", os.path.join(b.CSRC, "prot_capi.hip"), "-o", CAPI_T])
+UNITS = ("prot_kernels", "prot_olasave", "prot_olasave8k", "prot_olasave16k", "prot_sweep", "prot_kernels_f16")
+
+
+def link(tag, replaced):
+    """libprot_hip_<tag>.so from the shipped objects, `replaced` = {unit: object} swapped in"""
+    lib = os.path.join(vdir, "libprot_hip_%s.so" % tag)
+    objs = [replaced.get(u, os.path.join(b.OBJDIR, u + ".o")) for u in UNITS]
+    b._run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + [CAPI_T, "-lpthread"])
+    print("built", lib)
+
+
 for arg in sys.argv[1:]:
+    if arg.startswith("sw:"):
+        # "sw:<tag>:flag,flag": a variant of prot_sweep.hip
+        _, tag, fl = (arg.split(":") + [""])[:3]
+        o = os.path.join(b.OBJDIR, "prot_sweep_%s.o" % tag)
+        b._run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-ffast-math",
+                "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"] + [f for f in fl.split(",") if f] + ["-c", os.path.join(b.CSRC, "prot_sweep.hip"), "-o", o])
+        link(tag, {"prot_sweep": o})
+        continue
     if arg.startswith("sv8:"):
         # "sv8:<tag>[:flag,flag]": a variant of prot_olasave8k.hip (the generated loop csrc/variants/prot_olasave8k_asm_<tag>.inc
         # if it exists: python3 tools/gen/gen_olasave8k.py --variant <tag> --opts ...), linked with the shipped objects
@@ -27,10 +46,7 @@ for arg in sys.argv[1:]:
         b._run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-function",
                 "-I" + os.path.join(ROOT, "include"), "-ffast-math", "-fno-slp-vectorize"] + extra +
                ["-c", os.path.join(b.CSRC, "prot_olasave8k.hip"), "-o", o])
-        lib = os.path.join(vdir, "libprot_hip_%s.so" % tag)
-        b._run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, o, os.path.join(b.OBJDIR, "prot_kernels.o"), os.path.join(b.OBJDIR, "prot_olasave.o"),
-                os.path.join(b.OBJDIR, "prot_sweep.o"), os.path.join(b.OBJDIR, "prot_kernels_f16.o"), CAPI_T, "-lpthread"])
-        print("built", lib)
+        link(tag, {"prot_olasave8k": o})
         continue
     if arg.startswith("sv:"):
         # "sv:<tag>[:flag,flag]": a variant of prot_olasave.hip only (the generated loop csrc/variants/prot_olasave_asm_<tag>.inc
@@ -49,10 +65,7 @@ for arg in sys.argv[1:]:
         b._run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-function",
                 "-I" + os.path.join(ROOT, "include"), "-ffast-math", "-fno-slp-vectorize"] + extra +
                ["-c", os.path.join(b.CSRC, "prot_olasave.hip"), "-o", o])
-        lib = os.path.join(vdir, "libprot_hip_%s.so" % tag)
-        b._run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, o, os.path.join(b.OBJDIR, "prot_kernels.o"), os.path.join(b.OBJDIR, "prot_olasave8k.o"),
-                os.path.join(b.OBJDIR, "prot_sweep.o"), os.path.join(b.OBJDIR, "prot_kernels_f16.o"), CAPI_T, "-lpthread"])
-        print("built", lib)
+        link(tag, {"prot_olasave": o})
         continue
     tag, _, fl = arg.partition(":")
     extra = [f for f in fl.split(",") if f]
@@ -60,8 +73,4 @@ for arg in sys.argv[1:]:
     b._run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-function",
             "-I" + os.path.join(ROOT, "include"), "-ffast-math", "-fno-slp-vectorize", "-mllvm",
             "-amdgpu-mfma-vgpr-form"] + extra + ["-c", os.path.join(b.CSRC, "prot_kernels.hip"), "-o", o])
-    lib = os.path.join(vdir, "libprot_hip_%s.so" % tag)
-    b._run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, o,
-            os.path.join(b.OBJDIR, "prot_sweep.o"), os.path.join(b.OBJDIR, "prot_kernels_f16.o"), os.path.join(b.OBJDIR, "prot_olasave.o"), os.path.join(b.OBJDIR, "prot_olasave8k.o"),
-            CAPI_T, "-lpthread"])
-    print("built", lib)
+    link(tag, {"prot_kernels": o})

@@ -10,7 +10,7 @@ import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
 tag, out = sys.argv[1], sys.argv[2]
-HEAD, SWEEP, SWEEP_PLAIN = "olasave8k_kernel<13, 0>", "sweep_eval_kernel<3>", "sweep_kernel<3, false>"
+HEAD, SWEEP, SWEEP_PLAIN = "olasave8k_dyn_kernel<13, 0>", "sweep_eval_kernel<3>", "sweep_kernel<3, false>"
 SWEEP_FUSED = "olasave_kernel<12, 3>"  # the Hilbert pass with the sweep's test in its epilogue (cfg4: 96 kHz, blksiz 2048)
 
 

@@ -13,7 +13,7 @@ import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PASSES, SECONDS = 3, 3600.0  # (the bench's cfg4: 60 min)
-OURS = ("olasave_kernel", "olasave8k_kernel", "olapoly_kernel", "sweep_kernel", "sweep_eval_kernel", "sweep_plan_kernel", "sweep_merge", "sweep_reset", "hist_",
+OURS = ("olasave_kernel", "olasave8k_kernel", "olasave8k_dyn_kernel", "olasave16k_kernel", "sweep_seed", "olapoly_kernel", "sweep_kernel", "sweep_eval_kernel", "sweep_plan_kernel", "sweep_merge", "sweep_reset", "hist_",
         "ola4096", "zero_regions")
 
 
