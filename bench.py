@@ -579,8 +579,29 @@ def bench_run_host(pkg, np, local_rank):
         g.run(x0, 90.0)
     harness = (time.perf_counter() - t0) / 2000
     g.close()
+    # several plugin instances called in turn (round 5: one resident kernel serves every LV2 engine of the process)
+    multi = {}
+    try:
+        for label, specs in (("two_mono_48k", [(48000, 1), (48000, 1)]), ("mono_48k_and_stereo_96k", [(48000, 1), (96000, 2)]),
+                             ("four_mono_48k", [(48000, 1)] * 4)):
+            gs = [pkg.Lv2Instance(r, c, device=local_rank) for r, c in specs]
+            for g in gs:
+                g.activate()
+            runs_m, worst_m = [], 0.0
+            for _ in range(6):
+                m, w = pkg.time_lv2_run_multi(gs, 1024, 400)
+                runs_m.append(m)
+                worst_m = max(worst_m, w)
+            multi[label] = {"us_per_run": float(np.median(runs_m)), "worst_single_call_us": worst_m,
+                            "server_calls": [g.server_stats()["calls"] for g in gs], "server_kernels_started": sum(g.server_stats()["starts"] for g in gs)}
+            for g in gs:
+                g.close()
+    except Exception as ex:  # noqa: BLE001
+        multi["error"] = repr(ex)
     dt = res["server_c"]
-    return {"workload": "prot_lv2_run, mono 48 kHz, 1024-frame host buffers, through the run() server (resident kernel; mailbox in device memory "
+    return {"instances_in_turn": dict(multi, note="1024-frame run() calls on each instance in turn, looped in C (prot_internal_time_lv2_run_multi); us_per_run is per "
+                                                   "CALL; every instance is a set of slots of the one resident kernel"),
+            "workload": "prot_lv2_run, mono 48 kHz, 1024-frame host buffers, through the run() server (resident kernel; mailbox in device memory "
                         "that the CPU stores into through the PCIe BAR, doorbell, done word in pinned host memory: no launch and no stream sync "
                         "per call), called in a loop from C (prot_internal_time_lv2_run: what an LV2 host's audio thread sees)",
             "us_per_run": dt * 1e6, "frames_per_s": 1024 / dt, "realtime_factor_48k": 1024 / dt / 48000.0,

@@ -383,6 +383,18 @@ def analyze_file_multi(engines, data, ang_start, ang_end, ang_stride, chn=-1):
                                            ang_start, ang_end, ang_stride, chn), "prot_cli_analyze_file_multi")
 
 
+def time_lv2_run_multi(engines, frames, calls):
+    """(mean microseconds per prot_lv2_run call, slowest single call) with the engines called in turn, looped in C (test hook
+    prot_internal_time_lv2_run_multi: an LV2 host running several plugin instances per cycle)"""
+    lib = load_library()
+    us = (C.c_double * 3)()
+    hs = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    lib.prot_internal_time_lv2_run_multi.argtypes = [C.POINTER(C.c_void_p), C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_double)]
+    lib.prot_internal_time_lv2_run_multi.restype = C.c_int
+    _check(lib.prot_internal_time_lv2_run_multi(hs, len(engines), frames, calls, us), "prot_internal_time_lv2_run_multi")
+    return us[0], us[1]
+
+
 class Lv2Instance(Engine):
     """Mirror of the LV2 instance (src/phaserotate.c): instantiate(rate) ->
     activate() -> run(n_samples) with planar port buffers and the angle

@@ -1142,11 +1142,17 @@ int join_pipe (prot_engine* e, hipStream_t s)
 
 // ---- the run() server: at most ONE resident kernel per process (a resident kernel holds its hardware queue, and the
 // runtime multiplexes all streams of a process onto a few: one on a high-priority stream of its own keeps out of the way of
-// every other stream; a second LV2 instance takes the launch route).  Every other use of any engine -- a launch on an engine
-// stream, a reset, a synchronisation, create / destroy (hipFree waits for the whole device) -- first tells the server to leave
-// and waits for it; the next run() of its engine starts it again.
-std::mutex   g_srv_mu;
-prot_engine* g_srv_owner = nullptr;
+// every other stream; a second one would sooner or later share a queue with the first and wait behind it).  Round 5: that one
+// kernel serves EVERY LV2 engine of the process that is eligible -- a workgroup ("slot") per channel, a mailbox and a doorbell
+// per engine -- up to kServerMaxChn channels in all on one device; an engine beyond that takes the launch route.  The ROSTER
+// (g_srv_roster) lists the engines whose run() went through the server; whoever starts the kernel starts it for the whole
+// roster, so that two plugin instances called in turn do not keep replacing each other's server.
+// Every other use of any engine -- a launch on an engine stream, a reset, a synchronisation, create / destroy (hipFree waits
+// for the whole device) -- first tells the server to leave and waits for it; the next run() of a roster engine starts it again.
+std::mutex                g_srv_mu;
+std::vector<prot_engine*> g_srv_roster;           // engines the next kernel is started for
+std::vector<prot_engine*> g_srv_members;          // engines the running kernel has slots for (srv_running each)
+hipStream_t               g_srv_stream = nullptr; // the stream the running kernel was launched on (its starter's)
 // Calls that allocate, free or synchronise the whole device (create, destroy, reserve, reset, sync) HOLD the server off for
 // their whole duration: stopping it once is not enough when another thread's run() -- an audio thread calling every few
 // milliseconds -- may start it again while hipMalloc / hipFree / hipDeviceSynchronize are still waiting for a device without a
@@ -1155,21 +1161,26 @@ int g_srv_hold = 0;
 
 int server_stop_locked ()
 {
-	prot_engine* o = g_srv_owner;
-	if (o == nullptr) {
+	if (g_srv_members.empty ()) {
 		return PROT_OK;
 	}
-	g_srv_owner = nullptr;
-	if (o->srv_running) {
-		o->srv_running = false;
-		prot::SvServerBox* b = reinterpret_cast<prot::SvServerBox*> (o->srv_box);
-		o->srv_seq           = (o->srv_seq % (1u << 30)) + 1u;
-		_mm_sfence ();
-		__atomic_store_n (&b->bell, (uint64_t)o->srv_seq | ((uint64_t)1 << 63), __ATOMIC_RELEASE);
-		_mm_sfence ();
-		HIP_TRY (hipStreamSynchronize (o->srv_stream));
+	std::vector<prot_engine*> members;
+	members.swap (g_srv_members);
+	for (prot_engine* o : members) { // every engine's workgroups leave on their own doorbell
+		if (o->srv_running) {
+			prot::SvServerBox* b = reinterpret_cast<prot::SvServerBox*> (o->srv_box);
+			o->srv_seq           = (o->srv_seq % (1u << 30)) + 1u;
+			_mm_sfence ();
+			__atomic_store_n (&b->bell, (uint64_t)o->srv_seq | ((uint64_t)1 << 63), __ATOMIC_RELEASE);
+			_mm_sfence ();
+		}
 	}
-	return PROT_OK;
+	hipError_t err = g_srv_stream ? hipStreamSynchronize (g_srv_stream) : hipSuccess;
+	for (prot_engine* o : members) {
+		o->srv_running = false;
+	}
+	g_srv_stream = nullptr;
+	return err == hipSuccess ? PROT_OK : hip_fail (err, "run() server stop");
 }
 int server_stop_any ()
 {
@@ -1191,28 +1202,77 @@ struct ServerHold {
 	ServerHold (const ServerHold&)            = delete;
 	ServerHold& operator= (const ServerHold&) = delete;
 };
-// (g_srv_mu held) start e's server behind whatever the engine's own stream still has to do
+bool server_is_member (const prot_engine* e)
+{
+	return std::find (g_srv_members.begin (), g_srv_members.end (), e) != g_srv_members.end ();
+}
+// (g_srv_mu held) may e join the roster: same device as the others, a slot left for each of its channels
+bool server_roster_takes (prot_engine* e)
+{
+	if (std::find (g_srv_roster.begin (), g_srv_roster.end (), e) != g_srv_roster.end ()) {
+		return true;
+	}
+	size_t chn = e->info.n_chn;
+	for (const prot_engine* o : g_srv_roster) {
+		if (o->device != e->device) {
+			return false;
+		}
+		chn += o->info.n_chn;
+	}
+	return chn <= (size_t)prot::kServerMaxChn;
+}
+void server_roster_remove (prot_engine* e)
+{
+	g_srv_roster.erase (std::remove (g_srv_roster.begin (), g_srv_roster.end (), e), g_srv_roster.end ());
+}
+// (g_srv_mu held) start the server for the roster (e joins it) behind whatever the engines' own streams still have to do; a
+// kernel that is still there -- serving others, or on its way out -- leaves first
 int server_start_locked (prot_engine* e)
 {
-	if (e->srv_running) { // it has left by itself (idle): the kernel is over or about to be
+	int rc = server_stop_locked ();
+	if (rc) {
+		return rc;
+	}
+	if (e->srv_running) { // (a server of its own that left by itself: over or about to be)
 		HIP_TRY (hipStreamSynchronize (e->srv_stream));
 		e->srv_running = false;
 	}
-	HIP_TRY (hipEventRecord (e->srv_ev, e->stream));
-	HIP_TRY (hipStreamWaitEvent (e->srv_stream, e->srv_ev, 0));
-	prot::SvServerBox* b = reinterpret_cast<prot::SvServerBox*> (e->srv_box);
-	prot::SvServerAck* a = e->srv_ack.p;
-	__atomic_store_n (&b->bell, (uint64_t)e->srv_seq, __ATOMIC_RELEASE);
-	_mm_sfence ();
-	__atomic_store_n (&a->alive, 1u, __ATOMIC_RELEASE);
-	hipError_t err = prot::launch_ola_save_server (b, a, e->d_srv_relay.p, e->srv_seq, e->hopseg / 2, (int)e->info.n_chn, e->srv_stream);
+	if (std::find (g_srv_roster.begin (), g_srv_roster.end (), e) == g_srv_roster.end ()) {
+		g_srv_roster.push_back (e);
+	}
+	prot::SvServerSlots slots {};
+	for (prot_engine* o : g_srv_roster) {
+		HIP_TRY (hipEventRecord (o->srv_ev, o->stream));
+		HIP_TRY (hipStreamWaitEvent (e->srv_stream, o->srv_ev, 0));
+		prot::SvServerBox* b = reinterpret_cast<prot::SvServerBox*> (o->srv_box);
+		prot::SvServerAck* a = o->srv_ack.p;
+		__atomic_store_n (&b->bell, (uint64_t)o->srv_seq, __ATOMIC_RELEASE);
+		_mm_sfence ();
+		__atomic_store_n (&a->alive, 1u, __ATOMIC_RELEASE);
+		for (uint32_t c = 0; c < o->info.n_chn; ++c) {
+			prot::SvServerSlot& sl = slots.s[slots.n++];
+			sl.box      = b;
+			sl.ack      = a;
+			sl.relay    = o->d_srv_relay.p;
+			sl.last_seq = o->srv_seq;
+			sl.chn      = (int)c;
+			sl.n_chn    = (int)o->info.n_chn;
+			sl.hop_rows = o->hopseg / 2;
+		}
+	}
+	hipError_t err = prot::launch_ola_save_server (slots, e->srv_stream);
 	if (err != hipSuccess) {
-		a->alive = 0u;
+		for (prot_engine* o : g_srv_roster) {
+			o->srv_ack.p->alive = 0u;
+		}
 		return hip_fail (err, "run() server launch");
 	}
-	e->srv_running = true;
+	for (prot_engine* o : g_srv_roster) {
+		o->srv_running = true;
+	}
+	g_srv_members = g_srv_roster;
+	g_srv_stream  = e->srv_stream;
 	e->srv_starts++;
-	g_srv_owner = e;
 	return PROT_OK;
 }
 
@@ -1781,6 +1841,10 @@ void prot_engine_destroy (prot_engine* e)
 	}
 	(void)hipSetDevice (e->device);
 	ServerHold srv_hold; // (whoever's it is: hipFree waits for the whole device)
+	{
+		std::lock_guard<std::mutex> lk (g_srv_mu);
+		server_roster_remove (e);
+	}
 	if (e->srv_stream) {
 		(void)hipStreamSynchronize (e->srv_stream);
 		(void)hipStreamDestroy (e->srv_stream);
@@ -2778,12 +2842,12 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 
 	// The run() server (prot_olasave.hip): the call's parameters and frames go into the mailbox, the doorbell is rung, the resident
 	// kernel does the block and stores the call's number when the output is in h_out -- no launch, no stream synchronisation.
-	// One server per process (the first LV2 engine to ask: see g_srv_owner); calls of more than one block per channel, staged
+	// One server per process, a slot per channel of every engine on its roster (g_srv_roster); calls of more than one block per channel, staged
 	// calls and PROT_TEST_LV2_NO_SERVER take the launch below.  tools/run_latency.py: 38-40 us -> the figure in DESIGN.md.
 	bool served = false;
 	if (!staged && e->srv_eligible && test_opt (PROT_TEST_LV2_NO_SERVER) == 0) {
 		std::lock_guard<std::mutex> lk (g_srv_mu);
-		if (g_srv_hold == 0 && (g_srv_owner == nullptr || g_srv_owner == e)) {
+		if (g_srv_hold == 0 && server_roster_takes (e)) {
 			prot::SvServerBox* b = reinterpret_cast<prot::SvServerBox*> (e->srv_box);
 			prot::SvServerAck* a = e->srv_ack.p;
 			// the host -> device half of the mailbox is STORED into, never read (through the BAR a CPU load is microseconds): the
@@ -2811,8 +2875,8 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 			rc = ola_launch (e, srv_in, (int64_t)n, n, h_out, (int64_t)n, n, rot_inline ? nullptr : d_rot_c, steady ? nullptr : srv_rot, false, false, 0, (int)nc, s,
 			                 /*advance_hist*/ true, rot_inline ? d_rot_c : nullptr, nullptr, nullptr, b);
 			if (rc == PROT_OK) {
-				if (!e->srv_running || __atomic_load_n (&a->alive, __ATOMIC_ACQUIRE) == 0u) {
-					rc = server_start_locked (e);
+				if (!e->srv_running || !server_is_member (e) || __atomic_load_n (&a->alive, __ATOMIC_ACQUIRE) == 0u) {
+					rc = server_start_locked (e); // (for the whole roster: the other engines' workgroups come back with this one's)
 				}
 				if (rc == PROT_OK) {
 					e->srv_seq = (e->srv_seq % (1u << 30)) + 1u;
@@ -2830,7 +2894,12 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 							continue;
 						}
 						if (__atomic_load_n (&a->alive, __ATOMIC_ACQUIRE) == 0u) {
-							HIP_TRY (hipStreamSynchronize (e->srv_stream)); // the kernel is over: what it served is complete
+							// this engine's workgroups have left (idle, or the kernel's age): the others' follow on the stop below -- what
+							// they served is complete when the kernel is over
+							rc = server_stop_locked ();
+							if (rc) {
+								return rc;
+							}
 							bool all = true;
 							for (uint32_t k = 0; k < nc; ++k) {
 								all = all && __atomic_load_n (&a->done[k], __ATOMIC_ACQUIRE) == seq;
@@ -2857,6 +2926,7 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 							// does not answer: the launch route from here on -- ADVICE r4)
 							e->hist_cur     = hist_before;
 							e->srv_eligible = false;
+							server_roster_remove (e);
 							return PROT_EHIP;
 						}
 					}
@@ -2906,7 +2976,7 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 	}
 	{ // (the staged route uses the engine's stream and history: not beside this engine's own server)
 		std::lock_guard<std::mutex> lk (g_srv_mu);
-		if (g_srv_owner == e) {
+		if (server_is_member (e)) {
 			(void)server_stop_locked ();
 		}
 	}
@@ -3528,6 +3598,59 @@ int prot_internal_time_lv2_run (prot_engine* e, uint32_t frames, uint32_t calls,
 	us[0] = std::chrono::duration<double, std::micro> (t_p - t_0).count () / calls;
 	us[1] = worst;            // the slowest single call
 	us[2] = (double)worst_at; // ... and which
+	return PROT_OK;
+}
+
+// The same for a host that runs several plugin instances in turn (round 5: one resident kernel serves them all): `calls` rounds of
+// one prot_lv2_run on each of the n engines, into us[3]: mean microseconds per CALL (not per round), the slowest single call, its index.
+int prot_internal_time_lv2_run_multi (prot_engine* const* es, uint32_t n, uint32_t frames, uint32_t calls, double us[3])
+{
+	if (!es || n == 0 || n > 16 || !us || frames == 0 || calls == 0) {
+		return PROT_EINVAL;
+	}
+	uint32_t nc_max = 0;
+	for (uint32_t i = 0; i < n; ++i) {
+		if (!es[i] || es[i]->info.kind != PROT_KIND_LV2) {
+			return PROT_EINVAL;
+		}
+		nc_max = std::max (nc_max, es[i]->info.n_chn);
+	}
+	std::vector<float>        buf ((size_t)2 * nc_max * frames);
+	std::vector<const float*> in (nc_max);
+	std::vector<float*>       out (nc_max);
+	std::vector<float>        ang (nc_max, 90.f);
+	uint32_t                  x = 12345u;
+	for (size_t i = 0; i < (size_t)nc_max * frames; ++i) {
+		x ^= x << 13, x ^= x >> 17, x ^= x << 5;
+		buf[i] = (float)(x >> 8) * (1.f / 16777216.f) - 0.5f;
+	}
+	for (uint32_t c = 0; c < nc_max; ++c) {
+		in[c]  = buf.data () + (size_t)c * frames;
+		out[c] = buf.data () + (size_t)(nc_max + c) * frames;
+	}
+	double   worst = 0.0;
+	uint32_t worst_at = 0;
+	auto     t_0 = std::chrono::steady_clock::now ();
+	for (uint32_t k = 0; k < 50 + calls; ++k) {
+		if (k == 50) {
+			t_0 = std::chrono::steady_clock::now ();
+		}
+		for (uint32_t i = 0; i < n; ++i) {
+			const auto t_a = std::chrono::steady_clock::now ();
+			const int  rc  = prot_lv2_run (es[i], in.data (), out.data (), frames, ang.data ());
+			if (rc) {
+				return rc;
+			}
+			const double d = std::chrono::duration<double, std::micro> (std::chrono::steady_clock::now () - t_a).count ();
+			if (k >= 50 && d > worst) {
+				worst    = d;
+				worst_at = (k - 50) * n + i;
+			}
+		}
+	}
+	us[0] = std::chrono::duration<double, std::micro> (std::chrono::steady_clock::now () - t_0).count () / ((double)calls * n);
+	us[1] = worst;
+	us[2] = (double)worst_at;
 	return PROT_OK;
 }
 

@@ -28,6 +28,7 @@ int prot_internal_fused_lists (struct prot_engine* e, unsigned long long out[4])
 // mean microseconds per prot_lv2_run call on `frames` frames per channel, `calls` calls straight from C (what an LV2 host's audio
 // thread sees, without a binding in between)
 int prot_internal_time_lv2_run (struct prot_engine* e, unsigned frames, unsigned calls, double us[3]); // mean, slowest call, its index
+int prot_internal_time_lv2_run_multi (struct prot_engine* const* es, unsigned n, unsigned frames, unsigned calls, double us[3]); // the same, n engines in turn
 // the run() server of an LV2 engine: out = { calls it has taken, kernels started for it }
 int prot_internal_server_stats (struct prot_engine* e, unsigned long long out[2]);
 #ifdef __cplusplus

@@ -136,7 +136,20 @@ struct SvServerAck {
 	uint32_t pad0[15]; // how far each channel's workgroup has come (diagnostics)
 	uint32_t done[kServerMaxChn]; // done[c] = the call's number when channel c's output (and its next history) is complete
 };
-hipError_t launch_ola_save_server (const SvServerBox* box, SvServerAck* ack, unsigned* relay, unsigned last_seq, int hop_rows, int n_chn, hipStream_t s);
+// the slots of ONE resident kernel (round 5): a workgroup per channel of every engine it serves
+struct SvServerSlot {
+	const SvServerBox* box;
+	SvServerAck*       ack;
+	unsigned*          relay;    // device words of the slot's engine: its channel 0 relays the doorbell to its other channels
+	unsigned           last_seq; // the number of the last call the engine's server took
+	int                chn, n_chn; // the slot's channel / the channels of its engine
+	int                hop_rows; // 8 or 10: the engine's block (olasave_body<HS>)
+};
+struct SvServerSlots {
+	int          n;
+	SvServerSlot s[kServerMaxChn];
+};
+hipError_t launch_ola_save_server (const SvServerSlots& slots, hipStream_t s);
 hipError_t post_ola_save_server (const OlaParamsT<float>& p, int hop_rows, int n_rho_rows, int n_chn, SvServerBox* box);
 hipError_t launch_ola_save8k (const OlaParams& p, int hop_rows, int n_chn, hipStream_t s);
 // the same on 16384-point blocks (prot_olasave16k.hip: 1024-thread workgroups, hop_rows = 8: CLI blksiz 16384)

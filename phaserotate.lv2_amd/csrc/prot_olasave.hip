@@ -101,7 +101,7 @@ extern "C" int prot_debug_srv_t (unsigned* out)
 // WIDE (the run() server: one workgroup per CU, registers to spare, and every load a round trip nothing else hides): the 16 rows of
 // a staged block are fetched before the first is parked, the history slice moves eight frames per thread at a time, without a branch per frame
 template <int HS, int MODE, bool WIDE = false>
-PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_lo_s)
+PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_lo_s, const int chn = -1)
 {
 	constexpr int BLK = 512 * HS; // output frames per block
 	constexpr int NT  = 16 - HS;  // context rows
@@ -111,7 +111,7 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 	static_assert (MODE != MODE_SWEEP || HS != 10, "the fused sweep exists for the CLI engines (blksiz 2048, 4096)");
 
 	const int t0 = threadIdx.x;
-	const int c  = blockIdx.y;
+	const int c  = WIDE ? chn : (int)blockIdx.y; // (the run() server's workgroups are slots of several engines: the channel comes with the slot)
 	PROT_SRV_T (5)
 #ifdef PROT_SV_CLOCK
 	const uint64_t wg_t0 = __builtin_amdgcn_s_memrealtime ();
@@ -208,8 +208,8 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 			const int per = (p.hist_len + (int)gridDim.x - 1) / (int)gridDim.x;
 			const int i0  = (int)blockIdx.x * per;
 			const int i1  = i0 + per < p.hist_len ? i0 + per : p.hist_len;
-			const float* __restrict__ src = p.in + (int64_t)blockIdx.y * p.in_stride + (p.n_in - p.hist_len);
-			float* __restrict__ ho        = p.hist_out + (int64_t)blockIdx.y * p.hist_len;
+			const float* __restrict__ src = p.in + (int64_t)c * p.in_stride + (p.n_in - p.hist_len);
+			float* __restrict__ ho        = p.hist_out + (int64_t)c * p.hist_len;
 			for (int i = i0 + t0; i < i1; i += 256) {
 				__hip_atomic_store (&ho[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
@@ -230,7 +230,7 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 	run_of_workgroup (p, r0, rlen);
 	if (r0 >= p.n_out) {
 		if (!piped) {
-			hist_write_slice (p, blockIdx.y, threadIdx.x);
+			hist_write_slice (p, c, threadIdx.x);
 		}
 		if (MODE == MODE_SWEEP && (t0 & 63) == 0) {
 			p.surv_cnt[((int64_t)c * gridDim.x + blockIdx.x) * 4 + (t0 >> 6)] = 0u;
@@ -563,7 +563,7 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 				}
 			}
 		} else {
-			hist_write_slice (p, blockIdx.y, threadIdx.x);
+			hist_write_slice (p, c, threadIdx.x);
 		}
 	}
 	PROT_SRV_T (4)
@@ -612,18 +612,15 @@ constexpr uint64_t kServerIdleTicks = 25000000ull;
 // under continuous audio.
 constexpr uint64_t kServerLifeTicks = 25000000ull;
 
+// One slot of the server = one channel of one engine: the engine's mailbox (box, ack), the device word through which its channel 0
+// relays the doorbell to its other channels, the number of the last call it has served.  Round 5: ONE resident kernel serves every
+// LV2 engine of the process that asks (a slot per channel, up to kServerMaxChn in all) -- a second resident kernel would share a
+// hardware queue with the first sooner or later and wait behind it for as long as it stays.
 template <int HS>
-__global__ __launch_bounds__ (256, 1) void olasave_server_kernel (const SvServerBox* const box, SvServerAck* const ack, unsigned* const relay,
-                                                                    const unsigned last_seq)
+PROT_DEV void server_loop (const SvServerBox* const box, SvServerAck* const ack, unsigned* const relay, const unsigned last_seq, const int chn, const int n_chn,
+                           f2* const smem, float* const sw_lo_s, unsigned* const sh_w, float* const sh_in, unsigned* const sh_p)
 {
 	const float* const port_in = reinterpret_cast<const float*> (reinterpret_cast<const char*> (box) + kServerInOffset);
-	__shared__ f2       smem[kLdsExchange + 512];
-	__shared__ float    sw_lo_s[4];
-	__shared__ unsigned sh_w[2];
-	// the call's input frames of this channel, fetched from the mailbox ONCE (the block reads them twice -- its rows and
-	// the next history -- and every read of host memory is a trip over the host link that nothing hides)
-	__shared__ __attribute__ ((aligned (16))) float sh_in[512 * HS];
-	__shared__ __attribute__ ((aligned (16))) unsigned sh_p[(sizeof (OlaParams) + 3) / 4]; // the call's parameters (read in place)
 	const int tid  = threadIdx.x;
 	unsigned  seen = last_seq;
 	// (pad0[c]: how far channel c's workgroup has come -- 1 resident, 2 doorbell seen, 3 parameters read, 4 block done, 5 done
@@ -631,10 +628,10 @@ __global__ __launch_bounds__ (256, 1) void olasave_server_kernel (const SvServer
 	auto stage = [&] (unsigned v) {
 		int tid_s = tid;
 		asm volatile ("" : "+v"(tid_s));
-		if (tid_s == 0 && blockIdx.y < 8) {
-			__hip_atomic_store (&ack->pad0[blockIdx.y], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		if (tid_s == 0 && chn < 8) {
+			__hip_atomic_store (&ack->pad0[chn], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef PROT_SERVER_STAMPS
-			if (blockIdx.y == 0 && v >= 2u && v <= 5u) { // 100 MHz ticks at the stages of channel 0's workgroup
+			if (chn == 0 && v >= 2u && v <= 5u) { // 100 MHz ticks at the stages of channel 0's workgroup
 				__hip_atomic_store (&ack->pad0[6 + v], (unsigned)__builtin_amdgcn_s_memrealtime (), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 			}
 #endif
@@ -652,7 +649,7 @@ __global__ __launch_bounds__ (256, 1) void olasave_server_kernel (const SvServer
 		if (tid_poll == 0) {
 			unsigned word;
 			unsigned frames = 0u;
-			if (blockIdx.y == 0) {
+			if (chn == 0) {
 				unsigned       s = seen, cmd = 0u;
 				const uint64_t t_0 = __builtin_amdgcn_s_memrealtime ();
 				for (;;) {
@@ -671,7 +668,7 @@ __global__ __launch_bounds__ (256, 1) void olasave_server_kernel (const SvServer
 					__builtin_amdgcn_s_sleep (4);
 				}
 				word = 2u * s + cmd;
-				if (gridDim.y > 1) {
+				if (n_chn > 1) {
 					__hip_atomic_store (relay + 1, frames, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					__hip_atomic_store (relay, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 				}
@@ -705,8 +702,8 @@ __global__ __launch_bounds__ (256, 1) void olasave_server_kernel (const SvServer
 		{ // (the port block: [channel][frames], prot_capi.hip lv2_run_chunk)
 			// (system-scope loads: past the caches, whichever memory the box lives in; eight bytes per lane when the channel's frames
 			// start on an 8-byte boundary)
-			const float* const src = port_in + (int64_t)blockIdx.y * frames;
-			if (((blockIdx.y * frames) & 1) == 0) {
+			const float* const src = port_in + (int64_t)chn * frames;
+			if (((chn * frames) & 1) == 0) {
 				uint64_t* const       dst8 = reinterpret_cast<uint64_t*> (sh_in);
 				const uint64_t* const src8 = reinterpret_cast<const uint64_t*> (src);
 				for (int i = tid; i < frames / 2; i += 256) {
@@ -731,9 +728,9 @@ __global__ __launch_bounds__ (256, 1) void olasave_server_kernel (const SvServer
 		const OlaParams& p = *reinterpret_cast<const OlaParams*> (sh_p);
 		stage (3u);
 		if (p.rot_s != nullptr) {
-			olasave_body<HS, MODE_RAMP, true> (p, smem, sw_lo_s);
+			olasave_body<HS, MODE_RAMP, true> (p, smem, sw_lo_s, chn);
 		} else {
-			olasave_body<HS, MODE_ROT, true> (p, smem, sw_lo_s);
+			olasave_body<HS, MODE_ROT, true> (p, smem, sw_lo_s, chn);
 		}
 		stage (4u);
 		__builtin_amdgcn_fence (__ATOMIC_RELEASE, ""); // output frames and the next history: visible to the host / to later launches
@@ -741,32 +738,52 @@ __global__ __launch_bounds__ (256, 1) void olasave_server_kernel (const SvServer
 		int tid_done = tid;
 		asm volatile ("" : "+v"(tid_done));
 		if (tid_done == 0) {
-			__hip_atomic_store (&ack->done[blockIdx.y], word >> 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store (&ack->done[chn], word >> 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 		stage (5u);
 		seen = word >> 1;
 	}
 	stage (9u);
-	if (tid == 0 && blockIdx.y == 0) {
+	if (tid == 0 && chn == 0) {
 		__hip_atomic_store (&ack->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 }
 
-hipError_t launch_ola_save_server (const SvServerBox* box, SvServerAck* ack, unsigned* relay, unsigned last_seq, int hop_rows, int n_chn, hipStream_t s)
+__global__ __launch_bounds__ (256, 1) void olasave_server_kernel (const SvServerSlots slots)
 {
-	if (n_chn < 1 || n_chn > kServerMaxChn) {
+	__shared__ f2       smem[kLdsExchange + 512];
+	__shared__ float    sw_lo_s[4];
+	__shared__ unsigned sh_w[2];
+	// the call's input frames of this channel, fetched from the mailbox ONCE (the block reads them twice -- its rows and
+	// the next history -- and every read of host memory is a trip over the host link that nothing hides)
+	__shared__ __attribute__ ((aligned (16))) float sh_in[512 * 10];
+	__shared__ __attribute__ ((aligned (16))) unsigned sh_p[(sizeof (OlaParams) + 3) / 4]; // the call's parameters (read in place)
+	const SvServerSlot& sl = slots.s[blockIdx.y];
+	if (sl.hop_rows == 8) {
+		server_loop<8> (sl.box, sl.ack, sl.relay, sl.last_seq, sl.chn, sl.n_chn, smem, sw_lo_s, sh_w, sh_in, sh_p);
+	} else {
+		server_loop<10> (sl.box, sl.ack, sl.relay, sl.last_seq, sl.chn, sl.n_chn, smem, sw_lo_s, sh_w, sh_in, sh_p);
+	}
+}
+
+hipError_t launch_ola_save_server (const SvServerSlots& slots, hipStream_t s)
+{
+	if (slots.n < 1 || slots.n > kServerMaxChn) {
 		return hipErrorInvalidValue;
 	}
-	hipError_t err = hipMemsetD32Async (reinterpret_cast<hipDeviceptr_t> (relay), (int)(2u * last_seq), 1, s);
-	if (err != hipSuccess) {
-		return err;
+	for (int i = 0; i < slots.n; ++i) {
+		const SvServerSlot& sl = slots.s[i];
+		if ((sl.hop_rows != 8 && sl.hop_rows != 10) || sl.box == nullptr || sl.ack == nullptr || sl.relay == nullptr) {
+			return hipErrorInvalidValue;
+		}
+		if (sl.chn == 0) {
+			hipError_t err = hipMemsetD32Async (reinterpret_cast<hipDeviceptr_t> (sl.relay), (int)(2u * sl.last_seq), 1, s);
+			if (err != hipSuccess) {
+				return err;
+			}
+		}
 	}
-	const dim3 grid (1, (unsigned)n_chn), block (256);
-	switch (hop_rows) {
-		case 8: hipLaunchKernelGGL ((olasave_server_kernel<8>), grid, block, 0, s, box, ack, relay, last_seq); break;
-		case 10: hipLaunchKernelGGL ((olasave_server_kernel<10>), grid, block, 0, s, box, ack, relay, last_seq); break;
-		default: return hipErrorInvalidValue;
-	}
+	hipLaunchKernelGGL (olasave_server_kernel, dim3 (1, (unsigned)slots.n), dim3 (256), 0, s, slots);
 	return hipGetLastError ();
 }
 
