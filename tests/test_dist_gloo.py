@@ -39,12 +39,14 @@ def test_plan_shards(pkg):
         assert all(a[1] == b[0] for a, b in zip(pl, pl[1:])) and all(b0 % 3 == 0 for b0, _ in pl)
 
 
-@pytest.mark.parametrize("n_chn,n_frames", [(2, 2048 * 9 + 517), (1, 2048 * 4)])
-def test_sharded_sweep_world2_gloo(tmp_path, n_chn, n_frames):
+@pytest.mark.parametrize("n_chn,n_frames,mode", [(2, 2048 * 9 + 517, "one_phase"), (1, 2048 * 4, "one_phase"), (2, 2048 * 13 + 100, "two_phase")])
+def test_sharded_sweep_world2_gloo(tmp_path, n_chn, n_frames, mode):
+    """two_phase: sweep_dist.sweep_two_phase (seed -> MAX all-reduce -> main pass -> MAX all-reduce, round 5) over gloo with the
+    oracle as each rank's engine: the merged table is the single pass's, bit for bit."""
     blksiz, world = 2048, 2
     port = free_port()
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world),
-                               str(port), str(blksiz), str(n_chn), str(n_frames), str(tmp_path)])
+                               str(port), str(blksiz), str(n_chn), str(n_frames), str(tmp_path), mode])
              for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0
