@@ -1389,27 +1389,30 @@ void prot_sincos_lut (int a, float* s, float* c)
 	*c = g_lut[2 * a + 1];
 }
 
-prot_engine* prot_engine_create (const prot_config* cfg, int* status)
-{
-	int  st_dummy;
-	int& st = status ? *status : st_dummy;
-	st      = PROT_OK;
-	g_err[0] = 0;
-	if (!cfg || cfg->n_chn < 1 || cfg->n_chn > 65535) {
-		st = PROT_EINVAL;
-		return nullptr;
-	}
-	std::call_once (g_lut_once, lut_init);
-	ServerHold srv_hold; // (engine creation allocates, uploads and synchronises: nothing resident until it returns)
+// What prot_engine_create works out on the host before it touches the device (plan_engine), and the tables the block kernels it
+// picks need (pick_block_kernels); upload_engine allocates and uploads, setup_lv2 reserves run()'s buffers and the server's mailbox.
+struct EnginePlan {
+	prot_info           inf {};
+	std::vector<float>  fir_taps;
+	uint32_t            F = 4096, n_part = 0, part_len = 0;
+	int                 hopseg = 0;
+	bool                use_p2 = false, use_poly = false;
+	std::vector<float2> H_h, Hp_h, tw_h;
+	std::vector<float>  sv_h, sv8_h, sv16_h;
+};
 
-	prot_info inf {};
+// kind + parameter -> FIR, form (direct / polyphase), partitions, hop, history: host arithmetic only
+static int plan_engine (const prot_config* cfg, EnginePlan& pl)
+{
+	prot_info&          inf      = pl.inf;
+	std::vector<float>& fir_taps = pl.fir_taps;
+
 	inf.kind  = cfg->kind;
 	inf.n_chn = cfg->n_chn;
 	if (cfg->kind == PROT_KIND_CLI) {
 		const uint32_t P = (uint32_t)cfg->param;
 		if (P < 1024 || P > 32768 || (P & (P - 1)) || (double)P != cfg->param) { // cli/phase-rotate.cc:673, :753-755
-			st = PROT_EINVAL;
-			return nullptr;
+			return PROT_EINVAL;
 		}
 		inf.blksiz     = P;
 		inf.firlen     = P;      // cli/phase-rotate.cc:154 (c2r of _parsiz points)
@@ -1419,8 +1422,7 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	} else if (cfg->kind == PROT_KIND_LV2) {
 		const double rate = cfg->param;
 		if (!(rate > 0)) {
-			st = PROT_EINVAL;
-			return nullptr;
+			return PROT_EINVAL;
 		}
 		uint32_t fftlen, firlen; // src/phaserotate.c:278-289
 		if (rate < 64000) {
@@ -1439,8 +1441,7 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 		inf.latency    = inf.blksiz + firlen / 2;   // :297
 		inf.dry_delay  = inf.latency;
 	} else {
-		st = PROT_EINVAL;
-		return nullptr;
+		return PROT_EINVAL;
 	}
 	// device OLA geometry.  One 4096-point FFT per hop pair; FIRs of up to 3072 taps
 	// fit one transform (hop = 4096 - 3072 = 1024, or 2048 for <= 2049 taps).  Longer
@@ -1449,11 +1450,10 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	// partial Hilbert branches add up in the output (uniformly partitioned OLA, the
 	// scheme the reference's own LV2 engine uses with 256..1024-frame partitions,
 	// src/phaserotate.c:640-655).
-	const uint32_t F = 4096;
+	const uint32_t F = pl.F;
 	if (cfg->fftlen != 0 && cfg->fftlen != F) {
-		st = PROT_EUNSUPPORTED;
 		snprintf (g_err, sizeof (g_err), "fftlen %u not supported; the device transform is 4096 points", cfg->fftlen);
-		return nullptr;
+		return PROT_EUNSUPPORTED;
 	}
 	const uint32_t seg = F / 16;
 	// FIRs longer than one 2048-tap partition: partitions are convolved in PAIRS that share a
@@ -1465,7 +1465,6 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	// in POLYPHASE form: the stream read as complex samples x[2j-1] + i x[2j] is convolved with
 	// g[s] = fir[2 s + 1] (olapoly_kernel) -- half the taps, blocks of 4096 frames, one launch per
 	// PAIR of 2048-tap partitions of g.  PROT_CFG_DIRECT_FORM keeps the two-partition direct form.
-	std::vector<float> fir_taps;
 	fir_design ((int)inf.firlen, fir_taps);
 	// Which form is the default is decided by measurement (tools/order_check.py, 10 interleaved rounds on
 	// two boxes, ranges disjoint): polyphase wins wherever the odd taps leave room for a longer hop --
@@ -1484,8 +1483,9 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	for (uint32_t i = 0; use_poly && i < inf.firlen; i += 2) {
 		use_poly = fir_taps[i] == 0.f;
 	}
-	int        hopseg;
-	uint32_t   n_part, part_len;
+	int&      hopseg = pl.hopseg;
+	uint32_t& n_part = pl.n_part;
+	uint32_t& part_len = pl.part_len;
 	if (use_poly) {
 		part_len = F / 2;                                         // taps of g per partition
 		n_part   = (inf.firlen / 2 + part_len - 1) / part_len;
@@ -1527,6 +1527,313 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 	}
 	H          = std::max (H, inf.dry_delay);
 	inf.history = (H + 255) & ~255u;
+
+	pl.use_p2   = use_p2;
+	pl.use_poly = use_poly;
+	return PROT_OK;
+}
+
+// which block kernel convolves (overlap-save on 4096- / 8192- / 16384-point blocks, or the table forms) and its tables; the pipelined
+// route's streams
+static int pick_block_kernels (prot_engine* e, const prot_config* cfg, EnginePlan& pl)
+{
+	prot_info&                 inf      = pl.inf;
+	const std::vector<float>&  fir_taps = pl.fir_taps;
+	const uint32_t             F        = pl.F;
+	const uint32_t             n_part = pl.n_part, part_len = pl.part_len;
+	const int                  hopseg   = pl.hopseg;
+	const bool                 use_p2 = pl.use_p2, use_poly = pl.use_poly;
+	(void)F, (void)n_part, (void)part_len, (void)hopseg, (void)use_p2, (void)use_poly, (void)fir_taps, (void)inf;
+	std::vector<float>& sv_h = pl.sv_h;
+	std::vector<float>& sv8_h = pl.sv8_h;
+	std::vector<float>& sv16_h = pl.sv16_h;
+
+	if (use_poly && n_part == 1 && !(cfg->flags & PROT_CFG_OVERLAP_ADD) && tuning_env ("PROT_NO_SAVE") == nullptr &&
+	    2 * (inf.dry_delay - inf.conv_delay) == 256 * (32 - (uint32_t)hopseg) && inf.dry_delay % 2 == 0) {
+		e->sv_flags = test_opt (PROT_TEST_EDGE_PATH_ONLY) ? 1 : 0; // (test hook: every block through the staged path)
+		e->use_save = hopseg <= 24 && save_tables (fir_taps, F, sv_h, e->sv_gain, e->sv_rows) && e->sv_rows == 1;
+		if (e->use_save && e->cus > 0 && tuning_env ("PROT_WG_PER_CU") == nullptr) {
+			e->wg_slots = e->cus * 4; // 128 VGPRs, 38 KiB of LDS
+		}
+	}
+	if (e->use_save && inf.kind == PROT_KIND_LV2 && !(cfg->flags & PROT_CFG_BLOCK4096) && (inf.firlen == 3072 || inf.firlen == 4096) &&
+	    tuning_env ("PROT_NO_SAVE8K") == nullptr) {
+		e->use_save8 = save_tables8k (fir_taps, sv8_h, e->sv8_gain);
+		e->sv8_rows  = 16 - (int)(inf.firlen / 1024);
+	}
+	// CLI blksiz 4096 (2048 odd taps = 4 context rows of an 8192-point block, 12288 new frames per block): every fp32 launch on
+	// these blocks, as for blksiz 8192 below (rotate 0.295 -> 0.27 ms, the fused sweep's Hilbert pass -20 %)
+	if (e->use_save && inf.kind == PROT_KIND_CLI && inf.firlen == 4096 && inf.conv_delay == 0 && inf.dry_delay == 2048 &&
+	    !(cfg->flags & (PROT_CFG_BLOCK4096 | PROT_CFG_OVERLAP_ADD | PROT_CFG_POLYPHASE)) && !(e->sv_flags & 1) && tuning_env ("PROT_NO_SAVE8K") == nullptr) {
+		e->use_save8 = save_tables8k (fir_taps, sv8_h, e->sv8_gain);
+		if (e->use_save8) {
+			e->sv8_rows   = 12;
+			e->sv8_always = true;
+			inf.hop       = 12288;
+			inf.run_align = 12288;
+			inf.history   = std::max<uint32_t> (inf.history, 4096 + 256);
+			e->info.hop = inf.hop, e->info.run_align = inf.run_align, e->info.history = inf.history;
+			if (e->cus > 0 && tuning_env ("PROT_WG_PER_CU") == nullptr) {
+				e->wg_slots = e->cus * 2;
+			}
+		}
+	}
+	// LV2 at 176.4 / 192 kHz (8192 taps = 8 context rows of an 8192-point block, one table-free partition): long launches only, like
+	// the other LV2 rates (shorter ones keep olapoly_kernel's two partitions on 4096-point transforms)
+	if (use_poly && n_part == 2 && inf.kind == PROT_KIND_LV2 && inf.firlen == 8192 && 2 * (inf.dry_delay - inf.conv_delay) == 8192 &&
+	    inf.dry_delay % 2 == 0 && inf.history >= inf.dry_delay + 4096 + 2 &&
+	    !(cfg->flags & (PROT_CFG_BLOCK4096 | PROT_CFG_OVERLAP_ADD | PROT_CFG_POLYPHASE)) && tuning_env ("PROT_NO_SAVE8K") == nullptr) {
+		e->use_save8 = save_tables8k (fir_taps, sv8_h, e->sv8_gain);
+		e->sv8_rows  = 8;
+	}
+	// The CLI's default engine at 44.1 / 48 kHz (blksiz 8192, cli/phase-rotate.cc:749-755): 4096 odd taps = 8 context rows of an
+	// 8192-point block -- ONE table-free partition, 8192 new frames per block, instead of two 2048-tap partitions with a spectrum
+	// table on 4096-point transforms (olapoly_kernel, which stays for the fp16 path and under the flags that ask for it).  EVERY
+	// fp32 launch of such an engine takes this kernel, whatever its length: one form per CLI engine is what makes chunked and
+	// sharded sweeps bit-identical (the block grid starts at the call's first frame either way).
+	if (use_poly && n_part == 2 && inf.kind == PROT_KIND_CLI && inf.firlen == 8192 && inf.conv_delay == 0 && inf.dry_delay == 4096 &&
+	    !(cfg->flags & (PROT_CFG_BLOCK4096 | PROT_CFG_OVERLAP_ADD | PROT_CFG_POLYPHASE)) && tuning_env ("PROT_NO_SAVE8K") == nullptr) {
+		e->use_save8 = save_tables8k (fir_taps, sv8_h, e->sv8_gain);
+		if (e->use_save8) {
+			e->sv8_rows   = 8;
+			e->sv8_always = true;
+			inf.hop       = 8192;
+			inf.run_align = 8192;
+			inf.history   = std::max<uint32_t> (inf.history, 8192 + 256);
+			e->info.hop = inf.hop, e->info.run_align = inf.run_align, e->info.history = inf.history;
+			if (e->cus > 0 && tuning_env ("PROT_WG_PER_CU") == nullptr) {
+				e->wg_slots = e->cus * 2;
+			}
+		}
+	}
+	// The CLI's default engine at 88.2 / 96 kHz (blksiz 16384, cli/phase-rotate.cc:749-755): 8192 odd taps = 8 context rows of a
+	// 16384-POINT block -- ONE table-free partition, 16384 new frames per block, ONE launch (olasave16k_kernel, 1024-thread
+	// workgroups, one per CU) instead of two accumulating olapoly_kernel launches of two 2048-tap partitions each through a
+	// workspace in HBM.  Every fp32 launch of such an engine takes it (one form per CLI engine: chunked and sharded sweeps stay
+	// bit-identical); olapoly_kernel stays for its fp16 path and under the flags that ask for it.
+	if (use_poly && inf.kind == PROT_KIND_CLI && inf.firlen == 16384 && inf.conv_delay == 0 && inf.dry_delay == 8192 &&
+	    !(cfg->flags & (PROT_CFG_BLOCK4096 | PROT_CFG_OVERLAP_ADD | PROT_CFG_POLYPHASE)) && tuning_env ("PROT_NO_SAVE16K") == nullptr) {
+		e->use_save16 = save_tables16k (fir_taps, sv16_h, e->sv16_gain);
+		e->sv16_rows  = 8;
+		if (e->use_save16) {
+			inf.hop       = 16384;
+			inf.run_align = 16384;
+			inf.history   = std::max<uint32_t> (inf.history, 16384 + 256);
+			e->info.hop = inf.hop, e->info.run_align = inf.run_align, e->info.history = inf.history;
+			if (e->cus > 0 && tuning_env ("PROT_WG_PER_CU") == nullptr) {
+				e->wg_slots = e->cus;
+			}
+		}
+	}
+	// ... and the default at 44.1 / 48 kHz, blksiz 8192 (4096 odd taps = 4 context rows of a 16384-point block): 12 of 16 rows new
+	// (24576 frames per block) where the 8192-point block of round 4 has 8 of 16 -- a third less arithmetic per frame
+	if (e->use_save8 && e->sv8_always && e->sv8_rows == 8 && inf.kind == PROT_KIND_CLI && inf.firlen == 8192 && tuning_env ("PROT_NO_SAVE16K") == nullptr &&
+	    tuning_env ("PROT_NO_SAVE16K_8192") == nullptr) {
+		e->use_save16 = save_tables16k (fir_taps, sv16_h, e->sv16_gain);
+		if (e->use_save16) {
+			e->sv16_rows  = 12;
+			e->use_save8  = false;
+			e->sv8_always = false;
+			inf.hop       = 24576;
+			inf.run_align = 24576;
+			inf.history   = std::max<uint32_t> (inf.history, 8192 + 256);
+			e->info.hop = inf.hop, e->info.run_align = inf.run_align, e->info.history = inf.history;
+			if (e->cus > 0 && tuning_env ("PROT_WG_PER_CU") == nullptr) {
+				e->wg_slots = e->cus;
+			}
+		}
+	}
+	const char* pipe_env = tuning_env ("PROT_PIPELINE");
+	if (e->use_save && ((cfg->flags & PROT_CFG_PIPELINE) || (pipe_env && atoi (pipe_env) != 0)) && !(pipe_env && atoi (pipe_env) == 0)) {
+		// consecutive stateful prot_apply_dev calls on the engine's own streams overlap (DESIGN.md 4.1, cfg3)
+		bool ok = e->d_pipe.ensure (16) == PROT_OK && hipMemset (e->d_pipe.p, 0, 16 * sizeof (uint32_t)) == hipSuccess;
+		// (the engine's main stream is one of the three: the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware
+		// queues, 4 by default, and two pipe streams that share a queue do not overlap -- 10 us per launch instead of 5.5)
+		e->pipe_stream[0] = e->stream;
+		for (int i = 1; ok && i < prot_engine::kPipe; ++i) {
+			ok = hipStreamCreateWithFlags (&e->pipe_stream[i], hipStreamNonBlocking) == hipSuccess;
+		}
+		for (int i = 0; ok && i <= prot_engine::kPipe; ++i) {
+			ok = hipEventCreateWithFlags (&e->pipe_ev[i], hipEventDisableTiming) == hipSuccess;
+		}
+		if (!ok) {
+			return (PROT_EHIP);
+		}
+		e->pipeline = true;
+	}
+	return PROT_OK;
+}
+
+// spectra of the partitions, twiddles, every device buffer of the engine and their first contents
+static int upload_engine (prot_engine* e, const prot_config* cfg, EnginePlan& pl)
+{
+	prot_info&                 inf      = pl.inf;
+	const std::vector<float>&  fir_taps = pl.fir_taps;
+	const uint32_t             F        = pl.F;
+	const uint32_t             n_part = pl.n_part, part_len = pl.part_len;
+	const int                  hopseg   = pl.hopseg;
+	const bool                 use_p2 = pl.use_p2, use_poly = pl.use_poly;
+	(void)F, (void)n_part, (void)part_len, (void)hopseg, (void)use_p2, (void)use_poly, (void)fir_taps, (void)inf;
+	std::vector<float2>& H_h = pl.H_h;
+	std::vector<float2>& Hp_h = pl.Hp_h;
+	std::vector<float2>& tw_h = pl.tw_h;
+	const std::vector<float>& sv_h = pl.sv_h;
+	const std::vector<float>& sv8_h = pl.sv8_h;
+	const std::vector<float>& sv16_h = pl.sv16_h;
+	tw_h.resize (F);
+
+	// FIR -> spectrum / F (the 1/fftlen of the OLA c2r, cli/phase-rotate.cc:142,
+	// src/phaserotate.c:393, folded into the table)
+	e->fir      = fir_taps;
+	e->part_len = part_len;
+	// spectra / F of the partitions of `taps` (n partitions of plen taps)
+	auto spectra = [&] (const std::vector<float>& taps, uint32_t n, uint32_t plen, std::vector<float2>& dst) {
+		dst.assign ((size_t)F * n, make_float2 (0.f, 0.f));
+		for (uint32_t sp = 0; sp < n; ++sp) {
+			std::vector<double> re (F, 0.0), im (F, 0.0);
+			for (uint32_t i = 0; i < plen && (size_t)sp * plen + i < taps.size (); ++i) {
+				re[i] = taps[(size_t)sp * plen + i];
+			}
+			fft_f64 (re, im);
+			for (uint32_t k = 0; k < F; ++k) {
+				dst[(size_t)sp * F + k] = make_float2 ((float)(re[k] / F), (float)(im[k] / F));
+			}
+		}
+	};
+	if (use_poly) {
+		std::vector<float> g (inf.firlen / 2);
+		for (size_t i = 0; i < g.size (); ++i) {
+			g[i] = fir_taps[2 * i + 1];
+		}
+		spectra (g, n_part, part_len, H_h);
+	} else {
+		spectra (fir_taps, n_part, part_len, H_h);
+	}
+	// LV2 engines with the 4096-tap FIR run the direct form (faster per block), which needs TWO halo blocks
+	// per run; the polyphase form needs one.  For launches so short that a workgroup gets only a few blocks
+	// (run() buffers, batched buffers) the halo dominates, so those launches use the polyphase kernel --
+	// same filter, results equal to a rounding error.  fp32 launches of LV2 engines only: CLI engines keep one fp32
+	// form per engine, which is what makes sharded sweeps bit-identical whatever the shard sizes.  The fp16 sample
+	// path of every 4096-tap engine uses these tables too (prot_apply_dev_f16).
+	bool                poly_taps_ok = inf.firlen % 4 == 0 && inf.conv_delay % 2 == 0;
+	for (uint32_t i = 0; poly_taps_ok && i < inf.firlen; i += 2) {
+		poly_taps_ok = fir_taps[i] == 0.f;
+	}
+	if (use_p2 && !use_poly && inf.firlen == F && poly_taps_ok && (cfg->flags & ~PROT_CFG_PIPELINE) == 0 && tuning_env ("PROT_NO_POLY") == nullptr) {
+		std::vector<float> g (inf.firlen / 2);
+		for (size_t i = 0; i < g.size (); ++i) {
+			g[i] = fir_taps[2 * i + 1];
+		}
+		spectra (g, 1, F / 2, Hp_h);
+	}
+	for (uint32_t k = 0; k < F; ++k) {
+		const double a = -2.0 * M_PI * (double)k / (double)F;
+		tw_h[k] = make_float2 ((float)std::cos (a), (float)std::sin (a));
+	}
+	const size_t hn = (size_t)inf.history * inf.n_chn;
+	int rc;
+	if ((rc = e->d_H.ensure ((size_t)F * n_part)) ||
+	    (!Hp_h.empty () && (rc = e->d_Hp.ensure (Hp_h.size ()))) || (rc = e->d_tw.ensure (F)) || (rc = e->d_lut.ensure (PROT_MAXSAMPLE * 2)) ||
+	    (rc = e->d_rot.ensure (2 * (size_t)inf.n_chn)) || (rc = e->d_hist[0].ensure (hn)) || (rc = e->d_hist[2].ensure (hn)) || (rc = e->d_hist[3].ensure (hn)) ||
+	    (use_poly && ((rc = e->d_hist16[0].ensure (hn)) || (rc = e->d_hist16[1].ensure (hn)))) ||
+	    (rc = e->d_hist[1].ensure (hn)) || (rc = e->d_peaks.ensure ((size_t)PROT_MAXSAMPLE * inf.n_chn)) ||
+	    (rc = e->d_angles.ensure (PROT_MAXSAMPLE + 8)) || (rc = e->d_thr.ensure (prot::kSweepThrFloats * (size_t)inf.n_chn)) || (rc = e->d_ctr.ensure ((size_t)inf.n_chn * 32 * 32)) ||
+	    (rc = e->d_stats.ensure (4)) || (e->use_save && (rc = e->d_sv.ensure (sv_h.size ()))) ||
+	    (e->use_save8 && ((rc = e->d_sv8.ensure (sv8_h.size ())) || (rc = e->d_dyn.ensure ((size_t)prot_engine::kDynSets * inf.n_chn * prot::kDynWords)))) ||
+	    (e->use_save16 && (rc = e->d_sv16.ensure (sv16_h.size ())))) {
+		return (rc);
+	}
+	if (e->use_save16 && hipMemcpy (e->d_sv16.p, sv16_h.data (), sv16_h.size () * sizeof (float), hipMemcpyHostToDevice) != hipSuccess) {
+		return (PROT_EHIP);
+	}
+	if (e->use_save8 && hipMemset (e->d_dyn.p, 0, (size_t)prot_engine::kDynSets * inf.n_chn * prot::kDynWords * sizeof (uint32_t)) != hipSuccess) {
+		return (PROT_EHIP);
+	}
+	e->dyn_off = (cfg->flags & PROT_CFG_STATIC_RUNS) != 0 || tuning_env ("PROT_STATIC") != nullptr;
+	if (e->use_save8 && hipMemcpy (e->d_sv8.p, sv8_h.data (), sv8_h.size () * sizeof (float), hipMemcpyHostToDevice) != hipSuccess) {
+		return (PROT_EHIP);
+	}
+	if (e->use_save && hipMemcpy (e->d_sv.p, sv_h.data (), sv_h.size () * sizeof (float), hipMemcpyHostToDevice) != hipSuccess) {
+		return (PROT_EHIP);
+	}
+	e->info.form      = e->use_save16 ? PROT_FORM_POLY_SAVE16K : e->use_save8 ? PROT_FORM_POLY_SAVE8K : e->use_save ? PROT_FORM_POLY_SAVE : use_poly ? PROT_FORM_POLY_OLA : PROT_FORM_DIRECT;
+	e->info.wg_per_cu = e->cus > 0 ? (uint32_t)(e->wg_slots / e->cus) : 0;
+	if ((!Hp_h.empty () && hipMemcpy (e->d_Hp.p, Hp_h.data (), Hp_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess) ||
+	    hipMemcpy (e->d_H.p, H_h.data (), H_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemcpy (e->d_tw.p, tw_h.data (), F * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemcpy (e->d_lut.p, g_lut, sizeof (g_lut), hipMemcpyHostToDevice) != hipSuccess) {
+		return (PROT_EHIP);
+	}
+	if (hipMemset (e->d_thr.p, 0, prot::kSweepThrFloats * (size_t)inf.n_chn * sizeof (float)) != hipSuccess ||
+	    hipMemset (e->d_ctr.p, 0, (size_t)inf.n_chn * 32 * 32 * sizeof (unsigned)) != hipSuccess || zero_state (e) != PROT_OK ||
+	    hipStreamSynchronize (e->stream) != hipSuccess) {
+		return (PROT_EHIP);
+	}
+
+	return PROT_OK;
+}
+
+// LV2 engines: run()'s buffers, the run() server's mailbox and stream, the angle state machine
+static int setup_lv2 (prot_engine* e)
+{
+	const prot_info& inf = e->info;
+
+	if (inf.kind == PROT_KIND_LV2) {
+		e->h_io.coherent = true; // (the server reads and writes the port block while it is resident)
+		if (lv2_reserve (e, 8192) != PROT_OK) { // run() buffers up front; prot_lv2_set_max_block raises it
+			return (PROT_ENOMEM);
+		}
+		// the run() server: engines on the overlap-save kernel (both LV2 rates), up to 16 channels, not pipelined
+		if (e->use_poly && e->use_save && e->d_pipe.p == nullptr && inf.n_chn <= (uint32_t)prot::kServerMaxChn && (e->hopseg == 16 || e->hopseg == 20)) {
+			int lo = 0, hi = 0;
+			(void)hipDeviceGetStreamPriorityRange (&lo, &hi); // (hi = the numerically smallest = greatest priority)
+			e->srv_ack.coherent = true;
+			if (e->srv_ack.ensure (1) == PROT_OK && e->d_srv_relay.ensure (16) == PROT_OK &&
+			    hipStreamCreateWithPriority (&e->srv_stream, hipStreamNonBlocking, hi) == hipSuccess &&
+			    hipEventCreateWithFlags (&e->srv_ev, hipEventDisableTiming) == hipSuccess) {
+				memset (e->srv_ack.p, 0, sizeof (prot::SvServerAck));
+				e->srv_eligible = true;
+				if (lv2_reserve (e, 8192) != PROT_OK) { // (again, now with the mailbox)
+					return (PROT_ENOMEM);
+				}
+			}
+		}
+		e->interp_th = inf.blksiz * 1e-6f; // src/phaserotate.c:295
+		e->interp_nm = 1.f / inf.blksiz;   // :296
+		e->lv2.resize (inf.n_chn);
+		for (auto& c : e->lv2) {
+			c.rotq.assign ((size_t)inf.blksiz * 2, 0.f);
+			for (uint32_t i = 0; i < inf.blksiz; ++i) {
+				c.rotq[2 * i] = 1.f; // cos 0
+			}
+		}
+	}
+	return PROT_OK;
+}
+
+prot_engine* prot_engine_create (const prot_config* cfg, int* status)
+{
+	int  st_dummy;
+	int& st = status ? *status : st_dummy;
+	st      = PROT_OK;
+	g_err[0] = 0;
+	if (!cfg || cfg->n_chn < 1 || cfg->n_chn > 65535) {
+		st = PROT_EINVAL;
+		return nullptr;
+	}
+	std::call_once (g_lut_once, lut_init);
+	ServerHold srv_hold; // (engine creation allocates, uploads and synchronises: nothing resident until it returns)
+
+	EnginePlan pl;
+	pl.inf.kind  = cfg->kind;
+	pl.inf.n_chn = cfg->n_chn;
+	if ((st = plan_engine (cfg, pl)) != PROT_OK) {
+		return nullptr;
+	}
+	const prot_info& inf      = pl.inf;
+	const int        hopseg   = pl.hopseg;
+	const uint32_t   n_part   = pl.n_part;
+	const bool       use_p2 = pl.use_p2, use_poly = pl.use_poly;
 
 	int ndev = 0;
 	hipError_t he = hipGetDeviceCount (&ndev);
@@ -1589,241 +1896,9 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 		}
 	}
 
-	// FIR -> spectrum / F (the 1/fftlen of the OLA c2r, cli/phase-rotate.cc:142,
-	// src/phaserotate.c:393, folded into the table)
-	e->fir      = fir_taps;
-	e->part_len = part_len;
-	// spectra / F of the partitions of `taps` (n partitions of plen taps)
-	auto spectra = [&] (const std::vector<float>& taps, uint32_t n, uint32_t plen, std::vector<float2>& dst) {
-		dst.assign ((size_t)F * n, make_float2 (0.f, 0.f));
-		for (uint32_t sp = 0; sp < n; ++sp) {
-			std::vector<double> re (F, 0.0), im (F, 0.0);
-			for (uint32_t i = 0; i < plen && (size_t)sp * plen + i < taps.size (); ++i) {
-				re[i] = taps[(size_t)sp * plen + i];
-			}
-			fft_f64 (re, im);
-			for (uint32_t k = 0; k < F; ++k) {
-				dst[(size_t)sp * F + k] = make_float2 ((float)(re[k] / F), (float)(im[k] / F));
-			}
-		}
-	};
-	std::vector<float2> H_h, tw_h (F);
-	std::vector<float>  sv_h;
-	if (use_poly && n_part == 1 && !(cfg->flags & PROT_CFG_OVERLAP_ADD) && tuning_env ("PROT_NO_SAVE") == nullptr &&
-	    2 * (inf.dry_delay - inf.conv_delay) == 256 * (32 - (uint32_t)hopseg) && inf.dry_delay % 2 == 0) {
-		e->sv_flags = test_opt (PROT_TEST_EDGE_PATH_ONLY) ? 1 : 0; // (test hook: every block through the staged path)
-		e->use_save = hopseg <= 24 && save_tables (fir_taps, F, sv_h, e->sv_gain, e->sv_rows) && e->sv_rows == 1;
-		if (e->use_save && e->cus > 0 && tuning_env ("PROT_WG_PER_CU") == nullptr) {
-			e->wg_slots = e->cus * 4; // 128 VGPRs, 38 KiB of LDS
-		}
-	}
-	std::vector<float> sv8_h;
-	if (e->use_save && inf.kind == PROT_KIND_LV2 && !(cfg->flags & PROT_CFG_BLOCK4096) && (inf.firlen == 3072 || inf.firlen == 4096) &&
-	    tuning_env ("PROT_NO_SAVE8K") == nullptr) {
-		e->use_save8 = save_tables8k (fir_taps, sv8_h, e->sv8_gain);
-		e->sv8_rows  = 16 - (int)(inf.firlen / 1024);
-	}
-	// CLI blksiz 4096 (2048 odd taps = 4 context rows of an 8192-point block, 12288 new frames per block): every fp32 launch on
-	// these blocks, as for blksiz 8192 below (rotate 0.295 -> 0.27 ms, the fused sweep's Hilbert pass -20 %)
-	if (e->use_save && inf.kind == PROT_KIND_CLI && inf.firlen == 4096 && inf.conv_delay == 0 && inf.dry_delay == 2048 &&
-	    !(cfg->flags & (PROT_CFG_BLOCK4096 | PROT_CFG_OVERLAP_ADD | PROT_CFG_POLYPHASE)) && !(e->sv_flags & 1) && tuning_env ("PROT_NO_SAVE8K") == nullptr) {
-		e->use_save8 = save_tables8k (fir_taps, sv8_h, e->sv8_gain);
-		if (e->use_save8) {
-			e->sv8_rows   = 12;
-			e->sv8_always = true;
-			inf.hop       = 12288;
-			inf.run_align = 12288;
-			inf.history   = std::max<uint32_t> (inf.history, 4096 + 256);
-			e->info.hop = inf.hop, e->info.run_align = inf.run_align, e->info.history = inf.history;
-			if (e->cus > 0 && tuning_env ("PROT_WG_PER_CU") == nullptr) {
-				e->wg_slots = e->cus * 2;
-			}
-		}
-	}
-	// LV2 at 176.4 / 192 kHz (8192 taps = 8 context rows of an 8192-point block, one table-free partition): long launches only, like
-	// the other LV2 rates (shorter ones keep olapoly_kernel's two partitions on 4096-point transforms)
-	if (use_poly && n_part == 2 && inf.kind == PROT_KIND_LV2 && inf.firlen == 8192 && 2 * (inf.dry_delay - inf.conv_delay) == 8192 &&
-	    inf.dry_delay % 2 == 0 && inf.history >= inf.dry_delay + 4096 + 2 &&
-	    !(cfg->flags & (PROT_CFG_BLOCK4096 | PROT_CFG_OVERLAP_ADD | PROT_CFG_POLYPHASE)) && tuning_env ("PROT_NO_SAVE8K") == nullptr) {
-		e->use_save8 = save_tables8k (fir_taps, sv8_h, e->sv8_gain);
-		e->sv8_rows  = 8;
-	}
-	// The CLI's default engine at 44.1 / 48 kHz (blksiz 8192, cli/phase-rotate.cc:749-755): 4096 odd taps = 8 context rows of an
-	// 8192-point block -- ONE table-free partition, 8192 new frames per block, instead of two 2048-tap partitions with a spectrum
-	// table on 4096-point transforms (olapoly_kernel, which stays for the fp16 path and under the flags that ask for it).  EVERY
-	// fp32 launch of such an engine takes this kernel, whatever its length: one form per CLI engine is what makes chunked and
-	// sharded sweeps bit-identical (the block grid starts at the call's first frame either way).
-	if (use_poly && n_part == 2 && inf.kind == PROT_KIND_CLI && inf.firlen == 8192 && inf.conv_delay == 0 && inf.dry_delay == 4096 &&
-	    !(cfg->flags & (PROT_CFG_BLOCK4096 | PROT_CFG_OVERLAP_ADD | PROT_CFG_POLYPHASE)) && tuning_env ("PROT_NO_SAVE8K") == nullptr) {
-		e->use_save8 = save_tables8k (fir_taps, sv8_h, e->sv8_gain);
-		if (e->use_save8) {
-			e->sv8_rows   = 8;
-			e->sv8_always = true;
-			inf.hop       = 8192;
-			inf.run_align = 8192;
-			inf.history   = std::max<uint32_t> (inf.history, 8192 + 256);
-			e->info.hop = inf.hop, e->info.run_align = inf.run_align, e->info.history = inf.history;
-			if (e->cus > 0 && tuning_env ("PROT_WG_PER_CU") == nullptr) {
-				e->wg_slots = e->cus * 2;
-			}
-		}
-	}
-	// The CLI's default engine at 88.2 / 96 kHz (blksiz 16384, cli/phase-rotate.cc:749-755): 8192 odd taps = 8 context rows of a
-	// 16384-POINT block -- ONE table-free partition, 16384 new frames per block, ONE launch (olasave16k_kernel, 1024-thread
-	// workgroups, one per CU) instead of two accumulating olapoly_kernel launches of two 2048-tap partitions each through a
-	// workspace in HBM.  Every fp32 launch of such an engine takes it (one form per CLI engine: chunked and sharded sweeps stay
-	// bit-identical); olapoly_kernel stays for its fp16 path and under the flags that ask for it.
-	std::vector<float> sv16_h;
-	if (use_poly && inf.kind == PROT_KIND_CLI && inf.firlen == 16384 && inf.conv_delay == 0 && inf.dry_delay == 8192 &&
-	    !(cfg->flags & (PROT_CFG_BLOCK4096 | PROT_CFG_OVERLAP_ADD | PROT_CFG_POLYPHASE)) && tuning_env ("PROT_NO_SAVE16K") == nullptr) {
-		e->use_save16 = save_tables16k (fir_taps, sv16_h, e->sv16_gain);
-		e->sv16_rows  = 8;
-		if (e->use_save16) {
-			inf.hop       = 16384;
-			inf.run_align = 16384;
-			inf.history   = std::max<uint32_t> (inf.history, 16384 + 256);
-			e->info.hop = inf.hop, e->info.run_align = inf.run_align, e->info.history = inf.history;
-			if (e->cus > 0 && tuning_env ("PROT_WG_PER_CU") == nullptr) {
-				e->wg_slots = e->cus;
-			}
-		}
-	}
-	// ... and the default at 44.1 / 48 kHz, blksiz 8192 (4096 odd taps = 4 context rows of a 16384-point block): 12 of 16 rows new
-	// (24576 frames per block) where the 8192-point block of round 4 has 8 of 16 -- a third less arithmetic per frame
-	if (e->use_save8 && e->sv8_always && e->sv8_rows == 8 && inf.kind == PROT_KIND_CLI && inf.firlen == 8192 && tuning_env ("PROT_NO_SAVE16K") == nullptr &&
-	    tuning_env ("PROT_NO_SAVE16K_8192") == nullptr) {
-		e->use_save16 = save_tables16k (fir_taps, sv16_h, e->sv16_gain);
-		if (e->use_save16) {
-			e->sv16_rows  = 12;
-			e->use_save8  = false;
-			e->sv8_always = false;
-			inf.hop       = 24576;
-			inf.run_align = 24576;
-			inf.history   = std::max<uint32_t> (inf.history, 8192 + 256);
-			e->info.hop = inf.hop, e->info.run_align = inf.run_align, e->info.history = inf.history;
-			if (e->cus > 0 && tuning_env ("PROT_WG_PER_CU") == nullptr) {
-				e->wg_slots = e->cus;
-			}
-		}
-	}
-	const char* pipe_env = tuning_env ("PROT_PIPELINE");
-	if (e->use_save && ((cfg->flags & PROT_CFG_PIPELINE) || (pipe_env && atoi (pipe_env) != 0)) && !(pipe_env && atoi (pipe_env) == 0)) {
-		// consecutive stateful prot_apply_dev calls on the engine's own streams overlap (DESIGN.md 4.1, cfg3)
-		bool ok = e->d_pipe.ensure (16) == PROT_OK && hipMemset (e->d_pipe.p, 0, 16 * sizeof (uint32_t)) == hipSuccess;
-		// (the engine's main stream is one of the three: the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware
-		// queues, 4 by default, and two pipe streams that share a queue do not overlap -- 10 us per launch instead of 5.5)
-		e->pipe_stream[0] = e->stream;
-		for (int i = 1; ok && i < prot_engine::kPipe; ++i) {
-			ok = hipStreamCreateWithFlags (&e->pipe_stream[i], hipStreamNonBlocking) == hipSuccess;
-		}
-		for (int i = 0; ok && i <= prot_engine::kPipe; ++i) {
-			ok = hipEventCreateWithFlags (&e->pipe_ev[i], hipEventDisableTiming) == hipSuccess;
-		}
-		if (!ok) {
-			return fail (PROT_EHIP);
-		}
-		e->pipeline = true;
-	}
-	if (use_poly) {
-		std::vector<float> g (inf.firlen / 2);
-		for (size_t i = 0; i < g.size (); ++i) {
-			g[i] = fir_taps[2 * i + 1];
-		}
-		spectra (g, n_part, part_len, H_h);
-	} else {
-		spectra (fir_taps, n_part, part_len, H_h);
-	}
-	// LV2 engines with the 4096-tap FIR run the direct form (faster per block), which needs TWO halo blocks
-	// per run; the polyphase form needs one.  For launches so short that a workgroup gets only a few blocks
-	// (run() buffers, batched buffers) the halo dominates, so those launches use the polyphase kernel --
-	// same filter, results equal to a rounding error.  fp32 launches of LV2 engines only: CLI engines keep one fp32
-	// form per engine, which is what makes sharded sweeps bit-identical whatever the shard sizes.  The fp16 sample
-	// path of every 4096-tap engine uses these tables too (prot_apply_dev_f16).
-	std::vector<float2> Hp_h;
-	bool                poly_taps_ok = inf.firlen % 4 == 0 && inf.conv_delay % 2 == 0;
-	for (uint32_t i = 0; poly_taps_ok && i < inf.firlen; i += 2) {
-		poly_taps_ok = fir_taps[i] == 0.f;
-	}
-	if (use_p2 && !use_poly && inf.firlen == F && poly_taps_ok && (cfg->flags & ~PROT_CFG_PIPELINE) == 0 && tuning_env ("PROT_NO_POLY") == nullptr) {
-		std::vector<float> g (inf.firlen / 2);
-		for (size_t i = 0; i < g.size (); ++i) {
-			g[i] = fir_taps[2 * i + 1];
-		}
-		spectra (g, 1, F / 2, Hp_h);
-	}
-	for (uint32_t k = 0; k < F; ++k) {
-		const double a = -2.0 * M_PI * (double)k / (double)F;
-		tw_h[k] = make_float2 ((float)std::cos (a), (float)std::sin (a));
-	}
-	const size_t hn = (size_t)inf.history * inf.n_chn;
 	int rc;
-	if ((rc = e->d_H.ensure ((size_t)F * n_part)) ||
-	    (!Hp_h.empty () && (rc = e->d_Hp.ensure (Hp_h.size ()))) || (rc = e->d_tw.ensure (F)) || (rc = e->d_lut.ensure (PROT_MAXSAMPLE * 2)) ||
-	    (rc = e->d_rot.ensure (2 * (size_t)inf.n_chn)) || (rc = e->d_hist[0].ensure (hn)) || (rc = e->d_hist[2].ensure (hn)) || (rc = e->d_hist[3].ensure (hn)) ||
-	    (use_poly && ((rc = e->d_hist16[0].ensure (hn)) || (rc = e->d_hist16[1].ensure (hn)))) ||
-	    (rc = e->d_hist[1].ensure (hn)) || (rc = e->d_peaks.ensure ((size_t)PROT_MAXSAMPLE * inf.n_chn)) ||
-	    (rc = e->d_angles.ensure (PROT_MAXSAMPLE + 8)) || (rc = e->d_thr.ensure (prot::kSweepThrFloats * (size_t)inf.n_chn)) || (rc = e->d_ctr.ensure ((size_t)inf.n_chn * 32 * 32)) ||
-	    (rc = e->d_stats.ensure (4)) || (e->use_save && (rc = e->d_sv.ensure (sv_h.size ()))) ||
-	    (e->use_save8 && ((rc = e->d_sv8.ensure (sv8_h.size ())) || (rc = e->d_dyn.ensure ((size_t)prot_engine::kDynSets * inf.n_chn * prot::kDynWords)))) ||
-	    (e->use_save16 && (rc = e->d_sv16.ensure (sv16_h.size ())))) {
+	if ((rc = pick_block_kernels (e, cfg, pl)) || (rc = upload_engine (e, cfg, pl)) || (rc = setup_lv2 (e))) {
 		return fail (rc);
-	}
-	if (e->use_save16 && hipMemcpy (e->d_sv16.p, sv16_h.data (), sv16_h.size () * sizeof (float), hipMemcpyHostToDevice) != hipSuccess) {
-		return fail (PROT_EHIP);
-	}
-	if (e->use_save8 && hipMemset (e->d_dyn.p, 0, (size_t)prot_engine::kDynSets * inf.n_chn * prot::kDynWords * sizeof (uint32_t)) != hipSuccess) {
-		return fail (PROT_EHIP);
-	}
-	e->dyn_off = (cfg->flags & PROT_CFG_STATIC_RUNS) != 0 || tuning_env ("PROT_STATIC") != nullptr;
-	if (e->use_save8 && hipMemcpy (e->d_sv8.p, sv8_h.data (), sv8_h.size () * sizeof (float), hipMemcpyHostToDevice) != hipSuccess) {
-		return fail (PROT_EHIP);
-	}
-	if (e->use_save && hipMemcpy (e->d_sv.p, sv_h.data (), sv_h.size () * sizeof (float), hipMemcpyHostToDevice) != hipSuccess) {
-		return fail (PROT_EHIP);
-	}
-	e->info.form      = e->use_save16 ? PROT_FORM_POLY_SAVE16K : e->use_save8 ? PROT_FORM_POLY_SAVE8K : e->use_save ? PROT_FORM_POLY_SAVE : use_poly ? PROT_FORM_POLY_OLA : PROT_FORM_DIRECT;
-	e->info.wg_per_cu = e->cus > 0 ? (uint32_t)(e->wg_slots / e->cus) : 0;
-	if ((!Hp_h.empty () && hipMemcpy (e->d_Hp.p, Hp_h.data (), Hp_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess) ||
-	    hipMemcpy (e->d_H.p, H_h.data (), H_h.size () * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess ||
-	    hipMemcpy (e->d_tw.p, tw_h.data (), F * sizeof (float2), hipMemcpyHostToDevice) != hipSuccess ||
-	    hipMemcpy (e->d_lut.p, g_lut, sizeof (g_lut), hipMemcpyHostToDevice) != hipSuccess) {
-		return fail (PROT_EHIP);
-	}
-	if (hipMemset (e->d_thr.p, 0, prot::kSweepThrFloats * (size_t)inf.n_chn * sizeof (float)) != hipSuccess ||
-	    hipMemset (e->d_ctr.p, 0, (size_t)inf.n_chn * 32 * 32 * sizeof (unsigned)) != hipSuccess || zero_state (e) != PROT_OK ||
-	    hipStreamSynchronize (e->stream) != hipSuccess) {
-		return fail (PROT_EHIP);
-	}
-
-	if (inf.kind == PROT_KIND_LV2) {
-		e->h_io.coherent = true; // (the server reads and writes the port block while it is resident)
-		if (lv2_reserve (e, 8192) != PROT_OK) { // run() buffers up front; prot_lv2_set_max_block raises it
-			return fail (PROT_ENOMEM);
-		}
-		// the run() server: engines on the overlap-save kernel (both LV2 rates), up to 16 channels, not pipelined
-		if (e->use_poly && e->use_save && e->d_pipe.p == nullptr && inf.n_chn <= (uint32_t)prot::kServerMaxChn && (e->hopseg == 16 || e->hopseg == 20)) {
-			int lo = 0, hi = 0;
-			(void)hipDeviceGetStreamPriorityRange (&lo, &hi); // (hi = the numerically smallest = greatest priority)
-			e->srv_ack.coherent = true;
-			if (e->srv_ack.ensure (1) == PROT_OK && e->d_srv_relay.ensure (16) == PROT_OK &&
-			    hipStreamCreateWithPriority (&e->srv_stream, hipStreamNonBlocking, hi) == hipSuccess &&
-			    hipEventCreateWithFlags (&e->srv_ev, hipEventDisableTiming) == hipSuccess) {
-				memset (e->srv_ack.p, 0, sizeof (prot::SvServerAck));
-				e->srv_eligible = true;
-				if (lv2_reserve (e, 8192) != PROT_OK) { // (again, now with the mailbox)
-					return fail (PROT_ENOMEM);
-				}
-			}
-		}
-		e->interp_th = inf.blksiz * 1e-6f; // src/phaserotate.c:295
-		e->interp_nm = 1.f / inf.blksiz;   // :296
-		e->lv2.resize (inf.n_chn);
-		for (auto& c : e->lv2) {
-			c.rotq.assign ((size_t)inf.blksiz * 2, 0.f);
-			for (uint32_t i = 0; i < inf.blksiz; ++i) {
-				c.rotq[2 * i] = 1.f; // cos 0
-			}
-		}
 	}
 	e->h_peaks.assign ((size_t)PROT_MAXSAMPLE * inf.n_chn, 0.f);
 	{
@@ -2271,6 +2346,291 @@ int prot_apply_dev_f16_ramp (prot_engine* e, const void* d_in, int64_t in_stride
 
 // seed_blocks > 0: ONLY the seeding pass of the fused route over about that many blocks of the call (nothing of the engine's state
 // moves; a call the fused route does not take seeds nothing and returns PROT_OK)
+// one prot_sweep_dev call, as its three parts see it
+struct SweepCall {
+	const float* d_in;
+	int64_t      in_stride;
+	uint64_t     n_frames, n_out;
+	uint32_t     P;
+	bool         beg, end, raw0, fuse_poly;
+	int          c0, nc, n_ang, seed_blocks;
+	float*       pk;
+	const int*   lut_idx;
+	hipStream_t  s;
+};
+
+// FUSED (round 4): the sweep's test rides in the Hilbert pass (MODE_SWEEP: nothing but the surviving (d, h) pairs -- a few percent
+// of the frames -- is written), a seeding pass over a sparse sample of the call first when the table holds no bound yet, then plan ->
+// matrix-core evaluation of the lists -> merge; seed_blocks > 0: the seeding pass only (prot_sweep_seed_dev)
+static int sweep_fused (prot_engine* e, const SweepCall& k)
+{
+	const float* const d_in = k.d_in;
+	const int64_t      in_stride = k.in_stride;
+	const uint64_t     n_frames = k.n_frames, n_out = k.n_out;
+	const uint32_t     P = k.P;
+	const bool         beg = k.beg, end = k.end, raw0 = k.raw0;
+	const int          c0 = k.c0, nc = k.nc, n_ang = k.n_ang, seed_blocks = k.seed_blocks;
+	float* const       pk = k.pk;
+	const int* const   lut_idx = k.lut_idx;
+	hipStream_t        s = k.s;
+	int                rc = PROT_OK;
+	(void)beg, (void)end, (void)raw0, (void)c0, (void)nc, (void)n_ang, (void)seed_blocks, (void)pk, (void)lut_idx, (void)P, (void)n_frames, (void)d_in, (void)in_stride, (void)rc;
+	const bool fuse_poly = k.fuse_poly;
+	const float* hist_old = e->d_hist[e->hist_cur].p; (void)hist_old;
+	if (e->pos == 0 && !e->sweep_seeded_ext) {
+		e->sweep_seeded = false;
+	}
+	if (e->sweep_seeded_ext && seed_blocks == 0) { // the bound was seeded (and merged across shards) by the caller: two-phase sharded sweeps
+		e->sweep_seeded     = true;
+		e->sweep_seeded_ext = false;
+	}
+	int rc2;
+	const bool first_fused = e->d_fused_surv.p == nullptr;
+	// where the Hilbert launches write: nowhere (one launch: the overlap-save kernel lists only), or the workspace for the partial
+	// sums of the launches before the last
+	float*       f_out     = const_cast<float*> (d_in);
+	int64_t      f_ostride = in_stride;
+	if (fuse_poly) {
+		const size_t ustride = (size_t)((n_out + 255) & ~(uint64_t)255);
+		int          rcu     = e->d_u.ensure (ustride * e->info.n_chn);
+		if (rcu) {
+			return rcu;
+		}
+		f_out     = e->d_u.p;
+		f_ostride = (int64_t)ustride;
+	}
+	if ((rc2 = e->d_part.ensure (prot::sweep_scratch_floats ())) || (rc2 = e->d_fused_surv.ensure (1))) {
+		return rc2;
+	}
+	if (first_fused) {
+		HIP_TRY (hipMemsetAsync (e->d_fused_surv.p, 0, sizeof (unsigned long long), s));
+	}
+	// the bound is seeded from a sparse sample of the call: every k-th block, about 64 of them, at most every 8th
+	const uint64_t n_blocks    = n_out / (uint64_t)e->info.run_align;
+	const bool     sample_pass = seed_blocks > 0 || (!e->sweep_seeded && n_blocks >= 64);
+	auto fill = [&] (FusedSweep& fs, int pass) {
+		fs.peaks         = pk;
+		fs.angles        = e->d_angles.p;
+		fs.n_angles      = n_ang;
+		fs.raw_slot      = raw0 ? 0 : -1;
+		fs.raw_tail      = (raw0 && !end && pass == 1) ? 1 : 0;
+		fs.sample        = pass == 0;
+		fs.stride_blocks = (int)std::max<uint64_t> (8, n_blocks / 64); // (every 64th ... 512th block of an hour of material:
+		// the same times to the run-to-run spread; the bound hardly depends on it)
+		if (seed_blocks > 0) { // a shard's share of the sample (prot_sweep_seed_dev)
+			fs.stride_blocks = (int)std::max<uint64_t> (1, std::min<uint64_t> (n_blocks / (uint64_t)seed_blocks, (uint64_t)1 << 20));
+		}
+		if (const char* o = tuning_env ("PROT_FUSE_STRIDE")) {
+			fs.stride_blocks = std::max (2, atoi (o));
+		}
+		fs.t_begin       = beg ? P / 2 : 0; // :418-419
+		fs.dry_from      = beg ? P : 0;     // (local frames: the first block's dry term is the silent previous block, Q1)
+	};
+	{ // size the list buffers for both passes before anything is launched
+		size_t need_surv = 0, need_cnt = 0, need_desc = 0;
+		for (int pass = sample_pass ? 0 : 1; pass < 2; ++pass) {
+			FusedSweep fs {};
+			fill (fs, pass);
+			fs.plan_only = true;
+			rc = ola_launch (e, d_in, in_stride, n_frames, f_out, f_ostride, n_out, nullptr, nullptr, true, false, c0, nc, s, false, nullptr,
+			                 nullptr, &fs);
+			if (rc) {
+				return rc;
+			}
+			need_surv = std::max (need_surv, (size_t)fs.n_lists * fs.cap * nc + 2048);
+			need_cnt  = std::max (need_cnt, 2 * (size_t)fs.n_lists * nc);
+			need_desc = std::max (need_desc, ((size_t)fs.n_lists + (size_t)(n_out / 1024) + 8) * nc);
+		}
+		if ((rc2 = e->d_surv.ensure (need_surv)) || (rc2 = e->d_surv_cnt.ensure (need_cnt)) || (rc2 = e->d_desc.ensure (need_desc)) ||
+		    (rc2 = e->d_nsteps.ensure ((size_t)e->info.n_chn))) {
+			return rc2;
+		}
+	}
+	for (int pass = sample_pass ? 0 : 1; pass < (seed_blocks > 0 ? 1 : 2); ++pass) {
+		FusedSweep fs {};
+		fill (fs, pass);
+		rc = ola_launch (e, d_in, in_stride, n_frames, f_out, f_ostride, n_out, nullptr, nullptr, true, false, c0, nc, s,
+		                 /*advance_hist*/ pass == 1, nullptr, nullptr, &fs);
+		if (rc) {
+			return rc;
+		}
+		e->last_n_lists = fs.n_lists;
+		e->last_cap     = fs.cap;
+		if (pass == 0 && test_opt (PROT_TEST_SEED_MFMA) == 0) {
+			// the seeding pass's lists: a lower bound is all they have to give (prot_sweep.hip: sweep_seed_eval_kernel)
+			hipError_t err0 = prot::launch_sweep_seed_eval (e->d_surv.p, e->d_surv_cnt.p, fs.n_lists, fs.cap, e->d_angles.p, n_ang, e->d_lut.p, pk, c0, nc,
+			                                                e->d_part.p, prot::sweep_scratch_floats (), s);
+			if (err0 == hipSuccess) {
+				continue;
+			}
+			if (err0 != hipErrorInvalidValue) { // (InvalidValue: more lists than the scratch table holds -- the matrix-core route below)
+				return hip_fail (err0, "sweep seed evaluation launch");
+			}
+		}
+		const int64_t desc_stride = (int64_t)fs.n_lists + (int64_t)(n_out / 1024) + 8;
+		hipError_t    err = prot::launch_sweep_plan (e->d_surv_cnt.p, fs.n_lists, fs.cap, e->d_desc.p, desc_stride, e->d_nsteps.p, nc,
+		                                             pass == 1 ? e->d_fused_surv.p : nullptr, s);
+		if (err != hipSuccess) {
+			return hip_fail (err, "sweep plan launch");
+		}
+		prot::SweepParams sp {};
+		sp.surv        = e->d_surv.p;
+		sp.desc        = e->d_desc.p;
+		sp.desc_stride = desc_stride;
+		sp.n_steps     = e->d_nsteps.p;
+		sp.t_begin     = 0;
+		sp.t_end       = pass == 0 ? (int64_t)((n_out / ((uint64_t)fs.stride_blocks * e->info.run_align) + 1) * e->info.run_align) : (int64_t)n_out;
+		sp.angles      = e->d_angles.p;
+		sp.n_angles    = n_ang;
+		sp.lut         = e->d_lut.p;
+		sp.peaks       = pk;
+		sp.chn0        = c0;
+		sp.prune       = 1;
+		sp.thr         = e->d_thr.p;
+		sp.thr_blk     = e->d_thr.p + 4 * (size_t)e->info.n_chn;
+		sp.angles_host = lut_idx;
+		sp.stats       = e->d_stats.p;
+		sp.ctr         = e->d_ctr.p;
+		sp.part        = e->d_part.p;
+		sp.part_floats = prot::sweep_scratch_floats ();
+		sp.raw_slot    = -1; // (the raw peak went into the table from the fused pass)
+		err            = prot::launch_sweep (sp, nc, s);
+		if (err != hipSuccess) {
+			(void)hipMemsetAsync (e->d_thr.p, 0, prot::kSweepThrFloats * (size_t)e->info.n_chn * sizeof (float), s);
+			(void)hipMemsetAsync (e->d_ctr.p, 0, (size_t)e->info.n_chn * 32 * 32 * sizeof (unsigned), s);
+			return hip_fail (err, "sweep kernel launch (lists)");
+		}
+	}
+	if (seed_blocks > 0) {
+		e->sweep_seeded_ext = true;
+		return PROT_OK;
+	}
+	e->sweep_seeded = true;
+	e->fused_frames += n_out * (uint64_t)nc;
+	return PROT_OK;
+}
+
+// the separate passes (short calls, unpruned sweeps, engines without a listing kernel): Hilbert branch to the workspace, then
+// sweep_kernel over input and workspace
+static int sweep_separate (prot_engine* e, const SweepCall& k)
+{
+	const float* const d_in = k.d_in;
+	const int64_t      in_stride = k.in_stride;
+	const uint64_t     n_frames = k.n_frames, n_out = k.n_out;
+	const uint32_t     P = k.P;
+	const bool         beg = k.beg, end = k.end, raw0 = k.raw0;
+	const int          c0 = k.c0, nc = k.nc, n_ang = k.n_ang, seed_blocks = k.seed_blocks;
+	float* const       pk = k.pk;
+	const int* const   lut_idx = k.lut_idx;
+	hipStream_t        s = k.s;
+	int                rc = PROT_OK;
+	(void)beg, (void)end, (void)raw0, (void)c0, (void)nc, (void)n_ang, (void)seed_blocks, (void)pk, (void)lut_idx, (void)P, (void)n_frames, (void)d_in, (void)in_stride, (void)rc;
+	const bool unpruned = test_opt (PROT_TEST_SWEEP_UNPRUNED) != 0;
+	// 1. Hilbert branch u[t], t in [0, n_out)
+	const size_t ustride = (size_t)((n_out + 255) & ~(uint64_t)255);
+	rc = e->d_u.ensure (ustride * e->info.n_chn);
+	if (rc) {
+		return rc;
+	}
+	const float* hist_old = e->d_hist[e->hist_cur].p; // stays intact: the launch writes the next buffer of the ring
+	// (the launch also advances the input history -- fused into the kernel when all channels are swept, a small launch behind
+	// it otherwise: state step 4 of the reference, the reference has consumed the data blocks; the sweep below still reads
+	// the buffer of the ring that was current on entry)
+	rc = ola_launch (e, d_in, in_stride, n_frames, e->d_u.p, (int64_t)ustride, n_out, nullptr, nullptr, true,
+	                 false, c0, nc, s, /*advance_hist*/ true);
+	if (rc) {
+		return rc;
+	}
+	// 2. rotated peaks
+	if (n_ang > 0) {
+		prot::SweepParams sp {};
+		sp.x        = d_in;
+		sp.x_stride = in_stride;
+		sp.n_x      = (int64_t)n_frames;
+		sp.hist     = hist_old;
+		sp.hist_len = (int)e->info.history;
+		sp.u        = e->d_u.p;
+		sp.u_stride = (int64_t)ustride;
+		sp.t_begin  = beg ? P / 2 : 0;               // :418-419: first block looks at hil[firlen..parsiz) only
+		sp.t_end    = (int64_t)n_out;
+		sp.t_abs0   = (int64_t)e->pos;
+		sp.dry_from = beg ? (int64_t)e->pos + P : 0; // ... paired with the (silent) previous block
+		sp.delay    = (int)P / 2;
+		sp.angles   = e->d_angles.p;
+		sp.n_angles = n_ang;
+		sp.lut      = e->d_lut.p;
+		sp.peaks    = pk;
+		sp.chn0     = c0;
+		sp.prune       = unpruned ? 0 : 1; // exact either way; the unpruned sweep is for timing and tests (prot_internal.h)
+		sp.thr         = e->d_thr.p;
+		sp.stats       = e->d_stats.p;
+		if ((rc = e->d_part.ensure (prot::sweep_scratch_floats ())) != PROT_OK) {
+			return rc;
+		}
+		sp.ctr         = e->d_ctr.p;
+		sp.part        = e->d_part.p;
+		sp.part_floats = prot::sweep_scratch_floats ();
+		sp.raw_slot    = raw0 ? 0 : -1; // the raw peak rides along with the sweep (no pass of its own over the input)
+		sp.raw_tail    = (raw0 && !end) ? 1 : 0; // ... and is complete for this call's frames when the call returns (ADVICE r3)
+		// bounds are per launch: they refer to THIS call's angle set
+		// (p.thr is all zeros here: zeroed once when the engine was created, and again by every launch's merge kernel)
+		hipError_t err = prot::launch_sweep (sp, nc, s);
+		if (err != hipSuccess) {
+			// the launch may have died between the sweep and its merge kernel: the shared bounds and step counters are
+			// not known to be zero any more
+			(void)hipMemsetAsync (e->d_thr.p, 0, prot::kSweepThrFloats * (size_t)e->info.n_chn * sizeof (float), s);
+			(void)hipMemsetAsync (e->d_ctr.p, 0, (size_t)e->info.n_chn * 32 * 32 * sizeof (unsigned), s);
+			return hip_fail (err, "sweep kernel launch");
+		}
+	}
+	// 3. angle 0: raw peak of the (un-delayed) blocks -- on its own only when no other angle was asked for
+	if (raw0 && n_ang == 0) {
+		hipError_t err = prot::launch_absmax (d_in, in_stride, (int64_t)n_frames, pk, 0, c0, nc, s);
+		if (err != hipSuccess) {
+			return hip_fail (err, "absmax kernel launch");
+		}
+	}
+	return PROT_OK;
+}
+
+// the padding / flush frames of a call are silence that also entered the history
+static int sweep_pad_history (prot_engine* e, const SweepCall& k)
+{
+	const float* const d_in = k.d_in;
+	const int64_t      in_stride = k.in_stride;
+	const uint64_t     n_frames = k.n_frames, n_out = k.n_out;
+	const uint32_t     P = k.P;
+	const bool         beg = k.beg, end = k.end, raw0 = k.raw0;
+	const int          c0 = k.c0, nc = k.nc, n_ang = k.n_ang, seed_blocks = k.seed_blocks;
+	float* const       pk = k.pk;
+	const int* const   lut_idx = k.lut_idx;
+	hipStream_t        s = k.s;
+	int                rc = PROT_OK;
+	(void)beg, (void)end, (void)raw0, (void)c0, (void)nc, (void)n_ang, (void)seed_blocks, (void)pk, (void)lut_idx, (void)P, (void)n_frames, (void)d_in, (void)in_stride, (void)rc;
+	// 4. state: the reference has consumed nb blocks (zero padding included): the data frames went into the history with
+	// the Hilbert launch above
+	if (n_out > n_frames) {
+		// padding/flush frames are silence that also entered the history
+		const uint64_t extra = n_out - n_frames;
+		// shift history by `extra` frames of silence
+		const int    H    = (int)e->info.history;
+		const int    cur  = e->hist_cur;
+		const float* hin  = e->d_hist[cur].p;
+		float*       hout = e->d_hist[(cur + 1) % prot_engine::kHist].p;
+		if (nc != (int)e->info.n_chn) {
+			HIP_TRY (hipMemcpyAsync (hout, hin, (size_t)H * e->info.n_chn * sizeof (float), hipMemcpyDeviceToDevice, s));
+		}
+		// (one small launch: hout[c][i] = [hin | silence](extra + i), the input being empty)
+		hipError_t herr = prot::launch_hist_update (hin + (size_t)c0 * H, (int64_t)H, 0, hin + (size_t)c0 * H, hout + (size_t)c0 * H, H, nc, s,
+		                                            (int64_t)std::min<uint64_t> (extra, (uint64_t)H));
+		if (herr != hipSuccess) {
+			return hip_fail (herr, "history shift launch");
+		}
+		e->hist_cur = (cur + 1) % prot_engine::kHist;
+	}
+	return PROT_OK;
+}
+
 static int sweep_dev_impl (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_frames, int ang_start,
                            int ang_end, int ang_stride, int chn, float* d_peaks, uint32_t flags, void* stream, int seed_blocks)
 {
@@ -2358,233 +2718,18 @@ static int sweep_dev_impl (prot_engine* e, const float* d_in, int64_t in_stride,
 		e->angles_stream = s;
 		e->sweep_seeded  = false;
 	}
-	const bool unpruned = test_opt (PROT_TEST_SWEEP_UNPRUNED) != 0;
-	// FUSED (round 4): the sweep's test rides in the Hilbert pass (olasave_kernel MODE_SWEEP: nothing but the surviving (d, h)
-	// pairs -- a few percent of the frames -- is written), the matrix-core kernel evaluates the lists.  For the engines whose
-	// Hilbert pass is the overlap-save kernel (blksiz 2048, 4096), pruned sweeps, calls long enough to carry five more launches;
-	// the tables are bit-identical to the separate passes' (same blocks, same arithmetic per frame, max is order-free).
-	const bool fused = fusable && n_ang > 0 && n_out >= ((uint64_t)1 << 20);
+	const bool fused = fusable && n_ang > 0 && n_out >= ((uint64_t)1 << 20); // (calls long enough to carry five more launches)
 	if (seed_blocks > 0 && !fused) {
 		return PROT_OK;
 	}
-	if (fused) {
-		const float* hist_old = e->d_hist[e->hist_cur].p; (void)hist_old;
-		if (e->pos == 0 && !e->sweep_seeded_ext) {
-			e->sweep_seeded = false;
-		}
-		if (e->sweep_seeded_ext && seed_blocks == 0) { // the bound was seeded (and merged across shards) by the caller: two-phase sharded sweeps
-			e->sweep_seeded     = true;
-			e->sweep_seeded_ext = false;
-		}
-		int rc2;
-		const bool first_fused = e->d_fused_surv.p == nullptr;
-		// where the Hilbert launches write: nowhere (one launch: the overlap-save kernel lists only), or the workspace for the partial
-		// sums of the launches before the last
-		float*       f_out     = const_cast<float*> (d_in);
-		int64_t      f_ostride = in_stride;
-		if (fuse_poly) {
-			const size_t ustride = (size_t)((n_out + 255) & ~(uint64_t)255);
-			int          rcu     = e->d_u.ensure (ustride * e->info.n_chn);
-			if (rcu) {
-				return rcu;
-			}
-			f_out     = e->d_u.p;
-			f_ostride = (int64_t)ustride;
-		}
-		if ((rc2 = e->d_part.ensure (prot::sweep_scratch_floats ())) || (rc2 = e->d_fused_surv.ensure (1))) {
-			return rc2;
-		}
-		if (first_fused) {
-			HIP_TRY (hipMemsetAsync (e->d_fused_surv.p, 0, sizeof (unsigned long long), s));
-		}
-		// the bound is seeded from a sparse sample of the call: every k-th block, about 64 of them, at most every 8th
-		const uint64_t n_blocks    = n_out / (uint64_t)e->info.run_align;
-		const bool     sample_pass = seed_blocks > 0 || (!e->sweep_seeded && n_blocks >= 64);
-		auto fill = [&] (FusedSweep& fs, int pass) {
-			fs.peaks         = pk;
-			fs.angles        = e->d_angles.p;
-			fs.n_angles      = n_ang;
-			fs.raw_slot      = raw0 ? 0 : -1;
-			fs.raw_tail      = (raw0 && !end && pass == 1) ? 1 : 0;
-			fs.sample        = pass == 0;
-			fs.stride_blocks = (int)std::max<uint64_t> (8, n_blocks / 64); // (every 64th ... 512th block of an hour of material:
-			// the same times to the run-to-run spread; the bound hardly depends on it)
-			if (seed_blocks > 0) { // a shard's share of the sample (prot_sweep_seed_dev)
-				fs.stride_blocks = (int)std::max<uint64_t> (1, std::min<uint64_t> (n_blocks / (uint64_t)seed_blocks, (uint64_t)1 << 20));
-			}
-			if (const char* o = tuning_env ("PROT_FUSE_STRIDE")) {
-				fs.stride_blocks = std::max (2, atoi (o));
-			}
-			fs.t_begin       = beg ? P / 2 : 0; // :418-419
-			fs.dry_from      = beg ? P : 0;     // (local frames: the first block's dry term is the silent previous block, Q1)
-		};
-		{ // size the list buffers for both passes before anything is launched
-			size_t need_surv = 0, need_cnt = 0, need_desc = 0;
-			for (int pass = sample_pass ? 0 : 1; pass < 2; ++pass) {
-				FusedSweep fs {};
-				fill (fs, pass);
-				fs.plan_only = true;
-				rc = ola_launch (e, d_in, in_stride, n_frames, f_out, f_ostride, n_out, nullptr, nullptr, true, false, c0, nc, s, false, nullptr,
-				                 nullptr, &fs);
-				if (rc) {
-					return rc;
-				}
-				need_surv = std::max (need_surv, (size_t)fs.n_lists * fs.cap * nc + 2048);
-				need_cnt  = std::max (need_cnt, 2 * (size_t)fs.n_lists * nc);
-				need_desc = std::max (need_desc, ((size_t)fs.n_lists + (size_t)(n_out / 1024) + 8) * nc);
-			}
-			if ((rc2 = e->d_surv.ensure (need_surv)) || (rc2 = e->d_surv_cnt.ensure (need_cnt)) || (rc2 = e->d_desc.ensure (need_desc)) ||
-			    (rc2 = e->d_nsteps.ensure ((size_t)e->info.n_chn))) {
-				return rc2;
-			}
-		}
-		for (int pass = sample_pass ? 0 : 1; pass < (seed_blocks > 0 ? 1 : 2); ++pass) {
-			FusedSweep fs {};
-			fill (fs, pass);
-			rc = ola_launch (e, d_in, in_stride, n_frames, f_out, f_ostride, n_out, nullptr, nullptr, true, false, c0, nc, s,
-			                 /*advance_hist*/ pass == 1, nullptr, nullptr, &fs);
-			if (rc) {
-				return rc;
-			}
-			e->last_n_lists = fs.n_lists;
-			e->last_cap     = fs.cap;
-			if (pass == 0 && test_opt (PROT_TEST_SEED_MFMA) == 0) {
-				// the seeding pass's lists: a lower bound is all they have to give (prot_sweep.hip: sweep_seed_eval_kernel)
-				hipError_t err0 = prot::launch_sweep_seed_eval (e->d_surv.p, e->d_surv_cnt.p, fs.n_lists, fs.cap, e->d_angles.p, n_ang, e->d_lut.p, pk, c0, nc,
-				                                                e->d_part.p, prot::sweep_scratch_floats (), s);
-				if (err0 == hipSuccess) {
-					continue;
-				}
-				if (err0 != hipErrorInvalidValue) { // (InvalidValue: more lists than the scratch table holds -- the matrix-core route below)
-					return hip_fail (err0, "sweep seed evaluation launch");
-				}
-			}
-			const int64_t desc_stride = (int64_t)fs.n_lists + (int64_t)(n_out / 1024) + 8;
-			hipError_t    err = prot::launch_sweep_plan (e->d_surv_cnt.p, fs.n_lists, fs.cap, e->d_desc.p, desc_stride, e->d_nsteps.p, nc,
-			                                             pass == 1 ? e->d_fused_surv.p : nullptr, s);
-			if (err != hipSuccess) {
-				return hip_fail (err, "sweep plan launch");
-			}
-			prot::SweepParams sp {};
-			sp.surv        = e->d_surv.p;
-			sp.desc        = e->d_desc.p;
-			sp.desc_stride = desc_stride;
-			sp.n_steps     = e->d_nsteps.p;
-			sp.t_begin     = 0;
-			sp.t_end       = pass == 0 ? (int64_t)((n_out / ((uint64_t)fs.stride_blocks * e->info.run_align) + 1) * e->info.run_align) : (int64_t)n_out;
-			sp.angles      = e->d_angles.p;
-			sp.n_angles    = n_ang;
-			sp.lut         = e->d_lut.p;
-			sp.peaks       = pk;
-			sp.chn0        = c0;
-			sp.prune       = 1;
-			sp.thr         = e->d_thr.p;
-			sp.thr_blk     = e->d_thr.p + 4 * (size_t)e->info.n_chn;
-			sp.angles_host = lut_idx;
-			sp.stats       = e->d_stats.p;
-			sp.ctr         = e->d_ctr.p;
-			sp.part        = e->d_part.p;
-			sp.part_floats = prot::sweep_scratch_floats ();
-			sp.raw_slot    = -1; // (the raw peak went into the table from the fused pass)
-			err            = prot::launch_sweep (sp, nc, s);
-			if (err != hipSuccess) {
-				(void)hipMemsetAsync (e->d_thr.p, 0, prot::kSweepThrFloats * (size_t)e->info.n_chn * sizeof (float), s);
-				(void)hipMemsetAsync (e->d_ctr.p, 0, (size_t)e->info.n_chn * 32 * 32 * sizeof (unsigned), s);
-				return hip_fail (err, "sweep kernel launch (lists)");
-			}
-		}
-		if (seed_blocks > 0) {
-			e->sweep_seeded_ext = true;
-			return PROT_OK;
-		}
-		e->sweep_seeded = true;
-		e->fused_frames += n_out * (uint64_t)nc;
-	} else {
-	// 1. Hilbert branch u[t], t in [0, n_out)
-	const size_t ustride = (size_t)((n_out + 255) & ~(uint64_t)255);
-	rc = e->d_u.ensure (ustride * e->info.n_chn);
-	if (rc) {
+	const SweepCall k { d_in, in_stride, n_frames, n_out, P, beg, end, raw0, fuse_poly, c0, nc, n_ang, seed_blocks, pk, lut_idx, s };
+	rc = fused ? sweep_fused (e, k) : sweep_separate (e, k);
+	if (rc || seed_blocks > 0) {
 		return rc;
 	}
-	const float* hist_old = e->d_hist[e->hist_cur].p; // stays intact: the launch writes the next buffer of the ring
-	// (the launch also advances the input history -- fused into the kernel when all channels are swept, a small launch behind
-	// it otherwise: state step 4 of the reference, the reference has consumed the data blocks; the sweep below still reads
-	// the buffer of the ring that was current on entry)
-	rc = ola_launch (e, d_in, in_stride, n_frames, e->d_u.p, (int64_t)ustride, n_out, nullptr, nullptr, true,
-	                 false, c0, nc, s, /*advance_hist*/ true);
-	if (rc) {
+	// state: the reference has consumed nb blocks (zero padding included): the data frames went into the history with the Hilbert launch
+	if ((rc = sweep_pad_history (e, k)) != PROT_OK) {
 		return rc;
-	}
-	// 2. rotated peaks
-	if (n_ang > 0) {
-		prot::SweepParams sp {};
-		sp.x        = d_in;
-		sp.x_stride = in_stride;
-		sp.n_x      = (int64_t)n_frames;
-		sp.hist     = hist_old;
-		sp.hist_len = (int)e->info.history;
-		sp.u        = e->d_u.p;
-		sp.u_stride = (int64_t)ustride;
-		sp.t_begin  = beg ? P / 2 : 0;               // :418-419: first block looks at hil[firlen..parsiz) only
-		sp.t_end    = (int64_t)n_out;
-		sp.t_abs0   = (int64_t)e->pos;
-		sp.dry_from = beg ? (int64_t)e->pos + P : 0; // ... paired with the (silent) previous block
-		sp.delay    = (int)P / 2;
-		sp.angles   = e->d_angles.p;
-		sp.n_angles = n_ang;
-		sp.lut      = e->d_lut.p;
-		sp.peaks    = pk;
-		sp.chn0     = c0;
-		sp.prune       = unpruned ? 0 : 1; // exact either way; the unpruned sweep is for timing and tests (prot_internal.h)
-		sp.thr         = e->d_thr.p;
-		sp.stats       = e->d_stats.p;
-		if ((rc = e->d_part.ensure (prot::sweep_scratch_floats ())) != PROT_OK) {
-			return rc;
-		}
-		sp.ctr         = e->d_ctr.p;
-		sp.part        = e->d_part.p;
-		sp.part_floats = prot::sweep_scratch_floats ();
-		sp.raw_slot    = raw0 ? 0 : -1; // the raw peak rides along with the sweep (no pass of its own over the input)
-		sp.raw_tail    = (raw0 && !end) ? 1 : 0; // ... and is complete for this call's frames when the call returns (ADVICE r3)
-		// bounds are per launch: they refer to THIS call's angle set
-		// (p.thr is all zeros here: zeroed once when the engine was created, and again by every launch's merge kernel)
-		hipError_t err = prot::launch_sweep (sp, nc, s);
-		if (err != hipSuccess) {
-			// the launch may have died between the sweep and its merge kernel: the shared bounds and step counters are
-			// not known to be zero any more
-			(void)hipMemsetAsync (e->d_thr.p, 0, prot::kSweepThrFloats * (size_t)e->info.n_chn * sizeof (float), s);
-			(void)hipMemsetAsync (e->d_ctr.p, 0, (size_t)e->info.n_chn * 32 * 32 * sizeof (unsigned), s);
-			return hip_fail (err, "sweep kernel launch");
-		}
-	}
-	// 3. angle 0: raw peak of the (un-delayed) blocks -- on its own only when no other angle was asked for
-	if (raw0 && n_ang == 0) {
-		hipError_t err = prot::launch_absmax (d_in, in_stride, (int64_t)n_frames, pk, 0, c0, nc, s);
-		if (err != hipSuccess) {
-			return hip_fail (err, "absmax kernel launch");
-		}
-	}
-	}
-	// 4. state: the reference has consumed nb blocks (zero padding included): the data frames went into the history with
-	// the Hilbert launch above
-	if (n_out > n_frames) {
-		// padding/flush frames are silence that also entered the history
-		const uint64_t extra = n_out - n_frames;
-		// shift history by `extra` frames of silence
-		const int    H    = (int)e->info.history;
-		const int    cur  = e->hist_cur;
-		const float* hin  = e->d_hist[cur].p;
-		float*       hout = e->d_hist[(cur + 1) % prot_engine::kHist].p;
-		if (nc != (int)e->info.n_chn) {
-			HIP_TRY (hipMemcpyAsync (hout, hin, (size_t)H * e->info.n_chn * sizeof (float), hipMemcpyDeviceToDevice, s));
-		}
-		// (one small launch: hout[c][i] = [hin | silence](extra + i), the input being empty)
-		hipError_t herr = prot::launch_hist_update (hin + (size_t)c0 * H, (int64_t)H, 0, hin + (size_t)c0 * H, hout + (size_t)c0 * H, H, nc, s,
-		                                            (int64_t)std::min<uint64_t> (extra, (uint64_t)H));
-		if (herr != hipSuccess) {
-			return hip_fail (herr, "history shift launch");
-		}
-		e->hist_cur = (cur + 1) % prot_engine::kHist;
 	}
 	e->pos += n_out;
 	return PROT_OK;
