@@ -3464,15 +3464,20 @@ int prot_allreduce_peaks (prot_engine* const* engines, int n)
 			distinct = distinct && engines[k]->device != engines[i]->device;
 		}
 	}
-	if (n == 1) {
-		return PROT_OK;
-	}
 	// PROT_ALLREDUCE=host: merge through the host even on distinct devices; =rccl: take the collective even when the
 	// engines share a device (only meaningful with a stand-in library: real RCCL wants one rank per device)
-	const int   mode      = test_opt (PROT_TEST_ALLREDUCE); // (prot_internal.h: 1 = through the host, 2 = the collective even on one device)
+	const int   mode      = test_opt (PROT_TEST_ALLREDUCE); // (prot_internal.h: 1 = through the host, 2 = the collective even on one device,
+	                                                        // 3 = ... and even for ONE engine: the real library on a one-GPU box)
+	if (n == 1 && mode != 3) {
+		return PROT_OK;
+	}
 	const bool  want_host = mode == 1;
-	const bool  force     = mode == 2;
+	const bool  force     = mode == 2 || mode == 3;
 	std::lock_guard<std::mutex> lk (g_rccl_lock);
+	if (mode == 3 && !g_rccl.load ()) {
+		snprintf (g_err, sizeof (g_err), "no RCCL library could be loaded");
+		return PROT_EUNSUPPORTED;
+	}
 	if ((distinct || force) && !want_host && g_rccl.load ()) {
 		std::vector<int> devs (n);
 		for (int i = 0; i < n; ++i) {

@@ -12,7 +12,7 @@ enum {
 	PROT_TEST_SWEEP_UNPRUNED = 0, // != 0: prot_sweep_dev launches the unpruned sweep kernel (bit-identical tables; timing and tests)
 	PROT_TEST_EDGE_PATH_ONLY = 1, // != 0: engines created from now on run every overlap-save block through the staged (edge) path
 	PROT_TEST_LV2_STAGED     = 2, // != 0: prot_lv2_run copies its buffers through staging memory whatever their size
-	PROT_TEST_ALLREDUCE      = 3, // 0 automatic; 1 merge through the host; 2 the RCCL collective even when engines share a device
+	PROT_TEST_ALLREDUCE      = 3, // 0 automatic; 1 merge through the host; 2 the RCCL collective even when engines share a device; 3 ... and for one engine
 	PROT_TEST_SWEEP_UNFUSED  = 4, // != 0: prot_sweep_dev keeps the separate Hilbert and sweep passes where it would fuse them (bit-identical tables)
 	PROT_TEST_LV2_NO_SERVER  = 5, // != 0: prot_lv2_run launches every call (no resident server kernel)
 	PROT_TEST_LV2_NO_BAR     = 6, // != 0: engines created from now on keep the run() server's mailbox in pinned host memory (as on a device without a large BAR)

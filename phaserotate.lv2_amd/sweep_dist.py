@@ -81,6 +81,32 @@ def sweep_two_phase(engine, x, peaks, flags, world, stream=0, ang=(0, 360, 1), a
     return peaks
 
 
+def angle_shard(ang_start, ang_end, ang_stride, world, rank):
+    """Rank's share of the angles one analyze() call visits (loop bounds of cli/phase-rotate.cc:409-428), every world-th of them:
+    (start, end, stride) for prot_sweep_dev, or None when the list has fewer than rank + 1 angles.  BASELINE configs[3] words
+    the multi-GPU sweep as "angle-sharded" (SURVEY 8e's first option): every rank then runs the Hilbert pass over the WHOLE file --
+    72 % of a pass -- so frame-block shards (plan_shards, sweep_two_phase) are what bench.py and the CLI use; this axis is kept
+    for files too short to cut into blocks and as a cross-check (tests/test_gpu_multi.py)."""
+    first = ang_start + rank * ang_stride
+    if rank > 0 and first >= ang_end:
+        return None   # (the loop visits `end` itself only when it starts there)
+    return first, ang_end, ang_stride * world
+
+
+def sweep_angle_sharded(engine, x, peaks, flags, world, rank, stream=0, ang=(0, 360, 1), allreduce=None):
+    """One rank's angle-sharded sweep: the whole file (x: [n_chn, n] device tensor), this rank's angles, then ONE MAX all-reduce
+    of the table (the entries of the other ranks' angles are zero here).  Bit-identical to a single pass: an angle's maximum
+    does not depend on which other angles were asked for."""
+    allreduce = allreduce or allreduce_peaks
+    sub = angle_shard(ang[0], ang[1], ang[2], world, rank)
+    n_chn, n = x.shape
+    if sub is not None:
+        engine.sweep_dev(x.data_ptr(), x.stride(0), n, sub[0], sub[1], sub[2], -1, peaks.data_ptr(), flags, stream)
+    if world > 1:
+        allreduce(peaks)
+    return peaks
+
+
 def allreduce_peaks(peaks):
     """In-place MAX all-reduce of a [n_chn, 360] peak table (torch tensor)."""
     import torch.distributed as dist

@@ -39,6 +39,19 @@ def test_plan_shards(pkg):
         assert all(a[1] == b[0] for a, b in zip(pl, pl[1:])) and all(b0 % 3 == 0 for b0, _ in pl)
 
 
+def test_angle_shards_partition_the_angle_list(pkg):
+    """sweep_dist.angle_shard: the ranks' (start, end, stride) triples visit every angle of the call's loop exactly once
+    (cli/phase-rotate.cc:409-428: the loop visits `end` itself only when it starts there)."""
+    from phaserotate_lv2_amd import sweep_dist as sd
+    for ang in ((0, 360, 1), (0, 360, 24), (-12, 13, 1), (0, 0, 1), (5, 6, 1), (348, 372, 2), (-180, 180, 7)):
+        visited = sd.angle_list(*ang)
+        for world in (1, 2, 3, 5, 8, 16, 400):
+            shares = [sd.angle_shard(ang[0], ang[1], ang[2], world, r) for r in range(world)]
+            got = sorted(a for sh in shares if sh is not None for a in sd.angle_list(*sh))
+            assert got == sorted(visited), (ang, world)
+            assert shares[0] is not None
+
+
 @pytest.mark.parametrize("n_chn,n_frames,mode", [(2, 2048 * 9 + 517, "one_phase"), (1, 2048 * 4, "one_phase"), (2, 2048 * 13 + 100, "two_phase")])
 def test_sharded_sweep_world2_gloo(tmp_path, n_chn, n_frames, mode):
     """two_phase: sweep_dist.sweep_two_phase (seed -> MAX all-reduce -> main pass -> MAX all-reduce, round 5) over gloo with the
