@@ -385,6 +385,7 @@ struct Lv2Chn {            // Channel angle state, src/phaserotate.c:52-55, :61
 	float               angle = 0.f, sa = 0.f, ca = 1.f;
 	uint32_t            offset = 0;
 	std::vector<float>  rotq;  // [parsiz][2] {ca, sa} of the block being delivered
+	bool                rotq_steady = true; // every entry of rotq is {ca, sa} (no ramp in it)
 };
 
 struct Rccl {
@@ -2917,16 +2918,26 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 	// block-rate angle state machine, exactly process_channel's
 	// (src/phaserotate.c:563-571 target, :673-709 ramp, :710-717 steady)
 	bool steady = true;
+	auto target_of = [&] (uint32_t c) {
+		float target_angle = angle_deg[c] / -360.f;
+		return target_angle < -.5f ? -.5f : target_angle > 0.5f ? 0.5f : target_angle;
+	};
+	// the common call -- every channel at its target angle, no ramp in its queue -- needs none of the per-frame bookkeeping below:
+	// the block position moves on, the rotation of the call is {ca, sa} (what the queue holds in every entry); 1-1.5 us of a 14 us call
+	bool all_at_target = true;
+	for (uint32_t c = 0; c < nc && all_at_target; ++c) {
+		all_at_target = e->lv2[c].rotq_steady && target_of (c) == e->lv2[c].angle;
+	}
 	for (uint32_t c = 0; c < nc; ++c) {
 		memcpy (h_in + c * n, in[c] + off, n * sizeof (float));
 		Lv2Chn& ch = e->lv2[c];
-		float target_angle = angle_deg[c] / -360.f;
-		if (target_angle < -.5f) {
-			target_angle = -.5f;
+		if (all_at_target) {
+			ch.offset = (uint32_t)((ch.offset + (uint64_t)n_samples) % P);
+			h_rot[2 * n * c]     = ch.ca;
+			h_rot[2 * n * c + 1] = ch.sa;
+			continue;
 		}
-		if (target_angle > 0.5f) {
-			target_angle = 0.5f;
-		}
+		const float target_angle = target_of (c);
 		float*   r      = h_rot + 2 * n * c;
 		uint32_t remain = n_samples, done = 0;
 		while (remain > 0) {
@@ -2965,6 +2976,7 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 						ch.rotq[2 * i + 1] = sa;
 						angle += da;
 					}
+					ch.rotq_steady = false;
 					if (final_) {
 						angle = target_angle;
 					}
@@ -2976,6 +2988,7 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 						ch.rotq[2 * i]     = ch.ca;
 						ch.rotq[2 * i + 1] = ch.sa;
 					}
+					ch.rotq_steady = true;
 				}
 				ch.angle = angle;
 			}

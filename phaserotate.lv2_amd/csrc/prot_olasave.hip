@@ -100,6 +100,69 @@ extern "C" int prot_debug_srv_t (unsigned* out)
 //    sweep does not depend on where its chunks end), and stored from LDS with bounds.
 // WIDE (the run() server: one workgroup per CU, registers to spare, and every load a round trip nothing else hides): the 16 rows of
 // a staged block are fetched before the first is parked, the history slice moves eight frames per thread at a time, without a branch per frame
+// The next history of a run() server call (WIDE): hist_out[i] = [old history | input](i + n_in) -- the input is the server's LDS
+// copy, everything else global (address spaces said explicitly: see olasave_body).  Round 5: the server calls it BEHIND the done
+// word -- the host waits for the outputs, the history is this workgroup's own business until its next call (1.8 us off every call).
+PROT_DEV void server_next_history (const OlaParams& p, const int c)
+{
+	typedef __attribute__ ((address_space (3))) const float LdsInF;
+	auto in_f = [] (const float* q) -> float { return *(LdsInF*)q; };
+	auto gl_f = [] (const float* q) -> float { return *(PROT_GLOBAL const float*)q; };
+	const float* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
+	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
+	const int64_t n_in = p.n_in;
+	if (p.hist_out != nullptr) {
+		const int per = (p.hist_len + (int)gridDim.x - 1) / (int)gridDim.x;
+		const int i0  = (int)blockIdx.x * per;
+		const int i1  = i0 + per < p.hist_len ? i0 + per : p.hist_len;
+		float* __restrict__ ho = p.hist_out + (int64_t)c * p.hist_len;
+		// next history [i] = old history [i + n_in] while that exists, input [i - (hist_len - n_in)] after it: two loops without
+		// a branch per frame, eight loads in flight per thread (with the per-frame choice the loads went out one at a time)
+		const int64_t keep64 = (int64_t)p.hist_len - n_in;
+		const int     keep   = keep64 > 0 ? (int)keep64 : 0; // entries that come from the old history
+		const int     a1     = i1 < keep ? i1 : keep;
+		if (hist != nullptr) {
+			const float* __restrict__ hs = hist + n_in;
+			for (int base = i0 + (int)threadIdx.x; base < a1; base += 256 * 8) {
+				float v[8];
+#pragma unroll
+				for (int q = 0; q < 8; ++q) {
+					const int i = base + 256 * q;
+					v[q]        = gl_f (hs + (i < a1 ? i : a1 - 1));
+				}
+#pragma unroll
+				for (int q = 0; q < 8; ++q) {
+					const int i = base + 256 * q;
+					if (i < a1) {
+						*(PROT_GLOBAL float*)(ho + i) = v[q];
+					}
+				}
+			}
+		} else {
+			for (int i = i0 + (int)threadIdx.x; i < a1; i += 256) {
+				ho[i] = 0.f;
+			}
+		}
+		const float* __restrict__ is = in - keep64; // (keep64 < 0: more input than history, the last hist_len frames of it)
+		const int b0 = i0 > keep ? i0 : keep;
+		for (int base = b0 + (int)threadIdx.x; base < i1; base += 256 * 8) {
+			float v[8];
+#pragma unroll
+			for (int q = 0; q < 8; ++q) {
+				const int i = base + 256 * q;
+				v[q]        = in_f (is + (i < i1 ? i : i1 - 1));
+			}
+#pragma unroll
+			for (int q = 0; q < 8; ++q) {
+				const int i = base + 256 * q;
+				if (i < i1) {
+					*(PROT_GLOBAL float*)(ho + i) = v[q];
+				}
+			}
+		}
+	}
+}
+
 template <int HS, int MODE, bool WIDE = false>
 PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_lo_s, const int chn = -1)
 {
@@ -512,56 +575,7 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 #endif
 	if (!piped) {
 		if constexpr (WIDE) {
-			if (p.hist_out != nullptr) {
-				const int per = (p.hist_len + (int)gridDim.x - 1) / (int)gridDim.x;
-				const int i0  = (int)blockIdx.x * per;
-				const int i1  = i0 + per < p.hist_len ? i0 + per : p.hist_len;
-				float* __restrict__ ho = p.hist_out + (int64_t)c * p.hist_len;
-				// next history [i] = old history [i + n_in] while that exists, input [i - (hist_len - n_in)] after it: two loops without
-				// a branch per frame, eight loads in flight per thread (with the per-frame choice the loads went out one at a time)
-				const int64_t keep64 = (int64_t)p.hist_len - n_in;
-				const int     keep   = keep64 > 0 ? (int)keep64 : 0; // entries that come from the old history
-				const int     a1     = i1 < keep ? i1 : keep;
-				if (hist != nullptr) {
-					const float* __restrict__ hs = hist + n_in;
-					for (int base = i0 + (int)threadIdx.x; base < a1; base += 256 * 8) {
-						float v[8];
-#pragma unroll
-						for (int q = 0; q < 8; ++q) {
-							const int i = base + 256 * q;
-							v[q]        = gl_f (hs + (i < a1 ? i : a1 - 1));
-						}
-#pragma unroll
-						for (int q = 0; q < 8; ++q) {
-							const int i = base + 256 * q;
-							if (i < a1) {
-								*(PROT_GLOBAL float*)(ho + i) = v[q];
-							}
-						}
-					}
-				} else {
-					for (int i = i0 + (int)threadIdx.x; i < a1; i += 256) {
-						ho[i] = 0.f;
-					}
-				}
-				const float* __restrict__ is = in - keep64; // (keep64 < 0: more input than history, the last hist_len frames of it)
-				const int b0 = i0 > keep ? i0 : keep;
-				for (int base = b0 + (int)threadIdx.x; base < i1; base += 256 * 8) {
-					float v[8];
-#pragma unroll
-					for (int q = 0; q < 8; ++q) {
-						const int i = base + 256 * q;
-						v[q]        = in_f (is + (i < i1 ? i : i1 - 1));
-					}
-#pragma unroll
-					for (int q = 0; q < 8; ++q) {
-						const int i = base + 256 * q;
-						if (i < i1) {
-							*(PROT_GLOBAL float*)(ho + i) = v[q];
-						}
-					}
-				}
-			}
+			// (the run() server writes the next history itself, behind the done word: server_next_history)
 		} else {
 			hist_write_slice (p, c, threadIdx.x);
 		}
@@ -741,6 +755,9 @@ PROT_DEV void server_loop (const SvServerBox* const box, SvServerAck* const ack,
 			__hip_atomic_store (&ack->done[chn], word >> 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 		stage (5u);
+		// the next history: read by this workgroup's next call (program order) or by a launch behind the kernel's end -- nobody
+		// waits for it here
+		server_next_history (p, chn);
 		seen = word >> 1;
 	}
 	stage (9u);

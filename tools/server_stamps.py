@@ -11,12 +11,12 @@ if "--build" in sys.argv:
     b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
     b.build_lib()
     hipcc=b._hipcc()
-    fl=[hipcc,"--offload-arch=gfx950","-O3","-fPIC","-std=c++17","-Wno-unused-function","-DPROT_SERVER_STAMPS","-I" + os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")]
+    fl=[hipcc,"--offload-arch=gfx950","-O3","-fPIC","-std=c++17","-Wno-unused-function","-DPROT_SERVER_STAMPS","-DPROT_TESTHOOKS","-I" + os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")]
     o1=os.path.join(b.OBJDIR,"prot_olasave_stamps.o"); o2=os.path.join(b.OBJDIR,"prot_capi_stamps.o")
     b._run(fl+["-ffast-math","-fno-slp-vectorize","-c",os.path.join(b.CSRC,"prot_olasave.hip"),"-o",o1])
     b._run(fl+["-c",os.path.join(b.CSRC,"prot_capi.hip"),"-o",o2])
     lib=os.path.join(b.LIBDIR,"variants","libprot_hip_stamps.so")
-    b._run([hipcc,"--offload-arch=gfx950","-shared","-fPIC","-o",lib,o1,o2]+[os.path.join(b.OBJDIR,x) for x in ("prot_kernels.o","prot_olasave8k.o","prot_sweep.o","prot_kernels_f16.o")]+["-lpthread"])
+    b._run([hipcc,"--offload-arch=gfx950","-shared","-fPIC","-o",lib,o1,o2]+[os.path.join(b.OBJDIR,x) for x in ("prot_kernels.o","prot_olasave8k.o","prot_olasave16k.o","prot_sweep.o","prot_kernels_f16.o")]+["-lpthread"])
     print("built",lib)
     sys.exit(0)
 import os, sys, time, ctypes as C
