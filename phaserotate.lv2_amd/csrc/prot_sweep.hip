@@ -1109,7 +1109,7 @@ hipError_t launch_sweep (const SweepParams& p, int n_chn, hipStream_t s)
 // The step table of a sweep over lists (one workgroup per channel): list l has cnt[l] entries from entry l * cap on; its steps of
 // up to L entries follow those of the lists before it.  L = 1024 (a full stage) when there is plenty to do; a channel with few
 // entries -- a shard of a sharded sweep behind the merged seeds of all shards: 1-2 M entries -- is cut into steps of 512, 256 or
-// 128 entries instead, until there are about `want_steps` of them: the evaluation's workgroups claim FOUR steps when they start,
+// 128 entries instead, until there are about `want_steps` of them (eight per workgroup): the evaluation's workgroups claim FOUR steps when they start,
 // so 1300 full steps kept 325 of a channel's 512 workgroups busy with four steps each and the others with none (round 5:
 // sweep_eval_kernel 80 us of a 340 us shard pass).
 __global__ __launch_bounds__ (256) void sweep_plan_kernel (const unsigned* __restrict__ cnt, int n_lists, int64_t cap, uint2* __restrict__ desc,
@@ -1181,8 +1181,11 @@ hipError_t launch_sweep_plan (const unsigned* cnt, int n_lists, int64_t cap, uin
 			cus = 256;
 		}
 	}
-	// (sweep_eval_kernel runs four workgroups per CU, shared among the channels: about sixteen steps for each)
-	const unsigned want = 16u * (unsigned)std::max (1, 4 * cus / std::max (1, n_chn));
+	// (sweep_eval_kernel runs four workgroups per CU, shared among the channels: about eight steps for each)
+#ifndef PROT_PLAN_WANT_MUL
+#define PROT_PLAN_WANT_MUL 8u // (measured per shard of the harmonic hour, eval kernel us at blksiz 2048 / 16384: no cut 81 / 91, x4 76 / 90, x16 86 / 86, x64 142 / 132 --
+#endif                        // every step costs 3-4 us of its own, too few leave workgroups without work: tools/ab_build.py sw:<tag>:-DPROT_PLAN_WANT_MUL=<n>u)
+	const unsigned want = PROT_PLAN_WANT_MUL * (unsigned)std::max (1, 4 * cus / std::max (1, n_chn));
 	const int      per  = (n_lists + 255) / 256;
 	hipLaunchKernelGGL (sweep_plan_kernel, dim3 ((unsigned)n_chn, (unsigned)std::min (8, std::max (1, per))), dim3 (256), 0, s, cnt, n_lists, cap, desc, desc_stride,
 	                    n_steps, total, want);
