@@ -403,6 +403,9 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 		if (hist_al8 && ar + 512 <= 0 && ar + p.hist_len >= 0) {
 			return gl_c (reinterpret_cast<const f2*> (hist + (ar + p.hist_len)) + t);
 		}
+		if (ar >= n_in) { // a row of the silence behind the input (wave-uniform): seven of a 1024-frame run() call's sixteen rows, which
+			return mkf2 (0.f, 0.f); // otherwise take the frame-by-frame route below, two bounds-checked loads with a branch each per lane
+		}
 		const int64_t a = ar + 2 * (int64_t)t;
 		return mkf2 (ldv (in, n_in, hist, p.hist_len, a), ldv (in, n_in, hist, p.hist_len, a + 1));
 	};
