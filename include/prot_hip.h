@@ -213,7 +213,8 @@ int prot_sweep_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64
                     int ang_start, int ang_end, int ang_stride, int chn,
                     float* d_peaks, uint32_t flags, void* stream);
 
-/* block until everything queued on the engine's stream has finished */
+/* block until everything queued on the engine's stream -- and on the caller's stream the engine's last call named, whose
+ * handle the engine lets go of here ("Streams" above) -- has finished */
 int prot_engine_sync (prot_engine* e);
 
 /* ---- host-buffer drop-ins (mirror the reference call for call) ---------- */
@@ -223,7 +224,11 @@ int prot_engine_sync (prot_engine* e);
  * (:673-709) and the latency of `latency` frames.  Replaces
  * run()/process_channel (src/phaserotate.c:538-725, :840-843).
  * lvl (optional, [n_chn][2]) receives max|delayed in| is NOT computed here:
- * meters stay in host C (see host/lv2_plugin.c). */
+ * meters stay in host C (see host/lv2_plugin.c).
+ * Calls of one block per channel go through ONE resident kernel per process that serves every eligible LV2 engine (a
+ * workgroup per channel, a mailbox per engine): no launch and no stream synchronisation per call.  The
+ * library stops and restarts it by itself around every other use of any engine; run() calls of different engines made
+ * from different threads are serialised. */
 int prot_lv2_run (prot_engine* e, const float* const* in, float* const* out,
                   uint32_t n_samples, const float* angle_deg);
 
