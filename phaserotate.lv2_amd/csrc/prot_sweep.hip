@@ -677,36 +677,68 @@ __global__ __launch_bounds__ (256, 4) void sweep_eval_kernel (const SweepParams 
 	// value among the 32 lanes of the half -- one loud frame raises all 32 angles of a block to within cos 8 deg of its r, so this is
 	// nearly the min over rows of the max over lanes, for 16 v_min and 5 DPP instead of 80 reductions --; the block's bound is the
 	// smaller of the two halves')
-	auto refresh = [&] (int q, f32x16& mq) {
-		const int blk = g + q * G;
-		float     lo  = kBig;
+	// Round 5: ALL of a wave's blocks at once -- lane q looks up block q's shared bound and, when the wave has something better,
+	// raises it: two round trips at most.  One block after the other, each with a load and then an atomic whose result it needed,
+	// a refresh was three to six dependent round trips: 5-6 us, four times in a shard's eight steps -- with the refreshes compiled
+	// out the evaluation of a shard took 59 us instead of 82, the whole file's 243 instead of 292, stationary noise the same
+	// (tools/ab_build.py sw:noref:-DPROT_EVAL_NO_REFRESH; the whole pass on four materials, ms: harmonic 1.42 -> 1.38, noise 2.22 ->
+	// 2.21, a level rising in eight steps 1.41 -> 1.41, one loud passage the sample missed 2.22 -> 2.25): the lists were made against the
+	// seeding pass's bound, which is what the table holds at this launch's start, and the maxima found while evaluating them add
+	// little to it.  So: a refresh behind every 16th step (a workgroup with that many steps is in a long evaluation, where bounds
+	// that rise during it are all that prunes), and behind the first step of a launch that starts without a bound.
+	auto refresh_all = [&] () -> bool {
+		float lo3[NBLK];
 #pragma unroll
-		for (int r = 0; r < 16; ++r) {
-			const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
-			if (blk < nb && blk * 32 + row < p.n_angles) {
-				lo = fminf (lo, mq[r]);
+		for (int q = 0; q < NBLK; ++q) {
+			const int blk = g + q * G;
+			float     lo  = kBig;
+#pragma unroll
+			for (int r = 0; r < 16; ++r) {
+				const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+				if (blk < nb && blk * 32 + row < p.n_angles) {
+					lo = fminf (lo, m[q][r]);
+				}
+			}
+			lo            = lo >= kBig ? -1.f : lo; // (a half without rows must not win the max)
+			const float v = half_max_odd_rows (lo);
+			const float h0 = __uint_as_float ((unsigned)__builtin_amdgcn_readlane ((int)__float_as_uint (v), 16));
+			const float h1 = __uint_as_float ((unsigned)__builtin_amdgcn_readlane ((int)__float_as_uint (v), 48));
+			lo3[q]         = h0 < 0.f ? h1 : h1 < 0.f ? h0 : fminf (h0, h1);
+		}
+		float     mine = -1.f;
+		unsigned* sl   = slot[0];
+#pragma unroll
+		for (int q = 0; q < NBLK; ++q) {
+			if (lane == q) {
+				mine = lo3[q];
+				sl   = slot[q];
 			}
 		}
-		lo            = lo >= kBig ? -1.f : lo; // (a half without rows must not win the max)
-		const float v = half_max_odd_rows (lo);
-		const float h0 = __uint_as_float ((unsigned)__builtin_amdgcn_readlane ((int)__float_as_uint (v), 16));
-		const float h1 = __uint_as_float ((unsigned)__builtin_amdgcn_readlane ((int)__float_as_uint (v), 48));
-		lo             = h0 < 0.f ? h1 : h1 < 0.f ? h0 : fminf (h0, h1);
-		if (lo <= 0.f) {
-			return;
-		}
-		float best = lo;
-		if (lane == 0) {
-			float cur = __uint_as_float (__hip_atomic_load (slot[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-			if (lo > cur) {
-				cur = __uint_as_float (atomicMax (slot[q], __float_as_uint (lo)));
+		float cur = 0.f;
+		if (lane < NBLK && mine > 0.f) {
+			cur = __uint_as_float (__hip_atomic_load (sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+			if (mine > cur) {
+				cur = __uint_as_float (atomicMax (sl, __float_as_uint (mine))); // (non-negative floats order as their bit patterns)
 			}
-			best = fmaxf (lo, cur);
 		}
-		best    = uniform_f (best);
-		bnd[q]  = fmaxf (bnd[q], best * 0.99995f);
-		bnd2[q] = fmaxf (bnd2[q], best * best * 0.9999f);
+		bool rose = false;
+#pragma unroll
+		for (int q = 0; q < NBLK; ++q) {
+			const float other = __uint_as_float ((unsigned)__builtin_amdgcn_readlane ((int)__float_as_uint (cur), q));
+			if (lo3[q] > 0.f) { // (wave-uniform)
+				const float best = fmaxf (lo3[q], other) * 0.99995f;
+				rose             = rose || best > bnd[q] * 1.02f;
+				bnd[q]           = fmaxf (bnd[q], best);
+				bnd2[q]          = fmaxf (bnd2[q], best * best * (0.9999f / (0.99995f * 0.99995f)));
+			}
+		}
+		return rose;
 	};
+	bool unseeded = false; // a block of this wave starts without a bound (a call too short for a seeding pass)
+#pragma unroll
+	for (int q = 0; q < NBLK; ++q) {
+		unseeded = unseeded || (g + q * G < nb && bnd[q] <= 0.f);
+	}
 
 	// ---- the steps of the lists: handed out by counters, loaded once per workgroup, parked planar in the stage (sweep_kernel's scheme)
 	const unsigned  n_total = (unsigned)__builtin_amdgcn_readfirstlane ((int)p.n_steps[blockIdx.y]);
@@ -876,12 +908,13 @@ __global__ __launch_bounds__ (256, 4) void sweep_eval_kernel (const SweepParams 
 				}
 			}
 			n_seen += (unsigned)(2 * nch) / nsub;
-			// the bounds: after the workgroup's steps 1, 2, 4, 8, 16, then every 16th
-			if (((s + 1) & s) == 0 || (s & 15) == 15) {
-#pragma unroll
-				for (int q = 0; q < NBLK; ++q) {
-					refresh (q, m[q]);
-				}
+			// the bounds: behind every 16th step; a launch that starts without a bound also behind its steps 1, 2, 4, 8 (round 4's schedule)
+#ifdef PROT_EVAL_NO_REFRESH // (timing experiment: the bounds of the launch's start only -- still exact, more survivors)
+			if (false) {
+#else
+			if ((s & 15) == 15 || (unseeded && ((s + 1) & s) == 0)) {
+#endif
+				(void)refresh_all ();
 			}
 		}
 		if (asks) {
