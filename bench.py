@@ -735,15 +735,16 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
         halo = _sweep_signal(torch, np, dev, n_chn, f0 - H, H, 4321, kind).contiguous() if rank > 0 else None
 
         def one_pass():
-            eng.reset()
-            peaks.zero_()
-            if rank > 0:
-                eng.prime_dev(halo.data_ptr(), H, H, st)   # (the frames in front of the shard pass into the history: a copy)
             if world > 1:
                 # two phases (round 5): every rank seeds the pruning bound from a sparse sample of its shard, the sampled tables are
-                # merged, and the main pass lists against the GLOBAL bound (a shard alone lists twice what the whole file lists)
-                eng.sweep_seed_dev(x.data_ptr(), n, n, 0, 360, 1, -1, peaks.data_ptr(), flags, max(8, 64 // world), st)
+                # merged, and the main pass lists against the GLOBAL bound (a shard alone lists twice what the whole file lists).
+                # Phase one is ONE call: reset, table zeroed, the frames in front of the shard into the history (a copy), seeding pass
+                eng.sweep_shard_seed_dev(halo.data_ptr() if rank > 0 else 0, H, H if rank > 0 else 0, x.data_ptr(), n, n, 0, 360, 1,
+                                         peaks.data_ptr(), flags, max(8, 64 // world), st)
                 dist.all_reduce(peaks, op=dist.ReduceOp.MAX)
+            else:
+                eng.reset()
+                peaks.zero_()
             eng.sweep_dev(x.data_ptr(), n, n, 0, 360, 1, -1, peaks.data_ptr(), flags, st)
             if world > 1:
                 dist.all_reduce(peaks, op=dist.ReduceOp.MAX)

@@ -313,6 +313,14 @@ int prot_sweep_stats_fused (prot_engine* e, uint64_t out[2]);
 int prot_sweep_seed_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_frames, int ang_start,
                          int ang_end, int ang_stride, int chn, float* d_peaks, uint32_t flags, int n_blocks, void* stream);
 int prot_engine_prime_dev (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n_frames, void* stream);
+/* phase one of a shard in ONE call (a shard's fixed costs are what bounds the speed-up of a sharded sweep, and four short calls
+ * from a host that is slower than the device's few microseconds per kernel leave gaps between them): prot_engine_reset, the
+ * caller's table d_peaks ([n_chn][360], may be NULL: the engine's own) zeroed on `stream`, the n_halo frames in front of the shard
+ * primed (d_halo NULL or n_halo 0: the file's first shard), the seeding pass over all channels.  The same state and the same table
+ * as the four calls. */
+int prot_sweep_shard_seed_dev (prot_engine* e, const float* d_halo, int64_t halo_stride, uint64_t n_halo, const float* d_in, int64_t in_stride,
+                               uint64_t n_frames, int ang_start, int ang_end, int ang_stride, float* d_peaks, uint32_t flags, int n_blocks,
+                               void* stream);
 
 /* ---- several GPUs of one node, single process --------------------------- */
 /* MAX all-reduce of the engines' OWN peak tables (prot_cli_peaks_dev) across

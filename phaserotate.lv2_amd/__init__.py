@@ -46,7 +46,7 @@ ABI_SYMBOLS = (
     "prot_cli_apply_file", "prot_cli_peak", "prot_cli_peak_all", "prot_cli_peaks",
     "prot_cli_peaks_dev", "prot_allreduce_peaks", "prot_cli_analyze_file_multi", "prot_sweep_stats",
     "prot_sweep_stats_ex", "prot_sweep_stats_fused", "prot_cli_file_resident",
-    "prot_sweep_seed_dev", "prot_engine_prime_dev",
+    "prot_sweep_seed_dev", "prot_engine_prime_dev", "prot_sweep_shard_seed_dev",
 )
 
 
@@ -127,6 +127,9 @@ def load_library():
     lib.prot_sweep_seed_dev.restype = C.c_int
     lib.prot_engine_prime_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]
     lib.prot_engine_prime_dev.restype = C.c_int
+    lib.prot_sweep_shard_seed_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p, C.c_int64, C.c_uint64, C.c_int, C.c_int,
+                                              C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+    lib.prot_sweep_shard_seed_dev.restype = C.c_int
     lib.prot_lv2_run.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                  C.c_uint32, _f32p]
     lib.prot_lv2_get_angle.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
@@ -301,6 +304,13 @@ class Engine:
         _check(self._lib.prot_sweep_seed_dev(self._h, d_in, in_stride, n_frames, ang_start, ang_end,
                                              ang_stride, chn, d_peaks or None, flags, n_blocks, stream),
                "prot_sweep_seed_dev")
+
+    def sweep_shard_seed_dev(self, d_halo, halo_stride, n_halo, d_in, in_stride, n_frames, ang_start, ang_end, ang_stride,
+                             d_peaks=0, flags=0, n_blocks=8, stream=0):
+        """phase one of a shard in one call: reset, the table zeroed, the history primed with the halo, the seeding pass"""
+        _check(self._lib.prot_sweep_shard_seed_dev(self._h, d_halo or None, halo_stride, n_halo, d_in, in_stride, n_frames, ang_start,
+                                                   ang_end, ang_stride, d_peaks or None, flags, n_blocks, stream),
+               "prot_sweep_shard_seed_dev")
 
     def prime_dev(self, d_in, in_stride, n_frames, stream=0):
         """n_frames of input pass into the history untransformed (the frames in front of a shard)"""

@@ -2768,6 +2768,28 @@ int prot_engine_prime_dev (prot_engine* e, const float* d_in, int64_t in_stride,
 	return rc;
 }
 
+int prot_sweep_shard_seed_dev (prot_engine* e, const float* d_halo, int64_t halo_stride, uint64_t n_halo, const float* d_in, int64_t in_stride,
+                               uint64_t n_frames, int ang_start, int ang_end, int ang_stride, float* d_peaks, uint32_t flags, int n_blocks,
+                               void* stream)
+{
+	if (!e || !d_in || n_blocks < 1 || e->info.kind != PROT_KIND_CLI) {
+		return PROT_EINVAL;
+	}
+	int rc = prot_engine_reset (e);
+	if (rc) {
+		return rc;
+	}
+	if (d_peaks) {
+		// (behind whatever the caller's stream still does with the table, in front of the seeding pass's kernels: same stream)
+		HIP_TRY (hipSetDevice (e->device));
+		HIP_TRY (hipMemsetAsync (d_peaks, 0, (size_t)PROT_MAXSAMPLE * e->info.n_chn * sizeof (float), stream ? (hipStream_t)stream : e->stream));
+	}
+	if (d_halo && n_halo && (rc = prot_engine_prime_dev (e, d_halo, halo_stride, n_halo, stream)) != PROT_OK) {
+		return rc;
+	}
+	return sweep_dev_impl (e, d_in, in_stride, n_frames, ang_start, ang_end, ang_stride, -1, d_peaks, flags, stream, n_blocks);
+}
+
 float* prot_cli_peaks_dev (prot_engine* e)
 {
 	return e ? e->d_peaks.p : nullptr;

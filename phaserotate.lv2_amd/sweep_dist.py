@@ -66,15 +66,32 @@ def prime_history(engine, halo, stream=0):
     return scratch  # keep alive until the stream has consumed it
 
 
-def sweep_two_phase(engine, x, peaks, flags, world, stream=0, ang=(0, 360, 1), allreduce=None):
+def sweep_two_phase(engine, x, peaks, flags, world, stream=0, ang=(0, 360, 1), allreduce=None, halo=None, fresh=False):
     """One rank's sharded sweep in two phases: seed the pruning bound from a sparse sample of this shard (x: [n_chn, n] device
     tensor), merge the sampled tables over the ranks (MAX all-reduce of `peaks`), sweep against the GLOBAL bound, merge again.
-    Bit-identical to a single pass over the whole file (every seeded entry is a peak of real frames; max is exact)."""
+    Bit-identical to a single pass over the whole file (every seeded entry is a peak of real frames; max is exact).
+    fresh=True: the pass starts from scratch in ONE call -- engine reset, `peaks` zeroed, the history primed with `halo` ([n_chn, H]
+    device tensor: the frames in front of the shard; None for the file's first shard), the seeding pass (prot_sweep_shard_seed_dev)."""
     allreduce = allreduce or allreduce_peaks
     n_chn, n = x.shape
-    if world > 1:
+    if fresh and world > 1 and hasattr(engine, "sweep_shard_seed_dev"):
+        h = 0 if halo is None else halo.shape[1]
+        engine.sweep_shard_seed_dev(0 if halo is None else halo.data_ptr(), 0 if halo is None else halo.stride(0), h, x.data_ptr(), x.stride(0), n,
+                                    ang[0], ang[1], ang[2], peaks.data_ptr(), flags, max(8, 64 // world), stream)
+        allreduce(peaks)
+    elif world > 1:
+        if fresh:
+            engine.reset()
+            peaks.zero_()
+            if halo is not None:
+                prime_history(engine, halo, stream)
         engine.sweep_seed_dev(x.data_ptr(), x.stride(0), n, ang[0], ang[1], ang[2], -1, peaks.data_ptr(), flags, max(8, 64 // world), stream)
         allreduce(peaks)
+    elif fresh:
+        engine.reset()
+        peaks.zero_()
+        if halo is not None:
+            prime_history(engine, halo, stream)
     engine.sweep_dev(x.data_ptr(), x.stride(0), n, ang[0], ang[1], ang[2], -1, peaks.data_ptr(), flags, stream)
     if world > 1:
         allreduce(peaks)

@@ -104,23 +104,33 @@ def test_two_phase_sharded_sweep_equals_single_pass_and_lists_less(pkg, P, secon
     engines = [pkg.Engine(pkg.KIND_CLI, P, n_chn) for _ in range(world)]
     tabs = [torch.zeros((n_chn, 360), device=dev) for _ in range(world)]
     listed = {}
-    for two_phase in (False, True):
-        for r, e in enumerate(engines):
-            e.reset()
-            tabs[r].zero_()
-        torch.cuda.synchronize()
-        shards = []
+    for two_phase in (False, True, "one call"):
+        shards, halos = [], []
         for r, e in enumerate(engines):
             f0, nf = sweep_dist.shard_frames(n, P, plan, r)
-            if r > 0:
-                halo = x[:, f0 - H:f0].contiguous()
-                e.prime_dev(halo.data_ptr(), H, H)
             fl = (pkg.F_STREAM_START if r == 0 else 0) | (pkg.F_STREAM_END if r == world - 1 else 0)
             shards.append((x[:, f0:f0 + nf], nf, fl))
+            halos.append(x[:, f0 - H:f0].contiguous() if r > 0 else None)
+        if two_phase != "one call":
+            for r, e in enumerate(engines):
+                e.reset()
+                tabs[r].zero_()
+            torch.cuda.synchronize()
+            for r, e in enumerate(engines):
+                if r > 0:
+                    e.prime_dev(halos[r].data_ptr(), H, H)
+        else:
+            for t in tabs:
+                t.fill_(7.0)                     # (prot_sweep_shard_seed_dev zeroes the table itself)
+            torch.cuda.synchronize()
         if two_phase:
             for r, e in enumerate(engines):
                 xs, nf, fl = shards[r]
-                e.sweep_seed_dev(xs.data_ptr(), n, nf, 0, 360, 1, -1, tabs[r].data_ptr(), fl, 8)
+                if two_phase == "one call":      # reset + table zeroed + history primed + seeding pass: prot_sweep_shard_seed_dev
+                    e.sweep_shard_seed_dev(halos[r].data_ptr() if r > 0 else 0, H, H if r > 0 else 0, xs.data_ptr(), n, nf, 0, 360, 1,
+                                           tabs[r].data_ptr(), fl, 8)
+                else:
+                    e.sweep_seed_dev(xs.data_ptr(), n, nf, 0, 360, 1, -1, tabs[r].data_ptr(), fl, 8)
                 e.sync()
             seed = torch.stack(tabs).amax(0)     # (the first all-reduce)
             assert float(seed.max()) > 0
@@ -136,6 +146,7 @@ def test_two_phase_sharded_sweep_equals_single_pass_and_lists_less(pkg, P, secon
         listed[two_phase] = [e.sweep_stats_fused()["listed"] for e in engines]
     # the quiet shards (the first half of the file) list next to nothing against the global bound
     assert sum(listed[True][:4]) * 4 < sum(listed[False][:4]) + 4, listed
+    assert listed["one call"] == listed[True], listed
     for e in engines:
         e.close()
     # ... and the host-file entry point: eight engines on one device against one engine
