@@ -622,6 +622,9 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 // 0.25 s without a doorbell (s_memrealtime: 100 MHz) -- a resident kernel blocks whatever shares its hardware queue and
 // every device-wide synchronisation of the process, so it never outlives the stream of calls it serves; `alive` is its last
 // store.  The host treats a server that has left as absent and starts a new one (with the last served call's number).
+#ifndef PROT_SRV_POLL_SLEEP
+#define PROT_SRV_POLL_SLEEP 4 // (x 64 cycles between two looks at the doorbell; 1 and 0 measured the same to 0.1 us per call)
+#endif
 constexpr uint64_t kServerIdleTicks = 25000000ull;
 // ... and it never stays longer than this, calls or no calls: between two calls it leaves when it has been resident for
 // 0.25 s, and the next run() starts a new one (130-330 us, once) -- so that a hipFree or a device-wide synchronisation of ANY
@@ -682,7 +685,7 @@ PROT_DEV void server_loop (const SvServerBox* const box, SvServerAck* const ack,
 						cmd = 1u;
 						break;
 					}
-					__builtin_amdgcn_s_sleep (4);
+					__builtin_amdgcn_s_sleep (PROT_SRV_POLL_SLEEP);
 				}
 				word = 2u * s + cmd;
 				if (n_chn > 1) {
