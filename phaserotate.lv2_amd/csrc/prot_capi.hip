@@ -552,6 +552,11 @@ struct prot_engine {
 	// 3; tools/ubench/event_cost.hip: 2.9-5.3 us per hipEventRecord behind a kernel, whatever the event's flags).
 	hipEvent_t     ev_last        = nullptr;
 	bool           last_foreign   = false;
+	// Work queued on the ENGINE's stream (stream = NULL calls) since the host last waited for it: a call that names a stream of the
+	// caller's is put behind it by an event (pick_stream) -- prime_dev (NULL) followed by sweep_dev (S) reads the history the first
+	// wrote.  The common same-stream sequence never records anything.
+	hipEvent_t     ev_own         = nullptr;
+	bool           own_dirty      = false;
 	const void*    last_stream_id = nullptr;
 	hipEvent_t     ev_reset    = nullptr;
 	hipStream_t    reset_stream  = nullptr; // where the last prot_engine_reset put its zeroing, behind ev_reset ...
@@ -1301,6 +1306,16 @@ hipStream_t pick_stream (prot_engine* e, void* stream, bool keep_server = false)
 			(void)hipStreamWaitEvent (s, e->ev_last, 0);
 		}
 	}
+	if (s != e->stream && e->own_dirty) {
+		// an earlier call ran on the engine's own stream and nobody has waited for it since: this one, on a stream of the caller's,
+		// reads the state it left
+		if (e->ev_own && hipEventRecord (e->ev_own, e->stream) == hipSuccess) {
+			(void)hipStreamWaitEvent (s, e->ev_own, 0);
+		} else {
+			(void)hipStreamSynchronize (e->stream);
+		}
+		e->own_dirty = false;
+	}
 	if (e->reset_pending) {
 		// prot_engine_reset behind a call on a caller's stream does not block the host: its zeroing sits on the engine's stream behind
 		// that call's event; a call that arrives on another stream is put behind it here
@@ -1321,6 +1336,9 @@ struct CallStream {
 	{
 		e->last_foreign   = s != e->stream;
 		e->last_stream_id = e->last_foreign ? (const void*)s : nullptr;
+		if (!e->last_foreign) {
+			e->own_dirty = true;
+		}
 	}
 	CallStream (const CallStream&)            = delete;
 	CallStream& operator= (const CallStream&) = delete;
@@ -1331,6 +1349,9 @@ struct CallStream {
 hipError_t sync_own (prot_engine* e)
 {
 	hipError_t err = hipStreamSynchronize (e->stream);
+	if (err == hipSuccess) {
+		e->own_dirty = false;
+	}
 	if (err == hipSuccess && e->reset_pending && e->reset_stream != e->stream) {
 		err = hipEventSynchronize (e->ev_reset);
 	}
@@ -1885,6 +1906,7 @@ prot_engine* prot_engine_create (const prot_config* cfg, int* status)
 
 	(void)hipEventCreateWithFlags (&e->ev_reset, hipEventDisableTiming);
 	(void)hipEventCreateWithFlags (&e->ev_last, hipEventDisableTiming);
+	(void)hipEventCreateWithFlags (&e->ev_own, hipEventDisableTiming);
 	if (hipStreamCreateWithFlags (&e->stream, hipStreamNonBlocking) != hipSuccess) {
 		return fail (PROT_EHIP);
 	}
@@ -2018,6 +2040,10 @@ void prot_engine_destroy (prot_engine* e)
 		(void)hipEventDestroy (e->ev_last);
 		e->ev_last = nullptr;
 	}
+	if (e->ev_own) {
+		(void)hipEventDestroy (e->ev_own);
+		e->ev_own = nullptr;
+	}
 	if (e->ev_reset) {
 		(void)hipEventDestroy (e->ev_reset);
 	}
@@ -2042,7 +2068,17 @@ int prot_engine_reset (prot_engine* e)
 	// goes to the ENGINE's stream behind an event recorded on the last call's stream now (mark_last);
 	// pick_stream puts a call that arrives on another stream behind ev_reset, the readers of device state wait for the engine's
 	// stream (sync_own).
-	const bool  foreign = e->last_foreign && e->ev_reset != nullptr && mark_last (e);
+	bool foreign = false;
+	if (e->last_foreign) {
+		// (when the event cannot be recorded behind the last call, nothing would order the zeroing behind the kernels that
+		// still use the history and the tables: wait for that stream on the host, or give up)
+		if (e->ev_reset != nullptr && mark_last (e)) {
+			foreign = true;
+		} else if (e->last_stream_id == nullptr || hipStreamSynchronize ((hipStream_t)const_cast<void*> (e->last_stream_id)) != hipSuccess) {
+			snprintf (g_err, sizeof (g_err), "prot_engine_reset: cannot order the reset behind the last call's stream");
+			return PROT_EHIP;
+		}
+	}
 	hipStream_t zs      = e->stream;
 	if (foreign) {
 		HIP_TRY (hipStreamWaitEvent (zs, e->ev_last, 0));
@@ -2059,11 +2095,13 @@ int prot_engine_reset (prot_engine* e)
 		HIP_TRY (hipEventRecord (e->ev_reset, zs));
 		e->reset_stream  = zs;
 		e->reset_pending = true;
+		e->own_dirty     = false; // (ev_reset sits behind everything the engine's stream held)
 	} else {
 		// behind a call on the engine's own stream (stream = NULL): the caller has no way to order anything of its own against it
 		// but the host -- a table of the caller's zeroed between reset and the next call, say -- so the reset still ends with the wait
 		HIP_TRY (hipStreamSynchronize (zs));
 		e->reset_pending = false;
+		e->own_dirty     = false;
 	}
 	e->sweep_seeded_ext = false;
 	e->seed_chunk_ready = false;
@@ -2718,6 +2756,7 @@ static int sweep_dev_impl (prot_engine* e, const float* d_in, int64_t in_stride,
 		e->angles_last.assign (lut_idx, lut_idx + n_ang);
 		e->angles_stream = s;
 		e->sweep_seeded  = false;
+		e->sweep_seeded_ext = false; // (a seed for ANOTHER angle list or stream: this call seeds itself -- ADVICE r5)
 	}
 	const bool fused = fusable && n_ang > 0 && n_out >= ((uint64_t)1 << 20); // (calls long enough to carry five more launches)
 	if (seed_blocks > 0 && !fused) {

@@ -627,10 +627,12 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 #endif
 constexpr uint64_t kServerIdleTicks = 25000000ull;
 // ... and it never stays longer than this, calls or no calls: between two calls it leaves when it has been resident for
-// 0.25 s, and the next run() starts a new one (130-330 us, once) -- so that a hipFree or a device-wide synchronisation of ANY
-// code in the process, which the library cannot see and cannot stop the server for, completes within a quarter of a second even
-// under continuous audio.
-constexpr uint64_t kServerLifeTicks = 25000000ull;
+// 2 s, and the next run() starts a new one (130-330 us on the calling thread, once) -- so that a hipFree or a device-wide
+// synchronisation of ANY code in the process, which the library cannot see and cannot stop the server for, completes within two
+// seconds even under continuous audio.  (Round 5: 0.25 s -- four restarts a second on the audio thread under continuous audio,
+// every one of them a stall for every instance of the process: ADVICE r5.  The cap trades that jitter against how long foreign
+// device-wide calls may wait; INTEGRATION.md, "run() latency and jitter".)
+constexpr uint64_t kServerLifeTicks = 200000000ull;
 
 // One slot of the server = one channel of one engine: the engine's mailbox (box, ack), the device word through which its channel 0
 // relays the doorbell to its other channels, the number of the last call it has served.  Round 5: ONE resident kernel serves every

@@ -51,12 +51,26 @@ def shard_frames(n_frames, blksiz, plan, rank):
     return f0, max(0, f1 - f0)
 
 
-def prime_history(engine, halo, stream=0):
+def _stream_of(x, stream):
+    """The stream a call is queued on when the caller names none: torch's CURRENT stream on x's device -- the stream torch's own
+    work on `peaks` (zero_(), dist.all_reduce) is ordered on -- for a CUDA tensor; 0 (the engine's own stream: a CPU oracle
+    ignores it) otherwise.  ADVICE r5: with the engine's private non-blocking stream as the default, the first all-reduce could
+    merge a table the seeding pass was still writing."""
+    if stream is not None:
+        return stream
+    if getattr(x, "is_cuda", False):
+        import torch
+        return torch.cuda.current_stream(x.device).cuda_stream
+    return 0
+
+
+def prime_history(engine, halo, stream=None):
     """Pass `halo` ([n_chn, H] device tensor: the H frames in front of this
     rank's shard) into the engine's input history, which then equals what a
     single-GPU pass would hold at this point (round 5: a copy kernel,
     prot_engine_prime_dev; until then a Hilbert launch whose output was thrown away)."""
     n_chn, h = halo.shape
+    stream = _stream_of(halo, stream)
     if hasattr(engine, "prime_dev"):
         engine.prime_dev(halo.data_ptr(), h, h, stream)
         return halo
@@ -66,33 +80,57 @@ def prime_history(engine, halo, stream=0):
     return scratch  # keep alive until the stream has consumed it
 
 
-def sweep_two_phase(engine, x, peaks, flags, world, stream=0, ang=(0, 360, 1), allreduce=None, halo=None, fresh=False):
+def sweep_two_phase(engine, x, peaks, flags, world, stream=None, ang=(0, 360, 1), allreduce=None, halo=None, fresh=False):
     """One rank's sharded sweep in two phases: seed the pruning bound from a sparse sample of this shard (x: [n_chn, n] device
     tensor), merge the sampled tables over the ranks (MAX all-reduce of `peaks`), sweep against the GLOBAL bound, merge again.
     Bit-identical to a single pass over the whole file (every seeded entry is a peak of real frames; max is exact).
     fresh=True: the pass starts from scratch in ONE call -- engine reset, `peaks` zeroed, the history primed with `halo` ([n_chn, H]
-    device tensor: the frames in front of the shard; None for the file's first shard), the seeding pass (prot_sweep_shard_seed_dev)."""
+    device tensor: the frames in front of the shard; None for the file's first shard), the seeding pass (prot_sweep_shard_seed_dev).
+    stream=None: torch's current stream (where peaks.zero_() and the default all-reduce are ordered); a raw HIP stream handle otherwise --
+    then `allreduce` must be ordered on that stream too."""
     allreduce = allreduce or allreduce_peaks
     n_chn, n = x.shape
+    stream = _stream_of(x, stream)
+    # torch's DEFAULT stream has the handle 0, which the C ABI reads as "the engine's own stream": nothing on the device orders that
+    # stream against torch's work then, so the host does (a wait in front of the engine's calls, prot_engine_sync in front of torch's)
+    own = stream == 0 and getattr(x, "is_cuda", False)
+
+    def torch_done():
+        if own:
+            import torch
+            torch.cuda.current_stream(x.device).synchronize()
+
+    def engine_done():
+        if own:
+            engine.sync()
+
+    torch_done()
     if fresh and world > 1 and hasattr(engine, "sweep_shard_seed_dev"):
         h = 0 if halo is None else halo.shape[1]
         engine.sweep_shard_seed_dev(0 if halo is None else halo.data_ptr(), 0 if halo is None else halo.stride(0), h, x.data_ptr(), x.stride(0), n,
                                     ang[0], ang[1], ang[2], peaks.data_ptr(), flags, max(8, 64 // world), stream)
+        engine_done()
         allreduce(peaks)
+        torch_done()
     elif world > 1:
         if fresh:
             engine.reset()
             peaks.zero_()
+            torch_done()
             if halo is not None:
                 prime_history(engine, halo, stream)
         engine.sweep_seed_dev(x.data_ptr(), x.stride(0), n, ang[0], ang[1], ang[2], -1, peaks.data_ptr(), flags, max(8, 64 // world), stream)
+        engine_done()
         allreduce(peaks)
+        torch_done()
     elif fresh:
         engine.reset()
         peaks.zero_()
+        torch_done()
         if halo is not None:
             prime_history(engine, halo, stream)
     engine.sweep_dev(x.data_ptr(), x.stride(0), n, ang[0], ang[1], ang[2], -1, peaks.data_ptr(), flags, stream)
+    engine_done()
     if world > 1:
         allreduce(peaks)
     return peaks
@@ -110,15 +148,22 @@ def angle_shard(ang_start, ang_end, ang_stride, world, rank):
     return first, ang_end, ang_stride * world
 
 
-def sweep_angle_sharded(engine, x, peaks, flags, world, rank, stream=0, ang=(0, 360, 1), allreduce=None):
+def sweep_angle_sharded(engine, x, peaks, flags, world, rank, stream=None, ang=(0, 360, 1), allreduce=None):
     """One rank's angle-sharded sweep: the whole file (x: [n_chn, n] device tensor), this rank's angles, then ONE MAX all-reduce
     of the table (the entries of the other ranks' angles are zero here).  Bit-identical to a single pass: an angle's maximum
     does not depend on which other angles were asked for."""
     allreduce = allreduce or allreduce_peaks
     sub = angle_shard(ang[0], ang[1], ang[2], world, rank)
     n_chn, n = x.shape
+    stream = _stream_of(x, stream)
+    own = stream == 0 and getattr(x, "is_cuda", False)   # (torch's default stream: see sweep_two_phase)
+    if own:
+        import torch
+        torch.cuda.current_stream(x.device).synchronize()
     if sub is not None:
         engine.sweep_dev(x.data_ptr(), x.stride(0), n, sub[0], sub[1], sub[2], -1, peaks.data_ptr(), flags, stream)
+    if own:
+        engine.sync()
     if world > 1:
         allreduce(peaks)
     return peaks

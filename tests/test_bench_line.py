@@ -1,0 +1,53 @@
+"""bench.py's final stdout line must be ONE JSON object the driver can read from an 8 KB tail (VERDICT r5 item 1:
+BENCH_r05.json has "parsed": null because the line had grown to 22.5 KB).  The formatter is a pure function of the
+full record, so it is run here on recorded full records (profiles/rNN_bench.json: the full lines of earlier rounds)."""
+import glob
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+RECORDS = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]_bench.json")) +
+                 glob.glob(os.path.join(ROOT, "profiles", "r0[6-9]_bench_detail.json")))
+
+
+@pytest.mark.parametrize("path", RECORDS, ids=[os.path.basename(p) for p in RECORDS])
+def test_compact_line_fits_the_drivers_tail_and_round_trips(path):
+    import bench
+    full = json.load(open(path))
+    line = bench.compact_line(full)
+    assert "\n" not in line
+    assert len(line) < 8192, len(line)
+    d = json.loads(line)
+    # the contract's keys, with the full record's values (5 significant digits)
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert d[k] == full[k], k
+    for k in ("value", "ms_per_step"):
+        assert d[k] == pytest.approx(full[k], rel=1e-4), k
+    assert d["config"]["workload"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-3)
+    assert rf["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-4)
+    assert rf["kernel"] and "(" not in rf["kernel"]          # a name, not a paragraph
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    if "sweep" in full:
+        for k in ("blksiz_16384", "blksiz_2048"):
+            if k == "blksiz_16384" and full["sweep"].get("blksiz") != 16384:
+                continue  # (rounds before 5: the lead sweep line was -f 2048)
+            if k in d["sweep"]:
+                assert d["sweep"][k]["ms"] > 0 and "predicted_speedup" in d["sweep"][k]
+
+
+def test_compact_line_drops_side_objects_rather_than_overflow():
+    import bench
+    full = json.load(open(RECORDS[-1]))
+    full = dict(full, lv2_run_host=dict(full.get("lv2_run_host") or {},
+                                        instances_in_turn={"x%d" % i: {"us_per_run": 1.0, "worst_single_call_us": 2.0} for i in range(400)}))
+    line = bench.compact_line(full)
+    assert len(line) < 8192
+    d = json.loads(line)
+    assert "roofline" in d and "cpu_baseline" in d and "value" in d

@@ -350,3 +350,211 @@ def test_angle_sharded_sweep_equals_single_pass(pkg, P, ang, world):
     merged = torch.stack(tabs).amax(0)
     assert torch.equal(merged, pk1)
     assert sum(int((t > 0).any()) for t in tabs) == sum(sh is not None for sh in shares)
+
+
+@pytest.mark.parametrize("side_stream", [False, True])
+def test_sweep_two_phase_with_default_arguments_on_a_real_engine(pkg, side_stream):
+    """sweep_dist.sweep_two_phase's default stream was the engine's private non-blocking stream, while peaks.zero_() and
+    the default all-reduce run on torch's current stream: nothing ordered them.  Default arguments now mean torch's CURRENT stream
+    (on torch's default stream -- handle 0, which the C ABI reads as "the engine's own" -- the host orders the two).  Two shards of
+    one file, each through sweep_two_phase(fresh=True) with NO stream argument, the all-reduce a torch operation on the current
+    stream; repeated: the merged table equals the single pass bit for bit every time."""
+    import torch
+    from phaserotate_lv2_amd import sweep_dist
+    dev = torch.device("cuda:0")
+    P, n_chn, world = 2048, 2, 2
+    n = (1 << 23) // P * P
+    g = torch.Generator(device=dev).manual_seed(21)
+    tt = torch.arange(n, device=dev, dtype=torch.float64) / 96000.0
+    x = torch.empty((n_chn, n), device=dev)
+    for c in range(n_chn):
+        sig = sum((0.5 / k) * torch.cos(2 * np.pi * k * (110.0 + 27.5 * c) * tt + 0.3 * k) for k in range(1, 17))
+        x[c] = sig.float() * (0.2 + 0.5 * (tt / tt[-1]).float()) + 0.02 * (torch.rand(n, generator=g, device=dev) - 0.5)
+    del tt
+    one = pkg.Engine(pkg.KIND_CLI, P, n_chn)
+    pk1 = torch.zeros((n_chn, 360), device=dev)
+    torch.cuda.synchronize()
+    one.sweep_dev(x.data_ptr(), n, n, 0, 360, 1, -1, pk1.data_ptr(), pkg.F_STREAM_START | pkg.F_STREAM_END)
+    one.sync()
+    plan = sweep_dist.plan_shards(n, P, world, align=one.shard_align_blocks())
+    H = int(one.info.history)
+    one.close()
+    engines = [pkg.Engine(pkg.KIND_CLI, P, n_chn) for _ in range(world)]
+    ts = torch.cuda.Stream(device=dev) if side_stream else torch.cuda.current_stream(dev)
+    with torch.cuda.stream(ts):
+        for rep in range(6):
+            tabs = [torch.full((n_chn, 360), 3.0, device=dev) for _ in range(world)]  # (fresh=True zeroes them)
+            other = {}
+
+            def merge_with(r):
+                # stands where dist.all_reduce would: a torch operation on the CURRENT stream that reads and writes the table
+                def f(t):
+                    if r in other:
+                        t.copy_(torch.maximum(t, other[r]))
+                    return t
+                return f
+            # phase one of shard 1 first, to have its seed table for shard 0's "all-reduce" (and vice versa): seeds only
+            seeds = []
+            for r, e in enumerate(engines):
+                f0, nf = sweep_dist.shard_frames(n, P, plan, r)
+                halo = x[:, f0 - H:f0].contiguous() if r > 0 else None
+                fl = (pkg.F_STREAM_START if r == 0 else 0) | (pkg.F_STREAM_END if r == world - 1 else 0)
+                t = torch.zeros((n_chn, 360), device=dev)
+                e.sweep_shard_seed_dev(halo.data_ptr() if r > 0 else 0, H, H if r > 0 else 0, x[:, f0:].data_ptr(), n, nf, 0, 360, 1,
+                                       t.data_ptr(), fl, 32, ts.cuda_stream)
+                e.sync()
+                seeds.append(t)
+            for r, e in enumerate(engines):
+                other[r] = seeds[1 - r]
+            for r, e in enumerate(engines):
+                f0, nf = sweep_dist.shard_frames(n, P, plan, r)
+                halo = x[:, f0 - H:f0].contiguous() if r > 0 else None
+                fl = (pkg.F_STREAM_START if r == 0 else 0) | (pkg.F_STREAM_END if r == world - 1 else 0)
+                sweep_dist.sweep_two_phase(e, x[:, f0:f0 + nf], tabs[r], fl, world, allreduce=merge_with(r), halo=halo, fresh=True)
+            merged = torch.maximum(tabs[0], tabs[1])   # on the current stream, like a caller's next torch operation
+            for e in engines:
+                e.sync()
+            ts.synchronize()
+            assert torch.equal(merged, pk1), rep
+    for e in engines:
+        e.close()
+
+
+def test_call_on_a_callers_stream_waits_for_the_engines_own_stream(pkg):
+    """ADVICE r5: include/prot_hip.h promises that calls on one engine are ordered on the device whatever streams they name;
+    a call on the engine's OWN stream (stream = NULL) followed by a call on a caller's stream S was not (only caller -> other was).
+    prime_dev(NULL) then sweep_dev(S), many times on fresh engines, against the same two calls on one stream: same tables -- and
+    apply_dev(NULL) then apply_dev(S) on a stateful engine against the one-stream sequence, bit for bit."""
+    import torch
+    dev = torch.device("cuda:0")
+    P, n_chn = 2048, 2
+    n = (1 << 22)
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = (torch.rand((n_chn, n), generator=g, device=dev) - 0.5)
+    x[:, :P * 64] *= 3.0    # what the history holds decides the first blocks' peaks
+    s = torch.cuda.Stream(device=dev)
+    th = -2.0 * np.pi * 33.0 / 360.0
+    rot = np.array([np.cos(th), np.sin(th)] * n_chn, np.float32)
+    e0 = pkg.Engine(pkg.KIND_CLI, P, n_chn)
+    H = int(e0.info.history)
+    e0.close()
+    ref_pk = ref_y = None
+    for rep in range(8):
+        for mixed in (False, True):
+            e = pkg.Engine(pkg.KIND_CLI, P, n_chn)
+            pk = torch.zeros((n_chn, 360), device=dev)
+            y1 = torch.empty((n_chn, n // 2), device=dev)
+            y2 = torch.empty((n_chn, n // 2), device=dev)
+            torch.cuda.synchronize()
+            first = 0 if mixed else s.cuda_stream
+            # a long stateful call, then a call that continues from its history
+            e.apply_dev(x.data_ptr(), n, n // 2, y1.data_ptr(), n // 2, n // 2, rot, 0, first)
+            e.apply_dev(x[:, n // 2:].data_ptr(), n, n // 2, y2.data_ptr(), n // 2, n // 2, rot, 0, s.cuda_stream)
+            e.sync()
+            s.synchronize()
+            e.reset()
+            e.prime_dev(x[:, P * 64 - H:].data_ptr(), n, H, first)
+            e.sweep_dev(x[:, P * 64:].data_ptr(), n, n // 2, 0, 360, 1, -1, pk.data_ptr(), pkg.F_STREAM_END, s.cuda_stream)
+            e.sync()
+            s.synchronize()
+            if ref_pk is None:
+                ref_pk, ref_y = pk.clone(), y2.clone()
+            assert torch.equal(pk, ref_pk), (rep, mixed)
+            assert torch.equal(y2, ref_y), (rep, mixed)
+            e.close()
+
+
+@pytest.mark.parametrize("P", [16384, 2048])
+def test_cfg4_full_size_at_the_references_block_size(pkg, P):
+    """BASELINE configs[3] at FULL size (60 min stereo 96 kHz, the bench's harmonic material) at the block size the reference
+    itself picks for a 96 kHz file, 16384 (cli/phase-rotate.cc:749-755), and at -f 2048: ONE resident pass ==
+    eight two-phase frame-block shards (seed, merged seeds, main pass against the global bound) == eight angle shards, bit for
+    bit; the pruned pass evaluates < 10 % of its tiles and equals the unpruned table; and the first 10 s of the same material
+    against the CPU oracle: table within 1e-3 dB, minimum-peak angle index exact."""
+    import torch
+    import bench
+    import orc
+    from phaserotate_lv2_amd import sweep_dist
+    dev = torch.device("cuda:0")
+    n_chn, world = 2, 8
+    n = 3600 * 96000
+    x = bench._sweep_signal(torch, np, dev, n_chn, 0, n, 1234, "harmonic")
+    fl_all = pkg.F_STREAM_START | pkg.F_STREAM_END
+    one = pkg.Engine(pkg.KIND_CLI, P, n_chn)
+    pk1 = torch.zeros((n_chn, 360), device=dev)
+    torch.cuda.synchronize()
+    one.sweep_dev(x.data_ptr(), n, n, 0, 360, 1, -1, pk1.data_ptr(), fl_all)
+    one.sync()
+    ev, seen = one.sweep_stats()
+    assert seen > 0 and ev / seen < 0.1, (ev, seen)
+    A = one.shard_align_blocks()
+    H = int(one.info.history)
+    plan = sweep_dist.plan_shards(n, P, world, align=A)
+    # unpruned: the same table
+    pkg.set_test_option(pkg.TEST_SWEEP_UNPRUNED, 1)
+    try:
+        one.reset()
+        pku = torch.zeros((n_chn, 360), device=dev)
+        torch.cuda.synchronize()
+        one.sweep_dev(x.data_ptr(), n, n, 0, 360, 1, -1, pku.data_ptr(), fl_all)
+        one.sync()
+    finally:
+        pkg.set_test_option(pkg.TEST_SWEEP_UNPRUNED, 0)
+    assert torch.equal(pku, pk1)
+    one.close()
+    pk = pk1.cpu().numpy()
+    assert all(0 < int(pk[c].argmin()) < 360 for c in range(n_chn))
+    # eight frame-block shards in two phases, one engine per shard
+    engines = [pkg.Engine(pkg.KIND_CLI, P, n_chn) for _ in range(world)]
+    tabs = [torch.full((n_chn, 360), 9.0, device=dev) for _ in range(world)]
+    shards = []
+    torch.cuda.synchronize()
+    for r, e in enumerate(engines):
+        f0, nf = sweep_dist.shard_frames(n, P, plan, r)
+        fl = (pkg.F_STREAM_START if r == 0 else 0) | (pkg.F_STREAM_END if r == world - 1 else 0)
+        halo = x[:, f0 - H:f0].contiguous() if r > 0 else None
+        shards.append((f0, nf, fl, halo))
+        e.sweep_shard_seed_dev(halo.data_ptr() if r > 0 else 0, H, H if r > 0 else 0, x[:, f0:].data_ptr(), n, nf, 0, 360, 1,
+                               tabs[r].data_ptr(), fl, 8)
+        e.sync()
+    seed = torch.stack(tabs).amax(0)             # (the first all-reduce)
+    assert float(seed.max()) > 0 and bool((seed <= pk1).all())
+    for t in tabs:
+        t.copy_(seed)
+    torch.cuda.synchronize()
+    for r, e in enumerate(engines):
+        f0, nf, fl, _ = shards[r]
+        e.sweep_dev(x[:, f0:].data_ptr(), n, nf, 0, 360, 1, -1, tabs[r].data_ptr(), fl)
+        e.sync()
+    merged = torch.stack(tabs).amax(0)           # (the second all-reduce)
+    assert torch.equal(merged, pk1)
+    listed = sum(e.sweep_stats_fused()["listed"] for e in engines)
+    tested = sum(e.sweep_stats_fused()["tested"] for e in engines)
+    assert tested >= n * n_chn and listed < 0.1 * tested, (listed, tested)
+    for e in engines:
+        e.close()
+    # eight angle shards (configs[3]'s wording): every rank the whole file, every eighth angle
+    e = pkg.Engine(pkg.KIND_CLI, P, n_chn)
+    tabs = []
+    for r in range(world):
+        e.reset()
+        t = torch.zeros((n_chn, 360), device=dev)
+        torch.cuda.synchronize()
+        sweep_dist.sweep_angle_sharded(e, x, t, fl_all, world, r, 0, (0, 360, 1), allreduce=lambda t_: t_)
+        e.sync()
+        tabs.append(t)
+    assert torch.equal(torch.stack(tabs).amax(0), pk1)
+    # the first 10 s against the oracle
+    ns = 10 * 96000 // P * P
+    e.reset()
+    pk2 = torch.zeros((n_chn, 360), device=dev)
+    torch.cuda.synchronize()
+    e.sweep_dev(x.data_ptr(), n, ns, 0, 360, 1, -1, pk2.data_ptr(), fl_all)
+    e.sync()
+    e.close()
+    o = orc.CliEngine(P, n_chn)
+    o.analyze_file(np.ascontiguousarray(x[:, :ns].cpu().numpy().T).reshape(-1), 0, 360, 1)
+    pg, po = pk2.cpu().numpy(), o.peaks()
+    db = np.abs(20 * np.log10(np.maximum(pg, 1e-30)) - 20 * np.log10(np.maximum(po, 1e-30))).max()
+    assert db < 1e-3, db
+    assert [int(pg[c].argmin()) for c in range(n_chn)] == [int(po[c].argmin()) for c in range(n_chn)]
