@@ -231,12 +231,55 @@ struct pk32a : pk32 {
 	}
 };
 
+// TIMING EXPERIMENT (-DPROT_F16_MFMA_TIMING; results WRONG by design): an upper bound of what the fp16 sample
+// path would gain from radix-16 passes on the matrix core, measured IN SITU -- every packed-half radix-16 butterfly network
+// (two stages of DFT-4 and the W16 twiddles between them: ~100 v_pk_*_f16) is replaced by the instructions the matrix-core pass
+// issues instead: 4 v_mfma_f32_32x32x16_f16 (the real 32 x 32 DFT matrix, two K halves x two column halves of the wave) and the
+// 16 v_cvt_pkrtz that bring the fp32 products back to half.  The operands stand in for each other (no LDS layout change, no
+// matrix constants loaded): what is timed is the instruction mix in the kernel's own schedule, occupancy and LDS traffic.
+#ifdef PROT_F16_MFMA_TIMING
+template <class O> struct pkt_mfma_timing { static constexpr bool value = sizeof (typename O::cplx) == 4; };
+typedef _Float16 pkt_h8 __attribute__ ((ext_vector_type (8)));
+typedef float    pkt_f16v __attribute__ ((ext_vector_type (16)));
+PROT_DEV void pkt_mfma_dummy (h2 (&v)[16])
+{
+	pkt_h8 a0, a1;
+	asm volatile ("" : "=v"(a0), "=v"(a1)); // (the DFT matrix halves: registers of the kernel's lifetime in the real thing)
+	pkt_h8 b[4];
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		b[q] = pkt_h8{ v[4 * q].x, v[4 * q].y, v[4 * q + 1].x, v[4 * q + 1].y, v[4 * q + 2].x, v[4 * q + 2].y, v[4 * q + 3].x, v[4 * q + 3].y };
+	}
+	pkt_f16v z;
+#pragma unroll
+	for (int r = 0; r < 16; ++r) {
+		z[r] = 0.f;
+	}
+	pkt_f16v r0 = __builtin_amdgcn_mfma_f32_32x32x16_f16 (a0, b[0], z, 0, 0, 0);
+	r0          = __builtin_amdgcn_mfma_f32_32x32x16_f16 (a1, b[1], r0, 0, 0, 0);
+	pkt_f16v r1 = __builtin_amdgcn_mfma_f32_32x32x16_f16 (a0, b[2], z, 0, 0, 0);
+	r1          = __builtin_amdgcn_mfma_f32_32x32x16_f16 (a1, b[3], r1, 0, 0, 0);
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		v[i]     = __builtin_bit_cast (h2, __builtin_amdgcn_cvt_pkrtz (r0[2 * i], r0[2 * i + 1]));
+		v[8 + i] = __builtin_bit_cast (h2, __builtin_amdgcn_cvt_pkrtz (r1[2 * i], r1[2 * i + 1]));
+	}
+}
+template <class C> PROT_DEV void pkt_mfma_dummy (C (&)[16]) {}
+#else
+template <class O> struct pkt_mfma_timing { static constexpr bool value = false; };
+template <class C> PROT_DEV void pkt_mfma_dummy (C (&)[16]) {}
+#endif
+
 // 4-point DFT on packed values; CROT: operand c arrives un-rotated and still
 // has to be multiplied by -j (DIR > 0) / +j (DIR < 0) -- the W16^4 twiddle
 // folded into the butterfly.
 template <class O, int DIR, bool CROT = false>
 PROT_DEV void pkt_radix4 (typename O::cplx& a, typename O::cplx& b, typename O::cplx& c, typename O::cplx& d)
 {
+	if (pkt_mfma_timing<O>::value) {
+		return;
+	}
 	typename O::cplx t0, t1;
 	if (!CROT) {
 		t0 = a + c;
@@ -282,6 +325,10 @@ PROT_DEV typename O::cplx pkt_mul_w16 (typename O::cplx a)
 template <class O, int DIR>
 PROT_DEV void pkt_fft16_stage2 (typename O::cplx (&v)[16])
 {
+	if (pkt_mfma_timing<O>::value) {
+		pkt_mfma_dummy (v);
+		return;
+	}
 	pkt_radix4<O, DIR> (v[0], v[1], v[2], v[3]);
 	pkt_radix4<O, DIR> (v[4], v[5], v[6], v[7]);
 	pkt_radix4<O, DIR, true> (v[8], v[9], v[10], v[11]); // v[10] carries the pending W16^4 = -+j
@@ -298,6 +345,9 @@ PROT_DEV void pkt_fft16_stage2 (typename O::cplx (&v)[16])
 template <class O, int DIR>
 PROT_DEV void pkt_stage1_twiddles (typename O::cplx (&v)[16])
 {
+	if (pkt_mfma_timing<O>::value) {
+		return;
+	}
 	v[5]  = pkt_mul_w16<O, DIR, 1> (v[5]);
 	v[6]  = pkt_mul_w16<O, DIR, 2> (v[6]);
 	v[7]  = pkt_mul_w16<O, DIR, 3> (v[7]);
@@ -330,7 +380,7 @@ PROT_DEV void pkt_fft16_fwd_pruned (typename O::cplx (&v)[16])
 	static_assert (NNZ == 4 || (NNZ >= 8 && NNZ <= 16 && NNZ % 2 == 0), "zero-padded rows come in pairs");
 #pragma unroll
 	for (int be = 0; be < 4; ++be) {
-		const int n = (NNZ - be + 3) / 4; // non-zero inputs of this butterfly: rows be, be+4, ... < NNZ
+		const int n = pkt_mfma_timing<O>::value ? 4 : (NNZ - be + 3) / 4; // non-zero inputs of this butterfly: rows be, be+4, ... < NNZ
 		if (n == 1) { // y[al] = x[be]
 			v[4 + be] = v[8 + be] = v[12 + be] = v[be];
 		} else if (n == 2) { // DFT-4 of (a, b, 0, 0) = (a + b, a - j b, a - b, a + j b)
@@ -366,7 +416,7 @@ PROT_DEV void pkt_fft16_fwd_pruned_twout (typename O::cplx (&v)[16], const typen
 	static_assert (NNZ == 4 || (NNZ >= 8 && NNZ <= 16 && NNZ % 2 == 0), "zero-padded rows come in pairs");
 #pragma unroll
 	for (int be = 0; be < 4; ++be) {
-		const int n = (NNZ - be + 3) / 4;
+		const int n = pkt_mfma_timing<O>::value ? 4 : (NNZ - be + 3) / 4;
 		if (n == 1) {
 			v[4 + be] = v[8 + be] = v[12 + be] = v[be];
 		} else if (n == 2) {
@@ -417,6 +467,9 @@ template <int I> struct pkt_idx { static constexpr int value = I; };
 template <class O, int DIR, class S>
 PROT_DEV void pkt_fft16_stage2_each (typename O::cplx (&v)[16], S&& sink)
 {
+	if (pkt_mfma_timing<O>::value) {
+		pkt_mfma_dummy (v);
+	}
 	pkt_radix4<O, DIR> (v[0], v[1], v[2], v[3]);
 	sink (pkt_idx<0>{}, v[0], v[1], v[2], v[3]);
 	pkt_radix4<O, DIR> (v[4], v[5], v[6], v[7]);
@@ -433,7 +486,7 @@ PROT_DEV void pkt_fft16_fwd_pruned_twout_stage1 (typename O::cplx (&v)[16], cons
 	static_assert (NNZ == 4 || (NNZ >= 8 && NNZ <= 16 && NNZ % 2 == 0), "zero-padded rows come in pairs");
 #pragma unroll
 	for (int be = 0; be < 4; ++be) {
-		const int n = (NNZ - be + 3) / 4;
+		const int n = pkt_mfma_timing<O>::value ? 4 : (NNZ - be + 3) / 4;
 		if (n == 1) {
 			v[4 + be] = v[8 + be] = v[12 + be] = v[be];
 		} else if (n == 2) {

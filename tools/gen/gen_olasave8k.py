@@ -513,7 +513,8 @@ class Gen8k(Gen):
         self.cmul(B[3], B[2], self.TB1, 1, sc[1])
         # the previous block's last exchange has been read by both waves that share a column: its slots may be written
         self.stamp(2)
-        P.s_barrier()
+        if "nob1" not in self.opts:     # (timing experiment: results may be wrong)
+            P.s_barrier()
         self.stamp(3)
         up, done = self.label("L_wu"), self.label("L_wd")
         P.settle(list(v) + sc + [B[2], B[3]])
@@ -590,7 +591,8 @@ class Gen8k(Gen):
         fetch(0)
         if DIR > 0:
             # every wave has read both halves of its columns of the first exchange: the chunks (which lie in them) may be written
-            P.s_barrier()
+            if "nob3" not in self.opts:     # (timing experiment: results may be wrong)
+                P.s_barrier()
             self.stamp(7)
         for ka in range(4):
             self.run_ops(bfl[ka])
@@ -1622,7 +1624,7 @@ if __name__ == "__main__":
     if "--variant" in sys.argv:   # timing experiments: python3 gen_olasave8k.py --variant NAME --opts a,b  -> csrc/variants/
         name = sys.argv[sys.argv.index("--variant") + 1]
         opts = [o for o in sys.argv[sys.argv.index("--opts") + 1].split(",") if o] if "--opts" in sys.argv else []
-        wrong = {"nolds", "nomem", "novalu", "cyclic"} & set(opts)
+        wrong = {"nolds", "nomem", "novalu", "cyclic", "nob1", "nob3"} & set(opts)
         if not wrong:
             for HS, MODE in VARIANTS:
                 self_test(HS, MODE, nblk=2, opts=opts, verbose=False)
