@@ -744,8 +744,22 @@ def bench_run_host(pkg, np, local_rank):
                 g.close()
     except Exception as ex:  # noqa: BLE001
         multi["error"] = repr(ex)
+    # deferred run() (round 6, prot_lv2_set_deferred): a call posts its block and returns the block before without waiting; calls
+    # 150 us apart (a 64-frame period at 48 kHz is 1333 us), each timed by itself, looped in C -- the blocking route the same way beside it
+    rt = None
+    try:
+        g = pkg.Lv2Instance(48000, 1, device=local_rank)
+        g.activate()
+        mb, wb = g.time_lv2_run_paced(1024, 2000, 150)
+        g.lv2_set_deferred(1024)
+        md, wd = g.time_lv2_run_paced(1024, 2000, 150)
+        rt = dict(g.lv2_deferred_stats(), us_per_run=md, worst_single_call_us=wd, blocking_us_per_run=mb, blocking_worst_single_call_us=wb,
+                  extra_latency_frames=1024, calls=2000, gap_us=150)
+        g.close()
+    except Exception as ex:  # noqa: BLE001
+        rt = {"error": repr(ex)[:200]}
     dt = res["server_c"]
-    return {"instances_in_turn": dict(multi, note="1024-frame run() calls on each instance in turn, looped in C (prot_internal_time_lv2_run_multi); us_per_run is per "
+    return {"rt_mode": rt, "instances_in_turn": dict(multi, note="1024-frame run() calls on each instance in turn, looped in C (prot_internal_time_lv2_run_multi); us_per_run is per "
                                                    "CALL; every instance is a set of slots of the one resident kernel"),
             "workload": "prot_lv2_run, mono 48 kHz, 1024-frame host buffers, through the run() server (resident kernel; mailbox in device memory "
                         "that the CPU stores into through the PCIe BAR, doorbell, done word in pinned host memory: no launch and no stream sync "

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define PROT_ABI_VERSION 6
+#define PROT_ABI_VERSION 7
 #define PROT_SUBSAMPLE 2                      /* cli/phase-rotate.cc:38 */
 #define PROT_MAXSAMPLE (180 * PROT_SUBSAMPLE) /* cli/phase-rotate.cc:39 */
 
@@ -236,6 +236,22 @@ int prot_lv2_run (prot_engine* e, const float* const* in, float* const* out,
  * buffers are reserved by prot_engine_create for 8192 frames per call and raised here (instantiate / activate
  * time, e.g. from the host's options:maxBlockLength); longer calls are processed in chunks of that length. */
 int prot_lv2_set_max_block (prot_engine* e, uint32_t frames);
+
+/* DEFERRED run() (ABI 7; opt-in, default off): the mode in which prot_lv2_run never waits for the device, so that a bundle
+ * may declare lv2:hardRTCapable again (lv2ttl/phaserotate.ports.in:7).  frames > 0: a call posts its block to the resident
+ * kernel and returns at once with the output `frames` frames OLDER -- the blocking route's samples, delayed by exactly
+ * `frames` more (the host adds it to the latency port, src/phaserotate.c:788; the first `frames` frames after a reset are
+ * silence).  Calls longer than `frames` are taken in pieces of that length, and wait for the device between the pieces.  If the block of the call before is not back
+ * when a call arrives -- a device that is late by a whole period -- silence goes out in its place and the call's own
+ * frames are not posted: both are counted (prot_lv2_deferred_stats), nothing waits.  What still blocks: the first call
+ * after a reset or after 0.25 s without calls (the kernel is started: 0.1-0.3 ms), a call while another thread creates,
+ * destroys, resets or synchronises an engine (the launch route), calls of more than one transform block per channel.
+ * While the mode is on the resident kernel has no age limit (it leaves when idle or told to).  frames = 0: off.
+ * Call it where activate() may be called (it synchronises); PROT_EUNSUPPORTED for engines whose run() is launched
+ * (more than 16 channels, pipelined, direct-form engines). */
+int prot_lv2_set_deferred (prot_engine* e, uint32_t frames);
+/* calls whose predecessor's block was late (silence went out in its place) / calls whose own frames were never posted */
+int prot_lv2_deferred_stats (prot_engine* e, uint64_t* late, uint64_t* dropped);
 
 /* Channel.angle (src/phaserotate.c:53, :560, :725): the interpolated rotation
  * state in turns after the last run; the host compares it with the port's

@@ -42,7 +42,7 @@ ABI_SYMBOLS = (
     "prot_engine_create", "prot_engine_destroy", "prot_engine_reset", "prot_engine_info",
     "prot_engine_fir", "prot_engine_sync",
     "prot_apply_dev", "prot_apply_dev_ramp", "prot_apply_dev_f16", "prot_apply_dev_f16_ramp", "prot_sweep_dev",
-    "prot_lv2_run", "prot_lv2_set_max_block", "prot_lv2_get_angle", "prot_cli_apply", "prot_cli_analyze", "prot_cli_analyze_file",
+    "prot_lv2_run", "prot_lv2_set_max_block", "prot_lv2_set_deferred", "prot_lv2_deferred_stats", "prot_lv2_get_angle", "prot_cli_apply", "prot_cli_analyze", "prot_cli_analyze_file",
     "prot_cli_apply_file", "prot_cli_peak", "prot_cli_peak_all", "prot_cli_peaks",
     "prot_cli_peaks_dev", "prot_allreduce_peaks", "prot_cli_analyze_file_multi", "prot_sweep_stats",
     "prot_sweep_stats_ex", "prot_sweep_stats_fused", "prot_cli_file_resident",
@@ -120,6 +120,8 @@ def load_library():
                                        C.c_int64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.prot_apply_dev_f16_ramp.argtypes = lib.prot_apply_dev_f16.argtypes
     lib.prot_lv2_set_max_block.argtypes = [C.c_void_p, C.c_uint32]
+    lib.prot_lv2_set_deferred.argtypes = [C.c_void_p, C.c_uint32]
+    lib.prot_lv2_deferred_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.prot_sweep_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.prot_sweep_seed_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_int, C.c_int,
@@ -242,6 +244,15 @@ class Engine:
     def lv2_set_max_block(self, frames):
         _check(self._lib.prot_lv2_set_max_block(self._h, frames), "prot_lv2_set_max_block")
 
+    def lv2_set_deferred(self, frames):
+        """deferred run(): a call posts its block and returns the output `frames` frames older without waiting (0: off)"""
+        _check(self._lib.prot_lv2_set_deferred(self._h, frames), "prot_lv2_set_deferred")
+
+    def lv2_deferred_stats(self):
+        late, dropped = C.c_uint64(0), C.c_uint64(0)
+        _check(self._lib.prot_lv2_deferred_stats(self._h, C.byref(late), C.byref(dropped)), "prot_lv2_deferred_stats")
+        return {"late": late.value, "dropped": dropped.value}
+
     def hilbert_dev(self, d_in, in_stride, n_in, d_out, out_stride, n_out, flags=0, stream=0):
         _check(self._lib.prot_apply_dev(self._h, d_in, in_stride, n_in, d_out, out_stride, n_out,
                                         None, flags | F_HILBERT, stream), "prot_apply_dev")
@@ -283,6 +294,14 @@ class Engine:
         _check(self._lib.prot_internal_time_lv2_run(self._h, frames, calls, us), "prot_internal_time_lv2_run")
         self.last_worst_call = (us[1], int(us[2]))
         return us[0]
+
+    def time_lv2_run_paced(self, frames, calls, gap_us):
+        """(mean, slowest) microseconds of a prot_lv2_run call BY ITSELF, `gap_us` of busy-waiting between calls, looped in C"""
+        us = (C.c_double * 3)()
+        self._lib.prot_internal_time_lv2_run_paced.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_double)]
+        self._lib.prot_internal_time_lv2_run_paced.restype = C.c_int
+        _check(self._lib.prot_internal_time_lv2_run_paced(self._h, frames, calls, gap_us, us), "prot_internal_time_lv2_run_paced")
+        return us[0], us[1]
 
     def server_stats(self):
         """{calls, starts}: run() calls the resident server kernel has taken / kernels started for it (test hook)."""

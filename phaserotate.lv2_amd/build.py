@@ -91,7 +91,7 @@ def build_lib(force=False, verbose=False):
     if force or _newer(capi_hooks, [capi_src, os.path.join(CSRC, "prot_internal.h")] + hdrs):
         _run(common + ["-DPROT_TESTHOOKS", "-c", capi_src, "-o", capi_hooks])
     names = declared_symbols()
-    internal = ["prot_internal_set_rccl_library", "prot_internal_set_test_option", "prot_internal_fused_lists", "prot_internal_time_lv2_run", "prot_internal_time_lv2_run_multi",
+    internal = ["prot_internal_set_rccl_library", "prot_internal_set_test_option", "prot_internal_fused_lists", "prot_internal_time_lv2_run", "prot_internal_time_lv2_run_paced", "prot_internal_time_lv2_run_multi",
                 "prot_internal_server_stats"]
     if force or _newer(LIB, objs + [os.path.join(ROOT, "include", "prot_hip.h")]):
         vs = _version_script(os.path.join(OBJDIR, "exports.map"), names)

@@ -532,6 +532,18 @@ struct prot_engine {
 	uint32_t       srv_seq     = 0;      // number of the last call posted
 	uint64_t       srv_calls   = 0;      // calls the server took / kernels started for it (prot_internal_server_stats)
 	uint64_t       srv_starts  = 0;
+	// DEFERRED run() (prot_lv2_set_deferred; round 6): a call posts its block to the server and returns WITHOUT waiting for it; what
+	// it hands back is the output `rt_frames` frames older, out of a host ring that the next call tops up with the block posted by
+	// this one.  rt_frames = 0: off (every call waits for its own block).
+	uint32_t           rt_frames   = 0;     // the extra latency, = the longest call the mode takes in one piece
+	std::vector<float> rt_ring;             // [n_chn][rt_cap]
+	uint32_t           rt_cap = 0, rt_rd = 0, rt_fill = 0;
+	bool               rt_pending  = false; // a block is with the server (or, rt_pend_ready, was computed by a blocking route)
+	bool               rt_pend_ready = false;
+	bool               rt_discard  = false; // ... and silence has already gone into the ring in its place: it arrived late
+	uint32_t           rt_pend_seq = 0, rt_pend_n = 0, rt_skip_n = 0;
+	const float*       rt_pend_out = nullptr;
+	uint64_t           rt_late = 0, rt_dropped = 0;
 	// small host->device parameter copies (rotation pairs, angle lists) are staged through a ring of
 	// pinned slots owned by the engine, each guarded by an event: the caller's array may die as soon
 	// as the call returns, and a slot is never rewritten before its previous copy has been consumed
@@ -581,6 +593,7 @@ struct prot_engine {
 	std::vector<float> h_peaks; // host mirror for prot_cli_peak
 	bool               h_peaks_valid = false;
 };
+static void rt_ring_reset (prot_engine* e); // (deferred run(): the ring back to rt_frames frames of silence)
 
 namespace {
 
@@ -1165,6 +1178,26 @@ hipStream_t               g_srv_stream = nullptr; // the stream the running kern
 // resident kernel.  run() takes the launch route while the count is non-zero.
 int g_srv_hold = 0;
 
+// deferred run(): wait (bounded) until the block the engine posted last has been served -- the server is about to be told to leave
+void rt_wait_pending (prot_engine* o)
+{
+	if (!o->rt_pending || o->rt_pend_ready) {
+		return;
+	}
+	prot::SvServerAck* a  = o->srv_ack.p;
+	const auto         t0 = std::chrono::steady_clock::now ();
+	for (uint32_t c = 0; c < o->info.n_chn;) {
+		if (__atomic_load_n (&a->done[c], __ATOMIC_ACQUIRE) == o->rt_pend_seq) {
+			++c;
+			continue;
+		}
+		if (__atomic_load_n (&a->alive, __ATOMIC_ACQUIRE) == 0u || std::chrono::steady_clock::now () - t0 > std::chrono::seconds (2)) {
+			return; // (left without it, or not answering: rt_collect deals with that)
+		}
+	}
+	o->rt_pend_ready = true; // (its output stays in the pinned block until the next run() takes it)
+}
+
 int server_stop_locked ()
 {
 	if (g_srv_members.empty ()) {
@@ -1175,6 +1208,7 @@ int server_stop_locked ()
 	for (prot_engine* o : members) { // every engine's workgroups leave on their own doorbell
 		if (o->srv_running) {
 			prot::SvServerBox* b = reinterpret_cast<prot::SvServerBox*> (o->srv_box);
+			rt_wait_pending (o); // (deferred run(): the block it posted last is still the server's to do -- a leave command would overwrite its doorbell)
 			o->srv_seq           = (o->srv_seq % (1u << 30)) + 1u;
 			_mm_sfence ();
 			__atomic_store_n (&b->bell, (uint64_t)o->srv_seq | ((uint64_t)1 << 63), __ATOMIC_RELEASE);
@@ -1247,9 +1281,21 @@ int server_start_locked (prot_engine* e)
 		g_srv_roster.push_back (e);
 	}
 	prot::SvServerSlots slots {};
+	// (a failure anywhere below leaves NO engine of the roster marked alive with a kernel that never started)
+	auto undo = [&] () {
+		for (prot_engine* o : g_srv_roster) {
+			o->srv_ack.p->alive = 0u;
+		}
+	};
 	for (prot_engine* o : g_srv_roster) {
-		HIP_TRY (hipEventRecord (o->srv_ev, o->stream));
-		HIP_TRY (hipStreamWaitEvent (e->srv_stream, o->srv_ev, 0));
+		hipError_t herr = hipEventRecord (o->srv_ev, o->stream);
+		if (herr == hipSuccess) {
+			herr = hipStreamWaitEvent (e->srv_stream, o->srv_ev, 0);
+		}
+		if (herr != hipSuccess) {
+			undo ();
+			return hip_fail (herr, "run() server start (ordering behind an engine's stream)");
+		}
 		prot::SvServerBox* b = reinterpret_cast<prot::SvServerBox*> (o->srv_box);
 		prot::SvServerAck* a = o->srv_ack.p;
 		__atomic_store_n (&b->bell, (uint64_t)o->srv_seq, __ATOMIC_RELEASE);
@@ -1264,13 +1310,12 @@ int server_start_locked (prot_engine* e)
 			sl.chn      = (int)c;
 			sl.n_chn    = (int)o->info.n_chn;
 			sl.hop_rows = o->hopseg / 2;
+			sl.no_life_cap = o->rt_frames > 0 ? 1 : 0; // (deferred run(): a restart every two seconds would be two buffers of silence)
 		}
 	}
 	hipError_t err = prot::launch_ola_save_server (slots, e->srv_stream);
 	if (err != hipSuccess) {
-		for (prot_engine* o : g_srv_roster) {
-			o->srv_ack.p->alive = 0u;
-		}
+		undo ();
 		return hip_fail (err, "run() server launch");
 	}
 	for (prot_engine* o : g_srv_roster) {
@@ -2105,6 +2150,9 @@ int prot_engine_reset (prot_engine* e)
 	}
 	e->sweep_seeded_ext = false;
 	e->seed_chunk_ready = false;
+	if (e->rt_frames > 0) { // deferred run(): rt_frames frames of silence again (activate: src/phaserotate.c:538-560 clears every buffer)
+		rt_ring_reset (e);
+	}
 	e->last_foreign   = false; // (whatever comes next is ordered behind the engine's stream, which is behind that call)
 	e->last_stream_id = nullptr;
 	return PROT_OK;
@@ -2951,13 +2999,133 @@ int prot_lv2_set_max_block (prot_engine* e, uint32_t frames)
 	return lv2_reserve (e, frames);
 }
 
+// ---- deferred run() (prot_lv2_set_deferred): the host ring and the block that is with the server ----
+// The ring holds rt_frames frames when a call arrives at rt_pop: every call pushes the block of the call BEFORE it (its output, or
+// silence when that is late / was never posted) and pops its own length, so what a call returns is the blocking route's output
+// rt_frames frames later -- whatever the calls' lengths (each <= rt_frames).
+static void rt_push (prot_engine* e, const float* src, uint32_t n)
+{
+	const uint32_t nc = e->info.n_chn, cap = e->rt_cap;
+	if (n > cap - e->rt_fill) {
+		n = cap - e->rt_fill; // (cannot happen while every call is <= rt_frames)
+	}
+	const uint32_t wr = (e->rt_rd + e->rt_fill) % cap, n0 = std::min (n, cap - wr);
+	for (uint32_t c = 0; c < nc; ++c) {
+		float* r = e->rt_ring.data () + (size_t)c * cap;
+		if (src) {
+			memcpy (r + wr, src + (size_t)c * n, n0 * sizeof (float));
+			memcpy (r, src + (size_t)c * n + n0, (n - n0) * sizeof (float));
+		} else {
+			memset (r + wr, 0, n0 * sizeof (float));
+			memset (r, 0, (n - n0) * sizeof (float));
+		}
+	}
+	e->rt_fill += n;
+}
+static void rt_pop (prot_engine* e, float* const* out, uint32_t off, uint32_t n)
+{
+	const uint32_t nc = e->info.n_chn, cap = e->rt_cap;
+	const uint32_t m = std::min (n, e->rt_fill), n0 = std::min (m, cap - e->rt_rd);
+	for (uint32_t c = 0; c < nc; ++c) {
+		const float* r = e->rt_ring.data () + (size_t)c * cap;
+		memcpy (out[c] + off, r + e->rt_rd, n0 * sizeof (float));
+		memcpy (out[c] + off + n0, r, (m - n0) * sizeof (float));
+		if (m < n) {
+			memset (out[c] + off + m, 0, (n - m) * sizeof (float));
+		}
+	}
+	e->rt_rd   = (e->rt_rd + m) % cap;
+	e->rt_fill -= m;
+}
+static void rt_ring_reset (prot_engine* e)
+{
+	std::fill (e->rt_ring.begin (), e->rt_ring.end (), 0.f);
+	e->rt_rd = 0;
+	e->rt_fill = e->rt_frames;
+	e->rt_pending = e->rt_pend_ready = e->rt_discard = false;
+	e->rt_skip_n = 0;
+}
+// the block posted by the call before this one: into the ring if it is there (ONE look at the done words, no waiting), silence in
+// its place -- and its output thrown away when it arrives -- if it is not
+static int rt_collect (prot_engine* e, bool wait)
+{
+	if (e->rt_pending) {
+		prot::SvServerAck* a = e->srv_ack.p;
+		if (wait) { // (the second and later pieces of ONE call longer than rt_frames: there is no period between them to wait out)
+			rt_wait_pending (e);
+		}
+		bool done = e->rt_pend_ready;
+		auto look = [&] () {
+			bool all = true;
+			for (uint32_t c = 0; c < e->info.n_chn && all; ++c) {
+				all = __atomic_load_n (&a->done[c], __ATOMIC_ACQUIRE) == e->rt_pend_seq;
+			}
+			return all;
+		};
+		if (!done) {
+			done = look ();
+		}
+		if (!done && __atomic_load_n (&a->alive, __ATOMIC_ACQUIRE) == 0u) {
+			// the server left (idle time-out) between the check in front of the doorbell and the doorbell: started again with the
+			// number of the call before, it takes the block at once (what the blocking route does in its wait loop; rare, and it blocks)
+			std::lock_guard<std::mutex> lk (g_srv_mu);
+			int rc = server_stop_locked ();
+			if (rc) {
+				return rc;
+			}
+			done = look ();
+			if (!done && g_srv_hold == 0) {
+				prot::SvServerBox* b = reinterpret_cast<prot::SvServerBox*> (e->srv_box);
+				e->srv_running = false;
+				e->srv_seq     = e->rt_pend_seq - 1u;
+				rc             = server_start_locked (e);
+				e->srv_seq     = e->rt_pend_seq;
+				if (rc) {
+					return rc;
+				}
+				_mm_sfence ();
+				__atomic_store_n (&b->bell, (uint64_t)e->rt_pend_seq | ((uint64_t)e->rt_pend_n << 32), __ATOMIC_RELEASE);
+				_mm_sfence ();
+			}
+		}
+		if (done) {
+			if (!e->rt_discard) {
+				rt_push (e, e->rt_pend_out, e->rt_pend_n);
+			}
+			e->rt_pending = e->rt_pend_ready = e->rt_discard = false;
+		} else if (!e->rt_discard) {
+			rt_push (e, nullptr, e->rt_pend_n);
+			e->rt_discard = true;
+			e->rt_late++;
+		}
+	}
+	if (e->rt_skip_n) { // (the call before this one found the server busy: its block was never posted)
+		rt_push (e, nullptr, e->rt_skip_n);
+		e->rt_skip_n = 0;
+	}
+	return PROT_OK;
+}
+
 // one call of at most lv2_max_block frames, `off` frames into the host's port buffers
 static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* out, uint32_t off, uint32_t n_samples,
-                          const float* angle_deg)
+                          const float* angle_deg, bool wait_pending)
 {
 	const uint32_t nc = e->info.n_chn;
 	const uint32_t P  = e->info.blksiz;
 	const size_t   n  = n_samples;
+	const bool     deferred = e->rt_frames > 0;
+	if (deferred) {
+		int rcd = rt_collect (e, wait_pending);
+		if (rcd) {
+			return rcd;
+		}
+		if (e->rt_pending) { // the block before this one is still with the device: this call's frames cannot be posted (counted)
+			e->rt_skip_n = n_samples;
+			e->rt_dropped++;
+			rt_pop (e, out, off, n_samples);
+			return PROT_OK;
+		}
+	}
 	// (another engine's run() server stays: this call is itself a run(); this engine's own is stopped below if the call
 	// does not go through it)
 	CallStream    s (e, nullptr, /*keep_server*/ true);
@@ -3104,10 +3272,17 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 					_mm_sfence (); // (write-combined stores through the BAR: parameters and frames before the doorbell)
 					__atomic_store_n (&b->bell, bell, __ATOMIC_RELEASE);
 					_mm_sfence ();
+					if (deferred) { // the block is the server's now; the next call collects it (rt_collect)
+						e->rt_pending    = true;
+						e->rt_pend_ready = e->rt_discard = false;
+						e->rt_pend_seq   = seq;
+						e->rt_pend_n     = n_samples;
+						e->rt_pend_out   = h_out;
+					}
 					// wait for every channel's done word; a server that left by itself between the check above and the doorbell
 					// (idle time-out) is started again -- with the number of the last served call, so that it takes this one at once
 					const auto t_0 = std::chrono::steady_clock::now ();
-					for (uint32_t c = 0; c < nc;) {
+					for (uint32_t c = 0; c < nc && !deferred;) {
 						if (__atomic_load_n (&a->done[c], __ATOMIC_ACQUIRE) == seq) {
 							++c;
 							continue;
@@ -3164,11 +3339,26 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 			}
 		}
 	}
-	if (served) {
-		e->pos += n;
+	// deferred mode, a block a blocking route has just computed: it waits in the pinned block like a posted one
+	auto hand_back = [&] () {
+		if (deferred) {
+			if (!served) {
+				e->rt_pending    = true;
+				e->rt_pend_ready = true;
+				e->rt_discard    = false;
+				e->rt_pend_n     = n_samples;
+				e->rt_pend_out   = h_out;
+			}
+			rt_pop (e, out, off, n_samples);
+			return;
+		}
 		for (uint32_t c = 0; c < nc; ++c) {
 			memcpy (out[c] + off, h_out + c * n, n * sizeof (float));
 		}
+	};
+	if (served) {
+		e->pos += n;
+		hand_back ();
 		return PROT_OK;
 	}
 	if (!staged) {
@@ -3188,9 +3378,7 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 		}
 		e->pos += n;
 		HIP_TRY (hipStreamSynchronize (s)); // (polling hipStreamQuery instead measured the same: the runtime already spins)
-		for (uint32_t c = 0; c < nc; ++c) {
-			memcpy (out[c] + off, h_out + c * n, n * sizeof (float));
-		}
+		hand_back ();
 		return PROT_OK;
 	}
 	{ // (the staged route uses the engine's stream and history: not beside this engine's own server)
@@ -3222,9 +3410,7 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 	}
 	HIP_TRY (hipMemcpyAsync (h_out, e->d_out.p, n * nc * sizeof (float), hipMemcpyDeviceToHost, s));
 	HIP_TRY (hipStreamSynchronize (s));
-	for (uint32_t c = 0; c < nc; ++c) {
-		memcpy (out[c] + off, h_out + c * n, n * sizeof (float));
-	}
+	hand_back ();
 	return PROT_OK;
 }
 
@@ -3240,8 +3426,9 @@ int prot_lv2_run (prot_engine* e, const float* const* in, float* const* out, uin
 	HIP_TRY (hipSetDevice (e->device));
 	// calls longer than the reserved block length are cut up: the callback never allocates (src/phaserotate.c run()
 	// does not either).  In-place port buffers (in == out) are fine: a chunk's input is copied out before its output lands
-	for (uint32_t off = 0; off < n_samples; off += e->lv2_max_block) {
-		const int rc = lv2_run_chunk (e, in, out, off, std::min (e->lv2_max_block, n_samples - off), angle_deg);
+	const uint32_t step = e->rt_frames > 0 ? std::min (e->lv2_max_block, e->rt_frames) : e->lv2_max_block;
+	for (uint32_t off = 0; off < n_samples; off += step) {
+		const int rc = lv2_run_chunk (e, in, out, off, std::min (step, n_samples - off), angle_deg, /*wait_pending*/ off > 0);
 		if (rc) {
 			return rc;
 		}
@@ -3255,6 +3442,52 @@ int prot_lv2_get_angle (prot_engine* e, uint32_t chn, float* angle_turns)
 		return PROT_EINVAL;
 	}
 	*angle_turns = e->lv2[chn].angle;
+	return PROT_OK;
+}
+
+int prot_lv2_set_deferred (prot_engine* e, uint32_t frames)
+{
+	if (!e || e->info.kind != PROT_KIND_LV2 || frames > (1u << 20)) {
+		return PROT_EINVAL;
+	}
+	if (frames > 0 && !e->srv_eligible) {
+		snprintf (g_err, sizeof (g_err), "prot_lv2_set_deferred: this engine's run() does not go through the resident kernel");
+		return PROT_EUNSUPPORTED;
+	}
+	HIP_TRY (hipSetDevice (e->device));
+	ServerHold srv_hold; // (the server leaves -- behind the block it may still hold -- and comes back without / with its age limit)
+	(void)join_pipe (e, e->stream);
+	HIP_TRY (sync_own (e));
+	if (frames > 0) {
+		const int rc = lv2_reserve (e, std::max (frames, e->lv2_max_block));
+		if (rc) {
+			return rc;
+		}
+		try {
+			e->rt_ring.assign ((size_t)2 * frames * e->info.n_chn, 0.f);
+		} catch (...) {
+			return PROT_ENOMEM;
+		}
+	} else {
+		std::vector<float> ().swap (e->rt_ring);
+	}
+	e->rt_frames = frames;
+	e->rt_cap    = 2 * frames;
+	rt_ring_reset (e);
+	return PROT_OK;
+}
+
+int prot_lv2_deferred_stats (prot_engine* e, uint64_t* late, uint64_t* dropped)
+{
+	if (!e || e->info.kind != PROT_KIND_LV2) {
+		return PROT_EINVAL;
+	}
+	if (late) {
+		*late = e->rt_late;
+	}
+	if (dropped) {
+		*dropped = e->rt_dropped;
+	}
 	return PROT_OK;
 }
 
@@ -3822,6 +4055,51 @@ int prot_internal_time_lv2_run (prot_engine* e, uint32_t frames, uint32_t calls,
 	us[0] = std::chrono::duration<double, std::micro> (t_p - t_0).count () / calls;
 	us[1] = worst;            // the slowest single call
 	us[2] = (double)worst_at; // ... and which
+	return PROT_OK;
+}
+
+int prot_internal_time_lv2_run_paced (prot_engine* e, uint32_t frames, uint32_t calls, uint32_t gap_us, double us[3])
+{
+	if (!e || !us || e->info.kind != PROT_KIND_LV2 || frames == 0 || calls == 0) {
+		return PROT_EINVAL;
+	}
+	const uint32_t nc = e->info.n_chn;
+	std::vector<float>        buf ((size_t)2 * nc * frames);
+	std::vector<const float*> in (nc);
+	std::vector<float*>       out (nc);
+	std::vector<float>        ang (nc, 90.f);
+	uint32_t                  x = 12345u;
+	for (size_t i = 0; i < (size_t)nc * frames; ++i) {
+		x ^= x << 13, x ^= x >> 17, x ^= x << 5;
+		buf[i] = (float)(x >> 8) * (1.f / 16777216.f) - 0.5f;
+	}
+	for (uint32_t c = 0; c < nc; ++c) {
+		in[c]  = buf.data () + (size_t)c * frames;
+		out[c] = buf.data () + (size_t)(nc + c) * frames;
+	}
+	double   sum = 0.0, worst = 0.0;
+	uint32_t worst_at = 0;
+	for (uint32_t k = 0; k < 50 + calls; ++k) {
+		const auto t_a = std::chrono::steady_clock::now ();
+		const int  rc  = prot_lv2_run (e, in.data (), out.data (), frames, ang.data ());
+		if (rc) {
+			return rc;
+		}
+		const auto   t_b = std::chrono::steady_clock::now ();
+		const double d   = std::chrono::duration<double, std::micro> (t_b - t_a).count ();
+		if (k >= 50) {
+			sum += d;
+			if (d > worst) {
+				worst    = d;
+				worst_at = k - 50;
+			}
+		}
+		while (std::chrono::duration<double, std::micro> (std::chrono::steady_clock::now () - t_b).count () < (double)gap_us) {
+		}
+	}
+	us[0] = sum / calls;
+	us[1] = worst;
+	us[2] = (double)worst_at;
 	return PROT_OK;
 }
 

@@ -29,6 +29,9 @@ int prot_internal_fused_lists (struct prot_engine* e, unsigned long long out[4])
 // thread sees, without a binding in between)
 int prot_internal_time_lv2_run (struct prot_engine* e, unsigned frames, unsigned calls, double us[3]); // mean, slowest call, its index
 int prot_internal_time_lv2_run_multi (struct prot_engine* const* es, unsigned n, unsigned frames, unsigned calls, double us[3]); // the same, n engines in turn
+// the same with `gap_us` microseconds of busy-waiting between two calls (an audio period, scaled down: what a deferred run() needs
+// to find its last block served) and each call timed BY ITSELF: us = { mean call, slowest call, its index }
+int prot_internal_time_lv2_run_paced (struct prot_engine* e, unsigned frames, unsigned calls, unsigned gap_us, double us[3]);
 // the run() server of an LV2 engine: out = { calls it has taken, kernels started for it }
 int prot_internal_server_stats (struct prot_engine* e, unsigned long long out[2]);
 #ifdef __cplusplus

@@ -144,6 +144,7 @@ struct SvServerSlot {
 	unsigned           last_seq; // the number of the last call the engine's server took
 	int                chn, n_chn; // the slot's channel / the channels of its engine
 	int                hop_rows; // 8 or 10: the engine's block (olasave_body<HS>)
+	int                no_life_cap; // 1: the engine's workgroups leave when idle or told to, never by age (deferred run())
 };
 struct SvServerSlots {
 	int          n;

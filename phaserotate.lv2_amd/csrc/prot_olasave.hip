@@ -639,7 +639,7 @@ constexpr uint64_t kServerLifeTicks = 200000000ull;
 // LV2 engine of the process that asks (a slot per channel, up to kServerMaxChn in all) -- a second resident kernel would share a
 // hardware queue with the first sooner or later and wait behind it for as long as it stays.
 template <int HS>
-PROT_DEV void server_loop (const SvServerBox* const box, SvServerAck* const ack, unsigned* const relay, const unsigned last_seq, const int chn, const int n_chn,
+PROT_DEV void server_loop (const SvServerBox* const box, SvServerAck* const ack, unsigned* const relay, const unsigned last_seq, const int chn, const int n_chn, const int no_life_cap,
                            f2* const smem, float* const sw_lo_s, unsigned* const sh_w, float* const sh_in, unsigned* const sh_p)
 {
 	const float* const port_in = reinterpret_cast<const float*> (reinterpret_cast<const char*> (box) + kServerInOffset);
@@ -683,7 +683,7 @@ PROT_DEV void server_loop (const SvServerBox* const box, SvServerAck* const ack,
 						break;
 					}
 					const uint64_t now = __builtin_amdgcn_s_memrealtime ();
-					if (now - t_0 > kServerIdleTicks || now - t_born > kServerLifeTicks) {
+					if (now - t_0 > kServerIdleTicks || (!no_life_cap && now - t_born > kServerLifeTicks)) {
 						cmd = 1u;
 						break;
 					}
@@ -785,9 +785,9 @@ __global__ __launch_bounds__ (256, 1) void olasave_server_kernel (const SvServer
 	__shared__ __attribute__ ((aligned (16))) unsigned sh_p[(sizeof (OlaParams) + 3) / 4]; // the call's parameters (read in place)
 	const SvServerSlot& sl = slots.s[blockIdx.y];
 	if (sl.hop_rows == 8) {
-		server_loop<8> (sl.box, sl.ack, sl.relay, sl.last_seq, sl.chn, sl.n_chn, smem, sw_lo_s, sh_w, sh_in, sh_p);
+		server_loop<8> (sl.box, sl.ack, sl.relay, sl.last_seq, sl.chn, sl.n_chn, sl.no_life_cap, smem, sw_lo_s, sh_w, sh_in, sh_p);
 	} else {
-		server_loop<10> (sl.box, sl.ack, sl.relay, sl.last_seq, sl.chn, sl.n_chn, smem, sw_lo_s, sh_w, sh_in, sh_p);
+		server_loop<10> (sl.box, sl.ack, sl.relay, sl.last_seq, sl.chn, sl.n_chn, sl.no_life_cap, smem, sw_lo_s, sh_w, sh_in, sh_p);
 	}
 }
 

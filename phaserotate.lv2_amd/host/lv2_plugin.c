@@ -274,7 +274,6 @@ static LV2_Handle
 instantiate (const LV2_Descriptor* descriptor, double rate, const char* bundle_path,
              const LV2_Feature* const* features)
 {
-	(void)bundle_path;
 	Plugin* self = (Plugin*)calloc (1, sizeof (Plugin));
 	if (!self) {
 		return NULL;
@@ -372,6 +371,37 @@ instantiate (const LV2_Descriptor* descriptor, double rate, const char* bundle_p
 	prot_info info;
 	prot_engine_info (self->engine, &info);
 	self->latency = info.latency; /* 1792 / 2560 / 5120, src/phaserotate.c:297 */
+
+	/* Deferred run() (opt-in): run() posts its period to the device and returns the period before -- it never waits, which is what
+	 * lets a bundle declare lv2:hardRTCapable (lv2ttl/phaserotate.ports.in:7) -- at the price of D more frames of latency, reported
+	 * on the latency port like the rest (:788).  Asked for by the bundle (a file `deferred` beside the binary, written by
+	 * make_bundle.py --deferred N) or by the environment (PROT_LV2_DEFERRED=N); N = frames, 1 = the host's maxBlockLength (1024 if
+	 * the host does not say). */
+	uint32_t deferred = 0;
+	if (getenv ("PROT_LV2_DEFERRED")) {
+		deferred = (uint32_t)strtoul (getenv ("PROT_LV2_DEFERRED"), NULL, 10);
+	} else if (bundle_path && strlen (bundle_path) < 3900) {
+		char path[4096];
+		snprintf (path, sizeof (path), "%s%sdeferred", bundle_path, bundle_path[0] && bundle_path[strlen (bundle_path) - 1] == '/' ? "" : "/");
+		FILE* f = fopen (path, "r");
+		if (f) {
+			unsigned v = 0;
+			if (fscanf (f, "%u", &v) == 1) {
+				deferred = v;
+			}
+			fclose (f);
+		}
+	}
+	if (deferred == 1) {
+		deferred = max_block > 0 ? max_block : 1024;
+	}
+	if (deferred > 0) {
+		if (prot_lv2_set_deferred (self->engine, deferred) == PROT_OK) {
+			self->latency += deferred;
+		} else {
+			fprintf (stderr, "phaserotate.lv2 warning: deferred run() not available (%s): run() waits for the device\n", prot_last_error ());
+		}
+	}
 
 	for (uint32_t c = 0; c < self->n_chn; ++c) {
 		self->chn[c].dly = (float*)calloc (self->latency, sizeof (float));

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert all(n.startswith("prot_") for n in hooks)
     # library and header agree on the ABI revision (2: prot_info.run_align, prot_sweep_stats, PROT_CFG_* flags; 4: PROT_CFG_OVERLAP_ADD)
     declared = int(re.search(r"#define\s+PROT_ABI_VERSION\s+(\d+)", open(HDR).read()).group(1))
-    assert lib.prot_abi_version() == declared == 6   # (6: PROT_CFG_STATIC_RUNS, prot_sweep_seed_dev, prot_engine_prime_dev)
+    assert lib.prot_abi_version() == declared == 7   # (7: prot_lv2_set_deferred, prot_lv2_deferred_stats; 6: PROT_CFG_STATIC_RUNS, prot_sweep_seed_dev, prot_engine_prime_dev)
     import ctypes
     shipped = ctypes.CDLL(pkg.SHIPPED_LIB_PATH)
     shipped.prot_abi_version.restype = ctypes.c_int

@@ -60,6 +60,17 @@ def test_bundle_metadata(tmp_path):
     # every prefix that is used is declared
     for pfx in set(re.findall(r"\b([a-z]+):[A-Za-z]", ttl)) - {"http"}:
         assert "@prefix %s:" % pfx in ttl, pfx
+    # --deferred N: the bundle asks the plugin for its non-waiting run() and declares lv2:hardRTCapable again (lv2ttl/phaserotate.ports.in:7)
+    r = subprocess.run([sys.executable, os.path.join(HOST, "make_bundle.py"), str(tmp_path), "--deferred", "1024"], stdout=subprocess.PIPE, text=True)
+    assert r.returncode == 0
+    ttl_d = (b / "phaserotate.ttl").read_text()
+    for sfx in want:
+        body, ports = _ports(ttl_d, URI + sfx)
+        assert "lv2:optionalFeature lv2:hardRTCapable" in body
+        assert [(i, s_) for i, s_, _ in ports] == list(enumerate(want[sfx]))
+    assert (b / "deferred").read_text().strip() == "1024"
+    r = subprocess.run([sys.executable, os.path.join(HOST, "make_bundle.py"), str(tmp_path)], stdout=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and not (b / "deferred").exists() and "hardRTCapable" not in (b / "phaserotate.ttl").read_text()
     # against the reference's own templates, where the tree is present (this container; never on the GPU box)
     ref = "/root/reference/lv2ttl/"
     if os.path.exists(ref + "phaserotate.ports.in"):

@@ -1714,3 +1714,75 @@ def test_callers_stream_may_be_destroyed_after_sync(pkg):
         assert eng.peaks().tobytes() == want.tobytes(), rep
     torch.cuda.synchronize()
     eng.close()
+
+
+@pytest.mark.parametrize("rate,n_chn,D,sizes", [(48000, 1, 1024, [1024]), (96000, 2, 1024, [1024, 512, 64, 1000, 333]),
+                                                (48000, 2, 2048, [2048, 1024, 4096, 6000, 5, 777])])
+def test_lv2_deferred_run_equals_the_blocking_route_delayed_by_one_buffer(pkg, rate, n_chn, D, sizes):
+    """Round 6: prot_lv2_set_deferred(D) -- a call posts its block to the resident kernel and returns WITHOUT
+    waiting, with the output D frames older.  Against the blocking route on a second instance fed the same buffers: the same
+    samples BIT FOR BIT, shifted by exactly D frames (first D frames silence), for fixed and ragged buffer sizes (every call
+    <= D, and calls longer than D, which are taken in pieces), through an angle move (the ramp), a reset in the middle and an idle
+    pause (the kernel leaves and is started again); nothing late, nothing dropped (the calls are a Python loop apart)."""
+    import time
+    rng = np.random.default_rng(rate + D)
+    total = 60 * 1024
+    x = (rng.random((n_chn, total), dtype=np.float32) - 0.5)
+    a = pkg.Lv2Instance(rate, n_chn)       # blocking
+    b = pkg.Lv2Instance(rate, n_chn)       # deferred
+    a.activate()
+    b.activate()
+    b.lv2_set_deferred(D)
+    ya, yb = [], []
+    pos, k = 0, 0
+    seg_a, seg_b = [], []
+    while pos < total:
+        n = min(sizes[k % len(sizes)], total - pos)
+        ang = [90.0, -45.0][:n_chn] if pos < total // 3 else [-120.0, 30.0][:n_chn]     # one move: a ramp in the middle
+        blk = x[:, pos:pos + n]
+        for q in range(0, n, D):            # (the deferred mode takes a call longer than D in pieces of D: the same pieces here,
+            seg_a.append(a.run(blk[:, q:q + D], ang).copy())   # or the two routes transform different blocks and agree to 3e-7 only)
+        seg_b.append(b.run(blk, ang).copy())
+        pos += n
+        k += 1
+        if k == 7:
+            time.sleep(0.35)                # idle: the resident kernel leaves; the pending block was served before it left
+        if pos >= total // 2 and ya == []:  # a reset (activate) in the middle: both start again from silence
+            ya.append(np.concatenate(seg_a, 1)); yb.append(np.concatenate(seg_b, 1))
+            seg_a, seg_b = [], []
+            a.activate(); b.activate()
+    ya.append(np.concatenate(seg_a, 1)); yb.append(np.concatenate(seg_b, 1))
+    for sa, sb in zip(ya, yb):
+        m = sa.shape[1]
+        assert m > 2 * D
+        assert not sb[:, :D].any()                                   # D frames of silence first
+        assert sb[:, D:].tobytes() == sa[:, :m - D].tobytes()        # then the blocking route's samples, bit for bit
+    st = b.lv2_deferred_stats()
+    assert st == {"late": 0, "dropped": 0}, st
+    assert b.server_stats()["calls"] >= k - 12                        # (the long calls' pieces of more than one block are launched)
+    b.lv2_set_deferred(0)                                             # off again: the blocking route, no extra delay
+    a.activate(); b.activate()
+    blk = x[:, :4096]
+    assert b.run(blk, 10.0).tobytes() == a.run(blk, 10.0).tobytes()
+    a.close(); b.close()
+
+
+def test_lv2_deferred_run_never_waits_for_the_device(pkg):
+    """... and what the mode is for: with the calls an audio period apart (here 150 us of busy-waiting: a 64-frame period at 48 kHz is
+    1333) no call waits for the device -- mean and slowest single call of 2000, looped in C, against the blocking route's; a host
+    that calls back to back (no period at all) finds blocks late, and that is counted, not waited for."""
+    g = pkg.Lv2Instance(48000, 1)
+    g.activate()
+    mean_b, worst_b = g.time_lv2_run_paced(1024, 2000, 150)
+    g.lv2_set_deferred(1024)
+    mean_d, worst_d = g.time_lv2_run_paced(1024, 2000, 150)
+    st = g.lv2_deferred_stats()
+    print("run() 1024 frames, 150 us apart: blocking %.2f us (slowest %.1f), deferred %.2f us (slowest %.1f); %r" % (mean_b, worst_b, mean_d, worst_d, st))
+    assert st["late"] == 0 and st["dropped"] == 0, st
+    assert mean_d < 5.0 and mean_d < 0.5 * mean_b, (mean_d, mean_b)
+    assert worst_d < 60.0, worst_d          # (one preemption of the test process is allowed for; the mean is the claim)
+    g.activate()
+    g.time_lv2_run_paced(1024, 300, 0)      # back to back: the device cannot keep up with a caller that never pauses
+    st2 = g.lv2_deferred_stats()
+    assert st2["late"] + st2["dropped"] > 0, st2
+    g.close()

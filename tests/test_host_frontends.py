@@ -194,6 +194,30 @@ def test_plugin_run_matches_oracle(index, angles):
 
 
 @pytest.mark.gpu
+def test_plugin_deferred_run_reports_its_latency_and_returns_the_period_before(monkeypatch):
+    """Round 6: PROT_LV2_DEFERRED=N (or a bundle made with make_bundle.py --deferred N) puts the plugin's run() into the mode that
+    never waits for the device (prot_lv2_set_deferred): the latency port says latency + N (src/phaserotate.c:788 reports what the
+    host must compensate), and the samples are the oracle's, N frames later."""
+    n, bs, D = 16384, 1024, 1024
+    monkeypatch.setenv("PROT_LV2_DEFERRED", str(D))
+    h = Lv2Host(1)
+    assert h.handle
+    h.setup(bs)
+    h.set_control(None)
+    o = orc.Lv2Engine(48000, 2)
+    x = xorshift_uniform(n * 2, seed=78).reshape(2, n)
+    y = np.empty_like(x)
+    for s in range(0, n, bs):
+        y[:, s:s + bs] = h.run(x[:, s:s + bs], [30.0, -45.0])
+    assert h.latency.value == 1792.0 + D
+    yo = o.run_stream(x, [30.0, -45.0], bs)
+    assert not y[:, :D].any()
+    assert np.abs(y[:, 4096 + D:] - yo[:, 4096:n - D]).max() < 2e-6
+    assert np.abs(y[:, D:] - yo[:, :n - D]).max() < 1e-5
+    h.close()
+
+
+@pytest.mark.gpu
 def test_plugin_without_atom_ports_only_forwards_and_reports_latency():
     h = Lv2Host(0)
     h.setup(512, atom_ports=False)
