@@ -1327,6 +1327,45 @@ int server_start_locked (prot_engine* e)
 	return PROT_OK;
 }
 
+// deferred run(): the resident kernel is started where the host may wait -- activate() / prot_lv2_set_deferred -- and waited for
+// until its workgroups poll their doorbells: the first start of a process loads the code object (tens to hundreds of
+// milliseconds), and a run() that does not wait would hand out silence for all that time
+// (g_srv_mu held) start the server and wait until e's workgroups poll their doorbells
+int server_start_wait_locked (prot_engine* e)
+{
+	prot::SvServerAck* a = e->srv_ack.p;
+	const uint32_t     nc = std::min<uint32_t> (e->info.n_chn, 8u);
+	for (uint32_t c = 0; c < nc; ++c) {
+		__atomic_store_n (&a->pad0[c], 0u, __ATOMIC_RELAXED);
+	}
+	const int rc = server_start_locked (e);
+	if (rc) {
+		return rc;
+	}
+	const auto t0 = std::chrono::steady_clock::now ();
+	for (uint32_t c = 0; c < nc;) {
+		if (__atomic_load_n (&a->pad0[c], __ATOMIC_ACQUIRE) != 0u) {
+			++c;
+			continue;
+		}
+		if (std::chrono::steady_clock::now () - t0 > std::chrono::seconds (5)) {
+			break; // (not fatal: the first calls hand out silence until it is there)
+		}
+	}
+	return PROT_OK;
+}
+int rt_prestart (prot_engine* e)
+{
+	if (e->rt_frames == 0 || !e->srv_eligible) {
+		return PROT_OK;
+	}
+	std::lock_guard<std::mutex> lk (g_srv_mu);
+	if (g_srv_hold != 0 || !server_roster_takes (e)) {
+		return PROT_OK; // (another thread holds the server off, or the roster is full: the first run() sorts it out)
+	}
+	return server_start_wait_locked (e);
+}
+
 // ev_last on the stream of the last call when that was a caller's: whoever waits for ev_last comes behind that call.  The handle
 // is the caller's to keep alive until the engine has let go of it (prot_hip.h, "streams"): asking the runtime whether a stream
 // still exists is no way out -- hipStreamQuery on a destroyed stream crashes in this runtime (tried, round 5).
@@ -2101,12 +2140,19 @@ void prot_engine_destroy (prot_engine* e)
 	delete e;
 }
 
+static int engine_reset_held (prot_engine* e);
 int prot_engine_reset (prot_engine* e)
 {
 	if (!e) {
 		return PROT_EINVAL;
 	}
 	HIP_TRY (hipSetDevice (e->device));
+	const int rc_reset = engine_reset_held (e);
+	return rc_reset ? rc_reset : rt_prestart (e); // (deferred run(): the resident kernel is back before the first run())
+}
+
+static int engine_reset_held (prot_engine* e)
+{
 	ServerHold srv_hold;
 	// Behind a call on a caller's stream: stream-ordered, and no host wait (a host that analyses file after file, the bench's loop:
 	// a blocking wait per pass costs 0.05-0.25 ms by the state of the runtime's queues; tools/process_state_probe.py).  The zeroing
@@ -3097,7 +3143,15 @@ static int rt_collect (prot_engine* e, bool wait)
 			rt_push (e, nullptr, e->rt_pend_n);
 			e->rt_discard = true;
 			e->rt_late++;
+#ifdef PROT_RT_DEBUG
+			fprintf (stderr, "rt: late seq %u done %u %u alive %u stages %u %u bellseq %u running %d\n", e->rt_pend_seq, a->done[0], a->done[1], a->alive, a->pad0[0], a->pad0[1], e->srv_seq, (int)e->srv_running);
+#endif
 		}
+#ifdef PROT_RT_DEBUG
+		else if (!done) {
+			fprintf (stderr, "rt: still late seq %u done %u %u alive %u stages %u %u\n", e->rt_pend_seq, a->done[0], a->done[1], a->alive, a->pad0[0], a->pad0[1]);
+		}
+#endif
 	}
 	if (e->rt_skip_n) { // (the call before this one found the server busy: its block was never posted)
 		rt_push (e, nullptr, e->rt_skip_n);
@@ -3263,7 +3317,9 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 			                 /*advance_hist*/ true, rot_inline ? d_rot_c : nullptr, nullptr, nullptr, b);
 			if (rc == PROT_OK) {
 				if (!e->srv_running || !server_is_member (e) || __atomic_load_n (&a->alive, __ATOMIC_ACQUIRE) == 0u) {
-					rc = server_start_locked (e); // (for the whole roster: the other engines' workgroups come back with this one's)
+					// (for the whole roster: the other engines' workgroups come back with this one's; a deferred call waits HERE until the
+					// kernel polls -- 0.1-0.3 ms, after an idle time-out only -- or the next calls would find its block late)
+					rc = deferred ? server_start_wait_locked (e) : server_start_locked (e);
 				}
 				if (rc == PROT_OK) {
 					e->srv_seq = (e->srv_seq % (1u << 30)) + 1u;
@@ -3455,6 +3511,7 @@ int prot_lv2_set_deferred (prot_engine* e, uint32_t frames)
 		return PROT_EUNSUPPORTED;
 	}
 	HIP_TRY (hipSetDevice (e->device));
+	{
 	ServerHold srv_hold; // (the server leaves -- behind the block it may still hold -- and comes back without / with its age limit)
 	(void)join_pipe (e, e->stream);
 	HIP_TRY (sync_own (e));
@@ -3474,7 +3531,8 @@ int prot_lv2_set_deferred (prot_engine* e, uint32_t frames)
 	e->rt_frames = frames;
 	e->rt_cap    = 2 * frames;
 	rt_ring_reset (e);
-	return PROT_OK;
+	}
+	return rt_prestart (e);
 }
 
 int prot_lv2_deferred_stats (prot_engine* e, uint64_t* late, uint64_t* dropped)

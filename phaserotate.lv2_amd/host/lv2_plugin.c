@@ -74,6 +74,7 @@ typedef struct {
 	uint32_t     n_chn;
 	double       rate;
 	uint32_t     latency;
+	int          run_error_seen; /* the first failing run() is reported on stderr, the others are silent (and silence) */
 	prot_engine* engine;
 
 	uint32_t hold_time, frames_per_period;
@@ -265,6 +266,13 @@ cleanup (LV2_Handle instance)
 	}
 	for (uint32_t c = 0; c < MAX_CHANNELS; ++c) {
 		free (self->chn[c].dly);
+	}
+	if (self->engine) { /* deferred run(): periods the device was late for went out as silence -- say how many, if any */
+		uint64_t late = 0, dropped = 0;
+		if (prot_lv2_deferred_stats (self->engine, &late, &dropped) == PROT_OK && late + dropped > 0) {
+			fprintf (stderr, "phaserotate.lv2: deferred run(): %llu period(s) late, %llu not posted (silence went out instead)\n",
+			         (unsigned long long)late, (unsigned long long)dropped);
+		}
 	}
 	prot_engine_destroy (self->engine);
 	free (self);
@@ -550,7 +558,11 @@ run (LV2_Handle instance, uint32_t n_samples)
 
 	/* the hot path: one GPU call for all channels of this period */
 	if (n_samples > 0 && prot_lv2_run (self->engine, inp, outp, n_samples, ang) != PROT_OK) {
-		/* run() cannot report errors (no such path in LV2): emit silence rather than stale data */
+		/* run() cannot report errors (no such path in LV2): emit silence rather than stale data (and say so once) */
+		if (!self->run_error_seen) {
+			self->run_error_seen = 1;
+			fprintf (stderr, "phaserotate.lv2 error: run() failed: %s\n", prot_last_error ());
+		}
 		for (uint32_t c = 0; c < self->n_chn; ++c) {
 			memset (self->chn[c].out, 0, sizeof (float) * n_samples);
 		}

@@ -207,8 +207,10 @@ def test_plugin_deferred_run_reports_its_latency_and_returns_the_period_before(m
     o = orc.Lv2Engine(48000, 2)
     x = xorshift_uniform(n * 2, seed=78).reshape(2, n)
     y = np.empty_like(x)
+    import time
     for s in range(0, n, bs):
         y[:, s:s + bs] = h.run(x[:, s:s + bs], [30.0, -45.0])
+        time.sleep(0.0003)   # (a host calls once per period -- 21 ms for 1024 frames; back to back, 25 us apart, every block is "late")
     assert h.latency.value == 1792.0 + D
     yo = o.run_stream(x, [30.0, -45.0], bs)
     assert not y[:, :D].any()
