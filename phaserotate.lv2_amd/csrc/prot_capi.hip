@@ -2428,12 +2428,14 @@ static int apply_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint6
 	// at the headline shape with equal runs; the fp32 kernel cannot: 158 VGPRs, 53 KiB)
 	static const bool slots_forced = tuning_env ("PROT_WG_PER_CU") != nullptr; // tuning
 	// (two partitions per launch: 128-158 VGPRs, 34 KiB -- three per CU where the fp32 kernel has two; 0.367 -> 0.336 ms)
-	const int slots16 = (!f16_poly || slots_forced) ? e->wg_slots : e->cus * (e->info.partitions == 1 ? 4 : 3);
 	const uint32_t np16    = std::min<uint32_t> (2, e->info.partitions);
 	const uint32_t n_l16   = f16_poly ? e->info.partitions / np16 : 1;
-	p.run_frames = pick_run_frames (e, n_out, nc, 0, slots16); // the engine's own transform block: the fp16 kernels share its form
 	p.conv_delay = (int)e->info.conv_delay;
 	p.dry_delay  = (int)e->info.dry_delay;
+	// one partition, steady rotation: the radix-16 passes on the matrix core (prot_f16mfma.hip, round 6; three workgroups per CU)
+	const bool mfma16 = f16_poly && n_l16 == 1 && np16 == 1 && test_opt (PROT_TEST_F16_NO_MFMA) == 0 && prot::mfma_f16_takes (p, e->hopseg / 2);
+	const int slots16 = (!f16_poly || slots_forced) ? e->wg_slots : e->cus * (mfma16 ? prot::mfma_f16_wg_per_cu () : e->info.partitions == 1 ? 4 : 3);
+	p.run_frames = pick_run_frames (e, n_out, nc, 0, slots16); // the engine's own transform block: the fp16 kernels share its form
 	p.hist_len   = (int)e->info.history;
 	const bool carry = !stateless && n_out > 0;
 	if (!stateless) {
@@ -2449,7 +2451,7 @@ static int apply_f16 (prot_engine* e, const void* d_in, int64_t in_stride, uint6
 			p.H          = e->d_H.p + (size_t)(np16 * l) * e->info.fftlen;
 			p.conv_delay = (int)(e->info.conv_delay + np16 * l * e->info.fftlen); // a partition of g spans 4096 frames
 			p.accumulate = l > 0;
-			err          = prot::launch_ola_poly_f16 (p, (int)np16, e->hopseg / 2, nc, s);
+			err          = mfma16 ? prot::launch_ola_poly_f16_mfma (p, e->hopseg / 2, nc, s) : prot::launch_ola_poly_f16 (p, (int)np16, e->hopseg / 2, nc, s);
 			p.hist_out   = nullptr;
 		}
 	} else {

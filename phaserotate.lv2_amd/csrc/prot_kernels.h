@@ -108,6 +108,10 @@ hipError_t launch_ola4096_p2 (const OlaParams& p, int n_chn, hipStream_t s);
 hipError_t launch_ola_poly (const OlaParams& p, int n_part, int hop_rows, int n_chn, hipStream_t s);
 // the same on fp16 samples (no accumulating launches: FIRs of up to 8192 taps): BASELINE config 5
 hipError_t launch_ola_poly_f16 (const OlaParamsH& p, int n_part, int hop_rows, int n_chn, hipStream_t s);
+// ... one partition, steady rotation, with the radix-16 passes on the matrix core (prot_f16mfma.hip, round 6)
+hipError_t launch_ola_poly_f16_mfma (const OlaParamsH& p, int hop_rows, int n_chn, hipStream_t s);
+bool       mfma_f16_takes (const OlaParamsH& p, int hop_rows); // does a call qualify (delays, mode)?
+int        mfma_f16_wg_per_cu ();                              // resident workgroups per CU its launches are sized for
 
 // overlap-save, table-free form of launch_ola_poly for one partition of an antisymmetric g (prot_olasave.hip): four
 // workgroups per CU; hop_rows in {8, 10, 12}, n_rho_rows = 1; p.sv / p.sv_gain set; dry_delay even

@@ -14,7 +14,7 @@ CAPI_T = os.path.join(b.OBJDIR, "prot_capi_tuning.o")
 if b._newer(CAPI_T, [os.path.join(b.CSRC, "prot_capi.hip"), os.path.join(b.CSRC, "prot_kernels.h")]):
     b._run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-function", "-DPROT_TUNING", "-DPROT_TESTHOOKS",
             "-I" + os.path.join(ROOT, "include"), "-c", os.path.join(b.CSRC, "prot_capi.hip"), "-o", CAPI_T])
-UNITS = ("prot_kernels", "prot_olasave", "prot_olasave8k", "prot_olasave16k", "prot_sweep", "prot_kernels_f16")
+UNITS = ("prot_kernels", "prot_olasave", "prot_olasave8k", "prot_olasave16k", "prot_sweep", "prot_kernels_f16", "prot_f16mfma")
 
 
 def link(tag, replaced):
