@@ -255,7 +255,8 @@ def compact_line(out):
     if side:
         line["variants"] = side
     if g("fp16"):
-        line["fp16"] = {k: g("fp16").get(k) for k in ("value", "kernel_ms", "roofline_frac", "max_abs_err_vs_fp32", "rms_err_vs_fp32")}
+        line["fp16"] = {k: g("fp16").get(k) for k in ("value", "kernel", "kernel_ms", "roofline_frac", "vector_pipe_kernel_ms", "vector_pipe_roofline_frac",
+                                                        "max_abs_err_vs_fp32", "rms_err_vs_fp32")}
     c3 = g("lv2_stereo_batched")
     if c3:
         line["lv2_stereo_batched"] = {k: c3.get(k) for k in ("ms_per_launch", "roofline_frac", "pipelined_ms_per_launch",
@@ -592,7 +593,24 @@ def main():
         engH.apply_dev(xh.float().data_ptr(), n, n, y32.data_ptr(), n, n, rot, pkg.F_STATELESS, st)
         torch.cuda.synchronize()
         errh = (yh[: 1 << 22].float() - y32[: 1 << 22]).abs()
-        out["fp16"] = {"workload": "same as config (polyphase form), fp16 samples (2 B in + 2 B out per frame), packed-half butterflies, fp32 overlap-add and rotation",
+        # the same launch with the radix-16 passes on the vector pipe (rounds 2-5's kernel: olapoly_kernel<T16>), for the line beside it
+        kmsV = None
+        try:
+            pkg.set_test_option(pkg.TEST_F16_NO_MFMA, 1)
+            for _ in range(args.preroll // 2 + args.warmup):
+                step_h()
+            e0.record(ts)
+            for _ in range(args.steps):
+                step_h()
+            e1.record(ts)
+            torch.cuda.synchronize()
+            kmsV = e0.elapsed_time(e1) / args.steps
+        finally:
+            pkg.set_test_option(pkg.TEST_F16_NO_MFMA, 0)
+        out["fp16"] = {"workload": "same as config (polyphase overlap-add on 4096-point blocks), fp16 samples (2 B in + 2 B out per frame); round 6: the six radix-16 passes of a "
+                                   "transform pair on the MATRIX CORE (prot_f16mfma.hip: v_mfma_f32_32x32x16_f16, fp32 accumulate; twiddles packed half), fp32 overlap-add and rotation",
+                       "kernel": "olapolyh_mfma_kernel<10>", "vector_pipe_kernel_ms": kmsV,
+                       "vector_pipe_roofline_frac": (4.0 * n / (kmsV * 1e-3) / 1e9 / HBM_PEAK_GBS) if kmsV else None,
                        "value": world * n / (kmsH * 1e-3), "unit": "frames/s", "kernel_ms": kmsH,
                        "roofline_frac": 4.0 * n / (kmsH * 1e-3) / 1e9 / HBM_PEAK_GBS,
                        "max_abs_err_vs_fp32": float(errh.max()), "rms_err_vs_fp32": float(torch.sqrt(torch.mean(errh ** 2)))}

@@ -80,7 +80,11 @@ PROT_DEV constexpr int mf_enat (int h, int s) { return 8 * (s >> 2) + 4 * h + (s
 constexpr int kMfMat   = 5;       // matrices
 constexpr int kMfMatH  = 32 * 32; // halfs per matrix
 constexpr int kMfHsLen = 2049;
-constexpr int kMfWgPerCu = 3;     // 150-166 VGPRs, 37 KiB of LDS: three workgroups per CU (the host sizes its one-round launches for that)
+#ifndef MF_WPS
+#define MF_WPS 4
+#endif
+constexpr int kMfWgPerCu = MF_WPS;    // 124-126 VGPRs, 37 KiB of LDS: four workgroups per CU (the host sizes its one-round launches for
+                                      // that; three -- 150-168 VGPRs -- measure the same: 0.1885-0.1933 against 0.1897-0.1920 ms)
 
 // The 16 complex values of a lane: for column group g the elements / outputs of slots 0..3 and 4..7 as the two vectors of four
 // dwords the matrix core takes as B operands of its two K halves -- kept in that form through the whole block, so that no pass
@@ -103,8 +107,8 @@ PROT_DEV unsigned mf_bits (const MfV& v, int g, int s) { return v.b[g][s >> 2][s
 // one radix-16 pass of this wave's 64 columns: element slots -> output slots
 PROT_DEV void mf_pass (const __attribute__ ((address_space (3))) mf_h8* mat, int l, MfV& v)
 {
-	const mf_h8 a0 = mat[2 * (l & 31) + (l >> 5)];      // [kh][m'][h'][8]: K half 0
-	const mf_h8 a1 = mat[64 + 2 * (l & 31) + (l >> 5)]; // K half 1
+	const mf_h8 a0 = mat[l];      // [kh][h'][m'][8]: K half 0 (lane l = 32 h' + m' reads entry l: 1 KiB of LDS in lane order)
+	const mf_h8 a1 = mat[64 + l]; // K half 1
 	mf_f16 z;
 #pragma unroll
 	for (int r = 0; r < 16; ++r) {
@@ -174,10 +178,10 @@ __global__ __launch_bounds__ (256, kMfWgPerCu) void olapolyh_mfma_kernel (const 
 	// ---- tables: the five matrices, the spectrum and the W256 twiddles into LDS, the outer twiddles into registers
 	const f2* __restrict__ twp = reinterpret_cast<const f2*> (p.tw);
 	{
-		// matrix m, entry (M', K') -> half at ((m * 2 + kh) * 32 + M') * 16 + 8 h' + i with K' = 16 kh + 8 h' + i
+		// matrix m, entry (M', K') -> half at (((m * 2 + kh) * 2 + h') * 32 + M') * 8 + i with K' = 16 kh + 8 h' + i
 		// rows: output index P[M' >> 1], part M' & 1; columns: element Q[K' >> 1], part K' & 1
 		for (int e = t0; e < kMfMat * kMfMatH; e += 256) {
-			const int m = e >> 10, kh = (e >> 9) & 1, mp = (e >> 4) & 31, hp = (e >> 3) & 1, i = e & 7;
+			const int m = e >> 10, kh = (e >> 9) & 1, hp = (e >> 8) & 1, mp = (e >> 3) & 31, i = e & 7;
 			const int kp = 16 * kh + 8 * hp + i;
 			const int rs = mp >> 1, cs = kp >> 1;                     // row / column slot numbers 0..15
 			// slot number -> (half, slot-in-half): rows 4 (u >> 1) + 2 h + (u & 1), columns 8 (s >> 2) + 4 h + (s & 3)
@@ -280,7 +284,9 @@ __global__ __launch_bounds__ (256, kMfWgPerCu) void olapolyh_mfma_kernel (const 
 
 	for (int it = 0; it < n_it; ++it, s += BLK) {
 		int tt = t0;
-		asm volatile ("" : "+v"(tt)); // (the thread id opaque per iteration: per-lane address terms are recomputed, not carried in registers)
+		// (the thread id opaque per iteration: per-lane address terms are recomputed, not carried in registers -- hoisted as loop
+		// invariants they spill: 76-252 bytes of scratch per lane and 0.217 ms instead of 0.190)
+		asm volatile ("" : "+v"(tt));
 		tt &= 255;
 		const int l = tt & 63, w = tt >> 6, h = l >> 5, n = l & 31;
 		const int j0 = n & 15, ab = 4 * w + (n >> 4);

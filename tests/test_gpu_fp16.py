@@ -217,3 +217,58 @@ def test_fp16_full_size_every_frame(pkg, kind, param, chn, capsys):
         print("\n[fp16 full size] %s %d x%d, %d frames per channel: max |fp16 - fp32| %.3e at frame %d, rms %.3e" % (kind, param, chn, n, mx, at, rms))
     assert mx < MAX_ABS and rms < RMS
     e.close()
+
+
+@pytest.mark.parametrize("kind,param,n_chn", [("lv2", 48000, 1), ("lv2", 96000, 2), ("cli", 2048, 1), ("cli", 1024, 2)])
+def test_fp16_matrix_core_passes_against_oracle_and_vector_pipe(pkg, kind, param, n_chn, capsys):
+    """Round 6: the fp16 path's radix-16 passes on the matrix core (prot_f16mfma.hip: v_mfma_f32_32x32x16_f16,
+    fp32 accumulate) -- every block size that takes the route (HS = 10, 8, 12, 14 rows per block), against the ORACLE on the
+    rounded input and against the vector-pipe kernel it replaces (PROT_TEST_F16_NO_MFMA), on everything the fast path does NOT
+    see: a ragged length, a stream pointer that is 2 bytes off the dword grid (per-frame bounds-checked loads and stores), two
+    stateful chunks (the history in front of the second), two channels with their own rotations."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 150000 + 777
+    x16 = np.stack([_signal(n + 1, 11 + c).astype(np.float16) for c in range(n_chn)])
+    ang = [73, 250][:n_chn]
+    if kind == "lv2":
+        o = orc.Lv2Engine(param, n_chn)
+        deg = [33.0, -75.0][:n_chn]
+        yo = o.run_stream(x16[:, :n].astype(np.float32), deg, 1024)
+        rot = np.concatenate([[np.cos(-2.0 * np.pi * d / 360.0), np.sin(-2.0 * np.pi * d / 360.0)] for d in deg]).astype(np.float32)
+        s0 = o.latency + 2304
+    else:
+        o = orc.CliEngine(param, n_chn)
+        nb = n // param
+        xi = np.ascontiguousarray(x16[:, :nb * param].astype(np.float32).T)                  # interleaved blocks
+        yo = np.concatenate([o.apply(xi[b * param:(b + 1) * param].reshape(-1), ang).reshape(param, n_chn) for b in range(nb)]).T
+        rot = np.concatenate([list(orc.sincos_lut(a))[::-1] for a in ang]).astype(np.float32)
+        s0 = 0
+    outs = {}
+    for off in (0, 1):   # aligned / one half off the dword grid
+        for no_mfma in (0, 1):
+            pkg.set_test_option(pkg.TEST_F16_NO_MFMA, no_mfma)
+            try:
+                e = pkg.Engine(pkg.KIND_LV2 if kind == "lv2" else pkg.KIND_CLI, param, n_chn)
+                xd = torch.from_numpy(x16).to(dev)
+                yd = torch.zeros((n_chn, n + 1), dtype=torch.float16, device=dev)
+                xs, ys = xd[:, off:], yd[:, off:]
+                n1 = 70000 + 123                          # two stateful chunks, the first one ragged
+                torch.cuda.synchronize()
+                e.apply_dev_f16(xs.data_ptr(), n + 1, n1, ys.data_ptr(), n + 1, n1, rot, 0, 0)
+                e.apply_dev_f16(xs[:, n1:].data_ptr(), n + 1, n - n1, ys[:, n1:].data_ptr(), n + 1, n - n1, rot, 0, 0)
+                e.sync()
+                outs[(off, no_mfma)] = ys[:, :n].float().cpu().numpy()
+                e.close()
+            finally:
+                pkg.set_test_option(pkg.TEST_F16_NO_MFMA, 0)
+    m = yo.shape[1]
+    mx, rms = _report(capsys, "matrix-core passes, %s %d x%d, %d frames in two stateful chunks" % (kind, param, n_chn, n),
+                      np.abs(outs[(0, 0)][:, s0:m] - yo[:, s0:]), yo[:, s0:])
+    assert mx < MAX_ABS and rms < RMS
+    mxv, rmsv = _report(capsys, "  ... against the vector-pipe kernel", np.abs(outs[(0, 0)] - outs[(0, 1)]), yo)
+    assert mxv < 2 * MAX_ABS and rmsv < 2 * RMS
+    # the stream that starts one half later: the per-frame paths of both kernels see the same frames
+    mxo, rmso = _report(capsys, "  ... pointer 2 bytes off the dword grid, against the vector-pipe kernel", np.abs(outs[(1, 0)] - outs[(1, 1)]), yo)
+    assert mxo < 2 * MAX_ABS and rmso < 2 * RMS
+    assert np.abs(outs[(1, 0)]).max() > 0.1
