@@ -58,7 +58,7 @@ def build_lib(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
-    hdrs = [os.path.join(CSRC, h) for h in ("prot_fft.h", "prot_kernels.h", "prot_dev.h", "prot_ablate.h", "prot_olasave_asm.inc", "prot_olasave8k_asm.inc", "prot_olasave16k_asm.inc")] + \
+    hdrs = [os.path.join(CSRC, h) for h in ("prot_fft.h", "prot_fft4096.h", "prot_kernels.h", "prot_dev.h", "prot_ablate.h", "prot_olasave_asm.inc", "prot_olasave8k_asm.inc", "prot_olasave16k_asm.inc")] + \
            [os.path.join(ROOT, "include", "prot_hip.h")]
     common = [hipcc, "--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall",
               "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")]
@@ -68,15 +68,19 @@ def build_lib(force=False, verbose=False):
         # iteration to marshal register pairs (measured: 1500 -> 1240 VALU, 255 -> 165 VGPRs);
         # MFMA results in VGPRs (unified file on gfx950) so the sweep's v_max3 reads them directly
         ("prot_kernels.hip", ["-ffast-math", "-fno-slp-vectorize"]),
+        ("prot_olapoly.hip", ["-ffast-math", "-fno-slp-vectorize"]),
         ("prot_sweep.hip", ["-ffast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
         ("prot_kernels_f16.hip", ["-ffast-math"]),
         ("prot_f16mfma.hip", ["-ffast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
         ("prot_olasave.hip", ["-ffast-math", "-fno-slp-vectorize"]),
         ("prot_olasave8k.hip", ["-ffast-math", "-fno-slp-vectorize"]),
         ("prot_olasave16k.hip", ["-ffast-math", "-fno-slp-vectorize"]),
-        # host logic mirrors the reference's float arithmetic: no fast-math
-        ("prot_capi.hip", []),
     ]
+    # the host side of the C ABI (round 6: prot_capi.hip split into its parts; prot_engine.h is what they share).  Host logic mirrors the
+    # reference's float arithmetic: no fast-math.  Compiled twice: as shipped, and with -DPROT_TESTHOOKS (prot_internal_* entry points,
+    # the test options) for libprot_hip_hooks.so -- the device units are the same object code in both libraries
+    HOST_UNITS = ("prot_engine.hip", "prot_apply.hip", "prot_lv2.hip", "prot_sweep_host.hip", "prot_multi.hip")
+    HOOK_UNITS = HOST_UNITS + ("prot_hooks.hip",)
     objs = []
     for src, extra in units:
         s = os.path.join(CSRC, src)
@@ -86,18 +90,26 @@ def build_lib(force=False, verbose=False):
             if verbose and out:
                 print(out)
         objs.append(o)
-    # the test-hook build of the C ABI unit (prot_internal_set_test_option & co.): everything else is the same object code
-    capi_src = os.path.join(CSRC, "prot_capi.hip")
-    capi_hooks = os.path.join(OBJDIR, "prot_capi_hooks.o")
-    if force or _newer(capi_hooks, [capi_src, os.path.join(CSRC, "prot_internal.h")] + hdrs):
-        _run(common + ["-DPROT_TESTHOOKS", "-c", capi_src, "-o", capi_hooks])
+    host_hdrs = hdrs + [os.path.join(CSRC, "prot_engine.h"), os.path.join(CSRC, "prot_internal.h")]
+    objs_h = list(objs)
+    for src in HOST_UNITS:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        if force or _newer(o, [s] + host_hdrs):
+            _run(common + ["-c", s, "-o", o])
+        objs.append(o)
+    for src in HOOK_UNITS:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJDIR, src.replace(".hip", "_hooks.o"))
+        if force or _newer(o, [s] + host_hdrs):
+            _run(common + ["-DPROT_TESTHOOKS", "-c", s, "-o", o])
+        objs_h.append(o)
     names = declared_symbols()
     internal = ["prot_internal_set_rccl_library", "prot_internal_set_test_option", "prot_internal_fused_lists", "prot_internal_time_lv2_run", "prot_internal_time_lv2_run_paced", "prot_internal_time_lv2_run_multi",
                 "prot_internal_server_stats"]
     if force or _newer(LIB, objs + [os.path.join(ROOT, "include", "prot_hip.h")]):
         vs = _version_script(os.path.join(OBJDIR, "exports.map"), names)
         _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,--version-script=" + vs, "-o", LIB] + objs + ["-lpthread"])
-    objs_h = [capi_hooks if o.endswith("prot_capi.o") else o for o in objs]
     if force or _newer(LIB_HOOKS, objs_h + [os.path.join(ROOT, "include", "prot_hip.h")]):
         vs = _version_script(os.path.join(OBJDIR, "exports_hooks.map"), names + internal)
         _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,--version-script=" + vs, "-o", LIB_HOOKS] + objs_h + ["-lpthread"])

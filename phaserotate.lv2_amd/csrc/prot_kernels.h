@@ -1,5 +1,5 @@
 // prot_kernels.h -- launch interface between the C-ABI host code
-// (prot_capi.hip) and the gfx950 kernels (prot_kernels.hip).
+// (prot_engine.hip, prot_apply.hip, prot_lv2.hip, prot_sweep_host.hip, prot_multi.hip) and the gfx950 kernels (prot_kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

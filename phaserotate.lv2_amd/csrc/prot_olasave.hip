@@ -20,7 +20,7 @@
 //     re-indexing of rows), -i is an operand swizzle, and B is one multiply on the rows k3 = 0 and 15 from a per-thread
 //     register; its mean over the other rows (1 + 4e-8: the float taps' own rounding) rides in the rotation constant.
 //     16 KiB of LDS, 16 ds_read_b64 and the table's registers are gone; the host checks the antisymmetry and the flatness
-//     of B when the engine is created (prot_capi.hip) and keeps olapoly_kernel for any FIR that fails them.
+//     of B when the engine is created (prot_engine.hip) and keeps olapoly_kernel for any FIR that fails them.
 //  3. The rotation constants arrive as kernel arguments (no copy in front of the launch).
 //
 // The transform itself is olapoly_kernel's: 16 x 16 x 16, three radix-16 passes in registers (prot_fft.h), one
@@ -618,7 +618,7 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 // device word (ONE decision for all: serve call s, or leave), every workgroup runs the call's block with the code of the
 // launched kernel (olasave_body: same bits), publishes its output with a system-scope release and stores the call's number into
 // its done word, which the host polls.  No launch, no stream synchronisation, no copy command per call.
-// Leaving: on the host's stop command (any other use of the engine stops the server first: prot_capi.hip) and BY ITSELF after
+// Leaving: on the host's stop command (any other use of the engine stops the server first: prot_lv2.hip) and BY ITSELF after
 // 0.25 s without a doorbell (s_memrealtime: 100 MHz) -- a resident kernel blocks whatever shares its hardware queue and
 // every device-wide synchronisation of the process, so it never outlives the stream of calls it serves; `alive` is its last
 // store.  The host treats a server that has left as absent and starts a new one (with the last served call's number).
@@ -721,7 +721,7 @@ PROT_DEV void server_loop (const SvServerBox* const box, SvServerAck* const ack,
 		for (int i = tid; i < (int)(sizeof (OlaParams) / 4); i += 256) {
 			sh_p[i] = __hip_atomic_load (reinterpret_cast<unsigned*> (const_cast<OlaParams*> (&box->p)) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
-		{ // (the port block: [channel][frames], prot_capi.hip lv2_run_chunk)
+		{ // (the port block: [channel][frames], prot_lv2.hip lv2_run_chunk)
 			// (system-scope loads: past the caches, whichever memory the box lives in; eight bytes per lane when the channel's frames
 			// start on an 8-byte boundary)
 			const float* const src = port_in + (int64_t)chn * frames;

@@ -9,19 +9,21 @@ b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
 b.build_lib()
 vdir = os.path.join(b.LIBDIR, "variants"); os.makedirs(vdir, exist_ok=True)
 hipcc = b._hipcc()
-# variant libraries read the tuning switches of prot_capi.hip from the environment (-DPROT_TUNING); the shipped library never does
-CAPI_T = os.path.join(b.OBJDIR, "prot_capi_tuning.o")
-if b._newer(CAPI_T, [os.path.join(b.CSRC, "prot_capi.hip"), os.path.join(b.CSRC, "prot_kernels.h")]):
-    b._run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-function", "-DPROT_TUNING", "-DPROT_TESTHOOKS",
-            "-I" + os.path.join(ROOT, "include"), "-c", os.path.join(b.CSRC, "prot_capi.hip"), "-o", CAPI_T])
-UNITS = ("prot_kernels", "prot_olasave", "prot_olasave8k", "prot_olasave16k", "prot_sweep", "prot_kernels_f16", "prot_f16mfma")
+# variant libraries read the tuning switches of the host units from the environment (-DPROT_TUNING); the shipped library never does
+HOST = ("prot_engine", "prot_apply", "prot_lv2", "prot_sweep_host", "prot_multi", "prot_hooks")
+HOST_T = [os.path.join(b.OBJDIR, u + "_tuning.o") for u in HOST]
+for u, o in zip(HOST, HOST_T):
+    if b._newer(o, [os.path.join(b.CSRC, u + ".hip"), os.path.join(b.CSRC, "prot_engine.h"), os.path.join(b.CSRC, "prot_kernels.h")]):
+        b._run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-function", "-DPROT_TUNING", "-DPROT_TESTHOOKS",
+                "-I" + os.path.join(ROOT, "include"), "-c", os.path.join(b.CSRC, u + ".hip"), "-o", o])
+UNITS = ("prot_kernels", "prot_olapoly", "prot_olasave", "prot_olasave8k", "prot_olasave16k", "prot_sweep", "prot_kernels_f16", "prot_f16mfma")
 
 
 def link(tag, replaced):
     """libprot_hip_<tag>.so from the shipped objects, `replaced` = {unit: object} swapped in"""
     lib = os.path.join(vdir, "libprot_hip_%s.so" % tag)
     objs = [replaced.get(u, os.path.join(b.OBJDIR, u + ".o")) for u in UNITS]
-    b._run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + [CAPI_T, "-lpthread"])
+    b._run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + HOST_T + ["-lpthread"])
     print("built", lib)
 
 

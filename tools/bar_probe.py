@@ -1,7 +1,7 @@
 """Can the CPU store into device memory (large BAR), and how fast?  The run() server would rather be handed its input than fetch it over
 the host link (4 KiB at ~1 GB/s from a lone workgroup): measured here, the FIRST 4 KiB store into a page of device memory takes
 20-30 us, every later one ~0.2 us (write-combined, posted), a CPU LOAD through the BAR 5-7 us -- so the mailbox's host -> device half
-lives in device memory and is never read by the host (prot_capi.hip, lv2_run_chunk).
+lives in device memory and is never read by the host (prot_lv2.hip, lv2_run_chunk).
     python3 tools/bar_probe.py   (on the GPU box; each allocation kind in a child process)"""
 import ctypes as C, os, sys, time
 hip = C.CDLL("libamdhip64.so")

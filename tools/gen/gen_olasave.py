@@ -793,7 +793,7 @@ def self_test(HS, MODE, NA=1, nblk=3, seed=1, verbose=True, opts=(), kind="run",
     B = M.tables(gt)
     rho = -B
     mean = rho[256 * NA:4096 - 256 * NA].mean()
-    # device table (prot_capi.hip save_tables)
+    # device table (prot_engine.hip save_tables)
     tab = np.zeros(2 * 15 * 256, np.float32)
     def put(idx, ang):
         tab[2 * idx], tab[2 * idx + 1] = math.cos(ang), math.sin(ang)

@@ -534,7 +534,7 @@ class Gen16k(Gen8k):
 
 # ---------------------------------------------------------------------------------------------------- self-test
 def device_table(HS, fir=None):
-    """the per-engine constants as prot_capi.hip (save_tables16k) lays them out: five rows of 1024 float2 -- W_N^{(T - 1/2)},
+    """the per-engine constants as prot_engine.hip (save_tables16k) lays them out: five rows of 1024 float2 -- W_N^{(T - 1/2)},
     W_N^{4 (T - 1/2)}, the half-shifted middle table, the plain middle table, the |B| factors of the rows next to DC -- and the gain
     mean|B| / 16384"""
     import olasave_model16k as M

@@ -1244,7 +1244,7 @@ class Gen8kDyn(Gen8k):
 
 # ---------------------------------------------------------------------------------------------------- self-test
 def device_table(HS, fir=None):
-    """the per-engine constants as prot_capi.hip (save_tables8k) lays them out: five rows of 512 float2 -- W_N^{(T - 1/2)},
+    """the per-engine constants as prot_engine.hip (save_tables8k) lays them out: five rows of 512 float2 -- W_N^{(T - 1/2)},
     W_N^{4 (T - 1/2)}, the half-shifted middle table, the plain middle table, the |B| factors of the rows next to DC --
     and the gain mean|B| / 8192"""
     import olasave_model8k as M

@@ -5,6 +5,7 @@ import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "phaserotate.lv2_amd", "csrc")
 UNITS = [("prot_kernels.hip", ["-ffast-math", "-fno-slp-vectorize"]),
+         ("prot_olapoly.hip", ["-ffast-math", "-fno-slp-vectorize"]),
          ("prot_sweep.hip", ["-ffast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
          ("prot_kernels_f16.hip", ["-ffast-math"]),
          ("prot_f16mfma.hip", ["-ffast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
