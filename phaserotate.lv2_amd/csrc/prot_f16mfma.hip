@@ -104,8 +104,11 @@ PROT_DEV h2 mf_get (const MfV& v, int g, int s)
 PROT_DEV void mf_set (MfV& v, int g, int s, h2 x) { v.b[g][s >> 2][s & 3] = __builtin_bit_cast (unsigned, x); }
 PROT_DEV unsigned mf_bits (const MfV& v, int g, int s) { return v.b[g][s >> 2][s & 3]; }
 
-// one radix-16 pass of this wave's 64 columns: element slots -> output slots
-PROT_DEV void mf_pass (const __attribute__ ((address_space (3))) mf_h8* mat, int l, MfV& v)
+// one radix-16 pass of this wave's 64 columns: element slots -> output slots; LAST = the last pass of a block: its products stay
+// in fp32 (acc[g][2 u], acc[g][2 u + 1] = output slot u of column group g) -- the overlap-add and the rotation take them as they
+// are: no rounding to half and back, and 50 conversions fewer per block
+template <bool LAST = false>
+PROT_DEV void mf_pass (const __attribute__ ((address_space (3))) mf_h8* mat, int l, MfV& v, mf_f16* acc_out = nullptr)
 {
 	const mf_h8 a0 = mat[l];      // [kh][h'][m'][8]: K half 0 (lane l = 32 h' + m' reads entry l: 1 KiB of LDS in lane order)
 	const mf_h8 a1 = mat[64 + l]; // K half 1
@@ -122,6 +125,11 @@ PROT_DEV void mf_pass (const __attribute__ ((address_space (3))) mf_h8* mat, int
 #pragma unroll
 	for (int g = 0; g < 2; ++g) {
 		acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16 (a1, __builtin_bit_cast (mf_h8, v.b[g][1]), acc[g], 0, 0, 0);
+	}
+	if (LAST) {
+		acc_out[0] = acc[0];
+		acc_out[1] = acc[1];
+		return;
 	}
 #pragma unroll
 	for (int g = 0; g < 2; ++g) {
@@ -227,14 +235,15 @@ __global__ __launch_bounds__ (256, kMfWgPerCu) void olapolyh_mfma_kernel (const 
 		hm[g] = q == 0 ? 256 : ((m & ~255) | ((m & 15) << 4) | ((m >> 4) & 15));
 	}
 
-	// the overlap-add tail of the block before (what the last pass handed back is already rounded to half: kept as it came, summed
-	// in fp32 where it is used) and the block's last DH input pairs (lane half 1's: the dry frames of the next block's first rows)
-	unsigned tail[2][NTH], carry[2][DH];
+	// the overlap-add tail of the block before (fp32: the last pass's products as the matrix core accumulated them) and the block's
+	// last DH input pairs (lane half 1's: the dry frames of the next block's first rows)
+	float    tail[2][NTH][2];
+	unsigned carry[2][DH];
 #pragma unroll
 	for (int g = 0; g < 2; ++g) {
 #pragma unroll
 		for (int i = 0; i < NTH; ++i) {
-			tail[g][i] = 0u;
+			tail[g][i][0] = tail[g][i][1] = 0.f;
 		}
 	}
 
@@ -444,7 +453,8 @@ __global__ __launch_bounds__ (256, kMfWgPerCu) void olapolyh_mfma_kernel (const 
 			}
 		}
 		// ---- inverse pass A: rows O_h[u] of the lane's columns
-		mf_pass (matp + 4 * 128, l, v);
+		mf_f16 yo[2];
+		mf_pass<true> (matp + 4 * 128, l, v, yo);
 		// ---- overlap-add (fp32), dry frames from the input pairs the lane holds, rotation, store (both columns in one 8-byte access)
 		const bool emit = it >= 1;
 		const bool full = s + BLK <= r1;
@@ -453,9 +463,7 @@ __global__ __launch_bounds__ (256, kMfWgPerCu) void olapolyh_mfma_kernel (const 
 		for (int g = 0; g < 2; ++g) {
 #pragma unroll
 			for (int i = 0; i < HH; ++i) {
-				const h2 x  = mf_get (v, g, i);
-				const h2 tl = __builtin_bit_cast (h2, tail[g][i < NTH ? i : 0]);
-				const float u0 = (float)x.x + (i < NTH ? (float)tl.x : 0.f), u1 = (float)x.y + (i < NTH ? (float)tl.y : 0.f);
+				const float u0 = yo[g][2 * i] + (i < NTH ? tail[g][i < NTH ? i : 0][0] : 0.f), u1 = yo[g][2 * i + 1] + (i < NTH ? tail[g][i < NTH ? i : 0][1] : 0.f);
 				// (the two lane halves take their dry pairs from different slots: a select where they differ)
 				const int s0 = R::DSRC[0][i], s1 = R::DSRC[1][i]; // (compile-time after unrolling)
 				const unsigned d0 = s0 >= 0 ? cur[g][s0 >= 0 ? s0 : 0] : carry[g][s0 < 0 ? -1 - s0 : 0];
@@ -465,7 +473,8 @@ __global__ __launch_bounds__ (256, kMfWgPerCu) void olapolyh_mfma_kernel (const 
 			}
 #pragma unroll
 			for (int i = 0; i < NTH; ++i) {
-				tail[g][i] = mf_bits (v, g, HH + i);
+				tail[g][i][0] = yo[g][2 * (HH + i)];
+				tail[g][i][1] = yo[g][2 * (HH + i) + 1];
 			}
 #pragma unroll
 			for (int i = 0; i < DH; ++i) {
