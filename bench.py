@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--preroll", type=int, default=200,
                     help="untimed launches of the same step BEFORE the W warmup steps of every timed line: after any idle "
                          "time the launch takes ~150 launches (~50 ms of GPU time) to come down from 0.36 to its steady "
-                         "0.28 ms (tools/drift_probe.py; DESIGN.md section 5) -- the clocks, not the kernel.  Disclosed in "
+                         "0.28 ms (tools/attic/drift_probe.py; DESIGN.md section 5) -- the clocks, not the kernel.  Disclosed in "
                          "the JSON line as preroll_steps.  0 = cold figures")
     ap.add_argument("--frames-log2", type=int, default=27, help="frames per GPU per step (2^k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -508,7 +508,7 @@ def main():
                                                "state), with claimed blocks 4 %; what is left is the fill and drain of a pipeline whose stage is "
                                                "12 us long (5 %) and the dependent chains of two 8-wave workgroups per CU (DESIGN.md section 5)" if is8k else
                                                "packed-fp32 VALU issue (4 cycles per v_pk_*_f32, tools/ubench/pk_rate.hip) at the clock the "
-                                               "chip holds under this load (1.7 GHz in-kernel, tools/sv_clock.py), with LDS at about half of "
+                                               "chip holds under this load (1.7 GHz in-kernel, tools/attic/sv_clock.py), with LDS at about half of "
                                                "its cycles: DESIGN.md section 5")}, **pmc),
         "oracle_check": head_check,
     }
@@ -518,7 +518,7 @@ def main():
     # pipelined-LV2 section or the host-file section the sweep passes ran 6-8 % slower -- not a kernel: prot_engine_reset blocked
     # the host once per pass, and that wait costs 0.05-0.25 ms by the state of the runtime's queues once streams have waited on
     # one another.  The reset is stream-ordered now and the order of the sections no longer matters:
-    # tools/process_state_probe.py.)
+    # tools/attic/process_state_probe.py.)
     if not args.no_sweep:
         out["sweep"] = bench_sweep(args, pkg, torch, dist, dev, st, world, rank, local_rank, barrier)
 
@@ -800,7 +800,7 @@ def bench_file_host(pkg, np, local_rank):
     prot_cli_analyze_file = upload + de-interleave + Hilbert pass + 15-angle coarse sweep + reading the
     peak table back.  Host-link-inclusive; never `value`.  Bounded: 2^24 stereo frames (128 MiB each way).
     The output array is allocated and touched BEFORE the timed region: a fresh np.zeros per call costs
-    12 ms of page faults here, 3x the call itself (tools/hostlink_probe.py)."""
+    12 ms of page faults here, 3x the call itself (tools/attic/hostlink_probe.py)."""
     n, nc, P = 1 << 24, 2, 8192
     x = (np.random.default_rng(5).random(n * nc, dtype=np.float32) - 0.5)
     out = np.ones_like(x)
@@ -1165,7 +1165,7 @@ def _bench_sweep_at(P, full, args, pkg, torch, dist, dev, st, world, rank, local
             "value": h["value"], "unit": "channel-frames/s", "ms": h["ms"], "cold_ms": h["cold_ms"], "cold_value": h["value"] * h["ms"] / h["cold_ms"],
                 "warmup_passes": h["warmup_passes"],
             "cold_note": "ms / value: five passes after %d untimed ones (the steady state, as the headline's pre-roll: the pass time settles over ~50 ms "
-                         "of continuous work, tools/sweep_drift.py); cold_ms: the first " % SWEEP_WARM_PASSES +
+                         "of continuous work, tools/attic/sweep_drift.py); cold_ms: the first " % SWEEP_WARM_PASSES +
                          "three passes after ONE untimed pass (what rounds 1-3 reported as ms)",
             "unpruned_ms": h["unpruned_ms"],
             "evaluated_fraction": h["evaluated_fraction"], "table_identical_unpruned": h["table_identical_unpruned"],

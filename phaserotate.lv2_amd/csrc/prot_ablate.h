@@ -24,7 +24,7 @@
 
 namespace prot {
 
-// PROT_STAMPS (diagnostic build only, tools/phase_stamps.py): per-phase shader-cycle sums of the polyphase kernel's
+// PROT_STAMPS (diagnostic build only, tools/attic/phase_stamps.py): per-phase shader-cycle sums of the polyphase kernel's
 // main loop, accumulated per wave in SGPRs and added to g_stamps at the end.  Each stamp is an s_memtime, which
 // drains lgkmcnt: the stamped build runs ~10 % slower and nothing of it exists in the shipped library.
 #ifdef PROT_STAMPS

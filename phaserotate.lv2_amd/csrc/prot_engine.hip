@@ -515,7 +515,7 @@ static int plan_engine (const prot_config* cfg, EnginePlan& pl)
 	// g[s] = fir[2 s + 1] (olapoly_kernel) -- half the taps, blocks of 4096 frames, one launch per
 	// PAIR of 2048-tap partitions of g.  PROT_CFG_DIRECT_FORM keeps the two-partition direct form.
 	fir_design ((int)inf.firlen, fir_taps);
-	// Which form is the default is decided by measurement (tools/order_check.py, 10 interleaved rounds on
+	// Which form is the default is decided by measurement (tools/attic/order_check.py, 10 interleaved rounds on
 	// two boxes, ranges disjoint): polyphase wins wherever the odd taps leave room for a longer hop --
 	// 3072 taps (LV2 48 kHz, 5120 frames per block) -9 / -10 %, 2048 taps (CLI 2048, 6144) -9 / -11 %,
 	// 1024 taps (CLI 1024, 7168) -21 / -24 % -- and from 8192 taps up, where it halves the launches
@@ -1098,7 +1098,7 @@ static int engine_reset_held (prot_engine* e)
 {
 	ServerHold srv_hold;
 	// Behind a call on a caller's stream: stream-ordered, and no host wait (a host that analyses file after file, the bench's loop:
-	// a blocking wait per pass costs 0.05-0.25 ms by the state of the runtime's queues; tools/process_state_probe.py).  The zeroing
+	// a blocking wait per pass costs 0.05-0.25 ms by the state of the runtime's queues; tools/attic/process_state_probe.py).  The zeroing
 	// goes to the ENGINE's stream behind an event recorded on the last call's stream now (mark_last);
 	// pick_stream puts a call that arrives on another stream behind ev_reset, the readers of device state wait for the engine's
 	// stream (sync_own).

@@ -37,7 +37,7 @@ int lv2_reserve (prot_engine* e, uint32_t frames)
 				HIP_TRY (hipMemset (q, 0, sizeof (prot::SvServerBox)));
 				HIP_TRY (hipDeviceSynchronize ());
 			}
-			// (every page touched by the CPU now: the first store into a page through the BAR costs 20-30 us, tools/bar_probe.py --
+			// (every page touched by the CPU now: the first store into a page through the BAR costs 20-30 us, tools/attic/bar_probe.py --
 			// not in the audio callback)
 			memset (q, 0, need);
 			_mm_sfence ();
@@ -408,7 +408,7 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 	// straight from / to the pinned host block over the host link -- a run() call is two kernel
 	// launches and one stream sync, no copy commands.  PROT_LV2_STAGED=1 keeps the staged route
 	// (H2D copies -> device buffers -> D2H copy) for comparison.
-	// Measured (tools/run_latency.py): 64..1024-frame buffers 37..42 us zero-copy vs 46..47 us staged; at 8192 frames the
+	// Measured (tools/attic/run_latency.py): 64..1024-frame buffers 37..42 us zero-copy vs 46..47 us staged; at 8192 frames the
 	// DMA copies win (70 vs 76 us: 64 KiB over the host link from inside a latency-bound kernel) -- staged above 4096 samples.
 	const bool force_staged = test_opt (PROT_TEST_LV2_STAGED) != 0;
 	const bool        staged       = force_staged || n * nc > 4096;
@@ -503,7 +503,7 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 	// The run() server (prot_olasave.hip): the call's parameters and frames go into the mailbox, the doorbell is rung, the resident
 	// kernel does the block and stores the call's number when the output is in h_out -- no launch, no stream synchronisation.
 	// One server per process, a slot per channel of every engine on its roster (g_srv_roster); calls of more than one block per channel, staged
-	// calls and PROT_TEST_LV2_NO_SERVER take the launch below.  tools/run_latency.py: 38-40 us -> the figure in DESIGN.md.
+	// calls and PROT_TEST_LV2_NO_SERVER take the launch below.  tools/attic/run_latency.py: 38-40 us -> the figure in DESIGN.md.
 	bool served = false;
 	if (!staged && e->srv_eligible && test_opt (PROT_TEST_LV2_NO_SERVER) == 0) {
 		std::lock_guard<std::mutex> lk (g_srv_mu);

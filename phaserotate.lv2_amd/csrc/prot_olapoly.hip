@@ -77,7 +77,7 @@ __global__ __launch_bounds__ (256, WPS) void olapoly_kernel (const OlaParamsT<ty
 	// the position inside each group of eight consecutive runs by the group's number gives every XCD all eight residues
 	// in turn: measured -2 % (interleaved A/B of the shipped kernel).  (The 1.5x spread between XCDs that an earlier
 	// version of this comment quoted came from a stamped diagnostic build whose end-of-kernel atomics queued on one
-	// cache line; the timeline-only build shows the XCDs within +-3 %, tools/xcd_timeline.py.)
+	// cache line; the timeline-only build shows the XCDs within +-3 %, tools/attic/xcd_timeline.py.)
 	int bx = (int)blockIdx.x;
 	if ((bx | 7) < (int)gridDim.x) {
 		bx = (bx & ~7) | ((bx + (bx >> 3)) & 7);

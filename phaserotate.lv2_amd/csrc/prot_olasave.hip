@@ -190,7 +190,7 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 	float            sw_raw = 0.f;
 	// (the bound is parked in global memory -- behind the list lengths, one copy per wave -- and re-read where it is used: a
 	// register copy would live across the generated code.  An LDS word behind the exchange area was tried first and read back
-	// other values on the hardware from the second staged block on, for a reason that was not found: tools/sweep_shard_repro.py shows the symptom when the word is moved back)
+	// other values on the hardware from the second staged block on, for a reason that was not found: tools/attic/sweep_shard_repro.py shows the symptom when the word is moved back)
 	auto sw_thr_slot = [&] () -> float* {
 		const int w = __builtin_amdgcn_readfirstlane (threadIdx.x >> 6);
 		return reinterpret_cast<float*> (p.surv_cnt) + (int64_t)gridDim.y * gridDim.x * 4 + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + w;
@@ -208,7 +208,7 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 		return __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (((volatile float*)sw_lo_s)[0])));
 #elif defined(PROT_SW_THR_LDS)
 		// (the same word in LDS, read through an address that is made at the point of use from a scalar: nothing per-lane lives
-		// across the generated code -- tables bit-identical on the hardware, tools/sweep_shard_repro.py)
+		// across the generated code -- tables bit-identical on the hardware, tools/attic/sweep_shard_repro.py)
 		unsigned a = (unsigned)(uintptr_t)(__attribute__ ((address_space (3))) float*)sw_lo_s;
 		asm volatile ("" : "+s"(a));
 		float v;

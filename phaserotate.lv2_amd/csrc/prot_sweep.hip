@@ -578,7 +578,7 @@ __global__ __launch_bounds__ (256, PRUNE ? 4 : 3) void sweep_kernel (const Sweep
 constexpr int kERing = 128; // (d, h) entries of one block's ring: < 64 left over + 64 new
 
 #ifdef PROT_EVAL_STAMPS
-// diagnostic build (tools/ab_build.py sw:<tag>:-DPROT_EVAL_STAMPS, tools/eval_stamps.py): where a workgroup of sweep_eval_kernel spends
+// diagnostic build (tools/ab_build.py sw:<tag>:-DPROT_EVAL_STAMPS, tools/attic/eval_stamps.py): where a workgroup of sweep_eval_kernel spends
 // its time -- thread 0 stamps the 100 MHz clock at entry, after the prologue, the first claim, the first stage, each of its first
 // twelve steps, the loop's end, the rings' rest and the end
 __device__ unsigned long long g_eval_stamps[4096 * 24];
@@ -837,11 +837,11 @@ __global__ __launch_bounds__ (256, 4) void sweep_eval_kernel (const SweepParams 
 			const float* const st = stage_s + buf * 2 * kStage;
 			const int          nch = (__builtin_amdgcn_readfirstlane (sh_cnt[buf]) + 63) >> 6; // (a list's last step is short: the chunks beyond its entries are zeros)
 			// (fetching the next chunk's frames from the stage while this one is tested was measured: 1.5-3 % slower -- the other
-			// waves of the SIMD cover the LDS round trip already; tools/sweep_ab_libs.py)
+			// waves of the SIMD cover the LDS round trip already; tools/attic/sweep_ab_libs.py)
 			// Two chunks of 64 frames per turn, and ALL their tests -- 2 x NBLK sector tests of ten vector operations, three compares each
 			// as lane masks combined on the scalar unit -- before the first branch on any of them (round 5: with a test, a branch and a
 			// compaction per block in turn, every block's compare -> scalar -> branch chain stood exposed behind the one before: 10 us
-			// per 1024-frame step where the vector operations account for 4; tools/eval_stamps.py).  (Written with && / || the compiler
+			// per 1024-frame step where the vector operations account for 4; tools/attic/eval_stamps.py).  (Written with && / || the compiler
 			// nests two EXEC-masked regions per block, ~20 scalar instructions of bookkeeping around ten vector ones; the compaction is
 			// skipped when nothing of the chunk survives.)
 #pragma unroll 1

@@ -1,7 +1,7 @@
 """BASELINE config 3 in its own shape (LV2 stereo, 96 kHz filter, 256 x 1024-frame buffers per stateful launch): launch period by
 events; run under `rocprofv3 --kernel-trace --stats` for the kernel's own duration.  python3 tools/cfg3_probe.py [launches]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from __graft_entry__ import load_package

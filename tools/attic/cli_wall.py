@@ -3,7 +3,7 @@
 usage: python tools/cli_wall.py [minutes=10] [pcm24|f32]"""
 import os, struct, subprocess, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CLI = os.path.join(ROOT, "phaserotate.lv2_amd", "lib", "phase-rotate")
 minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0
 kind = sys.argv[2] if len(sys.argv) > 2 else "pcm24"

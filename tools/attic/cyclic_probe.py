@@ -6,7 +6,7 @@ are not reloaded) against the shipped run-per-workgroup order, complete and with
     python3 tools/ab_build.py sv8:cyc:-DPROT_SV8_CYCLIC sv8:cycmem:-DPROT_SV8_CYCLIC sv8:runmem
     python3 tools/cyclic_probe.py           (on the GPU box)"""
 import os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CHILD = r'''
 import sys
 sys.path.insert(0, %r)

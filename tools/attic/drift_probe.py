@@ -2,7 +2,7 @@
 events on the launch stream, `groups` groups in a row without a pause; then the same after a 2 s pause.
 usage: python tools/drift_probe.py [groups] [gen]   (gen: generate x with a seeded torch.Generator as bench.py does)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from __graft_entry__ import load_package
 pkg = load_package()

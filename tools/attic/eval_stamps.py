@@ -5,7 +5,7 @@ entry, after its prologue, the first claim, the first stage, each of the first t
 and the end.
     PROT_LIB_PATH=phaserotate.lv2_amd/lib/variants/libprot_hip_evst.so python3 tools/eval_stamps.py [blksiz [shards [which [kind]]]]"""
 import ctypes, json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 

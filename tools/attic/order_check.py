@@ -2,7 +2,7 @@
 R rounds, each round times every variant (20 launches after 3 untimed), order rotated per round.
 Prints median / min / max per variant -- the spread is the run-to-run noise any comparison has to beat."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from __graft_entry__ import load_package
 pkg = load_package()

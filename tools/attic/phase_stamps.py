@@ -3,7 +3,7 @@ Needs the stamped variant library: `python tools/ab_build.py stamps:-DPROT_STAMP
 `PROT_LIB_PATH=phaserotate.lv2_amd/lib/variants/libprot_hip_stamps.so python tools/phase_stamps.py [case]`.
 Prints the per-phase average shader cycles per wave-iteration (summed over all waves / wave-iterations)."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from __graft_entry__ import load_package
 pkg = load_package()

@@ -1,7 +1,7 @@
 """Pipelined (PROT_CFG_PIPELINE) against sequential stateful launches: which launches differ, where, how often.
 python3 tools/pipe_stress.py [launches] [repeats] [per]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from __graft_entry__ import load_package
 pkg = load_package()

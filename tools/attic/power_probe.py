@@ -1,7 +1,7 @@
 """Diagnostic: board power / shader clock while the headline kernel runs back to back (is the chip power-limited?).
 Reads the amdgpu hwmon files every 20 ms from a thread while the main thread keeps the stream full for ~4 s."""
 import glob, os, sys, threading, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from __graft_entry__ import load_package
 pkg = load_package()

@@ -5,7 +5,7 @@ Round 4's finding: only `events` (and the bench sections that wait across stream
 headline not at all -- and the cause was prot_engine_reset's host wait per pass, not a kernel (the reset is stream-ordered now).
     python3 tools/process_state_probe.py events"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import bench
 from __graft_entry__ import load_package

@@ -3,7 +3,7 @@ block per channel, a launch on the zero-copy host block beyond) vs staged (test 
 against the launch route: tools/server_probe.py.
 Each variant in its own process; median of 2000 calls after 200 warm-up calls."""
 import os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CHILD = r'''
 import sys, time
 sys.path.insert(0, %r)

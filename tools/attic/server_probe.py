@@ -2,7 +2,7 @@
 """The run() server on the hardware: same bits as the launch route, latency, idle exit and restart, a device-wide synchronisation
 beside it, two instances.  timeout 300 python3 tools/server_probe.py"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pkg = load_package()

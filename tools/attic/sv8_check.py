@@ -1,7 +1,7 @@
 """olasave8k_kernel against olasave_kernel (PROT_CFG_BLOCK4096) on one long stream: max difference, bit-identity of the generated
 loop and the staged path, and ms per 2^27 frames of both, interleaved.  python tools/sv8_check.py [rate] [log2 frames]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from __graft_entry__ import load_package

@@ -1,7 +1,7 @@
 """Dynamic blocks (olasave8k_dyn_kernel) against the static run plan (PROT_CFG_STATIC_RUNS): outputs bit for bit on several
 shapes (mono / stereo, lengths that are not whole blocks, stateless and stateful calls), then the two timed interleaved."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from __graft_entry__ import load_package
 pkg = load_package()

@@ -1,7 +1,7 @@
 """In-kernel clock of the generated loop (diagnostic libraries built with -DPROT_SV_CLOCK: tools/ab_build.py sv:<tag>:-DPROT_SV_CLOCK[,INC=<variant>]):
 `python tools/sv_clock.py tag1 tag2 ...` -> shader clock = cycles / (100 MHz ticks) while the loop runs, cycles per block."""
 import ctypes, os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CHILD = r"""
 import sys, os, ctypes
 sys.path.insert(0, %r)

@@ -1,7 +1,7 @@
 """Per-workgroup timeline of one headline launch of olasave_kernel (diagnostic library built with -DPROT_SV_CLOCK):
 `python tools/sv_timeline.py <tag> [PROT_RANK_W=...]` -> when the workgroups start, enter and leave the generated loop, and end."""
 import ctypes, os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CHILD = r"""
 import sys, os, ctypes
 sys.path.insert(0, %r)

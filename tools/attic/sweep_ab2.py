@@ -2,7 +2,7 @@
 usage: sweep_ab2.py <tagA>=<libA.so or 'main'> <tagB>=<libB.so> [rounds]"""
 import os, subprocess, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CHILD = r'''
 import os, sys, time
 sys.path.insert(0, %r)

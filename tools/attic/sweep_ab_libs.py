@@ -2,7 +2,7 @@
 """cfg4 pass times (harmonic, noise; blksiz 2048 or $PROT_AB_BLKSIZ) of several libraries, interleaved in child processes on ONE box:
     python3 tools/sweep_ab_libs.py main nopipe ...      ("main" = the shipped library; others = lib/variants/libprot_hip_<tag>.so)"""
 import os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CHILD = r'''
 import os, sys, time
 sys.path.insert(0, %r)

@@ -1,7 +1,7 @@
 """Fixed cost of one resident sweep pass (reset + sweep_dev over n frames, stereo, blksiz 2048) by size: what a shard pays however
 small it is.  python3 tools/sweep_fixed_cost.py"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from __graft_entry__ import load_package
 pkg = load_package()

@@ -1,7 +1,7 @@
 """Fused sweep (Hilbert pass + first test, lists, matrix-core evaluation) against the separate passes and the unpruned kernel:
 tables bit for bit, times, how many frames were listed.  python tools/sweep_fused_check.py [seconds of stereo 96 kHz audio] [blksiz]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from __graft_entry__ import load_package

@@ -1,7 +1,7 @@
 """The fused sweep pass's lists, inspected: two runs over the same stream must leave the same lists (same order, same bits), and their
 union must be exactly the frames with d^2 + h^2 above the bound (here 0: every frame with a non-zero pair)."""
 import os, sys, ctypes as C
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from __graft_entry__ import load_package

@@ -1,7 +1,7 @@
 """Sweep time with and without pruning (exact either way) on three signals: the bench's noise, noise + harmonic stack,
 and a monotonically growing signal (worst case: nothing can be skipped).  60 s of stereo 96 kHz per pass, 360 angles."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from __graft_entry__ import load_package
 pkg = load_package()

@@ -4,7 +4,7 @@ Prints, for each of N launches in ONE process, the median / max end time (us aft
 workgroups dealt to each XCD (blockIdx % 8), by dispatch rank -- to tell a per-XCD property (same pattern every launch and
 every process) from an address-dependent one (same within a process, different across processes) from noise."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from __graft_entry__ import load_package
 pkg = load_package()

@@ -106,7 +106,7 @@ class Gen8k(Gen):
 
     def tap(self, name, regs):
         """debugging: opts "probe" = snapshot in the emulator; "dump:<name>" = the 16 pairs to global memory (row k of the output
-        buffer <- regs[k]) and out: tools/sv8_core_test.py compares the hardware with the emulator stage by stage"""
+        buffer <- regs[k]) and out: tools/attic/sv8_core_test.py compares the hardware with the emulator stage by stage"""
         P = self.P
         regs = list(regs)
         if "probe" in self.opts:

@@ -1,4 +1,4 @@
-// debugging aid (tools/sv8_core_test.py): ONE workgroup runs the generated 8192-point CORE block on a staged block read from
+// debugging aid (tools/attic/sv8_core_test.py): ONE workgroup runs the generated 8192-point CORE block on a staged block read from
 // sv8_test_in.bin, once per tap; the 16 register pairs of the tap go to gpurun_out/sv8_stage_<k>.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
