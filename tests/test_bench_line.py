@@ -51,3 +51,16 @@ def test_compact_line_drops_side_objects_rather_than_overflow():
     assert len(line) < 8192
     d = json.loads(line)
     assert "roofline" in d and "cpu_baseline" in d and "value" in d
+
+
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[6-9]_bench_line.json")))
+
+
+@pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
+def test_recorded_line_of_a_gpu_run_is_one_object_under_8k(path):
+    """the stdout of `python bench.py` on the GPU box as the driver's tail sees it"""
+    text = open(path).read()
+    assert len(text) < 8192
+    d = json.loads(text.strip().splitlines()[-1])
+    assert d["roofline"]["frac"] == pytest.approx(d["roofline"]["achieved"] / d["roofline"]["peak"], rel=1e-3)
+    assert d["cpu_baseline"]["value"] > 0 and d["value"] > 0 and d["config"]["workload"]
