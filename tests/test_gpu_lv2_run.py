@@ -1,0 +1,473 @@
+"""GPU parity of the plugin's run() (src/phaserotate.c:257-330 restated in oracle/): buffer-by-buffer streams against the oracle
+(2e-6; ramp regions 1e-5), the resident server against the launched kernels bit for bit, the deferred mode against the blocking
+route shifted by one buffer, the batched / pipelined launches of configs[2].  Tolerances as in test_gpu_parity.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from conftest import harmonic_stack, xorshift_uniform
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-6
+TOL_RAMP = 1e-5
+TOL_DB = 1e-3
+
+
+def db(x):
+    return 20.0 * np.log10(np.maximum(np.asarray(x, np.float64), 1e-30))
+
+
+@pytest.mark.parametrize("rate,bufsize,angle,n_chn", [
+    (48000, 1024, 90.0, 1),    # BASELINE config 2
+    (48000, 64, -120.0, 1),
+    (48000, 4096, 180.0, 1),
+    (44100, 333, -77.0, 1),
+    (48000, 1024, (30.0, -45.0), 2),
+    (96000, 1024, 45.0, 1),             # 4096-tap FIR: 2 partitions (BASELINE config 3 filter)
+    (96000, 256, (10.0, -170.0), 2),
+    (192000, 333, -77.0, 1),            # 8192-tap FIR: 4 partitions
+])
+def test_lv2_run_stream(pkg, rate, bufsize, angle, n_chn):
+    n = 20000 if rate < 64000 else 40000
+    x = xorshift_uniform(n * n_chn, seed=int(rate) + bufsize).reshape(n_chn, n)
+    g = pkg.Lv2Instance(rate, n_chn)
+    g.activate()
+    o = orc.Lv2Engine(rate, n_chn)
+    assert g.latency == o.latency == {48000: 1792, 44100: 1792, 96000: 2560, 192000: 5120}[rate]
+    yg = g.run_stream(x, angle, bufsize)
+    yo = o.run_stream(x, angle, bufsize)
+    d = np.abs(yg - yo)
+    ramp_end = g.latency + 2304  # Q10: first blocks ramp from 0 deg
+    assert d[:, ramp_end:].max() < TOL, d[:, ramp_end:].max()
+    assert d[:, :ramp_end].max() < TOL_RAMP, d[:, :ramp_end].max()
+    g.close()
+
+
+@pytest.mark.parametrize("rate,bufsize,n_chn,angles", [
+    (48000, 1024, 1, (90.0,)),                         # BASELINE config 2
+    (48000, 1024, 2, ((30.0, -45.0),)),
+    (48000, 64, 1, (90.0, 45.0, 45.0, 10.0, -120.0)),  # ramps most of the time
+    (96000, 256, 2, ((10.0, -170.0), (10.0, -170.0), (0.0, 90.0))),
+    (44100, 333, 1, (-77.0,)),
+])
+def test_lv2_run_server_gives_the_launched_kernels_bits(pkg, rate, bufsize, n_chn, angles):
+    """prot_lv2_run's default route is the run() SERVER (a resident kernel that takes each call through a pinned mailbox: no
+    launch, no stream synchronisation); TEST_LV2_NO_SERVER = the launch route of rounds 1-3.  Same block code: the outputs are
+    equal bit for bit, call by call -- steady rotation, ramps, stereo, odd buffer sizes -- and the server really took the calls."""
+    xs = [xorshift_uniform(n_chn * bufsize, seed=100 + i).reshape(n_chn, bufsize) for i in range(40)]
+    outs, stats = {}, {}
+    try:
+        # mode 1: every call launched; 0: the server, its mailbox in device memory through the PCIe BAR (where the device has a large
+        # one: this pool does); 2: the server with the mailbox in pinned host memory (the route of a device without)
+        for mode in (1, 0, 2):
+            pkg.set_test_option(pkg.TEST_LV2_NO_SERVER, 1 if mode == 1 else 0)
+            pkg.set_test_option(pkg.TEST_LV2_NO_BAR, 1 if mode == 2 else 0)
+            g = pkg.Lv2Instance(rate, n_chn)
+            g.activate()
+            outs[mode] = np.stack([g.run(x, angles[i % len(angles)]).copy() for i, x in enumerate(xs)])
+            stats[mode] = g.server_stats()
+            g.close()
+    finally:
+        pkg.set_test_option(pkg.TEST_LV2_NO_SERVER, 0)
+        pkg.set_test_option(pkg.TEST_LV2_NO_BAR, 0)
+    assert outs[0].tobytes() == outs[1].tobytes() and outs[2].tobytes() == outs[1].tobytes()
+    assert stats[1] == dict(calls=0, starts=0)
+    for mode in (0, 2):
+        assert stats[mode]["calls"] == len(xs) and 1 <= stats[mode]["starts"] <= 3, stats  # (a start more if the box stalled past the idle time-out)
+
+
+def test_lv2_run_server_leaves_when_idle_and_for_every_other_use_of_the_engine(pkg):
+    """The resident kernel must never outlive the stream of run() calls it serves (it holds a hardware queue, and every
+    device-wide synchronisation of the process waits for it): it leaves by itself after 0.25 s without a doorbell and is
+    started again by the next call; reset, a device call on the engine, a long call (more than one block per channel: the
+    launch route) and a second instance (round 5: a slot of the same resident kernel) all keep the stream of samples intact."""
+    import time
+    import torch
+    n_buf, bs = 30, 512
+    x = xorshift_uniform(n_buf * bs, seed=77).reshape(1, -1)
+    o = orc.Lv2Engine(48000, 1)
+    want = o.run_stream(x, 90.0, bs)
+    g = pkg.Lv2Instance(48000, 1)
+    g.activate()
+    h = pkg.Lv2Instance(48000, 1)
+    h.activate()
+    got, got_h = [], []
+    for i in range(n_buf):
+        blk = x[:, i * bs:(i + 1) * bs]
+        got.append(g.run(blk, 90.0).copy())
+        got_h.append(h.run(blk, 90.0).copy())      # the second instance: its own slots of the same resident kernel
+        if i == 5:
+            time.sleep(0.4)                          # idle time-out: the server leaves, the next call starts a new one
+        if i == 9:
+            t0 = time.perf_counter()
+            torch.cuda.synchronize()                 # a device-wide synchronisation ends when the server has left
+            assert time.perf_counter() - t0 < 2.0
+        if i == 12:
+            g.sync()                                 # any other use of the engine stops the server first
+    st, st_h = g.server_stats(), h.server_stats()
+    y, y_h = np.concatenate(got, 1), np.concatenate(got_h, 1)
+    lat = g.latency + 2304
+    assert np.abs(y - want)[:, lat:].max() < TOL and np.abs(y - want)[:, :lat].max() < TOL_RAMP
+    assert y_h.tobytes() == y.tobytes()
+    assert st["calls"] == n_buf and st["starts"] >= 3, st     # first start, after the idle exit, after the syncs
+    assert st_h["calls"] == n_buf and st_h["starts"] >= 1, st_h   # (it started the kernel that took both instances in)
+    # a call of more than one block per channel goes through a launch, and the stream continues through the server afterwards
+    big = xorshift_uniform(6000, seed=78).reshape(1, -1)
+    tail = xorshift_uniform(bs, seed=79).reshape(1, -1)
+    w2 = np.concatenate([o.run_stream(big, 90.0, 6000), o.run_stream(tail, 90.0, bs)], 1)  # (the oracle engine of `want` goes on)
+    y2 = np.concatenate([g.run(big, 90.0).copy(), g.run(tail, 90.0).copy()], 1)
+    assert np.abs(y2 - w2).max() < TOL
+    assert g.server_stats()["calls"] == n_buf + 1
+    g.close()
+    h.close()
+
+
+def test_lv2_run_server_takes_every_instance_of_the_process(pkg):
+    """Round 5: ONE resident kernel serves every LV2 engine of the process -- a workgroup per channel of each,
+    a mailbox and a doorbell per engine.  Three plugin instances of different rates and channel counts (4096-point blocks with 10
+    and with 8 new rows in one kernel), run() called on them in turn as an LV2 host does: every call is served, the outputs equal
+    the launch route's bit for bit, and the kernel is not restarted per call (each instance starts it once, when it joins)."""
+    specs = [(48000, 1, 512, [90.0]), (96000, 2, 1024, [33.0, -45.0]), (44100, 2, 333, [10.0, 170.0])]
+    n_calls = 30
+    xs = [[xorshift_uniform(nc * bs, seed=1000 + 37 * k + i).reshape(nc, bs) for i in range(n_calls)] for k, (_, nc, bs, _) in enumerate(specs)]
+    outs, stats = {}, {}
+    try:
+        for mode in (1, 0):
+            pkg.set_test_option(pkg.TEST_LV2_NO_SERVER, mode)
+            gs = [pkg.Lv2Instance(rate, nc) for rate, nc, _, _ in specs]
+            for g in gs:
+                g.activate()
+            got = [[] for _ in specs]
+            for i in range(n_calls):
+                for k, g in enumerate(gs):
+                    ang = specs[k][3] if i % 7 else [a + 0.5 * i for a in specs[k][3]]   # (steady rotation and ramps)
+                    got[k].append(g.run(xs[k][i], ang).copy())
+            stats[mode] = [g.server_stats() for g in gs]
+            # one instance is cleaned up (the host removed a plugin): the kernel is stopped for the hipFree, the others' next run()
+            # starts it again without the slots of the one that is gone
+            gs[1].close()
+            for i in range(5):
+                for k in (0, 2):
+                    got[k].append(gs[k].run(xs[k][i], specs[k][3]).copy())
+            outs[mode] = [np.stack(v) for v in got]
+            stats[mode] += [gs[0].server_stats(), gs[2].server_stats()]
+            gs[0].close()
+            gs[2].close()
+    finally:
+        pkg.set_test_option(pkg.TEST_LV2_NO_SERVER, 0)
+    for k in range(len(specs)):
+        assert outs[0][k].tobytes() == outs[1][k].tobytes(), k
+        assert stats[1][k] == dict(calls=0, starts=0)
+        assert stats[0][k]["calls"] == n_calls, stats[0]
+    assert 3 <= sum(st["starts"] for st in stats[0][:3]) <= 8, stats[0]   # (one start per instance that joins; more only if the box stalled)
+    assert stats[0][3]["calls"] == n_calls + 5 and stats[0][4]["calls"] == n_calls + 5, stats[0]
+
+
+def test_lv2_run_server_is_held_off_while_another_thread_creates_and_destroys_engines(pkg):
+    """stopping the run() server ONCE is not enough -- an audio thread that calls run() every few milliseconds
+    starts it again while another thread's prot_engine_create / destroy is still inside hipMalloc / hipFree, which wait for a
+    device without a resident kernel: under continuous audio a second instance could not be instantiated or cleaned up.  Create,
+    destroy, reserve, reset and sync now HOLD the server off for their whole duration (run() takes the launch route meanwhile),
+    and the kernel leaves by itself after 0.25 s of residence whatever happens.  A run() loop on A for two seconds while B is
+    created and destroyed over and over: both threads make progress, A's stream of samples stays intact."""
+    import threading
+    import time
+    bs = 512
+    n_buf = 4000
+    x = xorshift_uniform(64 * bs, seed=5).reshape(1, -1)
+    a = pkg.Lv2Instance(48000, 1)
+    a.activate()
+    o = orc.Lv2Engine(48000, 1)
+    stop = threading.Event()
+    got, made, err = [], [0], []
+
+    def audio():
+        try:
+            i = 0
+            t_end = time.perf_counter() + 2.0
+            while time.perf_counter() < t_end and i < n_buf:
+                blk = x[:, (i % 64) * bs:(i % 64 + 1) * bs]
+                got.append(a.run(blk, 90.0).copy())
+                i += 1
+                time.sleep(0.0005)
+        except Exception as ex:   # noqa: BLE001
+            err.append(ex)
+        finally:
+            stop.set()
+
+    def churn():
+        try:
+            while not stop.is_set():
+                b = pkg.Lv2Instance(96000, 2)
+                b.activate()
+                b.run(np.zeros((2, 256), np.float32), [10.0, -20.0])
+                b.close()
+                made[0] += 1
+        except Exception as ex:   # noqa: BLE001
+            err.append(ex)
+
+    t1, t2 = threading.Thread(target=audio), threading.Thread(target=churn)
+    t0 = time.perf_counter()
+    t1.start(); t2.start()
+    t1.join(60.0); t2.join(60.0)
+    assert not t1.is_alive() and not t2.is_alive(), "a thread hangs: the resident kernel blocks the other thread's allocation"
+    assert not err, err
+    assert time.perf_counter() - t0 < 30.0
+    assert made[0] >= 3 and len(got) >= 100, (made[0], len(got))
+    # the stream of samples through the churn: against the oracle fed the same buffers
+    y = np.concatenate(got, 1)
+    xs = np.concatenate([x[:, (i % 64) * bs:(i % 64 + 1) * bs] for i in range(len(got))], 1)
+    want = o.run_stream(xs, 90.0, bs)
+    lat = a.latency + 2304
+    assert np.abs(y - want)[:, lat:].max() < TOL
+    a.close()
+
+
+def test_lv2_three_device_geometries_are_the_same_filter(pkg):
+    """LV2 48 kHz filter in the three device forms: polyphase (default: the odd taps on the stream
+    read as complex samples, one partition, 5120-frame blocks), direct form with two 2048-tap
+    partitions sharing a forward transform, and one zero-padded 4096-pt FFT per 1024-frame hop --
+    same LTI filter."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 300001  # odd: the last complex sample of the polyphase form is half outside
+    x = torch.from_numpy(xorshift_uniform(n, seed=31)).to(dev)
+    rot = np.array([0.28, -0.96], np.float32)
+    ys = []
+    # default for <= 4096 taps is the direct form (measured 2 % faster than polyphase there)
+    # (polyphase, the default: the 1536 odd taps need a 6-row tail, so 10 rows x 512 = 5120 frames are new per block)
+    want = {0: (1, 5120), pkg.CFG_POLYPHASE: (1, 5120), pkg.CFG_DIRECT_FORM: (2, 2048), pkg.CFG_SINGLE_FFT_PER_HOP: (1, 1024)}
+    for flags in want:
+        e = pkg.Engine(pkg.KIND_LV2, 48000, 1, flags=flags)
+        assert (e.info.partitions, e.info.hop) == want[flags]
+        y = torch.empty_like(x)
+        torch.cuda.synchronize()
+        e.apply_dev(x.data_ptr(), n, n, y.data_ptr(), n, n, rot, pkg.F_STATELESS)
+        e.sync()
+        ys.append(y)
+        e.close()
+    for other in ys[1:]:
+        assert (ys[0] - other).abs().max().item() < TOL
+
+
+def test_lv2_angle_change_mid_stream(pkg):
+    n, bs = 24000, 512
+    x = xorshift_uniform(n, seed=99).reshape(1, n)
+    g = pkg.Lv2Instance(48000, 1)
+    g.activate()
+    o = orc.Lv2Engine(48000, 1)
+    yg, yo = np.empty_like(x), np.empty_like(x)
+    for s in range(0, n, bs):
+        ang = 45.0 if s < 10240 else -135.0  # 180 deg step: longest ramp, wraps
+        yg[:, s:s + bs] = g.run(x[:, s:s + bs], ang)
+        yo[:, s:s + bs] = o.run(x[:, s:s + bs], ang)
+    assert np.abs(yg - yo).max() < TOL_RAMP
+    assert np.abs(yg[:, 16000:] - yo[:, 16000:]).max() < TOL
+    g.close()
+
+
+def test_lv2_reactivate_clears_history(pkg):
+    x = xorshift_uniform(4096, seed=3).reshape(1, -1)
+    g = pkg.Lv2Instance(48000, 1)
+    g.activate()
+    g.run_stream(x, 90.0, 1024)
+    g.activate()
+    y = g.run(np.zeros((1, 1024), np.float32), 90.0)
+    assert np.abs(y).max() == 0.0
+    g.close()
+
+
+def test_lv2_random_buffer_sizes_and_angle_moves(pkg):
+    """run() with ragged host buffer sizes (1..5000 frames) and the angle port moving at
+    random times: every reference block boundary / ramp start lands somewhere else."""
+    rng = np.random.default_rng(2024)
+    n = 60000
+    x = xorshift_uniform(2 * n, seed=17).reshape(2, n)
+    g = pkg.Lv2Instance(48000, 2)
+    g.activate()
+    o = orc.Lv2Engine(48000, 2)
+    yg, yo = np.empty_like(x), np.empty_like(x)
+    pos, ang = 0, np.array([10.0, -20.0], np.float32)
+    while pos < n:
+        sz = int(min(n - pos, rng.choice([1, 7, 64, 255, 256, 257, 1000, 1024, 3333, 5000])))
+        if rng.random() < 0.15:
+            ang = rng.uniform(-200, 200, 2).astype(np.float32)  # beyond +-180: clamped (src/phaserotate.c:566-571)
+        yg[:, pos:pos + sz] = g.run(x[:, pos:pos + sz], ang)
+        yo[:, pos:pos + sz] = o.run(x[:, pos:pos + sz], ang)
+        pos += sz
+    assert np.abs(yg - yo).max() < TOL_RAMP
+    g.close()
+
+
+def test_lv2_96k_engine_switches_form_between_long_and_short_launches(pkg):
+    """The 96 kHz LV2 engine runs the direct two-partition form on long launches and the polyphase form on
+    short ones (fewer halo blocks).  State is input history only, so a stream may alternate between them:
+    long chunk (direct), short chunks (polyphase), long again -- equal to one long launch within the gate,
+    with no step at the seams."""
+    import torch
+    dev = torch.device("cuda:0")
+    big = 1 << 25                      # 16 blocks per workgroup: direct form
+    cuts = [0, big, big + 700, big + 700 + 4096 * 3, 2 * big + 5000]
+    n = cuts[-1]
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.rand(n, generator=g, device=dev) - 0.5
+    rot = np.array([0.6, -0.8], np.float32)
+    e = pkg.Engine(pkg.KIND_LV2, 96000, 1)
+    y1 = torch.empty_like(x)
+    torch.cuda.synchronize()
+    e.apply_dev(x.data_ptr(), n, n, y1.data_ptr(), n, n, rot, pkg.F_STATELESS)   # one launch (direct form)
+    y2 = torch.empty_like(x)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        e.apply_dev(x.data_ptr() + 4 * a, n, b - a, y2.data_ptr() + 4 * a, n, b - a, rot, 0)
+    e.sync()
+    e.close()
+    d = (y1 - y2).abs()
+    assert d.max().item() < TOL, (d.max().item(), int(d.argmax().item()))
+    for c in cuts[1:-1]:
+        assert d[c - 6000:c + 6000].max().item() < TOL
+
+
+def test_cfg3_shape_against_oracle(pkg):
+    """BASELINE configs[2] in its own shape: LV2 stereo at 96 kHz (4096-tap FIR), 256 buffers of 1024 frames per STATEFUL
+    device launch, three launches back to back -- against the oracle's run() over the same 786 432 frames per channel."""
+    import torch
+    dev = torch.device("cuda:0")
+    n_chn, per = 2, 256 * 1024
+    n = 3 * per
+    x = xorshift_uniform(n_chn * n, seed=96).reshape(n_chn, n)
+    angles = [40.0, -115.0]
+    yo = orc.Lv2Engine(96000, n_chn).run_stream(x, angles, 1024)
+    e = pkg.Engine(pkg.KIND_LV2, 96000, n_chn)
+    rot = np.array([[np.cos(-2 * np.pi * a / 360.0), np.sin(-2 * np.pi * a / 360.0)] for a in angles], np.float32).reshape(-1)
+    xd = torch.from_numpy(x).to(dev)
+    yd = torch.empty_like(xd)
+    for k in range(3):
+        xin = xd[:, k * per:(k + 1) * per].contiguous()
+        yout = torch.empty_like(xin)
+        torch.cuda.synchronize()
+        e.apply_dev(xin.data_ptr(), per, per, yout.data_ptr(), per, per, rot, 0)  # stateful: the history carries over
+        e.sync()
+        yd[:, k * per:(k + 1) * per] = yout
+    yg = yd.cpu().numpy()
+    s0 = 2560 + 2 * 1024  # Q10: run() ramps from 0 deg on its first blocks; the device call starts steady
+    assert np.abs(yg[:, s0:] - yo[:, s0:]).max() < TOL
+    e.close()
+
+
+@pytest.mark.parametrize("rate,per,n_launch", [(96000, 256 * 1024, 24), (48000, 64 * 1024, 40), (96000, 20480, 33)])
+def test_pipelined_launches_equal_sequential_ones(pkg, rate, per, n_launch):
+    """PROT_CFG_PIPELINE: stateful launches on the engine's own streams alternate between two streams and
+    hand the history over on the device.  N pipelined launches must equal N sequential ones bit for bit -- outputs AND the
+    state they leave (one more, sequential, call on both engines) --, also when other calls (a ramp call, a sync, a call on
+    a caller's stream) interrupt the series and force a join, and for launches too short to qualify (n_in < history)."""
+    import torch
+    dev = torch.device("cuda:0")
+    n_chn = 2
+    n = (n_launch + 3) * per
+    x = torch.from_numpy(xorshift_uniform(n_chn * n, seed=77).reshape(n_chn, n)).to(dev)
+    rot = np.array([0.6, 0.8, -0.28, 0.96], np.float32)
+    outs = []
+    for flags in (0, pkg.CFG_PIPELINE):
+        e = pkg.Engine(pkg.KIND_LV2, rate, n_chn, flags=flags)
+        assert e.info.form in (pkg.FORM_POLY_SAVE, pkg.FORM_POLY_SAVE8K)   # (these launches are short: the 4096-point kernel either way)
+        y = torch.zeros_like(x)
+        ts = torch.cuda.Stream()
+        for k in range(n_launch):
+            xin, yout = x[:, k * per:(k + 1) * per], y[:, k * per:(k + 1) * per]
+            if k == 9:      # a call on a caller's stream in the middle of the series: ordered behind it, and the series after it
+                e.apply_dev(xin.data_ptr(), n, per, yout.data_ptr(), n, per, rot, 0, ts.cuda_stream)
+                ts.synchronize()
+            elif k == 17:   # a short call (less input than the history is long) cannot take the pipelined route
+                h = per // 2 if per // 2 < e.info.history else 1000
+                e.apply_dev(xin.data_ptr(), n, h, yout.data_ptr(), n, h, rot, 0)
+                e.apply_dev(xin.data_ptr() + 4 * h, n, per - h, yout.data_ptr() + 4 * h, n, per - h, rot, 0)
+            else:
+                e.apply_dev(xin.data_ptr(), n, per, yout.data_ptr(), n, per, rot, 0)
+            if k == 5:
+                e.sync()
+        # the state the series leaves: one more call, per-frame rotation (never pipelined)
+        k = n_launch
+        rs = torch.from_numpy(np.tile(rot, (per, 1)).reshape(per, n_chn, 2).transpose(1, 0, 2).copy()).to(dev)
+        e.apply_dev_ramp(x[:, k * per:].data_ptr(), n, per, y[:, k * per:].data_ptr(), n, per, rs.data_ptr(), 0)
+        e.sync()
+        torch.cuda.synchronize()
+        outs.append(y.cpu().numpy())
+        e.close()
+    assert np.abs(outs[0][:, :(n_launch + 1) * per]).max() > 0.05
+    assert outs[0].tobytes() == outs[1].tobytes()
+
+
+@pytest.mark.parametrize("rate,n_chn,D,sizes", [(48000, 1, 1024, [1024]), (96000, 2, 1024, [1024, 512, 64, 1000, 333]),
+                                                (48000, 2, 2048, [2048, 1024, 4096, 6000, 5, 777])])
+def test_lv2_deferred_run_equals_the_blocking_route_delayed_by_one_buffer(pkg, rate, n_chn, D, sizes):
+    """Round 6: prot_lv2_set_deferred(D) -- a call posts its block to the resident kernel and returns WITHOUT
+    waiting, with the output D frames older.  Against the blocking route on a second instance fed the same buffers: the same
+    samples BIT FOR BIT, shifted by exactly D frames (first D frames silence), for fixed and ragged buffer sizes (every call
+    <= D, and calls longer than D, which are taken in pieces), through an angle move (the ramp), a reset in the middle and an idle
+    pause (the kernel leaves and is started again); nothing late, nothing dropped (the calls are a Python loop apart)."""
+    import time
+    rng = np.random.default_rng(rate + D)
+    total = 60 * 1024
+    x = (rng.random((n_chn, total), dtype=np.float32) - 0.5)
+    a = pkg.Lv2Instance(rate, n_chn)       # blocking
+    b = pkg.Lv2Instance(rate, n_chn)       # deferred
+    a.activate()
+    b.activate()
+    b.lv2_set_deferred(D)
+    ya, yb = [], []
+    pos, k = 0, 0
+    seg_a, seg_b = [], []
+    while pos < total:
+        n = min(sizes[k % len(sizes)], total - pos)
+        ang = [90.0, -45.0][:n_chn] if pos < total // 3 else [-120.0, 30.0][:n_chn]     # one move: a ramp in the middle
+        blk = x[:, pos:pos + n]
+        for q in range(0, n, D):            # (the deferred mode takes a call longer than D in pieces of D: the same pieces here,
+            seg_a.append(a.run(blk[:, q:q + D], ang).copy())   # or the two routes transform different blocks and agree to 3e-7 only)
+        seg_b.append(b.run(blk, ang).copy())
+        pos += n
+        k += 1
+        if k == 7:
+            time.sleep(0.35)                # idle: the resident kernel leaves; the pending block was served before it left
+        if pos >= total // 2 and ya == []:  # a reset (activate) in the middle: both start again from silence
+            ya.append(np.concatenate(seg_a, 1)); yb.append(np.concatenate(seg_b, 1))
+            seg_a, seg_b = [], []
+            a.activate(); b.activate()
+    ya.append(np.concatenate(seg_a, 1)); yb.append(np.concatenate(seg_b, 1))
+    for sa, sb in zip(ya, yb):
+        m = sa.shape[1]
+        assert m > 2 * D
+        assert not sb[:, :D].any()                                   # D frames of silence first
+        assert sb[:, D:].tobytes() == sa[:, :m - D].tobytes()        # then the blocking route's samples, bit for bit
+    st = b.lv2_deferred_stats()
+    assert st == {"late": 0, "dropped": 0}, st
+    assert b.server_stats()["calls"] >= k - 12                        # (the long calls' pieces of more than one block are launched)
+    b.lv2_set_deferred(0)                                             # off again: the blocking route, no extra delay
+    a.activate(); b.activate()
+    blk = x[:, :4096]
+    assert b.run(blk, 10.0).tobytes() == a.run(blk, 10.0).tobytes()
+    a.close(); b.close()
+
+
+def test_lv2_deferred_run_never_waits_for_the_device(pkg):
+    """... and what the mode is for: with the calls an audio period apart (here 150 us of busy-waiting: a 64-frame period at 48 kHz is
+    1333) no call waits for the device -- mean and slowest single call of 2000, looped in C, against the blocking route's; a host
+    that calls back to back (no period at all) finds blocks late, and that is counted, not waited for."""
+    g = pkg.Lv2Instance(48000, 1)
+    g.activate()
+    mean_b, worst_b = g.time_lv2_run_paced(1024, 2000, 150)
+    g.lv2_set_deferred(1024)
+    mean_d, worst_d = g.time_lv2_run_paced(1024, 2000, 150)
+    st = g.lv2_deferred_stats()
+    print("run() 1024 frames, 150 us apart: blocking %.2f us (slowest %.1f), deferred %.2f us (slowest %.1f); %r" % (mean_b, worst_b, mean_d, worst_d, st))
+    assert st["late"] == 0 and st["dropped"] == 0, st
+    assert mean_d < 5.0 and mean_d < 0.5 * mean_b, (mean_d, mean_b)
+    assert worst_d < 60.0, worst_d          # (one preemption of the test process is allowed for; the mean is the claim)
+    g.activate()
+    g.time_lv2_run_paced(1024, 300, 0)      # back to back: the device cannot keep up with a caller that never pauses
+    st2 = g.lv2_deferred_stats()
+    assert st2["late"] + st2["dropped"] > 0, st2
+    g.close()

@@ -1,6 +1,8 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle on the
 same seeded inputs.  Tolerances: samples 2e-6 abs at
 |y| <= 1, ramp regions 1e-5, peak table 1e-3 dB, min-peak angle index exact.
+This file: the FIR design, the CLI apply path, the device-resident apply calls and their kernels (block sizes, forms,
+geometry, stream ordering).  The sweep: test_gpu_sweep.py; the plugin's run(): test_gpu_lv2_run.py.
 """
 import os
 
@@ -21,7 +23,14 @@ def db(x):
     return 20.0 * np.log10(np.maximum(np.asarray(x, np.float64), 1e-30))
 
 
-# ------------------------------------------------------------------ FIR ---
+def _signal(n, n_chn, seed):
+    chans = []
+    for c in range(n_chn):
+        h = harmonic_stack(n, f0=110.0 * (1 + 0.31 * c))
+        chans.append(0.85 * h + 0.1 * xorshift_uniform(n, seed=seed + c))
+    return np.stack(chans, axis=1).astype(np.float32).reshape(-1)  # interleaved
+
+
 @pytest.mark.parametrize("kind,param,n", [(0, 2048, 2048), (0, 1024, 1024), (1, 48000, 3072),
                                           (0, 8192, 8192), (1, 96000, 4096), (1, 192000, 8192)])
 def test_engine_fir_matches_reference_design(pkg, kind, param, n):
@@ -38,7 +47,6 @@ def test_engine_fir_matches_reference_design(pkg, kind, param, n):
     e.close()
 
 
-# ------------------------------------------------------------ CLI apply ---
 @pytest.mark.parametrize("blksiz,n_chn,angles,nblk", [
     (2048, 1, [90], 20),       # "4096-pt OLA", 45 deg
     (2048, 1, [-61], 20),      # -30.5 deg (Q9: negative wraps by +360)
@@ -121,240 +129,6 @@ def test_cli_apply_file_across_device_chunks(pkg, P):
     assert seam < m and d[seam - 3 * P:seam + 3 * P].max() < TOL
 
 
-# -------------------------------------------------------------- LV2 run ---
-@pytest.mark.parametrize("rate,bufsize,angle,n_chn", [
-    (48000, 1024, 90.0, 1),    # BASELINE config 2
-    (48000, 64, -120.0, 1),
-    (48000, 4096, 180.0, 1),
-    (44100, 333, -77.0, 1),
-    (48000, 1024, (30.0, -45.0), 2),
-    (96000, 1024, 45.0, 1),             # 4096-tap FIR: 2 partitions (BASELINE config 3 filter)
-    (96000, 256, (10.0, -170.0), 2),
-    (192000, 333, -77.0, 1),            # 8192-tap FIR: 4 partitions
-])
-def test_lv2_run_stream(pkg, rate, bufsize, angle, n_chn):
-    n = 20000 if rate < 64000 else 40000
-    x = xorshift_uniform(n * n_chn, seed=int(rate) + bufsize).reshape(n_chn, n)
-    g = pkg.Lv2Instance(rate, n_chn)
-    g.activate()
-    o = orc.Lv2Engine(rate, n_chn)
-    assert g.latency == o.latency == {48000: 1792, 44100: 1792, 96000: 2560, 192000: 5120}[rate]
-    yg = g.run_stream(x, angle, bufsize)
-    yo = o.run_stream(x, angle, bufsize)
-    d = np.abs(yg - yo)
-    ramp_end = g.latency + 2304  # Q10: first blocks ramp from 0 deg
-    assert d[:, ramp_end:].max() < TOL, d[:, ramp_end:].max()
-    assert d[:, :ramp_end].max() < TOL_RAMP, d[:, :ramp_end].max()
-    g.close()
-
-
-@pytest.mark.parametrize("rate,bufsize,n_chn,angles", [
-    (48000, 1024, 1, (90.0,)),                         # BASELINE config 2
-    (48000, 1024, 2, ((30.0, -45.0),)),
-    (48000, 64, 1, (90.0, 45.0, 45.0, 10.0, -120.0)),  # ramps most of the time
-    (96000, 256, 2, ((10.0, -170.0), (10.0, -170.0), (0.0, 90.0))),
-    (44100, 333, 1, (-77.0,)),
-])
-def test_lv2_run_server_gives_the_launched_kernels_bits(pkg, rate, bufsize, n_chn, angles):
-    """prot_lv2_run's default route is the run() SERVER (a resident kernel that takes each call through a pinned mailbox: no
-    launch, no stream synchronisation); TEST_LV2_NO_SERVER = the launch route of rounds 1-3.  Same block code: the outputs are
-    equal bit for bit, call by call -- steady rotation, ramps, stereo, odd buffer sizes -- and the server really took the calls."""
-    xs = [xorshift_uniform(n_chn * bufsize, seed=100 + i).reshape(n_chn, bufsize) for i in range(40)]
-    outs, stats = {}, {}
-    try:
-        # mode 1: every call launched; 0: the server, its mailbox in device memory through the PCIe BAR (where the device has a large
-        # one: this pool does); 2: the server with the mailbox in pinned host memory (the route of a device without)
-        for mode in (1, 0, 2):
-            pkg.set_test_option(pkg.TEST_LV2_NO_SERVER, 1 if mode == 1 else 0)
-            pkg.set_test_option(pkg.TEST_LV2_NO_BAR, 1 if mode == 2 else 0)
-            g = pkg.Lv2Instance(rate, n_chn)
-            g.activate()
-            outs[mode] = np.stack([g.run(x, angles[i % len(angles)]).copy() for i, x in enumerate(xs)])
-            stats[mode] = g.server_stats()
-            g.close()
-    finally:
-        pkg.set_test_option(pkg.TEST_LV2_NO_SERVER, 0)
-        pkg.set_test_option(pkg.TEST_LV2_NO_BAR, 0)
-    assert outs[0].tobytes() == outs[1].tobytes() and outs[2].tobytes() == outs[1].tobytes()
-    assert stats[1] == dict(calls=0, starts=0)
-    for mode in (0, 2):
-        assert stats[mode]["calls"] == len(xs) and 1 <= stats[mode]["starts"] <= 3, stats  # (a start more if the box stalled past the idle time-out)
-
-
-def test_lv2_run_server_leaves_when_idle_and_for_every_other_use_of_the_engine(pkg):
-    """The resident kernel must never outlive the stream of run() calls it serves (it holds a hardware queue, and every
-    device-wide synchronisation of the process waits for it): it leaves by itself after 0.25 s without a doorbell and is
-    started again by the next call; reset, a device call on the engine, a long call (more than one block per channel: the
-    launch route) and a second instance (round 5: a slot of the same resident kernel) all keep the stream of samples intact."""
-    import time
-    import torch
-    n_buf, bs = 30, 512
-    x = xorshift_uniform(n_buf * bs, seed=77).reshape(1, -1)
-    o = orc.Lv2Engine(48000, 1)
-    want = o.run_stream(x, 90.0, bs)
-    g = pkg.Lv2Instance(48000, 1)
-    g.activate()
-    h = pkg.Lv2Instance(48000, 1)
-    h.activate()
-    got, got_h = [], []
-    for i in range(n_buf):
-        blk = x[:, i * bs:(i + 1) * bs]
-        got.append(g.run(blk, 90.0).copy())
-        got_h.append(h.run(blk, 90.0).copy())      # the second instance: its own slots of the same resident kernel
-        if i == 5:
-            time.sleep(0.4)                          # idle time-out: the server leaves, the next call starts a new one
-        if i == 9:
-            t0 = time.perf_counter()
-            torch.cuda.synchronize()                 # a device-wide synchronisation ends when the server has left
-            assert time.perf_counter() - t0 < 2.0
-        if i == 12:
-            g.sync()                                 # any other use of the engine stops the server first
-    st, st_h = g.server_stats(), h.server_stats()
-    y, y_h = np.concatenate(got, 1), np.concatenate(got_h, 1)
-    lat = g.latency + 2304
-    assert np.abs(y - want)[:, lat:].max() < TOL and np.abs(y - want)[:, :lat].max() < TOL_RAMP
-    assert y_h.tobytes() == y.tobytes()
-    assert st["calls"] == n_buf and st["starts"] >= 3, st     # first start, after the idle exit, after the syncs
-    assert st_h["calls"] == n_buf and st_h["starts"] >= 1, st_h   # (it started the kernel that took both instances in)
-    # a call of more than one block per channel goes through a launch, and the stream continues through the server afterwards
-    big = xorshift_uniform(6000, seed=78).reshape(1, -1)
-    tail = xorshift_uniform(bs, seed=79).reshape(1, -1)
-    w2 = np.concatenate([o.run_stream(big, 90.0, 6000), o.run_stream(tail, 90.0, bs)], 1)  # (the oracle engine of `want` goes on)
-    y2 = np.concatenate([g.run(big, 90.0).copy(), g.run(tail, 90.0).copy()], 1)
-    assert np.abs(y2 - w2).max() < TOL
-    assert g.server_stats()["calls"] == n_buf + 1
-    g.close()
-    h.close()
-
-
-def test_lv2_run_server_takes_every_instance_of_the_process(pkg):
-    """Round 5: ONE resident kernel serves every LV2 engine of the process -- a workgroup per channel of each,
-    a mailbox and a doorbell per engine.  Three plugin instances of different rates and channel counts (4096-point blocks with 10
-    and with 8 new rows in one kernel), run() called on them in turn as an LV2 host does: every call is served, the outputs equal
-    the launch route's bit for bit, and the kernel is not restarted per call (each instance starts it once, when it joins)."""
-    specs = [(48000, 1, 512, [90.0]), (96000, 2, 1024, [33.0, -45.0]), (44100, 2, 333, [10.0, 170.0])]
-    n_calls = 30
-    xs = [[xorshift_uniform(nc * bs, seed=1000 + 37 * k + i).reshape(nc, bs) for i in range(n_calls)] for k, (_, nc, bs, _) in enumerate(specs)]
-    outs, stats = {}, {}
-    try:
-        for mode in (1, 0):
-            pkg.set_test_option(pkg.TEST_LV2_NO_SERVER, mode)
-            gs = [pkg.Lv2Instance(rate, nc) for rate, nc, _, _ in specs]
-            for g in gs:
-                g.activate()
-            got = [[] for _ in specs]
-            for i in range(n_calls):
-                for k, g in enumerate(gs):
-                    ang = specs[k][3] if i % 7 else [a + 0.5 * i for a in specs[k][3]]   # (steady rotation and ramps)
-                    got[k].append(g.run(xs[k][i], ang).copy())
-            stats[mode] = [g.server_stats() for g in gs]
-            # one instance is cleaned up (the host removed a plugin): the kernel is stopped for the hipFree, the others' next run()
-            # starts it again without the slots of the one that is gone
-            gs[1].close()
-            for i in range(5):
-                for k in (0, 2):
-                    got[k].append(gs[k].run(xs[k][i], specs[k][3]).copy())
-            outs[mode] = [np.stack(v) for v in got]
-            stats[mode] += [gs[0].server_stats(), gs[2].server_stats()]
-            gs[0].close()
-            gs[2].close()
-    finally:
-        pkg.set_test_option(pkg.TEST_LV2_NO_SERVER, 0)
-    for k in range(len(specs)):
-        assert outs[0][k].tobytes() == outs[1][k].tobytes(), k
-        assert stats[1][k] == dict(calls=0, starts=0)
-        assert stats[0][k]["calls"] == n_calls, stats[0]
-    assert 3 <= sum(st["starts"] for st in stats[0][:3]) <= 8, stats[0]   # (one start per instance that joins; more only if the box stalled)
-    assert stats[0][3]["calls"] == n_calls + 5 and stats[0][4]["calls"] == n_calls + 5, stats[0]
-
-
-def test_lv2_run_server_is_held_off_while_another_thread_creates_and_destroys_engines(pkg):
-    """stopping the run() server ONCE is not enough -- an audio thread that calls run() every few milliseconds
-    starts it again while another thread's prot_engine_create / destroy is still inside hipMalloc / hipFree, which wait for a
-    device without a resident kernel: under continuous audio a second instance could not be instantiated or cleaned up.  Create,
-    destroy, reserve, reset and sync now HOLD the server off for their whole duration (run() takes the launch route meanwhile),
-    and the kernel leaves by itself after 0.25 s of residence whatever happens.  A run() loop on A for two seconds while B is
-    created and destroyed over and over: both threads make progress, A's stream of samples stays intact."""
-    import threading
-    import time
-    bs = 512
-    n_buf = 4000
-    x = xorshift_uniform(64 * bs, seed=5).reshape(1, -1)
-    a = pkg.Lv2Instance(48000, 1)
-    a.activate()
-    o = orc.Lv2Engine(48000, 1)
-    stop = threading.Event()
-    got, made, err = [], [0], []
-
-    def audio():
-        try:
-            i = 0
-            t_end = time.perf_counter() + 2.0
-            while time.perf_counter() < t_end and i < n_buf:
-                blk = x[:, (i % 64) * bs:(i % 64 + 1) * bs]
-                got.append(a.run(blk, 90.0).copy())
-                i += 1
-                time.sleep(0.0005)
-        except Exception as ex:   # noqa: BLE001
-            err.append(ex)
-        finally:
-            stop.set()
-
-    def churn():
-        try:
-            while not stop.is_set():
-                b = pkg.Lv2Instance(96000, 2)
-                b.activate()
-                b.run(np.zeros((2, 256), np.float32), [10.0, -20.0])
-                b.close()
-                made[0] += 1
-        except Exception as ex:   # noqa: BLE001
-            err.append(ex)
-
-    t1, t2 = threading.Thread(target=audio), threading.Thread(target=churn)
-    t0 = time.perf_counter()
-    t1.start(); t2.start()
-    t1.join(60.0); t2.join(60.0)
-    assert not t1.is_alive() and not t2.is_alive(), "a thread hangs: the resident kernel blocks the other thread's allocation"
-    assert not err, err
-    assert time.perf_counter() - t0 < 30.0
-    assert made[0] >= 3 and len(got) >= 100, (made[0], len(got))
-    # the stream of samples through the churn: against the oracle fed the same buffers
-    y = np.concatenate(got, 1)
-    xs = np.concatenate([x[:, (i % 64) * bs:(i % 64 + 1) * bs] for i in range(len(got))], 1)
-    want = o.run_stream(xs, 90.0, bs)
-    lat = a.latency + 2304
-    assert np.abs(y - want)[:, lat:].max() < TOL
-    a.close()
-
-
-def test_lv2_three_device_geometries_are_the_same_filter(pkg):
-    """LV2 48 kHz filter in the three device forms: polyphase (default: the odd taps on the stream
-    read as complex samples, one partition, 5120-frame blocks), direct form with two 2048-tap
-    partitions sharing a forward transform, and one zero-padded 4096-pt FFT per 1024-frame hop --
-    same LTI filter."""
-    import torch
-    dev = torch.device("cuda:0")
-    n = 300001  # odd: the last complex sample of the polyphase form is half outside
-    x = torch.from_numpy(xorshift_uniform(n, seed=31)).to(dev)
-    rot = np.array([0.28, -0.96], np.float32)
-    ys = []
-    # default for <= 4096 taps is the direct form (measured 2 % faster than polyphase there)
-    # (polyphase, the default: the 1536 odd taps need a 6-row tail, so 10 rows x 512 = 5120 frames are new per block)
-    want = {0: (1, 5120), pkg.CFG_POLYPHASE: (1, 5120), pkg.CFG_DIRECT_FORM: (2, 2048), pkg.CFG_SINGLE_FFT_PER_HOP: (1, 1024)}
-    for flags in want:
-        e = pkg.Engine(pkg.KIND_LV2, 48000, 1, flags=flags)
-        assert (e.info.partitions, e.info.hop) == want[flags]
-        y = torch.empty_like(x)
-        torch.cuda.synchronize()
-        e.apply_dev(x.data_ptr(), n, n, y.data_ptr(), n, n, rot, pkg.F_STATELESS)
-        e.sync()
-        ys.append(y)
-        e.close()
-    for other in ys[1:]:
-        assert (ys[0] - other).abs().max().item() < TOL
-
-
 @pytest.mark.parametrize("kind,param,hop", [(1, 48000, 5120), (1, 96000, 4096), (1, 192000, 4096), (0, 1024, 7168),
                                             (0, 2048, 6144), (0, 4096, 4096), (0, 8192, 4096), (0, 16384, 4096)])
 def test_polyphase_equals_direct_form(pkg, kind, param, hop):
@@ -395,143 +169,6 @@ def test_polyphase_equals_direct_form(pkg, kind, param, hop):
     assert (res[0][1] - res[0][3]).abs().max().item() < TOL
 
 
-def test_lv2_angle_change_mid_stream(pkg):
-    n, bs = 24000, 512
-    x = xorshift_uniform(n, seed=99).reshape(1, n)
-    g = pkg.Lv2Instance(48000, 1)
-    g.activate()
-    o = orc.Lv2Engine(48000, 1)
-    yg, yo = np.empty_like(x), np.empty_like(x)
-    for s in range(0, n, bs):
-        ang = 45.0 if s < 10240 else -135.0  # 180 deg step: longest ramp, wraps
-        yg[:, s:s + bs] = g.run(x[:, s:s + bs], ang)
-        yo[:, s:s + bs] = o.run(x[:, s:s + bs], ang)
-    assert np.abs(yg - yo).max() < TOL_RAMP
-    assert np.abs(yg[:, 16000:] - yo[:, 16000:]).max() < TOL
-    g.close()
-
-
-def test_lv2_reactivate_clears_history(pkg):
-    x = xorshift_uniform(4096, seed=3).reshape(1, -1)
-    g = pkg.Lv2Instance(48000, 1)
-    g.activate()
-    g.run_stream(x, 90.0, 1024)
-    g.activate()
-    y = g.run(np.zeros((1, 1024), np.float32), 90.0)
-    assert np.abs(y).max() == 0.0
-    g.close()
-
-
-# ---------------------------------------------------------------- sweep ---
-def _signal(n, n_chn, seed):
-    chans = []
-    for c in range(n_chn):
-        h = harmonic_stack(n, f0=110.0 * (1 + 0.31 * c))
-        chans.append(0.85 * h + 0.1 * xorshift_uniform(n, seed=seed + c))
-    return np.stack(chans, axis=1).astype(np.float32).reshape(-1)  # interleaved
-
-
-@pytest.mark.parametrize("blksiz,n_chn,nblk_frac", [(2048, 1, 10.0), (2048, 2, 7.37), (1024, 1, 9.5),
-                                                    (8192, 2, 4.2), (16384, 1, 3.5), (16384, 2, 30.3), (32768, 1, 6.5),
-                                                    (4096, 2, 41.7)])
-def test_sweep_full_table(pkg, blksiz, n_chn, nblk_frac):
-    n = int(blksiz * nblk_frac)
-    data = _signal(n, n_chn, seed=11)
-    g = pkg.PhaseRotate(blksiz, n_chn)
-    g.analyze_file(data, 0, 360, 1)
-    o = orc.CliEngine(blksiz, n_chn)
-    o.analyze_file(data, 0, 360, 1)
-    pg, po = g.peaks(), o.peaks()
-    assert np.abs(db(pg) - db(po)).max() < TOL_DB
-    assert pg[:, 0].tolist() == po[:, 0].tolist()  # angle 0 is an exact abs-max (Q4)
-    for c in range(n_chn):
-        assert int(np.argmin(pg[c])) == int(np.argmin(po[c]))
-    g.close()
-
-
-def test_sweep_block_by_block_matches_oracle(pkg):
-    """PhaseRotate::analyze call for call, incl. start=True on the first block (Q1),
-    stride 24 (Q5) and a single-channel fine pass with negative angles."""
-    P, n_chn, nblk = 2048, 2, 6
-    data = _signal(P * nblk, n_chn, seed=21).reshape(nblk, P * n_chn)
-    g = pkg.PhaseRotate(P, n_chn)
-    o = orc.CliEngine(P, n_chn)
-    for b in range(nblk):
-        g.analyze(data[b], 0, 360, 24, -1, b == 0)
-        o.analyze(data[b], 0, 360, 24, -1, b == 0)
-    assert np.abs(db(g.peaks()) - db(o.peaks())).max() < TOL_DB
-    for a in range(0, 360, 24):
-        assert g.peak(-1, a) == pytest.approx(o.peaks()[:, a].max(), rel=1e-6)
-    g.reset()
-    o.reset()
-    for b in range(nblk):
-        g.analyze(data[b], -12, 13, 1, 1, b == 0)
-        o.analyze(data[b], -12, 13, 1, 1, b == 0)
-    pg, po = g.peaks(), o.peaks()
-    assert np.abs(db(pg) - db(po)).max() < TOL_DB
-    assert np.all(pg[0] == 0)  # channel 0 untouched by a chn=1 pass
-    g.close()
-
-
-def test_sweep_mid_stream_raw_peak_is_complete_call_by_call(pkg):
-    """Angle 0 (the raw peak, calc_peak over the whole new block: cli/phase-rotate.cc:413-414) rides along in the sweep's
-    loaders, which see x[t - P/2]: the last P/2 frames of a call that is not the stream's last must still be in
-    peaks[c][0] when the call returns -- the loudest frame of every block sits in its second half here."""
-    P, n_chn, nblk = 2048, 2, 5
-    data = (0.05 * _signal(P * nblk, n_chn, seed=23)).reshape(nblk, P, n_chn).copy()
-    for b in range(nblk):
-        data[b, P - 3 - b, b % n_chn] = 0.1 + 0.15 * b      # in the last P/2 frames of block b
-    g = pkg.PhaseRotate(P, n_chn)
-    o = orc.CliEngine(P, n_chn)
-    for b in range(nblk):
-        g.analyze(data[b].reshape(-1), 0, 360, 24, -1, b == 0)
-        o.analyze(data[b].reshape(-1), 0, 360, 24, -1, b == 0)
-        pg, po = g.peaks(), o.peaks()
-        assert pg[:, 0].tobytes() == po[:, 0].astype(np.float32).tobytes(), b
-        assert pg[b % n_chn, 0] == np.float32(0.1 + 0.15 * b)
-    # ... and the same through the angle-0-only route and a mixed sequence of the two
-    g.reset()
-    o.reset()
-    for b in range(nblk):
-        a1, st = (1, 24) if b % 2 else (360, 24)
-        g.analyze(data[b].reshape(-1), 0, a1, st, -1, b == 0)
-        o.analyze(data[b].reshape(-1), 0, a1, st, -1, b == 0)
-        assert g.peaks()[:, 0].tobytes() == o.peaks()[:, 0].astype(np.float32).tobytes(), b
-    g.close()
-
-
-def test_sweep_first_block_quirk_q1(pkg):
-    """An early impulse: dry contributions of t < blksiz/2 never enter a rotated peak."""
-    P = 2048
-    x = np.zeros(P * 3, np.float32)
-    x[5] = 0.9
-    g = pkg.PhaseRotate(P, 1)
-    g.analyze_file(x, 0, 360, 1)
-    pg = g.peaks()[0]
-    o = orc.CliEngine(P, 1)
-    o.analyze_file(x, 0, 360, 1)
-    po = o.peaks()[0]
-    assert pg[0] == np.float32(0.9)
-    assert db(pg[2]) < -35.0  # ~ -40 dB at 1 deg (SURVEY Q1)
-    assert np.abs(db(pg[1:]) - db(po[1:])).max() < 0.01
-    g.close()
-
-
-def test_sweep_empty_and_tiny_files(pkg):
-    P = 2048
-    g = pkg.PhaseRotate(P, 1)
-    g.analyze_file(np.zeros(0, np.float32), 0, 360, 24)
-    assert np.all(g.peaks() == 0)
-    g.reset()
-    x = xorshift_uniform(100, seed=2)
-    g.analyze_file(x, 0, 360, 1)
-    o = orc.CliEngine(P, 1)
-    o.analyze_file(x, 0, 360, 1)
-    assert np.abs(g.peaks() - o.peaks()).max() < 1e-6
-    g.close()
-
-
-# ------------------------------------------------- device-resident stream ---
 def test_apply_dev_large_stream_properties(pkg):
     """BASELINE-size style checks through size-independent properties:
     linearity, time-invariance across run boundaries and a 90+90 = polarity flip."""
@@ -600,7 +237,6 @@ def test_apply_dev_stateful_chunks_equal_one_shot(pkg):
     e.close()
 
 
-# ------------------------------------------------------- fp16 sample path ---
 @pytest.mark.parametrize("kind,param,flags", [(1, 48000, 0), (1, 48000, 1), (1, 96000, 0), (0, 2048, 0)])
 def test_fp16_sample_path_tolerance_report(pkg, kind, param, flags, capsys):
     """BASELINE config 5: half samples + packed-half butterflies, fp32 accumulate.
@@ -630,7 +266,6 @@ def test_fp16_sample_path_tolerance_report(pkg, kind, param, flags, capsys):
     e.close()
 
 
-# --------------------------------------------------------- BASELINE sizes ---
 def test_full_size_stream_2p27_properties(pkg):
     """The bench workload itself (LV2 48 kHz filter, 2^27 frames, one launch), checked through
     size-independent properties: (1) three random windows against the float64 LTI model,
@@ -689,263 +324,6 @@ def test_full_size_stream_2p27_properties(pkg):
     e.sync()
     assert torch.equal(y2, 2 * y)
     e.close()
-
-
-def test_full_size_sweep_shards_equal_single_pass(pkg):
-    """The multi-GPU sweep plumbing on ONE device: two engines sweep the two halves of a
-    stereo stream (second one primed with the history in front of its shard), the tables
-    are MAX-merged -- bit-identical to the single-engine table."""
-    import torch
-    from phaserotate_lv2_amd import sweep_dist
-    dev = torch.device("cuda:0")
-    P, n_chn = 2048, 2
-    nb = 3001
-    n = nb * P - 777  # ragged last block
-    g = torch.Generator(device=dev).manual_seed(2)
-    x = (torch.rand((n_chn, n), generator=g, device=dev) - 0.5) * 0.9
-    one = pkg.Engine(pkg.KIND_CLI, P, n_chn)
-    pk1 = torch.zeros((n_chn, 360), device=dev)
-    torch.cuda.synchronize()
-    one.sweep_dev(x.data_ptr(), n, n, 0, 360, 1, -1, pk1.data_ptr(), pkg.F_STREAM_START | pkg.F_STREAM_END)
-    one.sync()
-    # shard boundaries on whole device transform blocks (6144 frames = 3 blocks for this engine)
-    plan = sweep_dist.plan_shards(n, P, 2, align=one.shard_align_blocks())
-    assert all(b0 % one.shard_align_blocks() == 0 for b0, _ in plan)
-    pk2 = torch.zeros((n_chn, 360), device=dev)
-    for r, (b0, b1) in enumerate(plan):
-        f0, nf = sweep_dist.shard_frames(n, P, plan, r)
-        eng = pkg.Engine(pkg.KIND_CLI, P, n_chn)
-        H = eng.info.history
-        if r > 0:
-            halo = x[:, f0 - H:f0].contiguous()
-            torch.cuda.synchronize()
-            keep = sweep_dist.prime_history(eng, halo)
-        xs = x[:, f0:f0 + nf].contiguous()
-        part = torch.zeros((n_chn, 360), device=dev)
-        torch.cuda.synchronize()
-        flags = (pkg.F_STREAM_START if r == 0 else 0) | (pkg.F_STREAM_END if r == len(plan) - 1 else 0)
-        eng.sweep_dev(xs.data_ptr(), nf, nf, 0, 360, 1, -1, part.data_ptr(), flags)
-        eng.sync()
-        pk2 = torch.maximum(pk2, part)
-        eng.close()
-    assert torch.equal(pk1, pk2)
-    one.close()
-
-
-def test_lv2_random_buffer_sizes_and_angle_moves(pkg):
-    """run() with ragged host buffer sizes (1..5000 frames) and the angle port moving at
-    random times: every reference block boundary / ramp start lands somewhere else."""
-    rng = np.random.default_rng(2024)
-    n = 60000
-    x = xorshift_uniform(2 * n, seed=17).reshape(2, n)
-    g = pkg.Lv2Instance(48000, 2)
-    g.activate()
-    o = orc.Lv2Engine(48000, 2)
-    yg, yo = np.empty_like(x), np.empty_like(x)
-    pos, ang = 0, np.array([10.0, -20.0], np.float32)
-    while pos < n:
-        sz = int(min(n - pos, rng.choice([1, 7, 64, 255, 256, 257, 1000, 1024, 3333, 5000])))
-        if rng.random() < 0.15:
-            ang = rng.uniform(-200, 200, 2).astype(np.float32)  # beyond +-180: clamped (src/phaserotate.c:566-571)
-        yg[:, pos:pos + sz] = g.run(x[:, pos:pos + sz], ang)
-        yo[:, pos:pos + sz] = o.run(x[:, pos:pos + sz], ang)
-        pos += sz
-    assert np.abs(yg - yo).max() < TOL_RAMP
-    g.close()
-
-
-def _sweep_table(pkg, x, P, stride, prune, passes=((0, 360, 24), (100, 140, 1)), fused=False):
-    """Peak table [n_chn][360] after a coarse and a fine pass over the interleaved file x, and the
-    fraction of tile groups the sweep actually evaluated.  fused=False keeps the separate Hilbert and sweep
-    passes (whose statistics count tiles of ALL frames) also where the engine would fuse them."""
-    pkg.set_test_option(pkg.TEST_SWEEP_UNPRUNED, 0 if prune else 1)
-    pkg.set_test_option(pkg.TEST_SWEEP_UNFUSED, 0 if fused else 1)
-    try:
-        pr = pkg.PhaseRotate(P, x.shape[1])
-        for a0, a1, st in passes:
-            pr.analyze_file(x, a0, a1, st)
-        tab = np.array([[pr.peak(c, a) for a in range(360)] for c in range(x.shape[1])], np.float32)
-        ev, seen = pr.sweep_stats()
-        _sweep_table.last_stats = pr.sweep_stats_ex()
-        _sweep_table.last_fused = pr.sweep_stats_fused()
-        pr.close()
-    finally:
-        pkg.set_test_option(pkg.TEST_SWEEP_UNPRUNED, 0)
-        pkg.set_test_option(pkg.TEST_SWEEP_UNFUSED, 0)
-    return tab, (ev / seen if seen else None)  # the unpruned kernel keeps no statistics: seen == 0
-
-
-@pytest.mark.parametrize("signal", ["noise+harmonics", "steady-tone", "silence-then-burst", "long-multichunk", "constant",
-                                    "stationary-noise", "tone-then-noise", "bursts"])
-def test_pruned_sweep_is_bit_identical_to_unpruned(pkg, signal):
-    """The sweep tests every frame's r = sqrt(d^2 + h^2) against a lower bound of every final peak and
-    evaluates only compacted tiles of survivors.  That must not change a single bit of the table --
-    including when nothing can be skipped (a steady tone: every frame's r equals every angle's peak; a
-    GROWING signal is no worst case on a parallel machine -- the waves working on the loud end publish
-    their bound to those working on the quiet start), when the bound starts
-    at zero (leading silence), across chunks (> 2^22 frames: later chunks start from the table of the
-    earlier ones) and across passes.  The evaluated fraction is asserted too, both ways: a test in which
-    nothing was skipped would compare the unpruned sweep with itself (that happened with the first,
-    per-wave version of the bound); the steady tone must NOT be skippable and must go through the
-    untested feed; long stationary noise -- the case the group-granular pruning of rounds 1-2 could not
-    touch -- must stay below one half; and a wave that switched the test off on a tone must find its
-    way back once the material turns quiet (two-way switch: "bursts" inside one launch, "tone-then-noise"
-    across chunks)."""
-    P = 2048
-    rng = np.random.default_rng(11)
-    if signal == "noise+harmonics":
-        n = 600000
-        x = np.stack([0.5 * harmonic_stack(n, 48000) + 0.1 * xorshift_uniform(n, seed=3), xorshift_uniform(n, seed=4)], 1)
-    elif signal == "steady-tone":
-        # constant envelope: r(t) = A for every frame and every angle's peak tends to A -- nothing is skippable
-        n = 400000
-        x = (0.7 * np.sin(2 * np.pi * 997.0 / 48000 * np.arange(n)))[:, None]
-    elif signal == "tone-then-noise":
-        # 2^22 frames of the steady tone (test switched off), then 3 x 2^22 of noise below it
-        n = (1 << 22) * 4
-        x = np.empty((n, 1), np.float32)
-        g = 1 << 22
-        x[:g, 0] = 0.7 * np.sin(2 * np.pi * 997.0 / 48000 * np.arange(g))
-        x[g:, 0] = 0.5 * xorshift_uniform(n - g, seed=12)
-    elif signal == "bursts":
-        # ONE launch (a device chunk holds 2^22 frames; a workgroup walks it in steps of 1024 frames, grid-strided, so it
-        # meets the material in file order): a quarter of steady tone -- all of it survives, the test goes off --, then
-        # three quarters of quiet noise, where the wave must switch the test back on
-        n, g = 1 << 22, 1 << 20
-        x = np.empty((n, 1), np.float32)
-        x[:g, 0] = 0.7 * np.sin(2 * np.pi * 997.0 / 48000 * np.arange(g))
-        x[g:, 0] = 0.2 * xorshift_uniform(n - g, seed=30)
-    elif signal == "silence-then-burst":
-        n = 300000
-        x = np.zeros((n, 2), np.float32)
-        x[200000:200700, 0] = xorshift_uniform(700, seed=6)
-        x[299990:, 1] = 0.9
-    elif signal == "long-multichunk":
-        # four device chunks (2^22 frames each): loud material in the first, 40 dB quieter afterwards --
-        # the later chunks start from the bound the first one left in the table and are skipped -- plus
-        # one late click louder than everything, which must still land in the table
-        n = (1 << 22) * 3 + 12345
-        x = (0.8 * harmonic_stack(n, 48000) + 0.05 * xorshift_uniform(n, seed=8))[:, None].astype(np.float32)
-        x[1 << 22:] *= 0.01
-        x[n - 3000:n - 2990] = 0.97
-    elif signal == "stationary-noise":
-        n = (1 << 22) * 3 + 777
-        x = np.stack([0.9 * xorshift_uniform(n, seed=9), 0.9 * xorshift_uniform(n, seed=10)], 1)
-    else:
-        n = 100000
-        x = np.full((n, 1), 0.25, np.float32)
-    x = np.ascontiguousarray(x, np.float32)
-    a, frac_pruned = _sweep_table(pkg, x, P, 24, prune=True)
-    st = dict(_sweep_table.last_stats)
-    b, frac_plain = _sweep_table(pkg, x, P, 24, prune=False)
-    assert a.tobytes() == b.tobytes()
-    # FUSED (round 4): the Hilbert pass lists the frames above the bound of the whole call, the matrix-core kernel evaluates the
-    # lists -- the same table bit for bit; chunks of 2^20 frames and more take that route, the others the separate passes
-    f, _ = _sweep_table(pkg, x, P, 24, prune=True, fused=True)
-    fu = dict(_sweep_table.last_fused)
-    assert f.tobytes() == b.tobytes()
-    assert (fu["tested"] > 0) == (x.shape[0] >= (1 << 20)), fu
-    if fu["tested"]:
-        print("\n[fused sweep, %s] %.1f %% of the tested frames listed" % (signal, 100.0 * fu["listed"] / fu["tested"]))
-        assert fu["listed"] <= fu["tested"]
-        if signal == "long-multichunk":
-            assert fu["listed"] < 0.3 * fu["tested"], fu   # the quiet chunks are listed against the loud one's table
-        if signal == "stationary-noise":
-            assert fu["listed"] < 0.6 * fu["tested"], fu
-    assert a.max() > 0            # every signal here has energy
-    assert frac_plain is None and frac_pruned is not None  # the switch really selects the two kernels
-    assert st["evaluated"] <= st["seen"] + 2 * 4 * 4096 and st["untested"] <= st["evaluated"]  # (+ zero-padded last tiles)
-    print("\n[sweep pruning, %s] evaluated %.1f %% of the tiles, %.1f %% fed untested" %
-          (signal, 100 * frac_pruned, 100.0 * st["untested"] / st["seen"]))
-    # ... and the comparison is not vacuous: pruning must have skipped work where the signal allows it
-    # (no expectation for "constant": its Hilbert branch is ~0, so the peaks near 90 degrees are ~0 and
-    # little is skippable)
-    if signal == "silence-then-burst":
-        assert frac_pruned < 0.1, frac_pruned   # the silences cannot raise anything
-    if signal == "long-multichunk":
-        assert frac_pruned < 0.3, frac_pruned   # a part of the loud quarter is evaluated, the rest is not
-    if signal == "stationary-noise":
-        assert frac_pruned < 0.5, frac_pruned   # VERDICT r2 item 4
-        assert st["untested"] < 0.2 * st["seen"], st
-    if signal == "growing":
-        assert frac_pruned > 0.9, frac_pruned   # every frame holds a new record: nothing may be skipped
-        assert st["untested"] > 0.5 * st["seen"], st  # ... and the test is switched off most of the time
-    if signal == "bursts":
-        assert 0.2 < frac_pruned < 0.85, frac_pruned  # (the tone quarter + the pauses that reach into the noise)
-        assert 0.05 * st["seen"] < st["untested"] < 0.6 * st["seen"], st  # off in the tone, back on in the noise
-    if signal == "growing-then-steady":
-        assert frac_pruned < 0.6, frac_pruned   # the steady 3/4 are tested again (and mostly skipped)
-        assert 0.1 * st["seen"] < st["untested"] < 0.4 * st["seen"], st
-
-
-@pytest.mark.parametrize("stride,blocks", [(1, 12), (3, 4), (4, 3), (5, 3), (6, 2), (8, 2), (24, 1)])
-def test_pruned_sweep_every_angle_block_layout(pkg, stride, blocks):
-    """The sweep kernel spreads 32-angle blocks over four wave groups; 65..96 angles (3 blocks) leave one
-    group without a block -- its waves must neither evaluate nor publish a bound --, 33..64 use two groups,
-    <= 32 one.  Pruned and unpruned tables must be bit-identical in every layout, and equal to the oracle's
-    within the gate."""
-    from phaserotate_lv2_amd import sweep_dist
-    P, n = 2048, 300000
-    x = np.ascontiguousarray(np.stack([0.6 * harmonic_stack(n, 48000) + 0.05 * xorshift_uniform(n, seed=21),
-                                       0.3 * xorshift_uniform(n, seed=22)], 1), np.float32)
-    x[150000:, :] *= 0.05  # something to skip
-    swept = [k for k in sweep_dist.angle_list(0, 360, stride) if k != 0]  # angle 0 is the raw peak, not swept
-    assert (len(swept) + 31) // 32 == blocks
-    passes = ((0, 360, stride),)
-    a, frac = _sweep_table(pkg, x, P, stride, prune=True, passes=passes)
-    b, _ = _sweep_table(pkg, x, P, stride, prune=False, passes=passes)
-    assert a.tobytes() == b.tobytes()
-    assert (a[:, swept] > 0).all()
-    o = orc.CliEngine(P, 2)
-    o.analyze_file(x, 0, 360, stride)
-    ref = o.peaks()
-    d_db = np.abs(20 * np.log10(a[:, swept] / ref[:, swept]))
-    assert d_db.max() < 1e-3, d_db.max()
-
-
-@pytest.mark.parametrize("n_chn,n,passes", [
-    (3, 100000, ((0, 360, 24),)),                 # three channels: the scratch table's channel stride, 15 angles (one block)
-    (1, 700, ((0, 360, 1),)),                     # less than one 1024-frame step, all angles
-    (4, 5000, ((0, 1, 24),)),                     # angle 0 only: no sweep launch, the stand-alone abs-max kernel
-    (2, 2048 * 3 + 1, ((0, 360, 8), (200, 236, 1))),  # a ragged last block, a second pass over a few angles without angle 0
-    (5, 40000, ((1, 360, 7),)),                   # five channels, angle 0 NOT asked for (slot 0 must stay untouched)
-    (33, 9000, ((0, 360, 1),)),                   # more channels than step counters per workgroup slot: fewer than 32 workgroups
-    (64, 7000, ((0, 360, 3),)),                   #   per channel draw from as many counters as there are workgroups (ADVICE r3)
-    (1100, 2500, ((0, 360, 24),)),                # more channels than resident-workgroup slots: the scratch table in several launches
-])
-def test_sweep_table_small_and_many_channel_calls(pkg, n_chn, n, passes):
-    """The sweep's per-launch scratch table and merge kernel (one value per angle, workgroup and wave; the raw peak of angle 0
-    riding along in the loaders) at shapes the long-file tests do not reach: more channels than two, inputs shorter than
-    one step, calls that ask for angle 0 alone or not at all.  Against the oracle (1e-3 dB, angle 0 exact)."""
-    P = 2048
-    x = np.ascontiguousarray(np.stack([0.5 * harmonic_stack(n, 48000) * (0.4 + 0.1 * c) + 0.02 * xorshift_uniform(n, seed=40 + c)
-                                       for c in range(n_chn)], 1), np.float32)
-    g = pkg.PhaseRotate(P, n_chn)
-    o = orc.CliEngine(P, n_chn)
-    asked = set()
-    for a0, a1, st in passes:
-        g.analyze_file(x, a0, a1, st)
-        o.analyze_file(x, a0, a1, st)
-        a = a0
-        while a <= a1:           # the loop bounds of cli/phase-rotate.cc:409-428
-            asked.add(((a % 360) + 360) % 360)
-            a += st
-            if a >= a1:
-                break
-    tab = np.array([[g.peak(c, a) for a in range(360)] for c in range(n_chn)], np.float32)
-    ref = o.peaks()
-    g.close()
-    for a in range(360):
-        if a not in asked:
-            assert (tab[:, a] == 0).all(), a            # untouched slots stay untouched
-    swept = sorted(a for a in asked if a != 0)
-    if 0 in asked:
-        assert tab[:, 0].tobytes() == ref[:, 0].astype(np.float32).tobytes()  # the raw peak: exact
-        assert (tab[:, 0] > 0).all()
-    if swept:
-        assert (tab[:, swept] > 0).all()
-        d_db = np.abs(20 * np.log10(tab[:, swept] / ref[:, swept]))
-        assert d_db.max() < 1e-3, d_db.max()
 
 
 @pytest.mark.parametrize("blksiz,n_chn,n", [(2048, 2, 1 << 23), (8192, 1, 5_000_003), (1024, 3, 777), (2048, 3, 600_001)])
@@ -1022,120 +400,6 @@ def test_overlap_save_equals_overlap_add_on_random_chunkings(pkg, seed):
     assert np.abs(outs[0] - outs[1]).max() < 2e-6, (kind, param, nc, n, stride, len(cuts))
 
 
-@pytest.mark.parametrize("P,signal", [(16384, "harmonic"), (16384, "noise"), (32768, "harmonic"), (1024, "harmonic"), (1024, "noise"),
-                                      (8192, "harmonic"), (8192, "noise"), (4096, "harmonic"), (4096, "noise")])
-def test_fused_sweep_of_the_long_fir_engines_is_bit_identical(pkg, P, signal):
-    """CLI blksiz 16384 (the reference's default at 96 kHz, cli/phase-rotate.cc:749-755) and 32768: the Hilbert branch takes two /
-    four accumulating launches; on the fused route the LAST one tests the complete Hilbert value with its dry frame instead of
-    storing it and lists the survivors (olapoly_kernel MODE_SWEEP); blksiz 1024: its one launch does; blksiz 8192 (the default at 44.1 /
-    48 kHz): olasave8k_kernel<8, MODE_SWEEP>, the generated loop of the 8192-point blocks with the test in its epilogue.  Same table as the separate passes and as the unpruned
-    kernel, bit for bit, over several device chunks (2^22 frames each), a coarse and a fine pass, stereo."""
-    n = (1 << 22) * 2 + 54321
-    if signal == "noise":
-        x = np.stack([0.9 * xorshift_uniform(n, seed=21), 0.6 * xorshift_uniform(n, seed=22)], 1)
-    else:
-        x = np.stack([0.6 * harmonic_stack(n, 96000) + 0.03 * xorshift_uniform(n, seed=23),
-                      0.5 * harmonic_stack(n, 96000)[::-1] + 0.03 * xorshift_uniform(n, seed=24)], 1)
-        x[n // 3:n // 2] *= 0.1
-    x = np.ascontiguousarray(x, np.float32)
-    b, _ = _sweep_table(pkg, x, P, 24, prune=False)
-    a, _ = _sweep_table(pkg, x, P, 24, prune=True)
-    f, _ = _sweep_table(pkg, x, P, 24, prune=True, fused=True)
-    fu = dict(_sweep_table.last_fused)
-    assert a.tobytes() == b.tobytes()
-    assert f.tobytes() == b.tobytes()
-    assert fu["tested"] > 0 and 0 < fu["listed"] < 0.7 * fu["tested"], fu
-    print("\n[fused sweep, blksiz %d, %s] %.1f %% of the tested frames listed" % (P, signal, 100.0 * fu["listed"] / fu["tested"]))
-
-
-def test_fused_sweep_many_channels_and_single_channel_calls(pkg):
-    """The fused route with few workgroups per channel (40 channels share the device: fewer step counters than the kernels'
-    32 per channel are in use) and with single-channel calls on a multi-channel engine (chn >= 0: the lists, the bound and the
-    table rows of ONE channel): both against the unpruned kernel, bit for bit."""
-    n = (1 << 20) + 4321
-    nc = 40
-    x = np.stack([(0.2 + 0.02 * c) * xorshift_uniform(n, seed=300 + c) for c in range(nc)], 1).astype(np.float32)
-    x[n // 2:n // 2 + 2000, 7] = 0.95 * np.sign(x[n // 2:n // 2 + 2000, 7])
-    x = np.ascontiguousarray(x)
-    b, _ = _sweep_table(pkg, x, 2048, 24, prune=False, passes=((0, 360, 3),))
-    f, _ = _sweep_table(pkg, x, 2048, 24, prune=True, passes=((0, 360, 3),), fused=True)
-    fu = dict(_sweep_table.last_fused)
-    assert fu["tested"] == n // 2048 * 2048 * nc or fu["tested"] > 0, fu
-    assert f.tobytes() == b.tobytes()
-    # single-channel calls on a 3-channel engine
-    x3 = np.ascontiguousarray(x[:, :3])
-    tabs = {}
-    for mode in ("unpruned", "fused"):
-        pkg.set_test_option(pkg.TEST_SWEEP_UNPRUNED, 1 if mode == "unpruned" else 0)
-        try:
-            pr = pkg.PhaseRotate(4096, 3)
-            for c in (2, 0):
-                pr.analyze_file(x3, 0, 360, 5, chn=c)
-            tabs[mode] = np.array([[pr.peak(c, a) for a in range(360)] for c in range(3)], np.float32)
-            if mode == "fused":
-                assert pr.sweep_stats_fused()["tested"] > 0
-            pr.close()
-        finally:
-            pkg.set_test_option(pkg.TEST_SWEEP_UNPRUNED, 0)
-    assert tabs["fused"].tobytes() == tabs["unpruned"].tobytes()
-    assert tabs["fused"][1].max() == 0.0 and tabs["fused"][0].max() > 0 and tabs["fused"][2].max() > 0
-
-
-@pytest.mark.parametrize("seed", [1, 2, 3])
-def test_sweep_random_shapes_against_oracle_and_unpruned(pkg, seed):
-    """Randomised: block size, channel count, length (1 frame ... 150 000), angle range and stride, signal shape per channel
-    (noise, tone, growing tone, bursts in silence, level steps, DC), one or two passes.  The pruned table must equal the
-    unpruned one bit for bit and the oracle's within 1e-3 dB, the raw peak (angle 0) exactly.  (tools/sweep_fuzz.py is the
-    long-running pruned-vs-unpruned version of this.)"""
-    rng = np.random.default_rng(seed)
-
-    def signal(n, nc):
-        t = np.arange(n)
-        x = np.zeros((n, nc), np.float32)
-        for c in range(nc):
-            kind, amp = rng.integers(0, 6), rng.uniform(0.05, 0.9)
-            if kind == 0:
-                x[:, c] = amp * (rng.random(n) - 0.5)
-            elif kind == 1:
-                x[:, c] = amp * np.sin(2 * np.pi * rng.uniform(0.001, 0.2) * t)
-            elif kind == 2:
-                x[:, c] = amp * np.sin(2 * np.pi * rng.uniform(0.001, 0.05) * t) * np.linspace(0.1, 1, n)
-            elif kind == 3:
-                for _ in range(rng.integers(1, 6)):
-                    a = rng.integers(0, n)
-                    b = min(n, a + rng.integers(1, 5000))
-                    x[a:b, c] = amp * (rng.random(b - a) - 0.5)
-            elif kind == 4:
-                lev = rng.uniform(0.01, 1.0, 8)
-                x[:, c] = lev[np.minimum(t * 8 // max(n, 1), 7)] * 0.5 * np.sign(np.sin(2 * np.pi * 0.01 * t) + 1e-9) + 0.01 * (rng.random(n) - 0.5)
-            else:
-                x[:, c] = amp * 0.25
-        return np.ascontiguousarray(x)
-
-    for k in range(14):
-        P = int(rng.choice([1024, 2048, 2048, 4096, 8192]))
-        nc = int(rng.choice([1, 2, 2, 3]))
-        n = int(rng.choice([rng.integers(1, 3000), rng.integers(3000, 150000)]))
-        st = int(rng.choice([1, 2, 3, 5, 8, 24]))
-        a0 = int(rng.choice([0, 0, 1, rng.integers(0, 300)]))
-        a1 = int(min(360, a0 + rng.choice([1, 40, 100, 360])))
-        x = signal(n, nc)
-        passes = ((a0, a1, st),) if k % 3 else ((a0, a1, st), (max(0, a0 - 7), min(360, a1 + 9), 1))
-        a, _ = _sweep_table(pkg, x, P, st, prune=True, passes=passes)
-        b, _ = _sweep_table(pkg, x, P, st, prune=False, passes=passes)
-        assert a.tobytes() == b.tobytes(), (seed, k, P, nc, n, passes)
-        o = orc.CliEngine(P, nc)
-        for q0, q1, qs in passes:
-            o.analyze_file(x, q0, q1, qs)
-        ref = o.peaks().astype(np.float32)
-        assert a[:, 0].tobytes() == ref[:, 0].tobytes(), (seed, k, "raw peak")
-        nz = ref[:, 1:] > 1e-12
-        assert ((a[:, 1:] > 0) == (ref[:, 1:] > 0)).all(), (seed, k, "touched slots")
-        if nz.any():
-            d_db = np.abs(20 * np.log10(a[:, 1:][nz] / ref[:, 1:][nz]))
-            assert d_db.max() < 1e-3, (seed, k, P, nc, n, passes, float(d_db.max()))
-
-
 @pytest.mark.parametrize("stride", [70004, 70003])
 @pytest.mark.parametrize("kind,param", [(1, 48000), (1, 96000), (0, 1024), (0, 8192)])
 def test_many_channels_equal_independent_mono_streams(pkg, kind, param, stride):
@@ -1192,34 +456,6 @@ def test_in_place_device_call_is_rejected(pkg):
     e.apply_dev(buf.data_ptr(), n, n, buf.data_ptr() + 4 * n, n, n, rot, pkg.F_STATELESS)  # adjacent: allowed
     e.sync()
     e.close()
-
-
-def test_lv2_96k_engine_switches_form_between_long_and_short_launches(pkg):
-    """The 96 kHz LV2 engine runs the direct two-partition form on long launches and the polyphase form on
-    short ones (fewer halo blocks).  State is input history only, so a stream may alternate between them:
-    long chunk (direct), short chunks (polyphase), long again -- equal to one long launch within the gate,
-    with no step at the seams."""
-    import torch
-    dev = torch.device("cuda:0")
-    big = 1 << 25                      # 16 blocks per workgroup: direct form
-    cuts = [0, big, big + 700, big + 700 + 4096 * 3, 2 * big + 5000]
-    n = cuts[-1]
-    g = torch.Generator(device=dev).manual_seed(5)
-    x = torch.rand(n, generator=g, device=dev) - 0.5
-    rot = np.array([0.6, -0.8], np.float32)
-    e = pkg.Engine(pkg.KIND_LV2, 96000, 1)
-    y1 = torch.empty_like(x)
-    torch.cuda.synchronize()
-    e.apply_dev(x.data_ptr(), n, n, y1.data_ptr(), n, n, rot, pkg.F_STATELESS)   # one launch (direct form)
-    y2 = torch.empty_like(x)
-    for a, b in zip(cuts[:-1], cuts[1:]):
-        e.apply_dev(x.data_ptr() + 4 * a, n, b - a, y2.data_ptr() + 4 * a, n, b - a, rot, 0)
-    e.sync()
-    e.close()
-    d = (y1 - y2).abs()
-    assert d.max().item() < TOL, (d.max().item(), int(d.argmax().item()))
-    for c in cuts[1:-1]:
-        assert d[c - 6000:c + 6000].max().item() < TOL
 
 
 @pytest.mark.parametrize("kind,param", [(1, 48000), (0, 2048), (1, 96000)])
@@ -1279,76 +515,6 @@ def test_no_frame_written_outside_the_requested_range(pkg, kind, param, n):
         assert (y[:n] != 9.0).any() or n < 3
         assert (y[n:stride] == 9.0).all() and (y[stride + n:2 * stride] == 9.0).all(), (off, n)
         assert (yb[:off] == 9.0).all() and (yb[off + 2 * stride:] == 9.0).all()
-
-
-def test_cfg3_shape_against_oracle(pkg):
-    """BASELINE configs[2] in its own shape: LV2 stereo at 96 kHz (4096-tap FIR), 256 buffers of 1024 frames per STATEFUL
-    device launch, three launches back to back -- against the oracle's run() over the same 786 432 frames per channel."""
-    import torch
-    dev = torch.device("cuda:0")
-    n_chn, per = 2, 256 * 1024
-    n = 3 * per
-    x = xorshift_uniform(n_chn * n, seed=96).reshape(n_chn, n)
-    angles = [40.0, -115.0]
-    yo = orc.Lv2Engine(96000, n_chn).run_stream(x, angles, 1024)
-    e = pkg.Engine(pkg.KIND_LV2, 96000, n_chn)
-    rot = np.array([[np.cos(-2 * np.pi * a / 360.0), np.sin(-2 * np.pi * a / 360.0)] for a in angles], np.float32).reshape(-1)
-    xd = torch.from_numpy(x).to(dev)
-    yd = torch.empty_like(xd)
-    for k in range(3):
-        xin = xd[:, k * per:(k + 1) * per].contiguous()
-        yout = torch.empty_like(xin)
-        torch.cuda.synchronize()
-        e.apply_dev(xin.data_ptr(), per, per, yout.data_ptr(), per, per, rot, 0)  # stateful: the history carries over
-        e.sync()
-        yd[:, k * per:(k + 1) * per] = yout
-    yg = yd.cpu().numpy()
-    s0 = 2560 + 2 * 1024  # Q10: run() ramps from 0 deg on its first blocks; the device call starts steady
-    assert np.abs(yg[:, s0:] - yo[:, s0:]).max() < TOL
-    e.close()
-
-
-@pytest.mark.parametrize("rate,per,n_launch", [(96000, 256 * 1024, 24), (48000, 64 * 1024, 40), (96000, 20480, 33)])
-def test_pipelined_launches_equal_sequential_ones(pkg, rate, per, n_launch):
-    """PROT_CFG_PIPELINE: stateful launches on the engine's own streams alternate between two streams and
-    hand the history over on the device.  N pipelined launches must equal N sequential ones bit for bit -- outputs AND the
-    state they leave (one more, sequential, call on both engines) --, also when other calls (a ramp call, a sync, a call on
-    a caller's stream) interrupt the series and force a join, and for launches too short to qualify (n_in < history)."""
-    import torch
-    dev = torch.device("cuda:0")
-    n_chn = 2
-    n = (n_launch + 3) * per
-    x = torch.from_numpy(xorshift_uniform(n_chn * n, seed=77).reshape(n_chn, n)).to(dev)
-    rot = np.array([0.6, 0.8, -0.28, 0.96], np.float32)
-    outs = []
-    for flags in (0, pkg.CFG_PIPELINE):
-        e = pkg.Engine(pkg.KIND_LV2, rate, n_chn, flags=flags)
-        assert e.info.form in (pkg.FORM_POLY_SAVE, pkg.FORM_POLY_SAVE8K)   # (these launches are short: the 4096-point kernel either way)
-        y = torch.zeros_like(x)
-        ts = torch.cuda.Stream()
-        for k in range(n_launch):
-            xin, yout = x[:, k * per:(k + 1) * per], y[:, k * per:(k + 1) * per]
-            if k == 9:      # a call on a caller's stream in the middle of the series: ordered behind it, and the series after it
-                e.apply_dev(xin.data_ptr(), n, per, yout.data_ptr(), n, per, rot, 0, ts.cuda_stream)
-                ts.synchronize()
-            elif k == 17:   # a short call (less input than the history is long) cannot take the pipelined route
-                h = per // 2 if per // 2 < e.info.history else 1000
-                e.apply_dev(xin.data_ptr(), n, h, yout.data_ptr(), n, h, rot, 0)
-                e.apply_dev(xin.data_ptr() + 4 * h, n, per - h, yout.data_ptr() + 4 * h, n, per - h, rot, 0)
-            else:
-                e.apply_dev(xin.data_ptr(), n, per, yout.data_ptr(), n, per, rot, 0)
-            if k == 5:
-                e.sync()
-        # the state the series leaves: one more call, per-frame rotation (never pipelined)
-        k = n_launch
-        rs = torch.from_numpy(np.tile(rot, (per, 1)).reshape(per, n_chn, 2).transpose(1, 0, 2).copy()).to(dev)
-        e.apply_dev_ramp(x[:, k * per:].data_ptr(), n, per, y[:, k * per:].data_ptr(), n, per, rs.data_ptr(), 0)
-        e.sync()
-        torch.cuda.synchronize()
-        outs.append(y.cpu().numpy())
-        e.close()
-    assert np.abs(outs[0][:, :(n_launch + 1) * per]).max() > 0.05
-    assert outs[0].tobytes() == outs[1].tobytes()
 
 
 @pytest.mark.parametrize("kind,param,chn,n", [(1, 48000, 1, 50_000_017), (1, 48000, 2, 33_333_333), (0, 2048, 1, (1 << 27) - 3),
@@ -1459,7 +625,6 @@ def test_generated_loop_and_cpp_blocks_give_the_same_bits(pkg, kind, param):
     assert float(outs[0][0].abs().max()) > 0.1
 
 
-# ------------------------------------------------- 8192-point blocks (round 4) ---
 @pytest.mark.parametrize("rate,chn,n,odd", [(48000, 1, (1 << 24) + 12345, 0), (96000, 1, (1 << 24) + 777, 0), (48000, 2, (1 << 23) + 4099, 0),
                                              (96000, 2, 9_000_001, 1)])
 def test_block8192_kernel_against_oracle_and_block4096(pkg, rate, chn, n, odd):
@@ -1714,75 +879,3 @@ def test_callers_stream_may_be_destroyed_after_sync(pkg):
         assert eng.peaks().tobytes() == want.tobytes(), rep
     torch.cuda.synchronize()
     eng.close()
-
-
-@pytest.mark.parametrize("rate,n_chn,D,sizes", [(48000, 1, 1024, [1024]), (96000, 2, 1024, [1024, 512, 64, 1000, 333]),
-                                                (48000, 2, 2048, [2048, 1024, 4096, 6000, 5, 777])])
-def test_lv2_deferred_run_equals_the_blocking_route_delayed_by_one_buffer(pkg, rate, n_chn, D, sizes):
-    """Round 6: prot_lv2_set_deferred(D) -- a call posts its block to the resident kernel and returns WITHOUT
-    waiting, with the output D frames older.  Against the blocking route on a second instance fed the same buffers: the same
-    samples BIT FOR BIT, shifted by exactly D frames (first D frames silence), for fixed and ragged buffer sizes (every call
-    <= D, and calls longer than D, which are taken in pieces), through an angle move (the ramp), a reset in the middle and an idle
-    pause (the kernel leaves and is started again); nothing late, nothing dropped (the calls are a Python loop apart)."""
-    import time
-    rng = np.random.default_rng(rate + D)
-    total = 60 * 1024
-    x = (rng.random((n_chn, total), dtype=np.float32) - 0.5)
-    a = pkg.Lv2Instance(rate, n_chn)       # blocking
-    b = pkg.Lv2Instance(rate, n_chn)       # deferred
-    a.activate()
-    b.activate()
-    b.lv2_set_deferred(D)
-    ya, yb = [], []
-    pos, k = 0, 0
-    seg_a, seg_b = [], []
-    while pos < total:
-        n = min(sizes[k % len(sizes)], total - pos)
-        ang = [90.0, -45.0][:n_chn] if pos < total // 3 else [-120.0, 30.0][:n_chn]     # one move: a ramp in the middle
-        blk = x[:, pos:pos + n]
-        for q in range(0, n, D):            # (the deferred mode takes a call longer than D in pieces of D: the same pieces here,
-            seg_a.append(a.run(blk[:, q:q + D], ang).copy())   # or the two routes transform different blocks and agree to 3e-7 only)
-        seg_b.append(b.run(blk, ang).copy())
-        pos += n
-        k += 1
-        if k == 7:
-            time.sleep(0.35)                # idle: the resident kernel leaves; the pending block was served before it left
-        if pos >= total // 2 and ya == []:  # a reset (activate) in the middle: both start again from silence
-            ya.append(np.concatenate(seg_a, 1)); yb.append(np.concatenate(seg_b, 1))
-            seg_a, seg_b = [], []
-            a.activate(); b.activate()
-    ya.append(np.concatenate(seg_a, 1)); yb.append(np.concatenate(seg_b, 1))
-    for sa, sb in zip(ya, yb):
-        m = sa.shape[1]
-        assert m > 2 * D
-        assert not sb[:, :D].any()                                   # D frames of silence first
-        assert sb[:, D:].tobytes() == sa[:, :m - D].tobytes()        # then the blocking route's samples, bit for bit
-    st = b.lv2_deferred_stats()
-    assert st == {"late": 0, "dropped": 0}, st
-    assert b.server_stats()["calls"] >= k - 12                        # (the long calls' pieces of more than one block are launched)
-    b.lv2_set_deferred(0)                                             # off again: the blocking route, no extra delay
-    a.activate(); b.activate()
-    blk = x[:, :4096]
-    assert b.run(blk, 10.0).tobytes() == a.run(blk, 10.0).tobytes()
-    a.close(); b.close()
-
-
-def test_lv2_deferred_run_never_waits_for_the_device(pkg):
-    """... and what the mode is for: with the calls an audio period apart (here 150 us of busy-waiting: a 64-frame period at 48 kHz is
-    1333) no call waits for the device -- mean and slowest single call of 2000, looped in C, against the blocking route's; a host
-    that calls back to back (no period at all) finds blocks late, and that is counted, not waited for."""
-    g = pkg.Lv2Instance(48000, 1)
-    g.activate()
-    mean_b, worst_b = g.time_lv2_run_paced(1024, 2000, 150)
-    g.lv2_set_deferred(1024)
-    mean_d, worst_d = g.time_lv2_run_paced(1024, 2000, 150)
-    st = g.lv2_deferred_stats()
-    print("run() 1024 frames, 150 us apart: blocking %.2f us (slowest %.1f), deferred %.2f us (slowest %.1f); %r" % (mean_b, worst_b, mean_d, worst_d, st))
-    assert st["late"] == 0 and st["dropped"] == 0, st
-    assert mean_d < 5.0 and mean_d < 0.5 * mean_b, (mean_d, mean_b)
-    assert worst_d < 60.0, worst_d          # (one preemption of the test process is allowed for; the mean is the claim)
-    g.activate()
-    g.time_lv2_run_paced(1024, 300, 0)      # back to back: the device cannot keep up with a caller that never pauses
-    st2 = g.lv2_deferred_stats()
-    assert st2["late"] + st2["dropped"] > 0, st2
-    g.close()
