@@ -127,6 +127,10 @@ hipError_t launch_ola_save (const OlaParams& p, int hop_rows, int n_rho_rows, in
 // SvServerAck (device -> host): pinned host-coherent memory the kernel stores into and the host polls.
 constexpr int    kServerMaxChn   = 16;
 constexpr size_t kServerInOffset = 1024; // bytes from the box to the input frames
+// frames in front of a call's input that the server's workgroup keeps in LDS from call to call (round 6): what a block reaches back
+// (dry delay + the context rows in front of the first dry row + 1) has to fit -- post_ola_save_server checks
+constexpr int    kSrvHist        = 6144;
+constexpr int    kSrvIn          = 512 * 10; // the input of a call (at most a block's new rows) and the silence behind it
 struct SvServerBox {
 	// ONE 8-byte store, LAST: the doorbell.  bits 0..31 the call's number (1 .. 2^30, never the same twice in a row), bits 32..62 frames
 	// per channel of the call, bit 63: leave

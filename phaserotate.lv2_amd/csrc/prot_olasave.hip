@@ -103,12 +103,12 @@ extern "C" int prot_debug_srv_t (unsigned* out)
 // The next history of a run() server call (WIDE): hist_out[i] = [old history | input](i + n_in) -- the input is the server's LDS
 // copy, everything else global (address spaces said explicitly: see olasave_body).  Round 5: the server calls it BEHIND the done
 // word -- the host waits for the outputs, the history is this workgroup's own business until its next call (1.8 us off every call).
-PROT_DEV void server_next_history (const OlaParams& p, const int c)
+PROT_DEV void server_next_history (const OlaParams& p, const int c, const float* const srv_in)
 {
 	typedef __attribute__ ((address_space (3))) const float LdsInF;
 	auto in_f = [] (const float* q) -> float { return *(LdsInF*)q; };
 	auto gl_f = [] (const float* q) -> float { return *(PROT_GLOBAL const float*)q; };
-	const float* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
+	const float* __restrict__ in   = srv_in;
 	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
 	const int64_t n_in = p.n_in;
 	if (p.hist_out != nullptr) {
@@ -163,8 +163,49 @@ PROT_DEV void server_next_history (const OlaParams& p, const int c)
 	}
 }
 
+// The server's LDS copy of the frames in front of a call (round 6): sh_hist[kSrvHist + i] = frame i < 0 of the virtual stream
+// [history | input].  Filled from the engine's history in device memory when the workgroup does not hold the frames already (the
+// server's first call, a call whose history is not the one this workgroup wrote last), moved on by every call behind its done word.
+PROT_DEV void server_lds_history_fill (float* const sh_hist, const float* const hist_g, const int hist_len)
+{
+	typedef __attribute__ ((address_space (3))) float LdsF_;
+	for (int base = (int)threadIdx.x; base < kSrvHist; base += 256 * 8) {
+		float v[8];
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			const int h = base + 256 * q - (kSrvHist - hist_len); // index into the engine's history (shorter or longer than the copy)
+			v[q]        = (hist_g != nullptr && h >= 0 && base + 256 * q < kSrvHist) ? *(PROT_GLOBAL const float*)(hist_g + h) : 0.f;
+		}
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			if (base + 256 * q < kSrvHist) {
+				*(LdsF_*)(sh_hist + base + 256 * q) = v[q];
+			}
+		}
+	}
+}
+
+PROT_DEV void server_lds_history_advance (float* const sh_hist, const float* const sh_in, const int n_in)
+{
+	typedef __attribute__ ((address_space (3))) float LdsF_;
+	static_assert (kSrvHist % 256 == 0, "whole turns of the workgroup");
+	constexpr int PER = kSrvHist / 256;
+	const int     n   = n_in < kSrvHist ? n_in : kSrvHist;
+	float         v[PER];
+#pragma unroll
+	for (int q = 0; q < PER; ++q) { // new [i] = old [i + n] while that exists, the input's tail behind it
+		const int i = (int)threadIdx.x + 256 * q;
+		v[q]        = i + n < kSrvHist ? *(LdsF_*)(sh_hist + i + n) : *(LdsF_*)(sh_in + (n_in - kSrvHist + i));
+	}
+	__syncthreads ();
+#pragma unroll
+	for (int q = 0; q < PER; ++q) {
+		*(LdsF_*)(sh_hist + (int)threadIdx.x + 256 * q) = v[q];
+	}
+}
+
 template <int HS, int MODE, bool WIDE = false>
-PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_lo_s, const int chn = -1)
+PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_lo_s, const int chn = -1, const float* const srv_in = nullptr, const float* const srv_hist = nullptr)
 {
 	constexpr int BLK = 512 * HS; // output frames per block
 	constexpr int NT  = 16 - HS;  // context rows
@@ -321,8 +362,11 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 		__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");
 	}
 
-	const float* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
-	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
+	// (WIDE: the call's input frames and the last kSrvHist frames in front of them are the server's LDS copies -- round 6: a call
+	// of the resident server reads nothing from device memory but its parameters and its input)
+	const float* __restrict__ in   = WIDE ? srv_in : p.in + (int64_t)c * p.in_stride;
+	const float* __restrict__ hist = WIDE ? srv_hist : (p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr);
+	const int hist_len             = WIDE ? kSrvHist : p.hist_len;
 	float* __restrict__ out        = p.out + (int64_t)c * p.out_stride;
 	const int64_t n_in = p.n_in;
 	const int     Dd   = p.dry_delay; // even (host guarantees)
@@ -352,7 +396,7 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 	// (a pipelined launch reads a history that another launch, possibly on another XCD, wrote while this one was already
 	// running: frame by frame with device-scope loads -- the aligned 8-byte route could hit a stale line of this XCD's L2,
 	// found as launch 5 of a series reading what launch 1 had read from the same buffer of the ring)
-	const bool hist_al8 = !piped && hist != nullptr && (reinterpret_cast<uintptr_t> (hist) & 7) == 0 && (p.hist_len & 1) == 0;
+	const bool hist_al8 = !piped && hist != nullptr && (reinterpret_cast<uintptr_t> (hist) & 7) == 0 && (hist_len & 1) == 0;
 	// (WIDE: the server's parameters come out of LDS, so every pointer in them is a generic one to the compiler, and a generic load
 	// is waited for with both counters at zero before the next goes out -- the 16 row loads of a staged block went one at a time, 3.7 us;
 	// the address spaces are said here: the input is the server's LDS copy, everything else is global)
@@ -372,13 +416,6 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 			return *q;
 		}
 	};
-	auto gl_f = [] (const float* q) -> float {
-		if constexpr (WIDE) {
-			return *(PROT_GLOBAL const float*)q;
-		} else {
-			return *q;
-		}
-	};
 	auto gl_c = [] (const f2* q) -> f2 {
 		if constexpr (WIDE) {
 			return *(PROT_GLOBAL const f2*)q;
@@ -387,6 +424,9 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 		}
 	};
 	auto ldv = [&] (const float* in_, int64_t n_in_, const float* hist_, int hist_len_, int64_t i) -> float {
+		if constexpr (WIDE) {
+			return in_f (in_ + (int)i);
+		}
 		if (i >= 0) {
 			return i < n_in_ ? in_f (in_ + i) : 0.f;
 		}
@@ -394,20 +434,25 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 		if (hist_ == nullptr || h < 0) {
 			return 0.f;
 		}
-		return piped ? __hip_atomic_load (const_cast<float*> (hist_) + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gl_f (hist_ + h);
+		return piped ? __hip_atomic_load (const_cast<float*> (hist_) + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : in_f (hist_ + h);
 	};
 	auto row_pair = [&] (int64_t ar, int t) -> f2 {
+		if constexpr (WIDE) {
+			// (the server's [frames in front | input | silence to the end of the block] is ONE array in LDS: sixteen unconditional reads
+			// in flight -- with a wave-uniform choice of source per row they went out one at a time, 2.1 us of LDS latencies)
+			return in_c (reinterpret_cast<const f2*> (in + (int)ar) + t);
+		}
 		if (in_al8 && ar >= 0 && ar + 512 <= n_in) {
 			return in_c (reinterpret_cast<const f2*> (in + ar) + t);
 		}
-		if (hist_al8 && ar + 512 <= 0 && ar + p.hist_len >= 0) {
-			return gl_c (reinterpret_cast<const f2*> (hist + (ar + p.hist_len)) + t);
+		if (hist_al8 && ar + 512 <= 0 && ar + hist_len >= 0 && (!WIDE || (ar & 1) == 0)) {
+			return in_c (reinterpret_cast<const f2*> (hist + (ar + hist_len)) + t);
 		}
 		if (ar >= n_in) { // a row of the silence behind the input (wave-uniform): seven of a 1024-frame run() call's sixteen rows, which
 			return mkf2 (0.f, 0.f); // otherwise take the frame-by-frame route below, two bounds-checked loads with a branch each per lane
 		}
 		const int64_t a = ar + 2 * (int64_t)t;
-		return mkf2 (ldv (in, n_in, hist, p.hist_len, a), ldv (in, n_in, hist, p.hist_len, a + 1));
+		return mkf2 (ldv (in, n_in, hist, hist_len, a), ldv (in, n_in, hist, hist_len, a + 1));
 	};
 
 	for (int64_t s = r0; s < r1;) {
@@ -468,8 +513,10 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 				}
 				const int   l = t & 63, w = t >> 6;
 				const int   rc = l - (HS - NT), rn = NT + l;
-				const float gc = (rc >= 0 && rc < NT) ? ldv (in, n_in, hist, p.hist_len, a0 + 512 * (int64_t)rc + 128 * w - 1) : 0.f;
-				const float gn = (l < HS) ? ldv (in, n_in, hist, p.hist_len, a0 + 512 * (int64_t)rn + 128 * w - 1) : 0.f;
+				const bool  okc = rc >= 0 && rc < NT, okn = l < HS;
+				const float gcv = ldv (in, n_in, hist, hist_len, a0 + 512 * (int64_t)(okc ? rc : 0) + 128 * w - 1);
+				const float gnv = ldv (in, n_in, hist, hist_len, a0 + 512 * (int64_t)(okn ? rn : NT) + 128 * w - 1);
+				const float gc = okc ? gcv : 0.f, gn = okn ? gnv : 0.f;
 #pragma unroll
 				for (int k = 0; k < 16; ++k) {
 					st[256 * k + t] = v[k];
@@ -485,8 +532,8 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 			if constexpr (!WIDE) {
 				const int l = t & 63, w = t >> 6;
 				const int rc = l - (HS - NT), rn = NT + l; // the row this lane gathers for, as a carried / as a new row
-				gcar[t] = (rc >= 0 && rc < NT) ? ldv (in, n_in, hist, p.hist_len, a0 + 512 * (int64_t)rc + 128 * w - 1) : 0.f;
-				gnx[t]  = (l < HS) ? ldv (in, n_in, hist, p.hist_len, a0 + 512 * (int64_t)rn + 128 * w - 1) : 0.f;
+				gcar[t] = (rc >= 0 && rc < NT) ? ldv (in, n_in, hist, hist_len, a0 + 512 * (int64_t)rc + 128 * w - 1) : 0.f;
+				gnx[t]  = (l < HS) ? ldv (in, n_in, hist, hist_len, a0 + 512 * (int64_t)rn + 128 * w - 1) : 0.f;
 			}
 		}
 		__syncthreads ();
@@ -547,6 +594,9 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 		} else {
 #pragma unroll 2
 			for (int k = 0; k < HS; ++k) {
+				if (WIDE && s + 512 * (int64_t)k >= r1) { // (wave-uniform: a 1024-frame run() call ends behind two of its ten rows)
+					break;
+				}
 				f2            o    = st[256 * k + t];
 				const int64_t pos0 = s + 512 * (int64_t)k + 2 * (int64_t)t;
 				if (MODE == MODE_RAMP && pos0 < r1) {
@@ -555,6 +605,10 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 					const f2 cs0 = gl_c (reinterpret_cast<const f2*> (p.rot_s) + ((int64_t)c * p.n_out + pos0));
 					const f2 cs1 = pos0 + 1 < r1 ? gl_c (reinterpret_cast<const f2*> (p.rot_s) + ((int64_t)c * p.n_out + pos0 + 1)) : mkf2 (0.f, 0.f);
 					o            = mkf2 (cs0.x * d.x + cs0.y * o.x, cs1.x * d.y + cs1.y * o.y);
+				}
+				if (WIDE && out_al8 && pos0 + 1 < r1) { // (the server's outputs cross the host link: one 8-byte store per lane, whole lines per wave)
+					*(PROT_GLOBAL f2*)(out + pos0) = o;
+					continue;
 				}
 				if (pos0 < r1) {
 					out[pos0] = o.x;
@@ -640,8 +694,9 @@ constexpr uint64_t kServerLifeTicks = 200000000ull;
 // hardware queue with the first sooner or later and wait behind it for as long as it stays.
 template <int HS>
 PROT_DEV void server_loop (const SvServerBox* const box, SvServerAck* const ack, unsigned* const relay, const unsigned last_seq, const int chn, const int n_chn, const int no_life_cap,
-                           f2* const smem, float* const sw_lo_s, unsigned* const sh_w, float* const sh_in, unsigned* const sh_p)
+                           f2* const smem, float* const sw_lo_s, unsigned* const sh_w, float* const sh_in, unsigned* const sh_p, float* const sh_hist)
 {
+	const float* hist_tag = nullptr; // the history in device memory whose last kSrvHist frames sh_hist holds (nullptr: none yet)
 	const float* const port_in = reinterpret_cast<const float*> (reinterpret_cast<const char*> (box) + kServerInOffset);
 	const int tid  = threadIdx.x;
 	unsigned  seen = last_seq;
@@ -659,6 +714,9 @@ PROT_DEV void server_loop (const SvServerBox* const box, SvServerAck* const ack,
 #endif
 		}
 	};
+	for (int i = tid; i < kSrvIn; i += 256) {
+		*(__attribute__ ((address_space (3))) float*)(sh_in + i) = 0.f;
+	}
 	stage (1u);
 	const uint64_t t_born = __builtin_amdgcn_s_memrealtime ();
 	for (;;) {
@@ -741,18 +799,21 @@ PROT_DEV void server_loop (const SvServerBox* const box, SvServerAck* const ack,
 			}
 		}
 		__syncthreads ();
-		if (tid == 0) { // the block reads its input from here (a generic pointer into LDS; one workgroup = one channel: no stride)
-			OlaParams* const pw = reinterpret_cast<OlaParams*> (sh_p);
-			pw->in              = sh_in;
-			pw->in_stride       = 0;
+		const OlaParams& p = *reinterpret_cast<const OlaParams*> (sh_p); // (p.in is the mailbox: the block reads sh_in instead)
+		{
+			// the frames in front of this call: held in LDS since the call before it (whose next history in device memory is this call's
+			// history: the same address), fetched otherwise
+			const float* const hg = uniform_ptr_generic (p.hist ? p.hist + (int64_t)chn * p.hist_len : nullptr);
+			if (hg != hist_tag) {
+				server_lds_history_fill (sh_hist, hg, p.hist_len);
+				__syncthreads ();
+			}
 		}
-		__syncthreads ();
-		const OlaParams& p = *reinterpret_cast<const OlaParams*> (sh_p);
 		stage (3u);
 		if (p.rot_s != nullptr) {
-			olasave_body<HS, MODE_RAMP, true> (p, smem, sw_lo_s, chn);
+			olasave_body<HS, MODE_RAMP, true> (p, smem, sw_lo_s, chn, sh_in, sh_hist);
 		} else {
-			olasave_body<HS, MODE_ROT, true> (p, smem, sw_lo_s, chn);
+			olasave_body<HS, MODE_ROT, true> (p, smem, sw_lo_s, chn, sh_in, sh_hist);
 		}
 		stage (4u);
 		__builtin_amdgcn_fence (__ATOMIC_RELEASE, ""); // output frames and the next history: visible to the host / to later launches
@@ -765,7 +826,15 @@ PROT_DEV void server_loop (const SvServerBox* const box, SvServerAck* const ack,
 		stage (5u);
 		// the next history: read by this workgroup's next call (program order) or by a launch behind the kernel's end -- nobody
 		// waits for it here
-		server_next_history (p, chn);
+		server_next_history (p, chn, sh_in);
+		if (p.hist_out != nullptr) {
+			server_lds_history_advance (sh_hist, sh_in, (int)p.n_in);
+			hist_tag = uniform_ptr_generic (p.hist_out + (int64_t)chn * p.hist_len);
+		}
+		__syncthreads ();
+		for (int i = tid; i < kSrvIn; i += 256) { // silence behind the next call's input, to the end of its block
+			*(__attribute__ ((address_space (3))) float*)(sh_in + i) = 0.f;
+		}
 		seen = word >> 1;
 	}
 	stage (9u);
@@ -781,13 +850,17 @@ __global__ __launch_bounds__ (256, 1) void olasave_server_kernel (const SvServer
 	__shared__ unsigned sh_w[2];
 	// the call's input frames of this channel, fetched from the mailbox ONCE (the block reads them twice -- its rows and
 	// the next history -- and every read of host memory is a trip over the host link that nothing hides)
-	__shared__ __attribute__ ((aligned (16))) float sh_in[512 * 10];
+	// (round 6: sh_stream = [the kSrvHist frames in front of the call | the call's input | silence]: one array, a block's sixteen rows
+	// are sixteen unconditional reads of it)
+	__shared__ __attribute__ ((aligned (16))) float sh_stream[kSrvHist + kSrvIn];
+	float* const sh_hist = sh_stream;
+	float* const sh_in   = sh_stream + kSrvHist;
 	__shared__ __attribute__ ((aligned (16))) unsigned sh_p[(sizeof (OlaParams) + 3) / 4]; // the call's parameters (read in place)
 	const SvServerSlot& sl = slots.s[blockIdx.y];
 	if (sl.hop_rows == 8) {
-		server_loop<8> (sl.box, sl.ack, sl.relay, sl.last_seq, sl.chn, sl.n_chn, sl.no_life_cap, smem, sw_lo_s, sh_w, sh_in, sh_p);
+		server_loop<8> (sl.box, sl.ack, sl.relay, sl.last_seq, sl.chn, sl.n_chn, sl.no_life_cap, smem, sw_lo_s, sh_w, sh_in, sh_p, sh_hist);
 	} else {
-		server_loop<10> (sl.box, sl.ack, sl.relay, sl.last_seq, sl.chn, sl.n_chn, sl.no_life_cap, smem, sw_lo_s, sh_w, sh_in, sh_p);
+		server_loop<10> (sl.box, sl.ack, sl.relay, sl.last_seq, sl.chn, sl.n_chn, sl.no_life_cap, smem, sw_lo_s, sh_w, sh_in, sh_p, sh_hist);
 	}
 }
 
@@ -818,7 +891,9 @@ hipError_t post_ola_save_server (const OlaParams& p, int hop_rows, int n_rho_row
 {
 	if ((p.dry_delay & 1) || (p.run_frames % (512 * hop_rows)) != 0 || p.accumulate || p.sv == nullptr || n_rho_rows != 1 ||
 	    2 * (p.dry_delay - p.conv_delay) != 512 * (16 - hop_rows) || p.n_out <= 0 || p.run_stride != 0 || p.surv != nullptr || p.hilbert_only ||
-	    p.hs_flag != nullptr || (p.n_out + p.run_frames - 1) / p.run_frames != 1 || n_chn > kServerMaxChn || (hop_rows != 8 && hop_rows != 10)) {
+	    p.hs_flag != nullptr || (p.n_out + p.run_frames - 1) / p.run_frames != 1 || n_chn > kServerMaxChn || (hop_rows != 8 && hop_rows != 10) ||
+	    p.hist == nullptr || p.dry_delay + 512 * ((16 - hop_rows) / 2) + 2 > kSrvHist || 8192 - p.dry_delay - 512 * ((16 - hop_rows) / 2) > kSrvIn ||
+	    p.n_in > 512 * hop_rows) {
 		return hipErrorInvalidValue;
 	}
 	memcpy (&box->p, &p, sizeof (OlaParams));
