@@ -76,8 +76,9 @@ PROT_DEV void hist_write_slice (const OlaParamsT<S>& p, int c, int t)
 template <class S>
 PROT_DEV void run_of_workgroup (const OlaParamsT<S>& p, int64_t& r0, int64_t& rlen)
 {
-	int bx = (int)blockIdx.x;
-	if ((bx | 7) < (int)gridDim.x) {
+	int       bx = (int)blockIdx.x;
+	const int gx = (int)gridDim.x - p.hist_extra; // workgroups with a run (per channel)
+	if ((bx | 7) < gx) {
 		bx = (bx & ~7) | ((bx + (bx >> 3)) & 7);
 	}
 	rlen = p.run_frames;
@@ -86,7 +87,7 @@ PROT_DEV void run_of_workgroup (const OlaParamsT<S>& p, int64_t& r0, int64_t& rl
 		return;
 	}
 	if (p.rank_cu > 0) {
-		const int id = (int)blockIdx.y * (int)gridDim.x + bx, id0 = (int)blockIdx.y * (int)gridDim.x;
+		const int id = (int)blockIdx.y * gx + bx, id0 = (int)blockIdx.y * gx;
 		r0           = 0;
 		const int last = p.n_rank - 1;
 #pragma unroll

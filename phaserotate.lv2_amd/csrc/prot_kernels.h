@@ -38,6 +38,9 @@ struct OlaParamsT {
 	int32_t       rank_cu;
 	int32_t       n_rank;     // 3 (fp32: 3 workgroups per CU) or 4 (fp16 samples)
 	int32_t       rank_frames[4];
+	// olasave_kernel, short launches (round 6): the last hist_extra workgroups of each channel (blockIdx.x >= gridDim.x - hist_extra) copy
+	// the next history and do nothing else; the others skip their slice -- the copy's two round trips leave every block's chain
+	int32_t       hist_extra;
 	// steady rotation by value ({ca, sa} of channels 0..15, read when rot == NULL): two floats per channel ride in the
 	// kernel arguments instead of a host-to-device copy in front of every launch (4 us on a 20 us launch)
 	float         rot_v[2 * kRotInline];

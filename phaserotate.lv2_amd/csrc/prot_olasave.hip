@@ -163,6 +163,45 @@ PROT_DEV void server_next_history (const OlaParams& p, const int c, const float*
 	}
 }
 
+// Part `part` of `nparts` of a channel's next history, hist_out[i] = [hist | in | silence](n_in - hist_len + i), eight loads in flight per
+// thread and no branch around a load (short launches, round 6: the workgroups that do this do nothing else -- OlaParams::hist_extra)
+PROT_DEV void hist_write_part (const OlaParams& p, const int c, const int part, const int nparts)
+{
+	if (p.hist_out == nullptr) {
+		return;
+	}
+	const int per = (((p.hist_len + nparts - 1) / nparts) + 3) & ~3;
+	const int i0  = part * per;
+	const int i1  = i0 + per < p.hist_len ? i0 + per : p.hist_len;
+	const float* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
+	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
+	float* __restrict__ ho         = p.hist_out + (int64_t)c * p.hist_len;
+	if (p.n_in <= 0) {
+		for (int i = i0 + (int)threadIdx.x; i < i1; i += 256) {
+			ho[i] = ldv (in, p.n_in, hist, p.hist_len, p.n_in - p.hist_len + i);
+		}
+		return;
+	}
+	for (int base = i0 + (int)threadIdx.x; base < i1; base += 256 * 8) {
+		float v[8];
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			const int     i  = base + 256 * q < i1 ? base + 256 * q : i1 - 1;
+			const int64_t f  = p.n_in - p.hist_len + i; // frame of the virtual stream (< n_in)
+			const bool    hs = f < 0 && hist != nullptr && f + p.hist_len >= 0;
+			const float*  a  = hs ? hist + (f + p.hist_len) : in + (f >= 0 ? f : 0);
+			const float   x  = *a;
+			v[q]             = (f >= 0 || hs) ? x : 0.f;
+		}
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			if (base + 256 * q < i1) {
+				ho[base + 256 * q] = v[q];
+			}
+		}
+	}
+}
+
 // The server's LDS copy of the frames in front of a call (round 6): sh_hist[kSrvHist + i] = frame i < 0 of the virtual stream
 // [history | input].  Filled from the engine's history in device memory when the workgroup does not hold the frames already (the
 // server's first call, a call whose history is not the one this workgroup wrote last), moved on by every call behind its done word.
@@ -226,6 +265,12 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 	// last workgroup to get there.  (The host takes this route only when n_in >= hist_len: the slice is then a plain copy
 	// of input frames and does not read the previous history.)
 	const bool piped = MODE != MODE_SWEEP && p.hs_flag != nullptr;
+	if constexpr (!WIDE && MODE != MODE_SWEEP) {
+		if (p.hist_extra > 0 && (int)blockIdx.x >= (int)gridDim.x - p.hist_extra) { // a workgroup of the next history (short launches)
+			hist_write_part (p, c, (int)blockIdx.x - ((int)gridDim.x - p.hist_extra), p.hist_extra);
+			return;
+		}
+	}
 	// MODE_SWEEP: the bound of this launch -- the smallest of the table's entries for the call's angles as they stand now (they only
 	// grow: a lower bound of every final peak), squared, less prot_sweep.hip's margin; every wave appends to a list of its own
 	float            sw_raw = 0.f;
@@ -333,7 +378,7 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 	int64_t   r0, rlen;
 	run_of_workgroup (p, r0, rlen);
 	if (r0 >= p.n_out) {
-		if (!piped) {
+		if (!piped && p.hist_extra == 0) {
 			hist_write_slice (p, c, threadIdx.x);
 		}
 		if (MODE == MODE_SWEEP && (t0 & 63) == 0) {
@@ -481,12 +526,14 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 					PROT_SV_ALL (ASM, a_in, a_out, nf, ca, sa)
 				}
 #ifdef PROT_SV_CLOCK
+#ifndef PROT_SV_CLOCK_NOSUM // (the sums are four atomics at the end of every run: microseconds on a short launch -- tools/cfg3_timeline.py builds without)
 				if (t0 == 0) {
 					atomicAdd (&g_sv_clock[0], (unsigned long long)(__builtin_readcyclecounter () - c0));
 					atomicAdd (&g_sv_clock[1], (unsigned long long)(__builtin_amdgcn_s_memrealtime () - q0));
 					atomicAdd (&g_sv_clock[2], (unsigned long long)nf);
 					atomicAdd (&g_sv_clock[3], 1ull);
 				}
+#endif
 				wg_a0 = wg_a0 ? wg_a0 : q0;
 				wg_a1 = __builtin_amdgcn_s_memrealtime ();
 #endif
@@ -523,13 +570,46 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 				}
 				gcar[t] = gc;
 				gnx[t]  = gn;
+#ifdef PROT_NO_STAGE6
+			} else if (false) {
+#else
+			} else if (MODE != MODE_SWEEP && !piped) {
+#endif // (the sweep's instantiations have no registers for it: they spill as it is)
+				// (round 6: a staged block is the WHOLE chain of its workgroup on a short launch -- cfg3's first and last block of each
+				// channel took 9.2-9.7 us beside 6.1 for the blocks of the generated loop, with the sixteen rows fetched one after the
+				// other behind wave-uniform branches.  Every frame by one unconditional load from an address chosen without a branch:
+				// thirty-four loads in flight, one round trip)
+				const float* const safe = a_sv; // (an address that can always be read)
+				auto ldq = [&] (int64_t i) -> float {
+					const int64_t h    = i + hist_len;
+					const bool    ok_i = i >= 0 && i < n_in;
+					const bool    ok_h = i < 0 && hist != nullptr && h >= 0;
+					const float*  a    = ok_i ? in + i : (ok_h ? hist + h : safe);
+					const float   x    = *a;
+					return (ok_i || ok_h) ? x : 0.f;
+				};
+				f2 v[16];
+#pragma unroll
+				for (int k = 0; k < 16; ++k) {
+					const int64_t a = a0 + 512 * (int64_t)k + 2 * (int64_t)t;
+					v[k]            = mkf2 (ldq (a), ldq (a + 1));
+				}
+				const int   l = t & 63, w = t >> 6;
+				const int   rc = l - (HS - NT), rn = NT + l; // the row this lane gathers for, as a carried / as a new row
+				const bool  okc = rc >= 0 && rc < NT, okn = l < HS;
+				const float gcv = ldq (a0 + 512 * (int64_t)(okc ? rc : 0) + 128 * w - 1);
+				const float gnv = ldq (a0 + 512 * (int64_t)(okn ? rn : NT) + 128 * w - 1);
+#pragma unroll
+				for (int k = 0; k < 16; ++k) {
+					st[256 * k + t] = v[k];
+				}
+				gcar[t] = okc ? gcv : 0.f;
+				gnx[t]  = okn ? gnv : 0.f;
 			} else {
 #pragma unroll 2
 				for (int k = 0; k < 16; ++k) {
 					st[256 * k + t] = row_pair (a0 + 512 * (int64_t)k, t);
 				}
-			}
-			if constexpr (!WIDE) {
 				const int l = t & 63, w = t >> 6;
 				const int rc = l - (HS - NT), rn = NT + l; // the row this lane gathers for, as a carried / as a new row
 				gcar[t] = (rc >= 0 && rc < NT) ? ldv (in, n_in, hist, hist_len, a0 + 512 * (int64_t)rc + 128 * w - 1) : 0.f;
@@ -633,7 +713,7 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 	if (!piped) {
 		if constexpr (WIDE) {
 			// (the run() server writes the next history itself, behind the done word: server_next_history)
-		} else {
+		} else if (p.hist_extra == 0) {
 			hist_write_slice (p, c, threadIdx.x);
 		}
 	}
@@ -654,9 +734,29 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 	}
 }
 
+// Every 64-byte line of the kernel arguments asked for at once: OlaParams is seven lines and the compiler loads its fields where
+// they are used, each first touch of a line a miss that the next branch waits for -- 1.8 us from the kernel's entry to its first
+// block on a short launch (tools/cfg3_timeline.py).  The loaded words are thrown away; the loads behind them hit the scalar cache.
+PROT_DEV void kernarg_prefetch ()
+{
+	const uint64_t ka = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr ();
+	unsigned d0, d1, d2, d3, d4, d5, d6;
+	static_assert (sizeof (OlaParams) <= 7 * 64 && sizeof (OlaParams) > 6 * 64, "one load per line of the arguments");
+	asm volatile ("s_load_dword %0, %7, 0x0\n\ts_load_dword %1, %7, 0x40\n\ts_load_dword %2, %7, 0x80\n\ts_load_dword %3, %7, 0xc0\n\t"
+	              "s_load_dword %4, %7, 0x100\n\ts_load_dword %5, %7, 0x140\n\ts_load_dword %6, %7, 0x180\n\t"
+	              "s_waitcnt lgkmcnt(0)" // (the words arrive in registers the compiler believes written HERE: without the wait it reuses them at once
+	                                     // and the late words land on live values -- seen as a crash)
+	              : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6) // (early clobber: a word that arrives while the
+	                // later loads are still being issued -- a busy scalar cache on a big launch -- must not land on the address: seen as an aperture violation)
+	              : "s"(ka));
+}
+
 template <int HS, int MODE>
 __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 {
+#ifndef PROT_NO_KPREFETCH
+	kernarg_prefetch ();
+#endif
 	__shared__ f2    smem[kLdsExchange + 512]; // the exchange area + the two W256 tables (written by the generated prologue)
 	__shared__ float sw_lo_s[4];
 	olasave_body<HS, MODE> (p, smem, sw_lo_s);
@@ -900,6 +1000,8 @@ hipError_t post_ola_save_server (const OlaParams& p, int hop_rows, int n_rho_row
 	return hipSuccess;
 }
 
+constexpr int kHistExtra = 4, kHistExtraMaxRuns = 200;
+
 template <int HS>
 static hipError_t launch_sv_m (const OlaParams& p, dim3 grid, hipStream_t s)
 {
@@ -932,10 +1034,22 @@ hipError_t launch_ola_save (const OlaParams& p, int hop_rows, int n_rho_rows, in
 	const int64_t unit = p.run_stride > 0 ? p.run_stride : p.run_frames;
 	const int64_t runs = (p.n_out + unit - 1) / unit;
 	dim3          grid ((unsigned)runs, (unsigned)n_chn);
+	OlaParams     q = p;
+	// a short launch (fewer workgroups than CUs: every block is a lone dependent chain) that also writes the next history: four more
+	// workgroups per channel do that, beside the blocks instead of behind each of them (cfg3: 2.5 us of an 11 us launch)
+#ifndef PROT_NO_HISTEXTRA
+	if (p.hist_out != nullptr && p.hs_flag == nullptr && p.surv == nullptr && p.run_stride == 0 && !p.hilbert_only && runs * n_chn <= kHistExtraMaxRuns)
+#else
+	if (false)
+#endif
+	{
+		q.hist_extra = kHistExtra;
+		grid.x += kHistExtra;
+	}
 	switch (hop_rows * 4 + n_rho_rows) {
-		case 8 * 4 + 1: return launch_sv_m<8> (p, grid, s);
-		case 10 * 4 + 1: return launch_sv_m<10> (p, grid, s);
-		case 12 * 4 + 1: return launch_sv_m<12> (p, grid, s);
+		case 8 * 4 + 1: return launch_sv_m<8> (q, grid, s);
+		case 10 * 4 + 1: return launch_sv_m<10> (q, grid, s);
+		case 12 * 4 + 1: return launch_sv_m<12> (q, grid, s);
 		default: return hipErrorInvalidValue;
 	}
 }
