@@ -159,6 +159,7 @@ def load_library():
 
 # csrc/prot_internal.h: process-wide switches for tests and bench.py (NOT part of the drop-in boundary)
 TEST_SWEEP_UNPRUNED, TEST_EDGE_PATH_ONLY, TEST_LV2_STAGED, TEST_ALLREDUCE, TEST_SWEEP_UNFUSED, TEST_LV2_NO_SERVER, TEST_LV2_NO_BAR, TEST_SEED_MFMA, TEST_FUSED_SPLIT_LOG2, TEST_F16_NO_MFMA = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+TEST_NO_SHORT_CHAIN = 10
 
 
 def set_test_option(option, value):

@@ -145,6 +145,31 @@ bool save_tables (const std::vector<float>& fir, uint32_t F, std::vector<float>&
 				tab[2 * ((size_t)(13 + i) * 256 + t) + 1] = (float)(rho[q + 256 * (15 - i)] / mean);
 			}
 		}
+		if (rows == 1) {
+			// the 512-thread block's constants behind them (prot_kernels.h kSv5*; tools/model/olasave512_model.py tables())
+			tab.resize (2 * (size_t)(prot::kSv5Offset + prot::kSv5Size), 0.f);
+			auto put5 = [&] (size_t idx, double ang) { put ((size_t)prot::kSv5Offset + idx, ang); };
+			for (int j = 1; j <= 7; ++j) {
+				for (int t = 0; t < 512; ++t) {
+					put5 ((size_t)prot::kSv5fA + 512 * (j - 1) + t, -2.0 * M_PI * (t - 0.5) * j / 4096.0);
+					put5 ((size_t)prot::kSv5iA + 512 * (j - 1) + t, +2.0 * M_PI * (double)((t * j) & 4095) / 4096.0);
+				}
+				for (int t = 0; t < 64; ++t) {
+					put5 ((size_t)prot::kSv5fB + 64 * (j - 1) + t, -2.0 * M_PI * (t - 0.5) * j / 512.0);
+					put5 ((size_t)prot::kSv5iB + 64 * (j - 1) + t, +2.0 * M_PI * (double)((t * j) & 511) / 512.0);
+				}
+				for (int t = 0; t < 8; ++t) {
+					put5 ((size_t)prot::kSv5fC + 8 * (j - 1) + t, -2.0 * M_PI * (t - 0.5) * j / 64.0);
+					put5 ((size_t)prot::kSv5iC + 8 * (j - 1) + t, +2.0 * M_PI * (double)((t * j) & 63) / 64.0);
+				}
+			}
+			for (int t = 0; t < 512; ++t) {
+				const int k1 = t >> 6, k2 = (t >> 3) & 7, k3 = t & 7, kk = k1 + 8 * k2 + 64 * k3;
+				const size_t i5 = 2 * ((size_t)prot::kSv5Offset + prot::kSv5Rho + t);
+				tab[i5]     = k3 < 4 ? (float)(rho[kk] / mean) : 1.f;
+				tab[i5 + 1] = k3 >= 4 ? (float)(rho[kk + 3584] / mean) : 1.f;
+			}
+		}
 		return true;
 	}
 	return false;

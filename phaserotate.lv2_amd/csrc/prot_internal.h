@@ -19,7 +19,8 @@ enum {
 	PROT_TEST_SEED_MFMA      = 7, // != 0: the seeding pass of a fused sweep is evaluated by the matrix-core kernels of the main pass (rounds 4's route; A/B)
 	PROT_TEST_FUSED_SPLIT_LOG2 = 8, // > 0: prot_sweep_dev splits calls of more than 2^value channel-frames in two (default 31: the lists' 32-bit entry offsets)
 	PROT_TEST_F16_NO_MFMA    = 9, // != 0: the fp16 sample path keeps its packed-half butterflies on the vector pipe (olapoly_kernel<T16>; A/B and cross-check)
-	PROT_TEST_OPTIONS        = 10
+	PROT_TEST_NO_SHORT_CHAIN = 10, // != 0: short launches keep the 256-thread block (olasave_kernel) instead of the 512-thread one (A/B and cross-check)
+	PROT_TEST_OPTIONS        = 11
 };
 int prot_internal_set_test_option (int option, int value); // 0 or PROT_EINVAL
 // the lists the last fused sweep pass of the engine left (device pointers, valid until the next sweep): float2 entries (dry, hilbert),

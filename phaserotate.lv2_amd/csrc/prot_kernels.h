@@ -130,6 +130,12 @@ hipError_t launch_ola_save (const OlaParams& p, int hop_rows, int n_rho_rows, in
 // SvServerAck (device -> host): pinned host-coherent memory the kernel stores into and the host polls.
 constexpr int    kServerMaxChn   = 16;
 constexpr size_t kServerInOffset = 1024; // bytes from the box to the input frames
+// The 512-thread block's constants (prot_olasave512.hip; tools/model/olasave512_model.py tables()), in float2 behind the fifteen rows of
+// the 256-thread block's table: six twiddle tables [j - 1][index], j = 1..7 -- forward W4096^{(T - 1/2) j} (512 indices),
+// W512^{(t' - 1/2) j} (64), W64^{(d - 1/2) j} (8); inverse conj W4096^{t'' j}, conj W512^{u j}, conj W64^{k1 j} -- and per thread
+// (k1 = T >> 6, k2 = (T >> 3) & 7, k3 = T & 7) the |B| factors of its k4 = 0 and k4 = 7 bins over their mean (1 outside the rows next to DC)
+constexpr int kSv5Offset = 15 * 256;
+constexpr int kSv5fA = 0, kSv5iA = 3584, kSv5fB = 7168, kSv5iB = 7616, kSv5fC = 8064, kSv5iC = 8120, kSv5Rho = 8176, kSv5Size = 8688;
 // frames in front of a call's input that the server's workgroup keeps in LDS from call to call (round 6): what a block reaches back
 // (dry delay + the context rows in front of the first dry row + 1) has to fit -- post_ola_save_server checks
 constexpr int    kSrvHist        = 6144;
@@ -162,6 +168,8 @@ struct SvServerSlots {
 	SvServerSlot s[kServerMaxChn];
 };
 hipError_t launch_ola_save_server (const SvServerSlots& slots, hipStream_t s);
+bool       ola_save512_takes (const OlaParamsT<float>& p, int hop_rows, int n_rho_rows, int n_chn, int max_wg);
+hipError_t launch_ola_save512 (const OlaParamsT<float>& p, int hop_rows, int n_chn, hipStream_t s);
 hipError_t post_ola_save_server (const OlaParamsT<float>& p, int hop_rows, int n_rho_rows, int n_chn, SvServerBox* box);
 hipError_t launch_ola_save8k (const OlaParams& p, int hop_rows, int n_chn, hipStream_t s);
 // the same on 16384-point blocks (prot_olasave16k.hip: 1024-thread workgroups, hop_rows = 8: CLI blksiz 16384)

@@ -163,45 +163,6 @@ PROT_DEV void server_next_history (const OlaParams& p, const int c, const float*
 	}
 }
 
-// Part `part` of `nparts` of a channel's next history, hist_out[i] = [hist | in | silence](n_in - hist_len + i), eight loads in flight per
-// thread and no branch around a load (short launches, round 6: the workgroups that do this do nothing else -- OlaParams::hist_extra)
-PROT_DEV void hist_write_part (const OlaParams& p, const int c, const int part, const int nparts)
-{
-	if (p.hist_out == nullptr) {
-		return;
-	}
-	const int per = (((p.hist_len + nparts - 1) / nparts) + 3) & ~3;
-	const int i0  = part * per;
-	const int i1  = i0 + per < p.hist_len ? i0 + per : p.hist_len;
-	const float* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
-	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
-	float* __restrict__ ho         = p.hist_out + (int64_t)c * p.hist_len;
-	if (p.n_in <= 0) {
-		for (int i = i0 + (int)threadIdx.x; i < i1; i += 256) {
-			ho[i] = ldv (in, p.n_in, hist, p.hist_len, p.n_in - p.hist_len + i);
-		}
-		return;
-	}
-	for (int base = i0 + (int)threadIdx.x; base < i1; base += 256 * 8) {
-		float v[8];
-#pragma unroll
-		for (int q = 0; q < 8; ++q) {
-			const int     i  = base + 256 * q < i1 ? base + 256 * q : i1 - 1;
-			const int64_t f  = p.n_in - p.hist_len + i; // frame of the virtual stream (< n_in)
-			const bool    hs = f < 0 && hist != nullptr && f + p.hist_len >= 0;
-			const float*  a  = hs ? hist + (f + p.hist_len) : in + (f >= 0 ? f : 0);
-			const float   x  = *a;
-			v[q]             = (f >= 0 || hs) ? x : 0.f;
-		}
-#pragma unroll
-		for (int q = 0; q < 8; ++q) {
-			if (base + 256 * q < i1) {
-				ho[base + 256 * q] = v[q];
-			}
-		}
-	}
-}
-
 // The server's LDS copy of the frames in front of a call (round 6): sh_hist[kSrvHist + i] = frame i < 0 of the virtual stream
 // [history | input].  Filled from the engine's history in device memory when the workgroup does not hold the frames already (the
 // server's first call, a call whose history is not the one this workgroup wrote last), moved on by every call behind its done word.
@@ -732,23 +693,6 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 			}
 		}
 	}
-}
-
-// Every 64-byte line of the kernel arguments asked for at once: OlaParams is seven lines and the compiler loads its fields where
-// they are used, each first touch of a line a miss that the next branch waits for -- 1.8 us from the kernel's entry to its first
-// block on a short launch (tools/cfg3_timeline.py).  The loaded words are thrown away; the loads behind them hit the scalar cache.
-PROT_DEV void kernarg_prefetch ()
-{
-	const uint64_t ka = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr ();
-	unsigned d0, d1, d2, d3, d4, d5, d6;
-	static_assert (sizeof (OlaParams) <= 7 * 64 && sizeof (OlaParams) > 6 * 64, "one load per line of the arguments");
-	asm volatile ("s_load_dword %0, %7, 0x0\n\ts_load_dword %1, %7, 0x40\n\ts_load_dword %2, %7, 0x80\n\ts_load_dword %3, %7, 0xc0\n\t"
-	              "s_load_dword %4, %7, 0x100\n\ts_load_dword %5, %7, 0x140\n\ts_load_dword %6, %7, 0x180\n\t"
-	              "s_waitcnt lgkmcnt(0)" // (the words arrive in registers the compiler believes written HERE: without the wait it reuses them at once
-	                                     // and the late words land on live values -- seen as a crash)
-	              : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6) // (early clobber: a word that arrives while the
-	                // later loads are still being issued -- a busy scalar cache on a big launch -- must not land on the address: seen as an aperture violation)
-	              : "s"(ka));
 }
 
 template <int HS, int MODE>

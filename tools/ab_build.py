@@ -16,7 +16,7 @@ for u, o in zip(HOST, HOST_T):
     if b._newer(o, [os.path.join(b.CSRC, u + ".hip"), os.path.join(b.CSRC, "prot_engine.h"), os.path.join(b.CSRC, "prot_kernels.h")]):
         b._run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-function", "-DPROT_TUNING", "-DPROT_TESTHOOKS",
                 "-I" + os.path.join(ROOT, "include"), "-c", os.path.join(b.CSRC, u + ".hip"), "-o", o])
-UNITS = ("prot_kernels", "prot_olapoly", "prot_olasave", "prot_olasave8k", "prot_olasave16k", "prot_sweep", "prot_kernels_f16", "prot_f16mfma")
+UNITS = ("prot_kernels", "prot_olapoly", "prot_olasave", "prot_olasave8k", "prot_olasave16k", "prot_sweep", "prot_kernels_f16", "prot_f16mfma", "prot_olasave512")
 
 
 def link(tag, replaced):
@@ -68,6 +68,14 @@ for arg in sys.argv[1:]:
                 "-I" + os.path.join(ROOT, "include"), "-ffast-math", "-fno-slp-vectorize"] + extra +
                ["-c", os.path.join(b.CSRC, "prot_olasave.hip"), "-o", o])
         link(tag, {"prot_olasave": o})
+        continue
+    if arg.startswith("s5:"):
+        # "s5:<tag>[:flag,flag]": a variant of prot_olasave512.hip (the 512-thread short-chain block)
+        _, tag, fl = (arg.split(":") + [""])[:3]
+        o = os.path.join(b.OBJDIR, "prot_olasave512_%s.o" % tag)
+        b._run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-ffast-math",
+                "-fno-slp-vectorize"] + [f for f in fl.split(",") if f] + ["-c", os.path.join(b.CSRC, "prot_olasave512.hip"), "-o", o])
+        link(tag, {"prot_olasave512": o})
         continue
     tag, _, fl = arg.partition(":")
     extra = [f for f in fl.split(",") if f]

@@ -19,7 +19,7 @@ if "--build" in sys.argv:
         o=os.path.join(b.OBJDIR,u+"_stamps.o"); b._run(fl+["-c",os.path.join(b.CSRC,u+".hip"),"-o",o]); host.append(o)
     lib=os.path.join(b.LIBDIR,"variants","libprot_hip_stamps.so")
     os.makedirs(os.path.dirname(lib),exist_ok=True)
-    b._run([hipcc,"--offload-arch=gfx950","-shared","-fPIC","-o",lib,o1]+host+[os.path.join(b.OBJDIR,x) for x in ("prot_kernels.o","prot_olapoly.o","prot_olasave8k.o","prot_olasave16k.o","prot_sweep.o","prot_kernels_f16.o","prot_f16mfma.o")]+["-lpthread"])
+    b._run([hipcc,"--offload-arch=gfx950","-shared","-fPIC","-o",lib,o1]+host+[os.path.join(b.OBJDIR,x) for x in ("prot_kernels.o","prot_olapoly.o","prot_olasave8k.o","prot_olasave16k.o","prot_sweep.o","prot_kernels_f16.o","prot_f16mfma.o","prot_olasave512.o")]+["-lpthread"])
     print("built",lib)
     sys.exit(0)
 import os, sys, time, ctypes as C
