@@ -51,16 +51,7 @@ extern "C" int prot_debug_sv_wg (unsigned long long* out, int n_wg)
 	return hipMemcpyFromSymbol (out, HIP_SYMBOL (g_sv_wg), sizeof (unsigned long long) * 4 * (size_t)(n_wg < 4096 ? n_wg : 4096)) == hipSuccess ? 0 : -1;
 }
 #endif
-#ifdef PROT_SERVER_STAMPS
-__device__ unsigned g_srv_t[16];
-extern "C" int prot_debug_srv_t (unsigned* out)
-{
-	return hipMemcpyFromSymbol (out, HIP_SYMBOL (g_srv_t), sizeof (g_srv_t)) == hipSuccess ? 0 : -1;
-}
-#define PROT_SRV_T(i) if (WIDE && threadIdx.x == 0 && blockIdx.y == 0) { g_srv_t[i] = (unsigned)__builtin_amdgcn_s_memrealtime (); }
-#else
 #define PROT_SRV_T(i)
-#endif
 #define PROT_SV_CAT_(k, a, b, c) PROT_SV_##k##_##a##_##b##_##c
 #define PROT_SV_CLOB_(a) PROT_SV_ASM_CLOBBERS_##a
 // one generated block of code: KIND_ = ASM (a run of nf whole blocks streamed from / to global memory) or CORE (one block staged
@@ -100,110 +91,6 @@ extern "C" int prot_debug_srv_t (unsigned* out)
 //    sweep does not depend on where its chunks end), and stored from LDS with bounds.
 // WIDE (the run() server: one workgroup per CU, registers to spare, and every load a round trip nothing else hides): the 16 rows of
 // a staged block are fetched before the first is parked, the history slice moves eight frames per thread at a time, without a branch per frame
-// The next history of a run() server call (WIDE): hist_out[i] = [old history | input](i + n_in) -- the input is the server's LDS
-// copy, everything else global (address spaces said explicitly: see olasave_body).  Round 5: the server calls it BEHIND the done
-// word -- the host waits for the outputs, the history is this workgroup's own business until its next call (1.8 us off every call).
-PROT_DEV void server_next_history (const OlaParams& p, const int c, const float* const srv_in)
-{
-	typedef __attribute__ ((address_space (3))) const float LdsInF;
-	auto in_f = [] (const float* q) -> float { return *(LdsInF*)q; };
-	auto gl_f = [] (const float* q) -> float { return *(PROT_GLOBAL const float*)q; };
-	const float* __restrict__ in   = srv_in;
-	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
-	const int64_t n_in = p.n_in;
-	if (p.hist_out != nullptr) {
-		const int per = (p.hist_len + (int)gridDim.x - 1) / (int)gridDim.x;
-		const int i0  = (int)blockIdx.x * per;
-		const int i1  = i0 + per < p.hist_len ? i0 + per : p.hist_len;
-		float* __restrict__ ho = p.hist_out + (int64_t)c * p.hist_len;
-		// next history [i] = old history [i + n_in] while that exists, input [i - (hist_len - n_in)] after it: two loops without
-		// a branch per frame, eight loads in flight per thread (with the per-frame choice the loads went out one at a time)
-		const int64_t keep64 = (int64_t)p.hist_len - n_in;
-		const int     keep   = keep64 > 0 ? (int)keep64 : 0; // entries that come from the old history
-		const int     a1     = i1 < keep ? i1 : keep;
-		if (hist != nullptr) {
-			const float* __restrict__ hs = hist + n_in;
-			for (int base = i0 + (int)threadIdx.x; base < a1; base += 256 * 8) {
-				float v[8];
-#pragma unroll
-				for (int q = 0; q < 8; ++q) {
-					const int i = base + 256 * q;
-					v[q]        = gl_f (hs + (i < a1 ? i : a1 - 1));
-				}
-#pragma unroll
-				for (int q = 0; q < 8; ++q) {
-					const int i = base + 256 * q;
-					if (i < a1) {
-						*(PROT_GLOBAL float*)(ho + i) = v[q];
-					}
-				}
-			}
-		} else {
-			for (int i = i0 + (int)threadIdx.x; i < a1; i += 256) {
-				ho[i] = 0.f;
-			}
-		}
-		const float* __restrict__ is = in - keep64; // (keep64 < 0: more input than history, the last hist_len frames of it)
-		const int b0 = i0 > keep ? i0 : keep;
-		for (int base = b0 + (int)threadIdx.x; base < i1; base += 256 * 8) {
-			float v[8];
-#pragma unroll
-			for (int q = 0; q < 8; ++q) {
-				const int i = base + 256 * q;
-				v[q]        = in_f (is + (i < i1 ? i : i1 - 1));
-			}
-#pragma unroll
-			for (int q = 0; q < 8; ++q) {
-				const int i = base + 256 * q;
-				if (i < i1) {
-					*(PROT_GLOBAL float*)(ho + i) = v[q];
-				}
-			}
-		}
-	}
-}
-
-// The server's LDS copy of the frames in front of a call (round 6): sh_hist[kSrvHist + i] = frame i < 0 of the virtual stream
-// [history | input].  Filled from the engine's history in device memory when the workgroup does not hold the frames already (the
-// server's first call, a call whose history is not the one this workgroup wrote last), moved on by every call behind its done word.
-PROT_DEV void server_lds_history_fill (float* const sh_hist, const float* const hist_g, const int hist_len)
-{
-	typedef __attribute__ ((address_space (3))) float LdsF_;
-	for (int base = (int)threadIdx.x; base < kSrvHist; base += 256 * 8) {
-		float v[8];
-#pragma unroll
-		for (int q = 0; q < 8; ++q) {
-			const int h = base + 256 * q - (kSrvHist - hist_len); // index into the engine's history (shorter or longer than the copy)
-			v[q]        = (hist_g != nullptr && h >= 0 && base + 256 * q < kSrvHist) ? *(PROT_GLOBAL const float*)(hist_g + h) : 0.f;
-		}
-#pragma unroll
-		for (int q = 0; q < 8; ++q) {
-			if (base + 256 * q < kSrvHist) {
-				*(LdsF_*)(sh_hist + base + 256 * q) = v[q];
-			}
-		}
-	}
-}
-
-PROT_DEV void server_lds_history_advance (float* const sh_hist, const float* const sh_in, const int n_in)
-{
-	typedef __attribute__ ((address_space (3))) float LdsF_;
-	static_assert (kSrvHist % 256 == 0, "whole turns of the workgroup");
-	constexpr int PER = kSrvHist / 256;
-	const int     n   = n_in < kSrvHist ? n_in : kSrvHist;
-	float         v[PER];
-#pragma unroll
-	for (int q = 0; q < PER; ++q) { // new [i] = old [i + n] while that exists, the input's tail behind it
-		const int i = (int)threadIdx.x + 256 * q;
-		v[q]        = i + n < kSrvHist ? *(LdsF_*)(sh_hist + i + n) : *(LdsF_*)(sh_in + (n_in - kSrvHist + i));
-	}
-	__syncthreads ();
-#pragma unroll
-	for (int q = 0; q < PER; ++q) {
-		*(LdsF_*)(sh_hist + (int)threadIdx.x + 256 * q) = v[q];
-	}
-}
-
 template <int HS, int MODE, bool WIDE = false>
 PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_lo_s, const int chn = -1, const float* const srv_in = nullptr, const float* const srv_hist = nullptr)
 {
@@ -704,244 +591,6 @@ __global__ __launch_bounds__ (256, 4) void olasave_kernel (const OlaParams p)
 	__shared__ f2    smem[kLdsExchange + 512]; // the exchange area + the two W256 tables (written by the generated prologue)
 	__shared__ float sw_lo_s[4];
 	olasave_body<HS, MODE> (p, smem, sw_lo_s);
-}
-
-// ---- the run() server (round 4) ----------------------------------------------------------------------------------------------
-// An LV2 host calls run() (src/phaserotate.c:774-852) with ~1024 frames at a time, and a kernel launch plus a stream
-// synchronisation cost more than the block itself: 38-40 us per call, no faster than one host core.  The server is the same block
-// code as a RESIDENT kernel -- one workgroup per channel, started by the first run() and left running: the host stores the call's
-// parameters (the OlaParams the launch would have carried) and its input into the mailbox (SvServerBox, prot_kernels.h: device memory
-// through the PCIe BAR where there is a large one, pinned host-coherent memory otherwise) and rings a doorbell
-// word; workgroup 0 polls the doorbell over the host link, relays the decision to the other channels' workgroups through a
-// device word (ONE decision for all: serve call s, or leave), every workgroup runs the call's block with the code of the
-// launched kernel (olasave_body: same bits), publishes its output with a system-scope release and stores the call's number into
-// its done word, which the host polls.  No launch, no stream synchronisation, no copy command per call.
-// Leaving: on the host's stop command (any other use of the engine stops the server first: prot_lv2.hip) and BY ITSELF after
-// 0.25 s without a doorbell (s_memrealtime: 100 MHz) -- a resident kernel blocks whatever shares its hardware queue and
-// every device-wide synchronisation of the process, so it never outlives the stream of calls it serves; `alive` is its last
-// store.  The host treats a server that has left as absent and starts a new one (with the last served call's number).
-#ifndef PROT_SRV_POLL_SLEEP
-#define PROT_SRV_POLL_SLEEP 4 // (x 64 cycles between two looks at the doorbell; 1 and 0 measured the same to 0.1 us per call)
-#endif
-constexpr uint64_t kServerIdleTicks = 25000000ull;
-// ... and it never stays longer than this, calls or no calls: between two calls it leaves when it has been resident for
-// 2 s, and the next run() starts a new one (130-330 us on the calling thread, once) -- so that a hipFree or a device-wide
-// synchronisation of ANY code in the process, which the library cannot see and cannot stop the server for, completes within two
-// seconds even under continuous audio.  (Round 5: 0.25 s -- four restarts a second on the audio thread under continuous audio,
-// every one of them a stall for every instance of the process: ADVICE r5.  The cap trades that jitter against how long foreign
-// device-wide calls may wait; INTEGRATION.md, "run() latency and jitter".)
-constexpr uint64_t kServerLifeTicks = 200000000ull;
-
-// One slot of the server = one channel of one engine: the engine's mailbox (box, ack), the device word through which its channel 0
-// relays the doorbell to its other channels, the number of the last call it has served.  Round 5: ONE resident kernel serves every
-// LV2 engine of the process that asks (a slot per channel, up to kServerMaxChn in all) -- a second resident kernel would share a
-// hardware queue with the first sooner or later and wait behind it for as long as it stays.
-template <int HS>
-PROT_DEV void server_loop (const SvServerBox* const box, SvServerAck* const ack, unsigned* const relay, const unsigned last_seq, const int chn, const int n_chn, const int no_life_cap,
-                           f2* const smem, float* const sw_lo_s, unsigned* const sh_w, float* const sh_in, unsigned* const sh_p, float* const sh_hist)
-{
-	const float* hist_tag = nullptr; // the history in device memory whose last kSrvHist frames sh_hist holds (nullptr: none yet)
-	const float* const port_in = reinterpret_cast<const float*> (reinterpret_cast<const char*> (box) + kServerInOffset);
-	const int tid  = threadIdx.x;
-	unsigned  seen = last_seq;
-	// (pad0[c]: how far channel c's workgroup has come -- 1 resident, 2 doorbell seen, 3 parameters read, 4 block done, 5 done
-	// word stored, 9 left; what the host prints when a call is not served)
-	auto stage = [&] (unsigned v) {
-		int tid_s = tid;
-		asm volatile ("" : "+v"(tid_s));
-		if (tid_s == 0 && chn < 8) {
-			__hip_atomic_store (&ack->pad0[chn], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#ifdef PROT_SERVER_STAMPS
-			if (chn == 0 && v >= 2u && v <= 5u) { // 100 MHz ticks at the stages of channel 0's workgroup
-				__hip_atomic_store (&ack->pad0[6 + v], (unsigned)__builtin_amdgcn_s_memrealtime (), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-			}
-#endif
-		}
-	};
-	for (int i = tid; i < kSrvIn; i += 256) {
-		*(__attribute__ ((address_space (3))) float*)(sh_in + i) = 0.f;
-	}
-	stage (1u);
-	const uint64_t t_born = __builtin_amdgcn_s_memrealtime ();
-	for (;;) {
-		// (the thread id made opaque at each use, the decision made wave-uniform by readfirstlane: with `tid == 0` guarding both
-		// the end of one pass -- the done word -- and the start of the next -- the poll --, the compiler rotated the loop into
-		// "thread 0: store, poll; everybody else: straight back to the barrier", and the other 255 threads served the same call
-		// again and again while thread 0 waited, masked off, to store its done word: found on the hardware with the stage words)
-		int tid_poll = tid;
-		asm volatile ("" : "+v"(tid_poll));
-		if (tid_poll == 0) {
-			unsigned word;
-			unsigned frames = 0u;
-			if (chn == 0) {
-				unsigned       s = seen, cmd = 0u;
-				const uint64_t t_0 = __builtin_amdgcn_s_memrealtime ();
-				for (;;) {
-					const uint64_t bell = __hip_atomic_load (const_cast<uint64_t*> (&box->bell), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-					s                   = (unsigned)bell;
-					if (s != seen) {
-						cmd    = (unsigned)(bell >> 63);
-						frames = (unsigned)(bell >> 32) & 0x7fffffffu;
-						break;
-					}
-					const uint64_t now = __builtin_amdgcn_s_memrealtime ();
-					if (now - t_0 > kServerIdleTicks || (!no_life_cap && now - t_born > kServerLifeTicks)) {
-						cmd = 1u;
-						break;
-					}
-					__builtin_amdgcn_s_sleep (PROT_SRV_POLL_SLEEP);
-				}
-				word = 2u * s + cmd;
-				if (n_chn > 1) {
-					__hip_atomic_store (relay + 1, frames, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					__hip_atomic_store (relay, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-				}
-			} else {
-				while ((word = __hip_atomic_load (relay, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 2u * seen) {
-					__builtin_amdgcn_s_sleep (2);
-				}
-				frames = __hip_atomic_load (relay + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-			sh_w[0] = word;
-			sh_w[1] = frames;
-		}
-		__syncthreads ();
-		const unsigned word = (unsigned)__builtin_amdgcn_readfirstlane ((int)sh_w[0]);
-		if (word & 1u) {
-			break;
-		}
-		stage (2u);
-		// The host's stores (parameters, input frames, per-frame rotation) happened before its doorbell store, and what is read of
-		// them below is read past the caches (system-scope loads of host-coherent memory) after thread 0 has seen the doorbell.
-		// NO acquire fence: at system scope it invalidates the XCD's L2, and the block's own history -- written by this very
-		// workgroup on this very CU one call ago, the only device data of a call -- came back from HBM instead (staging 3.6 ->
-		// us, history slice 3.3 -> us per call, measured with the stage stamps).
-		// An agent-scope acquire it has to be: it empties this CU's vector cache, which otherwise still holds lines of the history
-		// ring as they were three calls ago (found as outputs that differed from the launched kernel's).
-		__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");
-		const int frames = __builtin_amdgcn_readfirstlane ((int)sh_w[1]) < 512 * HS ? __builtin_amdgcn_readfirstlane ((int)sh_w[1]) : 512 * HS;
-		for (int i = tid; i < (int)(sizeof (OlaParams) / 4); i += 256) {
-			sh_p[i] = __hip_atomic_load (reinterpret_cast<unsigned*> (const_cast<OlaParams*> (&box->p)) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-		}
-		{ // (the port block: [channel][frames], prot_lv2.hip lv2_run_chunk)
-			// (system-scope loads: past the caches, whichever memory the box lives in; eight bytes per lane when the channel's frames
-			// start on an 8-byte boundary)
-			const float* const src = port_in + (int64_t)chn * frames;
-			if (((chn * frames) & 1) == 0) {
-				uint64_t* const       dst8 = reinterpret_cast<uint64_t*> (sh_in);
-				const uint64_t* const src8 = reinterpret_cast<const uint64_t*> (src);
-				for (int i = tid; i < frames / 2; i += 256) {
-					dst8[i] = __hip_atomic_load (const_cast<uint64_t*> (src8) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-				}
-				if ((frames & 1) && tid == 0) {
-					sh_in[frames - 1] = __hip_atomic_load (const_cast<float*> (src) + frames - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-				}
-			} else {
-				for (int i = tid; i < frames; i += 256) {
-					sh_in[i] = __hip_atomic_load (const_cast<float*> (src) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-				}
-			}
-		}
-		__syncthreads ();
-		const OlaParams& p = *reinterpret_cast<const OlaParams*> (sh_p); // (p.in is the mailbox: the block reads sh_in instead)
-		{
-			// the frames in front of this call: held in LDS since the call before it (whose next history in device memory is this call's
-			// history: the same address), fetched otherwise
-			const float* const hg = uniform_ptr_generic (p.hist ? p.hist + (int64_t)chn * p.hist_len : nullptr);
-			if (hg != hist_tag) {
-				server_lds_history_fill (sh_hist, hg, p.hist_len);
-				__syncthreads ();
-			}
-		}
-		stage (3u);
-		if (p.rot_s != nullptr) {
-			olasave_body<HS, MODE_RAMP, true> (p, smem, sw_lo_s, chn, sh_in, sh_hist);
-		} else {
-			olasave_body<HS, MODE_ROT, true> (p, smem, sw_lo_s, chn, sh_in, sh_hist);
-		}
-		stage (4u);
-		__builtin_amdgcn_fence (__ATOMIC_RELEASE, ""); // output frames and the next history: visible to the host / to later launches
-		__syncthreads ();
-		int tid_done = tid;
-		asm volatile ("" : "+v"(tid_done));
-		if (tid_done == 0) {
-			__hip_atomic_store (&ack->done[chn], word >> 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-		}
-		stage (5u);
-		// the next history: read by this workgroup's next call (program order) or by a launch behind the kernel's end -- nobody
-		// waits for it here
-		server_next_history (p, chn, sh_in);
-		if (p.hist_out != nullptr) {
-			server_lds_history_advance (sh_hist, sh_in, (int)p.n_in);
-			hist_tag = uniform_ptr_generic (p.hist_out + (int64_t)chn * p.hist_len);
-		}
-		__syncthreads ();
-		for (int i = tid; i < kSrvIn; i += 256) { // silence behind the next call's input, to the end of its block
-			*(__attribute__ ((address_space (3))) float*)(sh_in + i) = 0.f;
-		}
-		seen = word >> 1;
-	}
-	stage (9u);
-	if (tid == 0 && chn == 0) {
-		__hip_atomic_store (&ack->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-	}
-}
-
-__global__ __launch_bounds__ (256, 1) void olasave_server_kernel (const SvServerSlots slots)
-{
-	__shared__ f2       smem[kLdsExchange + 512];
-	__shared__ float    sw_lo_s[4];
-	__shared__ unsigned sh_w[2];
-	// the call's input frames of this channel, fetched from the mailbox ONCE (the block reads them twice -- its rows and
-	// the next history -- and every read of host memory is a trip over the host link that nothing hides)
-	// (round 6: sh_stream = [the kSrvHist frames in front of the call | the call's input | silence]: one array, a block's sixteen rows
-	// are sixteen unconditional reads of it)
-	__shared__ __attribute__ ((aligned (16))) float sh_stream[kSrvHist + kSrvIn];
-	float* const sh_hist = sh_stream;
-	float* const sh_in   = sh_stream + kSrvHist;
-	__shared__ __attribute__ ((aligned (16))) unsigned sh_p[(sizeof (OlaParams) + 3) / 4]; // the call's parameters (read in place)
-	const SvServerSlot& sl = slots.s[blockIdx.y];
-	if (sl.hop_rows == 8) {
-		server_loop<8> (sl.box, sl.ack, sl.relay, sl.last_seq, sl.chn, sl.n_chn, sl.no_life_cap, smem, sw_lo_s, sh_w, sh_in, sh_p, sh_hist);
-	} else {
-		server_loop<10> (sl.box, sl.ack, sl.relay, sl.last_seq, sl.chn, sl.n_chn, sl.no_life_cap, smem, sw_lo_s, sh_w, sh_in, sh_p, sh_hist);
-	}
-}
-
-hipError_t launch_ola_save_server (const SvServerSlots& slots, hipStream_t s)
-{
-	if (slots.n < 1 || slots.n > kServerMaxChn) {
-		return hipErrorInvalidValue;
-	}
-	for (int i = 0; i < slots.n; ++i) {
-		const SvServerSlot& sl = slots.s[i];
-		if ((sl.hop_rows != 8 && sl.hop_rows != 10) || sl.box == nullptr || sl.ack == nullptr || sl.relay == nullptr) {
-			return hipErrorInvalidValue;
-		}
-		if (sl.chn == 0) {
-			hipError_t err = hipMemsetD32Async (reinterpret_cast<hipDeviceptr_t> (sl.relay), (int)(2u * sl.last_seq), 1, s);
-			if (err != hipSuccess) {
-				return err;
-			}
-		}
-	}
-	hipLaunchKernelGGL (olasave_server_kernel, dim3 (1, (unsigned)slots.n), dim3 (256), 0, s, slots);
-	return hipGetLastError ();
-}
-
-// what launch_ola_save checks, for a call the server is to take: one workgroup per channel, rotation (steady or per frame) --
-// and the parameters go into the box instead of into a launch
-hipError_t post_ola_save_server (const OlaParams& p, int hop_rows, int n_rho_rows, int n_chn, SvServerBox* box)
-{
-	if ((p.dry_delay & 1) || (p.run_frames % (512 * hop_rows)) != 0 || p.accumulate || p.sv == nullptr || n_rho_rows != 1 ||
-	    2 * (p.dry_delay - p.conv_delay) != 512 * (16 - hop_rows) || p.n_out <= 0 || p.run_stride != 0 || p.surv != nullptr || p.hilbert_only ||
-	    p.hs_flag != nullptr || (p.n_out + p.run_frames - 1) / p.run_frames != 1 || n_chn > kServerMaxChn || (hop_rows != 8 && hop_rows != 10) ||
-	    p.hist == nullptr || p.dry_delay + 512 * ((16 - hop_rows) / 2) + 2 > kSrvHist || 8192 - p.dry_delay - 512 * ((16 - hop_rows) / 2) > kSrvIn ||
-	    p.n_in > 512 * hop_rows) {
-		return hipErrorInvalidValue;
-	}
-	memcpy (&box->p, &p, sizeof (OlaParams));
-	return hipSuccess;
 }
 
 constexpr int kHistExtra = 4, kHistExtraMaxRuns = 200;

@@ -12,14 +12,14 @@ if "--build" in sys.argv:
     b.build_lib()
     hipcc=b._hipcc()
     fl=[hipcc,"--offload-arch=gfx950","-O3","-fPIC","-std=c++17","-Wno-unused-function","-DPROT_SERVER_STAMPS","-DPROT_TESTHOOKS","-I" + os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")]
-    o1=os.path.join(b.OBJDIR,"prot_olasave_stamps.o")
-    b._run(fl+["-ffast-math","-fno-slp-vectorize","-c",os.path.join(b.CSRC,"prot_olasave.hip"),"-o",o1])
+    o1=os.path.join(b.OBJDIR,"prot_olasave512_stamps.o")   # (round 6: the server lives with the 512-thread block)
+    b._run(fl+["-ffast-math","-fno-slp-vectorize","-c",os.path.join(b.CSRC,"prot_olasave512.hip"),"-o",o1])
     host=[]
     for u in ("prot_engine","prot_apply","prot_lv2","prot_sweep_host","prot_multi","prot_hooks"):   # (the host units of the C ABI, with the stamps' hook)
         o=os.path.join(b.OBJDIR,u+"_stamps.o"); b._run(fl+["-c",os.path.join(b.CSRC,u+".hip"),"-o",o]); host.append(o)
     lib=os.path.join(b.LIBDIR,"variants","libprot_hip_stamps.so")
     os.makedirs(os.path.dirname(lib),exist_ok=True)
-    b._run([hipcc,"--offload-arch=gfx950","-shared","-fPIC","-o",lib,o1]+host+[os.path.join(b.OBJDIR,x) for x in ("prot_kernels.o","prot_olapoly.o","prot_olasave8k.o","prot_olasave16k.o","prot_sweep.o","prot_kernels_f16.o","prot_f16mfma.o","prot_olasave512.o")]+["-lpthread"])
+    b._run([hipcc,"--offload-arch=gfx950","-shared","-fPIC","-o",lib,o1]+host+[os.path.join(b.OBJDIR,x) for x in ("prot_kernels.o","prot_olapoly.o","prot_olasave.o","prot_olasave8k.o","prot_olasave16k.o","prot_sweep.o","prot_kernels_f16.o","prot_f16mfma.o")]+["-lpthread"])
     print("built",lib)
     sys.exit(0)
 import os, sys, time, ctypes as C
