@@ -51,7 +51,6 @@ extern "C" int prot_debug_sv_wg (unsigned long long* out, int n_wg)
 	return hipMemcpyFromSymbol (out, HIP_SYMBOL (g_sv_wg), sizeof (unsigned long long) * 4 * (size_t)(n_wg < 4096 ? n_wg : 4096)) == hipSuccess ? 0 : -1;
 }
 #endif
-#define PROT_SRV_T(i)
 #define PROT_SV_CAT_(k, a, b, c) PROT_SV_##k##_##a##_##b##_##c
 #define PROT_SV_CLOB_(a) PROT_SV_ASM_CLOBBERS_##a
 // one generated block of code: KIND_ = ASM (a run of nf whole blocks streamed from / to global memory) or CORE (one block staged
@@ -89,10 +88,8 @@ extern "C" int prot_debug_sv_wg (unsigned long long* out, int n_wg)
 //    here into the LDS exchange area (16 rows of (q, c) pairs + the frames in front of each wave's first pair), transformed by
 //    the generated CORE (the same instructions on the same values: the two paths agree bit for bit, and a sharded or chunked
 //    sweep does not depend on where its chunks end), and stored from LDS with bounds.
-// WIDE (the run() server: one workgroup per CU, registers to spare, and every load a round trip nothing else hides): the 16 rows of
-// a staged block are fetched before the first is parked, the history slice moves eight frames per thread at a time, without a branch per frame
-template <int HS, int MODE, bool WIDE = false>
-PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_lo_s, const int chn = -1, const float* const srv_in = nullptr, const float* const srv_hist = nullptr)
+template <int HS, int MODE>
+PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_lo_s)
 {
 	constexpr int BLK = 512 * HS; // output frames per block
 	constexpr int NT  = 16 - HS;  // context rows
@@ -102,8 +99,7 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 	static_assert (MODE != MODE_SWEEP || HS != 10, "the fused sweep exists for the CLI engines (blksiz 2048, 4096)");
 
 	const int t0 = threadIdx.x;
-	const int c  = WIDE ? chn : (int)blockIdx.y; // (the run() server's workgroups are slots of several engines: the channel comes with the slot)
-	PROT_SRV_T (5)
+	const int c  = (int)blockIdx.y;
 #ifdef PROT_SV_CLOCK
 	const uint64_t wg_t0 = __builtin_amdgcn_s_memrealtime ();
 	uint64_t       wg_a0 = 0, wg_a1 = 0;
@@ -113,7 +109,7 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 	// last workgroup to get there.  (The host takes this route only when n_in >= hist_len: the slice is then a plain copy
 	// of input frames and does not read the previous history.)
 	const bool piped = MODE != MODE_SWEEP && p.hs_flag != nullptr;
-	if constexpr (!WIDE && MODE != MODE_SWEEP) {
+	if constexpr (MODE != MODE_SWEEP) {
 		if (p.hist_extra > 0 && (int)blockIdx.x >= (int)gridDim.x - p.hist_extra) { // a workgroup of the next history (short launches)
 			hist_write_part (p, c, (int)blockIdx.x - ((int)gridDim.x - p.hist_extra), p.hist_extra);
 			return;
@@ -255,11 +251,9 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 		__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");
 	}
 
-	// (WIDE: the call's input frames and the last kSrvHist frames in front of them are the server's LDS copies -- round 6: a call
-	// of the resident server reads nothing from device memory but its parameters and its input)
-	const float* __restrict__ in   = WIDE ? srv_in : p.in + (int64_t)c * p.in_stride;
-	const float* __restrict__ hist = WIDE ? srv_hist : (p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr);
-	const int hist_len             = WIDE ? kSrvHist : p.hist_len;
+	const float* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
+	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
+	const int hist_len             = p.hist_len;
 	float* __restrict__ out        = p.out + (int64_t)c * p.out_stride;
 	const int64_t n_in = p.n_in;
 	const int     Dd   = p.dry_delay; // even (host guarantees)
@@ -290,36 +284,10 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 	// running: frame by frame with device-scope loads -- the aligned 8-byte route could hit a stale line of this XCD's L2,
 	// found as launch 5 of a series reading what launch 1 had read from the same buffer of the ring)
 	const bool hist_al8 = !piped && hist != nullptr && (reinterpret_cast<uintptr_t> (hist) & 7) == 0 && (hist_len & 1) == 0;
-	// (WIDE: the server's parameters come out of LDS, so every pointer in them is a generic one to the compiler, and a generic load
-	// is waited for with both counters at zero before the next goes out -- the 16 row loads of a staged block went one at a time, 3.7 us;
-	// the address spaces are said here: the input is the server's LDS copy, everything else is global)
-	typedef __attribute__ ((address_space (3))) const float LdsInF;
-	typedef __attribute__ ((address_space (3))) const f2    LdsInC;
-	auto in_f = [] (const float* q) -> float {
-		if constexpr (WIDE) {
-			return *(LdsInF*)q;
-		} else {
-			return *q;
-		}
-	};
-	auto in_c = [] (const f2* q) -> f2 {
-		if constexpr (WIDE) {
-			return *(LdsInC*)q;
-		} else {
-			return *q;
-		}
-	};
-	auto gl_c = [] (const f2* q) -> f2 {
-		if constexpr (WIDE) {
-			return *(PROT_GLOBAL const f2*)q;
-		} else {
-			return *q;
-		}
-	};
+	auto in_f = [] (const float* q) -> float { return *q; };
+	auto in_c = [] (const f2* q) -> f2 { return *q; };
+	auto gl_c = [] (const f2* q) -> f2 { return *q; };
 	auto ldv = [&] (const float* in_, int64_t n_in_, const float* hist_, int hist_len_, int64_t i) -> float {
-		if constexpr (WIDE) {
-			return in_f (in_ + (int)i);
-		}
 		if (i >= 0) {
 			return i < n_in_ ? in_f (in_ + i) : 0.f;
 		}
@@ -330,15 +298,10 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 		return piped ? __hip_atomic_load (const_cast<float*> (hist_) + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : in_f (hist_ + h);
 	};
 	auto row_pair = [&] (int64_t ar, int t) -> f2 {
-		if constexpr (WIDE) {
-			// (the server's [frames in front | input | silence to the end of the block] is ONE array in LDS: sixteen unconditional reads
-			// in flight -- with a wave-uniform choice of source per row they went out one at a time, 2.1 us of LDS latencies)
-			return in_c (reinterpret_cast<const f2*> (in + (int)ar) + t);
-		}
 		if (in_al8 && ar >= 0 && ar + 512 <= n_in) {
 			return in_c (reinterpret_cast<const f2*> (in + ar) + t);
 		}
-		if (hist_al8 && ar + 512 <= 0 && ar + hist_len >= 0 && (!WIDE || (ar & 1) == 0)) {
+		if (hist_al8 && ar + 512 <= 0 && ar + hist_len >= 0) {
 			return in_c (reinterpret_cast<const f2*> (hist + (ar + hist_len)) + t);
 		}
 		if (ar >= n_in) { // a row of the silence behind the input (wave-uniform): seven of a 1024-frame run() call's sixteen rows, which
@@ -350,7 +313,7 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 
 	for (int64_t s = r0; s < r1;) {
 		const int64_t a0 = s - Dd - 512 * R0; // frame of (row 0, thread 0).q: the dry frame of output row r is input row r
-		if (!WIDE && MODE != MODE_RAMP && in_al8 && (out_al8 || MODE == MODE_SWEEP) && a0 >= 1 && !(p.sv_flags & 1) &&
+		if (MODE != MODE_RAMP && in_al8 && (out_al8 || MODE == MODE_SWEEP) && a0 >= 1 && !(p.sv_flags & 1) &&
 		    (MODE != MODE_SWEEP || (s >= p.sw_t_begin && s >= p.sw_dry_from))) {
 			// blocks from here on that read only frames inside the array and are emitted whole
 			const int64_t n1 = (r1 - s) / BLK;
@@ -397,31 +360,11 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 		LdsF* const gcar = (LdsF*)(smem + 4096);      // gathered frames in the generated code's lane layout:
 		LdsF* const gnx  = (LdsF*)(smem + 4096 + 128); //   lanes HS-NT..HS-1 <-> rows 0..NT-1, lanes 0..HS-1 <-> rows NT..15
 		__syncthreads (); // (every wave has left the generated loop, if that is where it comes from)
-		PROT_SRV_T (0)
 		{
-			if constexpr (WIDE) {
-				// (all of the block's loads in flight before the first is parked: one round trip)
-				f2 v[16];
-#pragma unroll
-				for (int k = 0; k < 16; ++k) {
-					v[k] = row_pair (a0 + 512 * (int64_t)k, t);
-				}
-				const int   l = t & 63, w = t >> 6;
-				const int   rc = l - (HS - NT), rn = NT + l;
-				const bool  okc = rc >= 0 && rc < NT, okn = l < HS;
-				const float gcv = ldv (in, n_in, hist, hist_len, a0 + 512 * (int64_t)(okc ? rc : 0) + 128 * w - 1);
-				const float gnv = ldv (in, n_in, hist, hist_len, a0 + 512 * (int64_t)(okn ? rn : NT) + 128 * w - 1);
-				const float gc = okc ? gcv : 0.f, gn = okn ? gnv : 0.f;
-#pragma unroll
-				for (int k = 0; k < 16; ++k) {
-					st[256 * k + t] = v[k];
-				}
-				gcar[t] = gc;
-				gnx[t]  = gn;
 #ifdef PROT_NO_STAGE6
-			} else if (false) {
+			if (false) {
 #else
-			} else if (MODE != MODE_SWEEP && !piped) {
+			if (MODE != MODE_SWEEP && !piped) {
 #endif // (the sweep's instantiations have no registers for it: they spill as it is)
 				// (round 6: a staged block is the WHOLE chain of its workgroup on a short launch -- cfg3's first and last block of each
 				// channel took 9.2-9.7 us beside 6.1 for the blocks of the generated loop, with the sixteen rows fetched one after the
@@ -465,7 +408,6 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 			}
 		}
 		__syncthreads ();
-		PROT_SRV_T (1)
 		{
 			const float  cca = (MODE == MODE_RAMP || MODE == MODE_SWEEP) ? 0.f : ca, csa = MODE == MODE_RAMP ? __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (p.sv_gain))) : sa;
 			const float* a_in  = a_sv; // (unused by the core)
@@ -474,7 +416,6 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 			PROT_SV_ALL (CORE, a_in, a_out, one, cca, csa)
 		}
 		__syncthreads ();
-		PROT_SRV_T (2)
 		// The thread id opaque AGAIN: nothing per-lane may be kept alive across the generated code (which owns v0..v119) except
 		// the thread id itself -- the compiler otherwise carries hoisted per-lane addresses across it through scratch, and a
 		// spill placed inside one of the divergent branches above comes back with the inactive lanes' slots stale
@@ -522,9 +463,6 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 		} else {
 #pragma unroll 2
 			for (int k = 0; k < HS; ++k) {
-				if (WIDE && s + 512 * (int64_t)k >= r1) { // (wave-uniform: a 1024-frame run() call ends behind two of its ten rows)
-					break;
-				}
 				f2            o    = st[256 * k + t];
 				const int64_t pos0 = s + 512 * (int64_t)k + 2 * (int64_t)t;
 				if (MODE == MODE_RAMP && pos0 < r1) {
@@ -533,10 +471,6 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 					const f2 cs0 = gl_c (reinterpret_cast<const f2*> (p.rot_s) + ((int64_t)c * p.n_out + pos0));
 					const f2 cs1 = pos0 + 1 < r1 ? gl_c (reinterpret_cast<const f2*> (p.rot_s) + ((int64_t)c * p.n_out + pos0 + 1)) : mkf2 (0.f, 0.f);
 					o            = mkf2 (cs0.x * d.x + cs0.y * o.x, cs1.x * d.y + cs1.y * o.y);
-				}
-				if (WIDE && out_al8 && pos0 + 1 < r1) { // (the server's outputs cross the host link: one 8-byte store per lane, whole lines per wave)
-					*(PROT_GLOBAL f2*)(out + pos0) = o;
-					continue;
 				}
 				if (pos0 < r1) {
 					out[pos0] = o.x;
@@ -547,7 +481,6 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 			}
 		}
 		__syncthreads (); // (the output rows have been read: the exchange area is free for whatever comes next)
-		PROT_SRV_T (3)
 		s += BLK;
 	}
 #ifdef PROT_SV_CLOCK
@@ -559,13 +492,10 @@ PROT_DEV void olasave_body (const OlaParams& p, f2* const smem, float* const sw_
 	}
 #endif
 	if (!piped) {
-		if constexpr (WIDE) {
-			// (the run() server writes the next history itself, behind the done word: server_next_history)
-		} else if (p.hist_extra == 0) {
+		if (p.hist_extra == 0) {
 			hist_write_slice (p, c, threadIdx.x);
 		}
 	}
-	PROT_SRV_T (4)
 	if constexpr (MODE == MODE_SWEEP) {
 		if ((t0 & 63) == 0) {
 			p.surv_cnt[((int64_t)c * gridDim.x + blockIdx.x) * 4 + (t0 >> 6)] = sw_cnt;

@@ -44,6 +44,27 @@ def test_model_of_the_table_free_form():
         assert np.abs(M.block(z, B, len(g), False, 1) - want)[lo:hi].max() < 1e-7
 
 
+def test_model_of_the_short_chain_block():
+    """tools/model/olasave512_model.py: the 512-thread block of prot_olasave512.hip thread by thread -- four radix-8 passes each way
+    over the digits of n and k, the three exchanges' LDS slots, the constants as the host lays them out (tables()) -- against the
+    convolution with g (and the radix-16 model) for the three block geometries"""
+    import numpy as np
+    import olasave_model as M
+    import olasave512_model as M5
+    rng = np.random.default_rng(3)
+    for n_taps, hs in [(3072, 10), (4096, 8), (2048, 12)]:
+        g = M.hilbert_fir(n_taps)[1::2]
+        B = M.tables(g)
+        tb = M5.tables(B)
+        assert tb["fA"].shape == (7, 512) and tb["iB"].shape == (7, 64) and tb["rho"].shape == (512, 2)
+        z = 0.3 * (rng.standard_normal(M.N) + 1j * rng.standard_normal(M.N))
+        want = np.convolve(z, g)[len(g) // 2:len(g) // 2 + M.N]
+        lo, hi = 256 * (16 - hs) // 2, M.N - 256 * (16 - hs) // 2
+        y = M5.block(z, tb)
+        assert np.abs(y - want)[lo:hi].max() < 1e-7
+        assert np.abs(y - M.block(z, B, len(g), False, 1))[lo:hi].max() < 1e-12   # (the same approximation of |B|: equal to rounding)
+
+
 def test_committed_include_is_current(tmp_path):
     import gen_olasave as G
     dst = tmp_path / "asm.inc"

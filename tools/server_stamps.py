@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where a run() call through the server goes (prot_olasave.hip, olasave_server_kernel): 100 MHz stamps of the resident kernel's stages
+"""Where a run() call through the server goes (prot_olasave512.hip, olasave512_server_kernel): 100 MHz stamps of the resident kernel's stages
 -- doorbell seen, parameters + input fetched, block done, done word stored -- and of the block's own phases, from a variant library
 built with -DPROT_SERVER_STAMPS.
     python3 tools/server_stamps.py --build                      (here: cross-compiles phaserotate.lv2_amd/lib/variants/libprot_hip_stamps.so)
