@@ -208,7 +208,7 @@ struct prot_engine {
 	int              last_n_lists = 0;          // geometry of the last fused pass (prot_internal_fused_lists)
 	int64_t          last_cap     = 0;
 	PinBuf<float>  h_io;
-	// the run() server (prot_olasave.hip): a resident kernel that takes prot_lv2_run's calls through a mailbox
+	// the run() server (prot_olasave512.hip): a resident kernel that takes prot_lv2_run's calls through a mailbox
 	char*          srv_box = nullptr;      // host -> device half (prot::SvServerBox + input frames + per-frame rotation): device memory
 	                                       // the CPU stores into through the BAR (srv_bar), or pinned host-coherent memory
 	size_t         srv_box_bytes = 0;

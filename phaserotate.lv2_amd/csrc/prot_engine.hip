@@ -78,7 +78,7 @@ void fft_f64 (std::vector<double>& re, std::vector<double>& im)
 	}
 }
 
-// Constants of olasave_kernel (prot_olasave.hip) for ONE partition of odd taps g (g[s] = fir[2 s + 1], Lg of them, a multiple
+// Constants of olasave_kernel (prot_olasave.hip) and of the 512-thread block (prot_olasave512.hip) for ONE partition of odd taps g (g[s] = fir[2 s + 1], Lg of them, a multiple
 // of 512): H[k] = sum g[s] W^{sk} = -i B[k] W^{(Lg/2) k} W^{-k/2} with B real IF g is antisymmetric about its centre.
 // Returns false (the engine keeps olapoly_kernel and its spectrum table) unless g is antisymmetric in its float values and
 // rho = -B is flat to 1.5e-7 outside `rows` x 256 bins on either side of DC for rows = 1 or 2.

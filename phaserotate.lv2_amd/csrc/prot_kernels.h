@@ -121,7 +121,7 @@ int        mfma_f16_wg_per_cu ();                              // resident workg
 hipError_t launch_ola_save (const OlaParams& p, int hop_rows, int n_rho_rows, int n_chn, hipStream_t s);
 // the same on 8192-point blocks (prot_olasave8k.hip): 512-thread workgroups, two per CU; hop_rows in {12, 13} (x 1024 new
 // frames per block: firlen = 1024 (16 - hop_rows)); p.sv = the five-row table of save_tables8k; no pipelined launches
-// ---- the run() server (prot_olasave.hip): the mailbox of one LV2 engine, in two halves.
+// ---- the run() server (prot_olasave512.hip): the mailbox of one LV2 engine, in two halves.
 // SvServerBox (host -> device): what the host writes and the resident kernel reads -- in DEVICE memory that the CPU stores into through
 // the PCIe BAR when the device has a large one (write-combined, posted: 4 KiB in ~0.2 us; the kernel then polls and fetches LOCAL
 // memory instead of reading host memory over the link at ~1 GB/s), else in pinned host-coherent memory.  The call's input frames

@@ -500,7 +500,7 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 		}
 	}
 
-	// The run() server (prot_olasave.hip): the call's parameters and frames go into the mailbox, the doorbell is rung, the resident
+	// The run() server (prot_olasave512.hip): the call's parameters and frames go into the mailbox, the doorbell is rung, the resident
 	// kernel does the block and stores the call's number when the output is in h_out -- no launch, no stream synchronisation.
 	// One server per process, a slot per channel of every engine on its roster (g_srv_roster); calls of more than one block per channel, staged
 	// calls and PROT_TEST_LV2_NO_SERVER take the launch below.  tools/attic/run_latency.py: 38-40 us -> the figure in DESIGN.md.
