@@ -75,7 +75,8 @@ def build_lib(force=False, verbose=False):
         ("prot_olasave.hip", ["-ffast-math", "-fno-slp-vectorize"]),
         ("prot_olasave8k.hip", ["-ffast-math", "-fno-slp-vectorize"]),
         ("prot_olasave16k.hip", ["-ffast-math", "-fno-slp-vectorize"]),
-        ("prot_olasave512.hip", ["-ffast-math", "-fno-slp-vectorize"]),
+        # (the launched kernel's first fourteen argument dwords preloaded into SGPRs at wave launch: prot_olasave512.hip)
+        ("prot_olasave512.hip", ["-ffast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=14"]),
     ]
     # the host side of the C ABI (round 6: prot_capi.hip split into its parts; prot_engine.h is what they share).  Host logic mirrors the
     # reference's float arithmetic: no fast-math.  Compiled twice: as shipped, and with -DPROT_TESTHOOKS (prot_internal_* entry points,

@@ -248,8 +248,14 @@ PROT_DEV void s5_transform (f2 (&v)[8], const S5Tw& w, const S5Lds& l)
 // (8 k1 + b) 64 + t', t' = T & 63, b = T >> 6) -> thread (k1, t') holds b = 0..7; pass over b; exchange 2 (inside wave k1: slot
 // (9 c + k2) 8 + d) -> lane (k2, d) holds c; pass over c; exchange 3 (slot (8 k2 + d) 9 + k3) -> lane (k2, k3) holds d; pass over d.
 // The inverse runs the same decimation from the k side and mirrors the three exchanges.  Two workgroup barriers per block.
+// What a block needs before it can ask for its rows and constants travels in the kernel's first fourteen argument dwords, which the
+// hardware PRELOADS into scalar registers at wave launch (-mllvm -amdgpu-kernarg-preload-count=14 for this unit: build.py) -- the
+// first scalar load of a kernel's arguments is a miss of ~0.7-1 us, a seventh of a lone block's launch; everything else (rotation,
+// output pointer, gain) is read from `p` while the rows are on their way.  (On firmware without the preload the compiler's
+// prologue loads the same registers: slower, not wrong.)  dd_hx = dry delay | history workgroups << 20; runs = workgroups with a block.
 template <int HS, int MODE>
-__global__ __launch_bounds__ (512) void olasave512_kernel (const OlaParams p)
+__global__ __launch_bounds__ (512) void olasave512_kernel (const float* const in0, const int64_t in_stride, const float* const hist0, const float* const sv, const int n_in32,
+                                                           const int n_out32, const int dd_hx, const int hist_len, const int runs, const OlaParams p)
 {
 	constexpr int BLK = 512 * HS; // output frames per block
 	constexpr int NT  = 16 - HS;  // context rows
@@ -258,41 +264,35 @@ __global__ __launch_bounds__ (512) void olasave512_kernel (const OlaParams p)
 	__shared__ f2 ex1[4096];
 	__shared__ f2 ex2[8 * kS5Chunk];
 	PROT_S5_T (0)
-	kernarg_prefetch ();
-	const int c = (int)blockIdx.y;
-	if (p.hist_extra > 0 && (int)blockIdx.x >= (int)gridDim.x - p.hist_extra) { // a workgroup of the next history
-		hist_write_part (p, c, (int)blockIdx.x - ((int)gridDim.x - p.hist_extra), p.hist_extra);
+	const int c  = (int)blockIdx.y;
+	const int hx = dd_hx >> 20, Dd = dd_hx & 0xfffff; // (Dd even: host guarantees)
+	if (hx > 0 && (int)blockIdx.x >= runs) { // a workgroup of the next history
+		hist_write_part (p, c, (int)blockIdx.x - runs, hx);
 		return;
 	}
-	int64_t r0, rlen;
-	run_of_workgroup (p, r0, rlen);
-	if (r0 >= p.n_out) {
+	int bx = (int)blockIdx.x; // (run_of_workgroup's rotation inside groups of eight: XCD k does not own the blocks k, k + 8, ...)
+	if ((bx | 7) < runs) {
+		bx = (bx & ~7) | ((bx + (bx >> 3)) & 7);
+	}
+	const int64_t n_out = n_out32, n_in = n_in32;
+	const int64_t r0    = (int64_t)bx * BLK;
+	if (r0 >= n_out) {
 		return;
 	}
-	const int64_t r1 = (r0 + rlen < p.n_out) ? r0 + rlen : p.n_out;
+	const int64_t r1 = r0 + BLK < n_out ? r0 + BLK : n_out;
 	const int T = (int)threadIdx.x;
 
-	const float* __restrict__ in   = p.in + (int64_t)c * p.in_stride;
-	const float* __restrict__ hist = p.hist ? p.hist + (int64_t)c * p.hist_len : nullptr;
-	float* __restrict__ out        = p.out + (int64_t)c * p.out_stride;
-	const int64_t n_in    = p.n_in;
-	const int     Dd      = p.dry_delay; // even (host guarantees)
+	const float* __restrict__ in   = in0 + (int64_t)c * in_stride;
+	const float* __restrict__ hist = hist0 ? hist0 + (int64_t)c * hist_len : nullptr;
 	const bool    in_al8  = (reinterpret_cast<uintptr_t> (in) & 7) == 0;
-	const bool    out_al8 = (reinterpret_cast<uintptr_t> (out) & 7) == 0;
-	float ca = 0.f, g = p.sv_gain;
-	if (MODE == MODE_ROT) {
-		ca = p.rot ? p.rot[2 * c] : p.rot_v[2 * c];
-		g  = (p.rot ? p.rot[2 * c + 1] : p.rot_v[2 * c + 1]) * p.sv_gain;
-	}
-	ca = __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (ca)));
-	g  = __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (g)));
 
 	// the engine's constants (behind the 256-thread block's fifteen rows): asked for now, used pass by pass
 	S5Tw w;
-	s5_load_tw (w, reinterpret_cast<const f2*> (p.sv) + kSv5Offset, T);
+	s5_load_tw (w, reinterpret_cast<const f2*> (sv) + kSv5Offset, T);
 	const S5Lds l = s5_lds (ex1, ex2, T);
 
-	for (int64_t s = r0; s < r1; s += BLK) {
+	{ // (one block per workgroup)
+		const int64_t s = r0;
 		const int64_t a0 = s - Dd - 512 * R0; // frame of (row 0, thread 0).q: z[j] = x[a0 + 2 j - 1] + i x[a0 + 2 j], dry pair (x[a0 + 2 j], x[a0 + 2 j + 1])
 		f2 v[8], dry[8];
 		if (in_al8 && a0 >= 1 && a0 + 8192 <= n_in) { // the whole block inside the input: (q, c) pairs are aligned, the frame in front a word
@@ -305,9 +305,9 @@ __global__ __launch_bounds__ (512) void olasave512_kernel (const OlaParams p)
 			}
 		} else {
 			// history or silence in reach: every frame by an unconditional load from an address chosen without a branch
-			const float* const safe = p.sv;
+			const float* const safe = sv;
 			auto ldq = [&] (int64_t i) -> float {
-				const int64_t h    = i + p.hist_len;
+				const int64_t h    = i + hist_len;
 				const bool    ok_i = i >= 0 && i < n_in;
 				const bool    ok_h = i < 0 && hist != nullptr && h >= 0;
 				const float*  a    = ok_i ? in + i : (ok_h ? hist + h : safe);
@@ -323,10 +323,18 @@ __global__ __launch_bounds__ (512) void olasave512_kernel (const OlaParams p)
 			}
 		}
 		PROT_S5_T (1)
-		if (s == r0) { // (the constants' products: once per workgroup, behind the wait for the block's rows)
-			s5_tw_powers (w);
-		}
+		s5_tw_powers (w); // (the constants' products: behind the wait for the block's rows)
 		s5_transform (v, w, l);
+		// ---- the rest of the arguments: asked for by the compiler wherever it likes, waited for here at the earliest
+		float* __restrict__ out = p.out + (int64_t)c * p.out_stride;
+		const bool out_al8      = (reinterpret_cast<uintptr_t> (out) & 7) == 0;
+		float      ca = 0.f, g = p.sv_gain;
+		if (MODE == MODE_ROT) {
+			ca = p.rot ? p.rot[2 * c] : p.rot_v[2 * c];
+			g  = (p.rot ? p.rot[2 * c + 1] : p.rot_v[2 * c + 1]) * p.sv_gain;
+		}
+		ca = __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (ca)));
+		g  = __uint_as_float (__builtin_amdgcn_readfirstlane (__float_as_uint (g)));
 		PROT_S5_T (3)
 		// ---- thread T holds y[512 a + T]: local row 2 a + (T >> 8), pair T & 255; rows R0 .. R0 + HS - 1 are the block's output
 		const int hi = T >> 8, tp = T & 255;
@@ -342,7 +350,7 @@ __global__ __launch_bounds__ (512) void olasave512_kernel (const OlaParams p)
 			}
 			f2 o;
 			if (MODE == MODE_RAMP) {
-				const f2* const rs = reinterpret_cast<const f2*> (p.rot_s) + ((int64_t)c * p.n_out + pos);
+				const f2* const rs = reinterpret_cast<const f2*> (p.rot_s) + ((int64_t)c * n_out + pos);
 				o                  = s5_mix_ramp (v[a], g, dry[a], rs[0], pos + 1 < r1 ? rs[1] : mkf2 (0.f, 0.f));
 			} else {
 				o = s5_mix (v[a], g, dry[a], ca); // (MODE_HILBERT: ca = 0)
@@ -358,7 +366,6 @@ __global__ __launch_bounds__ (512) void olasave512_kernel (const OlaParams p)
 				}
 			}
 		}
-		__syncthreads (); // (the next block's first exchange writes where this one's last was read)
 	}
 	PROT_S5_T (4)
 }
@@ -735,13 +742,17 @@ hipError_t post_ola_save_server (const OlaParams& p, int hop_rows, int n_rho_row
 template <int HS>
 static hipError_t launch_s5_m (const OlaParams& p, dim3 grid, hipStream_t s)
 {
+	const int runs  = (int)grid.x - p.hist_extra;
+	const int dd_hx = p.dry_delay | (p.hist_extra << 20);
+#define PROT_S5_LAUNCH(M) hipLaunchKernelGGL ((olasave512_kernel<HS, M>), grid, dim3 (512), 0, s, p.in, p.in_stride, p.hist, p.sv, (int)p.n_in, (int)p.n_out, dd_hx, p.hist_len, runs, p)
 	if (p.hilbert_only) {
-		hipLaunchKernelGGL ((olasave512_kernel<HS, MODE_HILBERT>), grid, dim3 (512), 0, s, p);
+		PROT_S5_LAUNCH (MODE_HILBERT);
 	} else if (p.rot_s != nullptr) {
-		hipLaunchKernelGGL ((olasave512_kernel<HS, MODE_RAMP>), grid, dim3 (512), 0, s, p);
+		PROT_S5_LAUNCH (MODE_RAMP);
 	} else {
-		hipLaunchKernelGGL ((olasave512_kernel<HS, MODE_ROT>), grid, dim3 (512), 0, s, p);
+		PROT_S5_LAUNCH (MODE_ROT);
 	}
+#undef PROT_S5_LAUNCH
 	return hipGetLastError ();
 }
 
@@ -751,6 +762,7 @@ bool ola_save512_takes (const OlaParams& p, int hop_rows, int n_rho_rows, int n_
 {
 	if ((hop_rows != 8 && hop_rows != 10 && hop_rows != 12) || n_rho_rows != 1 || (p.dry_delay & 1) || p.accumulate || p.sv == nullptr || p.n_out <= 0 ||
 	    2 * (p.dry_delay - p.conv_delay) != 512 * (16 - hop_rows) || p.surv != nullptr || p.hs_flag != nullptr || p.run_stride != 0 ||
+	    p.n_in >= ((int64_t)1 << 31) || p.dry_delay >= (1 << 20) ||
 	    p.hilbert_only) { // (the sweep's Hilbert passes: a sharded or chunked sweep is bit-identical to the single pass, so its block may not depend on a launch's length)
 		return false;
 	}

@@ -74,7 +74,8 @@ for arg in sys.argv[1:]:
         _, tag, fl = (arg.split(":") + [""])[:3]
         o = os.path.join(b.OBJDIR, "prot_olasave512_%s.o" % tag)
         b._run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-ffast-math",
-                "-fno-slp-vectorize"] + [f for f in fl.split(",") if f] + ["-c", os.path.join(b.CSRC, "prot_olasave512.hip"), "-o", o])
+                "-fno-slp-vectorize"] + ([] if "NOPRELOAD" in fl else ["-mllvm", "-amdgpu-kernarg-preload-count=14"]) + [f for f in fl.split(",") if f and f != "NOPRELOAD"] +
+               ["-c", os.path.join(b.CSRC, "prot_olasave512.hip"), "-o", o])
         link(tag, {"prot_olasave512": o})
         continue
     tag, _, fl = arg.partition(":")

@@ -49,12 +49,12 @@ if hasattr(lib, "prot_debug_s5_wg"):   # the 512-thread block (a -DPROT_S5_CLOCK
     nw = 256
     a = (ctypes.c_ulonglong * (8 * nw))()
     lib.prot_debug_s5_wg(a, nw)
-    w = np.array(list(a), dtype=np.float64).reshape(nw, 8)[:, :5] * 0.01
+    w = np.array(list(a), dtype=np.float64).reshape(nw, 8)[:, [0, 1, 3, 4]] * 0.01   # entry, rows + constants arrived, transform done, exit
     w = w[w[:, 0] > 0]
     if len(w):
         d = np.diff(w, axis=1)
-        print("512-thread block, %d workgroups: entry->rows+constants %.2f, forward %.2f, inverse %.2f, stores+exit %.2f; whole %.2f us (median), max %.2f; first entry -> last exit %.2f" % (
-            len(w), np.median(d[:, 0]), np.median(d[:, 1]), np.median(d[:, 2]), np.median(d[:, 3]), np.median(w[:, 4] - w[:, 0]), (w[:, 4] - w[:, 0]).max(), w[:, 4].max() - w[:, 0].min()))
-        slow = np.argsort(w[:, 4] - w[:, 0])[-3:]
+        print("512-thread block, %d workgroups: entry->rows+constants %.2f, transform %.2f, stores+exit %.2f; whole %.2f us (median), max %.2f; first entry -> last exit %.2f" % (
+            len(w), np.median(d[:, 0]), np.median(d[:, 1]), np.median(d[:, 2]), np.median(w[:, 3] - w[:, 0]), (w[:, 3] - w[:, 0]).max(), w[:, 3].max() - w[:, 0].min()))
+        slow = np.argsort(w[:, 3] - w[:, 0])[-3:]
         print("  slowest:", [(int(i), [round(float(x), 2) for x in d[i]]) for i in slow])
 eng.close()

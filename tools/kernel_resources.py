@@ -9,7 +9,7 @@ UNITS = [("prot_kernels.hip", ["-ffast-math", "-fno-slp-vectorize"]),
          ("prot_sweep.hip", ["-ffast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
          ("prot_kernels_f16.hip", ["-ffast-math"]),
          ("prot_f16mfma.hip", ["-ffast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
-         ("prot_olasave512.hip", ["-ffast-math", "-fno-slp-vectorize"]),
+         ("prot_olasave512.hip", ["-ffast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=14"]),
          ("prot_olasave.hip", ["-ffast-math", "-fno-slp-vectorize"]),
          ("prot_olasave8k.hip", ["-ffast-math", "-fno-slp-vectorize"]),
          ("prot_olasave16k.hip", ["-ffast-math", "-fno-slp-vectorize"])]

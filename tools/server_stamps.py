@@ -13,7 +13,7 @@ if "--build" in sys.argv:
     hipcc=b._hipcc()
     fl=[hipcc,"--offload-arch=gfx950","-O3","-fPIC","-std=c++17","-Wno-unused-function","-DPROT_SERVER_STAMPS","-DPROT_TESTHOOKS","-I" + os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")]
     o1=os.path.join(b.OBJDIR,"prot_olasave512_stamps.o")   # (round 6: the server lives with the 512-thread block)
-    b._run(fl+["-ffast-math","-fno-slp-vectorize","-c",os.path.join(b.CSRC,"prot_olasave512.hip"),"-o",o1])
+    b._run(fl+["-ffast-math","-fno-slp-vectorize","-mllvm","-amdgpu-kernarg-preload-count=14","-c",os.path.join(b.CSRC,"prot_olasave512.hip"),"-o",o1])
     host=[]
     for u in ("prot_engine","prot_apply","prot_lv2","prot_sweep_host","prot_multi","prot_hooks"):   # (the host units of the C ABI, with the stamps' hook)
         o=os.path.join(b.OBJDIR,u+"_stamps.o"); b._run(fl+["-c",os.path.join(b.CSRC,u+".hip"),"-o",o]); host.append(o)
