@@ -248,7 +248,7 @@ int prot_lv2_set_max_block (prot_engine* e, uint32_t frames);
  * destroys, resets or synchronises an engine (the launch route), calls of more than one transform block per channel.
  * While the mode is on the resident kernel has no age limit (it leaves when idle or told to).  frames = 0: off.
  * Call it where activate() may be called (it synchronises); PROT_EUNSUPPORTED for engines whose run() is launched
- * (more than 16 channels, pipelined, direct-form engines). */
+ * (more than 32 channels, pipelined, direct-form engines). */
 int prot_lv2_set_deferred (prot_engine* e, uint32_t frames);
 /* calls whose predecessor's block was late (silence went out in its place) / calls whose own frames were never posted */
 int prot_lv2_deferred_stats (prot_engine* e, uint64_t* late, uint64_t* dropped);

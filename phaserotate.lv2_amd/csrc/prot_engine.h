@@ -218,7 +218,7 @@ struct prot_engine {
 	hipStream_t    srv_stream  = nullptr;
 	hipEvent_t     srv_ev      = nullptr;
 	bool           sv8_always   = false; // CLI blksiz 8192: every fp32 launch on 8192-point blocks (one table-free partition)
-	bool           srv_eligible = false; // LV2 engine on the overlap-save kernel, <= 16 channels, not pipelined
+	bool           srv_eligible = false; // LV2 engine on the overlap-save kernel, <= 32 channels, not pipelined
 	bool           srv_running = false;
 	uint32_t       srv_seq     = 0;      // number of the last call posted
 	uint64_t       srv_calls   = 0;      // calls the server took / kernels started for it (prot_internal_server_stats)

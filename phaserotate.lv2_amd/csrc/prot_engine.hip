@@ -857,7 +857,7 @@ static int setup_lv2 (prot_engine* e)
 		if (lv2_reserve (e, 8192) != PROT_OK) { // run() buffers up front; prot_lv2_set_max_block raises it
 			return (PROT_ENOMEM);
 		}
-		// the run() server: engines on the overlap-save kernel (both LV2 rates), up to 16 channels, not pipelined
+		// the run() server: engines on the overlap-save kernel (both LV2 rates), up to 32 channels, not pipelined
 		if (e->use_poly && e->use_save && e->d_pipe.p == nullptr && inf.n_chn <= (uint32_t)prot::kServerMaxChn && (e->hopseg == 16 || e->hopseg == 20)) {
 			int lo = 0, hi = 0;
 			(void)hipDeviceGetStreamPriorityRange (&lo, &hi); // (hi = the numerically smallest = greatest priority)

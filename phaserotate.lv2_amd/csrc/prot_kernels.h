@@ -128,7 +128,7 @@ hipError_t launch_ola_save (const OlaParams& p, int hop_rows, int n_rho_rows, in
 // ([channel][frames]) and per-frame rotation ([channel][frames][2]) follow it at kServerInOffset.  The host never READS this half
 // (a CPU load through the BAR is 5-7 us).
 // SvServerAck (device -> host): pinned host-coherent memory the kernel stores into and the host polls.
-constexpr int    kServerMaxChn   = 16;
+constexpr int    kServerMaxChn   = 32;
 constexpr size_t kServerInOffset = 1024; // bytes from the box to the input frames
 // The 512-thread block's constants (prot_olasave512.hip; tools/model/olasave512_model.py tables()), in float2 behind the fifteen rows of
 // the 256-thread block's table: six twiddle tables [j - 1][index], j = 1..7 -- forward W4096^{(T - 1/2) j} (512 indices),

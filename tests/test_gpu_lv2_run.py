@@ -167,6 +167,36 @@ def test_lv2_run_server_takes_every_instance_of_the_process(pkg):
     assert stats[0][3]["calls"] == n_calls + 5 and stats[0][4]["calls"] == n_calls + 5, stats[0]
 
 
+def test_lv2_run_server_roster_of_more_than_sixteen_channels(pkg):
+    """Round 6: the resident kernel's roster holds 32 channels (16 before: VERDICT r5 noted further instances were demoted to the launch
+    route).  Twelve stereo instances (24 slots) called in turn: every call served, outputs equal to the launch route's bit for bit;
+    five more stereo instances would not fit and take the launch route -- same bits again."""
+    n_inst, n_calls, bs = 17, 6, 256
+    xs = [[xorshift_uniform(2 * bs, seed=5000 + 31 * k + i).reshape(2, bs) for i in range(n_calls)] for k in range(n_inst)]
+    outs, stats = {}, {}
+    try:
+        for mode in (1, 0):
+            pkg.set_test_option(pkg.TEST_LV2_NO_SERVER, mode)
+            gs = [pkg.Lv2Instance(48000 if k % 2 else 96000, 2) for k in range(n_inst)]
+            for g in gs:
+                g.activate()
+            got = [[] for _ in gs]
+            for i in range(n_calls):
+                for k, g in enumerate(gs):
+                    got[k].append(g.run(xs[k][i], [15.0 * k, -20.0 - k]).copy())
+            stats[mode] = [g.server_stats() for g in gs]
+            outs[mode] = [np.stack(v) for v in got]
+            for g in gs:
+                g.close()
+    finally:
+        pkg.set_test_option(pkg.TEST_LV2_NO_SERVER, 0)
+    for k in range(n_inst):
+        assert outs[0][k].tobytes() == outs[1][k].tobytes(), k
+    served = [st["calls"] for st in stats[0]]
+    assert served[:12] == [n_calls] * 12, served            # 24 channels: all through the server
+    assert sum(1 for c in served if c == n_calls) == 16 and sum(1 for c in served if c == 0) == 1, served   # 32 channels fit, the seventeenth instance does not
+
+
 def test_lv2_run_server_is_held_off_while_another_thread_creates_and_destroys_engines(pkg):
     """stopping the run() server ONCE is not enough -- an audio thread that calls run() every few milliseconds
     starts it again while another thread's prot_engine_create / destroy is still inside hipMalloc / hipFree, which wait for a
