@@ -430,8 +430,13 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 	for (uint32_t c = 0; c < nc && all_at_target; ++c) {
 		all_at_target = e->lv2[c].rotq_steady && target_of (c) == e->lv2[c].angle;
 	}
+	// (the input goes into the pinned block only for the routes that read it there: a served call's frames go straight into the mailbox)
+	auto fill_h_in = [&] () {
+		for (uint32_t c = 0; c < nc; ++c) {
+			memcpy (h_in + c * n, in[c] + off, n * sizeof (float));
+		}
+	};
 	for (uint32_t c = 0; c < nc; ++c) {
-		memcpy (h_in + c * n, in[c] + off, n * sizeof (float));
 		Lv2Chn& ch = e->lv2[c];
 		if (all_at_target) {
 			ch.offset = (uint32_t)((ch.offset + (uint64_t)n_samples) % P);
@@ -636,6 +641,7 @@ static int lv2_run_chunk (prot_engine* e, const float* const* in, float* const* 
 		hand_back ();
 		return PROT_OK;
 	}
+	fill_h_in ();
 	if (!staged) {
 		const float* d_rot_c = nullptr;
 		if (steady) {
