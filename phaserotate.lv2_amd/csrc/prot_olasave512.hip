@@ -505,14 +505,17 @@ PROT_DEV void server5_loop (const SvServerBox* const box, SvServerAck* const ack
 				}
 				word = 2u * s + cmd;
 				if (n_chn > 1) {
-					__hip_atomic_store (relay + 1, frames, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					__hip_atomic_store (relay, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+					// (decision and frame count in ONE 8-byte store: nothing else has to be ordered with it -- what the other channels read
+					// next is the host's mailbox, past the caches -- so no release, which on this path was a wait for every earlier store)
+					__hip_atomic_store (reinterpret_cast<uint64_t*> (relay), (uint64_t)word | ((uint64_t)frames << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
 			} else {
-				while ((word = __hip_atomic_load (relay, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 2u * seen) {
-					__builtin_amdgcn_s_sleep (2);
+				uint64_t both;
+				while ((unsigned)(both = __hip_atomic_load (reinterpret_cast<uint64_t*> (relay), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 2u * seen) {
+					__builtin_amdgcn_s_sleep (1);
 				}
-				frames = __hip_atomic_load (relay + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				word   = (unsigned)both;
+				frames = (unsigned)(both >> 32);
 			}
 			sh_w[0] = word;
 			sh_w[1] = frames;
