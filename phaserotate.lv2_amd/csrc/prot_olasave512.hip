@@ -250,8 +250,8 @@ PROT_DEV void s5_transform (f2 (&v)[8], const S5Tw& w, const S5Lds& l)
 // The inverse runs the same decimation from the k side and mirrors the three exchanges.  Two workgroup barriers per block.
 // What a block needs before it can ask for its rows and constants travels in the kernel's first fourteen argument dwords, which the
 // hardware PRELOADS into scalar registers at wave launch (-mllvm -amdgpu-kernarg-preload-count=14 for this unit: build.py) -- the
-// first scalar load of a kernel's arguments is a miss of ~0.7-1 us, a seventh of a lone block's launch; everything else (rotation,
-// output pointer, gain) is read from `p` while the rows are on their way.  (On firmware without the preload the compiler's
+// first scalar load of a kernel's arguments is a miss that every load of the block waits behind (0.25 us of a 7.3 us launch in an A/B on
+// one box: profiles/r06_experiments.txt); everything else (rotation, output pointer, gain) is read from `p` while the rows are on their way.  (On firmware without the preload the compiler's
 // prologue loads the same registers: slower, not wrong.)  dd_hx = dry delay | history workgroups << 20; runs = workgroups with a block.
 template <int HS, int MODE>
 __global__ __launch_bounds__ (512) void olasave512_kernel (const float* const in0, const int64_t in_stride, const float* const hist0, const float* const sv, const int n_in32,
@@ -377,8 +377,8 @@ __global__ __launch_bounds__ (512) void olasave512_kernel (const float* const in
 // launch would have carried) and its input into the mailbox (SvServerBox, prot_kernels.h: device memory through the PCIe BAR where there
 // is a large one, pinned host-coherent memory otherwise) and rings a doorbell word; channel 0's workgroup polls the doorbell, relays
 // the decision to the engine's other channels through a device word (ONE decision for all: serve call s, or leave), every workgroup does
-// its channel's block, publishes its output with a system-scope release and stores the call's number into its done word, which the host
-// polls.  No launch, no stream synchronisation, no copy command per call.
+// its channel's block, writes its output through to the host (system-scope stores, each acknowledged) and stores the call's number into
+// its done word, which the host polls.  No launch, no stream synchronisation, no copy command per call.
 // What a workgroup keeps from call to call (round 6): the frames in front of the call in LDS (sh_stream = [kSrvHist frames | the
 // call's input | silence]: a block's rows are unconditional LDS reads -- staging was 2.8 us of a 13.4 us call), the constants in registers.
 // Leaving: on the host's stop command (any other use of the engine stops the server first: prot_lv2.hip) and BY ITSELF after 0.25 s
