@@ -322,9 +322,8 @@ int ola_launch (prot_engine* e, const float* d_in, int64_t in_stride, uint64_t n
 			}
 			// a launch of fewer blocks than the device has CUs: every block is a lone workgroup's dependent chain -- the 512-thread
 			// block walks it in half the time (prot_olasave512.hip; not bit-identical to the 256-thread block: the route depends on
-			// the launch's shape only; a PROT_CFG_PIPELINE engine keeps ONE block for all its launches: its pipelined ones hand the history
-			// over inside olasave_kernel)
-			if (!fs && !e->pipeline && test_opt (PROT_TEST_NO_SHORT_CHAIN) == 0 && prot::ola_save512_takes (p, e->hopseg / 2, e->sv_rows, n_chn, e->cus)) {
+			// the launch's shape only; pipelined launches hand their history over inside it as they do inside olasave_kernel)
+			if (!fs && test_opt (PROT_TEST_NO_SHORT_CHAIN) == 0 && prot::ola_save512_takes (p, e->hopseg / 2, e->sv_rows, n_chn, e->cus)) {
 				hipError_t err5 = prot::launch_ola_save512 (p, e->hopseg / 2, n_chn, s);
 				if (err5 != hipSuccess) {
 					return hip_fail (err5, "overlap-save (512-thread block) ola kernel launch");

@@ -68,6 +68,8 @@ PROT_DEV void hist_write_slice (const OlaParamsT<S>& p, int c, int t)
 
 // Part `part` of `nparts` of a channel's next history, hist_out[i] = [hist | in | silence](n_in - hist_len + i), eight loads in flight per
 // thread and no branch around a load (short launches, round 6: the workgroups that do this do nothing else -- OlaParams::hist_extra)
+// (DEVICE_SCOPE: write-through stores -- a pipelined launch's history is read by the next launch while this one still runs)
+template <bool DEVICE_SCOPE = false>
 PROT_DEV void hist_write_part (const OlaParamsT<float>& p, const int c, const int part, const int nparts)
 {
 	if (p.hist_out == nullptr) {
@@ -100,7 +102,11 @@ PROT_DEV void hist_write_part (const OlaParamsT<float>& p, const int c, const in
 #pragma unroll
 		for (int q = 0; q < 8; ++q) {
 			if (base + nthr * q < i1) {
-				ho[base + nthr * q] = v[q];
+				if constexpr (DEVICE_SCOPE) {
+					__hip_atomic_store (&ho[base + nthr * q], v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				} else {
+					ho[base + nthr * q] = v[q];
+				}
 			}
 		}
 	}

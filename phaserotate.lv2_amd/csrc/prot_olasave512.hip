@@ -14,6 +14,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <type_traits>
 
 #include "prot_dev.h"
 #include "prot_fft.h"
@@ -253,7 +254,7 @@ PROT_DEV void s5_transform (f2 (&v)[8], const S5Tw& w, const S5Lds& l)
 // first scalar load of a kernel's arguments is a miss that every load of the block waits behind (0.25 us of a 7.3 us launch in an A/B on
 // one box: profiles/r06_experiments.txt); everything else (rotation, output pointer, gain) is read from `p` while the rows are on their way.  (On firmware without the preload the compiler's
 // prologue loads the same registers: slower, not wrong.)  dd_hx = dry delay | history workgroups << 20; runs = workgroups with a block.
-template <int HS, int MODE>
+template <int HS, int MODE, bool PIPED = false>
 __global__ __launch_bounds__ (512) void olasave512_kernel (const float* const in0, const int64_t in_stride, const float* const hist0, const float* const sv, const int n_in32,
                                                            const int n_out32, const int dd_hx, const int hist_len, const int runs, const OlaParams p)
 {
@@ -265,9 +266,26 @@ __global__ __launch_bounds__ (512) void olasave512_kernel (const float* const in
 	__shared__ f2 ex2[8 * kS5Chunk];
 	PROT_S5_T (0)
 	const int c  = (int)blockIdx.y;
-	const int hx = dd_hx >> 20, Dd = dd_hx & 0xfffff; // (Dd even: host guarantees)
+	const int  hx = (dd_hx >> 20) & 0x3ff, Dd = dd_hx & 0xfffff; // (Dd even: host guarantees)
+	constexpr bool pipelined = PIPED; // (p.hs_flag != nullptr: an instantiation of its own -- 0.23 us of a 7.1 us launch as a run-time branch)
 	if (hx > 0 && (int)blockIdx.x >= runs) { // a workgroup of the next history
-		hist_write_part (p, c, (int)blockIdx.x - runs, hx);
+		if (!pipelined) {
+			hist_write_part (p, c, (int)blockIdx.x - runs, hx);
+			return;
+		}
+		// pipelined stateful launches (PROT_CFG_PIPELINE: OlaParams::hs_*, prot_olasave.hip has the story): the launch behind this one,
+		// on another stream and possibly running already, needs nothing of this one but the history -- written through, awaited,
+		// counted; the last of the history workgroups publishes this launch's generation
+		hist_write_part<true> (p, c, (int)blockIdx.x - runs, hx);
+		asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads ();
+		if (threadIdx.x == 0) {
+			const unsigned total = (unsigned)hx * gridDim.y;
+			if (__hip_atomic_fetch_add (p.hs_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1u) {
+				__hip_atomic_store (p.hs_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store (p.hs_flag + (p.hs_post & 7u), p.hs_post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
 		return;
 	}
 	int bx = (int)blockIdx.x; // (run_of_workgroup's rotation inside groups of eight: XCD k does not own the blocks k, k + 8, ...)
@@ -285,6 +303,26 @@ __global__ __launch_bounds__ (512) void olasave512_kernel (const float* const in
 	const float* __restrict__ in   = in0 + (int64_t)c * in_stride;
 	const float* __restrict__ hist = hist0 ? hist0 + (int64_t)c * hist_len : nullptr;
 	const bool    in_al8  = (reinterpret_cast<uintptr_t> (in) & 7) == 0;
+	bool          piped   = false;
+	if (r0 - Dd - 512 * R0 < 1) { // the block reaches into the history
+		piped = pipelined;
+		if (piped && p.hs_wait != 0u) {
+			// ... which the launch before this one is writing (or has written) on another stream.  Bounded (prot_olasave.hip: the launch
+			// waited for cannot be behind this one in a queue; a wait that never ends is reported in the status word, PROT_EHIP)
+			if (threadIdx.x == 0) {
+				unsigned spins = 0;
+				while (__hip_atomic_load (p.hs_flag + (p.hs_wait & 7u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.hs_wait) {
+					__builtin_amdgcn_s_sleep (8);
+					if (++spins > kPipeSpinMax) {
+						__hip_atomic_store (p.hs_flag + kPipeStatusWord, p.hs_wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+						break;
+					}
+				}
+			}
+			__syncthreads ();
+			__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");
+		}
+	}
 
 	// the engine's constants (behind the 256-thread block's fifteen rows): asked for now, used pass by pass
 	S5Tw w;
@@ -304,22 +342,41 @@ __global__ __launch_bounds__ (512) void olasave512_kernel (const float* const in
 				v[a]           = mkf2 (pm, dry[a].x);
 			}
 		} else {
-			// history or silence in reach: every frame by an unconditional load from an address chosen without a branch
+			// history or silence in reach: every frame by an unconditional load from an address chosen without a branch.  (A pipelined
+			// launch's history was written by another launch while this one was already running: device-scope loads -- a plain one could
+			// hit a stale line of this XCD's L2.  Two copies of the loop under one wave-uniform branch: a choice per load would put
+			// control flow between the loads)
 			const float* const safe = sv;
-			auto ldq = [&] (int64_t i) -> float {
-				const int64_t h    = i + hist_len;
-				const bool    ok_i = i >= 0 && i < n_in;
-				const bool    ok_h = i < 0 && hist != nullptr && h >= 0;
-				const float*  a    = ok_i ? in + i : (ok_h ? hist + h : safe);
-				const float   x    = *a;
-				return (ok_i || ok_h) ? x : 0.f;
-			};
+			auto stage = [&] (auto device_scope) {
+				auto ldq = [&] (int64_t i) -> float {
+					const int64_t h    = i + hist_len;
+					const bool    ok_i = i >= 0 && i < n_in;
+					const bool    ok_h = i < 0 && hist != nullptr && h >= 0;
+					const float*  a    = ok_i ? in + i : (ok_h ? hist + h : safe);
+					float         x;
+					if constexpr (decltype (device_scope)::value) {
+						x = __hip_atomic_load (const_cast<float*> (a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					} else {
+						x = *a;
+					}
+					return (ok_i || ok_h) ? x : 0.f;
+				};
 #pragma unroll
-			for (int a = 0; a < 8; ++a) {
-				const int64_t f  = a0 + 1024 * a + 2 * (int64_t)T;
-				const float   pm = ldq (f - 1);
-				dry[a]           = mkf2 (ldq (f), ldq (f + 1));
-				v[a]             = mkf2 (pm, dry[a].x);
+				for (int a = 0; a < 8; ++a) {
+					const int64_t f  = a0 + 1024 * a + 2 * (int64_t)T;
+					const float   pm = ldq (f - 1);
+					dry[a]           = mkf2 (ldq (f), ldq (f + 1));
+					v[a]             = mkf2 (pm, dry[a].x);
+				}
+			};
+			if constexpr (PIPED) {
+				if (piped) {
+					stage (std::true_type ());
+				} else {
+					stage (std::false_type ());
+				}
+			} else {
+				stage (std::false_type ());
 			}
 		}
 		PROT_S5_T (1)
@@ -748,6 +805,13 @@ static hipError_t launch_s5_m (const OlaParams& p, dim3 grid, hipStream_t s)
 	const int runs  = (int)grid.x - p.hist_extra;
 	const int dd_hx = p.dry_delay | (p.hist_extra << 20);
 #define PROT_S5_LAUNCH(M) hipLaunchKernelGGL ((olasave512_kernel<HS, M>), grid, dim3 (512), 0, s, p.in, p.in_stride, p.hist, p.sv, (int)p.n_in, (int)p.n_out, dd_hx, p.hist_len, runs, p)
+	if (p.hs_flag != nullptr) { // (pipelined launches: steady rotation only -- prot_apply_dev's route)
+		if (p.hilbert_only || p.rot_s != nullptr) {
+			return hipErrorInvalidValue;
+		}
+		hipLaunchKernelGGL ((olasave512_kernel<HS, MODE_ROT, true>), grid, dim3 (512), 0, s, p.in, p.in_stride, p.hist, p.sv, (int)p.n_in, (int)p.n_out, dd_hx, p.hist_len, runs, p);
+		return hipGetLastError ();
+	}
 	if (p.hilbert_only) {
 		PROT_S5_LAUNCH (MODE_HILBERT);
 	} else if (p.rot_s != nullptr) {
@@ -764,7 +828,7 @@ static hipError_t launch_s5_m (const OlaParams& p, dim3 grid, hipStream_t s)
 bool ola_save512_takes (const OlaParams& p, int hop_rows, int n_rho_rows, int n_chn, int max_wg)
 {
 	if ((hop_rows != 8 && hop_rows != 10 && hop_rows != 12) || n_rho_rows != 1 || (p.dry_delay & 1) || p.accumulate || p.sv == nullptr || p.n_out <= 0 ||
-	    2 * (p.dry_delay - p.conv_delay) != 512 * (16 - hop_rows) || p.surv != nullptr || p.hs_flag != nullptr || p.run_stride != 0 ||
+	    2 * (p.dry_delay - p.conv_delay) != 512 * (16 - hop_rows) || p.surv != nullptr || p.run_stride != 0 || (p.hs_flag != nullptr && (p.hist_out == nullptr || p.rot_s != nullptr)) ||
 	    p.n_in >= ((int64_t)1 << 31) || p.dry_delay >= (1 << 20) ||
 	    p.hilbert_only) { // (the sweep's Hilbert passes: a sharded or chunked sweep is bit-identical to the single pass, so its block may not depend on a launch's length)
 		return false;

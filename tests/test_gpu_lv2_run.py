@@ -401,9 +401,9 @@ def test_pipelined_launches_equal_sequential_ones(pkg, rate, per, n_launch):
     x = torch.from_numpy(xorshift_uniform(n_chn * n, seed=77).reshape(n_chn, n)).to(dev)
     rot = np.array([0.6, 0.8, -0.28, 0.96], np.float32)
     outs = []
-    # (a pipelined engine keeps the 256-thread block for every launch; the sequential engine it is compared with, bit for bit, is told to
-    # do the same -- and the sequential engine as shipped, whose short launches take the 512-thread block, agrees to rounding)
-    for flags, no_short in ((0, 1), (pkg.CFG_PIPELINE, 0), (0, 0)):
+    # (sequential and pipelined, bit for bit, on the block a short launch takes as shipped -- the 512-thread one -- and on the 256-thread
+    # block, PROT_TEST_NO_SHORT_CHAIN; the two blocks agree to rounding)
+    for flags, no_short in ((0, 0), (pkg.CFG_PIPELINE, 0), (0, 1), (pkg.CFG_PIPELINE, 1)):
         pkg.set_test_option(pkg.TEST_NO_SHORT_CHAIN, no_short)
         e = pkg.Engine(pkg.KIND_LV2, rate, n_chn, flags=flags)
         assert e.info.form in (pkg.FORM_POLY_SAVE, pkg.FORM_POLY_SAVE8K)   # (these launches are short: the 4096-point kernel either way)
@@ -433,6 +433,7 @@ def test_pipelined_launches_equal_sequential_ones(pkg, rate, per, n_launch):
         pkg.set_test_option(pkg.TEST_NO_SHORT_CHAIN, 0)
     assert np.abs(outs[0][:, :(n_launch + 1) * per]).max() > 0.05
     assert outs[0].tobytes() == outs[1].tobytes()
+    assert outs[2].tobytes() == outs[3].tobytes()
     assert np.abs(outs[2] - outs[0]).max() < TOL
 
 
