@@ -85,9 +85,12 @@ PROT_DEV void twiddle7 (f2 (&v)[8], const f2 (&w)[7])
 	}
 }
 
-// the constants a thread multiplies by, pass by pass (prot_kernels.h kSv5*): w, w^2, w^4 of every table come from memory, w^3 = w w^2,
-// w^5 = w w^4, w^6 = w^2 w^4, w^7 = w^3 w^4 by one or two products (forty-three 8-byte loads per thread were 176 KB per workgroup
-// through one CU's cache: more than a microsecond of a lone block -- 9.6 against 7.4 us per launch on BASELINE configs[2])
+// the constants a thread multiplies by, pass by pass (prot_kernels.h kSv5*): ONLY w of every table comes from memory, w^2 = w w,
+// w^4 = w^2 w^2, w^3 = w w^2, w^5 = w w^4, w^6 = w^2 w^4, w^7 = w^3 w^4 are products.  A constant's load costs a lone block 0.07 us
+// (BASELINE configs[2], one box: all 43 per thread loaded 9.6 us per launch, w w^2 w^4 7.3, w alone 6.4) and a product's rounding
+// costs accuracy: against the oracle on 200 000 frames max 3.6e-7 / rms 7.9e-8 with every constant loaded (the 256-thread block:
+// 3.6e-7 / 8.0e-8), 4.2e-7 / 8.2e-8 with three, 6.0e-7 / 1.04e-7 with one -- the gate is 2e-6 (profiles/r06_experiments.txt;
+// -DPROT_S5_W124 / -DPROT_S5_ALL_TWIDDLES build the other two)
 struct S5Tw {
 	f2 fA[7], fB[7], fC[7], iA[7], iB[7], iC[7];
 	f2 rho; // |B| of this thread's k4 = 0 and k4 = 7 bins over the mean (1 outside the rows next to DC)
@@ -99,8 +102,10 @@ PROT_DEV void s5_load_tw (S5Tw& w, const f2* __restrict__ tab, const int T)
 	const int tpp  = 64 * (lane & 7) + 8 * (lane >> 3) + wave; // the inverse's first twiddle index: t'' = 64 k3 + 8 k2 + k1
 #pragma unroll
 	for (int j = 0; j < 7; ++j) {
-#ifndef PROT_S5_ALL_TWIDDLES
+#if defined(PROT_S5_W124)
 		if (j == 0 || j == 1 || j == 3)
+#elif !defined(PROT_S5_ALL_TWIDDLES)
+		if (j == 0)
 #endif
 		{
 			w.fA[j] = tab[kSv5fA + 512 * j + T];
@@ -118,6 +123,10 @@ PROT_DEV void s5_tw_powers (S5Tw& w)
 {
 #ifndef PROT_S5_ALL_TWIDDLES
 	auto powers = [] (f2 (&x)[7]) {
+#ifndef PROT_S5_W124
+		x[1] = pk32::cmul<1> (x[0], x[0]);
+		x[3] = pk32::cmul<1> (x[1], x[1]);
+#endif
 		x[2] = pk32::cmul<1> (x[0], x[1]);
 		x[4] = pk32::cmul<1> (x[0], x[3]);
 		x[5] = pk32::cmul<1> (x[1], x[3]);
